@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: BPR-MF positive-pairs/sec + full-catalog top-k users/sec.
+
+One JSON line on rank 0.  N=1 workload = BASELINE.json configs[1]: BPRMF d=128 on synthetic
+1M users x 100K items (SURVEY.md 8d "S-1M"), inputs resident in HBM before the timed region.
+
+  step (train) : sample B triplets on the device -> gather -> BPR loss -> Adam (TF-dense semantics, the
+                 reference's BPRMF_batch_model.train_step) for one batch of B = --batch triplets
+  step (top-k) : fused score + masked top-k for one block of --topk-block users against the full catalogue
+
+`value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Both legs carry a
+roofline object for their dominant kernel (duration from hipEvents recorded inside the library on the
+launch stream).  `cpu_baseline` times the CPU oracle (a port of the reference path; /root/reference is
+absent on the GPU box) on a bounded sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from elliot_amd import ops  # noqa: E402
+from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=100_000)
+    ap.add_argument("--factors", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1 << 20)
+    ap.add_argument("--topk-block", type=int, default=131072)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--opt", default="adam_tf_dense", choices=["adam_tf_dense", "adam_lazy", "sgd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-topk-users", type=int, default=192)
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, device):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(args, host):
+    """CPU oracle ("port") timed on this host: a bounded sample of the same workload."""
+    from oracle import bprmf_batch as ob
+    from oracle import cref
+    out = {"kind": "port", "cores": 1}
+    # --- train: one TF-semantics step (NumPy fp32) at the GPU workload's shapes, smaller batch
+    Bc = min(args.batch, 1 << 16)
+    rs = np.random.RandomState(0)
+    u = rs.randint(0, args.users, Bc)
+    i = rs.randint(0, args.items, Bc)
+    j = rs.randint(0, args.items, Bc)
+    orc = ob.BPRMFBatchOracle(host["Gu"], host["Gi"], host["Bi"], 0.001, 0.1, 0.001, optimizer=args.opt)
+    t0 = time.perf_counter()
+    orc.train_step((u, i, j))
+    dt = time.perf_counter() - t0
+    out["value"] = Bc / dt
+    out["unit"] = "pairs/s"
+    out["sample"] = (f"oracle/bprmf_batch.py train_step ({args.opt}), 1 step, B={Bc}, U={args.users}, I={args.items}, "
+                     f"F={args.factors}, NumPy fp32 single thread; {dt:.2f}s")
+    # --- top-k: C oracle (fmaf chain + selection) on a few users against the full catalogue
+    nu = args.cpu_topk_users
+    t0 = time.perf_counter()
+    cref.score_topk_f32(host["Gu"][:nu], host["Gi"], host["Bi"], 0, nu, args.k,
+                        excl=(host["indptr"][:nu + 1], host["indices"][:int(host["indptr"][nu])]))
+    dt = time.perf_counter() - t0
+    out["topk"] = {"value": nu / dt, "unit": "users/s", "cores": 1, "kind": "port",
+                   "sample": f"oracle/c/el_oracle.c orc_score_topk_f32, {nu} users x {args.items} items, F={args.factors}, "
+                             f"k={args.k}; {dt:.2f}s"}
+    return out
+
+
+def main():
+    args = parse()
+    world, rank, local = dist_setup(args)
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    ctx = ops.get_context(local)
+    dev = ctx.device
+    torch.cuda.set_device(dev)
+    U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
+
+    # ---------------- synthetic inputs, resident in HBM -------------------------------------------
+    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+    pos = ops.DeviceCSR.from_tensors(indptr, indices, I)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    lim_u, lim_i = (6.0 / (U + F)) ** 0.5, (6.0 / (I + F)) ** 0.5           # GlorotUniform (BPRMF_batch_model.py:39-42)
+    Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * lim_u
+    Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i
+    Bi = torch.zeros(I, device=dev)
+
+    # item shard of this rank (north_star: tables shard by item; N=1 -> the whole catalogue)
+    lo = (I * rank) // world
+    hi = (I * (rank + 1)) // world
+    st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
+    del Gu, Gi, Bi
+    lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
+    trip = tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3))
+    sample_ctr = [0]
+
+    def train_step():
+        ops.bpr_sample(ctx, pos, B, seed=42 + rank, first_sample=sample_ctr[0], out=trip)
+        sample_ctr[0] += B
+        st.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b)
+
+    Ub = min(args.topk_block, U)
+    n_blocks = max(1, U // Ub)
+    out_idx = torch.empty((Ub, k), dtype=torch.int32, device=dev)
+    out_val = torch.empty((Ub, k), dtype=torch.float32, device=dev)
+    blk = [0]
+    Gi_shard = st.Gi[lo:hi]
+    Bi_shard = st.Bi[lo:hi]
+
+    def topk_step():
+        s = (blk[0] % n_blocks) * Ub
+        blk[0] += 1
+        pi, pv = ops.score_topk(ctx, st.Gu, Gi_shard, Bi_shard, s, s + Ub, k, excl=pos, item_offset=lo,
+                                algo="mfma", out_idx=out_idx, out_val=out_val)
+        if world > 1:
+            import torch.distributed as dist
+            gi = torch.empty((world, Ub, k), dtype=torch.int32, device=dev)
+            gv = torch.empty((world, Ub, k), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(gi, pi)
+            dist.all_gather_into_tensor(gv, pv)
+            ops.topk_merge(ctx, gi, gv)
+
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        barrier(world)
+        ctx.timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier(world)
+        dt = time.perf_counter() - t0
+        ctx.timing(False)
+        rep = ctx.timing_report()
+        return max_over_ranks(dt, world, dev), rep
+
+    K, W = args.steps, args.warmup
+    dt_train, rep_train = timed(train_step, W, K)
+    loss = st.pop_loss()
+    dt_topk, rep_topk = timed(topk_step, W, K)
+
+    if rank != 0:
+        return
+    # ---------------- metrics ---------------------------------------------------------------------
+    pairs_per_s = world * B * K / dt_train if world == 1 else B * K * world / dt_train
+    users_per_s = Ub * K / dt_topk
+
+    def dominant(rep):
+        name = max(rep, key=lambda n: rep[n][1])
+        return name, rep[name][1] / rep[name][0] * 1e-3   # seconds per launch
+
+    # train roofline: algorithmic bytes of the dominant kernel (DESIGN.md "algorithmic bytes")
+    n_params = (U + (hi - lo)) * F + (hi - lo)
+    alg = {
+        "k_adam_dense_Gu": 24.0 * U * F,                      # theta, m, v read + write
+        "k_adam_dense_Gi": 24.0 * (hi - lo) * F,
+        "k_bprmf_fwd_bwd": B * (24.0 * F + 28.0),             # 3 rows read + 3 gradient rows written (+ idx, bias)
+        "k_rows_apply": B * (72.0 * F + 60.0) - B * (24.0 * F + 28.0) if args.opt == "adam_lazy" else B * (24.0 * F),
+        "k_bpr_sample": B * 48.0,
+    }
+    dn, dsec = dominant(rep_train)
+    achieved = alg.get(dn, 0.0) / dsec / 1e9
+    roof_train = {"kernel": dn, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                  "kernels_ms_per_step": {n: v[1] / K for n, v in rep_train.items()}}
+    tn, tsec = dominant(rep_topk)
+    flops = 2.0 * Ub * (hi - lo) * F
+    ach_t = flops / tsec / 1e12
+    roof_topk = {"kernel": tn, "bound": "mfma", "achieved": ach_t, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach_t / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                 "kernels_ms_per_step": {n: v[1] / K for n, v in rep_topk.items()}}
+
+    line = {
+        "metric": "BPR-MF positive-pairs/sec + full-catalog top-k users/sec",
+        "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt_train / K * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
+                   else f"BPRMF d={F}, synthetic {U} users x {I} items",
+                   "users": U, "items": I, "factors": F, "interactions": int(pos.nnz), "batch": B,
+                   "optimizer": args.opt, "topk_block": Ub, "k": k,
+                   "parallelism": "single" if world == 1 else f"item-shard x{world}"},
+        "loss_per_pair_last": loss / (B * (K + W)),
+        "roofline": roof_train,
+        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "roofline": roof_topk},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        host = {"Gu": st.Gu.cpu().numpy(), "Gi": st.Gi.cpu().numpy(), "Bi": st.Bi.cpu().numpy(),
+                "indptr": pos.indptr.cpu().numpy(), "indices": pos.indices.cpu().numpy()}
+        line["cpu_baseline"] = cpu_baseline(args, host)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""ctypes binding of include/elliot_hip.h.
+
+There is no CPU fallback: if libelliot_hip.so is missing or fails to load, every product
+entry point raises.  (oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libelliot_hip.so")
+
+EL_OPT_ADAM_TF_DENSE = 0
+EL_OPT_ADAM_LAZY = 2
+EL_OPT_SGD = 3
+EL_TOPK_AUTO = 0
+EL_TOPK_MFMA = 1
+EL_TOPK_SIMPLE = 2
+
+_f32p = C.c_void_p
+_i32p = C.c_void_p
+_i64p = C.c_void_p
+_f64p = C.c_void_p
+
+
+class BprmfState(C.Structure):
+    _fields_ = [
+        ("Gu", _f32p), ("Gi", _f32p), ("Bi", _f32p),
+        ("gGu", _f32p), ("gGi", _f32p), ("gBi", _f32p),
+        ("mGu", _f32p), ("vGu", _f32p), ("mGi", _f32p), ("vGi", _f32p), ("mBi", _f32p), ("vBi", _f32p),
+        ("tGu", _i32p), ("tGi", _i32p), ("tBi", _i32p),
+        ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32),
+    ]
+
+
+class BprsgdState(C.Structure):
+    _fields_ = [
+        ("P", _f64p), ("Q", _f64p), ("b", _f64p),
+        ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32),
+        ("lr", C.c_double), ("reg_bias", C.c_double), ("reg_user", C.c_double),
+        ("reg_pos", C.c_double), ("reg_neg", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/elliot_hip.h one to one
+PROTOTYPES = {
+    "el_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "el_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "el_last_error": (C.c_char_p, []),
+    "el_abi_version": (C.c_int, []),
+    "el_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "el_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "el_timing_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "el_bpr_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
+    "el_bprmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
+                                      C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_float, _f64p]),
+    "el_bprsgd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,
+                                  C.c_int64, C.c_int64]),
+    "el_bprsgd_apply_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,
+                                         C.c_void_p, C.c_int64]),
+    "el_bprsgd_levels_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "el_score_topk_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
+    "el_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64,
+                                C.c_int64, C.c_int32, _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p,
+                                C.c_int, C.c_void_p, C.c_size_t]),
+    "el_score_topk_f64": (C.c_int, [C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, C.c_int64, C.c_int64, C.c_int64,
+                                    C.c_int64, C.c_int32, _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f64p]),
+    "el_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int32, C.c_int64, C.c_int32, _i32p, _f32p]),
+    "el_dense_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p]),
+}
+
+_lib = None
+
+
+class ElliotHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libelliot_hip.so (once).  Raises ElliotHipError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ElliotHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  elliot_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().el_last_error()
+        raise ElliotHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

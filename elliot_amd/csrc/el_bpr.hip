@@ -1,0 +1,646 @@
+// BPR triplet sampler + BPR-MF training steps.
+//
+//   el_bpr_sample        <- dataset/samplers/custom_sampler.py:31-46
+//   el_bprmf_train_step  <- BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80)
+//   el_bprsgd_apply      <- MFModel.update_factors       (BPRMF_model.py:91-117)
+//
+// All three are HBM-bound gather/scatter kernels: a group of LPT lanes (LPT = 8..64, a
+// power of two) owns one triplet, each lane moves 16 bytes of every row it touches, dot
+// products are reduced with wavefront shuffles, nothing is staged through LDS because a
+// row is consumed exactly once per triplet.
+#include <vector>
+#include "el_common.h"
+
+// ---------------------------------------------------------------------------------------
+// K1: Philox sampler
+// ---------------------------------------------------------------------------------------
+struct PhiloxStream {
+    u32 n_lo, n_hi, k0, k1, a;
+    u32 w[4];
+    int have;
+    __device__ __forceinline__ void init(u64 n, u64 seed) {
+        n_lo = (u32)n;
+        n_hi = (u32)(n >> 32);
+        k0 = (u32)seed;
+        k1 = (u32)(seed >> 32);
+        a = 0;
+        have = 0;
+    }
+    __device__ __forceinline__ u32 next() {
+        if (have == 0) {
+            el_philox4 r = el_philox4x32_10(n_lo, n_hi, a, 0u, k0, k1);
+            w[0] = r.x;
+            w[1] = r.y;
+            w[2] = r.z;
+            w[3] = r.w;
+            a++;
+            have = 4;
+        }
+        u32 v = w[4 - have];
+        have--;
+        return v;
+    }
+    // uniform integer in [0, n), n >= 1: masked rejection (np.random.randint's scheme)
+    __device__ __forceinline__ u32 bounded(u32 n) {
+        u32 m = n - 1u;
+        m |= m >> 1;
+        m |= m >> 2;
+        m |= m >> 4;
+        m |= m >> 8;
+        m |= m >> 16;
+        u32 v;
+        do {
+            v = next() & m;
+        } while (v >= n);
+        return v;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_bpr_sample(const int64_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices, int64_t U, int64_t I,
+                                                    int64_t item_lo, int64_t item_hi, u64 seed, u64 first, int64_t n,
+                                                    int32_t* out_u, int32_t* out_i, int32_t* out_j) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    PhiloxStream ps;
+    ps.init(first + (u64)t, seed);
+    const u32 range = (u32)(item_hi - item_lo);
+    for (;;) {
+        u32 u = ps.bounded((u32)U);
+        int64_t r0 = indptr[u], r1 = indptr[u + 1];
+        int64_t lui = r1 - r0;
+        if (lui <= 0 || lui >= I) continue;  // no positive / no negative available: re-draw the user
+        u32 ipos = ps.bounded((u32)lui);
+        int32_t it = indices[r0 + ipos];
+        int32_t jt = -1;
+        for (int attempt = 0; attempt < 4096; ++attempt) {
+            int32_t cand = (int32_t)(item_lo + (int64_t)ps.bounded(range));
+            if (!el_row_contains(indices, r0, r1, cand)) {
+                jt = cand;
+                break;
+            }
+        }
+        if (jt < 0) continue;  // (sharded range fully positive for this user)
+        out_u[t] = (int32_t)u;
+        out_i[t] = it;
+        out_j[t] = jt;
+        return;
+    }
+}
+
+extern "C" int el_bpr_sample(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices,
+                             int64_t U, int64_t I, int64_t item_lo, int64_t item_hi, uint64_t seed,
+                             uint64_t first_sample, int64_t n, int32_t* out_u, int32_t* out_i, int32_t* out_j) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(pos_indptr && pos_indices && out_u && out_i && out_j, "el_bpr_sample: null pointer");
+    EL_REQUIRE(U >= 1 && U < 0xffffffffLL && I >= 2 && I < 0x7fffffffLL, "el_bpr_sample: U/I out of range");
+    EL_REQUIRE(item_lo >= 0 && item_hi <= I && item_hi > item_lo, "el_bpr_sample: bad negative range");
+    if (n <= 0) return 0;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    EL_LAUNCH("k_bpr_sample", k_bpr_sample, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos_indptr, pos_indices, U, I,
+                       item_lo, item_hi, (u64)seed, (u64)first_sample, n, out_u, out_i, out_j);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K2-K4: BPRMF_batch train step
+// ---------------------------------------------------------------------------------------
+template <int VW>
+__device__ __forceinline__ void ld_vec(const float* p, float* dst) {
+    if (VW == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        dst[0] = t.x;
+        dst[1] = t.y;
+        dst[2] = t.z;
+        dst[3] = t.w;
+    } else {
+        dst[0] = p[0];
+    }
+}
+
+__device__ __forceinline__ float el_softplus(float x) {
+    // tf.nn.softplus: x for large x, exp(x) for very negative x, log1p(exp(x)) otherwise
+    if (x > 15.0f) return x;
+    if (x < -15.0f) return expf(x);
+    return log1pf(expf(x));
+}
+
+// forward + backward of one batch; gradients are scatter-ADDED into the dense accumulators
+// gGu/gGi/gBi (duplicates sum, as OptimizerV2 de-duplicates IndexedSlices by segment-sum).
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bprmf_fwd_bwd(el_bprmf_state st, const int32_t* __restrict__ bu,
+                                                       const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
+                                                       int64_t B, float l_w, float l_b, int lpt, int32_t step,
+                                                       double* loss_out) {
+    const int F = st.F;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const bool active = b < B;
+    int32_t uu = 0, ii = 0, jj = 0;
+    if (active) {
+        uu = bu[b];
+        ii = bi_[b];
+        jj = bj[b];
+    }
+    const float* pu = st.Gu + (int64_t)uu * F;
+    const float* pi = st.Gi + (int64_t)ii * F;
+    const float* pj = st.Gi + (int64_t)jj * F;
+    float gu[CPL][VW], gi[CPL][VW], gj[CPL][VW];
+    float dpi = 0.f, dpj = 0.f, nu = 0.f, ni = 0.f, nj = 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+        const bool ok = active && e < F;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) gu[q][x] = gi[q][x] = gj[q][x] = 0.f;
+        if (ok) {
+            ld_vec<VW>(pu + e, gu[q]);
+            ld_vec<VW>(pi + e, gi[q]);
+            ld_vec<VW>(pj + e, gj[q]);
+        }
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+            dpi += gu[q][x] * gi[q][x];
+            dpj += gu[q][x] * gj[q][x];
+            nu += gu[q][x] * gu[q][x];
+            ni += gi[q][x] * gi[q][x];
+            nj += gj[q][x] * gj[q][x];
+        }
+    }
+    dpi = el_group_sum(dpi, lpt);
+    dpj = el_group_sum(dpj, lpt);
+    nu = el_group_sum(nu, lpt);
+    ni = el_group_sum(ni, lpt);
+    nj = el_group_sum(nj, lpt);
+    float beta_i = 0.f, beta_j = 0.f;
+    if (active) {
+        beta_i = st.Bi[ii];
+        beta_j = st.Bi[jj];
+    }
+    const float xui = beta_i + dpi, xuj = beta_j + dpj;
+    const float d = xui - xuj;
+    const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+    float s = 0.f;  // d loss / d difference
+    if (d >= -80.0f) s = -1.0f / (1.0f + expf(d));
+    float myloss = 0.f;
+    if (active && sub == 0) {
+        myloss = el_softplus(-dc) + l_w * 0.5f * (nu + ni + nj) + l_b * 0.5f * beta_i * beta_i +
+                 (l_b * 0.5f * beta_j * beta_j) / 10.0f;
+    }
+    if (active) {
+        float* gpu = st.gGu + (int64_t)uu * F;
+        float* gpi = st.gGi + (int64_t)ii * F;
+        float* gpj = st.gGi + (int64_t)jj * F;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) {
+#pragma unroll
+                for (int x = 0; x < VW; ++x) {
+                    atomicAdd(gpu + e + x, s * (gi[q][x] - gj[q][x]) + l_w * gu[q][x]);
+                    atomicAdd(gpi + e + x, s * gu[q][x] + l_w * gi[q][x]);
+                    atomicAdd(gpj + e + x, -s * gu[q][x] + l_w * gj[q][x]);
+                }
+            }
+        }
+        if (sub == 0) {
+            atomicAdd(st.gBi + ii, s + l_b * beta_i);
+            atomicAdd(st.gBi + jj, -s + (l_b / 10.0f) * beta_j);
+            if (st.tGu) {
+                st.tGu[uu] = step;
+                st.tGi[ii] = step;
+                st.tGi[jj] = step;
+                st.tBi[ii] = step;
+                st.tBi[jj] = step;
+            }
+        }
+    }
+    // block loss -> one double atomic
+    __shared__ float wsum[4];
+    float wl = el_group_sum(myloss, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+        if (tot != 0.0) atomicAdd(loss_out, tot);
+    }
+}
+
+// Keras-2.3 Adam, sparse-apply arithmetic, one element:
+//   m <- m*b1 ; m += g*(1-b1) ; v <- v*b2 ; v += (g*g)*(1-b2) ; theta -= (lr_t*m)/(sqrt(v)+eps)
+__device__ __forceinline__ void el_adam_elem(float& th, float& m, float& v, float g, float lr_t, float b1, float b2,
+                                             float omb1, float omb2, float eps) {
+    m = m * b1 + g * omb1;
+    v = v * b2 + (g * g) * omb2;
+    th = th - (lr_t * m) / (sqrtf(v) + eps);
+}
+
+// dense pass: EVERY element of the variable decays and moves (TF sparse-apply semantics);
+// the gradient accumulator is reset on the way.
+__global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ th, float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    float lr_t, float b1, float b2, float eps) {
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float4* th4 = reinterpret_cast<float4*>(th);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (int64_t e = t; e < n4; e += stride) {
+        float4 a = th4[e], gg = g4[e], mm = m4[e], vv = v4[e];
+        el_adam_elem(a.x, mm.x, vv.x, gg.x, lr_t, b1, b2, omb1, omb2, eps);
+        el_adam_elem(a.y, mm.y, vv.y, gg.y, lr_t, b1, b2, omb1, omb2, eps);
+        el_adam_elem(a.z, mm.z, vv.z, gg.z, lr_t, b1, b2, omb1, omb2, eps);
+        el_adam_elem(a.w, mm.w, vv.w, gg.w, lr_t, b1, b2, omb1, omb2, eps);
+        th4[e] = a;
+        m4[e] = mm;
+        v4[e] = vv;
+        if (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f) g4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t e = (n4 << 2) + t; e < n; e += stride) {
+        float a = th[e], gg = g[e], mm = m[e], vv = v[e];
+        el_adam_elem(a, mm, vv, gg, lr_t, b1, b2, omb1, omb2, eps);
+        th[e] = a;
+        m[e] = mm;
+        v[e] = vv;
+        if (gg != 0.f) g[e] = 0.f;
+    }
+}
+
+// touched-row pass (EL_OPT_ADAM_LAZY / EL_OPT_SGD): one lane group per batch entry and
+// role; the first group to claim a row (stamp step -> -step) applies the update once.
+// role 0: Gu[u], 1: Gi[i] (+Bi[i]), 2: Gi[j] (+Bi[j])
+template <int VW, int CPL, bool ADAM>
+__global__ __launch_bounds__(256) void k_rows_apply(el_bprmf_state st, const int32_t* __restrict__ bu,
+                                                    const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
+                                                    int64_t B, int lpt, int32_t step, float lr, float lr_t, float b1,
+                                                    float b2, float eps) {
+    const int F = st.F;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const int64_t b = grp / 3;
+    const int role = (int)(grp - b * 3);
+    const bool active = b < B;
+    int32_t row = 0;
+    if (active) row = (role == 0) ? bu[b] : (role == 1 ? bi_[b] : bj[b]);
+    int32_t* stamp = (role == 0) ? st.tGu : st.tGi;
+    int claimed = 0;
+    if (active && sub == 0) claimed = (atomicCAS(stamp + row, step, -step) == step) ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    claimed = __shfl(claimed, lane & ~(lpt - 1), 64);
+    if (!claimed) return;
+    float* th = ((role == 0) ? st.Gu : st.Gi) + (int64_t)row * F;
+    float* g = ((role == 0) ? st.gGu : st.gGi) + (int64_t)row * F;
+    float* m = ADAM ? ((role == 0) ? st.mGu : st.mGi) + (int64_t)row * F : nullptr;
+    float* v = ADAM ? ((role == 0) ? st.vGu : st.vGi) + (int64_t)row * F : nullptr;
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+        if (e < F) {
+            float a[VW], gg[VW], mm[VW], vv[VW];
+            ld_vec<VW>(th + e, a);
+            ld_vec<VW>(g + e, gg);
+            if (ADAM) {
+                ld_vec<VW>(m + e, mm);
+                ld_vec<VW>(v + e, vv);
+            }
+#pragma unroll
+            for (int x = 0; x < VW; ++x) {
+                if (ADAM)
+                    el_adam_elem(a[x], mm[x], vv[x], gg[x], lr_t, b1, b2, omb1, omb2, eps);
+                else
+                    a[x] = a[x] - lr * gg[x];
+                th[e + x] = a[x];
+                g[e + x] = 0.f;
+                if (ADAM) {
+                    m[e + x] = mm[x];
+                    v[e + x] = vv[x];
+                }
+            }
+        }
+    }
+    if (role != 0 && sub == 0) {
+        // item bias shares the item row's claim only if its own stamp is still pending
+        if (atomicCAS(st.tBi + row, step, -step) == step) {
+            float a = st.Bi[row], gg = st.gBi[row];
+            if (ADAM) {
+                float mm = st.mBi[row], vv = st.vBi[row];
+                el_adam_elem(a, mm, vv, gg, lr_t, b1, b2, omb1, omb2, eps);
+                st.mBi[row] = mm;
+                st.vBi[row] = vv;
+            } else {
+                a = a - lr * gg;
+            }
+            st.Bi[row] = a;
+            st.gBi[row] = 0.f;
+        }
+    }
+}
+
+// plain dense SGD (EL_OPT_SGD without stamp arrays)
+__global__ __launch_bounds__(256) void k_sgd_dense(float* __restrict__ th, float* __restrict__ g, int64_t n,
+                                                   float lr) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        float gg = g[e];
+        if (gg != 0.f) {
+            th[e] = th[e] - lr * gg;
+            g[e] = 0.f;
+        }
+    }
+}
+
+static int pick_lpt(int F, int vw, int* cpl) {
+    int groups = (F + vw - 1) / vw;  // vector chunks per row
+    int lpt = 8;
+    while (lpt < groups && lpt < 64) lpt <<= 1;
+    int c = (groups + lpt - 1) / lpt;
+    int cp = 1;
+    while (cp < c) cp <<= 1;
+    *cpl = cp;
+    return lpt;
+}
+
+static bool rows_aligned16(const void* p, int F) { return (F % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
+
+template <int VW>
+static int launch_fwd_bwd(const el_bprmf_state& st, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                          float l_w, float l_b, int32_t step, double* loss_out, hipStream_t s) {
+    int cpl = 1;
+    int lpt = pick_lpt(st.F, VW, &cpl);
+    EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build (max %d)", st.F, 64 * 4 * VW);
+    int64_t threads = B * lpt;
+    unsigned grid = (unsigned)((threads + 255) / 256);
+    if (cpl == 1)
+        EL_LAUNCH("k_bprmf_fwd_bwd", (k_bprmf_fwd_bwd<VW, 1>), dim3(grid), dim3(256), 0, s, st, u, i, j, B, l_w, l_b, lpt, step, loss_out);
+    else if (cpl == 2)
+        EL_LAUNCH("k_bprmf_fwd_bwd", (k_bprmf_fwd_bwd<VW, 2>), dim3(grid), dim3(256), 0, s, st, u, i, j, B, l_w, l_b, lpt, step, loss_out);
+    else
+        EL_LAUNCH("k_bprmf_fwd_bwd", (k_bprmf_fwd_bwd<VW, 4>), dim3(grid), dim3(256), 0, s, st, u, i, j, B, l_w, l_b, lpt, step, loss_out);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int VW, bool ADAM>
+static int launch_rows_apply(const el_bprmf_state& st, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                             int32_t step, float lr, float lr_t, hipStream_t s) {
+    int cpl = 1;
+    int lpt = pick_lpt(st.F, VW, &cpl);
+    EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build", st.F);
+    int64_t threads = B * 3 * lpt;
+    unsigned grid = (unsigned)((threads + 255) / 256);
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    if (cpl == 1)
+        EL_LAUNCH("k_rows_apply", (k_rows_apply<VW, 1, ADAM>), dim3(grid), dim3(256), 0, s, st, u, i, j, B, lpt, step, lr, lr_t, b1, b2, eps);
+    else if (cpl == 2)
+        EL_LAUNCH("k_rows_apply", (k_rows_apply<VW, 2, ADAM>), dim3(grid), dim3(256), 0, s, st, u, i, j, B, lpt, step, lr, lr_t, b1, b2, eps);
+    else
+        EL_LAUNCH("k_rows_apply", (k_rows_apply<VW, 4, ADAM>), dim3(grid), dim3(256), 0, s, st, u, i, j, B, lpt, step, lr, lr_t, b1, b2, eps);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+static unsigned stream_grid(el_ctx* ctx, int64_t n_threads) {
+    int64_t blocks = (n_threads + 255) / 256;
+    int64_t cap = (int64_t)ctx->cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+                                   const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w, float l_b,
+                                   int opt, int32_t step, float lr_t, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(stp != nullptr, "el_bprmf_train_step: null state");
+    const el_bprmf_state st = *stp;
+    EL_REQUIRE(st.Gu && st.Gi && st.Bi && st.gGu && st.gGi && st.gBi, "el_bprmf_train_step: null table/accumulator");
+    EL_REQUIRE(st.F >= 1 && st.U >= 1 && st.I >= 1, "el_bprmf_train_step: bad shape");
+    EL_REQUIRE(u && i && j && loss_out, "el_bprmf_train_step: null batch/loss pointer");
+    EL_REQUIRE(step >= 1, "el_bprmf_train_step: step is 1-based");
+    const bool adam = (opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_ADAM_LAZY);
+    EL_REQUIRE(adam || opt == EL_OPT_SGD, "el_bprmf_train_step: unknown optimiser %d", opt);
+    if (adam) EL_REQUIRE(st.mGu && st.vGu && st.mGi && st.vGi && st.mBi && st.vBi, "el_bprmf_train_step: Adam slots missing");
+    const bool rows_mode = (opt == EL_OPT_ADAM_LAZY) || (opt == EL_OPT_SGD && st.tGu != nullptr);
+    if (rows_mode) EL_REQUIRE(st.tGu && st.tGi && st.tBi, "el_bprmf_train_step: stamp arrays missing");
+    if (B <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = rows_aligned16(st.Gu, st.F) && rows_aligned16(st.Gi, st.F) && rows_aligned16(st.gGu, st.F) &&
+                     rows_aligned16(st.gGi, st.F) &&
+                     (!adam || (rows_aligned16(st.mGu, st.F) && rows_aligned16(st.vGu, st.F) &&
+                                rows_aligned16(st.mGi, st.F) && rows_aligned16(st.vGi, st.F)));
+    el_bprmf_state fst = st;
+    if (!rows_mode) fst.tGu = fst.tGi = fst.tBi = nullptr;
+    int rc = vec ? launch_fwd_bwd<4>(fst, u, i, j, B, l_w, l_b, step, loss_out, s)
+                 : launch_fwd_bwd<1>(fst, u, i, j, B, l_w, l_b, step, loss_out, s);
+    if (rc) return rc;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    if (opt == EL_OPT_ADAM_TF_DENSE) {
+        const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
+        EL_LAUNCH("k_adam_dense_Gu", k_adam_dense, dim3(stream_grid(ctx, nu / 4 + 1)), dim3(256), 0, s, st.Gu, st.gGu, st.mGu, st.vGu, nu, lr_t, b1, b2, eps);
+        EL_LAUNCH("k_adam_dense_Gi", k_adam_dense, dim3(stream_grid(ctx, ni / 4 + 1)), dim3(256), 0, s, st.Gi, st.gGi, st.mGi, st.vGi, ni, lr_t, b1, b2, eps);
+        EL_LAUNCH("k_adam_dense_Bi", k_adam_dense, dim3(stream_grid(ctx, st.I / 4 + 1)), dim3(256), 0, s, st.Bi, st.gBi, st.mBi, st.vBi, st.I, lr_t, b1, b2, eps);
+        EL_CHECK_LAUNCH();
+        return 0;
+    }
+    if (rows_mode) {
+        if (opt == EL_OPT_ADAM_LAZY)
+            return vec ? launch_rows_apply<4, true>(st, u, i, j, B, step, lr, lr_t, s)
+                       : launch_rows_apply<1, true>(st, u, i, j, B, step, lr, lr_t, s);
+        return vec ? launch_rows_apply<4, false>(st, u, i, j, B, step, lr, lr_t, s)
+                   : launch_rows_apply<1, false>(st, u, i, j, B, step, lr, lr_t, s);
+    }
+    // dense SGD
+    const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
+    EL_LAUNCH("k_sgd_dense", k_sgd_dense, dim3(stream_grid(ctx, nu)), dim3(256), 0, s, st.Gu, st.gGu, nu, lr);
+    EL_LAUNCH("k_sgd_dense", k_sgd_dense, dim3(stream_grid(ctx, ni)), dim3(256), 0, s, st.Gi, st.gGi, ni, lr);
+    EL_LAUNCH("k_sgd_dense", k_sgd_dense, dim3(stream_grid(ctx, st.I)), dim3(256), 0, s, st.Bi, st.gBi, st.I, lr);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K5: NumPy-semantics per-sample SGD, fp64
+// ---------------------------------------------------------------------------------------
+template <int VW>
+__device__ __forceinline__ void ld_vecd(const double* p, double* dst) {
+    if (VW == 2) {
+        double2 t = *reinterpret_cast<const double2*>(p);
+        dst[0] = t.x;
+        dst[1] = t.y;
+    } else {
+        dst[0] = p[0];
+    }
+}
+template <int VW>
+__device__ __forceinline__ void st_vecd(double* p, const double* src) {
+    if (VW == 2) {
+        *reinterpret_cast<double2*>(p) = make_double2(src[0], src[1]);
+    } else {
+        p[0] = src[0];
+    }
+}
+
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bprsgd_apply(el_bprsgd_state st, const int32_t* __restrict__ bu,
+                                                      const int32_t* __restrict__ bi_,
+                                                      const int32_t* __restrict__ bj, int64_t first, int64_t n,
+                                                      int lpt) {
+    const int F = st.F;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const bool active = t < n;
+    int32_t uu = 0, ii = 0, jj = 0;
+    if (active) {
+        uu = bu[first + t];
+        ii = bi_[first + t];
+        jj = bj[first + t];
+    }
+    double* pu = st.P + (int64_t)uu * F;
+    double* qi = st.Q + (int64_t)ii * F;
+    double* qj = st.Q + (int64_t)jj * F;
+    double vu[CPL][VW], vi[CPL][VW], vj[CPL][VW];
+    double di = 0.0, dj = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) vu[q][x] = vi[q][x] = vj[q][x] = 0.0;
+        if (active && e < F) {
+            ld_vecd<VW>(pu + e, vu[q]);
+            ld_vecd<VW>(qi + e, vi[q]);
+            ld_vecd<VW>(qj + e, vj[q]);
+        }
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+            di += vu[q][x] * vi[q][x];
+            dj += vu[q][x] * vj[q][x];
+        }
+    }
+    di = el_group_sum(di, lpt);
+    dj = el_group_sum(dj, lpt);
+    if (!active) return;
+    const double b_i = st.b[ii], b_j = st.b[jj];
+    // BPRMF_model.py:66-68,98: z = 1/(1+exp(x_ui - x_uj)), x = global_bias(0) + b + p.q
+    const double xui = (0.0 + b_i) + di, xuj = (0.0 + b_j) + dj;
+    const double z = 1.0 / (1.0 + exp(xui - xuj));
+    const double lr = st.lr;
+    if (sub == 0) {
+        st.b[ii] = b_i + lr * (z - st.reg_bias * b_i);      // :100-101
+        st.b[jj] = b_j + lr * (-z - st.reg_bias * b_j);     // :104-105
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+        if (e < F) {
+            double nu[VW], ni[VW], nj[VW];
+#pragma unroll
+            for (int x = 0; x < VW; ++x) {
+                // :108-109 user row first ...
+                nu[x] = vu[q][x] + lr * ((vi[q][x] - vj[q][x]) * z - st.reg_user * vu[q][x]);
+                // ... :112-117 item rows see the UPDATED user row (view aliasing)
+                ni[x] = vi[q][x] + lr * (nu[x] * z - st.reg_pos * vi[q][x]);
+                nj[x] = vj[q][x] + lr * (-nu[x] * z - st.reg_neg * vj[q][x]);
+            }
+            st_vecd<VW>(pu + e, nu);
+            st_vecd<VW>(qi + e, ni);
+            st_vecd<VW>(qj + e, nj);
+        }
+    }
+}
+
+static int launch_bprsgd(const el_bprsgd_state& st, const int32_t* u, const int32_t* i, const int32_t* j,
+                         int64_t first, int64_t n, hipStream_t s) {
+    const bool vec = (st.F % 2 == 0) && (((uintptr_t)st.P) % 16 == 0) && (((uintptr_t)st.Q) % 16 == 0);
+    const int vw = vec ? 2 : 1;
+    int cpl = 1;
+    int lpt = pick_lpt(st.F, vw, &cpl);
+    EL_REQUIRE(cpl <= 4, "el_bprsgd_apply: F=%d too large for this build", st.F);
+    int64_t threads = n * lpt;
+    unsigned grid = (unsigned)((threads + 255) / 256);
+#define EL_SGD_LAUNCH(VW_, CPL_) \
+    EL_LAUNCH("k_bprsgd_apply", (k_bprsgd_apply<VW_, CPL_>), dim3(grid), dim3(256), 0, s, st, u, i, j, first, n, lpt)
+    if (vec) {
+        if (cpl == 1) EL_SGD_LAUNCH(2, 1);
+        else if (cpl == 2) EL_SGD_LAUNCH(2, 2);
+        else EL_SGD_LAUNCH(2, 4);
+    } else {
+        if (cpl == 1) EL_SGD_LAUNCH(1, 1);
+        else if (cpl == 2) EL_SGD_LAUNCH(1, 2);
+        else EL_SGD_LAUNCH(1, 4);
+    }
+#undef EL_SGD_LAUNCH
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+static int check_sgd_state(const el_bprsgd_state* stp) {
+    EL_REQUIRE(stp != nullptr, "el_bprsgd: null state");
+    EL_REQUIRE(stp->P && stp->Q && stp->b, "el_bprsgd: null table");
+    EL_REQUIRE(stp->F >= 1 && stp->U >= 1 && stp->I >= 1, "el_bprsgd: bad shape");
+    return 0;
+}
+
+extern "C" int el_bprsgd_apply(el_ctx* ctx, void* stream, const el_bprsgd_state* stp, const int32_t* u,
+                               const int32_t* i, const int32_t* j, int64_t first, int64_t n) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = check_sgd_state(stp)) return rc;
+    EL_REQUIRE(u && i && j && first >= 0, "el_bprsgd_apply: bad triplet arrays");
+    if (n <= 0) return 0;
+    return launch_bprsgd(*stp, u, i, j, first, n, (hipStream_t)stream);
+}
+
+extern "C" int el_bprsgd_apply_levels(el_ctx* ctx, void* stream, const el_bprsgd_state* stp, const int32_t* u,
+                                      const int32_t* i, const int32_t* j, const int64_t* level_start_host,
+                                      int64_t n_levels) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = check_sgd_state(stp)) return rc;
+    EL_REQUIRE(u && i && j && level_start_host && n_levels >= 0, "el_bprsgd_apply_levels: bad arguments");
+    for (int64_t L = 0; L < n_levels; ++L) {
+        int64_t a = level_start_host[L], b = level_start_host[L + 1];
+        if (b > a)
+            if (int rc = launch_bprsgd(*stp, u, i, j, a, b - a, (hipStream_t)stream)) return rc;
+    }
+    return 0;
+}
+
+// Host-only scheduling helper: dependency levels of a triplet sequence.
+extern "C" int el_bprsgd_levels_host(const int32_t* u, const int32_t* i, const int32_t* j, int64_t n, int64_t U,
+                                     int64_t I, int32_t* order, int64_t* level_start, int64_t level_start_cap,
+                                     int64_t* n_levels) {
+    EL_REQUIRE(u && i && j && order && level_start && n_levels, "el_bprsgd_levels_host: null pointer");
+    EL_REQUIRE(n >= 0 && n < 0x7fffffffLL, "el_bprsgd_levels_host: n out of range");
+    std::vector<int32_t> lu((size_t)U, 0), li((size_t)I, 0), lev((size_t)n);
+    int32_t maxl = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        EL_REQUIRE(u[t] >= 0 && u[t] < U && i[t] >= 0 && i[t] < I && j[t] >= 0 && j[t] < I,
+                   "el_bprsgd_levels_host: triplet %lld out of range", (long long)t);
+        int32_t a = lu[u[t]], b = li[i[t]], c = li[j[t]];
+        int32_t l = a > b ? a : b;
+        l = (l > c ? l : c) + 1;
+        lev[t] = l;
+        lu[u[t]] = l;
+        li[i[t]] = l;
+        li[j[t]] = l;
+        if (l > maxl) maxl = l;
+    }
+    EL_REQUIRE((int64_t)maxl + 1 <= level_start_cap, "el_bprsgd_levels_host: %d levels exceed capacity %lld", maxl,
+               (long long)level_start_cap);
+    // level l (1-based) occupies order[level_start[l-1] .. level_start[l])
+    std::vector<int64_t> count((size_t)maxl + 1, 0);
+    for (int64_t t = 0; t < n; ++t) count[lev[t]]++;
+    level_start[0] = 0;
+    for (int32_t l = 1; l <= maxl; ++l) level_start[l] = level_start[l - 1] + count[l];
+    std::vector<int64_t> cur((size_t)maxl + 1, 0);
+    for (int32_t l = 1; l <= maxl; ++l) cur[l] = level_start[l - 1];
+    for (int64_t t = 0; t < n; ++t) order[cur[lev[t]]++] = (int32_t)t;
+    *n_levels = maxl;
+    return 0;
+}

@@ -1,0 +1,739 @@
+// Full-catalog scoring + masked top-k.
+//
+// Replaces BPRMF_batch_model.predict/get_top_k (BPRMF_batch_model.py:83-88),
+// MFModel.get_user_predictions (BPRMF_model.py:70-85) and the get_top_k bodies of the
+// VAE / NeuMF / GMF models (multi_vae_model.py:158-159, ...).
+//
+// Numerics contract (pinned by oracle/c/el_oracle.c):
+//   dot(u,i)  = fma chain over f = 0..F-1 in that order, starting from +0
+//               (v_mfma_f32_32x32x2_f32 is bitwise this chain, MI355X_MICROARCH.md)
+//   score     = (Bi ? dot + Bi[i] : dot) + 0.0f            (-0 canonicalised)
+//   order     = score descending, item index ascending     (tf.nn.top_k tie rule)
+//   NaN scores are never selected.
+// The [users, items] score matrix is never written to HBM: selection is fused behind the
+// MFMA accumulators (threshold filter in registers, candidate lists in LDS).
+#include "el_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct TopkParams {
+    const float* Gu;
+    const float* Gi;
+    const float* Bi;
+    int64_t u_start, u_stop, item_offset, I_local;
+    int F;
+    const int64_t* excl_indptr;
+    const int32_t* excl_indices;
+    const int64_t* cand_indptr;
+    const int32_t* cand_indices;
+    int k;
+    int32_t* out_idx;
+    float* out_val;
+    // dense-preds variant
+    const float* preds;
+    int64_t ld;
+};
+
+// ---- one-wave bitonic sort (descending) of n = 2^m u64 keys held in LDS --------------
+__device__ __forceinline__ void el_wave_bitonic_desc(u64* a, int n, int lane) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (n >> 1); t += 64) {
+                int i = 2 * t - (t & (stride - 1));
+                int j = i + stride;
+                bool desc = ((i & size) == 0);
+                u64 x = a[i], y = a[j];
+                bool sw = desc ? (x < y) : (x > y);
+                if (sw) {
+                    a[i] = y;
+                    a[j] = x;
+                }
+            }
+            el_wave_lds_sync();
+        }
+    }
+}
+
+// Sort one candidate list (n valid keys in a cap-slot LDS buffer), keep the best k.
+// Whole wave participates, all arguments wave-uniform. Returns the new threshold.
+__device__ __forceinline__ float el_wave_compact(u64* kb, int* cp, int cap, int k, int lane) {
+    el_wave_lds_sync();
+    int n = *cp;
+    for (int t = n + lane; t < cap; t += 64) kb[t] = 0ull;
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(kb, cap, lane);
+    int nn = n < k ? n : k;
+    if (lane == 0) *cp = nn;
+    float nt = (nn >= k) ? el_key_score(kb[k - 1]) : -INFINITY;
+    el_wave_lds_sync();
+    return nt;
+}
+
+// The r-th (0-based) masked item of a row, ascending, inside the local shard
+// [off, off+I_local): what tf.where(mask, preds, -inf) + top_k pads with.
+__device__ __forceinline__ int32_t el_fill_masked(const TopkParams& p, int64_t e0, int64_t e1, int64_t c0,
+                                                  int64_t c1, int64_t r) {
+    const int64_t off = p.item_offset, end = p.item_offset + p.I_local;
+    if (p.cand_indptr) {
+        // masked = NOT candidate.  q* = #candidates (inside the shard) with
+        // cand[q] - off - q <= r ; answer = off + r + q*.
+        int64_t lo = el_lower_bound(p.cand_indices, c0, c1, (int32_t)off);
+        int64_t hi = el_lower_bound(p.cand_indices, c0, c1, (int32_t)(end > 0x7fffffffLL ? 0x7fffffffLL : end));
+        int64_t a = lo, b = hi;
+        while (a < b) {
+            int64_t mid = (a + b) >> 1;
+            int64_t f = (int64_t)p.cand_indices[mid] - off - (mid - lo);
+            if (f <= r)
+                a = mid + 1;
+            else
+                b = mid;
+        }
+        int64_t g = off + r + (a - lo);
+        return g < end ? (int32_t)g : -1;
+    }
+    if (p.excl_indptr) {
+        int64_t lo = el_lower_bound(p.excl_indices, e0, e1, (int32_t)off);
+        int64_t hi = el_lower_bound(p.excl_indices, e0, e1, (int32_t)(end > 0x7fffffffLL ? 0x7fffffffLL : end));
+        return (lo + r < hi) ? p.excl_indices[lo + r] : -1;
+    }
+    return -1;
+}
+
+// =====================================================================================
+// Wave-per-user kernel (VALU fma chain).  General k, general F, candidate protocol,
+// dense-preds source.  Also the cross-check for the MFMA kernel (bitwise-equal scores).
+// =====================================================================================
+template <bool DENSE>
+__global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);              // [cap]
+    int* cnt_s = reinterpret_cast<int*>(smem + (size_t)cap * 8);  // [1] (+pad), used by el_wave_compact
+    const int lane = threadIdx.x;
+    const int64_t user = p.u_start + blockIdx.x;
+    const int F = p.F;
+    const float* gu = DENSE ? nullptr : p.Gu + user * (int64_t)F;
+    int64_t e0 = 0, e1 = 0, c0 = 0, c1 = 0;
+    if (p.excl_indptr) {
+        e0 = p.excl_indptr[user];
+        e1 = p.excl_indptr[user + 1];
+    }
+    int64_t ncand = p.I_local;
+    if (p.cand_indptr) {
+        c0 = p.cand_indptr[user];
+        c1 = p.cand_indptr[user + 1];
+        ncand = c1 - c0;
+    }
+    const bool use_excl = (p.excl_indptr != nullptr) && (p.cand_indptr == nullptr);
+    int cnt = 0;
+    float tau = -INFINITY;
+    for (int64_t base = 0; base < ncand; base += 64) {
+        int64_t pos = base + lane;
+        bool valid = pos < ncand;
+        int32_t gitem = -1;
+        int64_t il = 0;
+        if (valid) {
+            if (p.cand_indptr) {
+                gitem = p.cand_indices[c0 + pos];
+                il = (int64_t)gitem - p.item_offset;
+                valid = (il >= 0 && il < p.I_local);
+            } else {
+                il = pos;
+                gitem = (int32_t)(p.item_offset + pos);
+            }
+        }
+        float s = 0.f;
+        if (valid) {
+            if (DENSE) {
+                s = p.preds[(int64_t)blockIdx.x * p.ld + il] + 0.0f;
+            } else {
+                const float* gi = p.Gi + il * (int64_t)F;
+                float acc = 0.f;
+                for (int f = 0; f < F; ++f) acc = __builtin_fmaf(gi[f], gu[f], acc);
+                s = (p.Bi ? acc + p.Bi[il] : acc) + 0.0f;
+            }
+        }
+        bool hit = valid && (s >= tau);
+        if (hit && use_excl) hit = !el_row_contains(p.excl_indices, e0, e1, gitem);
+        u64 bal = __ballot(hit);
+        if (bal) {
+            int offp = __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit) keys[cnt + offp] = el_make_key(s, gitem);
+            cnt += __popcll(bal);
+        }
+        if (cnt > cap - 64) {
+            if (lane == 0) *cnt_s = cnt;
+            tau = el_wave_compact(keys, cnt_s, cap, p.k, lane);
+            cnt = cnt < p.k ? cnt : p.k;
+        }
+    }
+    if (lane == 0) *cnt_s = cnt;
+    el_wave_compact(keys, cnt_s, cap, p.k, lane);
+    const int nv = cnt < p.k ? cnt : p.k;
+    const int64_t orow = (int64_t)blockIdx.x * p.k;
+    for (int t = lane; t < p.k; t += 64) {
+        int32_t oi;
+        float ov;
+        if (t < nv) {
+            u64 key = keys[t];
+            oi = el_key_item(key);
+            ov = el_key_score(key);
+        } else {
+            oi = el_fill_masked(p, e0, e1, c0, c1, t - nv);
+            ov = -INFINITY;
+        }
+        p.out_idx[orow + t] = oi;
+        p.out_val[orow + t] = ov;
+    }
+}
+
+// =====================================================================================
+// MFMA kernel: 128 users per workgroup (4 waves x 32 users), items streamed in tiles of
+// 32*NIB rows through LDS in K-chunks of 32, user fragments resident in VGPRs for the
+// whole kernel, D[item][user] accumulated by v_mfma_f32_32x32x2_f32, selection fused.
+//   A operand (items): lane l supplies A[row = l&31][k = l>>5]    <- LDS (stride 33)
+//   B operand (users): lane l supplies B[k = l>>5][col = l&31]    <- registers
+//   D: lane l holds col (user) l&31, rows (items) (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
+// Lanes l and l+32 therefore own the same user; every user belongs to exactly one wave,
+// so all top-k state is wave-private (no cross-wave synchronisation outside staging).
+// =====================================================================================
+template <int FP, int NIB, int CAP>
+__global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(TopkParams p, int vec) {
+    constexpr int KC = 32, LDA = KC + 1, BI = 32 * NIB, NCH = FP / KC, UPB = 128;
+    constexpr int A_FLOATS = 2 * BI * LDA + 2 * BI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                // [2][BI][LDA]
+    float* Bs = As + 2 * BI * LDA;                             // [2][BI] bias
+    u64* keys = reinterpret_cast<u64*>(smem + A_FLOATS * 4);   // [UPB][CAP]
+    int* cnts = reinterpret_cast<int*>(keys + UPB * CAP);      // [UPB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    const int uslot = wave * 32 + col;
+    const int64_t ublock = p.u_start + (int64_t)blockIdx.x * UPB;
+    const int64_t user = ublock + uslot;
+    const bool uvalid = user < p.u_stop;
+    const int F = p.F;
+    const int64_t I = p.I_local;
+
+    // resident user fragments
+    float bfrag[FP / 2];
+    {
+        const float* gu = p.Gu + (uvalid ? user : p.u_start) * (int64_t)F;
+#pragma unroll
+        for (int s = 0; s < FP / 2; ++s) {
+            int kk = 2 * s + hi;
+            bfrag[s] = (uvalid && kk < F) ? gu[kk] : 0.f;
+        }
+    }
+    int64_t e0 = 0, e1 = 0;
+    if (p.excl_indptr && uvalid) {
+        e0 = p.excl_indptr[user];
+        e1 = p.excl_indptr[user + 1];
+    }
+    if (hi == 0) cnts[uslot] = 0;
+    float tau = -INFINITY;
+
+    const int ntiles = (int)((I + BI - 1) / BI);
+    const int nch = (F + KC - 1) / KC;
+
+    float4 pre[NIB];
+    float pre_bias = 0.f;
+
+    auto gload = [&](int tile, int ch) {
+#pragma unroll
+        for (int q = 0; q < NIB; ++q) {
+            int f4 = q * 256 + tid;
+            int row = f4 >> 3, c4 = f4 & 7;
+            int64_t item = (int64_t)tile * BI + row;
+            int kk = ch * KC + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < I && kk < F) {
+                const float* src = p.Gi + item * (int64_t)F + kk;
+                if (vec) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (kk + 1 < F) v.y = src[1];
+                    if (kk + 2 < F) v.z = src[2];
+                    if (kk + 3 < F) v.w = src[3];
+                }
+            }
+            pre[q] = v;
+        }
+        if (ch == 0 && tid < BI) {
+            int64_t item = (int64_t)tile * BI + tid;
+            pre_bias = (p.Bi && item < I) ? p.Bi[item] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf, int bias_buf) {
+#pragma unroll
+        for (int q = 0; q < NIB; ++q) {
+            int f4 = q * 256 + tid;
+            int row = f4 >> 3, c4 = f4 & 7;
+            float* dst = As + (buf * BI + row) * LDA + c4 * 4;
+            dst[0] = pre[q].x;
+            dst[1] = pre[q].y;
+            dst[2] = pre[q].z;
+            dst[3] = pre[q].w;
+        }
+        if (bias_buf >= 0 && tid < BI) Bs[bias_buf * BI + tid] = pre_bias;
+    };
+
+    u64* wkeys = keys + (size_t)wave * 32 * CAP;
+    int* wcnts = cnts + wave * 32;
+
+    int buf = 0;
+    if (ntiles > 0) gload(0, 0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        floatx16 acc[NIB];
+#pragma unroll
+        for (int b = 0; b < NIB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch < nch) {
+                lstore(buf, ch == 0 ? (tile & 1) : -1);
+                __syncthreads();
+                int nt = tile, nc = ch + 1;
+                if (nc >= nch) {
+                    nt = tile + 1;
+                    nc = 0;
+                }
+                if (nt < ntiles) gload(nt, nc);
+                const float* Ab = As + buf * BI * LDA;
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    float a[NIB];
+#pragma unroll
+                    for (int b = 0; b < NIB; ++b) a[b] = Ab[(b * 32 + col) * LDA + 2 * s + hi];
+#pragma unroll
+                    for (int b = 0; b < NIB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b], bfrag[ch * (KC / 2) + s], acc[b], 0, 0, 0);
+                }
+                buf ^= 1;
+            }
+        }
+
+        // ---- fused selection ------------------------------------------------------
+        const float* bb = Bs + (tile & 1) * BI;
+#pragma unroll
+        for (int b = 0; b < NIB; ++b) {
+            float sc[16];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sc[r] = (acc[b][r] + bb[row]) + 0.0f;
+                m = fmaxf(m, sc[r]);
+            }
+            if (__ballot(m >= tau) != 0ull) {
+                // rare path: bitmask of this lane's passing rows, then one insertion per lane
+                // per round (so a user -- lanes l and l+32 -- gains at most 2 keys per round)
+                u32 hm = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hm |= (sc[r] >= tau) ? (1u << r) : 0u;
+                while (__ballot(hm != 0u) != 0ull) {
+                    const bool pend = hm != 0u;
+                    const int r = pend ? (__ffs((int)hm) - 1) : 0;
+                    hm &= hm - 1u;
+                    float sv = sc[0];
+#pragma unroll
+                    for (int q = 1; q < 16; ++q) sv = (r == q) ? sc[q] : sv;
+                    int64_t il = (int64_t)tile * BI + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    bool v = pend && uvalid && il < I && (sv >= tau);
+                    int32_t g = (int32_t)(p.item_offset + il);
+                    if (v && e1 > e0) v = !el_row_contains(p.excl_indices, e0, e1, g);
+                    if (v) {
+                        int pos = atomicAdd(&cnts[uslot], 1);
+                        keys[(size_t)uslot * CAP + pos] = el_make_key(sv, g);
+                    }
+                    el_wave_lds_sync();
+                    int c = cnts[uslot];
+                    u64 full = __ballot(hi == 0 && c > CAP - 2);
+                    while (full) {
+                        int ul = __ffsll((long long)full) - 1;
+                        full &= full - 1ull;
+                        float ntau = el_wave_compact(wkeys + (size_t)ul * CAP, wcnts + ul, CAP, p.k, lane);
+                        if (col == ul) tau = ntau;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- final sort + write-out ---------------------------------------------------
+    for (int ul = 0; ul < 32; ++ul) {
+        const int64_t uu = ublock + wave * 32 + ul;
+        if (uu >= p.u_stop) break;
+        u64* kb = wkeys + (size_t)ul * CAP;
+        el_wave_compact(kb, wcnts + ul, CAP, p.k, lane);
+        const int nv = wcnts[ul];
+        const int64_t ue0 = __shfl(e0, ul, 64), ue1 = __shfl(e1, ul, 64);
+        const int64_t orow = (uu - p.u_start) * (int64_t)p.k;
+        for (int t = lane; t < p.k; t += 64) {
+            int32_t oi;
+            float ov;
+            if (t < nv) {
+                u64 key = kb[t];
+                oi = el_key_item(key);
+                ov = el_key_score(key);
+            } else {
+                oi = el_fill_masked(p, ue0, ue1, 0, 0, t - nv);
+                ov = -INFINITY;
+            }
+            p.out_idx[orow + t] = oi;
+            p.out_val[orow + t] = ov;
+        }
+        el_wave_lds_sync();
+    }
+}
+
+// =====================================================================================
+// merge of G partial lists per user
+// =====================================================================================
+__global__ __launch_bounds__(64) void k_topk_merge(const int32_t* parts_idx, const float* parts_val, int G,
+                                                   int64_t n_users, int k, int cap, int32_t* out_idx,
+                                                   float* out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t u = blockIdx.x;
+    const int total = G * k;
+    for (int t = lane; t < cap; t += 64) {
+        u64 key = 0ull;
+        if (t < total) {
+            int g = t / k, r = t - g * k;
+            int64_t src = ((int64_t)g * n_users + u) * k + r;
+            int32_t idx = parts_idx[src];
+            float v = parts_val[src];
+            if (idx >= 0 && v == v) key = el_make_key(v, idx);
+        }
+        keys[t] = key;
+    }
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(keys, cap, lane);
+    for (int t = lane; t < k; t += 64) {
+        u64 key = keys[t];
+        int32_t oi = -1;
+        float ov = -INFINITY;
+        if (key != 0ull) {
+            oi = el_key_item(key);
+            ov = el_key_score(key);
+        }
+        out_idx[u * k + t] = oi;
+        out_val[u * k + t] = ov;
+    }
+}
+
+// =====================================================================================
+// fp64 variant (BPRMF NumPy model): wave-per-user, (ord64(score), ~item) pairs
+// =====================================================================================
+struct TopkParams64 {
+    const double* P;
+    const double* Q;
+    const double* b;
+    int64_t u_start, u_stop, item_offset, I_local;
+    int F;
+    const int64_t* excl_indptr;
+    const int32_t* excl_indices;
+    const int64_t* cand_indptr;
+    const int32_t* cand_indices;
+    int k;
+    int32_t* out_idx;
+    double* out_val;
+};
+
+__device__ __forceinline__ bool el_pair_less(u64 pa, u32 sa, u64 pb, u32 sb) {
+    return (pa < pb) || (pa == pb && sa < sb);
+}
+
+__device__ __forceinline__ void el_wave_bitonic_desc_pair(u64* a, u32* s, int n, int lane) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (n >> 1); t += 64) {
+                int i = 2 * t - (t & (stride - 1));
+                int j = i + stride;
+                bool desc = ((i & size) == 0);
+                u64 x = a[i], y = a[j];
+                u32 sx = s[i], sy = s[j];
+                bool sw = desc ? el_pair_less(x, sx, y, sy) : el_pair_less(y, sy, x, sx);
+                if (sw) {
+                    a[i] = y;
+                    a[j] = x;
+                    s[i] = sy;
+                    s[j] = sx;
+                }
+            }
+            el_wave_lds_sync();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_topk_wave_f64(TopkParams64 p, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* prim = reinterpret_cast<u64*>(smem);        // [cap]
+    u32* sec = reinterpret_cast<u32*>(prim + cap);   // [cap]
+    const int lane = threadIdx.x;
+    const int64_t user = p.u_start + blockIdx.x;
+    const int F = p.F;
+    const double* pu = p.P + user * (int64_t)F;
+    int64_t e0 = 0, e1 = 0, c0 = 0, c1 = 0;
+    if (p.excl_indptr) {
+        e0 = p.excl_indptr[user];
+        e1 = p.excl_indptr[user + 1];
+    }
+    int64_t ncand = p.I_local;
+    if (p.cand_indptr) {
+        c0 = p.cand_indptr[user];
+        c1 = p.cand_indptr[user + 1];
+        ncand = c1 - c0;
+    }
+    const bool use_excl = (p.excl_indptr != nullptr) && (p.cand_indptr == nullptr);
+    int cnt = 0;
+    double tau = -INFINITY;
+    auto compact = [&]() {
+        el_wave_lds_sync();
+        for (int t = cnt + lane; t < cap; t += 64) {
+            prim[t] = 0ull;
+            sec[t] = 0u;
+        }
+        el_wave_lds_sync();
+        el_wave_bitonic_desc_pair(prim, sec, cap, lane);
+        cnt = cnt < p.k ? cnt : p.k;
+        tau = (cnt >= p.k) ? el_ord2d(prim[p.k - 1]) : -INFINITY;
+        el_wave_lds_sync();
+    };
+    for (int64_t base = 0; base < ncand; base += 64) {
+        int64_t pos = base + lane;
+        bool valid = pos < ncand;
+        int32_t gitem = -1;
+        int64_t il = 0;
+        if (valid) {
+            if (p.cand_indptr) {
+                gitem = p.cand_indices[c0 + pos];
+                il = (int64_t)gitem - p.item_offset;
+                valid = (il >= 0 && il < p.I_local);
+            } else {
+                il = pos;
+                gitem = (int32_t)(p.item_offset + pos);
+            }
+        }
+        double s = 0.0;
+        if (valid) {
+            const double* qi = p.Q + il * (int64_t)F;
+            double acc = 0.0;
+            for (int f = 0; f < F; ++f) acc = __builtin_fma(qi[f], pu[f], acc);
+            s = (p.b ? acc + p.b[il] : acc) + 0.0;
+        }
+        bool hit = valid && (s >= tau);
+        if (hit && use_excl) hit = !el_row_contains(p.excl_indices, e0, e1, gitem);
+        u64 bal = __ballot(hit);
+        if (bal) {
+            int offp = __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit) {
+                prim[cnt + offp] = el_d2ord(s);
+                sec[cnt + offp] = 0xffffffffu - (u32)gitem;
+            }
+            cnt += __popcll(bal);
+        }
+        if (cnt > cap - 64) compact();
+    }
+    compact();
+    const int nv = cnt;
+    const int64_t orow = (int64_t)blockIdx.x * p.k;
+    TopkParams pf = {};
+    pf.item_offset = p.item_offset;
+    pf.I_local = p.I_local;
+    pf.excl_indptr = p.excl_indptr;
+    pf.excl_indices = p.excl_indices;
+    pf.cand_indptr = p.cand_indptr;
+    pf.cand_indices = p.cand_indices;
+    for (int t = lane; t < p.k; t += 64) {
+        int32_t oi;
+        double ov;
+        if (t < nv) {
+            oi = (int32_t)(0xffffffffu - sec[t]);
+            ov = el_ord2d(prim[t]);
+        } else {
+            oi = el_fill_masked(pf, e0, e1, c0, c1, t - nv);
+            ov = -INFINITY;
+        }
+        p.out_idx[orow + t] = oi;
+        p.out_val[orow + t] = ov;
+    }
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+static int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+static int wave_cap_for_k(int k) {
+    int cap = next_pow2(k + 64);
+    return cap < 128 ? 128 : cap;
+}
+
+static bool mfma_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 256 && k >= 1 && k <= 40; }
+
+extern "C" size_t el_score_topk_ws_bytes(int64_t, int64_t, int32_t, int32_t, int) { return 0; }
+
+template <int FP, int NIB, int CAP>
+static int launch_mfma(const TopkParams& p, int vec, hipStream_t st) {
+    constexpr int KC = 32, LDA = KC + 1, BI = 32 * NIB;
+    constexpr size_t lds = (size_t)(2 * BI * LDA + 2 * BI) * 4 + (size_t)128 * CAP * 8 + 128 * 4;
+    auto kern = k_score_topk_mfma<FP, NIB, CAP>;
+    EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t n_users = p.u_stop - p.u_start;
+    unsigned grid = (unsigned)((n_users + 127) / 128);
+    EL_LAUNCH("k_score_topk_mfma", kern, dim3(grid), dim3(256), lds, st, p, vec);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int CAP>
+static int dispatch_mfma_fp(const TopkParams& p, int vec, hipStream_t st) {
+    if (p.F <= 32) return launch_mfma<32, 4, CAP>(p, vec, st);
+    if (p.F <= 64) return launch_mfma<64, 4, CAP>(p, vec, st);
+    if (p.F <= 128) return launch_mfma<128, 4, CAP>(p, vec, st);
+    return launch_mfma<256, 2, CAP>(p, vec, st);
+}
+
+static int check_topk_args(const char* fn, int64_t u_start, int64_t u_stop, int64_t I_local, int F, int k,
+                           const void* out_idx, const void* out_val) {
+    EL_REQUIRE(u_stop >= u_start, "%s: u_stop < u_start", fn);
+    EL_REQUIRE(I_local >= 0 && I_local < 0x7fffffffLL, "%s: I_local out of range", fn);
+    EL_REQUIRE(F >= 1, "%s: F must be >= 1", fn);
+    EL_REQUIRE(k >= 1 && k <= 4032, "%s: k=%d unsupported (1..4032)", fn, k);
+    EL_REQUIRE(out_idx && out_val, "%s: null output", fn);
+    return 0;
+}
+
+extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const float* Gi, const float* Bi,
+                             int64_t u_start, int64_t u_stop, int64_t item_offset, int64_t I_local, int32_t F,
+                             const int64_t* excl_indptr, const int32_t* excl_indices, const int64_t* cand_indptr,
+                             const int32_t* cand_indices, int32_t k, int32_t* out_idx, float* out_val, int algo,
+                             void* ws, size_t ws_bytes) {
+    (void)ws;
+    (void)ws_bytes;
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = check_topk_args("el_score_topk", u_start, u_stop, I_local, F, k, out_idx, out_val)) return rc;
+    EL_REQUIRE(Gu && Gi, "el_score_topk: null factor table");
+    EL_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr) || excl_indptr != nullptr,
+               "el_score_topk: excl_indices without excl_indptr");
+    EL_REQUIRE((cand_indptr == nullptr) == (cand_indices == nullptr), "el_score_topk: cand CSR needs both arrays");
+    if (u_stop == u_start) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    TopkParams p;
+    memset(&p, 0, sizeof(p));
+    p.Gu = Gu;
+    p.Gi = Gi;
+    p.Bi = Bi;
+    p.u_start = u_start;
+    p.u_stop = u_stop;
+    p.item_offset = item_offset;
+    p.I_local = I_local;
+    p.F = F;
+    p.excl_indptr = excl_indptr;
+    p.excl_indices = excl_indices;
+    p.cand_indptr = cand_indptr;
+    p.cand_indices = cand_indices;
+    p.k = k;
+    p.out_idx = out_idx;
+    p.out_val = out_val;
+    bool elig = mfma_eligible(F, k, cand_indptr);
+    if (algo == EL_TOPK_MFMA) EL_REQUIRE(elig, "el_score_topk: MFMA kernel needs F<=256, k<=40 and no candidate list");
+    bool use_mfma = (algo == EL_TOPK_MFMA) || (algo == EL_TOPK_AUTO && elig);
+    if (use_mfma) {
+        int vec = (F % 4 == 0) && (((uintptr_t)Gi) % 16 == 0);
+        if (k <= 14) return dispatch_mfma_fp<32>(p, vec, st);
+        return dispatch_mfma_fp<64>(p, vec, st);
+    }
+    int cap = wave_cap_for_k(k);
+    EL_LAUNCH("k_topk_wave", k_topk_wave<false>, dim3((unsigned)(u_stop - u_start)), dim3(64), (size_t)cap * 8 + 16, st, p, cap);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_dense_topk(el_ctx* ctx, void* stream, const float* preds, int64_t ld, int64_t u_start,
+                             int64_t u_stop, int64_t I, const int64_t* excl_indptr, const int32_t* excl_indices,
+                             const int64_t* cand_indptr, const int32_t* cand_indices, int32_t k, int32_t* out_idx,
+                             float* out_val) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = check_topk_args("el_dense_topk", u_start, u_stop, I, 1, k, out_idx, out_val)) return rc;
+    EL_REQUIRE(preds && ld >= I, "el_dense_topk: bad preds/ld");
+    if (u_stop == u_start) return 0;
+    TopkParams p;
+    memset(&p, 0, sizeof(p));
+    p.u_start = u_start;
+    p.u_stop = u_stop;
+    p.item_offset = 0;
+    p.I_local = I;
+    p.F = 1;
+    p.excl_indptr = excl_indptr;
+    p.excl_indices = excl_indices;
+    p.cand_indptr = cand_indptr;
+    p.cand_indices = cand_indices;
+    p.k = k;
+    p.out_idx = out_idx;
+    p.out_val = out_val;
+    p.preds = preds;
+    p.ld = ld;
+    int cap = wave_cap_for_k(k);
+    EL_LAUNCH("k_topk_wave", k_topk_wave<true>, dim3((unsigned)(u_stop - u_start)), dim3(64), (size_t)cap * 8 + 16,
+                       (hipStream_t)stream, p, cap);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_score_topk_f64(el_ctx* ctx, void* stream, const double* P, const double* Q, const double* b,
+                                 int64_t u_start, int64_t u_stop, int64_t item_offset, int64_t I_local, int32_t F,
+                                 const int64_t* excl_indptr, const int32_t* excl_indices, const int64_t* cand_indptr,
+                                 const int32_t* cand_indices, int32_t k, int32_t* out_idx, double* out_val) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = check_topk_args("el_score_topk_f64", u_start, u_stop, I_local, F, k, out_idx, out_val)) return rc;
+    EL_REQUIRE(P && Q, "el_score_topk_f64: null factor table");
+    if (u_stop == u_start) return 0;
+    TopkParams64 p;
+    memset(&p, 0, sizeof(p));
+    p.P = P;
+    p.Q = Q;
+    p.b = b;
+    p.u_start = u_start;
+    p.u_stop = u_stop;
+    p.item_offset = item_offset;
+    p.I_local = I_local;
+    p.F = F;
+    p.excl_indptr = excl_indptr;
+    p.excl_indices = excl_indices;
+    p.cand_indptr = cand_indptr;
+    p.cand_indices = cand_indices;
+    p.k = k;
+    p.out_idx = out_idx;
+    p.out_val = out_val;
+    int cap = wave_cap_for_k(k);
+    EL_LAUNCH("k_topk_wave_f64", k_topk_wave_f64, dim3((unsigned)(u_stop - u_start)), dim3(64), (size_t)cap * 12,
+                       (hipStream_t)stream, p, cap);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_topk_merge(el_ctx* ctx, void* stream, const int32_t* parts_idx, const float* parts_val, int32_t G,
+                             int64_t n_users, int32_t k, int32_t* out_idx, float* out_val) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(parts_idx && parts_val && out_idx && out_val, "el_topk_merge: null pointer");
+    EL_REQUIRE(G >= 1 && k >= 1 && (int64_t)G * k <= 8192, "el_topk_merge: G*k=%lld unsupported (<=8192)",
+               (long long)G * k);
+    if (n_users <= 0) return 0;
+    int cap = next_pow2(G * k);
+    if (cap < 64) cap = 64;
+    EL_LAUNCH("k_topk_merge", k_topk_merge, dim3((unsigned)n_users), dim3(64), (size_t)cap * 8, (hipStream_t)stream,
+                       parts_idx, parts_val, G, n_users, k, cap, out_idx, out_val);
+    EL_CHECK_LAUNCH();
+    return 0;
+}

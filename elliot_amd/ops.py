@@ -1,0 +1,343 @@
+"""Tensor-level wrappers over the C ABI.
+
+torch tensors are used ONLY as device-buffer holders (allocation, streams, H2D/D2H copies);
+all arithmetic happens inside libelliot_hip.so.  Every function raises if the library or a
+GPU is missing -- there is no CPU path here.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (EL_OPT_ADAM_LAZY, EL_OPT_ADAM_TF_DENSE, EL_OPT_SGD, EL_TOPK_AUTO, EL_TOPK_MFMA,
+                   EL_TOPK_SIMPLE, BprmfState, BprsgdState, check)
+
+OPTIMIZERS = {"adam": EL_OPT_ADAM_TF_DENSE, "adam_tf_dense": EL_OPT_ADAM_TF_DENSE,
+              "adam_lazy": EL_OPT_ADAM_LAZY, "sgd": EL_OPT_SGD}
+TOPK_ALGOS = {"auto": EL_TOPK_AUTO, "mfma": EL_TOPK_MFMA, "simple": EL_TOPK_SIMPLE}
+
+
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.ElliotHipError(f"{name}: tensor must live on the GPU (got {t.device})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One el_ctx per device (include/elliot_hip.h: el_ctx_create)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.ElliotHipError("no GPU visible: elliot_amd needs an MI355X (gfx950)")
+        self.device = torch.device("cuda", int(device))
+        h = C.c_void_p()
+        check(self.lib.el_ctx_create(int(device), C.byref(h)), "el_ctx_create")
+        self.handle = h
+        name = C.create_string_buffer(64)
+        cus = C.c_int()
+        hbm = C.c_int64()
+        check(self.lib.el_device_info(h, name, 64, C.byref(cus), C.byref(hbm)), "el_device_info")
+        self.arch, self.cus, self.hbm_bytes = name.value.decode(), cus.value, hbm.value
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def timing(self, on):
+        check(self.lib.el_timing_enable(self.handle, 1 if on else 0), "el_timing_enable")
+
+    def timing_report(self):
+        """{kernel_name: (launches, total_ms)} since the last report (synchronises the events)."""
+        buf = C.create_string_buffer(1 << 16)
+        check(self.lib.el_timing_report(self.handle, buf, len(buf)), "el_timing_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.el_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_ctx_cache = {}
+
+
+def get_context(device=0):
+    device = int(device)
+    if device not in _ctx_cache:
+        _ctx_cache[device] = Context(device)
+    return _ctx_cache[device]
+
+
+class DeviceCSR:
+    """CSR (int64 indptr, int32 indices, rows sorted ascending) resident in HBM.
+
+    Stands in for the reference's dense bool masks (dataset.py:230-245) and the sampler's
+    per-user positive lists (custom_sampler.py:19-22)."""
+
+    def __init__(self, indptr, indices, n_cols, device):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        if indptr.ndim != 1 or indptr[0] != 0 or indptr[-1] != indices.shape[0]:
+            raise ValueError("malformed CSR")
+        self.n_rows = indptr.shape[0] - 1
+        self.n_cols = int(n_cols)
+        self.nnz = int(indices.shape[0])
+        self.indptr = torch.from_numpy(indptr).to(device)
+        # never hand a zero-length buffer's null pointer to the kernels
+        self.indices = torch.from_numpy(indices if self.nnz else np.zeros(1, np.int32)).to(device)
+
+    @classmethod
+    def from_tensors(cls, indptr, indices, n_cols):
+        """Adopt device tensors (int64 indptr, int32 indices) without a host round trip."""
+        self = cls.__new__(cls)
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
+        self.n_rows = indptr.shape[0] - 1
+        self.n_cols = int(n_cols)
+        self.nnz = int(indices.shape[0])
+        self.indptr = indptr.contiguous()
+        self.indices = indices.contiguous() if self.nnz else torch.zeros(1, dtype=torch.int32, device=indptr.device)
+        return self
+
+    @staticmethod
+    def from_scipy(m, device):
+        m = m.tocsr()
+        m.sort_indices()
+        return DeviceCSR(m.indptr, m.indices, m.shape[1], device)
+
+
+def _csr_ptrs(csr):
+    if csr is None:
+        return None, None
+    return _ptr(csr.indptr, torch.int64, "indptr"), _ptr(csr.indices, torch.int32, "indices")
+
+
+# ------------------------------------------------------------------------------------------
+# scoring + top-k
+# ------------------------------------------------------------------------------------------
+def score_topk(ctx, Gu, Gi, Bi, u_start, u_stop, k, excl=None, cand=None, item_offset=0, algo="auto",
+               out_idx=None, out_val=None):
+    """BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) for users
+    [u_start, u_stop): returns (idx int32 [n,k], val float32 [n,k]) on the device."""
+    n = int(u_stop) - int(u_start)
+    I_local, F = Gi.shape
+    if Gu.shape[1] != F:
+        raise ValueError("Gu/Gi factor mismatch")
+    if out_idx is None:
+        out_idx = torch.empty((n, k), dtype=torch.int32, device=ctx.device)
+    if out_val is None:
+        out_val = torch.empty((n, k), dtype=torch.float32, device=ctx.device)
+    ep, ei = _csr_ptrs(excl)
+    cp, ci = _csr_ptrs(cand)
+    check(ctx.lib.el_score_topk(ctx.handle, ctx.stream(), _ptr(Gu, torch.float32, "Gu"),
+                                _ptr(Gi, torch.float32, "Gi"), _ptr(Bi, torch.float32, "Bi"),
+                                int(u_start), int(u_stop), int(item_offset), int(I_local), int(F),
+                                ep, ei, cp, ci, int(k), _ptr(out_idx, torch.int32), _ptr(out_val, torch.float32),
+                                TOPK_ALGOS[algo] if isinstance(algo, str) else int(algo), None, 0),
+          "el_score_topk")
+    return out_idx, out_val
+
+
+def score_topk_f64(ctx, P, Q, b, u_start, u_stop, k, excl=None, cand=None, item_offset=0):
+    """MFModel.get_user_predictions (BPRMF_model.py:70-85), fp64 tables."""
+    n = int(u_stop) - int(u_start)
+    I_local, F = Q.shape
+    out_idx = torch.empty((n, k), dtype=torch.int32, device=ctx.device)
+    out_val = torch.empty((n, k), dtype=torch.float64, device=ctx.device)
+    ep, ei = _csr_ptrs(excl)
+    cp, ci = _csr_ptrs(cand)
+    check(ctx.lib.el_score_topk_f64(ctx.handle, ctx.stream(), _ptr(P, torch.float64, "P"),
+                                    _ptr(Q, torch.float64, "Q"), _ptr(b, torch.float64, "b"),
+                                    int(u_start), int(u_stop), int(item_offset), int(I_local), int(F),
+                                    ep, ei, cp, ci, int(k), _ptr(out_idx), _ptr(out_val)), "el_score_topk_f64")
+    return out_idx, out_val
+
+
+def dense_topk(ctx, preds, u_start, u_stop, k, excl=None, cand=None):
+    """get_top_k (multi_vae_model.py:158-159 et al.) over a materialised [n_users, I] block."""
+    n, I = preds.shape
+    if n != int(u_stop) - int(u_start):
+        raise ValueError("preds rows must equal u_stop - u_start")
+    out_idx = torch.empty((n, k), dtype=torch.int32, device=ctx.device)
+    out_val = torch.empty((n, k), dtype=torch.float32, device=ctx.device)
+    ep, ei = _csr_ptrs(excl)
+    cp, ci = _csr_ptrs(cand)
+    check(ctx.lib.el_dense_topk(ctx.handle, ctx.stream(), _ptr(preds, torch.float32, "preds"), int(preds.stride(0)),
+                                int(u_start), int(u_stop), int(I), ep, ei, cp, ci, int(k),
+                                _ptr(out_idx), _ptr(out_val)), "el_dense_topk")
+    return out_idx, out_val
+
+
+def topk_merge(ctx, parts_idx, parts_val):
+    """Merge [G, n_users, k] partial lists (item shards) into [n_users, k]."""
+    G, n, k = parts_idx.shape
+    out_idx = torch.empty((n, k), dtype=torch.int32, device=ctx.device)
+    out_val = torch.empty((n, k), dtype=torch.float32, device=ctx.device)
+    check(ctx.lib.el_topk_merge(ctx.handle, ctx.stream(), _ptr(parts_idx, torch.int32), _ptr(parts_val, torch.float32),
+                                int(G), int(n), int(k), _ptr(out_idx), _ptr(out_val)), "el_topk_merge")
+    return out_idx, out_val
+
+
+# ------------------------------------------------------------------------------------------
+# sampler
+# ------------------------------------------------------------------------------------------
+def bpr_sample(ctx, pos, n, seed, first_sample=0, item_lo=0, item_hi=None, out=None):
+    """custom_sampler.Sampler.step (custom_sampler.py:31-46) on the device: n triplets."""
+    U, I = pos.n_rows, pos.n_cols
+    if item_hi is None:
+        item_hi = I
+    if out is None:
+        out = tuple(torch.empty((n,), dtype=torch.int32, device=ctx.device) for _ in range(3))
+    check(ctx.lib.el_bpr_sample(ctx.handle, ctx.stream(), *_csr_ptrs(pos), int(U), int(I), int(item_lo), int(item_hi),
+                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample), int(n),
+                                _ptr(out[0], torch.int32), _ptr(out[1], torch.int32), _ptr(out[2], torch.int32)),
+          "el_bpr_sample")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# BPRMF_batch (TF semantics)
+# ------------------------------------------------------------------------------------------
+def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
+    """Keras Adam bias-corrected step size, computed in fp32 like TF does."""
+    b1p = np.power(np.float32(beta1), np.float32(step))
+    b2p = np.power(np.float32(beta2), np.float32(step))
+    return float(np.float32(lr) * np.sqrt(np.float32(1.0) - b2p) / (np.float32(1.0) - b1p))
+
+
+class BprmfDeviceState:
+    """Gu/Gi/Bi + gradient accumulators + Adam slots in HBM (BPRMF_batch_model.py:39-44)."""
+
+    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam"):
+        self.ctx = ctx
+        self.opt = OPTIMIZERS[optimizer] if isinstance(optimizer, str) else int(optimizer)
+        dev = ctx.device
+
+        def own(x, dt):
+            if isinstance(x, np.ndarray):
+                x = torch.from_numpy(np.ascontiguousarray(x))
+            return x.to(device=dev, dtype=dt).contiguous().clone()
+
+        self.Gu, self.Gi, self.Bi = own(Gu, torch.float32), own(Gi, torch.float32), own(Bi, torch.float32)
+        self.U, self.F = self.Gu.shape
+        self.I = self.Gi.shape[0]
+        z = torch.zeros_like
+        self.gGu, self.gGi, self.gBi = z(self.Gu), z(self.Gi), z(self.Bi)
+        adam = self.opt in (EL_OPT_ADAM_TF_DENSE, EL_OPT_ADAM_LAZY)
+        self.mGu = z(self.Gu) if adam else None
+        self.vGu = z(self.Gu) if adam else None
+        self.mGi = z(self.Gi) if adam else None
+        self.vGi = z(self.Gi) if adam else None
+        self.mBi = z(self.Bi) if adam else None
+        self.vBi = z(self.Bi) if adam else None
+        rows = self.opt in (EL_OPT_ADAM_LAZY, EL_OPT_SGD)
+        self.tGu = torch.zeros(self.U, dtype=torch.int32, device=dev) if rows else None
+        self.tGi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
+        self.tBi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.step = 0
+        self._c = BprmfState(
+            Gu=self.Gu.data_ptr(), Gi=self.Gi.data_ptr(), Bi=self.Bi.data_ptr(),
+            gGu=self.gGu.data_ptr(), gGi=self.gGi.data_ptr(), gBi=self.gBi.data_ptr(),
+            mGu=self.mGu.data_ptr() if adam else None, vGu=self.vGu.data_ptr() if adam else None,
+            mGi=self.mGi.data_ptr() if adam else None, vGi=self.vGi.data_ptr() if adam else None,
+            mBi=self.mBi.data_ptr() if adam else None, vBi=self.vBi.data_ptr() if adam else None,
+            tGu=self.tGu.data_ptr() if rows else None, tGi=self.tGi.data_ptr() if rows else None,
+            tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F)
+
+    def train_step(self, u, i, j, lr, l_w, l_b):
+        """BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80).  u,i,j: int32 device tensors.
+        The batch loss is accumulated into self.loss (device double) -- no host sync here."""
+        self.step += 1
+        B = u.numel()
+        lr_t = adam_lr_t(lr, self.step)
+        check(self.ctx.lib.el_bprmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c),
+                                               _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
+                                               _ptr(j, torch.int32, "j"), int(B), float(lr), float(l_w), float(l_b),
+                                               self.opt, int(self.step), float(lr_t), _ptr(self.loss, torch.float64)),
+              "el_bprmf_train_step")
+
+    def pop_loss(self):
+        v = float(self.loss.item())
+        self.loss.zero_()
+        return v
+
+
+# ------------------------------------------------------------------------------------------
+# BPRMF (NumPy semantics, fp64)
+# ------------------------------------------------------------------------------------------
+class BprSgdDeviceState:
+    """MFModel parameters in HBM (BPRMF_model.py:40-56), fp64."""
+
+    def __init__(self, ctx, P, Q, b, lr, reg_bias, reg_user, reg_pos, reg_neg):
+        self.ctx = ctx
+        dev = ctx.device
+
+        def own(x):
+            if isinstance(x, np.ndarray):
+                x = torch.from_numpy(np.ascontiguousarray(x))
+            return x.to(device=dev, dtype=torch.float64).contiguous().clone()
+
+        self.P, self.Q, self.b = own(P), own(Q), own(b)
+        self.U, self.F = self.P.shape
+        self.I = self.Q.shape[0]
+        self._c = BprsgdState(P=self.P.data_ptr(), Q=self.Q.data_ptr(), b=self.b.data_ptr(), U=self.U, I=self.I,
+                              F=self.F, lr=float(lr), reg_bias=float(reg_bias), reg_user=float(reg_user),
+                              reg_pos=float(reg_pos), reg_neg=float(reg_neg))
+
+    def apply(self, u, i, j, first=0, n=None):
+        """Concurrent application of triplets [first, first+n) (Hogwild unless conflict-free)."""
+        if n is None:
+            n = u.numel() - first
+        check(self.ctx.lib.el_bprsgd_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c),
+                                           _ptr(u, torch.int32), _ptr(i, torch.int32), _ptr(j, torch.int32),
+                                           int(first), int(n)), "el_bprsgd_apply")
+
+    def apply_sequential_equivalent(self, u_host, i_host, j_host):
+        """Bit-for-bit the sequential order of MFModel.train_step (BPRMF_model.py:87-89): triplets are
+        grouped into dependency levels on the host, each level is one conflict-free launch."""
+        order, starts = sgd_levels(u_host, i_host, j_host, self.U, self.I)
+        dev = self.ctx.device
+        u = torch.from_numpy(np.ascontiguousarray(u_host[order], dtype=np.int32)).to(dev)
+        i = torch.from_numpy(np.ascontiguousarray(i_host[order], dtype=np.int32)).to(dev)
+        j = torch.from_numpy(np.ascontiguousarray(j_host[order], dtype=np.int32)).to(dev)
+        check(self.ctx.lib.el_bprsgd_apply_levels(self.ctx.handle, self.ctx.stream(), C.byref(self._c),
+                                                  _ptr(u), _ptr(i), _ptr(j), starts.ctypes.data_as(C.c_void_p),
+                                                  int(starts.shape[0] - 1)), "el_bprsgd_apply_levels")
+        return int(starts.shape[0] - 1)
+
+
+def sgd_levels(u_host, i_host, j_host, U, I):
+    """Host-only: dependency levels of a triplet sequence (el_bprsgd_levels_host)."""
+    lib = _lib.load()
+    u = np.ascontiguousarray(u_host, dtype=np.int32)
+    i = np.ascontiguousarray(i_host, dtype=np.int32)
+    j = np.ascontiguousarray(j_host, dtype=np.int32)
+    n = u.shape[0]
+    order = np.empty(n, dtype=np.int32)
+    starts = np.empty(n + 2, dtype=np.int64)
+    nl = C.c_int64()
+    check(lib.el_bprsgd_levels_host(u.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p),
+                                    j.ctypes.data_as(C.c_void_p), n, int(U), int(I),
+                                    order.ctypes.data_as(C.c_void_p), starts.ctypes.data_as(C.c_void_p),
+                                    n + 2, C.byref(nl)), "el_bprsgd_levels_host")
+    return order, starts[: nl.value + 1].copy()

@@ -1,0 +1,208 @@
+/*
+ * elliot_hip.h -- C ABI of libelliot_hip.so, the MI355X (gfx950) backend for the
+ * latent-factor hot path of sisinflab/elliot (BPRMF, BPRMF_batch, MultiVAE, NeuMF/GMF).
+ *
+ * This header IS the drop-in boundary.  The reference is pure Python; its "FFI" for
+ * this path is the set of TensorFlow / NumPy calls made by the model classes.  Each
+ * entry point below names the reference call sites (file:line, relative to the
+ * reference checkout) that it replaces.  A Python plugin binds these with ctypes
+ * (elliot_amd/_lib.py; INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; el_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - all data pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr() of a
+ *     tensor on the ctx's device) unless the parameter name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous on that stream; the library never synchronises unless documented.
+ *   - the library never allocates or frees caller buffers.  Scratch space is passed
+ *     in explicitly (ws / ws_bytes) and sized with the matching *_ws_bytes() query.
+ *   - embedding tables are row-major [rows, F]; CSR index arrays are int64 indptr /
+ *     int32 indices with column indices sorted ascending inside each row.
+ *   - one el_ctx per device; a ctx is not thread-safe, distinct ctxs may be used
+ *     from distinct threads.
+ */
+#ifndef ELLIOT_HIP_H
+#define ELLIOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct el_ctx el_ctx;
+
+#define EL_ABI_VERSION 1
+
+/* ---- context ---------------------------------------------------------------- */
+
+/* Replaces: device selection in elliot/namespace/namespace_model.py:74
+ * (CUDA_VISIBLE_DEVICES) -- one ctx per visible MI355X.                          */
+int el_ctx_create(int device, el_ctx** out);
+int el_ctx_destroy(el_ctx* ctx);
+const char* el_last_error(void);
+int el_abi_version(void);
+/* Fills name[0..len) with the gcnArchName, returns CU count in *cus.             */
+int el_device_info(el_ctx* ctx, char* name, int len, int* cus, int64_t* hbm_bytes);
+
+/* Per-kernel timing for bench.py's roofline leg (new; the reference has no profiler).
+ * When enabled every kernel launch is bracketed by hipEvents on its launch stream.
+ * el_timing_report synchronises them and writes "kernel_name launches total_ms\n" lines. */
+int el_timing_enable(el_ctx* ctx, int on);
+int el_timing_report(el_ctx* ctx, char* buf, int len);
+
+/* ---- BPR triplet sampler (K1) ------------------------------------------------ */
+
+/* Replaces: elliot/dataset/samplers/custom_sampler.py:31-46 (Sampler.step/sample).
+ * Counter-based (Philox4x32-10) device sampler.  Sample n (global sample index
+ * `first_sample + n`) draws u ~ U[0,U), i ~ U(pos(u)), j ~ U[0,I) rejected while
+ * j in pos(u) -- the reference's distribution; the bit stream is Philox, not
+ * MT19937 (the exact stream is restated in oracle/sampler.py).  Users with an empty
+ * row are re-drawn; users whose row covers [0,I) are re-drawn.
+ * When item_lo/item_hi restrict the negative range (item-sharded training,
+ * SURVEY 8e) j ~ U[item_lo,item_hi).  Pass 0, I for the reference behaviour.      */
+int el_bpr_sample(el_ctx* ctx, void* stream,
+                  const int64_t* pos_indptr, const int32_t* pos_indices,
+                  int64_t U, int64_t I, int64_t item_lo, int64_t item_hi,
+                  uint64_t seed, uint64_t first_sample, int64_t n,
+                  int32_t* out_u, int32_t* out_i, int32_t* out_j);
+
+/* ---- BPR-MF, TF semantics (BPRMF_batch; K2-K4) ------------------------------- */
+
+/* Optimiser applied by el_bprmf_train_step. */
+enum {
+    EL_OPT_ADAM_TF_DENSE = 0, /* Keras-2.3 Adam sparse apply: every row of m, v and
+                                 theta moves every step -- THE REFERENCE */
+    EL_OPT_ADAM_LAZY = 2,     /* only touched rows decay/move (NOT the reference)     */
+    EL_OPT_SGD = 3            /* theta -= lr * grad            (NOT the reference)     */
+};
+
+typedef struct el_bprmf_state {
+    float* Gu;  /* [U,F] user factors      (BPRMF_batch_model.py:41) */
+    float* Gi;  /* [I,F] item factors      (BPRMF_batch_model.py:42) */
+    float* Bi;  /* [I]   item bias         (BPRMF_batch_model.py:40) */
+    float* gGu; /* [U,F] gradient accumulators, zero on entry, zero on exit */
+    float* gGi; /* [I,F] */
+    float* gBi; /* [I]   */
+    float* mGu; float* vGu; /* Adam slots (NULL for EL_OPT_SGD) */
+    float* mGi; float* vGi;
+    float* mBi; float* vBi;
+    int32_t* tGu; /* [U] per-row claim stamps, zero-initialised (LAZY, sparse SGD), else NULL */
+    int32_t* tGi; /* [I] */
+    int32_t* tBi; /* [I] */
+    int64_t U, I;
+    int32_t F;
+} el_bprmf_state;
+
+/* Replaces: BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80): two gathers
+ * (:49-51), x_ui/x_uj (:53), clip + softplus batch SUM (:65-66), L2 terms (:68-72),
+ * tape.gradient + Adam.apply_gradients (:77-78; beta1 .9, beta2 .999, eps 1e-7).
+ *   u,i,j     : int32[B] triplets
+ *   step      : 1-based optimiser iteration t
+ *   lr_t      : bias-corrected step size lr*sqrt(1-beta2^t)/(1-beta1^t) (Adam modes)
+ *   loss_out  : device double[1]; the batch loss is ADDED to it.                 */
+int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st,
+                        const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                        float lr, float l_w, float l_b, int opt, int32_t step,
+                        float lr_t, double* loss_out);
+
+/* ---- BPR-MF, NumPy semantics (BPRMF; K5) ------------------------------------- */
+
+typedef struct el_bprsgd_state {
+    double* P;  /* [U,F] user factors  (BPRMF_model.py:53-54) */
+    double* Q;  /* [I,F] item factors  (BPRMF_model.py:55-56) */
+    double* b;  /* [I]   item bias     (BPRMF_model.py:52)    */
+    int64_t U, I;
+    int32_t F;
+    double lr, reg_bias, reg_user, reg_pos, reg_neg; /* BPRMF.py:63-71 */
+} el_bprsgd_state;
+
+/* Replaces: MFModel.update_factors (BPRMF_model.py:91-117), fp64, including the
+ * in-place aliasing order (item rows see the UPDATED user row).  Triplets
+ * [first, first+n) are applied concurrently: the caller guarantees they are
+ * mutually conflict-free (level schedule, el_bprsgd_levels_host) for the result to
+ * equal the sequential reference; otherwise the update is Hogwild.               */
+int el_bprsgd_apply(el_ctx* ctx, void* stream, const el_bprsgd_state* st,
+                    const int32_t* u, const int32_t* i, const int32_t* j,
+                    int64_t first, int64_t n);
+
+/* One launch per level: segments [level_start_host[L], level_start_host[L+1]) of the
+ * (already level-ordered) device triplet arrays, L = 0..n_levels-1, in stream order. */
+int el_bprsgd_apply_levels(el_ctx* ctx, void* stream, const el_bprsgd_state* st,
+                           const int32_t* u, const int32_t* i, const int32_t* j,
+                           const int64_t* level_start_host, int64_t n_levels);
+
+/* Host helper (no GPU): dependency levels that make concurrent application equal to
+ * the sequential order of MFModel.train_step (BPRMF_model.py:87-89).
+ *   level[t]   = 1 + max(level of the last earlier triplet sharing u, i or j)
+ *   order_host = stable argsort of level (int32[n]); level L (0-based) is
+ *                order_host[level_start_host[L] .. level_start_host[L+1])
+ * Returns the number of levels in *n_levels (level_start_host holds n_levels+1
+ * entries; level_start_cap is its capacity).                                     */
+int el_bprsgd_levels_host(const int32_t* u_host, const int32_t* i_host, const int32_t* j_host,
+                          int64_t n, int64_t U, int64_t I,
+                          int32_t* order_host, int64_t* level_start_host,
+                          int64_t level_start_cap, int64_t* n_levels);
+
+/* ---- full-catalog scoring + masked top-k (K6/K7) ------------------------------ */
+
+enum {
+    EL_TOPK_AUTO = 0,   /* MFMA kernel when eligible, else the wave-per-user kernel */
+    EL_TOPK_MFMA = 1,   /* force v_mfma_f32_32x32x2_f32 kernel (error if ineligible) */
+    EL_TOPK_SIMPLE = 2  /* force wave-per-user VALU kernel                          */
+};
+
+/* Replaces: BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) and
+ * MFModel.get_user_predictions (BPRMF_model.py:70-85) for users [u_start,u_stop):
+ *   score(u,i) = Bi[i] + sum_f Gu[u,f]*Gi[i,f]   (fp32, k-ordered fma chain)
+ *   mask       = NOT (item_offset+i in excl row u)      [allunrated_mask, dataset.py:245]
+ *                or, when cand_indptr != NULL, (item in cand row u) [val/test mask]
+ *   top-k by (score desc, item index asc)  [tf.nn.top_k sorted=True tie rule];
+ *   rows with fewer than k unmasked items are padded with -inf and the lowest
+ *   masked item indices, as tf.where(mask, preds, -inf) + top_k would return.
+ * Gi / Bi describe the LOCAL item shard [item_offset, item_offset+I_local); out_idx
+ * holds GLOBAL item indices.  CSR rows are indexed by absolute user id.
+ *   out_idx int32[(u_stop-u_start), k], out_val float[(u_stop-u_start), k]
+ * ws: el_score_topk_ws_bytes(...) bytes (may be 0).                               */
+size_t el_score_topk_ws_bytes(int64_t n_users, int64_t I_local, int32_t F, int32_t k, int algo);
+int el_score_topk(el_ctx* ctx, void* stream,
+                  const float* Gu, const float* Gi, const float* Bi,
+                  int64_t u_start, int64_t u_stop, int64_t item_offset, int64_t I_local, int32_t F,
+                  const int64_t* excl_indptr, const int32_t* excl_indices,
+                  const int64_t* cand_indptr, const int32_t* cand_indices,
+                  int32_t k, int32_t* out_idx, float* out_val,
+                  int algo, void* ws, size_t ws_bytes);
+
+/* Same contract for fp64 tables (BPRMF NumPy model, BPRMF_model.py:70-85).
+ * Scores are fp64 k-ordered fma chains; out_val is double.                        */
+int el_score_topk_f64(el_ctx* ctx, void* stream,
+                      const double* P, const double* Q, const double* b,
+                      int64_t u_start, int64_t u_stop, int64_t item_offset, int64_t I_local, int32_t F,
+                      const int64_t* excl_indptr, const int32_t* excl_indices,
+                      const int64_t* cand_indptr, const int32_t* cand_indices,
+                      int32_t k, int32_t* out_idx, double* out_val);
+
+/* Merge G partial top-k lists per user (item shards / item splits) into one, with the
+ * same (score desc, index asc) rule.  parts_idx int32[G, n_users, k] (index -1 =
+ * empty), parts_val float[G, n_users, k].  New design: the reference has
+ * no multi-device path; the merged result equals the single-shard result.         */
+int el_topk_merge(el_ctx* ctx, void* stream,
+                  const int32_t* parts_idx, const float* parts_val,
+                  int32_t G, int64_t n_users, int32_t k,
+                  int32_t* out_idx, float* out_val);
+
+/* Top-k over a materialised score block (MultiVAE / NeuMF predict outputs):
+ * Replaces get_top_k (multi_vae_model.py:158-159,
+ * neural_matrix_factorization_model.py:147-148) on preds float[n_users, I].        */
+int el_dense_topk(el_ctx* ctx, void* stream, const float* preds, int64_t ld,
+                  int64_t u_start, int64_t u_stop, int64_t I,
+                  const int64_t* excl_indptr, const int32_t* excl_indices,
+                  const int64_t* cand_indptr, const int32_t* cand_indices,
+                  int32_t k, int32_t* out_idx, float* out_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELLIOT_HIP_H */

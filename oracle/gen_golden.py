@@ -1,0 +1,179 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CODE (build container only).
+
+TEST INFRASTRUCTURE.  Needs /root/reference (read-only; PYTHONDONTWRITEBYTECODE is forced so nothing
+is written there).  The reference modules are loaded BY FILE PATH because importing the package
+`elliot.recommender` pulls TensorFlow (absent).  What is pinned here:
+
+  sampler_ref.npz       triplet stream of custom_sampler.Sampler (custom_sampler.py:14-46), seed 42
+  bprmf_sgd_trace.npz   MFModel init + N sequential update_factors calls (BPRMF_model.py:40-56,91-117)
+  bprmf_sgd_topk.npz    MFModel.get_user_predictions (BPRMF_model.py:70-85)
+  ndcg_ref.npz          elliot.evaluation nDCG/Precision/Recall/HR on fixed recs (evaluator oracle)
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+import importlib.util
+import os
+import sys
+from types import SimpleNamespace
+
+sys.dont_write_bytecode = True
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from elliot_amd.synthetic import small_dataset  # noqa: E402
+from oracle import sampler as osampler, sgd as osgd  # noqa: E402
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_ui_lists(i_train_dict):
+    """custom_sampler.py:21 -- list(set(...)) per user, in CPython's order."""
+    return [list(set(i_train_dict[u])) for u in i_train_dict]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cs = load_by_path("ref_custom_sampler", "elliot/dataset/samplers/custom_sampler.py")
+    mfm = load_by_path("ref_bprmf_model", "elliot/recommender/latent_factor_models/BPRMF/BPRMF_model.py")
+
+    U = 200
+    indptr, indices, itd = small_dataset(U, 150, seed=0)
+    I = int(indices.max()) + 1
+    lists = ref_ui_lists(itd)
+    lp = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+    li = np.concatenate([np.asarray(l, np.int32) for l in lists])
+
+    # ---- 1. sampler stream ----------------------------------------------------------------------
+    N = 6000
+    ref = cs.Sampler(itd)                          # seeds np.random with 42
+    trip = [b for b in ref.step(N, 512)]
+    ru = np.concatenate([b[0] for b in trip]).reshape(-1)
+    ri = np.concatenate([b[1] for b in trip]).reshape(-1)
+    rj = np.concatenate([b[2] for b in trip]).reshape(-1)
+    ora = osampler.RefSampler(lists, I, seed=42)
+    ot = [b for b in ora.step(N, 512)]
+    assert np.array_equal(ru, np.concatenate([b[0] for b in ot]).reshape(-1))
+    assert np.array_equal(ri, np.concatenate([b[1] for b in ot]).reshape(-1))
+    assert np.array_equal(rj, np.concatenate([b[2] for b in ot]).reshape(-1))
+    np.savez_compressed(os.path.join(OUT, "sampler_ref.npz"), indptr=indptr, indices=indices, lists_indptr=lp,
+                        lists_items=li, n_users=U, n_items=I, u=ru.astype(np.int32), i=ri.astype(np.int32),
+                        j=rj.astype(np.int32))
+    print("sampler_ref.npz: oracle == reference for", N, "triplets")
+
+    # ---- 2. SGD trace ---------------------------------------------------------------------------
+    F = 16
+    hp = dict(lr=0.05, reg_bias=0.0, reg_user=0.0025, reg_pos=0.0025, reg_neg=0.00025)  # BPRMF.py:63-71
+    data = SimpleNamespace(users=list(range(U)), items=list(range(I)),
+                           private_users={p: p for p in range(U)}, public_users={p: p for p in range(U)},
+                           private_items={p: p for p in range(I)}, public_items={p: p for p in range(I)})
+    model = mfm.MFModel(F, data, hp["lr"], hp["reg_user"], hp["reg_bias"], hp["reg_pos"], hp["reg_neg"], 42)
+    P0, Q0, b0 = model._user_factors.copy(), model._item_factors.copy(), model._item_bias.copy()
+    Po, Qo, bo = osgd.initialize(U, I, F, 42)
+    assert np.array_equal(P0, Po) and np.array_equal(Q0, Qo) and np.array_equal(b0, bo)
+    NT = 3000
+    tu, ti, tj = ru[:NT], ri[:NT], rj[:NT]
+    model.train_step((tu[:, None], ti[:, None], tj[:, None]))
+    osgd.train_sequential(Po, Qo, bo, tu, ti, tj, **hp)
+    err = max(np.abs(Po - model._user_factors).max(), np.abs(Qo - model._item_factors).max(),
+              np.abs(bo - model._item_bias).max())
+    print("bprmf_sgd_trace: max |oracle - reference| after", NT, "updates =", err)
+    assert err < 1e-12
+    np.savez_compressed(os.path.join(OUT, "bprmf_sgd_trace.npz"), P0=P0, Q0=Q0, b0=b0, u=tu.astype(np.int32),
+                        i=ti.astype(np.int32), j=tj.astype(np.int32), P1=model._user_factors,
+                        Q1=model._item_factors, b1=model._item_bias, **{k: np.float64(v) for k, v in hp.items()})
+
+    # ---- 3. get_user_predictions ----------------------------------------------------------------
+    mask = np.ones((U, I), dtype=bool)
+    for u in range(U):
+        mask[u, indices[indptr[u]:indptr[u + 1]]] = False     # allunrated_mask, dataset.py:245
+    users = np.arange(0, U, 7)
+    k = 10
+    tidx = np.empty((len(users), k), np.int32)
+    tval = np.empty((len(users), k), np.float64)
+    for r, u in enumerate(users):
+        rec = model.get_user_predictions(int(u), mask, k)
+        tidx[r] = [x[0] for x in rec]
+        tval[r] = [x[1] for x in rec]
+        oi, ov = osgd.get_user_predictions(model._user_factors, model._item_factors, model._item_bias, int(u),
+                                           mask[u], k)
+        assert np.array_equal(oi, tidx[r]) and np.allclose(ov, tval[r], rtol=0, atol=1e-13)
+    np.savez_compressed(os.path.join(OUT, "bprmf_sgd_topk.npz"), users=users.astype(np.int32), k=k, idx=tidx,
+                        val=tval)
+    print("bprmf_sgd_topk.npz:", len(users), "users")
+
+    # ---- 4. evaluator metrics -------------------------------------------------------------------
+    try:
+        gen_metrics(U, I, indptr, indices)
+    except Exception as ex:  # the evaluation package is heavier; report but keep the other fixtures
+        print("metrics fixture skipped:", repr(ex))
+
+
+def gen_metrics(U, I, indptr, indices):
+    sys.path.insert(0, REF)
+    from elliot.evaluation.evaluator import Evaluator
+    import elliot.utils.logging as elog
+    import logging
+    rs = np.random.RandomState(7)
+    # held-out test items: 3 per user not in train, ratings 1..5
+    test = {}
+    for u in range(U):
+        row = set(indices[indptr[u]:indptr[u + 1]].tolist())
+        cand = np.array([x for x in range(I) if x not in row])
+        pick = rs.choice(cand, size=3, replace=False)
+        test[u] = {int(x): float(rs.randint(1, 6)) for x in pick}
+    k = 10
+    recs = {}
+    for u in range(U):
+        row = set(indices[indptr[u]:indptr[u + 1]].tolist())
+        cand = np.array([x for x in range(I) if x not in row])
+        top = rs.choice(cand, size=k, replace=False)
+        # make some hits
+        if u % 2 == 0:
+            top[rs.randint(0, k)] = list(test[u].keys())[0]
+        top = list(dict.fromkeys(int(x) for x in top))
+        while len(top) < k:
+            c = int(rs.choice(cand))
+            if c not in top:
+                top.append(c)
+        recs[u] = [(it, float(k - r)) for r, it in enumerate(top)]
+    cfg = SimpleNamespace(top_k=k, evaluation=SimpleNamespace(cutoffs=[k, 5], simple_metrics=["nDCG", "Precision", "Recall", "HR", "MAP", "MRR"],
+                                                            relevance_threshold=0, paired_ttest=False, wilcoxon_test=False,
+                                                            complex_metrics=[]),
+                          config_test=True)
+    data = SimpleNamespace(config=cfg, test_dict=test, train_dict={u: {int(i): 1.0 for i in indices[indptr[u]:indptr[u + 1]]} for u in range(U)},
+                           users=list(range(U)), items=list(range(I)), num_items=I, num_users=U,
+                           private_users={p: p for p in range(U)}, public_users={p: p for p in range(U)},
+                           private_items={p: p for p in range(I)}, public_items={p: p for p in range(I)})
+    # Evaluator looks up a logger by class name
+    try:
+        elog.init(os.path.join(REF, "elliot", "config", "logger_config.yml"), "/tmp/elliot_log")
+    except Exception:
+        pass
+    params = SimpleNamespace(meta=SimpleNamespace())
+    ev = Evaluator(data, params)
+    res = ev.eval((recs, recs))
+    out = {}
+    for cutoff, d in res.items():
+        for name, val in d["test_results"].items():
+            out[f"{name}@{cutoff}"] = float(val)
+    print("reference metrics:", out)
+    tu = np.repeat(np.arange(U), 3)
+    ti = np.array([it for u in range(U) for it in test[u].keys()], np.int32)
+    tr = np.array([r for u in range(U) for r in test[u].values()], np.float64)
+    ridx = np.array([[it for it, _ in recs[u]] for u in range(U)], np.int32)
+    np.savez_compressed(os.path.join(OUT, "metrics_ref.npz"), test_indptr=np.arange(0, 3 * U + 1, 3, dtype=np.int64),
+                        test_items=ti, test_ratings=tr, recs=ridx, k=k,
+                        names=np.array(list(out.keys())), values=np.array(list(out.values())))
+
+
+if __name__ == "__main__":
+    main()

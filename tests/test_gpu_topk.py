@@ -1,0 +1,190 @@
+"""GPU parity: fused scoring + masked top-k (el_score_topk / el_topk_merge / el_dense_topk / f64)
+against the C oracle on the same seeded inputs.  Bit-exact: index lists AND score bits."""
+import numpy as np
+import pytest
+import torch
+
+from elliot_amd import ops
+from oracle import cref
+from tests.gpu_util import assert_topk_equal, cpu, random_excl
+
+pytestmark = pytest.mark.gpu
+
+
+def make(rs, U, I, F, bias=True, ties=True, scale=1.0):
+    Gu = (rs.normal(size=(U, F)) * scale).astype(np.float32)
+    Gi = (rs.normal(size=(I, F)) * scale).astype(np.float32)
+    Bi = rs.normal(size=I).astype(np.float32) if bias else None
+    if ties and I > 60:
+        for dst, src in ((50, 20), (51, 20), (I - 1, 3)):   # exact duplicate items -> exact score ties
+            Gi[dst] = Gi[src]
+            if Bi is not None:
+                Bi[dst] = Bi[src]
+    return Gu, Gi, Bi
+
+
+def run_gpu(ctx, Gu, Gi, Bi, u0, u1, k, excl=None, cand=None, item_offset=0, algo="auto"):
+    d = ctx.device
+    tGu = torch.from_numpy(Gu).to(d)
+    tGi = torch.from_numpy(Gi).to(d)
+    tBi = None if Bi is None else torch.from_numpy(Bi).to(d)
+    n_items_global = Gi.shape[0] + item_offset
+    e = None if excl is None else ops.DeviceCSR(excl[0], excl[1], n_items_global, d)
+    c = None if cand is None else ops.DeviceCSR(cand[0], cand[1], n_items_global, d)
+    idx, val = ops.score_topk(ctx, tGu, tGi, tBi, u0, u1, k, excl=e, cand=c, item_offset=item_offset, algo=algo)
+    torch.cuda.synchronize()
+    return cpu(idx), cpu(val)
+
+
+@pytest.mark.parametrize("algo", ["simple", "mfma"])
+@pytest.mark.parametrize("F,k", [(64, 10), (128, 10), (10, 10), (128, 1), (32, 14), (200, 10), (256, 10), (64, 32), (128, 40), (12, 5)])
+def test_topk_matches_oracle_bitexact(ctx, algo, F, k):
+    rs = np.random.RandomState(100 + F + k)
+    U, I = 300, 1000 + F        # ragged last user block (300 = 2*128 + 44) and ragged last item tile
+    Gu, Gi, Bi = make(rs, U, I, F)
+    excl = random_excl(rs, U, I, 0, 30)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo=algo)
+    assert_topk_equal(f"topk_{algo}_F{F}_k{k}", gi, gv, ei, ev)
+
+
+@pytest.mark.parametrize("algo", ["simple", "mfma"])
+def test_topk_no_bias_no_mask_and_user_subrange(ctx, algo):
+    rs = np.random.RandomState(7)
+    U, I, F, k = 500, 777, 64, 10
+    Gu, Gi, _ = make(rs, U, I, F, bias=False)
+    ei, ev = cref.score_topk_f32(Gu, Gi, None, 130, 401, k)
+    gi, gv = run_gpu(ctx, Gu, Gi, None, 130, 401, k, algo=algo)
+    assert_topk_equal(f"topk_{algo}_nobias_subrange", gi, gv, ei, ev)
+
+
+@pytest.mark.parametrize("algo", ["simple", "mfma"])
+def test_topk_large_k_needs_wave_kernel_or_errors(ctx, algo):
+    rs = np.random.RandomState(8)
+    U, I, F, k = 70, 900, 48, 100
+    Gu, Gi, Bi = make(rs, U, I, F)
+    excl = random_excl(rs, U, I, 0, 20)
+    if algo == "mfma":
+        with pytest.raises(Exception):
+            run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="mfma")
+        return
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="auto")
+    assert_topk_equal("topk_k100", gi, gv, ei, ev)
+
+
+@pytest.mark.parametrize("algo", ["simple", "mfma"])
+def test_topk_heavy_exclusions_trained_like(ctx, algo):
+    """Excluded (train) items get the HIGHEST scores, as after training: they must never surface."""
+    rs = np.random.RandomState(9)
+    U, I, F, k = 260, 2000, 64, 10
+    Gu, Gi, Bi = make(rs, U, I, F, ties=False)
+    excl = random_excl(rs, U, I, 20, 120)
+    ip, ix = excl
+    for u in range(U):                       # make each user's train items score very high
+        cols = ix[ip[u]:ip[u + 1]]
+        Gi[cols[:3]] += 0.5 * Gu[u]
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo=algo)
+    assert_topk_equal(f"topk_{algo}_heavy_excl", gi, gv, ei, ev)
+    for u in range(U):
+        assert not set(gi[u]) & set(ix[ip[u]:ip[u + 1]])
+
+
+@pytest.mark.parametrize("algo", ["simple", "mfma"])
+def test_topk_fewer_than_k_candidates_pads_with_neg_inf(ctx, algo):
+    rs = np.random.RandomState(10)
+    U, I, F, k = 40, 64, 16, 10
+    Gu, Gi, Bi = make(rs, U, I, F, ties=False)
+    rows = [np.sort(rs.choice(I, I - rs.randint(0, 6), replace=False)) for _ in range(U)]  # 0..5 unmasked
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = np.concatenate(rows).astype(np.int32)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=(indptr, indices))
+    assert np.isneginf(ev).any()
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=(indptr, indices), algo=algo)
+    assert_topk_equal(f"topk_{algo}_pad", gi, gv, ei, ev)
+
+
+def test_topk_candidate_protocol(ctx):
+    """negative-sampling protocol: mask = candidate rows (recommender_utils_mixin.py:102-107)."""
+    rs = np.random.RandomState(11)
+    U, I, F = 90, 700, 64
+    Gu, Gi, Bi = make(rs, U, I, F)
+    cand = random_excl(rs, U, I, 5, 120)
+    for k in (10, 50):
+        ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, cand=cand)
+        gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, cand=cand)
+        assert_topk_equal(f"topk_cand_k{k}", gi, gv, ei, ev)
+
+
+@pytest.mark.parametrize("algo", ["simple", "mfma"])
+def test_item_shards_merge_equals_single_shard(ctx, algo):
+    rs = np.random.RandomState(12)
+    U, I, F, k = 200, 1500, 64, 10
+    Gu, Gi, Bi = make(rs, U, I, F)
+    excl = random_excl(rs, U, I, 0, 40)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    bounds = [0, 400, 401, 1100, 1500]
+    pi, pv = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        gi, gv = run_gpu(ctx, Gu, np.ascontiguousarray(Gi[lo:hi]), np.ascontiguousarray(Bi[lo:hi]), 0, U, k,
+                         excl=excl, item_offset=lo, algo=algo)
+        oi, ov = cref.score_topk_f32(Gu, Gi[lo:hi], Bi[lo:hi], 0, U, k, excl=excl, item_offset=lo)
+        assert_topk_equal(f"topk_{algo}_shard_{lo}", gi, gv, oi, ov)
+        pi.append(gi)
+        pv.append(gv)
+    d = ctx.device
+    mi, mv = ops.topk_merge(ctx, torch.from_numpy(np.stack(pi)).to(d), torch.from_numpy(np.stack(pv)).to(d))
+    torch.cuda.synchronize()
+    assert_topk_equal(f"topk_{algo}_merged", cpu(mi), cpu(mv), ei, ev)
+
+
+def test_empty_user_range_and_arg_errors(ctx):
+    rs = np.random.RandomState(13)
+    Gu, Gi, Bi = make(rs, 10, 100, 8)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 5, 5, 3)
+    assert gi.shape == (0, 3)
+    with pytest.raises(Exception):
+        run_gpu(ctx, Gu, Gi, Bi, 0, 10, 0)
+
+
+def test_dense_topk(ctx):
+    rs = np.random.RandomState(14)
+    U, I, k = 150, 1234, 20
+    preds = rs.normal(size=(U, I)).astype(np.float32)
+    preds[:, 10] = preds[:, 5]
+    excl = random_excl(rs, U + 7, I, 0, 50)
+    ei, ev = cref.topk_rows_f32(preds, 7, k, excl=excl)      # rows are users 7..7+U
+    d = ctx.device
+    e = ops.DeviceCSR(excl[0], excl[1], I, d)
+    gi, gv = ops.dense_topk(ctx, torch.from_numpy(preds).to(d), 7, 7 + U, k, excl=e)
+    torch.cuda.synchronize()
+    assert_topk_equal("dense_topk", cpu(gi), cpu(gv), ei, ev)
+
+
+def test_topk_f64_matches_oracle_and_reference_fixture(ctx, golden):
+    t, s, kf = golden("bprmf_sgd_trace.npz"), golden("sampler_ref.npz"), golden("bprmf_sgd_topk.npz")
+    d = ctx.device
+    P, Q, b = (torch.from_numpy(t[n]).to(d) for n in ("P1", "Q1", "b1"))
+    U, I = P.shape[0], Q.shape[0]
+    excl = ops.DeviceCSR(s["indptr"], s["indices"], I, d)
+    k = int(kf["k"])
+    gi, gv = ops.score_topk_f64(ctx, P, Q, b, 0, U, k, excl=excl)
+    torch.cuda.synchronize()
+    ei, ev = cref.score_topk_f64(t["P1"], t["Q1"], t["b1"], 0, U, k, excl=(s["indptr"], s["indices"]))
+    assert_topk_equal("topk_f64", cpu(gi), cpu(gv), ei, ev)
+    # and the reference's own MFModel.get_user_predictions outputs (BPRMF_model.py:70-85)
+    for r, u in enumerate(kf["users"]):
+        assert np.array_equal(cpu(gi)[u], kf["idx"][r])
+        assert np.allclose(cpu(gv)[u], kf["val"][r], rtol=0, atol=1e-12)
+
+
+def test_scores_within_fp32_roundoff_of_fp64_matmul(ctx):
+    """The pinned fma chain vs the mathematically exact score: |err| <= ~1e-6 * sum|a*b| (MFMA f32)."""
+    rs = np.random.RandomState(15)
+    U, I, F, k = 128, 512, 128, 10
+    Gu, Gi, Bi = make(rs, U, I, F, ties=False)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, algo="mfma")
+    ref = Bi.astype(np.float64) + Gu.astype(np.float64) @ Gi.astype(np.float64).T
+    exact = np.take_along_axis(ref, gi.astype(np.int64), axis=1)
+    assert np.abs(gv - exact).max() < 5e-5
