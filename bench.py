@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--topk-block", type=int, default=131072)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--opt", default="adam_tf_dense", choices=["adam_tf_dense", "adam_lazy", "sgd"])
+    ap.add_argument("--train-algo", default="auto", choices=["auto", "atomic", "sorted"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-topk-users", type=int, default=192)
     return ap.parse_args()
@@ -141,7 +142,7 @@ def main():
     def train_step():
         ops.bpr_sample(ctx, pos, B, seed=42 + rank, first_sample=sample_ctr[0], out=trip)
         sample_ctr[0] += B
-        st.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b)
+        st.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b, algo=args.train_algo)
 
     Ub = min(args.topk_block, U)
     n_blocks = max(1, U // Ub)
@@ -199,6 +200,9 @@ def main():
         "k_adam_dense_Gu": 24.0 * U * F,                      # theta, m, v read + write
         "k_adam_dense_Gi": 24.0 * (hi - lo) * F,
         "k_bprmf_fwd_bwd": B * (24.0 * F + 28.0),             # 3 rows read + 3 gradient rows written (+ idx, bias)
+        "k_bpr_user_seg": B * (16.0 * F + 28.0),              # gamma_u, gamma_i, gamma_j read + dGu row written
+        "k_bpr_item_seg": 2.0 * B * (8.0 * F + 12.0),         # gamma_u(b) read + dGi row written, per occurrence
+        "rocprim_radix_sort_pairs": 3.0 * B * 16.0,
         "k_rows_apply": B * (72.0 * F + 60.0) - B * (24.0 * F + 28.0) if args.opt == "adam_lazy" else B * (24.0 * F),
         "k_bpr_sample": B * 48.0,
     }

@@ -15,6 +15,9 @@ EL_OPT_SGD = 3
 EL_TOPK_AUTO = 0
 EL_TOPK_MFMA = 1
 EL_TOPK_SIMPLE = 2
+EL_BPR_AUTO = 0
+EL_BPR_ATOMIC = 1
+EL_BPR_SORTED = 2
 
 _f32p = C.c_void_p
 _i32p = C.c_void_p
@@ -53,7 +56,9 @@ PROTOTYPES = {
     "el_bpr_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "el_bprmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
-                                      C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_float, _f64p]),
+                                      C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_float, _f64p,
+                                      C.c_int, C.c_void_p, C.c_size_t]),
+    "el_bprmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "el_bprsgd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,
                                   C.c_int64, C.c_int64]),
     "el_bprsgd_apply_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_sgd_dense(float* __restrict__ th, float
     }
 }
 
-static int pick_lpt(int F, int vw, int* cpl) {
+int el_pick_lpt(int F, int vw, int* cpl) {
     int groups = (F + vw - 1) / vw;  // vector chunks per row
     int lpt = 8;
     while (lpt < groups && lpt < 64) lpt <<= 1;
@@ -373,7 +373,7 @@ template <int VW>
 static int launch_fwd_bwd(const el_bprmf_state& st, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                           float l_w, float l_b, int32_t step, double* loss_out, hipStream_t s) {
     int cpl = 1;
-    int lpt = pick_lpt(st.F, VW, &cpl);
+    int lpt = el_pick_lpt(st.F, VW, &cpl);
     EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build (max %d)", st.F, 64 * 4 * VW);
     int64_t threads = B * lpt;
     unsigned grid = (unsigned)((threads + 255) / 256);
@@ -391,7 +391,7 @@ template <int VW, bool ADAM>
 static int launch_rows_apply(const el_bprmf_state& st, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                              int32_t step, float lr, float lr_t, hipStream_t s) {
     int cpl = 1;
-    int lpt = pick_lpt(st.F, VW, &cpl);
+    int lpt = el_pick_lpt(st.F, VW, &cpl);
     EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build", st.F);
     int64_t threads = B * 3 * lpt;
     unsigned grid = (unsigned)((threads + 255) / 256);
@@ -414,12 +414,11 @@ static unsigned stream_grid(el_ctx* ctx, int64_t n_threads) {
     return (unsigned)blocks;
 }
 
-extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
-                                   const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w, float l_b,
-                                   int opt, int32_t step, float lr_t, double* loss_out) {
-    if (int rc = el_bind(ctx)) return rc;
+// shared argument validation of both train-step paths
+int el_bprmf_check_state(const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j,
+                         double* loss_out, int opt, int32_t step, bool* vec, bool* rows_mode) {
     EL_REQUIRE(stp != nullptr, "el_bprmf_train_step: null state");
-    const el_bprmf_state st = *stp;
+    const el_bprmf_state& st = *stp;
     EL_REQUIRE(st.Gu && st.Gi && st.Bi && st.gGu && st.gGi && st.gBi, "el_bprmf_train_step: null table/accumulator");
     EL_REQUIRE(st.F >= 1 && st.U >= 1 && st.I >= 1, "el_bprmf_train_step: bad shape");
     EL_REQUIRE(u && i && j && loss_out, "el_bprmf_train_step: null batch/loss pointer");
@@ -427,19 +426,24 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
     const bool adam = (opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_ADAM_LAZY);
     EL_REQUIRE(adam || opt == EL_OPT_SGD, "el_bprmf_train_step: unknown optimiser %d", opt);
     if (adam) EL_REQUIRE(st.mGu && st.vGu && st.mGi && st.vGi && st.mBi && st.vBi, "el_bprmf_train_step: Adam slots missing");
+    *rows_mode = (opt == EL_OPT_ADAM_LAZY) || (opt == EL_OPT_SGD && st.tGu != nullptr);
+    if (*rows_mode) EL_REQUIRE(st.tGu && st.tGi && st.tBi, "el_bprmf_train_step: stamp arrays missing");
+    *vec = rows_aligned16(st.Gu, st.F) && rows_aligned16(st.Gi, st.F) && rows_aligned16(st.gGu, st.F) &&
+           rows_aligned16(st.gGi, st.F) &&
+           (!adam || (rows_aligned16(st.mGu, st.F) && rows_aligned16(st.vGu, st.F) &&
+                      rows_aligned16(st.mGi, st.F) && rows_aligned16(st.vGi, st.F)));
+    return 0;
+}
+
+// optimiser phase shared by both gradient paths (gradients are in gGu/gGi/gBi, stamps set in rows mode)
+int el_bprmf_apply_optimizer(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, const int32_t* u, const int32_t* i,
+                             const int32_t* j, int64_t B, float lr, int opt, int32_t step, float lr_t) {
+    const bool adam = (opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_ADAM_LAZY);
     const bool rows_mode = (opt == EL_OPT_ADAM_LAZY) || (opt == EL_OPT_SGD && st.tGu != nullptr);
-    if (rows_mode) EL_REQUIRE(st.tGu && st.tGi && st.tBi, "el_bprmf_train_step: stamp arrays missing");
-    if (B <= 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
     const bool vec = rows_aligned16(st.Gu, st.F) && rows_aligned16(st.Gi, st.F) && rows_aligned16(st.gGu, st.F) &&
                      rows_aligned16(st.gGi, st.F) &&
                      (!adam || (rows_aligned16(st.mGu, st.F) && rows_aligned16(st.vGu, st.F) &&
                                 rows_aligned16(st.mGi, st.F) && rows_aligned16(st.vGi, st.F)));
-    el_bprmf_state fst = st;
-    if (!rows_mode) fst.tGu = fst.tGi = fst.tBi = nullptr;
-    int rc = vec ? launch_fwd_bwd<4>(fst, u, i, j, B, l_w, l_b, step, loss_out, s)
-                 : launch_fwd_bwd<1>(fst, u, i, j, B, l_w, l_b, step, loss_out, s);
-    if (rc) return rc;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     if (opt == EL_OPT_ADAM_TF_DENSE) {
         const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
@@ -456,13 +460,41 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
         return vec ? launch_rows_apply<4, false>(st, u, i, j, B, step, lr, lr_t, s)
                    : launch_rows_apply<1, false>(st, u, i, j, B, step, lr, lr_t, s);
     }
-    // dense SGD
     const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
     EL_LAUNCH("k_sgd_dense", k_sgd_dense, dim3(stream_grid(ctx, nu)), dim3(256), 0, s, st.Gu, st.gGu, nu, lr);
     EL_LAUNCH("k_sgd_dense", k_sgd_dense, dim3(stream_grid(ctx, ni)), dim3(256), 0, s, st.Gi, st.gGi, ni, lr);
     EL_LAUNCH("k_sgd_dense", k_sgd_dense, dim3(stream_grid(ctx, st.I)), dim3(256), 0, s, st.Bi, st.gBi, st.I, lr);
     EL_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+                                          const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w,
+                                          float l_b, int opt, int32_t step, float lr_t, double* loss_out, void* ws,
+                                          size_t ws_bytes);
+extern "C" size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I);
+
+extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+                                   const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w, float l_b,
+                                   int opt, int32_t step, float lr_t, double* loss_out, int algo, void* ws,
+                                   size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    bool vec = false, rows_mode = false;
+    if (int rc = el_bprmf_check_state(stp, u, i, j, loss_out, opt, step, &vec, &rows_mode)) return rc;
+    EL_REQUIRE(algo == EL_BPR_AUTO || algo == EL_BPR_ATOMIC || algo == EL_BPR_SORTED, "el_bprmf_train_step: bad algo %d", algo);
+    if (B <= 0) return 0;
+    const el_bprmf_state st = *stp;
+    bool sorted = (algo == EL_BPR_SORTED);
+    if (algo == EL_BPR_AUTO) sorted = (B >= 2048) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I);
+    if (sorted)
+        return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, lr, l_w, l_b, opt, step, lr_t, loss_out, ws, ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    el_bprmf_state fst = st;
+    if (!rows_mode) fst.tGu = fst.tGi = fst.tBi = nullptr;
+    int rc = vec ? launch_fwd_bwd<4>(fst, u, i, j, B, l_w, l_b, step, loss_out, s)
+                 : launch_fwd_bwd<1>(fst, u, i, j, B, l_w, l_b, step, loss_out, s);
+    if (rc) return rc;
+    return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -561,7 +593,7 @@ static int launch_bprsgd(const el_bprsgd_state& st, const int32_t* u, const int3
     const bool vec = (st.F % 2 == 0) && (((uintptr_t)st.P) % 16 == 0) && (((uintptr_t)st.Q) % 16 == 0);
     const int vw = vec ? 2 : 1;
     int cpl = 1;
-    int lpt = pick_lpt(st.F, vw, &cpl);
+    int lpt = el_pick_lpt(st.F, vw, &cpl);
     EL_REQUIRE(cpl <= 4, "el_bprsgd_apply: F=%d too large for this build", st.F);
     int64_t threads = n * lpt;
     unsigned grid = (unsigned)((threads + 255) / 256);

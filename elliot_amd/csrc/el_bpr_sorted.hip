@@ -1,0 +1,404 @@
+// BPRMF_batch train step, sort-based gradient reduction (no floating-point atomics on hot rows).
+//
+// Replaces BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80).  TensorFlow hands the
+// optimiser IndexedSlices whose duplicate rows are segment-summed; here the batch is sorted by
+// row once and every row's gradient is reduced in registers by the lane group that walks its
+// segment:
+//   1. k_bpr_prep          keys/payloads: (u_b, b) and (item, b | neg<<31) for i_b and j_b
+//   2. rocprim radix sort  (stable -> segments keep batch order -> the sums are deterministic)
+//   3. k_bpr_user_seg      per user segment: gather gamma_i, gamma_j of every occurrence, x_ui - x_uj,
+//                          s_b = dloss/dd, batch loss, dGu row = sum s_b (gamma_i - gamma_j) + cnt l_w gamma_u
+//   4. k_bpr_item_seg      per item segment: dGi row = sum +-s_b gamma_u(b) + cnt l_w gamma_item, dBi
+//   5. optimiser           k_adam_dense (TF semantics) / k_rows_apply (el_bpr.hip)
+// Segments longer than a chunk (popular items under Zipf: tens of thousands of occurrences) are
+// split over several lane groups whose partial rows are combined with a few atomics; segments that
+// live inside one chunk are written with plain stores.
+#include "el_common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+template <int VW>
+__device__ __forceinline__ void ldv(const float* p, float* dst) {
+    if (VW == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        dst[0] = t.x;
+        dst[1] = t.y;
+        dst[2] = t.z;
+        dst[3] = t.w;
+    } else {
+        dst[0] = p[0];
+    }
+}
+template <int VW>
+__device__ __forceinline__ void stv(float* p, const float* src) {
+    if (VW == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(src[0], src[1], src[2], src[3]);
+    } else {
+        p[0] = src[0];
+    }
+}
+
+__device__ __forceinline__ float el_softplus_s(float x) {
+    if (x > 15.0f) return x;
+    if (x < -15.0f) return expf(x);
+    return log1pf(expf(x));
+}
+
+__global__ __launch_bounds__(256) void k_bpr_prep(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
+                                                  const int32_t* __restrict__ j, int64_t B, u32* keyU, u32* valU,
+                                                  u32* keyI, u32* valI) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    keyU[t] = (u32)u[t];
+    valU[t] = (u32)t;
+    keyI[t] = (u32)i[t];
+    valI[t] = (u32)t;
+    keyI[B + t] = (u32)j[t];
+    valI[B + t] = (u32)t | 0x80000000u;
+}
+
+struct SegParams {
+    el_bprmf_state st;
+    const int32_t* bi;   // item of positive per triplet
+    const int32_t* bj;   // negative
+    const int32_t* bu;   // user
+    const u32* keys;     // sorted row ids
+    const u32* vals;     // sorted payloads
+    float* s;            // [B] dloss/dd per triplet
+    int64_t n;           // number of sorted entries (B or 2B)
+    int chunk;           // positions per lane group
+    int lpt;
+    float l_w, l_b;
+    int32_t step;
+    double* loss_out;
+};
+
+// ---- user segments -----------------------------------------------------------------------
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
+    const int F = p.st.F, lpt = p.lpt;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const int64_t p0 = grp * p.chunk;
+    const int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
+    float myloss = 0.f;
+    if (p0 < p.n) {
+        int64_t cur = -1;
+        bool started_inside = false;
+        float gu[CPL][VW], acc[CPL][VW];
+        float nu = 0.f;
+        int cnt = 0;
+        auto flush = [&](bool ends_inside) {
+            float* g = p.st.gGu + cur * F;
+            const float w = (float)cnt * p.l_w;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+                if (e < F) {
+                    float v[VW];
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) v[x] = acc[q][x] + w * gu[q][x];
+                    if (started_inside && ends_inside) {
+                        stv<VW>(g + e, v);
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) atomicAdd(g + e + x, v[x]);
+                    }
+                }
+            }
+            if (sub == 0 && p.st.tGu) p.st.tGu[cur] = p.step;
+        };
+        for (int64_t pos = p0; pos < p1; ++pos) {
+            const int64_t key = (int64_t)p.keys[pos];
+            const int64_t b = (int64_t)p.vals[pos];
+            if (key != cur) {
+                if (cur >= 0) flush(true);
+                cur = key;
+                started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                cnt = 0;
+                nu = 0.f;
+                const float* pu = p.st.Gu + key * F;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) gu[q][x] = acc[q][x] = 0.f;
+                    if (e < F) ldv<VW>(pu + e, gu[q]);
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) nu += gu[q][x] * gu[q][x];
+                }
+                nu = el_group_sum(nu, lpt);
+            }
+            const int32_t ii = p.bi[b], jj = p.bj[b];
+            const float* pi = p.st.Gi + (int64_t)ii * F;
+            const float* pj = p.st.Gi + (int64_t)jj * F;
+            float gi[CPL][VW], gj[CPL][VW];
+            float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                for (int x = 0; x < VW; ++x) gi[q][x] = gj[q][x] = 0.f;
+                if (e < F) {
+                    ldv<VW>(pi + e, gi[q]);
+                    ldv<VW>(pj + e, gj[q]);
+                }
+#pragma unroll
+                for (int x = 0; x < VW; ++x) {
+                    dpi += gu[q][x] * gi[q][x];
+                    dpj += gu[q][x] * gj[q][x];
+                    ni += gi[q][x] * gi[q][x];
+                    nj += gj[q][x] * gj[q][x];
+                }
+            }
+            dpi = el_group_sum(dpi, lpt);
+            dpj = el_group_sum(dpj, lpt);
+            ni = el_group_sum(ni, lpt);
+            nj = el_group_sum(nj, lpt);
+            const float beta_i = p.st.Bi[ii], beta_j = p.st.Bi[jj];
+            const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
+            const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+            float sb = 0.f;
+            if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+            if (sub == 0) {
+                p.s[b] = sb;
+                myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
+                          (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int x = 0; x < VW; ++x) acc[q][x] += sb * (gi[q][x] - gj[q][x]);
+            cnt++;
+        }
+        flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
+    }
+    __shared__ float wsum[4];
+    float wl = el_group_sum(myloss, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+        if (tot != 0.0) atomicAdd(p.loss_out, tot);
+    }
+}
+
+// ---- item segments -----------------------------------------------------------------------
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
+    const int F = p.st.F, lpt = p.lpt;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const int64_t p0 = grp * p.chunk;
+    if (p0 >= p.n) return;
+    const int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
+    int64_t cur = -1;
+    bool started_inside = false;
+    float acc[CPL][VW];
+    float bacc = 0.f;
+    int cpos = 0, cneg = 0;
+    auto flush = [&](bool ends_inside) {
+        const float* pr = p.st.Gi + cur * F;
+        float* g = p.st.gGi + cur * F;
+        const float w = (float)(cpos + cneg) * p.l_w;
+        const bool plain = started_inside && ends_inside;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) {
+                float r[VW], v[VW];
+                ldv<VW>(pr + e, r);
+#pragma unroll
+                for (int x = 0; x < VW; ++x) v[x] = acc[q][x] + w * r[x];
+                if (plain) {
+                    stv<VW>(g + e, v);
+                } else {
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) atomicAdd(g + e + x, v[x]);
+                }
+            }
+        }
+        if (sub == 0) {
+            const float beta = p.st.Bi[cur];
+            const float gb = bacc + p.l_b * (float)cpos * beta + (p.l_b / 10.0f) * (float)cneg * beta;
+            if (plain)
+                p.st.gBi[cur] = gb;
+            else
+                atomicAdd(p.st.gBi + cur, gb);
+            if (p.st.tGi) {
+                p.st.tGi[cur] = p.step;
+                p.st.tBi[cur] = p.step;
+            }
+        }
+    };
+    for (int64_t pos = p0; pos < p1; ++pos) {
+        const int64_t key = (int64_t)p.keys[pos];
+        const u32 pay = p.vals[pos];
+        if (key != cur) {
+            if (cur >= 0) flush(true);
+            cur = key;
+            started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+            cpos = cneg = 0;
+            bacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+        }
+        const int64_t b = (int64_t)(pay & 0x7fffffffu);
+        const bool neg = (pay >> 31) != 0u;
+        const float sb = p.s[b];
+        const float coef = neg ? -sb : sb;
+        const float* pu = p.st.Gu + (int64_t)p.bu[b] * F;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) {
+                float r[VW];
+                ldv<VW>(pu + e, r);
+#pragma unroll
+                for (int x = 0; x < VW; ++x) acc[q][x] += coef * r[x];
+            }
+        }
+        bacc += coef;
+        if (neg)
+            cneg++;
+        else
+            cpos++;
+    }
+    flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
+}
+
+// ---- host ---------------------------------------------------------------------------------
+static int bits_for(int64_t n) {
+    int b = 1;
+    while ((1LL << b) < n && b < 32) ++b;
+    return b;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct SortedWs {
+    u32 *keyU_in, *valU_in, *keyU, *valU, *keyI_in, *valI_in, *keyI, *valI;
+    float* s;
+    void* tmp;
+    size_t tmp_bytes;
+    size_t total;
+};
+
+static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    w->keyU_in = (u32*)take((size_t)B * 4);
+    w->valU_in = (u32*)take((size_t)B * 4);
+    w->keyU = (u32*)take((size_t)B * 4);
+    w->valU = (u32*)take((size_t)B * 4);
+    w->keyI_in = (u32*)take((size_t)B * 8);
+    w->valI_in = (u32*)take((size_t)B * 8);
+    w->keyI = (u32*)take((size_t)B * 8);
+    w->valI = (u32*)take((size_t)B * 8);
+    w->s = (float*)take((size_t)B * 4);
+    size_t t1 = 0, t2 = 0;
+    u32* np = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, t1, np, np, np, np, (unsigned)B, 0, bits_for(U), (hipStream_t)0) != hipSuccess) return 1;
+    if (rocprim::radix_sort_pairs(nullptr, t2, np, np, np, np, (unsigned)(2 * B), 0, bits_for(I), (hipStream_t)0) != hipSuccess) return 1;
+    w->tmp_bytes = t1 > t2 ? t1 : t2;
+    w->tmp = take(w->tmp_bytes);
+    w->total = off;
+    return 0;
+}
+
+extern "C" size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I) {
+    if (B <= 0) return 0;
+    SortedWs w;
+    if (carve_ws(B, U, I, nullptr, &w)) return 0;
+    return w.total;
+}
+
+// defined in el_bpr.hip
+int el_bprmf_apply_optimizer(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, const int32_t* u, const int32_t* i,
+                             const int32_t* j, int64_t B, float lr, int opt, int32_t step, float lr_t);
+int el_bprmf_check_state(const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j,
+                         double* loss_out, int opt, int32_t step, bool* vec, bool* rows_mode);
+int el_pick_lpt(int F, int vw, int* cpl);
+
+template <int VW>
+static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w) {
+    int cpl = 1;
+    const int lpt = el_pick_lpt(base.st.F, VW, &cpl);
+    EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build", base.st.F);
+    SegParams pu = base;
+    pu.keys = w.keyU;
+    pu.vals = w.valU;
+    pu.n = B;
+    pu.chunk = 4;
+    pu.lpt = lpt;
+    SegParams pi = base;
+    pi.keys = w.keyI;
+    pi.vals = w.valI;
+    pi.n = 2 * B;
+    pi.chunk = 16;
+    pi.lpt = lpt;
+    const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
+    const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
+#define EL_SEG(CPL_)                                                                                      \
+    do {                                                                                                  \
+        EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), 0, s, pu);         \
+        EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_>), dim3(gridI), dim3(256), 0, s, pi);         \
+    } while (0)
+    if (cpl == 1) EL_SEG(1);
+    else if (cpl == 2) EL_SEG(2);
+    else EL_SEG(4);
+#undef EL_SEG
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+                                          const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w,
+                                          float l_b, int opt, int32_t step, float lr_t, double* loss_out, void* ws,
+                                          size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    bool vec = false, rows_mode = false;
+    if (int rc = el_bprmf_check_state(stp, u, i, j, loss_out, opt, step, &vec, &rows_mode)) return rc;
+    if (B <= 0) return 0;
+    EL_REQUIRE(B < (1LL << 30), "el_bprmf_train_step_sorted: batch too large");
+    const el_bprmf_state st = *stp;
+    SortedWs w;
+    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_bprmf_train_step_sorted: rocprim size query failed");
+    EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_train_step_sorted: workspace too small (%zu < %zu)",
+               ws_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in,
+              w.valU_in, w.keyI_in, w.valI_in);
+    {
+        ElKernelTimer t("rocprim_radix_sort_pairs", s);
+        size_t tb = w.tmp_bytes;
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)B, 0,
+                                               bits_for(st.U), s));
+        tb = w.tmp_bytes;
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)(2 * B), 0,
+                                               bits_for(st.I), s));
+    }
+    SegParams base;
+    memset(&base, 0, sizeof(base));
+    base.st = st;
+    if (!rows_mode) base.st.tGu = base.st.tGi = base.st.tBi = nullptr;
+    base.bi = i;
+    base.bj = j;
+    base.bu = u;
+    base.s = w.s;
+    base.l_w = l_w;
+    base.l_b = l_b;
+    base.step = step;
+    base.loss_out = loss_out;
+    int rc = vec ? launch_segs<4>(base, s, B, w) : launch_segs<1>(base, s, B, w);
+    if (rc) return rc;
+    return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
+}

@@ -610,7 +610,7 @@ static int check_topk_args(const char* fn, int64_t u_start, int64_t u_stop, int6
     EL_REQUIRE(I_local >= 0 && I_local < 0x7fffffffLL, "%s: I_local out of range", fn);
     EL_REQUIRE(F >= 1, "%s: F must be >= 1", fn);
     EL_REQUIRE(k >= 1 && k <= 4032, "%s: k=%d unsupported (1..4032)", fn, k);
-    EL_REQUIRE(out_idx && out_val, "%s: null output", fn);
+    EL_REQUIRE(u_stop == u_start || (out_idx && out_val), "%s: null output", fn);
     return 0;
 }
 

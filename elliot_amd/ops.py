@@ -17,6 +17,7 @@ from ._lib import (EL_OPT_ADAM_LAZY, EL_OPT_ADAM_TF_DENSE, EL_OPT_SGD, EL_TOPK_A
 OPTIMIZERS = {"adam": EL_OPT_ADAM_TF_DENSE, "adam_tf_dense": EL_OPT_ADAM_TF_DENSE,
               "adam_lazy": EL_OPT_ADAM_LAZY, "sgd": EL_OPT_SGD}
 TOPK_ALGOS = {"auto": EL_TOPK_AUTO, "mfma": EL_TOPK_MFMA, "simple": EL_TOPK_SIMPLE}
+BPR_ALGOS = {"auto": _lib.EL_BPR_AUTO, "atomic": _lib.EL_BPR_ATOMIC, "sorted": _lib.EL_BPR_SORTED}
 
 
 def _ptr(t, dtype=None, name="tensor"):
@@ -255,6 +256,7 @@ class BprmfDeviceState:
         self.tBi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.step = 0
+        self._ws = None
         self._c = BprmfState(
             Gu=self.Gu.data_ptr(), Gi=self.Gi.data_ptr(), Bi=self.Bi.data_ptr(),
             gGu=self.gGu.data_ptr(), gGi=self.gGi.data_ptr(), gBi=self.gBi.data_ptr(),
@@ -264,16 +266,24 @@ class BprmfDeviceState:
             tGu=self.tGu.data_ptr() if rows else None, tGi=self.tGi.data_ptr() if rows else None,
             tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F)
 
-    def train_step(self, u, i, j, lr, l_w, l_b):
+    def train_step(self, u, i, j, lr, l_w, l_b, algo="auto"):
         """BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80).  u,i,j: int32 device tensors.
         The batch loss is accumulated into self.loss (device double) -- no host sync here."""
         self.step += 1
         B = u.numel()
         lr_t = adam_lr_t(lr, self.step)
+        algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
+        ws, ws_bytes = None, 0
+        if algo == _lib.EL_BPR_SORTED or (algo == _lib.EL_BPR_AUTO and B >= 2048):
+            need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+            ws, ws_bytes = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
         check(self.ctx.lib.el_bprmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c),
                                                _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
                                                _ptr(j, torch.int32, "j"), int(B), float(lr), float(l_w), float(l_b),
-                                               self.opt, int(self.step), float(lr_t), _ptr(self.loss, torch.float64)),
+                                               self.opt, int(self.step), float(lr_t), _ptr(self.loss, torch.float64),
+                                               algo, ws, ws_bytes),
               "el_bprmf_train_step")
 
     def pop_loss(self):

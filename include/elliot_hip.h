@@ -96,6 +96,17 @@ typedef struct el_bprmf_state {
     int32_t F;
 } el_bprmf_state;
 
+/* How the duplicate-row gradient sum (OptimizerV2's segment-sum of IndexedSlices) is formed. */
+enum {
+    EL_BPR_AUTO = 0,    /* SORTED when B >= 2048 and a large-enough workspace is given        */
+    EL_BPR_ATOMIC = 1,  /* one kernel, float atomics into the dense accumulators              */
+    EL_BPR_SORTED = 2   /* radix-sort the batch by row, reduce each segment in registers
+                           (deterministic summation order; no atomics on hot rows)           */
+};
+
+/* Bytes of scratch el_bprmf_train_step needs for the SORTED path with batch size B. */
+size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I);
+
 /* Replaces: BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80): two gathers
  * (:49-51), x_ui/x_uj (:53), clip + softplus batch SUM (:65-66), L2 terms (:68-72),
  * tape.gradient + Adam.apply_gradients (:77-78; beta1 .9, beta2 .999, eps 1e-7).
@@ -106,7 +117,7 @@ typedef struct el_bprmf_state {
 int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                         const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                         float lr, float l_w, float l_b, int opt, int32_t step,
-                        float lr_t, double* loss_out);
+                        float lr_t, double* loss_out, int algo, void* ws, size_t ws_bytes);
 
 /* ---- BPR-MF, NumPy semantics (BPRMF; K5) ------------------------------------- */
 
