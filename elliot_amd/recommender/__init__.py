@@ -1,0 +1,7 @@
+"""Host-side mirror of Elliot's plugin surface for the latent-factor path."""
+from .base_recommender_model import BaseRecommenderModel, init_charger
+from .recommender_utils_mixin import RecMixin
+from .latent_factor_models.BPRMF_batch.BPRMF_batch import BPRMF_batch
+from .latent_factor_models.BPRMF.BPRMF import BPRMF
+
+__all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF"]

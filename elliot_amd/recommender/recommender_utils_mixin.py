@@ -1,0 +1,144 @@
+"""Plugin surface, part 2: RecMixin (train / evaluate / get_recommendations / bookkeeping).
+
+Same method names, signatures and return shapes as elliot/recommender/recommender_utils_mixin.py:9-136.
+The scoring half differs in HOW, not WHAT: instead of `predict` -> dense [Ub, I] block -> `get_top_k` with a
+dense bool mask slice (reference :63-88), `get_recommendations` asks the model for fused top-k lists
+(`self._model.recommend(mask_csr, k, start, stop)`) and converts the resulting [Ub, k] arrays to the
+reference's `{public_user: [(public_item, score), ...]}` dicts in one vectorised pass.
+"""
+import os
+
+import numpy as np
+from tqdm import tqdm
+
+from . import _compat
+
+
+class RecMixin(object):
+
+    def train(self):
+        if self._restore:
+            return self.restore_weights()
+        for it in self.iterate(self._epochs):
+            loss, steps = 0, 0
+            with tqdm(total=int(self._data.transactions // self._batch_size), disable=not self._verbose) as t:
+                for batch in self._sampler.step(self._data.transactions, self._batch_size):
+                    steps += 1
+                    loss += self._model.train_step(batch)
+                    t.update()
+            self.evaluate(it, float(loss) / (it + 1))
+
+    def evaluate(self, it=None, loss=0):
+        if (it is None) or (not (it + 1) % self._validation_rate):
+            recs = self.get_recommendations(self.evaluator.get_needed_recommendations())
+            result_dict = self.evaluator.eval(recs)
+            self._losses.append(loss)
+            self._results.append(result_dict)
+            if it is not None:
+                self.logger.info(f'Epoch {(it + 1)}/{self._epochs} loss {loss/(it + 1):.5f}')
+            else:
+                self.logger.info('Finished')
+            if self._save_recs:
+                self.logger.info(f"Writing recommendations at: {self._config.path_output_rec_result}")
+                fname = f"{self.name}_it={it + 1}.tsv" if it is not None else f"{self.name}.tsv"
+                _compat.store_recommendation(
+                    recs[1], os.path.abspath(os.sep.join([self._config.path_output_rec_result, fname])))
+            if (len(self._results) - 1) == self.get_best_arg():
+                if it is not None:
+                    self._params.best_iteration = it + 1
+                self.logger.info("******************************************")
+                self.best_metric_value = self._results[-1][self._validation_k]["val_results"][self._validation_metric]
+                if self._save_weights:
+                    if hasattr(self, "_model"):
+                        self._model.save_weights(self._saving_filepath)
+                    else:
+                        self.logger.warning("Saving weights FAILED. No model to save.")
+
+    # -- scoring -------------------------------------------------------------------------------------
+    def get_recommendations(self, k: int = 100):
+        predictions_top_k_test, predictions_top_k_val = {}, {}
+        block = self._recommendation_block()
+        for offset in range(0, self._num_users, block):
+            offset_stop = min(offset + block, self._num_users)
+            recs_val, recs_test = self.process_protocol(k, offset, offset_stop)
+            predictions_top_k_val.update(recs_val)
+            predictions_top_k_test.update(recs_test)
+        return predictions_top_k_val, predictions_top_k_test
+
+    def _recommendation_block(self):
+        """Users per scoring launch: >= the reference's `batch_size` blocks, large enough to fill 256 CUs."""
+        return max(int(self._batch_size) if self._batch_size and self._batch_size > 0 else 0, 65536)
+
+    def process_protocol(self, k, *args):
+        if not self._negative_sampling:
+            recs = self.get_single_recommendation(self.get_candidate_mask(), k, *args)
+            return recs, recs
+        val = self.get_single_recommendation(self.get_candidate_mask(validation=True), k, *args) \
+            if hasattr(self._data, "val_dict") else {}
+        return val, self.get_single_recommendation(self.get_candidate_mask(), k, *args)
+
+    def get_single_recommendation(self, mask, k, offset, offset_stop):
+        """`mask` is what get_candidate_mask() returned (a device CSR descriptor, see below)."""
+        idx, val = self._model.recommend(mask, k, offset, offset_stop)       # [Ub, k] device tensors
+        return self._arrays_to_recs(idx.cpu().numpy(), val.cpu().numpy(), offset, offset_stop)
+
+    def _arrays_to_recs(self, idx, val, offset, offset_stop):
+        """recommender_utils_mixin.py:86-88: private -> public ids, `{user: [(item, score), ...]}`."""
+        pub_items = self._public_item_array()
+        items = pub_items[idx]
+        pu = self._data.private_users
+        il, vl = items.tolist(), val.tolist()
+        return {pu[u]: list(zip(il[r], vl[r])) for r, u in enumerate(range(offset, offset_stop))}
+
+    def _public_item_array(self):
+        if getattr(self, "_pub_items_cache", None) is None:
+            pi = self._data.private_items
+            arr = np.array([pi[p] for p in range(self._num_items)], dtype=object)
+            try:
+                arr = arr.astype(np.int64)
+            except (TypeError, ValueError):
+                pass
+            self._pub_items_cache = arr
+        return self._pub_items_cache
+
+    def get_candidate_mask(self, validation=False):
+        """Reference: dense bool [U, I] (`allunrated_mask` / `val_mask` / `test_mask`, :102-109).  Here: a tagged
+        device CSR -- ("excl", train CSR) meaning `True where train == 0`, or ("cand", candidate CSR)."""
+        from .masks import device_masks
+        m = device_masks(self._data, self._model.ctx)
+        if self._negative_sampling:
+            return ("cand", m.val if validation else m.test)
+        return ("excl", m.train)
+
+    def restore_weights(self):
+        try:
+            self._model.load_weights(self._saving_filepath)
+            print("Model correctly Restored")
+            self.evaluate()
+            return True
+        except Exception as ex:
+            raise Exception(f"Error in model restoring operation! {ex}")
+
+    # -- bookkeeping (identical contracts to :111-136) ----------------------------------------------------
+    def get_loss(self):
+        if self._optimize_internal_loss:
+            return min(self._losses)
+        return -max(r[self._validation_k]["val_results"][self._validation_metric] for r in self._results)
+
+    def get_params(self):
+        return self._params.__dict__
+
+    def get_results(self):
+        return self._results[self.get_best_arg()]
+
+    def get_best_arg(self):
+        if self._optimize_internal_loss:
+            return np.argmin(self._losses)
+        return np.argmax([r[self._validation_k]["val_results"][self._validation_metric] for r in self._results])
+
+    def iterate(self, epochs):
+        for iteration in range(epochs):
+            if self._early_stopping.stop(self._losses[:], self._results):
+                self.logger.info(f"Met Early Stopping conditions: {self._early_stopping}")
+                break
+            yield iteration

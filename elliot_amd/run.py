@@ -1,0 +1,110 @@
+"""Minimal experiment runner for the latent-factor plugins (single configuration, no hyperopt).
+
+Honours the slice of Elliot's YAML schema (elliot/namespace/namespace_model.py:28-61) that the hello-world style
+experiments use: dataset, data_config {strategy: dataset|fixed, dataset_path | train_path/test_path},
+splitting.test_splitting {strategy: random_subsampling, test_ratio}, top_k, evaluation {cutoffs, simple_metrics,
+relevance_threshold}, gpu, path_output_rec_*, models {<Model>: {meta: {...}, <hyper-params>}}.
+The full driver (HPO, result handlers, statistical tests: elliot/run.py:39-148) stays Elliot's: plug the models in
+there through elliot_amd/external/__init__.py.
+"""
+import logging
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import yaml
+
+from .dataset.dataset import DataSet, load_tsv_dataset
+from . import recommender as rec
+
+
+def _ns(d):
+    return SimpleNamespace(**{k: v for k, v in d.items()})
+
+
+def _resolve(base_dir, path, dataset):
+    path = path.format(dataset)
+    return path if os.path.isabs(path) else os.path.abspath(os.path.join(base_dir, path))
+
+
+def build_config(exp, base_dir):
+    ds = exp.get("dataset", "dataset")
+    ev = dict(exp.get("evaluation", {}))
+    ev.setdefault("simple_metrics", ["nDCG"])
+    ev.setdefault("relevance_threshold", 0)             # run.py:55-56
+    ev.setdefault("paired_ttest", False)
+    ev.setdefault("wilcoxon_test", False)
+    ev.setdefault("complex_metrics", [])
+    cfg = SimpleNamespace(
+        dataset=ds, top_k=exp.get("top_k", 10), evaluation=_ns(ev), config_test=False, gpu=exp.get("gpu", 0),
+        path_output_rec_result=_resolve(base_dir, exp.get("path_output_rec_result", "../results/{0}/recs/"), ds),
+        path_output_rec_weight=_resolve(base_dir, exp.get("path_output_rec_weight", "../results/{0}/weights/"), ds),
+        path_output_rec_performance=_resolve(base_dir, exp.get("path_output_rec_performance",
+                                                               "../results/{0}/performance/"), ds))
+    if "negative_sampling" in exp:
+        cfg.negative_sampling = _ns(exp["negative_sampling"])
+    for p in (cfg.path_output_rec_result, cfg.path_output_rec_weight, cfg.path_output_rec_performance):
+        os.makedirs(p, exist_ok=True)
+    return cfg
+
+
+def load_data(exp, cfg, base_dir):
+    dc = exp["data_config"]
+    seed = exp.get("random_seed", 42)
+    if dc["strategy"] == "dataset":
+        sp = exp.get("splitting", {}).get("test_splitting", {"strategy": "random_subsampling", "test_ratio": 0.2})
+        if sp.get("strategy") != "random_subsampling":
+            raise Exception(f"splitting strategy {sp.get('strategy')} is not available in the mini runner")
+        return load_tsv_dataset(cfg, _resolve(base_dir, dc["dataset_path"], cfg.dataset), sp.get("test_ratio", 0.2), seed)
+    if dc["strategy"] == "fixed":
+        import pandas as pd
+
+        def rd(key):
+            df = pd.read_csv(_resolve(base_dir, dc[key], cfg.dataset), sep="\t", header=None)
+            return df[0].values, df[1].values, df[2].values
+        val = rd("validation_path") if "validation_path" in dc else None
+        return DataSet(cfg, rd("train_path"), rd("test_path"), val)
+    raise Exception(f"data_config strategy {dc['strategy']} is not available in the mini runner")
+
+
+def model_params(model_cfg):
+    meta = _ns(dict(model_cfg.get("meta", {})))
+    params = {k: v for k, v in model_cfg.items() if k != "meta"}
+    for k, v in params.items():
+        if isinstance(v, (list, tuple)):
+            raise Exception(f"hyper-parameter search ({k}: {v}) needs Elliot's driver; give scalars to the mini runner")
+    ns = _ns(params)
+    ns.meta = meta
+    return ns
+
+
+def run_experiment(config_path=""):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(message)s")
+    with open(config_path) as f:
+        exp = yaml.safe_load(f)["experiment"]
+    base_dir = os.path.dirname(os.path.abspath(config_path))
+    cfg = build_config(exp, base_dir)
+    data = load_data(exp, cfg, base_dir)
+    results = {}
+    for key, model_cfg in exp["models"].items():
+        cls_name = key.split(".")[-1]
+        cls = getattr(rec, cls_name, None)
+        if cls is None:
+            raise Exception(f"Model {key} is not provided by elliot_amd (available: {rec.__all__})")
+        params = model_params(model_cfg or {})
+        model = cls(data=data, config=cfg, params=params)
+        model.train()
+        best = model.get_results()
+        results[model.name] = best
+        perf = os.path.join(cfg.path_output_rec_performance, f"rec_{model.name}.tsv")
+        with open(perf, "w") as out:
+            for cutoff, d in best.items():
+                for metric, value in d["test_results"].items():
+                    out.write(f"{model.name}\t{cutoff}\t{metric}\t{value}\n")
+        print(f"{model.name}: " + ", ".join(f"{m}@{c}={v:.5f}" for c, d in best.items() for m, v in d["test_results"].items()))
+    return results
+
+
+if __name__ == "__main__":
+    run_experiment(sys.argv[1])

@@ -115,6 +115,52 @@ def main():
         gen_metrics(U, I, indptr, indices)
     except Exception as ex:  # the evaluation package is heavier; report but keep the other fixtures
         print("metrics fixture skipped:", repr(ex))
+    gen_splitter()
+    gen_early_stopping()
+
+
+def gen_splitter():
+    """splitter/base_splitter.py:63-98,256-274 -- random_subsampling, test_ratio 0.2, seed 42."""
+    sys.path.insert(0, REF)
+    import pandas as pd
+    from elliot.splitter.base_splitter import Splitter
+    rs = np.random.RandomState(3)
+    n = 3000
+    df = pd.DataFrame({"userId": rs.randint(100, 180, n), "itemId": rs.randint(0, 400, n),
+                       "rating": rs.randint(1, 6, n).astype(float), "timestamp": rs.randint(0, 10 ** 6, n)})
+    df = df.drop_duplicates(["userId", "itemId"]).reset_index(drop=True)
+    ns = SimpleNamespace(test_splitting=SimpleNamespace(strategy="random_subsampling", test_ratio=0.2))
+    (train, test), = Splitter(df, ns, 42).process_splitting()
+    key = lambda d: set(zip(d["userId"].tolist(), d["itemId"].tolist()))
+    tk = key(test)
+    flags = np.array([1 if (u, i) in tk else 0 for u, i in zip(df["userId"], df["itemId"])], np.int8)
+    assert flags.sum() == len(test) and len(train) + len(test) == len(df)
+    np.savez_compressed(os.path.join(OUT, "splitter_ref.npz"), users=df["userId"].values, items=df["itemId"].values,
+                        ratings=df["rating"].values, test_flag=flags)
+    print("splitter_ref.npz:", len(df), "rows,", int(flags.sum()), "test")
+
+
+def gen_early_stopping():
+    """recommender/early_stopping.py:62-90 decisions on fixed sequences."""
+    sys.path.insert(0, REF)
+    es = load_by_path("ref_early_stopping", "elliot/recommender/early_stopping.py")
+    cases = []
+    rs = np.random.RandomState(5)
+    opts_list = [dict(patience=2), dict(patience=1, monitor="loss"), dict(patience=3, min_delta=0.01),
+                 dict(patience=2, rel_delta=0.05), dict(patience=1, monitor="nDCG@10", baseline=0.3), dict()]
+    import json
+    for opts in opts_list:
+        for trial in range(6):
+            seq = np.round(np.cumsum(rs.normal(0.0, 0.05, 9)) + 0.5, 4).tolist()
+            dec = []
+            for t in range(1, len(seq) + 1):
+                e = es.EarlyStopping(SimpleNamespace(**opts), "nDCG", 10, [10], ["nDCG"])
+                results = [{10: {"val_results": {"nDCG": v}}} for v in seq[:t]]
+                dec.append(bool(e.stop(seq[:t], results)))
+            cases.append({"opts": opts, "seq": seq, "decisions": dec})
+    with open(os.path.join(OUT, "early_stopping_ref.json"), "w") as f:
+        json.dump(cases, f)
+    print("early_stopping_ref.json:", len(cases), "cases")
 
 
 def gen_metrics(U, I, indptr, indices):
@@ -145,11 +191,12 @@ def gen_metrics(U, I, indptr, indices):
             if c not in top:
                 top.append(c)
         recs[u] = [(it, float(k - r)) for r, it in enumerate(top)]
-    cfg = SimpleNamespace(top_k=k, evaluation=SimpleNamespace(cutoffs=[k, 5], simple_metrics=["nDCG", "Precision", "Recall", "HR", "MAP", "MRR"],
+    cfg = SimpleNamespace(top_k=k, evaluation=SimpleNamespace(cutoffs=[k, 5], simple_metrics=["nDCG", "Precision", "Recall", "HR", "MAP", "MRR", "F1"],
                                                             relevance_threshold=0, paired_ttest=False, wilcoxon_test=False,
                                                             complex_metrics=[]),
                           config_test=True)
     data = SimpleNamespace(config=cfg, test_dict=test, train_dict={u: {int(i): 1.0 for i in indices[indptr[u]:indptr[u + 1]]} for u in range(U)},
+                           get_test=lambda: test, get_validation=lambda: None, transactions=int(indptr[-1]),
                            users=list(range(U)), items=list(range(I)), num_items=I, num_users=U,
                            private_users={p: p for p in range(U)}, public_users={p: p for p in range(U)},
                            private_items={p: p for p in range(I)}, public_items={p: p for p in range(I)})

@@ -1,0 +1,158 @@
+"""GPU end-to-end: the plugin classes (BPRMF_batch, BPRMF) driven the way ModelCoordinator.single drives them
+(model_coordinator.py:100-103), checked against a full CPU replay with the oracle."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from elliot_amd.dataset.dataset import DataSet, default_config
+from elliot_amd.evaluation.evaluator import Evaluator
+from elliot_amd.recommender import BPRMF, BPRMF_batch
+from elliot_amd.synthetic import small_dataset
+from oracle import bprmf_batch as ob
+from oracle import cref
+from oracle import sampler as osampler
+from oracle import sgd as osgd
+
+pytestmark = pytest.mark.gpu
+
+
+def make_data(tmp_path, top_k=10):
+    indptr, indices, _ = small_dataset(300, 220, seed=4)
+    I = int(indices.max()) + 1
+    rs = np.random.RandomState(9)
+    U = indptr.shape[0] - 1
+    users = np.repeat(np.arange(U), np.diff(indptr))
+    ratings = rs.randint(1, 6, indices.shape[0]).astype(float)
+    # hold out ~20% of every user's items as test (users keep >= 1 train item)
+    flag = np.zeros(indices.shape[0], bool)
+    for u in range(U):
+        a, b = indptr[u], indptr[u + 1]
+        n_te = (b - a) // 5
+        if n_te:
+            flag[a + rs.choice(b - a, n_te, replace=False)] = True
+    cfg = default_config(top_k=top_k, cutoffs=[top_k, 5], simple_metrics=["nDCG", "Recall"], out_dir=str(tmp_path))
+    for p in (cfg.path_output_rec_result, cfg.path_output_rec_weight):
+        os.makedirs(p, exist_ok=True)
+    # public ids = 1000 + private user, 5000 + private item (so that the id maps are exercised)
+    tr = (users[~flag] + 1000, indices[~flag] + 5000, ratings[~flag])
+    te = (users[flag] + 1000, indices[flag] + 5000, ratings[flag])
+    return DataSet(cfg, tr, te), cfg
+
+
+def test_bprmf_batch_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
+    data, cfg = make_data(tmp_path)
+    F, lr, l_w, l_b, B, epochs = 16, 0.01, 0.1, 0.001, 512, 2
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=True, verbose=False), epochs=epochs, batch_size=B,
+                             factors=F, lr=lr, l_w=l_w, l_b=l_b, seed=42)
+    model = BPRMF_batch(data=data, config=cfg, params=params)
+    st0 = model._model.state
+    Gu0, Gi0, Bi0 = st0.Gu.cpu().numpy().copy(), st0.Gi.cpu().numpy().copy(), st0.Bi.cpu().numpy().copy()
+    assert model.name.startswith("BPRNN_seed=42_e=2_bs=512_factors=16_lr=0$01")
+    model.train()
+    results = model.get_results()
+    assert set(results.keys()) == {10, 5} and 0.0 <= results[10]["test_results"]["nDCG"] <= 1.0
+    assert isinstance(model.get_loss(), float) and model.get_params()["name"] == model.name
+
+    # ---- CPU replay: same Philox stream, same initial weights, TF-semantics oracle ------------------
+    m = data.sp_i_train
+    U, I, T = data.num_users, data.num_items, data.transactions
+    orc = ob.BPRMFBatchOracle(Gu0, Gi0, Bi0, lr, l_w, l_b)
+    drawn, losses = 0, []
+    for it in range(epochs):
+        tot = 0.0
+        for start in range(0, T, B):
+            n = min(start + B, T) - start
+            u, i, j = osampler.philox_sample(m.indptr, m.indices, U, I, 42, drawn, n)
+            drawn += n
+            tot += orc.train_step((u, i, j))
+        losses.append(tot / (it + 1))                       # BPRMF_batch.py:109
+    for got, exp in zip(model._losses, losses):
+        assert abs(got - exp) <= 1e-4 * abs(exp), (model._losses, losses)
+    st = model._model.state
+    assert (np.abs(st.Gu.cpu().numpy() - orc.Gu) > 2e-5).mean() < 1e-3
+    assert (np.abs(st.Gi.cpu().numpy() - orc.Gi) > 2e-5).mean() < 1e-3
+
+    # ---- recommendations: device lists == oracle lists computed from the DEVICE's final weights ------
+    recs_val, recs_test = model.get_recommendations(10)
+    oi, ov = cref.score_topk_f32(st.Gu.cpu().numpy(), st.Gi.cpu().numpy(), st.Bi.cpu().numpy(), 0, U, 10,
+                                 excl=(m.indptr, m.indices))
+    assert list(recs_test.keys()) == [data.private_users[u] for u in range(U)]
+    for u in range(U):
+        pub = recs_test[data.private_users[u]]
+        assert [it for it, _ in pub] == [data.private_items[int(x)] for x in oi[u]]
+        assert np.array_equal(np.array([s for _, s in pub], np.float32), ov[u])
+    # metric = stand-alone evaluator on those lists (itself pinned to the reference Evaluator on CPU)
+    again = Evaluator(data, params).eval((recs_val, recs_test))
+    assert again[10]["test_results"] == model._results[-1][10]["test_results"]
+    # save_recs wrote the reference's TSV format (utils/write.py:35-44)
+    f = os.path.join(cfg.path_output_rec_result, f"{model.name}_it=2.tsv")
+    first = open(f).readline().rstrip("\n").split("\t")
+    assert len(first) == 3 and int(first[0]) == data.private_users[0]
+
+
+def test_bprmf_plugin_epoch_equals_sequential_reference_semantics(ctx, tmp_path):
+    data, cfg = make_data(tmp_path)
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=1, factors=12, lr=0.05, seed=42)
+    model = BPRMF(data=data, config=cfg, params=params)
+    U, I, T = data.num_users, data.num_items, data.transactions
+    P, Q, b = osgd.initialize(U, I, 12, 42)                 # MFModel.initialize stream (BPRMF_model.py:24,40-56)
+    assert np.array_equal(model._model.state.P.cpu().numpy(), P)
+    model.train()
+    assert model._model.levels_last > 1
+    m = data.sp_i_train
+    u, i, j = osampler.philox_sample(m.indptr, m.indices, U, I, 42, 0, T)
+    osgd.train_sequential(P, Q, b, u, i, j, lr=0.05, reg_bias=0, reg_user=0.0025, reg_pos=0.0025, reg_neg=0.00025)
+    st = model._model.state
+    assert np.abs(st.P.cpu().numpy() - P).max() < 1e-12 and np.abs(st.Q.cpu().numpy() - Q).max() < 1e-12
+    assert np.abs(st.b.cpu().numpy() - b).max() < 1e-12
+    _, recs = model.get_recommendations(10)
+    oi, ov = cref.score_topk_f64(st.P.cpu().numpy(), st.Q.cpu().numpy(), st.b.cpu().numpy(), 0, U, 10,
+                                 excl=(m.indptr, m.indices))
+    for uu in range(U):
+        assert [it for it, _ in recs[data.private_users[uu]]] == [data.private_items[int(x)] for x in oi[uu]]
+    assert model.name.startswith("BPRMF_seed=42_e=1_bs=1_f=12_lr=0$05")
+
+
+def test_checkpoint_roundtrip(ctx, tmp_path):
+    data, cfg = make_data(tmp_path)
+    params = SimpleNamespace(meta=SimpleNamespace(save_weights=True, verbose=False), epochs=1, batch_size=256,
+                             factors=8, lr=0.01, seed=1)
+    model = BPRMF_batch(data=data, config=cfg, params=params)
+    model.train()
+    assert os.path.exists(model._saving_filepath)
+    before = model.get_recommendations(10)[1]
+    params2 = SimpleNamespace(meta=SimpleNamespace(restore=True, verbose=False), epochs=1, batch_size=256,
+                              factors=8, lr=0.01, seed=1)
+    model2 = BPRMF_batch(data=data, config=cfg, params=params2)
+    model2.train()                                           # restore path: load + evaluate (BPRMF_batch.py:96-97)
+    assert model2.get_recommendations(10)[1] == before
+
+
+def test_mini_runner_yaml(ctx, tmp_path):
+    import yaml
+    from elliot_amd.run import run_experiment
+    indptr, indices, _ = small_dataset(250, 200, seed=11)
+    rs = np.random.RandomState(0)
+    users = np.repeat(np.arange(250), np.diff(indptr))
+    with open(tmp_path / "dataset.tsv", "w") as f:
+        for u, i in zip(users, indices):
+            f.write(f"{u + 1}\t{i + 1}\t{rs.randint(1, 6)}\t{rs.randint(0, 10 ** 6)}\n")
+    cfg = {"experiment": {
+        "dataset": "toy", "data_config": {"strategy": "dataset", "dataset_path": "dataset.tsv"},
+        "splitting": {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2}},
+        "top_k": 10, "evaluation": {"simple_metrics": ["nDCG"]},
+        "path_output_rec_result": "out/recs/", "path_output_rec_weight": "out/weights/",
+        "path_output_rec_performance": "out/perf/",
+        "models": {"external.BPRMF_batch": {"meta": {"save_recs": True}, "epochs": 2, "batch_size": 512, "factors": 64,
+                                            "lr": 0.001, "l_w": 0.1, "l_b": 0.001},
+                   "BPRMF": {"meta": {}, "epochs": 1, "factors": 64}}}}
+    with open(tmp_path / "exp.yml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    res = run_experiment(str(tmp_path / "exp.yml"))
+    assert len(res) == 2
+    for name, r in res.items():
+        assert 0.0 <= r[10]["test_results"]["nDCG"] <= 1.0
+    assert os.listdir(tmp_path / "out" / "perf")
