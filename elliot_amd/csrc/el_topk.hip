@@ -12,6 +12,7 @@
 //   NaN scores are never selected.
 // The [users, items] score matrix is never written to HBM: selection is fused behind the
 // MFMA accumulators (threshold filter in registers, candidate lists in LDS).
+#include <stdlib.h>
 #include "el_common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -32,6 +33,7 @@ struct TopkParams {
     // dense-preds variant
     const float* preds;
     int64_t ld;
+    int dbg;  // experiment switches (EL_TOPK_DEBUG): 1 = skip the fused selection (GEMM-only timing)
 };
 
 // ---- one-wave bitonic sort (descending) of n = 2^m u64 keys held in LDS --------------
@@ -62,6 +64,33 @@ __device__ __forceinline__ float el_wave_compact(u64* kb, int* cp, int cap, int 
     for (int t = n + lane; t < cap; t += 64) kb[t] = 0ull;
     el_wave_lds_sync();
     el_wave_bitonic_desc(kb, cap, lane);
+    int nn = n < k ? n : k;
+    if (lane == 0) *cp = nn;
+    float nt = (nn >= k) ? el_key_score(kb[k - 1]) : -INFINITY;
+    el_wave_lds_sync();
+    return nt;
+}
+
+// Same, but first drops keys whose item is in the (sorted) exclusion row idx[e0,e1): the MFMA kernel
+// inserts candidates unchecked and pays the membership test (a chain of dependent global loads) once
+// per compaction for the whole buffer instead of once per insertion.  cap <= 64 here.
+__device__ __forceinline__ float el_wave_compact_excl(u64* kb, int* cp, int cap, int k, int lane,
+                                                      const int32_t* __restrict__ idx, int64_t e0, int64_t e1) {
+    el_wave_lds_sync();
+    int n = *cp;
+    bool drop = false;
+    if (lane < cap) {
+        if (lane < n) {
+            if (e1 > e0) drop = el_row_contains(idx, e0, e1, el_key_item(kb[lane]));
+            if (drop) kb[lane] = 0ull;
+        } else {
+            kb[lane] = 0ull;
+        }
+    }
+    const int removed = __popcll(__ballot(drop));
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(kb, cap, lane);
+    n -= removed;
     int nn = n < k ? n : k;
     if (lane == 0) *cp = nn;
     float nt = (nn >= k) ? el_key_score(kb[k - 1]) : -INFINITY;
@@ -196,13 +225,18 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
 // Lanes l and l+32 therefore own the same user; every user belongs to exactly one wave,
 // so all top-k state is wave-private (no cross-wave synchronisation outside staging).
 // =====================================================================================
-template <int FP, int NIB, int CAP>
-__global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(TopkParams p, int vec) {
-    constexpr int KC = 32, LDA = KC + 1, BI = 32 * NIB, NCH = FP / KC, UPB = 128;
-    constexpr int A_FLOATS = 2 * BI * LDA + 2 * BI;
+template <int FP, int NIB, int CAP, int KC, int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, int vec) {
+    constexpr int LDA = KC + 1, BI = 32 * NIB, NCH = (FP + KC - 1) / KC, UPB = NW * 32, NT = NW * 64;
+    constexpr int C4 = KC / 4;                      // float4 pieces per staged row
+    constexpr int NLD = (BI * C4 + NT - 1) / NT;    // float4 loads per thread per chunk
+    static_assert((BI * C4) % NT == 0, "staging must divide evenly");
+    constexpr int A_FLOATS = 2 * BI * LDA + 2 * BI + 8;
+    static_assert(CAP <= 64, "el_wave_compact_excl handles one key per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                // [2][BI][LDA]
     float* Bs = As + 2 * BI * LDA;                             // [2][BI] bias
+    float* Bm = Bs + 2 * BI;                                   // [2][4] per-wave max of the staged bias tile
     u64* keys = reinterpret_cast<u64*>(smem + A_FLOATS * 4);   // [UPB][CAP]
     int* cnts = reinterpret_cast<int*>(keys + UPB * CAP);      // [UPB]
 
@@ -236,14 +270,14 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
     const int ntiles = (int)((I + BI - 1) / BI);
     const int nch = (F + KC - 1) / KC;
 
-    float4 pre[NIB];
+    float4 pre[NLD];
     float pre_bias = 0.f;
 
     auto gload = [&](int tile, int ch) {
 #pragma unroll
-        for (int q = 0; q < NIB; ++q) {
-            int f4 = q * 256 + tid;
-            int row = f4 >> 3, c4 = f4 & 7;
+        for (int q = 0; q < NLD; ++q) {
+            int f4 = q * NT + tid;
+            int row = f4 / C4, c4 = f4 % C4;
             int64_t item = (int64_t)tile * BI + row;
             int kk = ch * KC + c4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -267,16 +301,22 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
     };
     auto lstore = [&](int buf, int bias_buf) {
 #pragma unroll
-        for (int q = 0; q < NIB; ++q) {
-            int f4 = q * 256 + tid;
-            int row = f4 >> 3, c4 = f4 & 7;
+        for (int q = 0; q < NLD; ++q) {
+            int f4 = q * NT + tid;
+            int row = f4 / C4, c4 = f4 % C4;
             float* dst = As + (buf * BI + row) * LDA + c4 * 4;
             dst[0] = pre[q].x;
             dst[1] = pre[q].y;
             dst[2] = pre[q].z;
             dst[3] = pre[q].w;
         }
-        if (bias_buf >= 0 && tid < BI) Bs[bias_buf * BI + tid] = pre_bias;
+        if (bias_buf >= 0 && tid < ((BI + 63) & ~63)) {   // whole waves: tid < BI rounded up to 64
+            if (tid < BI) Bs[bias_buf * BI + tid] = pre_bias;
+            float wm = (tid < BI) ? pre_bias : -INFINITY;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+            if (lane == 0) Bm[bias_buf * 4 + wave] = wm;
+        }
     };
 
     u64* wkeys = keys + (size_t)wave * 32 * CAP;
@@ -305,6 +345,7 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
                 const float* Ab = As + buf * BI * LDA;
 #pragma unroll
                 for (int s = 0; s < KC / 2; ++s) {
+                    if (ch * (KC / 2) + s >= FP / 2) break;   // compile-time (FP < KC * NCH)
                     float a[NIB];
 #pragma unroll
                     for (int b = 0; b < NIB; ++b) a[b] = Ab[(b * 32 + col) * LDA + 2 * s + hi];
@@ -318,22 +359,35 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
 
         // ---- fused selection ------------------------------------------------------
         const float* bb = Bs + (tile & 1) * BI;
+        if (p.dbg & 1) {
+            float sink = 0.f;
+#pragma unroll
+            for (int b = 0; b < NIB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sink += acc[b][r];
+            if (sink == 123.456f) tau = sink;   // keeps the accumulators live
+            continue;
+        }
+        float bmax = Bm[(tile & 1) * 4];
+        if (BI > 64) bmax = fmaxf(bmax, Bm[(tile & 1) * 4 + 1]);
 #pragma unroll
         for (int b = 0; b < NIB; ++b) {
-            float sc[16];
-            float m = -INFINITY;
+            // cheap conservative filter: max over this lane's 16 rows plus the tile's largest bias.
+            // fl(acc + bias) <= fl(max acc + max bias) (rounding is monotonic) => no false negatives.
+            float m = acc[b][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sc[r] = (acc[b][r] + bb[row]) + 0.0f;
-                m = fmaxf(m, sc[r]);
-            }
-            if (__ballot(m >= tau) != 0ull) {
-                // rare path: bitmask of this lane's passing rows, then one insertion per lane
-                // per round (so a user -- lanes l and l+32 -- gains at most 2 keys per round)
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[b][r]);
+            if (__ballot(m + bmax >= tau) != 0ull) {
+                // rare path: exact scores, bitmask of this lane's passing rows, then one insertion per
+                // lane per round (so a user -- lanes l and l+32 -- gains at most 2 keys per round)
+                float sc[16];
                 u32 hm = 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hm |= (sc[r] >= tau) ? (1u << r) : 0u;
+                for (int r = 0; r < 16; ++r) {
+                    int row = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sc[r] = (acc[b][r] + bb[row]) + 0.0f;
+                    hm |= (sc[r] >= tau) ? (1u << r) : 0u;
+                }
                 while (__ballot(hm != 0u) != 0ull) {
                     const bool pend = hm != 0u;
                     const int r = pend ? (__ffs((int)hm) - 1) : 0;
@@ -344,7 +398,6 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
                     int64_t il = (int64_t)tile * BI + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     bool v = pend && uvalid && il < I && (sv >= tau);
                     int32_t g = (int32_t)(p.item_offset + il);
-                    if (v && e1 > e0) v = !el_row_contains(p.excl_indices, e0, e1, g);
                     if (v) {
                         int pos = atomicAdd(&cnts[uslot], 1);
                         keys[(size_t)uslot * CAP + pos] = el_make_key(sv, g);
@@ -355,7 +408,9 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
                     while (full) {
                         int ul = __ffsll((long long)full) - 1;
                         full &= full - 1ull;
-                        float ntau = el_wave_compact(wkeys + (size_t)ul * CAP, wcnts + ul, CAP, p.k, lane);
+                        const int64_t ue0 = __shfl(e0, ul, 64), ue1 = __shfl(e1, ul, 64);
+                        float ntau = el_wave_compact_excl(wkeys + (size_t)ul * CAP, wcnts + ul, CAP, p.k, lane,
+                                                          p.excl_indices, ue0, ue1);
                         if (col == ul) tau = ntau;
                     }
                 }
@@ -368,9 +423,9 @@ __global__ __launch_bounds__(256, (FP <= 128 ? 2 : 1)) void k_score_topk_mfma(To
         const int64_t uu = ublock + wave * 32 + ul;
         if (uu >= p.u_stop) break;
         u64* kb = wkeys + (size_t)ul * CAP;
-        el_wave_compact(kb, wcnts + ul, CAP, p.k, lane);
-        const int nv = wcnts[ul];
         const int64_t ue0 = __shfl(e0, ul, 64), ue1 = __shfl(e1, ul, 64);
+        el_wave_compact_excl(kb, wcnts + ul, CAP, p.k, lane, p.excl_indices, ue0, ue1);
+        const int nv = wcnts[ul];
         const int64_t orow = (uu - p.u_start) * (int64_t)p.k;
         for (int t = lane; t < p.k; t += 64) {
             int32_t oi;
@@ -583,25 +638,40 @@ static bool mfma_eligible(int F, int k, const void* cand) { return cand == nullp
 
 extern "C" size_t el_score_topk_ws_bytes(int64_t, int64_t, int32_t, int32_t, int) { return 0; }
 
-template <int FP, int NIB, int CAP>
+template <int FP, int NIB, int CAP, int KC, int NW, int OCC>
 static int launch_mfma(const TopkParams& p, int vec, hipStream_t st) {
-    constexpr int KC = 32, LDA = KC + 1, BI = 32 * NIB;
-    constexpr size_t lds = (size_t)(2 * BI * LDA + 2 * BI) * 4 + (size_t)128 * CAP * 8 + 128 * 4;
-    auto kern = k_score_topk_mfma<FP, NIB, CAP>;
+    constexpr int LDA = KC + 1, BI = 32 * NIB, UPB = NW * 32;
+    constexpr size_t lds = (size_t)(2 * BI * LDA + 2 * BI + 8) * 4 + (size_t)UPB * CAP * 8 + UPB * 4;
+    auto kern = k_score_topk_mfma<FP, NIB, CAP, KC, NW, OCC>;
     EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t n_users = p.u_stop - p.u_start;
-    unsigned grid = (unsigned)((n_users + 127) / 128);
-    EL_LAUNCH("k_score_topk_mfma", kern, dim3(grid), dim3(256), lds, st, p, vec);
+    unsigned grid = (unsigned)((n_users + UPB - 1) / UPB);
+    EL_LAUNCH("k_score_topk_mfma", kern, dim3(grid), dim3(NW * 64), lds, st, p, vec);
     EL_CHECK_LAUNCH();
     return 0;
 }
 
+// experiment hook: EL_TOPK_VARIANT selects an alternative geometry for F in (64,128]
+static int topk_variant() {
+    const char* e = getenv("EL_TOPK_VARIANT");
+    return e ? atoi(e) : 0;
+}
+
 template <int CAP>
 static int dispatch_mfma_fp(const TopkParams& p, int vec, hipStream_t st) {
-    if (p.F <= 32) return launch_mfma<32, 4, CAP>(p, vec, st);
-    if (p.F <= 64) return launch_mfma<64, 4, CAP>(p, vec, st);
-    if (p.F <= 128) return launch_mfma<128, 4, CAP>(p, vec, st);
-    return launch_mfma<256, 2, CAP>(p, vec, st);
+    if (p.F <= 32) return launch_mfma<32, 4, CAP, 32, 4, 2>(p, vec, st);
+    if (p.F <= 64) return launch_mfma<64, 4, CAP, 32, 4, 2>(p, vec, st);
+    if (p.F <= 128) {
+        switch (topk_variant()) {
+            case 1: return launch_mfma<128, 2, CAP, 32, 4, 3>(p, vec, st);   // 64-item tiles, 3 waves/SIMD
+            case 2: return launch_mfma<128, 4, CAP, 64, 8, 2>(p, vec, st);   // 256 users/WG, K chunk 64
+            case 3: return launch_mfma<128, 4, CAP, 64, 4, 1>(p, vec, st);   // K chunk 64, 1 WG/CU
+            case 4: return launch_mfma<128, 2, CAP, 64, 4, 2>(p, vec, st);   // 64-item tiles, K chunk 64
+            case 5: return launch_mfma<128, 4, CAP, 32, 8, 2>(p, vec, st);   // 256 users/WG, K chunk 32
+            default: return launch_mfma<128, 4, CAP, 32, 4, 2>(p, vec, st);
+        }
+    }
+    return launch_mfma<256, 2, CAP, 32, 4, 1>(p, vec, st);
 }
 
 static int check_topk_args(const char* fn, int64_t u_start, int64_t u_stop, int64_t I_local, int F, int k,
@@ -646,6 +716,10 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
     p.k = k;
     p.out_idx = out_idx;
     p.out_val = out_val;
+    {
+        const char* e = getenv("EL_TOPK_DEBUG");
+        p.dbg = e ? atoi(e) : 0;
+    }
     bool elig = mfma_eligible(F, k, cand_indptr);
     if (algo == EL_TOPK_MFMA) EL_REQUIRE(elig, "el_score_topk: MFMA kernel needs F<=256, k<=40 and no candidate list");
     bool use_mfma = (algo == EL_TOPK_MFMA) || (algo == EL_TOPK_AUTO && elig);

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of single hot kernels (for rocprofv3 PMC passes and A/B of kernel variants).
+usage: python scripts/mb.py topk|adam|train [--users N --items N --factors F --k K --iters N --algo ...]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elliot_amd import ops  # noqa: E402
+from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["topk", "train"])
+    ap.add_argument("--users", type=int, default=131072)
+    ap.add_argument("--items", type=int, default=100000)
+    ap.add_argument("--factors", type=int, default=128)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1 << 20)
+    ap.add_argument("--algo", default="mfma")
+    ap.add_argument("--opt", default="adam_tf_dense")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-excl", action="store_true")
+    a = ap.parse_args()
+    os.environ["EL_TOPK_VARIANT"] = str(a.variant)
+    ctx = ops.get_context(0)
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    U, I, F = a.users, a.items, a.factors
+    Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * 0.01
+    Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * 0.01
+    Bi = torch.zeros(I, device=dev)
+    ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, seed=5)
+    pos = ops.DeviceCSR.from_tensors(ip, ix, I)
+    ctx.timing(True)
+    if a.what == "topk":
+        for _ in range(a.iters):
+            ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)
+        torch.cuda.synchronize()
+        rep = ctx.timing_report()
+        for n, (c, ms) in rep.items():
+            per = ms / c
+            print(f"{n}: {per:.3f} ms/launch  {2.0 * U * I * F / per / 1e9:.1f} TFLOP/s  {U / per * 1e3:.0f} users/s")
+    else:
+        st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=a.opt)
+        for it in range(a.iters):
+            u, i, j = ops.bpr_sample(ctx, pos, a.batch, seed=3, first_sample=it * a.batch)
+            st.train_step(u, i, j, 0.001, 0.1, 0.001, algo=a.algo if a.algo in ("auto", "atomic", "sorted") else "auto")
+        torch.cuda.synchronize()
+        rep = ctx.timing_report()
+        tot = 0
+        for n, (c, ms) in rep.items():
+            print(f"{n}: {ms / a.iters:.4f} ms/step ({c} launches)")
+            tot += ms / a.iters
+        print(f"total {tot:.4f} ms/step -> {a.batch / tot * 1e3 / 1e6:.1f} M pairs/s")
+
+
+if __name__ == "__main__":
+    main()
