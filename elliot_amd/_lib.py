@@ -44,6 +44,16 @@ class BprsgdState(C.Structure):
     ]
 
 
+class VaeState(C.Structure):
+    _fields_ = [
+        ("I", C.c_int64), ("H", C.c_int32), ("L", C.c_int32), ("Bmax", C.c_int64),
+        ("w", C.c_void_p * 8), ("g", C.c_void_p * 8), ("m", C.c_void_p * 8), ("v", C.c_void_p * 8),
+        ("h", _f32p), ("mv", _f32p), ("z", _f32p), ("dz", _f32p), ("h2", _f32p), ("logits", _f32p),
+        ("dh2", _f32p), ("dmv", _f32p), ("dh", _f32p), ("rnorm", _f32p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/elliot_hip.h one to one
 PROTOTYPES = {
     "el_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -72,6 +82,12 @@ PROTOTYPES = {
     "el_score_topk_f64": (C.c_int, [C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, C.c_int64, C.c_int64, C.c_int64,
                                     C.c_int64, C.c_int32, _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f64p]),
     "el_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int32, C.c_int64, C.c_int32, _i32p, _f32p]),
+    "el_gemm_ws_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "el_gemm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _f32p, C.c_int64,
+                              _f32p, C.c_int64, _f32p, C.c_int64, _f32p, C.c_int, C.c_void_p, C.c_size_t]),
+    "el_vae_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(VaeState), _i64p, _i32p, _i32p, C.c_int64, _f32p,
+                                    C.c_float, C.c_float, C.c_uint64, C.c_int32, C.c_float, _f64p]),
+    "el_vae_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(VaeState), _i64p, _i32p, _i32p, C.c_int64, _f32p]),
     "el_dense_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p]),
 }

@@ -1,0 +1,348 @@
+// Mult-VAE train step / predict.
+//
+// Replaces VariationalAutoEncoder.call / train_step / predict (multi_vae_model.py:115-155; Encoder :32-64,
+// Decoder :67-83, Sampling :20-29) and the dense-row sampler feeding it (sparse_sampler.py:19-25).
+//
+//   x~ = l2_normalize(x) -> dropout -> h = tanh(x~ W1 + b1) -> [mu | logvar] = h [Wm | Wv] + [bm | bv]
+//   z = mu + exp(logvar/2) eps -> h2 = tanh(z W3 + b3) -> logits = h2 W4 + b4
+//   loss = -mean_b sum_i log_softmax(logits)_i x_i + anneal * (-1/2) mean_{b,j}(logvar - mu^2 - exp(logvar) + 1)
+//
+// The reference multiplies a 99.7 %-sparse dense [B, I] block by W1; here the batch stays CSR and the first
+// layer is a gather-sum of W1 rows (k_vae_enc1), its weight gradient a scatter of dh rows (k_vae_dw1).  Every
+// other product is a dense fp32 MFMA GEMM (el_gemm.hip) with bias/tanh fused into the epilogue; softmax +
+// multinomial NLL + its gradient are one row-wise kernel over the logits.  Adam uses the arithmetic of TF's
+// dense ApplyAdam kernel (m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= (m*alpha)/(sqrt(v)+eps)).
+// The L2 kernel_regularizers declared by the reference are never added to its loss: no-op here too.
+#include "el_common.h"
+
+extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                           const float* bias, int act, void* ws, size_t ws_bytes);
+
+// ---- first layer: CSR rows x W1 ------------------------------------------------------------------------
+// keep-probability mask of nonzero (user, item): Philox keyed by (seed, step); 1/(1-rate) scaling as Keras Dropout
+__device__ __forceinline__ float vae_drop_scale(float rate, u64 seed, u32 step, u32 user, u32 item) {
+    if (rate <= 0.f) return 1.f;
+    el_philox4 r = el_philox4x32_10(user, item, step, 0u, (u32)seed, (u32)(seed >> 32));
+    const float uni = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+    return uni < rate ? 0.f : 1.0f / (1.0f - rate);
+}
+
+// one wave per batch row; lane owns float4 chunks c = lane, lane+64, ... of the H hidden units
+template <int CPL>
+__global__ __launch_bounds__(256) void k_vae_enc1(const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
+                                                  const int32_t* __restrict__ indices, const float* __restrict__ W1,
+                                                  const float* __restrict__ b1, int64_t B, int H, float rate, u64 seed,
+                                                  u32 step, float* __restrict__ h, float* __restrict__ rnorm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int32_t user = rows[b];
+    const int64_t r0 = indptr[user], r1 = indptr[user + 1];
+    // K.l2_normalize(x, axis=1): x / sqrt(max(sum x^2, 1e-12)); x is the binary train row (sp_i_train)
+    const float nrm = 1.0f / sqrtf(fmaxf((float)(r1 - r0), 1e-12f));
+    float acc[CPL][4];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+    const int H4 = H >> 2;
+    for (int64_t e = r0; e < r1; ++e) {
+        const int32_t item = indices[e];
+        const float w = nrm * vae_drop_scale(rate, seed, step, (u32)user, (u32)item);
+        if (w == 0.f) continue;
+        const float4* wr = reinterpret_cast<const float4*>(W1 + (int64_t)item * H);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = lane + q * 64;
+            if (c < H4) {
+                const float4 t = wr[c];
+                acc[q][0] += w * t.x;
+                acc[q][1] += w * t.y;
+                acc[q][2] += w * t.z;
+                acc[q][3] += w * t.w;
+            }
+        }
+    }
+    float* hb = h + b * (int64_t)H;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lane + q * 64;
+        if (c < H4) {
+            const float4 bb = reinterpret_cast<const float4*>(b1)[c];
+            float4 o;
+            o.x = tanhf(acc[q][0] + bb.x);
+            o.y = tanhf(acc[q][1] + bb.y);
+            o.z = tanhf(acc[q][2] + bb.z);
+            o.w = tanhf(acc[q][3] + bb.w);
+            reinterpret_cast<float4*>(hb)[c] = o;
+        }
+    }
+    if (lane == 0) rnorm[b] = nrm;
+}
+
+// dW1[item,:] += x~(b,item) * dhpre[b,:] for every nonzero of the batch (scatter; rows untouched stay zero)
+template <int CPL>
+__global__ __launch_bounds__(256) void k_vae_dw1(const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices, const float* __restrict__ dh,
+                                                 const float* __restrict__ rnorm, int64_t B, int H, float rate, u64 seed,
+                                                 u32 step, float* __restrict__ gW1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int32_t user = rows[b];
+    const int64_t r0 = indptr[user], r1 = indptr[user + 1];
+    const float nrm = rnorm[b];
+    const int H4 = H >> 2;
+    float4 d[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lane + q * 64;
+        d[q] = (c < H4) ? reinterpret_cast<const float4*>(dh + b * (int64_t)H)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t e = r0; e < r1; ++e) {
+        const int32_t item = indices[e];
+        const float w = nrm * vae_drop_scale(rate, seed, step, (u32)user, (u32)item);
+        if (w == 0.f) continue;
+        float* g = gW1 + (int64_t)item * H;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = lane + q * 64;
+            if (c < H4) {
+                atomicAdd(g + 4 * c + 0, w * d[q].x);
+                atomicAdd(g + 4 * c + 1, w * d[q].y);
+                atomicAdd(g + 4 * c + 2, w * d[q].z);
+                atomicAdd(g + 4 * c + 3, w * d[q].w);
+            }
+        }
+    }
+}
+
+// ---- sampling + KL ------------------------------------------------------------------------------------------
+// mv = [mu | logvar] [B, 2L]; z = mu + exp(logvar/2) eps (multi_vae_model.py:25-29);
+// loss += anneal * (-1/2) * mean_{b,j}(logvar - mu^2 - exp(logvar) + 1)   (:119-121, :137)
+__global__ __launch_bounds__(256) void k_vae_sample(const float* __restrict__ mv, const float* __restrict__ eps,
+                                                    int64_t B, int L, float anneal, float* __restrict__ z,
+                                                    double* loss_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (t < B * L) {
+        const int64_t b = t / L;
+        const int j = (int)(t - b * L);
+        const float mu = mv[b * 2 * L + j], lv = mv[b * 2 * L + L + j];
+        const float e = eps ? eps[t] : 0.f;
+        z[t] = mu + expf(0.5f * lv) * e;
+        term = lv - mu * mu - expf(lv) + 1.0f;
+    }
+    __shared__ float wsum[4];
+    float wl = el_group_sum(term, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) {
+        const double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+        if (tot != 0.0 && anneal != 0.f) atomicAdd(loss_out, (double)anneal * (-0.5) * tot / ((double)B * (double)L));
+    }
+}
+
+// d[mu | logvar] from dz and the KL term
+__global__ __launch_bounds__(256) void k_vae_dmv(const float* __restrict__ dz, const float* __restrict__ mv,
+                                                 const float* __restrict__ eps, int64_t B, int L, float anneal,
+                                                 float* __restrict__ dmv) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * L) return;
+    const int64_t b = t / L;
+    const int j = (int)(t - b * L);
+    const float mu = mv[b * 2 * L + j], lv = mv[b * 2 * L + L + j];
+    const float e = eps ? eps[t] : 0.f;
+    const float g = dz[t];
+    const float kscale = anneal / ((float)B * (float)L);
+    dmv[b * 2 * L + j] = g + kscale * mu;
+    dmv[b * 2 * L + L + j] = g * e * 0.5f * expf(0.5f * lv) + kscale * 0.5f * (expf(lv) - 1.0f);
+}
+
+// in place: d <- d * (1 - y^2)   (tanh backward)
+__global__ __launch_bounds__(256) void k_tanh_bwd(float* __restrict__ d, const float* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const float yy = y[t];
+        d[t] = d[t] * (1.0f - yy * yy);
+    }
+}
+
+// out[n] = sum_b X[b, n]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t B, int64_t N, int64_t ld,
+                                                float* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int64_t b = 0; b < B; ++b) s += X[b * ld + n];
+    out[n] = s;
+}
+
+// ---- row-wise log-softmax / multinomial NLL / gradient ---------------------------------------------------
+// One workgroup per batch row over logits[b, 0..I).
+//   mode 0 (predict): logits <- log_softmax(logits)                         (multi_vae_model.py:153-155)
+//   mode 1 (train)  : loss += -(1/B) sum_i log_softmax_i x_i ;  logits <- d loss / d logits
+//                     = (softmax * sum_i x_i - x) / B                        (:131-137)
+__global__ __launch_bounds__(256) void k_vae_softmax(float* __restrict__ logits, const int32_t* __restrict__ rows,
+                                                     const int64_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ indices, int64_t B, int64_t I,
+                                                     int mode, double* loss_out) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int64_t b = blockIdx.x;
+    float* row = logits + b * I;
+    const int tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int64_t i = tid; i < I; i += 256) m = fmaxf(m, row[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = bc;
+    float s = 0.f;
+    for (int64_t i = tid; i < I; i += 256) s += expf(row[i] - m);
+    s = el_group_sum(s, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bc = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const float lse = m + logf(bc);
+    if (mode == 0) {
+        for (int64_t i = tid; i < I; i += 256) row[i] = row[i] - lse;
+        return;
+    }
+    const int32_t user = rows[b];
+    const int64_t r0 = indptr[user], r1 = indptr[user + 1];
+    const float cnt = (float)(r1 - r0);          // sum_i x_i for the binary train row
+    // NLL over the row's positives (reads the ORIGINAL logits: do this before overwriting)
+    float nll = 0.f;
+    for (int64_t e = r0 + tid; e < r1; e += 256) nll += row[indices[e]] - lse;
+    nll = el_group_sum(nll, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = nll;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+        atomicAdd(loss_out, -tot / (double)B);
+    }
+    const float invB = 1.0f / (float)B;
+    for (int64_t i = tid; i < I; i += 256) row[i] = expf(row[i] - lse) * cnt * invB;
+    __syncthreads();
+    for (int64_t e = r0 + tid; e < r1; e += 256) row[indices[e]] -= invB;
+}
+
+// TF dense ApplyAdam arithmetic; resets the gradient buffer
+__global__ __launch_bounds__(256) void k_adam_apply_dense(float* __restrict__ th, float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                          float alpha, float b1, float b2, float eps, int zero_g) {
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const float gg = g[e];
+        float mm = m[e], vv = v[e];
+        mm = mm + (gg - mm) * omb1;
+        vv = vv + (gg * gg - vv) * omb2;
+        th[e] = th[e] - (mm * alpha) / (sqrtf(vv) + eps);
+        m[e] = mm;
+        v[e] = vv;
+        if (zero_g && gg != 0.f) g[e] = 0.f;
+    }
+}
+
+// ---- host orchestration -----------------------------------------------------------------------------------------
+static unsigned grid1d(int64_t n, el_ctx* ctx) {
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)ctx->cus * 16;
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+static int vae_check(const el_vae_state* st, int64_t B) {
+    EL_REQUIRE(st != nullptr, "el_vae: null state");
+    EL_REQUIRE(st->I >= 1 && st->H >= 4 && st->L >= 1 && st->H % 4 == 0, "el_vae: bad dims (H must be a multiple of 4)");
+    EL_REQUIRE(st->H <= 1024, "el_vae: intermediate_dim > 1024 unsupported in this build");
+    EL_REQUIRE(B >= 1 && B <= st->Bmax, "el_vae: batch %lld exceeds Bmax %lld", (long long)B, (long long)st->Bmax);
+    for (int t = 0; t < 8; ++t) EL_REQUIRE(st->w[t] != nullptr, "el_vae: null weight %d", t);
+    EL_REQUIRE(st->h && st->mv && st->z && st->h2 && st->logits && st->rnorm, "el_vae: null activation buffer");
+    return 0;
+}
+
+#define EL_VAE_ENC1(KERN, ...)                                                                          \
+    do {                                                                                                \
+        const int cpl = (st->H / 4 + 63) / 64;                                                          \
+        const unsigned g = (unsigned)((B + 3) / 4);                                                     \
+        if (cpl <= 1) EL_LAUNCH(#KERN, (KERN<1>), dim3(g), dim3(256), 0, s, __VA_ARGS__);               \
+        else if (cpl <= 2) EL_LAUNCH(#KERN, (KERN<2>), dim3(g), dim3(256), 0, s, __VA_ARGS__);          \
+        else if (cpl <= 3) EL_LAUNCH(#KERN, (KERN<3>), dim3(g), dim3(256), 0, s, __VA_ARGS__);          \
+        else EL_LAUNCH(#KERN, (KERN<4>), dim3(g), dim3(256), 0, s, __VA_ARGS__);                        \
+    } while (0)
+
+static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
+                       const int32_t* rows, int64_t B, const float* eps, float anneal, float rate, u64 seed, u32 step,
+                       double* loss_out) {
+    const int H = st->H, L = st->L;
+    const int64_t I = st->I;
+    EL_VAE_ENC1(k_vae_enc1, rows, indptr, indices, st->w[0], st->w[1], B, H, rate, seed, step, st->h, st->rnorm);
+    if (int rc = el_gemm_f32(ctx, s, 0, 0, B, 2 * L, H, st->h, H, st->w[2], 2 * L, st->mv, 2 * L, st->w[3], 0, st->ws, st->ws_bytes)) return rc;
+    EL_LAUNCH("k_vae_sample", k_vae_sample, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->mv, eps, B, L, anneal, st->z, loss_out);
+    if (int rc = el_gemm_f32(ctx, s, 0, 0, B, H, L, st->z, L, st->w[4], H, st->h2, H, st->w[5], 1 /*tanh*/, st->ws, st->ws_bytes)) return rc;
+    if (int rc = el_gemm_f32(ctx, s, 0, 0, B, I, H, st->h2, H, st->w[6], I, st->logits, I, st->w[7], 0, st->ws, st->ws_bytes)) return rc;
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr,
+                                 const int32_t* indices, const int32_t* rows, int64_t B, const float* eps, float anneal,
+                                 float dropout_rate, uint64_t dropout_seed, int32_t step, float lr_t, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = vae_check(st, B)) return rc;
+    EL_REQUIRE(indptr && indices && rows && loss_out && step >= 1, "el_vae_train_step: bad arguments");
+    for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t] && st->m[t] && st->v[t], "el_vae_train_step: optimiser buffers missing");
+    EL_REQUIRE(st->dh2 && st->dmv && st->dh, "el_vae_train_step: backward buffers missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = st->H, L = st->L;
+    const int64_t I = st->I;
+    if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, anneal, dropout_rate, dropout_seed, (u32)step, loss_out)) return rc;
+    // loss + dlogits (in place)
+    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out);
+    float* dl = st->logits;
+    // decoder output layer
+    if (int rc = el_gemm_f32(ctx, s, 1, 0, H, I, B, st->h2, H, dl, I, st->g[6], I, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dW4 = h2^T dl
+    EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, dl, B, I, I, st->g[7]);
+    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dh2 = dl W4^T
+    EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh2, st->h2, B * H);
+    if (int rc = el_gemm_f32(ctx, s, 1, 0, L, H, B, st->z, L, st->dh2, H, st->g[4], H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dW3 = z^T dh2pre
+    EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, s, st->dh2, B, (int64_t)H, (int64_t)H, st->g[5]);
+    // dz reuses the z buffer after dW3 consumed z
+    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, L, H, st->dh2, H, st->w[4], H, st->dz, L, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dz = dh2pre W3^T
+    EL_LAUNCH("k_vae_dmv", k_vae_dmv, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->dz, st->mv, eps, B, L, anneal, st->dmv);
+    if (int rc = el_gemm_f32(ctx, s, 1, 0, H, 2 * L, B, st->h, H, st->dmv, 2 * L, st->g[2], 2 * L, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dWmv
+    EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((2 * L + 255) / 256)), dim3(256), 0, s, st->dmv, B, (int64_t)(2 * L), (int64_t)(2 * L), st->g[3]);
+    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, 2 * L, st->dmv, 2 * L, st->w[2], 2 * L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dh = dmv Wmv^T
+    EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh, st->h, B * H);
+    EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, s, st->dh, B, (int64_t)H, (int64_t)H, st->g[1]);
+    EL_VAE_ENC1(k_vae_dw1, rows, indptr, indices, st->dh, st->rnorm, B, H, dropout_rate, (u64)dropout_seed, (u32)step, st->g[0]);
+    // Adam on the ten variables (W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4)
+    const int64_t sizes[8] = {I * H, H, (int64_t)H * 2 * L, 2 * L, (int64_t)L * H, H, (int64_t)H * I, I};
+    for (int t = 0; t < 8; ++t) {
+        // g[0] (dW1) is accumulated by atomics and must be returned to zero; the others are overwritten every step
+        EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(grid1d(sizes[t], ctx)), dim3(256), 0, s, st->w[t], st->g[t],
+                  st->m[t], st->v[t], sizes[t], lr_t, 0.9f, 0.999f, 1e-7f, t == 0 ? 1 : 0);
+    }
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// log_softmax(logits) of the batch rows into st->logits [B, I] (multi_vae_model.py:145-155; dropout off)
+extern "C" int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr,
+                              const int32_t* indices, const int32_t* rows, int64_t B, const float* eps) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = vae_check(st, B)) return rc;
+    EL_REQUIRE(indptr && indices && rows, "el_vae_predict: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, 0.f, 0.f, 0, 0, nullptr)) return rc;
+    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, st->I, 0, nullptr);
+    EL_CHECK_LAUNCH();
+    return 0;
+}

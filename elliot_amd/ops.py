@@ -351,3 +351,101 @@ def sgd_levels(u_host, i_host, j_host, U, I):
                                     order.ctypes.data_as(C.c_void_p), starts.ctypes.data_as(C.c_void_p),
                                     n + 2, C.byref(nl)), "el_bprsgd_levels_host")
     return order, starts[: nl.value + 1].copy()
+
+
+# ------------------------------------------------------------------------------------------
+# dense layers (fp32 MFMA GEMM) and Mult-VAE
+# ------------------------------------------------------------------------------------------
+ACTS = {None: 0, "none": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
+
+
+def gemm(ctx, A, B, transA=False, transB=False, bias=None, act=None, out=None):
+    """C = act(op(A) op(B) + bias) through el_gemm_f32 (keras Dense forward / backward products)."""
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    Kb = B.shape[1] if transB else B.shape[0]
+    if K != Kb:
+        raise ValueError(f"inner dimensions differ: {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=ctx.device)
+    need = int(ctx.lib.el_gemm_ws_bytes(ctx.handle, int(M), int(N), int(K)))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=ctx.device) if need else None
+    check(ctx.lib.el_gemm_f32(ctx.handle, ctx.stream(), int(bool(transA)), int(bool(transB)), int(M), int(N), int(K),
+                              _ptr(A, torch.float32, "A"), int(A.stride(0)), _ptr(B, torch.float32, "B"),
+                              int(B.stride(0)), _ptr(out, torch.float32, "C"), int(out.stride(0)),
+                              _ptr(bias, torch.float32, "bias"), ACTS[act],
+                              C.c_void_p(ws.data_ptr()) if ws is not None else None, need), "el_gemm_f32")
+    return out
+
+
+class VaeDeviceState:
+    """Variables, Adam slots and activation buffers of the Mult-VAE in HBM (multi_vae_model.py:86-109).
+
+    weights: dict with W1[I,H] b1[H] Wm[H,L] bm[L] Wv[H,L] bv[L] W3[L,H] b3[H] W4[H,I] b4[I] (Keras Dense
+    kernel layout [in, out]); the mean / log-variance heads are stored side by side as one [H, 2L] matrix."""
+    ORDER = ("W1", "b1", "Wmv", "bmv", "W3", "b3", "W4", "b4")
+
+    def __init__(self, ctx, weights, max_batch):
+        self.ctx = ctx
+        dev = ctx.device
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) if isinstance(x, np.ndarray) \
+            else x.to(device=dev, dtype=torch.float32).contiguous().clone()
+        W1, W4 = f(weights["W1"]), f(weights["W4"])
+        self.I, self.H = W1.shape
+        self.L = int(weights["Wm"].shape[1])
+        self.Bmax = int(max_batch)
+        t = {"W1": W1, "b1": f(weights["b1"]),
+             "Wmv": torch.cat([f(weights["Wm"]), f(weights["Wv"])], dim=1).contiguous(),
+             "bmv": torch.cat([f(weights["bm"]), f(weights["bv"])]).contiguous(),
+             "W3": f(weights["W3"]), "b3": f(weights["b3"]), "W4": W4, "b4": f(weights["b4"])}
+        self.w = [t[n] for n in self.ORDER]
+        self.g = [torch.zeros_like(x) for x in self.w]
+        self.m = [torch.zeros_like(x) for x in self.w]
+        self.v = [torch.zeros_like(x) for x in self.w]
+        B, H, L, I = self.Bmax, self.H, self.L, self.I
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.h, self.mv, self.z, self.dz, self.h2 = z(B, H), z(B, 2 * L), z(B, L), z(B, L), z(B, H)
+        self.logits, self.dh2, self.dmv, self.dh, self.rnorm = z(B, I), z(B, H), z(B, 2 * L), z(B, H), z(B)
+        need = max(int(ctx.lib.el_gemm_ws_bytes(ctx.handle, *mnk)) for mnk in
+                   ((B, H, I), (B, L, H), (B, H, 2 * L), (H, 2 * L, B), (L, H, B), (B, 2 * L, H), (H, I, B)))
+        self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.step = 0
+        arr = lambda ts: (C.c_void_p * 8)(*[x.data_ptr() for x in ts])
+        self._c = _lib.VaeState(I=I, H=H, L=L, Bmax=B, w=arr(self.w), g=arr(self.g), m=arr(self.m), v=arr(self.v),
+                                h=self.h.data_ptr(), mv=self.mv.data_ptr(), z=self.z.data_ptr(), dz=self.dz.data_ptr(),
+                                h2=self.h2.data_ptr(), logits=self.logits.data_ptr(), dh2=self.dh2.data_ptr(),
+                                dmv=self.dmv.data_ptr(), dh=self.dh.data_ptr(), rnorm=self.rnorm.data_ptr(),
+                                ws=self._ws.data_ptr(), ws_bytes=self._ws.numel())
+
+    def weights(self):
+        """Host copies keyed like the constructor argument."""
+        L = self.L
+        w = {n: x.cpu().numpy() for n, x in zip(self.ORDER, self.w)}
+        return {"W1": w["W1"], "b1": w["b1"], "Wm": w["Wmv"][:, :L].copy(), "Wv": w["Wmv"][:, L:].copy(),
+                "bm": w["bmv"][:L].copy(), "bv": w["bmv"][L:].copy(), "W3": w["W3"], "b3": w["b3"], "W4": w["W4"],
+                "b4": w["b4"]}
+
+    def train_step(self, train_csr, rows, lr, anneal, eps=None, dropout_rate=0.0, dropout_seed=42):
+        """VariationalAutoEncoder.train_step (multi_vae_model.py:125-142) on users `rows` (int32 device tensor)."""
+        self.step += 1
+        B = rows.numel()
+        check(self.ctx.lib.el_vae_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), *_csr_ptrs(train_csr),
+                                             _ptr(rows, torch.int32, "rows"), int(B), _ptr(eps, torch.float32, "eps"),
+                                             float(anneal), float(dropout_rate), int(dropout_seed), int(self.step),
+                                             float(adam_lr_t(lr, self.step)), _ptr(self.loss, torch.float64)),
+              "el_vae_train_step")
+
+    def predict(self, train_csr, rows, eps=None):
+        """log_softmax(logits) [B, I] view of the activation buffer (multi_vae_model.py:144-155)."""
+        B = rows.numel()
+        check(self.ctx.lib.el_vae_predict(self.ctx.handle, self.ctx.stream(), C.byref(self._c), *_csr_ptrs(train_csr),
+                                          _ptr(rows, torch.int32, "rows"), int(B), _ptr(eps, torch.float32, "eps")),
+              "el_vae_predict")
+        return self.logits[:B]
+
+    def pop_loss(self):
+        v = float(self.loss.item())
+        self.loss.zero_()
+        return v

@@ -3,5 +3,6 @@ from .base_recommender_model import BaseRecommenderModel, init_charger
 from .recommender_utils_mixin import RecMixin
 from .latent_factor_models.BPRMF_batch.BPRMF_batch import BPRMF_batch
 from .latent_factor_models.BPRMF.BPRMF import BPRMF
+from .autoencoders.vae.multi_vae import MultiVAE
 
-__all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF"]
+__all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF", "MultiVAE"]

@@ -213,6 +213,64 @@ int el_dense_topk(el_ctx* ctx, void* stream, const float* preds, int64_t ld,
                   const int64_t* cand_indptr, const int32_t* cand_indices,
                   int32_t k, int32_t* out_idx, float* out_val);
 
+/* ---- dense layers: fp32 MFMA GEMM with fused bias + activation (K9, K12) ----------------- */
+
+/* Replaces: keras.layers.Dense forward/backward products of the neural latent-factor models
+ * (multi_vae_model.py:44-53,72-78; neural_matrix_factorization_model.py:59-64; tf.matmul).
+ *   C[M,N] = act(op(A) op(B) + bias[N]);  act: 0 none, 1 tanh, 2 relu, 3 sigmoid
+ *   transA = 0: A is [M,K] row-major (lda >= K); 1: A is stored [K,M] (lda >= M)
+ *   transB = 0: B is [K,N] row-major (ldb >= N); 1: B is stored [N,K] (ldb >= K)
+ * ws: el_gemm_ws_bytes(...) bytes enable the deterministic split-K path for small M*N.        */
+size_t el_gemm_ws_bytes(el_ctx* ctx, int64_t M, int64_t N, int64_t K);
+int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                const float* bias, int act, void* ws, size_t ws_bytes);
+
+/* ---- Mult-VAE (K9-K11) -------------------------------------------------------------------- */
+
+typedef struct el_vae_state {
+    int64_t I;       /* items = original_dim                (multi_vae_model.py:101)           */
+    int32_t H, L;    /* intermediate_dim, latent_dim         (multi_vae.py:57-58)               */
+    int64_t Bmax;    /* rows the activation buffers can hold                                   */
+    /* variables, gradients and Adam slots in the order
+     * W1[I,H] b1[H] Wmv[H,2L] bmv[2L] W3[L,H] b3[H] W4[H,I] b4[I]
+     * (Wmv = [dense_mean.kernel | dense_log_var.kernel], multi_vae_model.py:48-53)            */
+    float* w[8];
+    float* g[8];     /* g[0] must be zero on entry (scatter target); all are overwritten/zeroed */
+    float* m[8];
+    float* v[8];
+    /* activations / backward buffers, row-major, Bmax rows */
+    float* h;        /* [Bmax,H]   tanh(x~ W1 + b1)             */
+    float* mv;       /* [Bmax,2L]  [mu | logvar]                */
+    float* z;        /* [Bmax,L]                                */
+    float* dz;       /* [Bmax,L]                                */
+    float* h2;       /* [Bmax,H]   tanh(z W3 + b3)              */
+    float* logits;   /* [Bmax,I]   logits -> dlogits / log_softmax (in place) */
+    float* dh2;      /* [Bmax,H]                                */
+    float* dmv;      /* [Bmax,2L]                               */
+    float* dh;       /* [Bmax,H]                                */
+    float* rnorm;    /* [Bmax]     1/||x_b||                    */
+    void* ws;        /* split-K workspace (may be NULL)         */
+    size_t ws_bytes;
+} el_vae_state;
+
+/* Replaces: VariationalAutoEncoder.train_step (multi_vae_model.py:125-142) on the batch whose rows
+ * are users rows[0..B) of the train CSR (what sparse_sampler.py:19-25 yields as dense rows).
+ *   eps          : device float[B,L] standard-normal draws (Sampling, :28) or NULL for eps = 0
+ *   anneal       : KL weight of this step (multi_vae.py:105-108)
+ *   dropout_rate : 1 - dropout_pkeep (multi_vae.py:71); the mask is Philox(dropout_seed, step)
+ *   lr_t         : bias-corrected Adam step size; loss_out: device double[1], loss is ADDED. */
+int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* st,
+                      const int64_t* indptr, const int32_t* indices, const int32_t* rows, int64_t B,
+                      const float* eps, float anneal, float dropout_rate, uint64_t dropout_seed,
+                      int32_t step, float lr_t, double* loss_out);
+
+/* Replaces: VariationalAutoEncoder.predict (multi_vae_model.py:144-155): st->logits[0..B) receives
+ * log_softmax(logits) of users rows[0..B) (dropout off; eps as above).                        */
+int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st,
+                   const int64_t* indptr, const int32_t* indices, const int32_t* rows, int64_t B,
+                   const float* eps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""GPU parity: fp32 MFMA GEMM (el_gemm_f32) and the Mult-VAE train step / predict against the NumPy oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from elliot_amd import ops
+from oracle import multi_vae as ov
+from oracle.sampler import philox4x32_10
+from tests.gpu_util import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(300, 513, 77), (128, 128, 32), (512, 600, 5000), (5, 1030, 600), (600, 260, 512)])
+def test_gemm_matches_fp64(ctx, tA, tB, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.normal(size=N).astype(np.float32)
+    d = ctx.device
+    ref = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
+    got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
+    tol = 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02
+    assert np.abs(got - ref).max() < tol, (np.abs(got - ref).max(), tol)
+    got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB,
+                       bias=torch.from_numpy(bias).to(d), act="tanh"))
+    assert np.abs(got - np.tanh(ref + bias)).max() < tol
+    got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB,
+                       bias=torch.from_numpy(bias).to(d), act="relu"))
+    assert np.abs(got - np.maximum(ref + bias, 0)).max() < tol
+
+
+def test_gemm_unaligned_leading_dims(ctx):
+    rs = np.random.RandomState(5)
+    A = rs.normal(size=(70, 33)).astype(np.float32)       # lda = 33: scalar load path
+    Bm = rs.normal(size=(33, 45)).astype(np.float32)
+    d = ctx.device
+    got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d)))
+    assert np.abs(got - A.astype(np.float64) @ Bm.astype(np.float64)).max() < 1e-4
+
+
+def drop_scale_matrix(users, I, rate, seed, step):
+    out = np.ones((len(users), I), np.float32)
+    if rate <= 0:
+        return out
+    for r, u in enumerate(users):
+        for i in range(I):
+            x = philox4x32_10(int(u), i, step, 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)[0]
+            uni = np.float32(x >> 8) * np.float32(1.0 / 16777216.0)
+            out[r, i] = 0.0 if uni < np.float32(rate) else np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    return out
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.3])
+def test_vae_train_steps_and_predict_match_oracle(ctx, rate):
+    rs = np.random.RandomState(11)
+    U, I, H, L, B = 300, 700, 64, 16, 128
+    X = (rs.rand(U, I) < 0.04).astype(np.float32)
+    X[np.arange(U), rs.randint(0, I, U)] = 1.0               # every user has >= 1 item
+    m = sp.csr_matrix(X)
+    m.sort_indices()
+    w0 = ov.init_weights(I, H, L, 42)
+    for k in ("b1", "bm", "bv", "b3", "b4"):
+        w0[k] = rs.normal(scale=0.01, size=w0[k].shape).astype(np.float32)
+    lr = 0.001
+    st = ops.VaeDeviceState(ctx, w0, max_batch=B)
+    orc = ov.MultiVAEOracle(w0, lr)
+    csr = ops.DeviceCSR(m.indptr, m.indices, I, ctx.device)
+    d = ctx.device
+    for s in range(5):
+        rows = rs.permutation(U)[:B if s != 3 else 37].astype(np.int32)
+        eps = rs.normal(size=(len(rows), L)).astype(np.float32)
+        anneal = min(0.2, s / 10.0)
+        st.train_step(csr, torch.from_numpy(rows).to(d), lr, anneal, eps=torch.from_numpy(eps).to(d),
+                      dropout_rate=rate, dropout_seed=42)
+        got = st.pop_loss()
+        exp = orc.train_step(X[rows], eps, anneal, drop_scale_matrix(rows, I, rate, 42, s + 1) if rate > 0 else None)
+        assert abs(got - exp) <= 1e-4 * abs(exp), (s, got, exp)
+        gw = st.weights()
+        for k in ov.NAMES:
+            err = np.abs(gw[k] - orc.w[k])
+            assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()), float((err > 2e-5).mean()))
+    rows = np.arange(40, 40 + 64, dtype=np.int32)
+    eps = rs.normal(size=(64, L)).astype(np.float32)
+    pred = cpu(st.predict(csr, torch.from_numpy(rows).to(d), eps=torch.from_numpy(eps).to(d)))
+    w_dev = st.weights()
+    ref = ov.log_softmax(ov.forward(w_dev, X[rows], eps, dtype=np.float64)["logits"])
+    assert np.abs(pred - ref).max() < 1e-4
+    assert np.abs(np.exp(pred).sum(1) - 1).max() < 1e-4
