@@ -236,7 +236,7 @@ typedef struct el_vae_state {
      * W1[I,H] b1[H] Wmv[H,2L] bmv[2L] W3[L,H] b3[H] W4[H,I] b4[I]
      * (Wmv = [dense_mean.kernel | dense_log_var.kernel], multi_vae_model.py:48-53)            */
     float* w[8];
-    float* g[8];     /* g[0] must be zero on entry (scatter target); all are overwritten/zeroed */
+    float* g[8];     /* gradients (overwritten every step)                                      */
     float* m[8];
     float* v[8];
     /* activations / backward buffers, row-major, Bmax rows */
@@ -245,7 +245,7 @@ typedef struct el_vae_state {
     float* z;        /* [Bmax,L]                                */
     float* dz;       /* [Bmax,L]                                */
     float* h2;       /* [Bmax,H]   tanh(z W3 + b3)              */
-    float* logits;   /* [Bmax,I]   logits -> dlogits / log_softmax (in place) */
+    float* logits;   /* [Bmax,I]   logits -> dlogits / log_softmax (in place); reused as the dense x~ image */
     float* dh2;      /* [Bmax,H]                                */
     float* dmv;      /* [Bmax,2L]                               */
     float* dh;       /* [Bmax,H]                                */

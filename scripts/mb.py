@@ -15,7 +15,7 @@ from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["topk", "train"])
+    ap.add_argument("what", choices=["topk", "train", "vae", "gemm"])
     ap.add_argument("--users", type=int, default=131072)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--factors", type=int, default=128)
@@ -32,6 +32,48 @@ def main():
     dev = ctx.device
     g = torch.Generator(device=dev)
     g.manual_seed(1)
+    if a.what == "gemm":
+        ctx.timing(True)
+        for (M, N, K, tA, tB) in [(512, 26744, 600, 0, 0), (600, 26744, 512, 1, 0), (512, 600, 26744, 0, 1),
+                                  (4096, 4096, 4096, 0, 0), (8192, 8192, 1024, 0, 1)]:
+            A = torch.randn((K, M) if tA else (M, K), device=dev)
+            Bm = torch.randn((N, K) if tB else (K, N), device=dev)
+            for _ in range(5):
+                ops.gemm(ctx, A, Bm, bool(tA), bool(tB))
+            torch.cuda.synchronize()
+            rep = ctx.timing_report()
+            ms = sum(v[1] for v in rep.values()) / 5
+            print(f"gemm M={M} N={N} K={K} tA={tA} tB={tB}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s  {rep}")
+        return
+    if a.what == "vae":
+        import numpy as np
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import multi_vae as ov
+        U, I, H, L, B = 138493, 26744, 600, 200, 512
+        ip, ix = zipf_csr_device(U, I, dev, mean_log=4.5, sigma_log=1.0, dmin=20, dmax=3000, seed=5)
+        csr = ops.DeviceCSR.from_tensors(ip, ix, I)
+        print("interactions", csr.nnz)
+        st = ops.VaeDeviceState(ctx, ov.init_weights(I, H, L, 1), max_batch=B)
+        rows_all = torch.randperm(U, device=dev, generator=g).to(torch.int32)
+        ctx.timing(True)
+        steps = a.iters
+        for it in range(steps + 2):
+            if it == 2:
+                torch.cuda.synchronize(); ctx.timing_report(); t0 = time.perf_counter()
+            rows = rows_all[it * B:(it + 1) * B].contiguous()
+            eps = torch.randn((B, L), device=dev)
+            st.train_step(csr, rows, 0.001, 0.1, eps=eps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rep = ctx.timing_report()
+        tot = 0
+        for n, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
+            print(f"{n}: {ms / steps:.4f} ms/step ({c // steps} launches/step)")
+            tot += ms / steps
+        flops = B * (2.0 * (H * 2 * L + L * H + H * I) * 3)   # dense GEMM flops fwd + 2x bwd (first layer is sparse)
+        print(f"kernel total {tot:.3f} ms/step, wall {dt / steps * 1e3:.3f} ms/step -> {B / (dt / steps):.0f} users/s, "
+              f"{flops / (tot * 1e-3) / 1e12:.1f} TFLOP/s on the dense part")
+        return
     U, I, F = a.users, a.items, a.factors
     Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * 0.01
     Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * 0.01
