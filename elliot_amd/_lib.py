@@ -54,6 +54,24 @@ class VaeState(C.Structure):
     ]
 
 
+_P4 = C.c_void_p * 4
+
+
+class NmfState(C.Structure):
+    _fields_ = [
+        ("U", C.c_int64), ("I", C.c_int64), ("Bmax", C.c_int64),
+        ("F", C.c_int32), ("E", C.c_int32), ("n_layers", C.c_int32), ("use_mf", C.c_int32), ("use_mlp", C.c_int32),
+        ("head_bias", C.c_int32), ("units", C.c_int32 * 4),
+        ("tab", _P4), ("gtab", _P4), ("mtab", _P4), ("vtab", _P4),
+        ("W", _P4), ("b", _P4), ("gW", _P4), ("gb", _P4), ("mW", _P4), ("vW", _P4), ("mb", _P4), ("vb", _P4),
+        ("hw", _f32p), ("hb", _f32p), ("ghw", _f32p), ("ghb", _f32p), ("mhw", _f32p), ("vhw", _f32p),
+        ("mhb", _f32p), ("vhb", _f32p),
+        ("X0", _f32p), ("dX0", _f32p), ("MF", _f32p), ("dlogit", _f32p),
+        ("act", _P4), ("dact", _P4),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/elliot_hip.h one to one
 PROTOTYPES = {
     "el_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -88,6 +106,11 @@ PROTOTYPES = {
     "el_vae_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(VaeState), _i64p, _i32p, _i32p, C.c_int64, _f32p,
                                     C.c_float, C.c_float, C.c_uint64, C.c_int32, C.c_float, _f64p]),
     "el_vae_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(VaeState), _i64p, _i32p, _i32p, C.c_int64, _f32p]),
+    "el_pointwise_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
+                                      C.c_int64, _i32p, _i32p, _f32p]),
+    "el_nmf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, C.c_int64, _f32p]),
+    "el_nmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, _f32p, C.c_int64,
+                                    C.c_int32, C.c_float, _f64p]),
     "el_dense_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p]),
 }

@@ -1,0 +1,336 @@
+// NeuMF / GMF: point-wise neural matrix factorisation.
+//
+// Replaces NeuralMatrixFactorizationModel.call / train_step / get_recs
+// (neural/NeuMF/neural_matrix_factorization_model.py:75-93,96-106,120-144) and
+// GeneralizedMatrixFactorizationModel.call / train_step (neural/GeneralizedMF/
+// generalized_matrix_factorization_model.py:59-79), plus the GMF sampler
+// (dataset/samplers/pointwise_pos_neg_sampler.py:26-50).
+//
+//   mf   = Umf[u] * Imf[i]                               (element-wise)
+//   mlp  = relu-MLP([Umlp[u] ; Imlp[i]])                 (Dense(relu) x n_layers, el_gemm.hip, MFMA fp32)
+//   y    = sigmoid(w . [mf ; mlp] + b0)                  (GMF: mf only, no bias, w = edge_weight h)
+//   loss = keras BinaryCrossentropy: mean_b -(t log p + (1-t) log(1-p)), p clipped to [1e-7, 1-1e-7]
+// Embedding tables receive IndexedSlices gradients -> Keras Adam sparse apply (every row decays/moves, SURVEY
+// A.4, k_adam_dense of el_bpr.hip); Dense kernels/biases and the head use the dense ApplyAdam arithmetic.
+// Gathers/scatters are HBM-bound row operations (one lane group per sample, 16 B per lane); the MLP is GEMM-bound.
+#include "el_common.h"
+
+extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                           const float* bias, int act, void* ws, size_t ws_bytes);
+// el_bpr.hip / el_vae.hip
+__global__ void k_adam_dense(float* th, float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps);
+__global__ void k_adam_apply_dense(float* th, float* g, float* m, float* v, int64_t n, float alpha, float b1, float b2,
+                                   float eps, int zero_g);
+__global__ void k_colsum(const float* X, int64_t B, int64_t N, int64_t ld, float* out);
+
+// ---- point-wise sampler (GMF) --------------------------------------------------------------------------
+struct PwPhilox {
+    u32 n_lo, n_hi, k0, k1, a, w[4];
+    int have;
+    __device__ __forceinline__ void init(u64 n, u64 seed) {
+        n_lo = (u32)n;
+        n_hi = (u32)(n >> 32);
+        k0 = (u32)seed;
+        k1 = (u32)(seed >> 32);
+        a = 0;
+        have = 0;
+    }
+    __device__ __forceinline__ u32 next() {
+        if (have == 0) {
+            el_philox4 r = el_philox4x32_10(n_lo, n_hi, a, 1u /* stream id: point-wise sampler */, k0, k1);
+            w[0] = r.x;
+            w[1] = r.y;
+            w[2] = r.z;
+            w[3] = r.w;
+            a++;
+            have = 4;
+        }
+        u32 v = w[4 - have];
+        have--;
+        return v;
+    }
+    __device__ __forceinline__ u32 bounded(u32 n) {
+        u32 m = n - 1u;
+        m |= m >> 1;
+        m |= m >> 2;
+        m |= m >> 4;
+        m |= m >> 8;
+        m |= m >> 16;
+        u32 v;
+        do {
+            v = next() & m;
+        } while (v >= n);
+        return v;
+    }
+};
+
+// u ~ U[0,U); coin; positive: i ~ U(pos(u)), label 1; negative: i ~ U[0,I) \ pos(u), label 0
+// (pointwise_pos_neg_sampler.py:33-46)
+__global__ __launch_bounds__(256) void k_pw_sample(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                   int64_t U, int64_t I, u64 seed, u64 first, int64_t n, int32_t* out_u,
+                                                   int32_t* out_i, float* out_y) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    PwPhilox ps;
+    ps.init(first + (u64)t, seed);
+    for (;;) {
+        u32 u = ps.bounded((u32)U);
+        int64_t r0 = indptr[u], r1 = indptr[u + 1];
+        int64_t lui = r1 - r0;
+        if (lui <= 0 || lui >= I) continue;
+        u32 coin = ps.next() >> 31;                       // random.getrandbits(1)
+        int32_t it = -1;
+        if (coin) {
+            it = indices[r0 + ps.bounded((u32)lui)];
+        } else {
+            for (int attempt = 0; attempt < 4096 && it < 0; ++attempt) {
+                int32_t cand = (int32_t)ps.bounded((u32)I);
+                if (!el_row_contains(indices, r0, r1, cand)) it = cand;
+            }
+            if (it < 0) continue;
+        }
+        out_u[t] = (int32_t)u;
+        out_i[t] = it;
+        out_y[t] = coin ? 1.0f : 0.0f;
+        return;
+    }
+}
+
+extern "C" int el_pointwise_sample(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices,
+                                   int64_t U, int64_t I, uint64_t seed, uint64_t first_sample, int64_t n, int32_t* out_u,
+                                   int32_t* out_i, float* out_label) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(pos_indptr && pos_indices && out_u && out_i && out_label, "el_pointwise_sample: null pointer");
+    EL_REQUIRE(U >= 1 && U < 0xffffffffLL && I >= 2 && I < 0x7fffffffLL, "el_pointwise_sample: U/I out of range");
+    if (n <= 0) return 0;
+    EL_LAUNCH("k_pw_sample", k_pw_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_indptr,
+              pos_indices, U, I, (u64)seed, (u64)first_sample, n, out_u, out_i, out_label);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- gather: X0[b] = [Umlp[u] ; Imlp[i]], MF[b] = Umf[u] * Imf[i] -------------------------------------------
+__global__ __launch_bounds__(256) void k_nmf_gather(el_nmf_state st, const int32_t* __restrict__ bu,
+                                                    const int32_t* __restrict__ bi, int64_t n) {
+    // one wave per sample; generic strided loops (F, E need not be multiples of 4)
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int64_t u = bu[b], i = bi[b];
+    if (st.use_mf) {
+        const float* pu = st.tab[0] + u * st.F;
+        const float* pi = st.tab[1] + i * st.F;
+        float* o = st.MF + b * st.F;
+        for (int f = lane; f < st.F; f += 64) o[f] = pu[f] * pi[f];
+    }
+    if (st.use_mlp) {
+        const float* pu = st.tab[2] + u * st.E;
+        const float* pi = st.tab[3] + i * st.E;
+        float* o = st.X0 + b * 2 * st.E;
+        for (int f = lane; f < st.E; f += 64) {
+            o[f] = pu[f];
+            o[st.E + f] = pi[f];
+        }
+    }
+}
+
+// ---- head: logit, probability, BCE, d logit, head gradients --------------------------------------------------
+// one wave per sample.  mode 0: forward only (out_prob[b] = p).  mode 1: training.
+__global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* __restrict__ label, int64_t n, int mode,
+                                                  float* out_prob, double* loss_out) {
+    __shared__ float wsum[4];
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool active = b < n;
+    const int F = st.use_mf ? st.F : 0;
+    const int Hl = st.use_mlp ? st.units[st.n_layers - 1] : 0;
+    const float* hlast = st.use_mlp ? st.act[st.n_layers - 1] + b * (int64_t)Hl : nullptr;
+    float part = 0.f;
+    if (active) {
+        for (int f = lane; f < F; f += 64) part += st.MF[b * F + f] * st.hw[f];
+        for (int f = lane; f < Hl; f += 64) part += hlast[f] * st.hw[F + f];
+    }
+    const float logit = el_group_sum(part, 64) + (st.head_bias ? st.hb[0] : 0.f);
+    const float p = 1.0f / (1.0f + expf(-logit));
+    float myloss = 0.f;
+    if (mode == 0) {
+        if (active && lane == 0) out_prob[b] = p;
+        return;
+    }
+    float dlogit = 0.f;
+    if (active) {
+        const float t = label[b];
+        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);          // keras backend epsilon clipping
+        if (lane == 0) myloss = -(t * logf(pc) + (1.0f - t) * logf(1.0f - pc)) / (float)n;
+        // d/dlogit: zero where the clip is active
+        if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n;
+        if (lane == 0) st.dlogit[b] = dlogit;
+        for (int f = lane; f < F; f += 64) atomicAdd(st.ghw + f, dlogit * st.MF[b * F + f]);
+        if (st.use_mlp) {
+            float* dh = st.dact[st.n_layers - 1] + b * (int64_t)Hl;
+            for (int f = lane; f < Hl; f += 64) {
+                atomicAdd(st.ghw + F + f, dlogit * hlast[f]);
+                dh[f] = dlogit * st.hw[F + f];
+            }
+        }
+        if (st.head_bias && lane == 0) atomicAdd(st.ghb, dlogit);
+    }
+    float wl = el_group_sum(myloss, 64);
+    if (lane == 0) wsum[threadIdx.x >> 6] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) {
+        const double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+        if (tot != 0.0) atomicAdd(loss_out, tot);
+    }
+}
+
+// in place: d <- d * (y > 0)   (relu backward)
+__global__ __launch_bounds__(256) void k_relu_bwd(float* __restrict__ d, const float* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+        if (!(y[t] > 0.f)) d[t] = 0.f;
+}
+
+// embedding gradients (IndexedSlices, duplicates summed): scatter-add one row per sample and table
+__global__ __launch_bounds__(256) void k_nmf_scatter(el_nmf_state st, const int32_t* __restrict__ bu,
+                                                     const int32_t* __restrict__ bi, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int64_t u = bu[b], i = bi[b];
+    if (st.use_mf) {
+        const float dl = st.dlogit[b];
+        const float* pu = st.tab[0] + u * st.F;
+        const float* pi = st.tab[1] + i * st.F;
+        float* gu = st.gtab[0] + u * st.F;
+        float* gi = st.gtab[1] + i * st.F;
+        for (int f = lane; f < st.F; f += 64) {
+            const float s = dl * st.hw[f];
+            atomicAdd(gu + f, s * pi[f]);
+            atomicAdd(gi + f, s * pu[f]);
+        }
+    }
+    if (st.use_mlp) {
+        const float* dx = st.dX0 + b * 2 * st.E;
+        float* gu = st.gtab[2] + u * st.E;
+        float* gi = st.gtab[3] + i * st.E;
+        for (int f = lane; f < st.E; f += 64) {
+            atomicAdd(gu + f, dx[f]);
+            atomicAdd(gi + f, dx[st.E + f]);
+        }
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------
+static unsigned g1(int64_t n, el_ctx* ctx) {
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)ctx->cus * 16;
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
+    EL_REQUIRE(st != nullptr, "el_nmf: null state");
+    EL_REQUIRE(st->use_mf || st->use_mlp, "el_nmf: mf_train and mlp_train can not be False at the same time");
+    EL_REQUIRE(n >= 1 && n <= st->Bmax, "el_nmf: %lld samples exceed Bmax %lld", (long long)n, (long long)st->Bmax);
+    EL_REQUIRE(st->hw != nullptr && st->dlogit != nullptr, "el_nmf: head buffers missing");
+    if (st->use_mf) EL_REQUIRE(st->tab[0] && st->tab[1] && st->MF && st->F >= 1, "el_nmf: MF tables missing");
+    if (st->use_mlp) {
+        EL_REQUIRE(st->tab[2] && st->tab[3] && st->X0 && st->E >= 1, "el_nmf: MLP tables missing");
+        EL_REQUIRE(st->n_layers >= 1 && st->n_layers <= 4, "el_nmf: 1..4 hidden layers supported");
+        for (int l = 0; l < st->n_layers; ++l) EL_REQUIRE(st->W[l] && st->b[l] && st->act[l] && st->units[l] >= 1, "el_nmf: layer %d missing", l);
+    }
+    if (train) {
+        EL_REQUIRE(st->ghw && st->mhw && st->vhw, "el_nmf: head optimiser buffers missing");
+        if (st->use_mlp) EL_REQUIRE(st->dX0 != nullptr, "el_nmf: dX0 missing");
+    }
+    return 0;
+}
+
+static int nmf_forward(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n) {
+    EL_LAUNCH("k_nmf_gather", k_nmf_gather, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
+    if (st->use_mlp) {
+        const float* in = st->X0;
+        int64_t kin = 2 * (int64_t)st->E;
+        for (int l = 0; l < st->n_layers; ++l) {
+            if (int rc = el_gemm_f32(ctx, s, 0, 0, n, st->units[l], kin, in, kin, st->W[l], st->units[l], st->act[l],
+                                     st->units[l], st->b[l], 2 /*relu*/, st->ws, st->ws_bytes)) return rc;
+            in = st->act[l];
+            kin = st->units[l];
+        }
+    }
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// probabilities of the pairs (u[b], i[b]) -- get_recs (neural_matrix_factorization_model.py:120-144)
+extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                              int64_t n, float* out_prob) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (n == 0) return 0;
+    if (int rc = nmf_check(st, n, false)) return rc;
+    EL_REQUIRE(u && i && out_prob, "el_nmf_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
+    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, nullptr, n, 0, out_prob, nullptr);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                                 const float* label, int64_t n, int32_t step, float lr_t, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (n == 0) return 0;
+    if (int rc = nmf_check(st, n, true)) return rc;
+    EL_REQUIRE(u && i && label && loss_out && step >= 1, "el_nmf_train_step: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = st->use_mf ? st->F : 0;
+    const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
+    if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
+    EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
+    if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
+    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out);
+    if (st->use_mlp) {
+        for (int l = st->n_layers - 1; l >= 0; --l) {
+            const int64_t units = st->units[l];
+            const float* in = (l == 0) ? st->X0 : st->act[l - 1];
+            const int64_t kin = (l == 0) ? 2 * (int64_t)st->E : st->units[l - 1];
+            EL_LAUNCH("k_relu_bwd", k_relu_bwd, dim3(g1(n * units, ctx)), dim3(256), 0, s, st->dact[l], st->act[l], n * units);
+            if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+            EL_CHECK_HIP(hipMemsetAsync(st->gb[l], 0, (size_t)units * 4, s));
+            EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((units + 255) / 256), (unsigned)((n + 31) / 32)), dim3(256), 0, s,
+                      st->dact[l], n, units, units, st->gb[l]);
+            float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
+            if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+        }
+    }
+    EL_LAUNCH("k_nmf_scatter", k_nmf_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
+    // optimiser
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    const int64_t rows[4] = {st->U, st->I, st->U, st->I};
+    const int64_t dims[4] = {st->F, st->F, st->E, st->E};
+    for (int t = 0; t < 4; ++t) {
+        const bool on = (t < 2) ? st->use_mf : st->use_mlp;
+        if (!on) continue;
+        const int64_t cnt = rows[t] * dims[t];
+        EL_LAUNCH("k_adam_dense_tab", k_adam_dense, dim3(g1(cnt / 4 + 1, ctx)), dim3(256), 0, s, st->tab[t], st->gtab[t],
+                  st->mtab[t], st->vtab[t], cnt, lr_t, b1, b2, eps);
+    }
+    if (st->use_mlp) {
+        for (int l = 0; l < st->n_layers; ++l) {
+            const int64_t kin = (l == 0) ? 2 * (int64_t)st->E : st->units[l - 1];
+            EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(g1(kin * st->units[l], ctx)), dim3(256), 0, s, st->W[l],
+                      st->gW[l], st->mW[l], st->vW[l], kin * st->units[l], lr_t, b1, b2, eps, 0);
+            EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(g1(st->units[l], ctx)), dim3(256), 0, s, st->b[l], st->gb[l],
+                      st->mb[l], st->vb[l], (int64_t)st->units[l], lr_t, b1, b2, eps, 0);
+        }
+    }
+    EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(g1(F + Hl, ctx)), dim3(256), 0, s, st->hw, st->ghw, st->mhw, st->vhw,
+              (int64_t)(F + Hl), lr_t, b1, b2, eps, 0);
+    if (st->head_bias)
+        EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(1), dim3(256), 0, s, st->hb, st->ghb, st->mhb, st->vhb, (int64_t)1,
+                  lr_t, b1, b2, eps, 0);
+    EL_CHECK_LAUNCH();
+    return 0;
+}

@@ -449,3 +449,112 @@ class VaeDeviceState:
         v = float(self.loss.item())
         self.loss.zero_()
         return v
+
+
+# ------------------------------------------------------------------------------------------
+# NeuMF / GMF
+# ------------------------------------------------------------------------------------------
+def pointwise_sample(ctx, pos, n, seed, first_sample=0):
+    """pointwise_pos_neg_sampler.Sampler.step (pointwise_pos_neg_sampler.py:26-50) on the device."""
+    u = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    i = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    y = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    check(ctx.lib.el_pointwise_sample(ctx.handle, ctx.stream(), *_csr_ptrs(pos), int(pos.n_rows), int(pos.n_cols),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample), int(n), _ptr(u), _ptr(i), _ptr(y)),
+          "el_pointwise_sample")
+    return u, i, y
+
+
+class NmfDeviceState:
+    """NeuMF / GMF variables, optimiser slots and activation buffers in HBM.
+
+    weights: dict with optional "Umf" [U,F], "Imf" [I,F] (MF branch), "Umlp" [U,E], "Imlp" [I,E], "W" list of
+    [in,out] kernels and "b" list of biases (MLP branch), "hw" head weights [F + units[-1]] and optional "hb" [1]."""
+
+    def __init__(self, ctx, weights, max_batch):
+        self.ctx = ctx
+        dev = ctx.device
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        self.use_mf = "Umf" in weights
+        self.use_mlp = "Umlp" in weights
+        self.head_bias = "hb" in weights
+        names = ["Umf", "Imf", "Umlp", "Imlp"]
+        self.tab = [f(weights[n]) if n in weights else None for n in names]
+        ref = self.tab[0] if self.use_mf else self.tab[2]
+        self.U = ref.shape[0]
+        self.I = (self.tab[1] if self.use_mf else self.tab[3]).shape[0]
+        self.F = self.tab[0].shape[1] if self.use_mf else 0
+        self.E = self.tab[2].shape[1] if self.use_mlp else 0
+        z = lambda t: None if t is None else torch.zeros_like(t)
+        self.gtab, self.mtab, self.vtab = [z(t) for t in self.tab], [z(t) for t in self.tab], [z(t) for t in self.tab]
+        self.W = [f(w) for w in weights.get("W", [])]
+        self.b = [f(b) for b in weights.get("b", [])]
+        self.units = [w.shape[1] for w in self.W]
+        self.gW, self.mW, self.vW = [z(w) for w in self.W], [z(w) for w in self.W], [z(w) for w in self.W]
+        self.gb, self.mb, self.vb = [z(b) for b in self.b], [z(b) for b in self.b], [z(b) for b in self.b]
+        self.hw = f(weights["hw"])
+        self.hb = f(weights["hb"]) if self.head_bias else None
+        self.ghw, self.mhw, self.vhw = z(self.hw), z(self.hw), z(self.hw)
+        self.ghb, self.mhb, self.vhb = z(self.hb), z(self.hb), z(self.hb)
+        B = self.Bmax = int(max_batch)
+        zz = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.X0 = zz(B, 2 * self.E) if self.use_mlp else None
+        self.dX0 = zz(B, 2 * self.E) if self.use_mlp else None
+        self.MF = zz(B, self.F) if self.use_mf else None
+        self.dlogit = zz(B)
+        self.act = [zz(B, n) for n in self.units]
+        self.dact = [zz(B, n) for n in self.units]
+        dims = [2 * self.E] + self.units
+        need = 16
+        for l in range(len(self.units)):
+            for mnk in ((B, dims[l + 1], dims[l]), (dims[l], dims[l + 1], B), (B, dims[l], dims[l + 1])):
+                need = max(need, int(ctx.lib.el_gemm_ws_bytes(ctx.handle, *mnk)))
+        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.step = 0
+        p = lambda t: None if t is None else t.data_ptr()
+        a4 = lambda ts: _lib._P4(*([p(t) for t in ts] + [None] * (4 - len(ts))))
+        self._c = _lib.NmfState(
+            U=self.U, I=self.I, Bmax=B, F=self.F, E=self.E, n_layers=len(self.units), use_mf=int(self.use_mf),
+            use_mlp=int(self.use_mlp), head_bias=int(self.head_bias),
+            units=(C.c_int32 * 4)(*(self.units + [0] * (4 - len(self.units)))),
+            tab=a4(self.tab), gtab=a4(self.gtab), mtab=a4(self.mtab), vtab=a4(self.vtab),
+            W=a4(self.W), b=a4(self.b), gW=a4(self.gW), gb=a4(self.gb), mW=a4(self.mW), vW=a4(self.vW),
+            mb=a4(self.mb), vb=a4(self.vb),
+            hw=p(self.hw), hb=p(self.hb), ghw=p(self.ghw), ghb=p(self.ghb), mhw=p(self.mhw), vhw=p(self.vhw),
+            mhb=p(self.mhb), vhb=p(self.vhb), X0=p(self.X0), dX0=p(self.dX0), MF=p(self.MF), dlogit=p(self.dlogit),
+            act=a4(self.act), dact=a4(self.dact), ws=self._ws.data_ptr(), ws_bytes=self._ws.numel())
+
+    def weights(self):
+        out = {}
+        for n, t in zip(["Umf", "Imf", "Umlp", "Imlp"], self.tab):
+            if t is not None:
+                out[n] = t.cpu().numpy()
+        if self.use_mlp:
+            out["W"] = [w.cpu().numpy() for w in self.W]
+            out["b"] = [b.cpu().numpy() for b in self.b]
+        out["hw"] = self.hw.cpu().numpy()
+        if self.head_bias:
+            out["hb"] = self.hb.cpu().numpy()
+        return out
+
+    def train_step(self, u, i, label, lr):
+        self.step += 1
+        n = u.numel()
+        check(self.ctx.lib.el_nmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                             _ptr(i, torch.int32), _ptr(label, torch.float32), int(n), int(self.step),
+                                             float(adam_lr_t(lr, self.step)), _ptr(self.loss, torch.float64)),
+              "el_nmf_train_step")
+
+    def forward(self, u, i, out=None):
+        n = u.numel()
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.ctx.device)
+        check(self.ctx.lib.el_nmf_forward(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                          _ptr(i, torch.int32), int(n), _ptr(out, torch.float32)), "el_nmf_forward")
+        return out
+
+    def pop_loss(self):
+        v = float(self.loss.item())
+        self.loss.zero_()
+        return v

@@ -271,6 +271,50 @@ int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st,
                    const int64_t* indptr, const int32_t* indices, const int32_t* rows, int64_t B,
                    const float* eps);
 
+/* ---- NeuMF / GMF (K12-K13) ----------------------------------------------------------------- */
+
+typedef struct el_nmf_state {
+    int64_t U, I, Bmax;      /* users, items, samples the activation buffers can hold                   */
+    int32_t F, E;            /* mf embedding size, mlp embedding size (NeuMF: E = F)                    */
+    int32_t n_layers;        /* hidden Dense(relu) layers of the MLP tower (NeuMF: 3 = 4F, 2F, F)       */
+    int32_t use_mf, use_mlp; /* is_mf_train / is_mlp_train (neural_matrix_factorization.py:64-65)       */
+    int32_t head_bias;       /* NeuMF predict_layer = Dense(1) has a bias; GMF's edge weight h has none */
+    int32_t units[4];
+    /* embedding tables U_MF[U,F] I_MF[I,F] U_MLP[U,E] I_MLP[I,E] (+ gradient accumulators, zero on entry
+     * and exit, and Adam slots): neural_matrix_factorization_model.py:40-51                            */
+    float* tab[4];  float* gtab[4]; float* mtab[4]; float* vtab[4];
+    /* Dense layers, Keras layout kernel [in, out], bias [out]                                          */
+    float* W[4];  float* b[4];  float* gW[4]; float* gb[4];
+    float* mW[4]; float* vW[4]; float* mb[4]; float* vb[4];
+    /* head: w [F + units[last]] (GMF: h [F]), optional scalar bias                                     */
+    float* hw; float* hb; float* ghw; float* ghb; float* mhw; float* vhw; float* mhb; float* vhb;
+    /* activations, Bmax rows */
+    float* X0;      /* [Bmax, 2E]  concat(U_MLP[u], I_MLP[i])     */
+    float* dX0;     /* [Bmax, 2E]                                 */
+    float* MF;      /* [Bmax, F]   U_MF[u] * I_MF[i]              */
+    float* dlogit;  /* [Bmax]                                     */
+    float* act[4];  /* [Bmax, units[l]]                           */
+    float* dact[4];
+    void* ws; size_t ws_bytes;   /* GEMM split-K workspace */
+} el_nmf_state;
+
+/* Replaces: pointwise_pos_neg_sampler.Sampler.step (dataset/samplers/pointwise_pos_neg_sampler.py:26-50):
+ * u uniform, fair coin, positive item of u (label 1) or rejected-uniform negative (label 0); Philox stream. */
+int el_pointwise_sample(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices,
+                        int64_t U, int64_t I, uint64_t seed, uint64_t first_sample, int64_t n,
+                        int32_t* out_u, int32_t* out_i, float* out_label);
+
+/* Replaces: NeuralMatrixFactorizationModel.get_recs / GeneralizedMatrixFactorizationModel.get_recs on an
+ * explicit pair list (neural_matrix_factorization_model.py:120-144): out_prob[b] = sigmoid(...) of (u[b], i[b]). */
+int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                   int64_t n, float* out_prob);
+
+/* Replaces: train_step of both models (neural_matrix_factorization_model.py:96-106;
+ * generalized_matrix_factorization_model.py:68-79): forward, keras BinaryCrossentropy (batch mean), backward,
+ * Adam.  label: float[n] in {0,1}.  loss_out: device double[1], loss is ADDED.                          */
+int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                      const float* label, int64_t n, int32_t step, float lr_t, double* loss_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,79 @@
+"""GPU parity: NeuMF / GMF train step and pair scoring (el_nmf_*) and the point-wise sampler against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from elliot_amd import ops
+from elliot_amd.synthetic import zipf_csr
+from oracle import neumf as on
+from tests.gpu_util import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def run_steps(ctx, w0, U, I, steps=5, B=700, lr=0.002, seed=0):
+    rs = np.random.RandomState(seed)
+    st = ops.NmfDeviceState(ctx, w0, max_batch=B)
+    orc = on.NeuMFOracle(w0, lr)
+    d = ctx.device
+    for s in range(steps):
+        n = B if s != 2 else 33
+        u = rs.randint(0, U, n).astype(np.int32)
+        i = rs.randint(0, min(I, 30), n).astype(np.int32)       # hot items -> duplicate rows
+        y = rs.randint(0, 2, n).astype(np.float32)
+        st.train_step(torch.from_numpy(u).to(d), torch.from_numpy(i).to(d), torch.from_numpy(y).to(d), lr)
+        got = st.pop_loss()
+        exp = orc.train_step(u, i, y)
+        assert abs(got - exp) <= 1e-4 * max(abs(exp), 1e-3), (s, got, exp)
+        gw = st.weights()
+        for k, v in orc.w.items():
+            pairs = zip(gw[k], v) if isinstance(v, list) else [(gw[k], v)]
+            for a, b in pairs:
+                err = np.abs(a - b)
+                assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()), float((err > 2e-5).mean()))
+    return st, orc
+
+
+@pytest.mark.parametrize("F", [8, 32, 10])
+def test_neumf_train_matches_oracle(ctx, F):
+    U, I = 200, 150
+    st, orc = run_steps(ctx, on.init_neumf(U, I, F, 3), U, I)
+    # pair scoring == oracle predict on the device's weights
+    rs = np.random.RandomState(9)
+    u = rs.randint(0, U, 500).astype(np.int32)
+    i = rs.randint(0, I, 500).astype(np.int32)
+    d = ctx.device
+    p = cpu(st.forward(torch.from_numpy(u).to(d), torch.from_numpy(i).to(d)))
+    ref = on.forward(st.weights(), u.astype(np.int64), i.astype(np.int64), dtype=np.float64)["p"]
+    assert np.abs(p - ref).max() < 1e-5
+
+
+def test_gmf_train_matches_oracle(ctx):
+    U, I = 300, 120
+    run_steps(ctx, on.init_gmf(U, I, 16, 5), U, I)
+
+
+def test_neumf_branches(ctx):
+    U, I, F = 100, 90, 8
+    w = on.init_neumf(U, I, F, 2)
+    mlp_only = {k: v for k, v in w.items() if k not in ("Umf", "Imf")}
+    mlp_only["hw"] = w["hw"][F:].copy()
+    run_steps(ctx, mlp_only, U, I, steps=3)
+    mf_only = {"Umf": w["Umf"], "Imf": w["Imf"], "hw": w["hw"][:F].copy(), "hb": w["hb"]}
+    run_steps(ctx, mf_only, U, I, steps=3)
+
+
+def test_pointwise_sampler_invariants(ctx):
+    U, I = 3000, 2000
+    indptr, indices = zipf_csr(U, I, mean_log=2.5, sigma_log=0.7, dmin=1, dmax=200, seed=4)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    n = 200000
+    u, i, y = (cpu(t) for t in ops.pointwise_sample(ctx, pos, n, seed=42))
+    assert abs(y.mean() - 0.5) < 0.01                               # fair coin (pointwise_pos_neg_sampler.py:39)
+    rows = [set(indices[indptr[x]:indptr[x + 1]].tolist()) for x in range(U)]
+    for uu, ii, yy in zip(u[:20000], i[:20000], y[:20000]):
+        assert (ii in rows[uu]) == (yy == 1.0)
+    cnt = np.bincount(u, minlength=U)
+    assert cnt.std() < 1.25 * np.sqrt(n / U)
+    u2, i2, y2 = (cpu(t) for t in ops.pointwise_sample(ctx, pos, 100, seed=42, first_sample=500))
+    assert np.array_equal(u2, u[500:600]) and np.array_equal(i2, i[500:600]) and np.array_equal(y2, y[500:600])

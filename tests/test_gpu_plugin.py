@@ -202,3 +202,60 @@ def test_multivae_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
         hits += got_items == exp_items
         assert set(got_items).isdisjoint({data.private_items[int(i)] for i in m.indices[m.indptr[u]:m.indptr[u + 1]]})
     assert hits >= 0.97 * U          # fp32 vs fp64 scores: only near-ties at the k-th place may differ
+
+
+def test_neumf_and_gmf_plugins_end_to_end(ctx, tmp_path):
+    import random
+    from elliot_amd.recommender import GMF, NeuMF
+    from oracle import neumf as on
+    data, cfg = make_data(tmp_path)
+    U, I, F, lr = data.num_users, data.num_items, 8, 0.002
+    # ---- NeuMF: m = 1 negatives, CPU replay of the reference's epoch construction (custom_sampler.py:27-48)
+    w0 = on.init_neumf(U, I, F, 11)
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=1, batch_size=256, mf_factors=F, lr=lr, m=1, seed=42)
+    model = NeuMF(data=data, config=cfg, params=params, init_weights=w0)
+    assert model.name.startswith("NeuMF_seed=42_e=1_bs=256_lr=0$002_mffactors=8_drop=0_mftrain=True_mlptrain=True_m=1")
+    model.train()
+    np.random.seed(42)
+    random.seed(42)
+    itd = data.i_train_dict
+    ui = {u: list(set(itd[u])) for u in itd}
+    pos = {(u, i, 1) for u, items in ui.items() for i in items}
+    neg = set()
+    for u, i, _ in pos:
+        j = np.random.randint(I)
+        while j in ui[u]:
+            j = np.random.randint(I)
+        neg.add((u, j, 0))
+    samples = list(pos)
+    samples.extend(list(neg))
+    samples = np.asarray(random.sample(samples, len(samples)))
+    orc = on.NeuMFOracle(w0, lr)
+    tot = 0.0
+    for s in range(0, len(samples), 256):
+        b = samples[s:s + 256]
+        tot += orc.train_step(b[:, 0], b[:, 1], b[:, 2].astype(np.float32))
+    assert abs(model._losses[0] - tot) <= 1e-4 * abs(tot), (model._losses, tot)
+    gw = model._model.state.weights()
+    assert (np.abs(gw["Umf"] - orc.w["Umf"]) > 5e-5).mean() < 5e-3
+    assert (np.abs(gw["W"][0] - orc.w["W"][0]) > 5e-5).mean() < 5e-3
+    # recommendations: probabilities of every (user, item) pair from the device weights, masked top-k
+    _, recs = model.get_recommendations(10)
+    ug, ig = np.repeat(np.arange(U), I), np.tile(np.arange(I), U)
+    ref = on.forward(gw, ug, ig, dtype=np.float64)["p"].reshape(U, I)
+    m = data.sp_i_train
+    agree = 0
+    for u in range(U):
+        masked = ref[u].copy()
+        masked[m.indices[m.indptr[u]:m.indptr[u + 1]]] = -np.inf
+        exp_items = [data.private_items[int(i)] for i in np.lexsort((np.arange(I), -masked))[:10]]
+        agree += [it for it, _ in recs[data.private_users[u]]] == exp_items
+    assert agree >= 0.95 * U
+    # ---- GMF: device Philox point-wise sampler; loss decreases and results are well-formed
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=3, batch_size=512, mf_factors=16, lr=0.01, seed=42)
+    g = GMF(data=data, config=cfg, params=params)
+    g.train()
+    assert g.name.startswith("GeneralizedMF_seed=42_e=3_bs=512_lr=0$01_mffactors=16_isedgeweighttrain=True")
+    per_epoch = [l * (n + 1) for n, l in enumerate(g._losses)]
+    assert per_epoch[-1] < per_epoch[0]
+    assert 0.0 <= g.get_results()[10]["test_results"]["nDCG"] <= 1.0
