@@ -25,7 +25,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from elliot_amd import ops  # noqa: E402
+from elliot_amd import ops, parallel  # noqa: E402
 from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -134,39 +134,46 @@ def main():
     Bi = torch.zeros(I, device=dev)
 
     # item shard of this rank (north_star: tables shard by item; N=1 -> the whole catalogue)
-    lo = (I * rank) // world
-    hi = (I * (rank + 1)) // world
-    st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
-    del Gu, Gi, Bi
+    lo, hi = parallel.item_range(I, rank, world)
     lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
     trip = tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3))
     sample_ctr = [0]
+    coll = parallel._Collectives()
+    if world == 1:
+        st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
+        pos_train = pos
 
-    def train_step():
-        ops.bpr_sample(ctx, pos, B, seed=42 + rank, first_sample=sample_ctr[0], out=trip)
-        sample_ctr[0] += B
-        st.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b, algo=args.train_algo)
+        def train_step():
+            ops.bpr_sample(ctx, pos, B, seed=42, first_sample=sample_ctr[0], out=trip)
+            sample_ctr[0] += B
+            st.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b, algo=args.train_algo)
+
+        pop_loss = st.pop_loss
+    else:
+        # item-sharded training: B triplets PER RANK with positive and negative inside the rank's shard, all-gather of
+        # the per-triplet user-gradient rows, identical user-table replicas (elliot_amd/parallel.py)
+        sip, six = parallel.shard_csr(indptr, indices, lo, hi)
+        pos_train = ops.DeviceCSR.from_tensors(sip, six, hi - lo)
+        be = parallel.HipBackend(ctx, Gu, Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), optimizer=args.opt)
+        trainer = parallel.ShardedBprmf(be, coll)
+        st = be.state
+
+        def train_step():
+            ops.bpr_sample(ctx, pos_train, B, seed=42 + rank, first_sample=sample_ctr[0], out=trip)
+            sample_ctr[0] += B
+            trainer.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b)
+
+        pop_loss = trainer.pop_loss
+    del Gu, Gi, Bi
 
     Ub = min(args.topk_block, U)
     n_blocks = max(1, U // Ub)
-    out_idx = torch.empty((Ub, k), dtype=torch.int32, device=dev)
-    out_val = torch.empty((Ub, k), dtype=torch.float32, device=dev)
     blk = [0]
-    Gi_shard = st.Gi[lo:hi]
-    Bi_shard = st.Bi[lo:hi]
 
     def topk_step():
         s = (blk[0] % n_blocks) * Ub
         blk[0] += 1
-        pi, pv = ops.score_topk(ctx, st.Gu, Gi_shard, Bi_shard, s, s + Ub, k, excl=pos, item_offset=lo,
-                                algo="mfma", out_idx=out_idx, out_val=out_val)
-        if world > 1:
-            import torch.distributed as dist
-            gi = torch.empty((world, Ub, k), dtype=torch.int32, device=dev)
-            gv = torch.empty((world, Ub, k), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(gi, pi)
-            dist.all_gather_into_tensor(gv, pv)
-            ops.topk_merge(ctx, gi, gv)
+        parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo="mfma")
 
     def timed(fn, warmup, steps):
         for _ in range(warmup):
@@ -184,13 +191,13 @@ def main():
 
     K, W = args.steps, args.warmup
     dt_train, rep_train = timed(train_step, W, K)
-    loss = st.pop_loss()
+    loss = pop_loss()
     dt_topk, rep_topk = timed(topk_step, W, K)
 
     if rank != 0:
         return
     # ---------------- metrics ---------------------------------------------------------------------
-    pairs_per_s = world * B * K / dt_train if world == 1 else B * K * world / dt_train
+    pairs_per_s = world * B * K / dt_train            # B triplets per rank and step
     users_per_s = Ub * K / dt_topk
 
     def dominant(rep):
@@ -205,6 +212,8 @@ def main():
         "k_bprmf_fwd_bwd": B * (24.0 * F + 28.0),             # 3 rows read + 3 gradient rows written (+ idx, bias)
         "k_bpr_user_seg": B * (16.0 * F + 28.0),              # gamma_u, gamma_i, gamma_j read + dGu row written
         "k_bpr_item_seg": 2.0 * B * (8.0 * F + 12.0),         # gamma_u(b) read + dGi row written, per occurrence
+        "k_bpr_triplet_rows": B * (16.0 * F + 28.0),          # 3 rows read, dGu row written
+        "k_rows_segsum": world * B * 8.0 * F,                 # gathered row read + reduced row written
         "rocprim_radix_sort_pairs": 3.0 * B * 16.0,
         "k_rows_apply": B * (72.0 * F + 60.0) - B * (24.0 * F + 28.0) if args.opt == "adam_lazy" else B * (24.0 * F),
         "k_bpr_sample": B * 48.0,
@@ -224,16 +233,19 @@ def main():
     line = {
         "metric": "BPR-MF positive-pairs/sec + full-catalog top-k users/sec",
         "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt_train / K * 1e3, "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": dt_train / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
                    else f"BPRMF d={F}, synthetic {U} users x {I} items",
                    "users": U, "items": I, "factors": F, "interactions": int(pos.nnz), "batch": B,
-                   "optimizer": args.opt, "topk_block": Ub, "k": k,
-                   "parallelism": "single" if world == 1 else f"item-shard x{world}"},
-        "loss_per_pair_last": loss / (B * (K + W)),
+                   "batch_per_gpu": B, "optimizer": args.opt, "topk_block": Ub, "k": k,
+                   "parallelism": "single" if world == 1 else
+                   f"item-shard x{world}: train = {B} triplets/rank + all-gather of user-gradient rows (weak); "
+                   f"top-k = all users vs I/{world} items per rank + all-gather/merge (strong)"},
+        "loss_per_pair_last": loss / (B * world * (K + W)),
         "roofline": roof_train,
-        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "roofline": roof_topk},
+        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "scaling": "strong",
+                 "roofline": roof_topk},
     }
     if world == 1 and not args.no_cpu_baseline:
         host = {"Gu": st.Gu.cpu().numpy(), "Gi": st.Gi.cpu().numpy(), "Bi": st.Bi.cpu().numpy(),

@@ -402,3 +402,288 @@ extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bp
     if (rc) return rc;
     return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
 }
+
+// =====================================================================================================
+// Item-sharded training (new design -- the reference is single-device).
+// Rank r holds the item rows [lo_r, hi_r) (+ their optimiser state) and a replica of the user table.  One step:
+//   1. el_bprmf_shard_grads   local triplets (positives and negatives inside the shard): s_b, loss, the item-row
+//                             gradients (sorted segments, as above) and ONE user-gradient row per triplet
+//                             dU[b,:] = s_b (gamma_i - gamma_j) + l_w gamma_u          (no reduction yet)
+//   2. RCCL all-gather of (u[b], dU[b,:]) over the ranks                      (torch.distributed, parallel.py)
+//   3. el_rows_segment_sum    every rank reduces the gathered rows by user id into its dense dGu -- the same
+//                             rows in the same order on every rank, so the user-table replicas stay bit-identical
+//   4. el_bprmf_apply         optimiser on the replicated user table and the local item shard
+// The gradient of the global batch is the sum over triplets, so G ranks x B triplets equal one rank with the
+// concatenated batch (tests/test_dist_gloo.py checks exactly that).
+// =====================================================================================================
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bpr_triplet_rows(el_bprmf_state st, const int32_t* __restrict__ bu,
+                                                          const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
+                                                          int64_t B, float l_w, float l_b, int lpt, float* __restrict__ s_out,
+                                                          float* __restrict__ dU, double* loss_out) {
+    const int F = st.F;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const bool active = b < B;
+    int32_t uu = 0, ii = 0, jj = 0;
+    if (active) {
+        uu = bu[b];
+        ii = bi_[b];
+        jj = bj[b];
+    }
+    const float* pu = st.Gu + (int64_t)uu * F;
+    const float* pi = st.Gi + (int64_t)ii * F;
+    const float* pj = st.Gi + (int64_t)jj * F;
+    float gu[CPL][VW], gi[CPL][VW], gj[CPL][VW];
+    float dpi = 0.f, dpj = 0.f, nu = 0.f, ni = 0.f, nj = 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) gu[q][x] = gi[q][x] = gj[q][x] = 0.f;
+        if (active && e < F) {
+            ldv<VW>(pu + e, gu[q]);
+            ldv<VW>(pi + e, gi[q]);
+            ldv<VW>(pj + e, gj[q]);
+        }
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+            dpi += gu[q][x] * gi[q][x];
+            dpj += gu[q][x] * gj[q][x];
+            nu += gu[q][x] * gu[q][x];
+            ni += gi[q][x] * gi[q][x];
+            nj += gj[q][x] * gj[q][x];
+        }
+    }
+    dpi = el_group_sum(dpi, lpt);
+    dpj = el_group_sum(dpj, lpt);
+    nu = el_group_sum(nu, lpt);
+    ni = el_group_sum(ni, lpt);
+    nj = el_group_sum(nj, lpt);
+    float beta_i = 0.f, beta_j = 0.f;
+    if (active) {
+        beta_i = st.Bi[ii];
+        beta_j = st.Bi[jj];
+    }
+    const float d = (beta_i + dpi) - (beta_j + dpj);
+    const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+    float sb = 0.f;
+    if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+    float myloss = 0.f;
+    if (active) {
+        if (sub == 0) {
+            s_out[b] = sb;
+            myloss = el_softplus_s(-dc) + l_w * 0.5f * (nu + ni + nj) + l_b * 0.5f * beta_i * beta_i +
+                     (l_b * 0.5f * beta_j * beta_j) / 10.0f;
+        }
+        float* o = dU + b * F;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) {
+                float v[VW];
+#pragma unroll
+                for (int x = 0; x < VW; ++x) v[x] = sb * (gi[q][x] - gj[q][x]) + l_w * gu[q][x];
+                stv<VW>(o + e, v);
+            }
+        }
+    }
+    __shared__ float wsum[4];
+    float wl = el_group_sum(myloss, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+        if (tot != 0.0) atomicAdd(loss_out, tot);
+    }
+}
+
+// out[id,:] = sum of rows[pos,:] over the sorted (id, pos) pairs.  One lane group per sorted position; only the
+// group sitting on a segment HEAD works and walks its whole segment in order -> plain stores, no atomics, the same
+// summation order on every rank (user segments are short: Poisson(B/U)).
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_rows_segsum(const u32* __restrict__ keys, const u32* __restrict__ vals,
+                                                     const float* __restrict__ rows, int64_t n, int F, int chunk, int lpt,
+                                                     float* __restrict__ out) {
+    (void)chunk;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pos0 = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    if (pos0 >= n) return;
+    const u32 key = keys[pos0];
+    if (pos0 > 0 && keys[pos0 - 1] == key) return;      // not a head
+    float acc[CPL][VW];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+        for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+    for (int64_t pos = pos0; pos < n && keys[pos] == key; ++pos) {
+        const float* r = rows + (int64_t)vals[pos] * F;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) {
+                float t[VW];
+                ldv<VW>(r + e, t);
+#pragma unroll
+                for (int x = 0; x < VW; ++x) acc[q][x] += t[x];
+            }
+        }
+    }
+    float* g = out + (int64_t)key * F;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+        if (e < F) stv<VW>(g + e, acc[q]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iota_keys(const int32_t* __restrict__ ids, int64_t n, u32* key, u32* val) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    key[t] = (u32)ids[t];
+    val[t] = (u32)t;
+}
+
+extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+                                    const int32_t* i, const int32_t* j, int64_t B, float l_w, float l_b, int32_t step,
+                                    float* dU, double* loss_out, void* ws, size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    bool vec = false, rows_mode = false;
+    if (int rc = el_bprmf_check_state(stp, u, i, j, loss_out, EL_OPT_SGD, step, &vec, &rows_mode)) return rc;
+    EL_REQUIRE(dU != nullptr, "el_bprmf_shard_grads: null dU");
+    if (B <= 0) return 0;
+    const el_bprmf_state st = *stp;
+    vec = vec && (((uintptr_t)dU) % 16 == 0);
+    SortedWs w;
+    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_bprmf_shard_grads: rocprim size query failed");
+    EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_shard_grads: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    int cpl = 1;
+    const int lpt = el_pick_lpt(st.F, vec ? 4 : 1, &cpl);
+    EL_REQUIRE(cpl <= 4, "el_bprmf_shard_grads: F=%d too large for this build", st.F);
+    const unsigned gridT = (unsigned)((B * lpt + 255) / 256);
+#define EL_TR(VW_, CPL_) \
+    EL_LAUNCH("k_bpr_triplet_rows", (k_bpr_triplet_rows<VW_, CPL_>), dim3(gridT), dim3(256), 0, s, st, u, i, j, B, l_w, l_b, lpt, w.s, dU, loss_out)
+    if (vec) {
+        if (cpl == 1) EL_TR(4, 1); else if (cpl == 2) EL_TR(4, 2); else EL_TR(4, 4);
+    } else {
+        if (cpl == 1) EL_TR(1, 1); else if (cpl == 2) EL_TR(1, 2); else EL_TR(1, 4);
+    }
+#undef EL_TR
+    // item side: sorted segments over the local shard
+    EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
+              w.keyI_in, w.valI_in);
+    {
+        ElKernelTimer t("rocprim_radix_sort_pairs", s);
+        size_t tb = w.tmp_bytes;
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)(2 * B), 0,
+                                               bits_for(st.I), s));
+    }
+    SegParams pi;
+    memset(&pi, 0, sizeof(pi));
+    pi.st = st;
+    pi.st.tGu = pi.st.tGi = pi.st.tBi = nullptr;
+    pi.bi = i;
+    pi.bj = j;
+    pi.bu = u;
+    pi.s = w.s;
+    pi.l_w = l_w;
+    pi.l_b = l_b;
+    pi.step = step;
+    pi.loss_out = loss_out;
+    pi.keys = w.keyI;
+    pi.vals = w.valI;
+    pi.n = 2 * B;
+    pi.chunk = 16;
+    pi.lpt = lpt;
+    const int64_t gi = (2 * B + pi.chunk - 1) / pi.chunk;
+    const unsigned gridI = (unsigned)((gi * lpt + 255) / 256);
+#define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_>), dim3(gridI), dim3(256), 0, s, pi)
+    if (vec) {
+        if (cpl == 1) EL_IS(4, 1); else if (cpl == 2) EL_IS(4, 2); else EL_IS(4, 4);
+    } else {
+        if (cpl == 1) EL_IS(1, 1); else if (cpl == 2) EL_IS(1, 2); else EL_IS(1, 4);
+    }
+#undef EL_IS
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+static int carve_rows_ws(int64_t n, int64_t n_ids, char* base, u32** kin, u32** vin, u32** kout, u32** vout, void** tmp,
+                         size_t* tmp_bytes, size_t* total) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    *kin = (u32*)take((size_t)n * 4);
+    *vin = (u32*)take((size_t)n * 4);
+    *kout = (u32*)take((size_t)n * 4);
+    *vout = (u32*)take((size_t)n * 4);
+    size_t t1 = 0;
+    u32* np = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, t1, np, np, np, np, (unsigned)n, 0, bits_for(n_ids), (hipStream_t)0) != hipSuccess) return 1;
+    *tmp_bytes = t1;
+    *tmp = take(t1);
+    *total = off;
+    return 0;
+}
+
+extern "C" size_t el_rows_segment_sum_ws_bytes(int64_t n, int64_t n_ids) {
+    if (n <= 0) return 0;
+    u32 *a, *b, *c, *d;
+    void* t;
+    size_t tb, total;
+    if (carve_rows_ws(n, n_ids, nullptr, &a, &b, &c, &d, &t, &tb, &total)) return 0;
+    return total;
+}
+
+// out[ids[p], :] = sum over p of rows[p, :] per id (touched rows are overwritten; stable order, deterministic)
+extern "C" int el_rows_segment_sum(el_ctx* ctx, void* stream, const int32_t* ids, const float* rows, int64_t n, int32_t F,
+                                   int64_t n_ids, float* out, void* ws, size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(ids && rows && out && F >= 1 && n_ids >= 1, "el_rows_segment_sum: bad arguments");
+    if (n <= 0) return 0;
+    EL_REQUIRE(n < (1LL << 31), "el_rows_segment_sum: too many rows");
+    u32 *kin, *vin, *kout, *vout;
+    void* tmp;
+    size_t tb, total;
+    EL_REQUIRE(carve_rows_ws(n, n_ids, (char*)ws, &kin, &vin, &kout, &vout, &tmp, &tb, &total) == 0, "el_rows_segment_sum: size query failed");
+    EL_REQUIRE(ws != nullptr && ws_bytes >= total, "el_rows_segment_sum: workspace too small (%zu < %zu)", ws_bytes, total);
+    hipStream_t s = (hipStream_t)stream;
+    EL_LAUNCH("k_iota_keys", k_iota_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, n, kin, vin);
+    {
+        ElKernelTimer t("rocprim_radix_sort_pairs", s);
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (unsigned)n, 0, bits_for(n_ids), s));
+    }
+    const bool vec = (F % 4 == 0) && (((uintptr_t)rows) % 16 == 0) && (((uintptr_t)out) % 16 == 0);
+    int cpl = 1;
+    const int lpt = el_pick_lpt(F, vec ? 4 : 1, &cpl);
+    EL_REQUIRE(cpl <= 4, "el_rows_segment_sum: F=%d too large for this build", F);
+    const int chunk = 1;
+    const int64_t groups = n;
+    const unsigned grid = (unsigned)((groups * lpt + 255) / 256);
+#define EL_RS(VW_, CPL_) EL_LAUNCH("k_rows_segsum", (k_rows_segsum<VW_, CPL_>), dim3(grid), dim3(256), 0, s, kout, vout, rows, n, (int)F, chunk, lpt, out)
+    if (vec) {
+        if (cpl == 1) EL_RS(4, 1); else if (cpl == 2) EL_RS(4, 2); else EL_RS(4, 4);
+    } else {
+        if (cpl == 1) EL_RS(1, 1); else if (cpl == 2) EL_RS(1, 2); else EL_RS(1, 4);
+    }
+#undef EL_RS
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// optimiser phase alone (gradients already in gGu / gGi / gBi): TF-dense Adam or dense SGD
+extern "C" int el_bprmf_apply(el_ctx* ctx, void* stream, const el_bprmf_state* stp, float lr, int opt, int32_t step, float lr_t) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(stp != nullptr && stp->Gu && stp->Gi && stp->Bi && stp->gGu && stp->gGi && stp->gBi, "el_bprmf_apply: null state");
+    EL_REQUIRE(opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_SGD, "el_bprmf_apply: only the dense optimisers (adam_tf_dense, sgd) are available here");
+    if (opt == EL_OPT_ADAM_TF_DENSE) EL_REQUIRE(stp->mGu && stp->vGu && stp->mGi && stp->vGi && stp->mBi && stp->vBi, "el_bprmf_apply: Adam slots missing");
+    el_bprmf_state st = *stp;
+    st.tGu = st.tGi = st.tBi = nullptr;
+    return el_bprmf_apply_optimizer(ctx, (hipStream_t)stream, st, nullptr, nullptr, nullptr, 0, lr, opt, step, lr_t);
+}

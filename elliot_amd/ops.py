@@ -15,7 +15,7 @@ from ._lib import (EL_OPT_ADAM_LAZY, EL_OPT_ADAM_TF_DENSE, EL_OPT_SGD, EL_TOPK_A
                    EL_TOPK_SIMPLE, BprmfState, BprsgdState, check)
 
 OPTIMIZERS = {"adam": EL_OPT_ADAM_TF_DENSE, "adam_tf_dense": EL_OPT_ADAM_TF_DENSE,
-              "adam_lazy": EL_OPT_ADAM_LAZY, "sgd": EL_OPT_SGD}
+              "adam_lazy": EL_OPT_ADAM_LAZY, "sgd": EL_OPT_SGD, "sgd_dense": EL_OPT_SGD}
 TOPK_ALGOS = {"auto": EL_TOPK_AUTO, "mfma": EL_TOPK_MFMA, "simple": EL_TOPK_SIMPLE}
 BPR_ALGOS = {"auto": _lib.EL_BPR_AUTO, "atomic": _lib.EL_BPR_ATOMIC, "sorted": _lib.EL_BPR_SORTED}
 
@@ -250,7 +250,7 @@ class BprmfDeviceState:
         self.vGi = z(self.Gi) if adam else None
         self.mBi = z(self.Bi) if adam else None
         self.vBi = z(self.Bi) if adam else None
-        rows = self.opt in (EL_OPT_ADAM_LAZY, EL_OPT_SGD)
+        rows = self.opt in (EL_OPT_ADAM_LAZY, EL_OPT_SGD) and optimizer != "sgd_dense"
         self.tGu = torch.zeros(self.U, dtype=torch.int32, device=dev) if rows else None
         self.tGi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
         self.tBi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None

@@ -119,6 +119,27 @@ int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                         float lr, float l_w, float l_b, int opt, int32_t step,
                         float lr_t, double* loss_out, int algo, void* ws, size_t ws_bytes);
 
+/* ---- BPR-MF across GPUs: item-sharded tables (new design; the reference is single-device) -- */
+
+/* Step 1 on rank r: st holds the replicated user table (Gu [U,F]) and the LOCAL item shard (Gi [I_r,F],
+ * Bi [I_r], their accumulators); i/j are LOCAL item ids (both inside the shard).  Computes the batch loss,
+ * the item-row gradients (gGi/gBi, sorted segments) and one user-gradient row per triplet:
+ *   dU[b,:] = s_b (gamma_i - gamma_j) + l_w gamma_u      (float [B,F], reduced by user after the all-gather)
+ * ws: el_bprmf_ws_bytes(B, U, I_r).                                                               */
+int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
+                         const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                         float l_w, float l_b, int32_t step, float* dU, double* loss_out,
+                         void* ws, size_t ws_bytes);
+
+/* Step 3: out[ids[p],:] += rows[p,:], p in [0,n) -- the gathered (user id, gradient row) pairs of all ranks
+ * reduced into the dense accumulator (stable sort by id: every rank sums in the same order).        */
+size_t el_rows_segment_sum_ws_bytes(int64_t n, int64_t n_ids);
+int el_rows_segment_sum(el_ctx* ctx, void* stream, const int32_t* ids, const float* rows, int64_t n, int32_t F,
+                        int64_t n_ids, float* out, void* ws, size_t ws_bytes);
+
+/* Step 4: optimiser alone on (Gu, local Gi, local Bi); opt = EL_OPT_ADAM_TF_DENSE or EL_OPT_SGD.  */
+int el_bprmf_apply(el_ctx* ctx, void* stream, const el_bprmf_state* st, float lr, int opt, int32_t step, float lr_t);
+
 /* ---- BPR-MF, NumPy semantics (BPRMF; K5) ------------------------------------- */
 
 typedef struct el_bprsgd_state {

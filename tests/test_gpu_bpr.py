@@ -163,3 +163,45 @@ def test_sorted_path_is_deterministic(ctx):
     # users (short segments) must be identical; items/bias agree to round-off
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-4 and abs(outs[0][3] - outs[1][3]) < 1e-3
+
+
+# ---------------------------------------------------------------------------------- item-sharded path
+def test_item_sharded_hip_path_equals_concatenated_batch(ctx):
+    """Two virtual ranks on one GPU (the all-gather is emulated by torch.cat): the sharded kernels
+    (el_bprmf_shard_grads / el_rows_segment_sum / el_bprmf_apply) must reproduce ONE reference-semantics step on
+    the concatenated batch, and both user-table replicas must stay bit-identical."""
+    from elliot_amd import parallel
+    rs = np.random.RandomState(31)
+    U, I, F, B, G = 700, 400, 64, 3000, 2
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    d = ctx.device
+    bes, rng = [], []
+    for r in range(G):
+        lo, hi = parallel.item_range(I, r, G)
+        rng.append((lo, hi))
+        bes.append(parallel.HipBackend(ctx, Gu, Gi[lo:hi], Bi[lo:hi], optimizer="adam_tf_dense"))
+    orc = ob.BPRMFBatchOracle(Gu, Gi, Bi, lr, l_w, l_b)
+    for step in range(3):
+        batches = [(rs.randint(0, U, B), rs.randint(lo, min(lo + 25, hi), B), rs.randint(lo, hi, B)) for lo, hi in rng]
+        dUs, us = [], []
+        for r, (be, (lo, hi), (u, i, j)) in enumerate(zip(bes, rng, batches)):
+            tu = torch.from_numpy(u.astype(np.int32)).to(d)
+            dUs.append(be.shard_grads(tu, torch.from_numpy((i - lo).astype(np.int32)).to(d),
+                                      torch.from_numpy((j - lo).astype(np.int32)).to(d), l_w, l_b).clone())
+            us.append(tu)
+        ids, rows = torch.cat(us), torch.cat(dUs)
+        loss = 0.0
+        for be in bes:
+            be.reduce_user_rows(ids, rows)
+            be.apply(lr)
+            loss += be.state.pop_loss()
+        cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+        exp = orc.train_step((cu, ci, cj))
+        assert abs(loss - exp) <= 1e-4 * abs(exp), (step, loss, exp)
+        assert torch.equal(bes[0].state.Gu, bes[1].state.Gu)
+        assert (np.abs(cpu(bes[0].state.Gu) - orc.Gu) > 2e-5).mean() < 2e-4
+        for be, (lo, hi) in zip(bes, rng):
+            assert (np.abs(cpu(be.state.Gi) - orc.Gi[lo:hi]) > 2e-5).mean() < 2e-4
+            assert (np.abs(cpu(be.state.Bi) - orc.Bi[lo:hi]) > 2e-5).mean() < 2e-3
+            assert not cpu(be.state.gGu).any() and not cpu(be.state.gGi).any()
