@@ -13,10 +13,17 @@ from ... import ops
 
 
 class Sampler:
-    def __init__(self, indexed_ratings, ctx=None, seed=42, n_items=None):
+    def __init__(self, indexed_ratings, ctx=None, seed=42, n_items=None, replay=False):
         """indexed_ratings: the reference's {private_user: {private_item: rating}} dict (dataset.py:216-217)
-        or a scipy CSR train matrix (`data.sp_i_train`)."""
+        or a scipy CSR train matrix (`data.sp_i_train`).
+
+        replay=True (needs the dict): emit the reference's EXACT triplet stream -- MT19937 seeded 42, per-user lists in
+        `list(set(...))` order (custom_sampler.py:15,21) -- through el_bpr_sample_mt19937 instead of the Philox
+        sampler.  Meant for seed-exact comparisons with the reference; the Philox path is the fast one."""
         self.ctx = ctx or ops.get_context(0)
+        self._replay = None
+        if replay and sp.issparse(indexed_ratings):
+            raise ValueError("replay=True needs the reference's i_train_dict (its set order defines the stream)")
         if sp.issparse(indexed_ratings):
             m = indexed_ratings.tocsr()
             m.sort_indices()
@@ -33,10 +40,16 @@ class Sampler:
         self.pos = ops.DeviceCSR(indptr, indices, self._nitems, self.ctx.device)
         self.seed = seed                                              # custom_sampler.py:15 seeds 42
         self._drawn = 0
+        if replay:
+            lists = [list(set(indexed_ratings[u])) for u in indexed_ratings]      # custom_sampler.py:21
+            self._replay = ops.MtReplaySampler(self.ctx, lists, self.pos, seed=42)
 
     def step(self, events: int, batch_size: int):
         for start in range(0, events, batch_size):
             n = min(start + batch_size, events) - start
+            if self._replay is not None:
+                yield self._replay.sample(n)
+                continue
             u, i, j = ops.bpr_sample(self.ctx, self.pos, n, seed=self.seed, first_sample=self._drawn)
             self._drawn += n
             yield u, i, j

@@ -215,6 +215,48 @@ def bpr_sample(ctx, pos, n, seed, first_sample=0, item_lo=0, item_hi=None, out=N
     return out
 
 
+def mt19937_init_state(seed):
+    """np.random.seed(int) = MT19937 init_genrand: 624 words + position 624 (next draw twists)."""
+    mt = np.empty(625, dtype=np.uint32)
+    x = int(seed) & 0xFFFFFFFF
+    mt[0] = x
+    for i in range(1, 624):
+        x = (1812433253 * (x ^ (x >> 30)) + i) & 0xFFFFFFFF
+        mt[i] = x
+    mt[624] = 624
+    return mt
+
+
+class MtReplaySampler:
+    """Device replay of custom_sampler.Sampler's exact triplet stream (el_bpr_sample_mt19937)."""
+
+    def __init__(self, ctx, ui_lists, pos, seed=42):
+        """ui_lists: per-user positive lists in the reference's order (list(set(...)), custom_sampler.py:21);
+        pos: DeviceCSR of the same rows sorted ascending."""
+        self.ctx, self.pos = ctx, pos
+        lp = np.concatenate([[0], np.cumsum([len(l) for l in ui_lists])]).astype(np.int64)
+        li = np.concatenate([np.asarray(l, dtype=np.int32) for l in ui_lists]) if len(ui_lists) else np.zeros(0, np.int32)
+        self.lists = DeviceCSR.__new__(DeviceCSR)
+        self.lists.n_rows, self.lists.n_cols, self.lists.nnz = len(ui_lists), pos.n_cols, int(li.shape[0])
+        self.lists.indptr = torch.from_numpy(lp).to(ctx.device)
+        self.lists.indices = torch.from_numpy(li if li.size else np.zeros(1, np.int32)).to(ctx.device)
+        self.state = torch.from_numpy(mt19937_init_state(seed).view(np.int32).copy()).to(ctx.device)
+        self._ws = None
+
+    def sample(self, n):
+        ctx = self.ctx
+        need = int(ctx.lib.el_bpr_sample_mt19937_ws_bytes(int(n)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+        out = tuple(torch.empty(n, dtype=torch.int32, device=ctx.device) for _ in range(3))
+        check(ctx.lib.el_bpr_sample_mt19937(ctx.handle, ctx.stream(), C.c_void_p(self.state.data_ptr()),
+                                            _ptr(self.lists.indptr, torch.int64), _ptr(self.lists.indices, torch.int32),
+                                            *_csr_ptrs(self.pos), int(self.pos.n_rows), int(self.pos.n_cols), int(n),
+                                            _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                            C.c_void_p(self._ws.data_ptr()), self._ws.numel()), "el_bpr_sample_mt19937")
+        return out
+
+
 # ------------------------------------------------------------------------------------------
 # BPRMF_batch (TF semantics)
 # ------------------------------------------------------------------------------------------

@@ -50,7 +50,11 @@ class BPRMF(RecMixin, BaseRecommenderModel):
                               self._negative_item_regularization, self._seed, ctx=self._ctx,
                               hogwild=bool(getattr(self._params, "hogwild", False)),
                               init_weights=kwargs.get("init_weights"))
-        self._sampler = cs.Sampler(self._data.sp_i_train, ctx=self._ctx)
+        # `sampler: replay` -> the reference's exact MT19937 triplet stream (seed-exact runs); default: Philox
+        if getattr(self._params, "sampler", "philox") == "replay":
+            self._sampler = cs.Sampler(self._data.i_train_dict, ctx=self._ctx, replay=True)
+        else:
+            self._sampler = cs.Sampler(self._data.sp_i_train, ctx=self._ctx)
 
     @property
     def name(self):

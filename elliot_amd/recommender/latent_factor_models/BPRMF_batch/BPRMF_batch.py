@@ -42,7 +42,10 @@ class BPRMF_batch(RecMixin, BaseRecommenderModel):
             self._batch_size = self._data.transactions
         self._optimizer = getattr(self._params, "optimizer", "adam")
         self._ctx = ops.get_context(max(int(getattr(self._config, "gpu", 0) or 0), 0))
-        self._sampler = cs.Sampler(self._data.sp_i_train, ctx=self._ctx)
+        if getattr(self._params, "sampler", "philox") == "replay":   # the reference's exact MT19937 stream
+            self._sampler = cs.Sampler(self._data.i_train_dict, ctx=self._ctx, replay=True)
+        else:
+            self._sampler = cs.Sampler(self._data.sp_i_train, ctx=self._ctx)
         self._model = BPRMF_batch_model(self._factors, self._learning_rate, self._l_w, self._l_b, self._num_users,
                                         self._num_items, self._seed, ctx=self._ctx, optimizer=self._optimizer,
                                         init_weights=kwargs.get("init_weights"))

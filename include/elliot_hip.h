@@ -59,7 +59,7 @@ int el_timing_report(el_ctx* ctx, char* buf, int len);
  * Counter-based (Philox4x32-10) device sampler.  Sample n (global sample index
  * `first_sample + n`) draws u ~ U[0,U), i ~ U(pos(u)), j ~ U[0,I) rejected while
  * j in pos(u) -- the reference's distribution; the bit stream is Philox, not
- * MT19937 (the exact stream is restated in oracle/sampler.py).  Users with an empty
+ * MT19937 (el_bpr_sample_mt19937 replays that one exactly).  Users with an empty
  * row are re-drawn; users whose row covers [0,I) are re-drawn.
  * When item_lo/item_hi restrict the negative range (item-sharded training,
  * SURVEY 8e) j ~ U[item_lo,item_hi).  Pass 0, I for the reference behaviour.      */
@@ -68,6 +68,24 @@ int el_bpr_sample(el_ctx* ctx, void* stream,
                   int64_t U, int64_t I, int64_t item_lo, int64_t item_hi,
                   uint64_t seed, uint64_t first_sample, int64_t n,
                   int32_t* out_u, int32_t* out_i, int32_t* out_j);
+
+/* Exact replay of the reference stream: np.random.seed(s) then the draw order of custom_sampler.py:32-41
+ * (u, position of i, j repeated while j in pos(u)) with np.random.randint's masked rejection over successive
+ * 32-bit MT19937 outputs (no draw when the range is a single value).
+ *   mt_state     : device uint32[625] = 624 state words + position (as RandomState.get_state()); updated in
+ *                  place, so consecutive calls continue the stream like consecutive Sampler.step batches
+ *   lists_indptr / lists_items : per-user positive list IN THE REFERENCE'S ORDER
+ *                  (list(set(...)), custom_sampler.py:21), CSR int64/int32
+ *   pos_indptr / pos_indices   : the same rows sorted ascending (membership test `j in ui`)
+ * ws: el_bpr_sample_mt19937_ws_bytes(n) bytes.  Synchronises the stream once (the number of consumed words
+ * determines the new generator state).                                                              */
+size_t el_bpr_sample_mt19937_ws_bytes(int64_t n);
+int el_bpr_sample_mt19937(el_ctx* ctx, void* stream, uint32_t* mt_state,
+                          const int64_t* lists_indptr, const int32_t* lists_items,
+                          const int64_t* pos_indptr, const int32_t* pos_indices,
+                          int64_t U, int64_t I, int64_t n,
+                          int32_t* out_u, int32_t* out_i, int32_t* out_j,
+                          void* ws, size_t ws_bytes);
 
 /* ---- BPR-MF, TF semantics (BPRMF_batch; K2-K4) ------------------------------- */
 

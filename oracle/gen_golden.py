@@ -117,6 +117,43 @@ def main():
         print("metrics fixture skipped:", repr(ex))
     gen_splitter()
     gen_early_stopping()
+    gen_bprmf_end_to_end(cs, mfm)
+
+
+def gen_bprmf_end_to_end(cs, mfm):
+    """The reference's BPRMF inner loop (BPRMF.py:83-91,119-127) with its OWN MFModel + Sampler: MFModel(seed 42),
+    Sampler(seed 42), one epoch = `transactions` single-triplet train_steps, then get_user_predictions for everyone."""
+    U = 300
+    indptr, indices, itd = small_dataset(U, 160, seed=3)
+    I = int(indices.max()) + 1
+    T = int(indptr[-1])
+    F = 8
+    data = SimpleNamespace(users=list(range(U)), items=list(range(I)),
+                           private_users={p: p for p in range(U)}, public_users={p: p for p in range(U)},
+                           private_items={p: p for p in range(I)}, public_items={p: p for p in range(I)})
+    model = mfm.MFModel(F, data, 0.05, 0.0025, 0, 0.0025, 0.00025, 42)      # BPRMF.py:63-71 defaults
+    sampler = cs.Sampler(itd)
+    stream = []
+    for batch in sampler.step(T, 1):                                          # batch_size = 1 (BPRMF.py:80)
+        model.train_step(batch)
+        stream.append((int(batch[0][0, 0]), int(batch[1][0, 0]), int(batch[2][0, 0])))
+    mask = np.ones((U, I), dtype=bool)
+    for u in range(U):
+        mask[u, indices[indptr[u]:indptr[u + 1]]] = False
+    k = 10
+    ridx = np.array([[x[0] for x in model.get_user_predictions(u, mask, k)] for u in range(U)], np.int32)
+    rval = np.array([[x[1] for x in model.get_user_predictions(u, mask, k)] for u in range(U)], np.float64)
+    lists = ref_ui_lists(itd)
+    lp = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+    li = np.concatenate([np.asarray(l, np.int32) for l in lists])
+    order = np.array([list(itd[u].keys()) for u in range(U)], dtype=object)
+    tu = np.repeat(np.arange(U), [len(itd[u]) for u in range(U)])
+    ti = np.concatenate([np.fromiter(itd[u].keys(), dtype=np.int64) for u in range(U)])
+    tr = np.concatenate([np.fromiter(itd[u].values(), dtype=np.float64) for u in range(U)])
+    np.savez_compressed(os.path.join(OUT, "bprmf_e2e_ref.npz"), train_u=tu, train_i=ti, train_r=tr, lists_indptr=lp,
+                        lists_items=li, P=model._user_factors, Q=model._item_factors, b=model._item_bias,
+                        rec_idx=ridx, rec_val=rval, stream=np.asarray(stream, np.int32), factors=F, k=k)
+    print("bprmf_e2e_ref.npz: reference epoch of", T, "triplets,", U, "users")
 
 
 def gen_splitter():
