@@ -200,6 +200,16 @@ def main():
     pairs_per_s = world * B * K / dt_train            # B triplets per rank and step
     users_per_s = Ub * K / dt_topk
 
+    # HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.md), valid for the default workload only
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        c = tj["config"]
+        if (c["users"], c["items"], c["factors"], c["batch"], c["topk_block"]) == (U, I, F, B, Ub) and world == 1:
+            traffic = tj["bytes_per_launch"]
+    except Exception:
+        pass
+
     def dominant(rep):
         name = max(rep, key=lambda n: rep[n][1])
         return name, rep[name][1] / rep[name][0] * 1e-3   # seconds per launch
@@ -221,13 +231,13 @@ def main():
     dn, dsec = dominant(rep_train)
     achieved = alg.get(dn, 0.0) / dsec / 1e9
     roof_train = {"kernel": dn, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dn),
                   "kernels_ms_per_step": {n: v[1] / K for n, v in rep_train.items()}}
     tn, tsec = dominant(rep_topk)
     flops = 2.0 * Ub * (hi - lo) * F
     ach_t = flops / tsec / 1e12
     roof_topk = {"kernel": tn, "bound": "mfma", "achieved": ach_t, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": ach_t / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                 "frac": ach_t / MFMA_F32_PEAK_TFLOPS, "traffic": traffic.get(tn),
                  "kernels_ms_per_step": {n: v[1] / K for n, v in rep_topk.items()}}
 
     line = {

@@ -14,6 +14,7 @@
 // split over several lane groups whose partial rows are combined with a few atomics; segments that
 // live inside one chunk are written with plain stores.
 #include "el_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -109,68 +110,95 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
             }
             if (sub == 0 && p.st.tGu) p.st.tGu[cur] = p.step;
         };
-        for (int64_t pos = p0; pos < p1; ++pos) {
-            const int64_t key = (int64_t)p.keys[pos];
-            const int64_t b = (int64_t)p.vals[pos];
-            if (key != cur) {
-                if (cur >= 0) flush(true);
-                cur = key;
-                started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
-                cnt = 0;
-                nu = 0.f;
-                const float* pu = p.st.Gu + key * F;
+        // Positions are processed SUB at a time: all index loads, then all row gathers of the sub-block are issued
+        // before the (order-dependent) accumulation, so a lane group keeps SUB*3 row loads in flight instead of one
+        // dependent chain per position (the kernel is latency-bound otherwise).
+        constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
+        for (int64_t base = p0; base < p1; base += SUB) {
+            int64_t keyv[SUB], bv[SUB];
+            int32_t iv[SUB], jv[SUB];
+            bool okv[SUB];
+#pragma unroll
+            for (int t = 0; t < SUB; ++t) {
+                okv[t] = base + t < p1;
+                keyv[t] = okv[t] ? (int64_t)p.keys[base + t] : -2;
+                bv[t] = okv[t] ? (int64_t)p.vals[base + t] : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < SUB; ++t) {
+                iv[t] = okv[t] ? p.bi[bv[t]] : 0;
+                jv[t] = okv[t] ? p.bj[bv[t]] : 0;
+            }
+            float rgu[SUB][CPL][VW], rgi[SUB][CPL][VW], rgj[SUB][CPL][VW], rbi[SUB], rbj[SUB];
+#pragma unroll
+            for (int t = 0; t < SUB; ++t) {
+                const float* pu = p.st.Gu + (okv[t] ? keyv[t] : 0) * F;
+                const float* pi = p.st.Gi + (int64_t)iv[t] * F;
+                const float* pj = p.st.Gi + (int64_t)jv[t] * F;
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
                     const int e = (sub + q * lpt) * VW;
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) gu[q][x] = acc[q][x] = 0.f;
-                    if (e < F) ldv<VW>(pu + e, gu[q]);
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) nu += gu[q][x] * gu[q][x];
+                    for (int x = 0; x < VW; ++x) rgu[t][q][x] = rgi[t][q][x] = rgj[t][q][x] = 0.f;
+                    if (okv[t] && e < F) {
+                        ldv<VW>(pu + e, rgu[t][q]);
+                        ldv<VW>(pi + e, rgi[t][q]);
+                        ldv<VW>(pj + e, rgj[t][q]);
+                    }
                 }
-                nu = el_group_sum(nu, lpt);
-            }
-            const int32_t ii = p.bi[b], jj = p.bj[b];
-            const float* pi = p.st.Gi + (int64_t)ii * F;
-            const float* pj = p.st.Gi + (int64_t)jj * F;
-            float gi[CPL][VW], gj[CPL][VW];
-            float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                const int e = (sub + q * lpt) * VW;
-#pragma unroll
-                for (int x = 0; x < VW; ++x) gi[q][x] = gj[q][x] = 0.f;
-                if (e < F) {
-                    ldv<VW>(pi + e, gi[q]);
-                    ldv<VW>(pj + e, gj[q]);
-                }
-#pragma unroll
-                for (int x = 0; x < VW; ++x) {
-                    dpi += gu[q][x] * gi[q][x];
-                    dpj += gu[q][x] * gj[q][x];
-                    ni += gi[q][x] * gi[q][x];
-                    nj += gj[q][x] * gj[q][x];
-                }
-            }
-            dpi = el_group_sum(dpi, lpt);
-            dpj = el_group_sum(dpj, lpt);
-            ni = el_group_sum(ni, lpt);
-            nj = el_group_sum(nj, lpt);
-            const float beta_i = p.st.Bi[ii], beta_j = p.st.Bi[jj];
-            const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
-            const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
-            float sb = 0.f;
-            if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
-            if (sub == 0) {
-                p.s[b] = sb;
-                myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
-                          (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+                rbi[t] = okv[t] ? p.st.Bi[iv[t]] : 0.f;
+                rbj[t] = okv[t] ? p.st.Bi[jv[t]] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < CPL; ++q)
+            for (int t = 0; t < SUB; ++t) {
+                if (!okv[t]) continue;                       // group-uniform
+                const int64_t pos = base + t, key = keyv[t], b = bv[t];
+                if (key != cur) {
+                    if (cur >= 0) flush(true);
+                    cur = key;
+                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                    cnt = 0;
+                    nu = 0.f;
 #pragma unroll
-                for (int x = 0; x < VW; ++x) acc[q][x] += sb * (gi[q][x] - gj[q][x]);
-            cnt++;
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            gu[q][x] = rgu[t][q][x];
+                            acc[q][x] = 0.f;
+                            nu += gu[q][x] * gu[q][x];
+                        }
+                    nu = el_group_sum(nu, lpt);
+                }
+                float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) {
+                        dpi += gu[q][x] * rgi[t][q][x];
+                        dpj += gu[q][x] * rgj[t][q][x];
+                        ni += rgi[t][q][x] * rgi[t][q][x];
+                        nj += rgj[t][q][x] * rgj[t][q][x];
+                    }
+                dpi = el_group_sum(dpi, lpt);
+                dpj = el_group_sum(dpj, lpt);
+                ni = el_group_sum(ni, lpt);
+                nj = el_group_sum(nj, lpt);
+                const float beta_i = rbi[t], beta_j = rbj[t];
+                const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
+                const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+                float sb = 0.f;
+                if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+                if (sub == 0) {
+                    p.s[b] = sb;
+                    myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
+                              (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) acc[q][x] += sb * (rgi[t][q][x] - rgj[t][q][x]);
+                cnt++;
+            }
         }
         flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
     }
@@ -233,45 +261,83 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
             }
         }
     };
-    for (int64_t pos = p0; pos < p1; ++pos) {
-        const int64_t key = (int64_t)p.keys[pos];
-        const u32 pay = p.vals[pos];
-        if (key != cur) {
-            if (cur >= 0) flush(true);
-            cur = key;
-            started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
-            cpos = cneg = 0;
-            bacc = 0.f;
+    constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
+    for (int64_t base = p0; base < p1; base += SUB) {
+        int64_t keyv[SUB];
+        u32 payv[SUB];
+        bool okv[SUB];
+#pragma unroll
+        for (int t = 0; t < SUB; ++t) {
+            okv[t] = base + t < p1;
+            keyv[t] = okv[t] ? (int64_t)p.keys[base + t] : -2;
+            payv[t] = okv[t] ? p.vals[base + t] : 0u;
+        }
+        float sbv[SUB];
+        int32_t uv[SUB];
+#pragma unroll
+        for (int t = 0; t < SUB; ++t) {
+            const int64_t b = (int64_t)(payv[t] & 0x7fffffffu);
+            sbv[t] = okv[t] ? p.s[b] : 0.f;
+            uv[t] = okv[t] ? p.bu[b] : 0;
+        }
+        float rr[SUB][CPL][VW];
+#pragma unroll
+        for (int t = 0; t < SUB; ++t) {
+            const float* pu = p.st.Gu + (int64_t)uv[t] * F;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                for (int x = 0; x < VW; ++x) rr[t][q][x] = 0.f;
+                if (okv[t] && e < F) ldv<VW>(pu + e, rr[t][q]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SUB; ++t) {
+            if (!okv[t]) continue;
+            const int64_t pos = base + t, key = keyv[t];
+            if (key != cur) {
+                if (cur >= 0) flush(true);
+                cur = key;
+                started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                cpos = cneg = 0;
+                bacc = 0.f;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+            }
+            const bool neg = (payv[t] >> 31) != 0u;
+            const float coef = neg ? -sbv[t] : sbv[t];
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+                for (int x = 0; x < VW; ++x) acc[q][x] += coef * rr[t][q][x];
+            bacc += coef;
+            if (neg)
+                cneg++;
+            else
+                cpos++;
         }
-        const int64_t b = (int64_t)(pay & 0x7fffffffu);
-        const bool neg = (pay >> 31) != 0u;
-        const float sb = p.s[b];
-        const float coef = neg ? -sb : sb;
-        const float* pu = p.st.Gu + (int64_t)p.bu[b] * F;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const int e = (sub + q * lpt) * VW;
-            if (e < F) {
-                float r[VW];
-                ldv<VW>(pu + e, r);
-#pragma unroll
-                for (int x = 0; x < VW; ++x) acc[q][x] += coef * r[x];
-            }
-        }
-        bacc += coef;
-        if (neg)
-            cneg++;
-        else
-            cpos++;
     }
     flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
 }
 
 // ---- host ---------------------------------------------------------------------------------
+// Positions per lane group.  Popular items (Zipf) own segments of tens of thousands of occurrences; every chunk that
+// does not contain a whole segment ends with an atomic flush onto the same few cache lines, so long chunks matter for
+// the item side (16 -> 128 positions: 0.84 -> 0.35 ms at B = 1M) as long as enough groups remain to fill the chip.
+static int item_chunk_for(int64_t B) {
+    if (const char* e = getenv("EL_ICHUNK")) return atoi(e);
+    int64_t c = (2 * B) / 16384;
+    return (int)(c < 16 ? 16 : (c > 256 ? 256 : c));
+}
+static int user_chunk_for(int64_t B) {
+    if (const char* e = getenv("EL_UCHUNK")) return atoi(e);
+    int64_t c = B / 65536;
+    return (int)(c < 4 ? 4 : (c > 16 ? 16 : c));
+}
+
 static int bits_for(int64_t n) {
     int b = 1;
     while ((1LL << b) < n && b < 32) ++b;
@@ -337,13 +403,13 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     pu.keys = w.keyU;
     pu.vals = w.valU;
     pu.n = B;
-    pu.chunk = 4;
+    pu.chunk = user_chunk_for(B);
     pu.lpt = lpt;
     SegParams pi = base;
     pi.keys = w.keyI;
     pi.vals = w.valI;
     pi.n = 2 * B;
-    pi.chunk = 16;
+    pi.chunk = item_chunk_for(B);
     pi.lpt = lpt;
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
@@ -596,7 +662,7 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     pi.keys = w.keyI;
     pi.vals = w.valI;
     pi.n = 2 * B;
-    pi.chunk = 16;
+    pi.chunk = item_chunk_for(B);
     pi.lpt = lpt;
     const int64_t gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridI = (unsigned)((gi * lpt + 255) / 256);
