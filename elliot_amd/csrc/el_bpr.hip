@@ -8,6 +8,7 @@
 // power of two) owns one triplet, each lane moves 16 bytes of every row it touches, dot
 // products are reduced with wavefront shuffles, nothing is staged through LDS because a
 // row is consumed exactly once per triplet.
+#include <stdlib.h>
 #include <vector>
 #include "el_common.h"
 
@@ -238,28 +239,67 @@ __device__ __forceinline__ void el_adam_elem(float& th, float& m, float& v, floa
 }
 
 // dense pass: EVERY element of the variable decays and moves (TF sparse-apply semantics);
-// the gradient accumulator is reset on the way.
-__global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ th, float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                    float lr_t, float b1, float b2, float eps) {
+// the gradient accumulator is reset on the way.  Pure streaming: 4 read + 3(4) write streams.
+// NT: non-temporal loads/stores (nothing here is re-read before the next step); UNR: float4 groups per iteration.
+template <bool NT, int UNR>
+__device__ __forceinline__ void adam_dense_body(float* __restrict__ th, float* __restrict__ g, float* __restrict__ m,
+                                                float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
+                                                float eps) {
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float4* th4 = reinterpret_cast<float4*>(th);
-    float4* g4 = reinterpret_cast<float4*>(g);
-    float4* m4 = reinterpret_cast<float4*>(m);
-    float4* v4 = reinterpret_cast<float4*>(v);
-    for (int64_t e = t; e < n4; e += stride) {
-        float4 a = th4[e], gg = g4[e], mm = m4[e], vv = v4[e];
-        el_adam_elem(a.x, mm.x, vv.x, gg.x, lr_t, b1, b2, omb1, omb2, eps);
-        el_adam_elem(a.y, mm.y, vv.y, gg.y, lr_t, b1, b2, omb1, omb2, eps);
-        el_adam_elem(a.z, mm.z, vv.z, gg.z, lr_t, b1, b2, omb1, omb2, eps);
-        el_adam_elem(a.w, mm.w, vv.w, gg.w, lr_t, b1, b2, omb1, omb2, eps);
-        th4[e] = a;
-        m4[e] = mm;
-        v4[e] = vv;
-        if (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f) g4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* th4 = reinterpret_cast<f4*>(th);
+    f4* g4 = reinterpret_cast<f4*>(g);
+    f4* m4 = reinterpret_cast<f4*>(m);
+    f4* v4 = reinterpret_cast<f4*>(v);
+    for (int64_t e0 = t; e0 < n4; e0 += stride * UNR) {
+        f4 a[UNR], gg[UNR], mm[UNR], vv[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int64_t e = e0 + q * stride;
+            if (e < n4) {
+                if (NT) {
+                    a[q] = __builtin_nontemporal_load(th4 + e);
+                    gg[q] = __builtin_nontemporal_load(g4 + e);
+                    mm[q] = __builtin_nontemporal_load(m4 + e);
+                    vv[q] = __builtin_nontemporal_load(v4 + e);
+                } else {
+                    a[q] = th4[e];
+                    gg[q] = g4[e];
+                    mm[q] = m4[e];
+                    vv[q] = v4[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int64_t e = e0 + q * stride;
+            if (e < n4) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float ax = a[q][x], mx = mm[q][x], vx = vv[q][x];
+                    el_adam_elem(ax, mx, vx, gg[q][x], lr_t, b1, b2, omb1, omb2, eps);
+                    a[q][x] = ax;
+                    mm[q][x] = mx;
+                    vv[q][x] = vx;
+                }
+                const bool nz = gg[q][0] != 0.f || gg[q][1] != 0.f || gg[q][2] != 0.f || gg[q][3] != 0.f;
+                const f4 zero = {0.f, 0.f, 0.f, 0.f};
+                if (NT) {
+                    __builtin_nontemporal_store(a[q], th4 + e);
+                    __builtin_nontemporal_store(mm[q], m4 + e);
+                    __builtin_nontemporal_store(vv[q], v4 + e);
+                    if (nz) __builtin_nontemporal_store(zero, g4 + e);
+                } else {
+                    th4[e] = a[q];
+                    m4[e] = mm[q];
+                    v4[e] = vv[q];
+                    if (nz) g4[e] = zero;
+                }
+            }
+        }
     }
     for (int64_t e = (n4 << 2) + t; e < n; e += stride) {
         float a = th[e], gg = g[e], mm = m[e], vv = v[e];
@@ -269,6 +309,14 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ th, floa
         v[e] = vv;
         if (gg != 0.f) g[e] = 0.f;
     }
+}
+
+// Measured on the 128M-element user table (MI355X): plain 0.82 ms, non-temporal 0.76 ms, non-temporal + 2 groups in
+// flight 0.75 ms per pass (28-32 B/element of HBM traffic -> ~5.2 TB/s).
+__global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ th, float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    float lr_t, float b1, float b2, float eps) {
+    adam_dense_body<true, 2>(th, g, m, v, n, lr_t, b1, b2, eps);
 }
 
 // touched-row pass (EL_OPT_ADAM_LAZY / EL_OPT_SGD): one lane group per batch entry and

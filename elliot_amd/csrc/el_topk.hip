@@ -74,10 +74,9 @@ __device__ __forceinline__ float el_wave_compact(u64* kb, int* cp, int cap, int 
 // Same, but first drops keys whose item is in the (sorted) exclusion row idx[e0,e1): the MFMA kernel
 // inserts candidates unchecked and pays the membership test (a chain of dependent global loads) once
 // per compaction for the whole buffer instead of once per insertion.  cap <= 64 here.
-__device__ __forceinline__ float el_wave_compact_excl(u64* kb, int* cp, int cap, int k, int lane,
+__device__ __forceinline__ float el_wave_compact_excl(u64* kb, int n, int& n_out, int cap, int k, int lane,
                                                       const int32_t* __restrict__ idx, int64_t e0, int64_t e1) {
     el_wave_lds_sync();
-    int n = *cp;
     bool drop = false;
     if (lane < cap) {
         if (lane < n) {
@@ -92,10 +91,16 @@ __device__ __forceinline__ float el_wave_compact_excl(u64* kb, int* cp, int cap,
     el_wave_bitonic_desc(kb, cap, lane);
     n -= removed;
     int nn = n < k ? n : k;
-    if (lane == 0) *cp = nn;
+    n_out = nn;
     float nt = (nn >= k) ? el_key_score(kb[k - 1]) : -INFINITY;
     el_wave_lds_sync();
     return nt;
+}
+
+// value held by the partner lane (l <-> l+32) -- v_permlane32_swap_b32, no LDS round trip
+__device__ __forceinline__ u32 el_partner32(u32 x, int hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return hi ? r[0] : r[1];
 }
 
 // The r-th (0-based) masked item of a row, ascending, inside the local shard
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
         e0 = p.excl_indptr[user];
         e1 = p.excl_indptr[user + 1];
     }
-    if (hi == 0) cnts[uslot] = 0;
+    int ucnt = 0;            // keys in this user's list (identical in lanes l and l+32)
     float tau = -INFINITY;
 
     const int ntiles = (int)((I + BI - 1) / BI);
@@ -396,22 +401,26 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
 #pragma unroll
                     for (int q = 1; q < 16; ++q) sv = (r == q) ? sc[q] : sv;
                     int64_t il = (int64_t)tile * BI + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    bool v = pend && uvalid && il < I && (sv >= tau);
-                    int32_t g = (int32_t)(p.item_offset + il);
-                    if (v) {
-                        int pos = atomicAdd(&cnts[uslot], 1);
-                        keys[(size_t)uslot * CAP + pos] = el_make_key(sv, g);
-                    }
-                    el_wave_lds_sync();
-                    int c = cnts[uslot];
-                    u64 full = __ballot(hi == 0 && c > CAP - 2);
+                    const bool v = pend && uvalid && il < I && (sv >= tau);
+                    const int32_t g = (int32_t)(p.item_offset + il);
+                    // slot bookkeeping in registers: the two lanes of a user exchange their insert flags with one
+                    // v_permlane32_swap (no LDS atomic, no wait); lane l writes first, lane l+32 after it
+                    const u32 pv = el_partner32(v ? 1u : 0u, hi);
+                    if (v) keys[(size_t)uslot * CAP + ucnt + (hi ? (int)pv : 0)] = el_make_key(sv, g);
+                    ucnt += (v ? 1 : 0) + (int)pv;
+                    u64 full = __ballot(hi == 0 && ucnt > CAP - 2);
                     while (full) {
-                        int ul = __ffsll((long long)full) - 1;
+                        const int ul = __ffsll((long long)full) - 1;
                         full &= full - 1ull;
                         const int64_t ue0 = __shfl(e0, ul, 64), ue1 = __shfl(e1, ul, 64);
-                        float ntau = el_wave_compact_excl(wkeys + (size_t)ul * CAP, wcnts + ul, CAP, p.k, lane,
-                                                          p.excl_indices, ue0, ue1);
-                        if (col == ul) tau = ntau;
+                        const int un = __shfl(ucnt, ul, 64);
+                        int nn = 0;
+                        const float ntau = el_wave_compact_excl(wkeys + (size_t)ul * CAP, un, nn, CAP, p.k, lane,
+                                                                p.excl_indices, ue0, ue1);
+                        if (col == ul) {
+                            tau = ntau;
+                            ucnt = nn;
+                        }
                     }
                 }
             }
@@ -424,8 +433,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
         if (uu >= p.u_stop) break;
         u64* kb = wkeys + (size_t)ul * CAP;
         const int64_t ue0 = __shfl(e0, ul, 64), ue1 = __shfl(e1, ul, 64);
-        el_wave_compact_excl(kb, wcnts + ul, CAP, p.k, lane, p.excl_indices, ue0, ue1);
-        const int nv = wcnts[ul];
+        const int un = __shfl(ucnt, ul, 64);
+        int nv = 0;
+        el_wave_compact_excl(kb, un, nv, CAP, p.k, lane, p.excl_indices, ue0, ue1);
         const int64_t orow = (uu - p.u_start) * (int64_t)p.k;
         for (int t = lane; t < p.k; t += 64) {
             int32_t oi;
