@@ -15,6 +15,7 @@ EL_OPT_SGD = 3
 EL_TOPK_AUTO = 0
 EL_TOPK_MFMA = 1
 EL_TOPK_SIMPLE = 2
+EL_TOPK_SCREEN = 3
 EL_BPR_AUTO = 0
 EL_BPR_ATOMIC = 1
 EL_BPR_SORTED = 2
@@ -102,7 +103,7 @@ PROTOTYPES = {
                                          C.c_void_p, C.c_int64]),
     "el_bprsgd_levels_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
-    "el_score_topk_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
+    "el_score_topk_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int]),
     "el_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int64, C.c_int32, _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p,
                                 C.c_int, C.c_void_p, C.c_size_t]),

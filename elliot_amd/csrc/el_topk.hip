@@ -15,123 +15,7 @@
 #include <stdlib.h>
 #include "el_common.h"
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-struct TopkParams {
-    const float* Gu;
-    const float* Gi;
-    const float* Bi;
-    int64_t u_start, u_stop, item_offset, I_local;
-    int F;
-    const int64_t* excl_indptr;
-    const int32_t* excl_indices;
-    const int64_t* cand_indptr;
-    const int32_t* cand_indices;
-    int k;
-    int32_t* out_idx;
-    float* out_val;
-    // dense-preds variant
-    const float* preds;
-    int64_t ld;
-    int dbg;  // experiment switches (EL_TOPK_DEBUG): 1 = skip the fused selection (GEMM-only timing)
-};
-
-// ---- one-wave bitonic sort (descending) of n = 2^m u64 keys held in LDS --------------
-__device__ __forceinline__ void el_wave_bitonic_desc(u64* a, int n, int lane) {
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = lane; t < (n >> 1); t += 64) {
-                int i = 2 * t - (t & (stride - 1));
-                int j = i + stride;
-                bool desc = ((i & size) == 0);
-                u64 x = a[i], y = a[j];
-                bool sw = desc ? (x < y) : (x > y);
-                if (sw) {
-                    a[i] = y;
-                    a[j] = x;
-                }
-            }
-            el_wave_lds_sync();
-        }
-    }
-}
-
-// Sort one candidate list (n valid keys in a cap-slot LDS buffer), keep the best k.
-// Whole wave participates, all arguments wave-uniform. Returns the new threshold.
-__device__ __forceinline__ float el_wave_compact(u64* kb, int* cp, int cap, int k, int lane) {
-    el_wave_lds_sync();
-    int n = *cp;
-    for (int t = n + lane; t < cap; t += 64) kb[t] = 0ull;
-    el_wave_lds_sync();
-    el_wave_bitonic_desc(kb, cap, lane);
-    int nn = n < k ? n : k;
-    if (lane == 0) *cp = nn;
-    float nt = (nn >= k) ? el_key_score(kb[k - 1]) : -INFINITY;
-    el_wave_lds_sync();
-    return nt;
-}
-
-// Same, but first drops keys whose item is in the (sorted) exclusion row idx[e0,e1): the MFMA kernel
-// inserts candidates unchecked and pays the membership test (a chain of dependent global loads) once
-// per compaction for the whole buffer instead of once per insertion.  cap <= 64 here.
-__device__ __forceinline__ float el_wave_compact_excl(u64* kb, int n, int& n_out, int cap, int k, int lane,
-                                                      const int32_t* __restrict__ idx, int64_t e0, int64_t e1) {
-    el_wave_lds_sync();
-    bool drop = false;
-    if (lane < cap) {
-        if (lane < n) {
-            if (e1 > e0) drop = el_row_contains(idx, e0, e1, el_key_item(kb[lane]));
-            if (drop) kb[lane] = 0ull;
-        } else {
-            kb[lane] = 0ull;
-        }
-    }
-    const int removed = __popcll(__ballot(drop));
-    el_wave_lds_sync();
-    el_wave_bitonic_desc(kb, cap, lane);
-    n -= removed;
-    int nn = n < k ? n : k;
-    n_out = nn;
-    float nt = (nn >= k) ? el_key_score(kb[k - 1]) : -INFINITY;
-    el_wave_lds_sync();
-    return nt;
-}
-
-// value held by the partner lane (l <-> l+32) -- v_permlane32_swap_b32, no LDS round trip
-__device__ __forceinline__ u32 el_partner32(u32 x, int hi) {
-    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return hi ? r[0] : r[1];
-}
-
-// The r-th (0-based) masked item of a row, ascending, inside the local shard
-// [off, off+I_local): what tf.where(mask, preds, -inf) + top_k pads with.
-__device__ __forceinline__ int32_t el_fill_masked(const TopkParams& p, int64_t e0, int64_t e1, int64_t c0,
-                                                  int64_t c1, int64_t r) {
-    const int64_t off = p.item_offset, end = p.item_offset + p.I_local;
-    if (p.cand_indptr) {
-        // masked = NOT candidate.  q* = #candidates (inside the shard) with
-        // cand[q] - off - q <= r ; answer = off + r + q*.
-        int64_t lo = el_lower_bound(p.cand_indices, c0, c1, (int32_t)off);
-        int64_t hi = el_lower_bound(p.cand_indices, c0, c1, (int32_t)(end > 0x7fffffffLL ? 0x7fffffffLL : end));
-        int64_t a = lo, b = hi;
-        while (a < b) {
-            int64_t mid = (a + b) >> 1;
-            int64_t f = (int64_t)p.cand_indices[mid] - off - (mid - lo);
-            if (f <= r)
-                a = mid + 1;
-            else
-                b = mid;
-        }
-        int64_t g = off + r + (a - lo);
-        return g < end ? (int32_t)g : -1;
-    }
-    if (p.excl_indptr) {
-        int64_t lo = el_lower_bound(p.excl_indices, e0, e1, (int32_t)off);
-        int64_t hi = el_lower_bound(p.excl_indices, e0, e1, (int32_t)(end > 0x7fffffffLL ? 0x7fffffffLL : end));
-        return (lo + r < hi) ? p.excl_indices[lo + r] : -1;
-    }
-    return -1;
-}
+#include "el_topk_common.h"
 
 // =====================================================================================
 // Wave-per-user kernel (VALU fma chain).  General k, general F, candidate protocol,
@@ -144,6 +28,7 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
     int* cnt_s = reinterpret_cast<int*>(smem + (size_t)cap * 8);  // [1] (+pad), used by el_wave_compact
     const int lane = threadIdx.x;
     const int64_t user = p.u_start + blockIdx.x;
+    if (p.only_flagged && p.only_flagged[blockIdx.x] == 0) return;
     const int F = p.F;
     const float* gu = DENSE ? nullptr : p.Gu + user * (int64_t)F;
     int64_t e0 = 0, e1 = 0, c0 = 0, c1 = 0;
@@ -248,9 +133,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
     const int uslot = wave * 32 + col;
-    const int64_t ublock = p.u_start + (int64_t)blockIdx.x * UPB;
-    const int64_t user = ublock + uslot;
-    const bool uvalid = user < p.u_stop;
+    // users of this workgroup: a slice of [u_start, u_stop), or of the caller's list (exact fallback of the screened path)
+    int64_t nlist = p.u_stop - p.u_start;
+    if (p.ulist) {
+        nlist = (int64_t)*p.ulist_n;
+        if (p.ulist_max > 0 && nlist > p.ulist_max) nlist = p.ulist_max;
+        nlist -= p.ulist_skip;
+    }
+    if ((int64_t)blockIdx.x * UPB >= nlist) return;
+    const int64_t uidx = (int64_t)blockIdx.x * UPB + uslot;
+    const bool uvalid = uidx < nlist;
+    const int64_t user = p.u_start + (uvalid ? (p.ulist ? (int64_t)p.ulist[p.ulist_skip + uidx] : uidx) : 0);
     const int F = p.F;
     const int64_t I = p.I_local;
 
@@ -272,7 +165,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
     int ucnt = 0;            // keys in this user's list (identical in lanes l and l+32)
     float tau = -INFINITY;
 
-    const int ntiles = (int)((I + BI - 1) / BI);
+    const int ntiles_all = (int)((I + BI - 1) / BI);
+    const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int tile0 = (int)((int64_t)ntiles_all * blockIdx.y / nsplit);         // this workgroup's slice of the item tiles
+    const int ntiles = (int)((int64_t)ntiles_all * (blockIdx.y + 1) / nsplit);
     const int nch = (F + KC - 1) / KC;
 
     float4 pre[NLD];
@@ -328,8 +224,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
     int* wcnts = cnts + wave * 32;
 
     int buf = 0;
-    if (ntiles > 0) gload(0, 0);
-    for (int tile = 0; tile < ntiles; ++tile) {
+    if (ntiles > tile0) gload(tile0, 0);
+    for (int tile = tile0; tile < ntiles; ++tile) {
         floatx16 acc[NIB];
 #pragma unroll
         for (int b = 0; b < NIB; ++b)
@@ -429,14 +325,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
 
     // ---- final sort + write-out ---------------------------------------------------
     for (int ul = 0; ul < 32; ++ul) {
-        const int64_t uu = ublock + wave * 32 + ul;
-        if (uu >= p.u_stop) break;
+        if ((int64_t)blockIdx.x * UPB + wave * 32 + ul >= nlist) break;
+        const int64_t uu = __shfl(user, ul, 64);
         u64* kb = wkeys + (size_t)ul * CAP;
         const int64_t ue0 = __shfl(e0, ul, 64), ue1 = __shfl(e1, ul, 64);
         const int un = __shfl(ucnt, ul, 64);
         int nv = 0;
         el_wave_compact_excl(kb, un, nv, CAP, p.k, lane, p.excl_indices, ue0, ue1);
-        const int64_t orow = (uu - p.u_start) * (int64_t)p.k;
+        int64_t orow = (uu - p.u_start) * (int64_t)p.k;
+        int64_t fill_lo = p.item_offset, fill_hi = p.item_offset + I;
+        if (nsplit > 1) {                            // partial list of this item slice; pads with the slice's own masked items
+            orow = ((int64_t)blockIdx.y * p.part_stride + (int64_t)blockIdx.x * UPB + wave * 32 + ul) * (int64_t)p.k;
+            fill_lo = p.item_offset + (int64_t)tile0 * BI;
+            const int64_t hi_raw = p.item_offset + (int64_t)ntiles * BI;
+            fill_hi = hi_raw < fill_hi ? hi_raw : fill_hi;
+        }
         for (int t = lane; t < p.k; t += 64) {
             int32_t oi;
             float ov;
@@ -445,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
                 oi = el_key_item(key);
                 ov = el_key_score(key);
             } else {
-                oi = el_fill_masked(p, ue0, ue1, 0, 0, t - nv);
+                oi = el_fill_masked_range(p, fill_lo, fill_hi, ue0, ue1, 0, 0, t - nv);
                 ov = -INFINITY;
             }
             p.out_idx[orow + t] = oi;
@@ -458,13 +361,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
 // =====================================================================================
 // merge of G partial lists per user
 // =====================================================================================
+// row_map / n_rows (optional): only the first min(*n_rows, n_users) rows exist and row u is written to out row row_map[u]
 __global__ __launch_bounds__(64) void k_topk_merge(const int32_t* parts_idx, const float* parts_val, int G,
                                                    int64_t n_users, int k, int cap, int32_t* out_idx,
-                                                   float* out_val) {
+                                                   float* out_val, const int32_t* row_map, const int32_t* n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int lane = threadIdx.x;
     const int64_t u = blockIdx.x;
+    if (n_rows && u >= (int64_t)*n_rows) return;
+    const int64_t orow = row_map ? (int64_t)row_map[u] : u;
     const int total = G * k;
     for (int t = lane; t < cap; t += 64) {
         u64 key = 0ull;
@@ -487,8 +393,8 @@ __global__ __launch_bounds__(64) void k_topk_merge(const int32_t* parts_idx, con
             oi = el_key_item(key);
             ov = el_key_score(key);
         }
-        out_idx[u * k + t] = oi;
-        out_val[u * k + t] = ov;
+        out_idx[orow * k + t] = oi;
+        out_val[orow * k + t] = ov;
     }
 }
 
@@ -644,9 +550,25 @@ static int wave_cap_for_k(int k) {
     return cap < 128 ? 128 : cap;
 }
 
+int el_topk_launch_wave(const TopkParams& p, hipStream_t st) {
+    const int cap = wave_cap_for_k(p.k);
+    EL_LAUNCH("k_topk_wave", k_topk_wave<false>, dim3((unsigned)(p.u_stop - p.u_start)), dim3(64), (size_t)cap * 8 + 16, st, p, cap);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
 static bool mfma_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 256 && k >= 1 && k <= 40; }
 
-extern "C" size_t el_score_topk_ws_bytes(int64_t, int64_t, int32_t, int32_t, int) { return 0; }
+// el_topk_screen.hip
+bool el_topk_screen_eligible(int F, int k, const void* cand);
+size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, int64_t excl_nnz);
+int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream_t st);
+
+extern "C" size_t el_score_topk_ws_bytes(int64_t n_users, int64_t I_local, int32_t F, int32_t k, int64_t excl_nnz, int algo) {
+    if ((algo == EL_TOPK_AUTO || algo == EL_TOPK_SCREEN) && el_topk_screen_eligible(F, k, nullptr) && n_users > 0)
+        return el_topk_screen_ws_bytes(n_users, I_local, F, k, excl_nnz);
+    return 0;
+}
 
 template <int FP, int NIB, int CAP, int KC, int NW, int OCC>
 static int launch_mfma(const TopkParams& p, int vec, hipStream_t st) {
@@ -655,8 +577,9 @@ static int launch_mfma(const TopkParams& p, int vec, hipStream_t st) {
     auto kern = k_score_topk_mfma<FP, NIB, CAP, KC, NW, OCC>;
     EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t n_users = p.u_stop - p.u_start;
+    if (p.ulist && p.ulist_max > 0 && n_users > p.ulist_max) n_users = p.ulist_max;
     unsigned grid = (unsigned)((n_users + UPB - 1) / UPB);
-    EL_LAUNCH("k_score_topk_mfma", kern, dim3(grid), dim3(NW * 64), lds, st, p, vec);
+    EL_LAUNCH("k_score_topk_mfma", kern, dim3(grid, p.nsplit > 1 ? p.nsplit : 1), dim3(NW * 64), lds, st, p, vec);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -694,13 +617,69 @@ static int check_topk_args(const char* fn, int64_t u_start, int64_t u_stop, int6
     return 0;
 }
 
+int el_topk_launch_mfma(const TopkParams& p, hipStream_t st) {
+    const int vec = (p.F % 4 == 0) && (((uintptr_t)p.Gi) % 16 == 0);
+    if (p.k <= 14) return dispatch_mfma_fp<32>(p, vec, st);
+    return dispatch_mfma_fp<64>(p, vec, st);
+}
+
+// ---- exact top-k of a device-side user list (fallback of the screened path) -----------------------------------------
+static const int LIST_SPLIT = 64;
+
+static int64_t list_cap_for(int64_t n_users) {
+    int64_t c = n_users / 16;
+    if (c < 512) c = 512;
+    return c < n_users ? c : n_users;
+}
+
+static size_t a256_(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t el_topk_list_scratch_bytes(int64_t n_users, int k) {
+    return 2 * a256_((size_t)LIST_SPLIT * (size_t)list_cap_for(n_users) * (size_t)k * 4);
+}
+
+int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    const int64_t n_users = p0.u_stop - p0.u_start;
+    const int64_t cap = list_cap_for(n_users);
+    EL_REQUIRE(scratch && scratch_bytes >= el_topk_list_scratch_bytes(n_users, p0.k), "el_topk_run_list: scratch too small");
+    int32_t* part_idx = (int32_t*)scratch;
+    float* part_val = (float*)((char*)scratch + a256_((size_t)LIST_SPLIT * (size_t)cap * (size_t)p0.k * 4));
+    // item slices of >= 4 MFMA tiles (128 items each), at most LIST_SPLIT of them
+    int64_t S = (p0.I_local + 511) / 512;
+    if (S > LIST_SPLIT) S = LIST_SPLIT;
+    if (S < 1) S = 1;
+    TopkParams p = p0;
+    p.ulist_skip = 0;
+    p.ulist_max = (int)cap;
+    p.nsplit = (int)(S > 1 ? S : 0);
+    if (S > 1) {
+        p.part_stride = cap;
+        p.out_idx = part_idx;
+        p.out_val = part_val;
+    }
+    if (int rc = el_topk_launch_mfma(p, st)) return rc;
+    if (S > 1) {
+        int mcap = next_pow2((int)S * p0.k);
+        if (mcap < 64) mcap = 64;
+        EL_LAUNCH("k_topk_merge", k_topk_merge, dim3((unsigned)cap), dim3(64), (size_t)mcap * 8, st, (const int32_t*)part_idx,
+                  (const float*)part_val, (int)S, cap, p0.k, mcap, p0.out_idx, p0.out_val, p0.ulist, p0.ulist_n);
+        EL_CHECK_LAUNCH();
+    }
+    if (n_users > cap) {                             // more flagged users than the split scratch holds: plain kernel for the rest
+        TopkParams q = p0;
+        q.ulist_skip = (int)cap;
+        q.ulist_max = 0;
+        q.nsplit = 0;
+        if (int rc = el_topk_launch_mfma(q, st)) return rc;
+    }
+    return 0;
+}
+
 extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const float* Gi, const float* Bi,
                              int64_t u_start, int64_t u_stop, int64_t item_offset, int64_t I_local, int32_t F,
                              const int64_t* excl_indptr, const int32_t* excl_indices, const int64_t* cand_indptr,
                              const int32_t* cand_indices, int32_t k, int32_t* out_idx, float* out_val, int algo,
                              void* ws, size_t ws_bytes) {
-    (void)ws;
-    (void)ws_bytes;
     if (int rc = el_bind(ctx)) return rc;
     if (int rc = check_topk_args("el_score_topk", u_start, u_stop, I_local, F, k, out_idx, out_val)) return rc;
     EL_REQUIRE(Gu && Gi, "el_score_topk: null factor table");
@@ -730,14 +709,15 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
         const char* e = getenv("EL_TOPK_DEBUG");
         p.dbg = e ? atoi(e) : 0;
     }
+    const bool selig = el_topk_screen_eligible(F, k, cand_indptr);
+    if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=128, k<=30 and no candidate list");
+    if (algo == EL_TOPK_SCREEN ||
+        (algo == EL_TOPK_AUTO && selig && ws != nullptr && ws_bytes >= el_topk_screen_ws_bytes(u_stop - u_start, I_local, F, k, 0)))
+        return el_topk_screen_run(p, ws, ws_bytes, st);
     bool elig = mfma_eligible(F, k, cand_indptr);
     if (algo == EL_TOPK_MFMA) EL_REQUIRE(elig, "el_score_topk: MFMA kernel needs F<=256, k<=40 and no candidate list");
     bool use_mfma = (algo == EL_TOPK_MFMA) || (algo == EL_TOPK_AUTO && elig);
-    if (use_mfma) {
-        int vec = (F % 4 == 0) && (((uintptr_t)Gi) % 16 == 0);
-        if (k <= 14) return dispatch_mfma_fp<32>(p, vec, st);
-        return dispatch_mfma_fp<64>(p, vec, st);
-    }
+    if (use_mfma) return el_topk_launch_mfma(p, st);
     int cap = wave_cap_for_k(k);
     EL_LAUNCH("k_topk_wave", k_topk_wave<false>, dim3((unsigned)(u_stop - u_start)), dim3(64), (size_t)cap * 8 + 16, st, p, cap);
     EL_CHECK_LAUNCH();
@@ -817,7 +797,7 @@ extern "C" int el_topk_merge(el_ctx* ctx, void* stream, const int32_t* parts_idx
     int cap = next_pow2(G * k);
     if (cap < 64) cap = 64;
     EL_LAUNCH("k_topk_merge", k_topk_merge, dim3((unsigned)n_users), dim3(64), (size_t)cap * 8, (hipStream_t)stream,
-                       parts_idx, parts_val, G, n_users, k, cap, out_idx, out_val);
+                       parts_idx, parts_val, G, n_users, k, cap, out_idx, out_val, (const int32_t*)nullptr, (const int32_t*)nullptr);
     EL_CHECK_LAUNCH();
     return 0;
 }

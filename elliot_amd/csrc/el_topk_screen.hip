@@ -1,0 +1,645 @@
+// Full-catalog top-k, bf16-screened and fp32-exact (EL_TOPK_SCREEN).
+//
+// Same contract and the same answers as el_topk.hip (score = fp32 fma chain, order = score desc / item asc), but the
+// 2*I*F flop per user run on the bf16 matrix cores (16x the fp32 MFMA rate) and only a handful of candidates per user
+// are re-scored with the exact fp32 chain.  Exactness comes from a rigorous error bound, not from luck:
+//
+//   s   = exact fp32-chain score of (u, i)            s' = bf16 MFMA score  sum_f bf16(u_f) bf16(i_f)  (+ bias, fp32)
+//   |s - s'| <= E_u := ||u|| * max_i ||i|| * (2^-7 * 1.02 + F * 2^-21) + 2^-21 (||u|| max||i|| + max|bias|)
+//        (bf16 rounding: relative 2^-8 per factor -> (2^-7 + 2^-16) sum|u_f i_f| <= ... ||u|| ||i|| by Cauchy-Schwarz;
+//         fp32 accumulation of either chain: <= F 2^-24 sum|u_f i_f| each, taken with a 4x margin; bias add 2^-24 rel.)
+//   If T is ANY value such that k unmasked items have s' >= T, every member of the exact top-k has s' >= T - 2 E_u.
+//        (k items have s >= T - E_u, so the k-th exact score s_(k) >= T - E_u, and a member has s' >= s - E_u.)
+//
+// Selection in a stream is VALU work that the 16x faster matrix cores no longer hide, so the pass is done twice:
+//
+//   pass 1  k_screen_pass<MODE 1>  s' for all (user, item) pairs; the only epilogue is a running max per ACCUMULATOR
+//           POSITION: item tile row (64 of them) -> 64 disjoint item groups per user, one max each ("slot maxima").
+//   thr     k_screen_thr           per user: slots whose maximum may belong to a masked (train) item are dropped -- the
+//           masked items are few, their s' is recomputed on the VALU and compared with a tolerance; T = k-th largest
+//           surviving slot maximum (k distinct unmasked items reach it), thr = T - 2 E_u.  T is the ~(k+2)-th best score
+//           of the catalogue, so the window holds k + a few items.
+//   pass 2  k_screen_pass<MODE 2>  the same GEMM (bit-identical s'), epilogue = max over the 16 accumulators of a lane
+//           against the FINAL threshold; the rare hit is appended to the user's list (64 + nnz_u slots, masked or not).
+//   final   k_screen_final         per user: drop masked hits, exact fp32 chain for the survivors, sort, write.
+//   Users with fewer than k clean slots, a non-finite bound, or more than 64 unmasked hits (pathological ties) are
+//   flagged and recomputed by the wave-per-user kernel, so the result is exact for every input.
+//
+// Geometry of a pass: 512 threads = 8 waves, 64 users per wave (2 MFMA column blocks) -> 512 users per workgroup share
+// one 64-item bf16 tile.  A operand (items): 16 B per lane straight out of an XOR-swizzled LDS image (conflict-free
+// ds_read_b128); B operand (users): resident in VGPRs for the whole kernel.
+#include <stdio.h>
+#include <stdlib.h>
+#include "el_topk_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define SCR_TI 64        // items per tile == slots per user
+#define SCR_SURV 128     // unmasked hits a user may have before it is sent to the exact fallback
+
+__device__ __forceinline__ u32 el_f2bf(float x) {
+    u32 b = __float_as_uint(x);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return b >> 16;
+}
+__device__ __forceinline__ float el_bf2f(u32 h) { return __uint_as_float(h << 16); }
+
+// E (screening error bound) and tol (bound on the difference of two fp32 evaluations of the same bf16 dot product)
+__device__ __forceinline__ void el_screen_bounds(float nu, float imax, float babs, int F, float& E, float& tol) {
+    tol = (float)F * 4.8e-7f * nu * imax + 4.8e-7f * (nu * imax + babs) + 1e-30f;
+    E = nu * imax * (0.0078125f * 1.02f) + tol;
+}
+
+// accumulator position (tile row 0..63) -> slot id, the order pass 1 stores the maxima in
+__device__ __forceinline__ int el_screen_slot(int row) {
+    const int ib = row >> 5, r32 = row & 31;
+    return ib * 32 + ((r32 >> 2) & 1) * 16 + (r32 & 3) + 4 * (r32 >> 3);
+}
+
+// ---- item side preparation: bf16 image [I][FP] (zero padded), max ||i||, max |bias| ------------------------------
+__global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ Gi, const float* __restrict__ Bi, int64_t I,
+                                                     int F, int FP, unsigned short* __restrict__ Gib, float* stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;   // 16 items per wave
+    u32 nmax = 0u, bmax = 0u;                            // non-negative floats order as their bit patterns
+    for (int t = 0; t < 16; ++t) {
+        const int64_t item = first + t;
+        if (item >= I) break;
+        float ss = 0.f;
+        for (int f = lane; f < FP; f += 64) {
+            const float v = (f < F) ? Gi[item * F + f] : 0.f;
+            Gib[item * FP + f] = (unsigned short)el_f2bf(v);
+            ss += v * v;
+        }
+        ss = el_group_sum(ss, 64);
+        float nrm = sqrtf(ss) * 1.001f;
+        if (!(nrm < INFINITY)) nrm = INFINITY;           // NaN / inf rows poison the bound -> every user falls back
+        nmax = max(nmax, __float_as_uint(nrm));
+        if (Bi) {
+            float b = fabsf(Bi[item]);
+            if (!(b < INFINITY)) b = INFINITY;
+            bmax = max(bmax, __float_as_uint(b));
+        }
+    }
+    if (lane == 0 && first < I) {
+        atomicMax(reinterpret_cast<unsigned int*>(stats), nmax);
+        if (Bi) atomicMax(reinterpret_cast<unsigned int*>(stats) + 1, bmax);
+    }
+}
+
+struct ScreenParams {
+    TopkParams t;
+    const unsigned short* Gib;   // [I_local][FP] bf16
+    const float* stats;          // [0] max item norm, [1] max |bias|
+    float* smax;                 // [n_users][64] slot maxima (pass 1)
+    float* thr;                  // [n_users] final threshold (+inf: user is flagged)
+    int32_t* cnt;                // [n_users] hits appended in pass 2
+    int32_t* ovf;                // [n_users] 1 = recompute with the exact wave kernel
+    u64* lists;                  // user u: [64 * (u - u_start) + indptr[u] - indptr[u_start], +64 + nnz_u)
+    int64_t list_cap;            // entries in `lists`
+    int32_t* ulist;              // [n_users] flagged users (relative ids), filled by k_screen_flags
+    int32_t* ulist_n;            // [1]
+    int stride;                  // pass 1 visits tiles t with t % stride == 0
+    unsigned long long* prof;    // EL_SCREEN_PROF=1: [n_waves][8] cycle / event counters (developer tool)
+};
+
+#define PROF_T() (PROF ? __builtin_amdgcn_s_memtime() : 0ull)
+
+template <int FP, int MODE, int NW, bool PROF>
+__global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
+    constexpr int NT = NW * 64;
+    constexpr int TI = SCR_TI;
+    constexpr int ROWB = FP * 2;                // bytes per bf16 row
+    constexpr int SL = FP / 8;                  // 16-byte slots per row
+    constexpr int RPB = (256 / ROWB) ? (256 / ROWB) : 1;   // rows per 256 B (one sweep over the 64 LDS banks)
+    constexpr int SWZ = (SL >= 16) ? 15 : (SL - 1);        // slot' = slot ^ ((row / RPB) & SWZ): 16 consecutive rows never collide
+    constexpr int TILEB = TI * ROWB;
+    constexpr int NPC = (TI * SL + NT - 1) / NT;  // 16-byte pieces per thread per tile
+    constexpr int NKS = FP / 16;                // MFMA k-steps
+    constexpr int UPB = NW * 64;
+    const TopkParams& p = sp.t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tiles = smem;                                              // [2][TILEB]
+    float* Bs = reinterpret_cast<float*>(smem + 2 * TILEB);          // [2][TI] bias, -inf past the end of the catalogue
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    const int F = p.F;
+    const int64_t I = p.I_local;
+    const int64_t ublock = p.u_start + (int64_t)blockIdx.x * UPB + wave * 64;
+
+    // ---- resident user fragments (bf16) ------------------------------------------------------------------------------
+    bf16x8 bfr[2][NKS];
+    bool uvalid[2];
+    float thr[2] = {INFINITY, INFINITY};
+    int ucnt[2] = {0, 0}, lcap[2] = {0, 0};
+    int64_t lbase[2] = {0, 0};
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+        const int64_t user = ublock + ub * 32 + col;
+        uvalid[ub] = user < p.u_stop;
+        const float* gu = p.Gu + (uvalid[ub] ? user : p.u_start) * (int64_t)F;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int k0 = ks * 16 + hi * 8;
+            union {
+                u32 w[4];
+                bf16x8 v;
+            } pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ka = k0 + 2 * j, kb = ka + 1;
+                const float a = (uvalid[ub] && ka < F) ? gu[ka] : 0.f;
+                const float b = (uvalid[ub] && kb < F) ? gu[kb] : 0.f;
+                pk.w[j] = el_f2bf(a) | (el_f2bf(b) << 16);
+            }
+            bfr[ub][ks] = pk.v;
+        }
+        if (MODE == 2 && uvalid[ub]) {
+            const int64_t ur = user - p.u_start;
+            thr[ub] = sp.thr[ur];
+            int64_t nz = 0, zoff = 0;
+            if (p.excl_indptr) {
+                const int64_t z0 = p.excl_indptr[user];
+                nz = p.excl_indptr[user + 1] - z0;
+                zoff = z0 - p.excl_indptr[p.u_start];
+            }
+            lbase[ub] = ur * SCR_SURV + zoff;
+            int64_t cap = SCR_SURV + nz;
+            if (lbase[ub] + cap > sp.list_cap) cap = sp.list_cap - lbase[ub];     // undersized workspace: flag, never write OOB
+            lcap[ub] = (int)(cap < 0 ? 0 : (cap > 0x3fffffff ? 0x3fffffff : cap));
+        }
+    }
+    floatx16 mx[2][2];
+    if (MODE == 1) {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[ub][ib][r] = -INFINITY;
+    }
+
+    // ---- item tile staging -------------------------------------------------------------------------------------------
+    const int ntiles = (int)((I + TI - 1) / TI);
+    const int step = (MODE == 1) ? sp.stride : 1;
+    uint4 pre[NPC];
+    float pre_bias = 0.f;
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) {
+            const int piece = q * NT + tid;
+            const int r = piece / SL, sl = piece % SL;
+            const int64_t item = (int64_t)tile * TI + r;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (piece < TI * SL && item < I) v = *reinterpret_cast<const uint4*>(sp.Gib + item * FP + sl * 8);
+            pre[q] = v;
+        }
+        if (tid < TI) {
+            const int64_t item = (int64_t)tile * TI + tid;
+            pre_bias = (item < I) ? (p.Bi ? p.Bi[item] : 0.f) : -INFINITY;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) {
+            const int piece = q * NT + tid;
+            const int r = piece / SL, sl = piece % SL;
+            if (piece < TI * SL) *reinterpret_cast<uint4*>(tiles + buf * TILEB + r * ROWB + ((sl ^ ((r / RPB) & SWZ)) << 4)) = pre[q];
+        }
+        if (tid < TI) Bs[buf * TI + tid] = pre_bias;
+    };
+
+    int buf = 0;
+    unsigned long long pc_stage = 0, pc_mfma = 0, pc_epi = 0, pc_rare = 0, pn_enter = 0, pn_hits = 0, pn_blocks = 0;
+    const unsigned long long pt_begin = PROF_T();
+    if (ntiles > 0) gload(0);
+    for (int tile = 0; tile < ntiles; tile += step) {
+        unsigned long long pt0 = PROF_T();
+        lstore(buf);
+        __syncthreads();
+        if (tile + step < ntiles) gload(tile + step);
+        unsigned long long pt1 = PROF_T();
+        pc_stage += pt1 - pt0;
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ub][ib][r] = 0.f;
+        const char* tb = tiles + buf * TILEB;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 a[2];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int row = ib * 32 + col;
+                a[ib] = *reinterpret_cast<const bf16x8*>(tb + row * ROWB + (((ks * 2 + hi) ^ ((row / RPB) & SWZ)) << 4));
+            }
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    acc[ub][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ib], bfr[ub][ks], acc[ub][ib], 0, 0, 0);
+        }
+        // bias of this lane's 2 x 16 accumulator rows: rows ib*32 + 8q + 4hi + {0..3} are r = 4q..4q+3
+        const float* bb = Bs + buf * TI;
+        floatx16 bias16[2];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(bb + ib * 32 + 8 * q + 4 * hi);
+                bias16[ib][4 * q + 0] = v[0];
+                bias16[ib][4 * q + 1] = v[1];
+                bias16[ib][4 * q + 2] = v[2];
+                bias16[ib][4 * q + 3] = v[3];
+            }
+        if (PROF) {
+            float sink = acc[0][0][0] + acc[0][1][0] + acc[1][0][0] + acc[1][1][0];
+            asm volatile("" ::"v"(sink));
+            pt0 = PROF_T();
+            pc_mfma += pt0 - pt1;
+            pn_blocks += 4;
+        }
+        unsigned long long rare_t = 0;
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const floatx16 sc = acc[ub][ib] + bias16[ib];          // s' (a padded row carries -inf)
+                if (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx[ub][ib][r] = fmaxf(mx[ub][ib][r], sc[r]);
+                } else {
+                    float m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, sc[r]), sc[r + 1]);
+                    if (__ballot(m >= thr[ub]) != 0ull) {
+                        const unsigned long long r0 = PROF_T();
+                        pn_enter += 1;
+                        u32 hm = 0u;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hm |= (sc[r] >= thr[ub]) ? (1u << r) : 0u;
+                        while (__ballot(hm != 0u) != 0ull) {
+                            const bool pend = hm != 0u;
+                            const int r = pend ? (__ffs((int)hm) - 1) : 0;
+                            hm &= hm - 1u;
+                            float sv = sc[0];
+#pragma unroll
+                            for (int q = 1; q < 16; ++q) sv = (r == q) ? sc[q] : sv;
+                            const int64_t il = (int64_t)tile * TI + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const int32_t g = (int32_t)(p.item_offset + il);
+                            const u32 pv = el_partner32(pend ? 1u : 0u, hi);
+                            const int pos = ucnt[ub] + (hi ? (int)pv : 0);
+                            if (pend && pos < lcap[ub]) sp.lists[lbase[ub] + pos] = el_make_key(sv, g);
+                            ucnt[ub] += (pend ? 1 : 0) + (int)pv;
+                            if (PROF) pn_hits += __popcll(__ballot(pend));
+                        }
+                        if (PROF) rare_t += PROF_T() - r0;
+                    }
+                }
+            }
+        }
+        if (PROF) {
+            pc_epi += PROF_T() - pt0 - rare_t;
+            pc_rare += rare_t;
+        }
+        buf ^= 1;
+    }
+
+    if (MODE == 1) {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            const int64_t user = ublock + ub * 32 + col;
+            if (!uvalid[ub]) continue;
+            float* o = sp.smax + (user - p.u_start) * SCR_TI + hi * 16;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    floatx4 v;
+                    v[0] = mx[ub][ib][4 * q + 0];
+                    v[1] = mx[ub][ib][4 * q + 1];
+                    v[2] = mx[ub][ib][4 * q + 2];
+                    v[3] = mx[ub][ib][4 * q + 3];
+                    *reinterpret_cast<floatx4*>(o + ib * 32 + 4 * q) = v;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            const int64_t user = ublock + ub * 32 + col;
+            if (!uvalid[ub] || hi) continue;
+            const int64_t ur = user - p.u_start;
+            sp.cnt[ur] = ucnt[ub] < lcap[ub] ? ucnt[ub] : lcap[ub];
+            if (ucnt[ub] > lcap[ub]) sp.ovf[ur] = 1;
+        }
+    }
+    if (PROF && lane == 0) {
+        unsigned long long* o = sp.prof + ((int64_t)blockIdx.x * NW + wave) * 8;
+        o[0] = PROF_T() - pt_begin;
+        o[1] = pc_stage;
+        o[2] = pc_mfma;
+        o[3] = pc_epi;
+        o[4] = pc_rare;
+        o[5] = pn_blocks;
+        o[6] = pn_enter;
+        o[7] = pn_hits;
+    }
+}
+
+// ---- per-user threshold from the slot maxima ---------------------------------------------------------------------
+// One wave per user.  A masked item j contaminates its slot when it may be the slot's arg-max: its s' is recomputed
+// here (same bf16 operands, fp32 fma chain) and compared with the slot maximum with the fp32 re-association tolerance.
+// (If it is NOT flagged, the arg-max is another item, and that item is unmasked or it would have flagged the slot.)
+template <int FP>
+__global__ __launch_bounds__(64) void k_screen_thr(ScreenParams sp) {
+    const TopkParams& p = sp.t;
+    const int lane = threadIdx.x;
+    const int64_t ur = blockIdx.x, user = p.u_start + ur;
+    __shared__ float sm[SCR_TI];
+    __shared__ int inv[SCR_TI];
+    __shared__ __attribute__((aligned(16))) float ubf[FP];
+    __shared__ u64 keys[SCR_TI];
+    const float M = sp.smax[ur * SCR_TI + lane];
+    sm[lane] = M;
+    inv[lane] = 0;
+    const float* gu = p.Gu + user * (int64_t)p.F;
+    float ss = 0.f;
+    for (int f = lane; f < FP; f += 64) {
+        const float v = (f < p.F) ? gu[f] : 0.f;
+        ubf[f] = el_bf2f(el_f2bf(v));
+        ss += v * v;
+    }
+    ss = el_group_sum(ss, 64);
+    const float nu = sqrtf(ss) * 1.001f;
+    float E, tol;
+    el_screen_bounds(nu, sp.stats[0], sp.stats[1], p.F, E, tol);
+    el_wave_lds_sync();
+    if (p.excl_indptr) {
+        const int64_t e0 = p.excl_indptr[user], e1 = p.excl_indptr[user + 1];
+        for (int64_t e = e0 + lane; e < e1; e += 64) {
+            const int64_t il = (int64_t)p.excl_indices[e] - p.item_offset;
+            if (il < 0 || il >= p.I_local) continue;
+            if (((il >> 6) % sp.stride) != 0) continue;                  // tile not visited by pass 1
+            const int slot = el_screen_slot((int)(il & 63));
+            const uint4* row = reinterpret_cast<const uint4*>(sp.Gib + il * FP);
+            float a = 0.f;
+#pragma unroll 2
+            for (int c = 0; c < FP / 8; ++c) {
+                const uint4 v = row[c];
+                const float* uu = ubf + c * 8;
+                a = __builtin_fmaf(el_bf2f(v.x & 0xffffu), uu[0], a);
+                a = __builtin_fmaf(el_bf2f(v.x >> 16), uu[1], a);
+                a = __builtin_fmaf(el_bf2f(v.y & 0xffffu), uu[2], a);
+                a = __builtin_fmaf(el_bf2f(v.y >> 16), uu[3], a);
+                a = __builtin_fmaf(el_bf2f(v.z & 0xffffu), uu[4], a);
+                a = __builtin_fmaf(el_bf2f(v.z >> 16), uu[5], a);
+                a = __builtin_fmaf(el_bf2f(v.w & 0xffffu), uu[6], a);
+                a = __builtin_fmaf(el_bf2f(v.w >> 16), uu[7], a);
+            }
+            const float s = a + (p.Bi ? p.Bi[il] : 0.f);
+            if (!(s < sm[slot] - tol)) inv[slot] = 1;                    // NaN lands here too (conservative)
+        }
+    }
+    el_wave_lds_sync();
+    const bool ok = (inv[lane] == 0) && (M > -INFINITY) && (M < INFINITY);
+    keys[lane] = ok ? el_make_key(M, lane) : 0ull;
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(keys, SCR_TI, lane);
+    if (lane == 0) {
+        const u64 kk = keys[p.k - 1];                                    // k <= 30 < 64 (eligibility)
+        const bool good = (kk != 0ull) && (E < INFINITY);
+        sp.thr[ur] = good ? (el_key_score(kk) - 2.0f * E) : INFINITY;
+        sp.ovf[ur] = good ? 0 : 1;
+        sp.cnt[ur] = 0;
+    }
+}
+
+// ---- exact re-scoring of the survivors + write-out -------------------------------------------------------------------
+__device__ __forceinline__ float el_exact_score(const TopkParams& p, int64_t user, int64_t il, bool vec4) {
+    const float* gi = p.Gi + il * (int64_t)p.F;
+    const float* gu = p.Gu + user * (int64_t)p.F;
+    float a = 0.f;
+    if (vec4) {                                      // 16 B per lane per request: the rows are read through L1, not re-fetched
+        const float4* gi4 = reinterpret_cast<const float4*>(gi);
+        const float4* gu4 = reinterpret_cast<const float4*>(gu);
+        for (int c = 0; c < p.F / 4; ++c) {
+            const float4 x = gi4[c], y = gu4[c];
+            a = __builtin_fmaf(x.x, y.x, a);
+            a = __builtin_fmaf(x.y, y.y, a);
+            a = __builtin_fmaf(x.z, y.z, a);
+            a = __builtin_fmaf(x.w, y.w, a);
+        }
+    } else {
+        for (int f = 0; f < p.F; ++f) a = __builtin_fmaf(gi[f], gu[f], a);
+    }
+    return (p.Bi ? a + p.Bi[il] : a) + 0.0f;
+}
+
+__global__ __launch_bounds__(64) void k_screen_final(ScreenParams sp) {
+    const TopkParams& p = sp.t;
+    const int lane = threadIdx.x;
+    const int64_t ur = blockIdx.x, user = p.u_start + ur;
+    if (sp.ovf[ur]) return;
+    __shared__ u64 surv[SCR_SURV];
+    const int n = sp.cnt[ur];
+    int64_t e0 = 0, e1 = 0, zoff = 0;
+    if (p.excl_indptr) {
+        e0 = p.excl_indptr[user];
+        e1 = p.excl_indptr[user + 1];
+        zoff = e0 - p.excl_indptr[p.u_start];
+    }
+    const u64* list = sp.lists + ur * SCR_SURV + zoff;
+    for (int t = lane; t < SCR_SURV; t += 64) surv[t] = 0ull;
+    el_wave_lds_sync();
+    int ns = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int t = base + lane;
+        u64 key = 0ull;
+        bool keep = false;
+        if (t < n) {
+            key = list[t];
+            keep = !(e1 > e0 && el_row_contains(p.excl_indices, e0, e1, el_key_item(key)));
+        }
+        const u64 b = __ballot(keep);
+        const int pos = ns + __popcll(b & ((1ull << lane) - 1ull));
+        if (keep && pos < SCR_SURV) surv[pos] = key;
+        ns += __popcll(b);
+    }
+    el_wave_lds_sync();
+    if (ns > SCR_SURV || ns < p.k) {                 // window overflow / cannot happen unless flagged: exact fallback
+        if (lane == 0) sp.ovf[ur] = 1;
+        return;
+    }
+    const bool vec4 = (p.F % 4 == 0) && (((reinterpret_cast<uintptr_t>(p.Gi) | reinterpret_cast<uintptr_t>(p.Gu)) & 15) == 0);
+    u64 nk[SCR_SURV / 64];
+#pragma unroll
+    for (int q = 0; q < SCR_SURV / 64; ++q) {
+        const int t = q * 64 + lane;
+        nk[q] = 0ull;
+        if (t < ns) {
+            const int32_t g = el_key_item(surv[t]);
+            const float s = el_exact_score(p, user, (int64_t)g - p.item_offset, vec4);
+            if (s == s) nk[q] = el_make_key(s, g);
+        }
+    }
+    el_wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < SCR_SURV / 64; ++q) surv[q * 64 + lane] = nk[q];
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(surv, SCR_SURV, lane);
+    int nv = 0;
+#pragma unroll
+    for (int q = 0; q < SCR_SURV / 64; ++q) nv += __popcll(__ballot(surv[q * 64 + lane] != 0ull));
+    if (nv < p.k) {                                  // exact score NaN where the screen was finite: let the fallback decide
+        if (lane == 0) sp.ovf[ur] = 1;
+        return;
+    }
+    const int64_t orow = ur * (int64_t)p.k;
+    if (lane < p.k) {
+        const u64 kk = surv[lane];
+        p.out_idx[orow + lane] = el_key_item(kk);
+        p.out_val[orow + lane] = el_key_score(kk);
+    }
+}
+
+// flagged users -> list for the fp32 MFMA kernel (order is irrelevant: rows are independent)
+__global__ __launch_bounds__(256) void k_screen_flags(ScreenParams sp, int64_t n_users) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u < n_users && sp.ovf[u]) sp.ulist[atomicAdd(sp.ulist_n, 1)] = (int32_t)u;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------
+static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int screen_fp(int F) { return F <= 32 ? 32 : (F <= 64 ? 64 : 128); }
+
+bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 128 && k >= 1 && k <= 30; }
+
+size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, int64_t excl_nnz) {
+    const int FP = screen_fp(F);
+    if (excl_nnz < 0) excl_nnz = 0;
+    return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 4 * a256((size_t)n_users * 4) +
+           a256(el_topk_list_scratch_bytes(n_users, k)) + a256(((size_t)n_users * SCR_SURV + (size_t)excl_nnz) * 8);
+}
+
+template <int FP, int MODE, int NW, bool PROF>
+static int launch_pass(const ScreenParams& sp, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * SCR_TI * FP * 2 + 2 * SCR_TI * 4;
+    auto kern = k_screen_pass<FP, MODE, NW, PROF>;
+    const int64_t n_users = sp.t.u_stop - sp.t.u_start;
+    EL_LAUNCH(MODE == 1 ? "k_screen_pass1" : "k_screen_pass2", kern, dim3((unsigned)((n_users + NW * 64 - 1) / (NW * 64))), dim3(NW * 64),
+              lds, st, sp);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int FP, int NW, bool PROF>
+static int run_passes(ScreenParams& sp, hipStream_t st) {
+    const int64_t n_users = sp.t.u_stop - sp.t.u_start;
+    const int64_t nw = ((n_users + NW * 64 - 1) / (NW * 64)) * NW;
+    unsigned long long* h = nullptr;
+    if (PROF) {
+        EL_CHECK_HIP(hipMalloc((void**)&sp.prof, (size_t)nw * 64));
+        h = (unsigned long long*)malloc((size_t)nw * 64);
+    }
+    auto report = [&](const char* name) -> int {
+        EL_CHECK_HIP(hipStreamSynchronize(st));
+        EL_CHECK_HIP(hipMemcpy(h, sp.prof, (size_t)nw * 64, hipMemcpyDeviceToHost));
+        double a[8] = {0};
+        for (int64_t w = 0; w < nw; ++w)
+            for (int q = 0; q < 8; ++q) a[q] += (double)h[w * 8 + q] / (double)nw;
+        fprintf(stderr, "[screen prof] %s per wave: total %.0f  stage %.0f  mfma %.0f  epilogue %.0f  rare %.0f cycles | "
+                "blocks %.0f entered %.0f hits %.0f\n", name, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+        return 0;
+    };
+    if (int rc = launch_pass<FP, 1, NW, PROF>(sp, st)) return rc;
+    if (PROF) report("pass1");
+    auto kthr = k_screen_thr<FP>;
+    EL_LAUNCH("k_screen_thr", kthr, dim3((unsigned)n_users), dim3(64), 0, st, sp);
+    if (int rc = launch_pass<FP, 2, NW, PROF>(sp, st)) return rc;
+    if (PROF) {
+        report("pass2");
+        free(h);
+        EL_CHECK_HIP(hipFree(sp.prof));
+        sp.prof = nullptr;
+    }
+    EL_LAUNCH("k_screen_final", k_screen_final, dim3((unsigned)n_users), dim3(64), 0, st, sp);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int64_t n_users = p.u_stop - p.u_start;
+    if (n_users <= 0) return 0;
+    const int FP = screen_fp(p.F);
+    const size_t fixed = el_topk_screen_ws_bytes(n_users, p.I_local, p.F, p.k, 0);
+    EL_REQUIRE(ws != nullptr && ws_bytes >= fixed, "el_score_topk: screened top-k needs a workspace of el_score_topk_ws_bytes() bytes");
+    char* base = (char*)ws;
+    ScreenParams sp;
+    sp.t = p;
+    unsigned short* gib = (unsigned short*)base;
+    base += a256((size_t)p.I_local * FP * 2);
+    float* stats = (float*)base;
+    base += a256(16);
+    sp.smax = (float*)base;
+    base += a256((size_t)n_users * SCR_TI * 4);
+    sp.thr = (float*)base;
+    base += a256((size_t)n_users * 4);
+    sp.cnt = (int32_t*)base;
+    base += a256((size_t)n_users * 4);
+    sp.ovf = (int32_t*)base;
+    base += a256((size_t)n_users * 4);
+    sp.ulist = (int32_t*)base;
+    base += a256((size_t)n_users * 4);
+    sp.ulist_n = (int32_t*)(stats + 2);
+    void* fb_scratch = base;
+    const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.k);
+    base += a256(fb_bytes);
+    sp.lists = (u64*)base;
+    sp.list_cap = (int64_t)(((char*)ws + ws_bytes - base) / 8);      // whatever the caller provisioned for 64*U + nnz
+    sp.Gib = gib;
+    sp.stats = stats;
+    sp.prof = nullptr;
+    const int ntiles = (int)((p.I_local + SCR_TI - 1) / SCR_TI);
+    sp.stride = 1;   // 2 halves pass 1 but doubles the hits of pass 2 / final: a wash on MI355X (EL_SCREEN_STRIDE to experiment)
+    (void)ntiles;
+    if (const char* se = getenv("EL_SCREEN_STRIDE")) {
+        const int v = atoi(se);
+        if (v >= 1 && v <= 8) sp.stride = v;
+    }
+    EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
+    if (p.I_local > 0)
+        EL_LAUNCH("k_screen_prep", k_screen_prep, dim3((unsigned)((p.I_local + 63) / 64)), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F,
+                  FP, gib, stats);
+    const char* pe = getenv("EL_SCREEN_PROF");
+    const bool prof = pe && pe[0] == '1';
+    int rc;
+#define SCR_RUN(FPV) (prof ? run_passes<FPV, 8, true>(sp, st) : run_passes<FPV, 8, false>(sp, st))
+    if (FP == 32)
+        rc = SCR_RUN(32);
+    else if (FP == 64)
+        rc = SCR_RUN(64);
+    else
+        rc = SCR_RUN(128);
+#undef SCR_RUN
+    if (rc) return rc;
+    // exact recomputation of the flagged users by the fp32 MFMA kernel (a grid of early exits when nothing is flagged)
+    EL_LAUNCH("k_screen_flags", k_screen_flags, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st, sp, n_users);
+    EL_CHECK_LAUNCH();
+    if (prof) {
+        int32_t nf = 0;
+        EL_CHECK_HIP(hipStreamSynchronize(st));
+        EL_CHECK_HIP(hipMemcpy(&nf, sp.ulist_n, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[screen prof] flagged users: %d of %lld (stride %d)\n", nf, (long long)n_users, sp.stride);
+    }
+    TopkParams pw = p;
+    pw.ulist = sp.ulist;
+    pw.ulist_n = sp.ulist_n;
+    return el_topk_run_list(pw, fb_scratch, fb_bytes, st);
+}

@@ -11,12 +11,12 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (EL_OPT_ADAM_LAZY, EL_OPT_ADAM_TF_DENSE, EL_OPT_SGD, EL_TOPK_AUTO, EL_TOPK_MFMA,
+from ._lib import (EL_OPT_ADAM_LAZY, EL_OPT_ADAM_TF_DENSE, EL_OPT_SGD, EL_TOPK_AUTO, EL_TOPK_MFMA, EL_TOPK_SCREEN,
                    EL_TOPK_SIMPLE, BprmfState, BprsgdState, check)
 
 OPTIMIZERS = {"adam": EL_OPT_ADAM_TF_DENSE, "adam_tf_dense": EL_OPT_ADAM_TF_DENSE,
               "adam_lazy": EL_OPT_ADAM_LAZY, "sgd": EL_OPT_SGD, "sgd_dense": EL_OPT_SGD}
-TOPK_ALGOS = {"auto": EL_TOPK_AUTO, "mfma": EL_TOPK_MFMA, "simple": EL_TOPK_SIMPLE}
+TOPK_ALGOS = {"auto": EL_TOPK_AUTO, "mfma": EL_TOPK_MFMA, "simple": EL_TOPK_SIMPLE, "screen": EL_TOPK_SCREEN}
 BPR_ALGOS = {"auto": _lib.EL_BPR_AUTO, "atomic": _lib.EL_BPR_ATOMIC, "sorted": _lib.EL_BPR_SORTED}
 
 
@@ -149,11 +149,21 @@ def score_topk(ctx, Gu, Gi, Bi, u_start, u_stop, k, excl=None, cand=None, item_o
         out_val = torch.empty((n, k), dtype=torch.float32, device=ctx.device)
     ep, ei = _csr_ptrs(excl)
     cp, ci = _csr_ptrs(cand)
+    algo_id = TOPK_ALGOS[algo] if isinstance(algo, str) else int(algo)
+    ws, need = None, 0
+    if cand is None and algo_id in (EL_TOPK_AUTO, EL_TOPK_SCREEN):
+        need = int(ctx.lib.el_score_topk_ws_bytes(int(n), int(I_local), int(F), int(k), int(excl.nnz) if excl is not None else 0, algo_id))
+        if need:
+            cached = getattr(ctx, "_topk_ws", None)
+            if cached is None or cached.numel() < need:
+                cached = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+                ctx._topk_ws = cached
+            ws = C.c_void_p(cached.data_ptr())
     check(ctx.lib.el_score_topk(ctx.handle, ctx.stream(), _ptr(Gu, torch.float32, "Gu"),
                                 _ptr(Gi, torch.float32, "Gi"), _ptr(Bi, torch.float32, "Bi"),
                                 int(u_start), int(u_stop), int(item_offset), int(I_local), int(F),
                                 ep, ei, cp, ci, int(k), _ptr(out_idx, torch.int32), _ptr(out_val, torch.float32),
-                                TOPK_ALGOS[algo] if isinstance(algo, str) else int(algo), None, 0),
+                                algo_id, ws, need),
           "el_score_topk")
     return out_idx, out_val
 

@@ -199,9 +199,10 @@ int el_bprsgd_levels_host(const int32_t* u_host, const int32_t* i_host, const in
 /* ---- full-catalog scoring + masked top-k (K6/K7) ------------------------------ */
 
 enum {
-    EL_TOPK_AUTO = 0,   /* MFMA kernel when eligible, else the wave-per-user kernel */
-    EL_TOPK_MFMA = 1,   /* force v_mfma_f32_32x32x2_f32 kernel (error if ineligible) */
-    EL_TOPK_SIMPLE = 2  /* force wave-per-user VALU kernel                          */
+    EL_TOPK_AUTO = 0,   /* SCREEN when eligible and a workspace is given, else MFMA, else the wave kernel */
+    EL_TOPK_MFMA = 1,   /* force the fp32 kernel, v_mfma_f32_32x32x2_f32 (F<=256, k<=40)                */
+    EL_TOPK_SIMPLE = 2, /* force the wave-per-user VALU kernel (any F, k<=4032, candidate protocol)     */
+    EL_TOPK_SCREEN = 3  /* force the bf16-screened / fp32-exact kernel (F<=128, k<=30); same results    */
 };
 
 /* Replaces: BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) and
@@ -215,8 +216,11 @@ enum {
  * Gi / Bi describe the LOCAL item shard [item_offset, item_offset+I_local); out_idx
  * holds GLOBAL item indices.  CSR rows are indexed by absolute user id.
  *   out_idx int32[(u_stop-u_start), k], out_val float[(u_stop-u_start), k]
- * ws: el_score_topk_ws_bytes(...) bytes (may be 0).                               */
-size_t el_score_topk_ws_bytes(int64_t n_users, int64_t I_local, int32_t F, int32_t k, int algo);
+ * ws: el_score_topk_ws_bytes(...) bytes (0 unless the screened kernel can run);
+ *     excl_nnz = entries of the exclusion rows [u_start,u_stop) (0 without a mask): the
+ *     screened kernel keeps 64 + nnz_u candidate slots per user.  With ws == NULL, AUTO
+ *     uses the fp32 kernels.                                                           */
+size_t el_score_topk_ws_bytes(int64_t n_users, int64_t I_local, int32_t F, int32_t k, int64_t excl_nnz, int algo);
 int el_score_topk(el_ctx* ctx, void* stream,
                   const float* Gu, const float* Gi, const float* Bi,
                   int64_t u_start, int64_t u_stop, int64_t item_offset, int64_t I_local, int32_t F,

@@ -23,7 +23,7 @@ for f in sorted(glob.glob("$OUT/g*/*counter_collection.csv")):
         k = r["Kernel_Name"][:40]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
     for k, d in agg.items():
-        if "topk" in k:
+        if "topk" in k or "screen" in k:
             print(f, k, dict(d))
 PY
 cat $OUT/plain.txt | tail -3

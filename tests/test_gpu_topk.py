@@ -36,9 +36,11 @@ def run_gpu(ctx, Gu, Gi, Bi, u0, u1, k, excl=None, cand=None, item_offset=0, alg
     return cpu(idx), cpu(val)
 
 
-@pytest.mark.parametrize("algo", ["simple", "mfma"])
+@pytest.mark.parametrize("algo", ["simple", "mfma", "screen"])
 @pytest.mark.parametrize("F,k", [(64, 10), (128, 10), (10, 10), (128, 1), (32, 14), (200, 10), (256, 10), (64, 32), (128, 40), (12, 5)])
 def test_topk_matches_oracle_bitexact(ctx, algo, F, k):
+    if algo == "screen" and (F > 128 or k > 30):
+        pytest.skip("screened kernel: F <= 128, k <= 30")
     rs = np.random.RandomState(100 + F + k)
     U, I = 300, 1000 + F        # ragged last user block (300 = 2*128 + 44) and ragged last item tile
     Gu, Gi, Bi = make(rs, U, I, F)
@@ -48,7 +50,7 @@ def test_topk_matches_oracle_bitexact(ctx, algo, F, k):
     assert_topk_equal(f"topk_{algo}_F{F}_k{k}", gi, gv, ei, ev)
 
 
-@pytest.mark.parametrize("algo", ["simple", "mfma"])
+@pytest.mark.parametrize("algo", ["simple", "mfma", "screen"])
 def test_topk_no_bias_no_mask_and_user_subrange(ctx, algo):
     rs = np.random.RandomState(7)
     U, I, F, k = 500, 777, 64, 10
@@ -73,7 +75,7 @@ def test_topk_large_k_needs_wave_kernel_or_errors(ctx, algo):
     assert_topk_equal("topk_k100", gi, gv, ei, ev)
 
 
-@pytest.mark.parametrize("algo", ["simple", "mfma"])
+@pytest.mark.parametrize("algo", ["simple", "mfma", "screen"])
 def test_topk_heavy_exclusions_trained_like(ctx, algo):
     """Excluded (train) items get the HIGHEST scores, as after training: they must never surface."""
     rs = np.random.RandomState(9)
@@ -91,7 +93,7 @@ def test_topk_heavy_exclusions_trained_like(ctx, algo):
         assert not set(gi[u]) & set(ix[ip[u]:ip[u + 1]])
 
 
-@pytest.mark.parametrize("algo", ["simple", "mfma"])
+@pytest.mark.parametrize("algo", ["simple", "mfma", "screen"])
 def test_topk_fewer_than_k_candidates_pads_with_neg_inf(ctx, algo):
     rs = np.random.RandomState(10)
     U, I, F, k = 40, 64, 16, 10
@@ -117,7 +119,7 @@ def test_topk_candidate_protocol(ctx):
         assert_topk_equal(f"topk_cand_k{k}", gi, gv, ei, ev)
 
 
-@pytest.mark.parametrize("algo", ["simple", "mfma"])
+@pytest.mark.parametrize("algo", ["simple", "mfma", "screen"])
 def test_item_shards_merge_equals_single_shard(ctx, algo):
     rs = np.random.RandomState(12)
     U, I, F, k = 200, 1500, 64, 10
@@ -188,3 +190,57 @@ def test_scores_within_fp32_roundoff_of_fp64_matmul(ctx):
     ref = Bi.astype(np.float64) + Gu.astype(np.float64) @ Gi.astype(np.float64).T
     exact = np.take_along_axis(ref, gi.astype(np.int64), axis=1)
     assert np.abs(gv - exact).max() < 5e-5
+
+
+def test_screened_topk_pathological_ties_fall_back_exactly(ctx):
+    """All items identical for half of the users (every score ties -> the 2E window holds the whole catalogue): the
+    overflow flag must route those users through the exact wave kernel; results stay bit-identical to the oracle."""
+    rs = np.random.RandomState(21)
+    U, I, F, k = 600, 900, 64, 10
+    Gu, Gi, Bi = make(rs, U, I, F, ties=False)
+    Gi[100:800] = Gi[100]                    # 700 identical items
+    Bi[100:800] = Bi[100]
+    Gu[::2] *= 40.0                          # large norms -> wide windows as well
+    excl = random_excl(rs, U, I, 0, 30)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
+    assert_topk_equal("topk_screen_ties", gi, gv, ei, ev)
+
+
+def test_screened_topk_large_random_block(ctx):
+    rs = np.random.RandomState(22)
+    U, I, F, k = 1100, 5000, 128, 10
+    Gu = rs.uniform(-0.01, 0.01, size=(U, F)).astype(np.float32)
+    Gi = rs.uniform(-0.03, 0.03, size=(I, F)).astype(np.float32)
+    Gi[rs.randint(0, I, 50)] *= 6.0          # a few large-norm (popular) items
+    Bi = rs.normal(scale=0.001, size=I).astype(np.float32)
+    excl = random_excl(rs, U, I, 5, 60)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
+    assert_topk_equal("topk_screen_large", gi, gv, ei, ev)
+
+
+def test_screened_topk_all_users_fall_back(ctx):
+    """Every item identical -> every score of a user ties -> every user is flagged: exercises the item-split list
+    fallback (first 512 flagged users) and the plain list kernel (the rest)."""
+    rs = np.random.RandomState(23)
+    U, I, F, k = 700, 3000, 32, 10
+    Gu = rs.normal(scale=0.1, size=(U, F)).astype(np.float32)
+    Gi = np.repeat(rs.normal(scale=0.1, size=(1, F)).astype(np.float32), I, axis=0)
+    Bi = np.zeros(I, np.float32)
+    excl = random_excl(rs, U, I, 0, 40)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
+    assert_topk_equal("topk_screen_all_fallback", gi, gv, ei, ev)
+
+
+def test_screened_topk_nonfinite_inputs_fall_back(ctx):
+    rs = np.random.RandomState(24)
+    U, I, F, k = 130, 1000, 64, 10
+    Gu, Gi, Bi = make(rs, U, I, F, ties=False)
+    Gi[17, 3] = np.nan
+    Gi[400, 0] = np.inf
+    excl = random_excl(rs, U, I, 0, 20)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
+    assert_topk_equal("topk_screen_nonfinite", gi, gv, ei, ev)
