@@ -107,6 +107,24 @@ struct ScreenParams {
 
 #define PROF_T() (PROF ? __builtin_amdgcn_s_memtime() : 0ull)
 
+// v_max_f32 ignores a quiet NaN operand (MFMA results are quiet); fmaxf() would add a canonicalising v_max per call
+__device__ __forceinline__ float el_vmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float el_vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// One pass over the catalogue.  Software pipeline per wave (acc[ub][ib]: ub = user column block, ib = item row block):
+//
+//     MFMA(t, ib1) || E(t, ib0)   ->   stage tile t+1, barrier   ->   MFMA(t+1, ib0) || E(t, ib1)
+//
+// the epilogue E of one half tile is VALU work issued while the matrix core runs the other half; the bias enters as the
+// C operand of the first MFMA of a chain (s' = bias + sum, no VALU add).  LDS: two item tiles, a ring of four bias rows.
 template <int FP, int MODE, int NW, bool PROF>
 __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     constexpr int NT = NW * 64;
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     const TopkParams& p = sp.t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tiles = smem;                                              // [2][TILEB]
-    float* Bs = reinterpret_cast<float*>(smem + 2 * TILEB);          // [2][TI] bias, -inf past the end of the catalogue
+    float* Bs = reinterpret_cast<float*>(smem + 2 * TILEB);          // [4][TI] bias, -inf past the end of the catalogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
@@ -202,113 +220,94 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
             pre_bias = (item < I) ? (p.Bi ? p.Bi[item] : 0.f) : -INFINITY;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int it) {
 #pragma unroll
         for (int q = 0; q < NPC; ++q) {
             const int piece = q * NT + tid;
             const int r = piece / SL, sl = piece % SL;
-            if (piece < TI * SL) *reinterpret_cast<uint4*>(tiles + buf * TILEB + r * ROWB + ((sl ^ ((r / RPB) & SWZ)) << 4)) = pre[q];
+            if (piece < TI * SL)
+                *reinterpret_cast<uint4*>(tiles + (it & 1) * TILEB + r * ROWB + ((sl ^ ((r / RPB) & SWZ)) << 4)) = pre[q];
         }
-        if (tid < TI) Bs[buf * TI + tid] = pre_bias;
+        if (tid < TI) Bs[(it & 3) * TI + tid] = pre_bias;
     };
 
-    int buf = 0;
-    unsigned long long pc_stage = 0, pc_mfma = 0, pc_epi = 0, pc_rare = 0, pn_enter = 0, pn_hits = 0, pn_blocks = 0;
-    const unsigned long long pt_begin = PROF_T();
-    if (ntiles > 0) gload(0);
-    for (int tile = 0; tile < ntiles; tile += step) {
-        unsigned long long pt0 = PROF_T();
-        lstore(buf);
-        __syncthreads();
-        if (tile + step < ntiles) gload(tile + step);
-        unsigned long long pt1 = PROF_T();
-        pc_stage += pt1 - pt0;
-        floatx16 acc[2][2];
+    floatx16 acc[2][2];
+    // 2 x NKS MFMAs of item row block ib of the tile staged in slot `it`
+    auto mfma_half = [&](int it, int ib) {
+        // bias of this lane's 16 accumulator rows: rows ib*32 + 8q + 4hi + {0..3} are r = 4q..4q+3
+        const float* bb = Bs + (it & 3) * TI + ib * 32 + 4 * hi;
+        floatx16 b16;
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ub][ib][r] = 0.f;
-        const char* tb = tiles + buf * TILEB;
+        for (int q = 0; q < 4; ++q) {
+            const floatx4 v = *reinterpret_cast<const floatx4*>(bb + 8 * q);
+            b16[4 * q + 0] = v[0];
+            b16[4 * q + 1] = v[1];
+            b16[4 * q + 2] = v[2];
+            b16[4 * q + 3] = v[3];
+        }
+        const int row = ib * 32 + col;
+        const char* rb = tiles + (it & 1) * TILEB + row * ROWB;
+        const int key = (row / RPB) & SWZ;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            bf16x8 a[2];
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const int row = ib * 32 + col;
-                a[ib] = *reinterpret_cast<const bf16x8*>(tb + row * ROWB + (((ks * 2 + hi) ^ ((row / RPB) & SWZ)) << 4));
-            }
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + (((ks * 2 + hi) ^ key) << 4));
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
-                    acc[ub][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ib], bfr[ub][ks], acc[ub][ib], 0, 0, 0);
+                acc[ub][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[ub][ks], ks == 0 ? b16 : acc[ub][ib], 0, 0, 0);
         }
-        // bias of this lane's 2 x 16 accumulator rows: rows ib*32 + 8q + 4hi + {0..3} are r = 4q..4q+3
-        const float* bb = Bs + buf * TI;
-        floatx16 bias16[2];
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const floatx4 v = *reinterpret_cast<const floatx4*>(bb + ib * 32 + 8 * q + 4 * hi);
-                bias16[ib][4 * q + 0] = v[0];
-                bias16[ib][4 * q + 1] = v[1];
-                bias16[ib][4 * q + 2] = v[2];
-                bias16[ib][4 * q + 3] = v[3];
-            }
-        if (PROF) {
-            float sink = acc[0][0][0] + acc[0][1][0] + acc[1][0][0] + acc[1][1][0];
-            asm volatile("" ::"v"(sink));
-            pt0 = PROF_T();
-            pc_mfma += pt0 - pt1;
-            pn_blocks += 4;
-        }
-        unsigned long long rare_t = 0;
+    };
+
+    unsigned long long pn_enter = 0, pn_hits = 0, pn_blocks = 0;
+    // epilogue of item row block ib of tile `tile` (scores in acc[.][ib])
+    auto epi_half = [&](int tile, int ib) {
+        if (PROF) pn_blocks += 2;
 #pragma unroll
         for (int ub = 0; ub < 2; ++ub) {
+            const floatx16& sc = acc[ub][ib];                          // s' (a padded row carries -inf)
+            if (MODE == 1) {
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const floatx16 sc = acc[ub][ib] + bias16[ib];          // s' (a padded row carries -inf)
-                if (MODE == 1) {
+                for (int r = 0; r < 16; ++r) mx[ub][ib][r] = el_vmax(mx[ub][ib][r], sc[r]);
+            } else {
+                float m = el_vmax(sc[0], sc[1]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx[ub][ib][r] = fmaxf(mx[ub][ib][r], sc[r]);
-                } else {
-                    float m = fmaxf(sc[0], sc[1]);
+                for (int r = 2; r < 16; r += 2) m = el_vmax3(m, sc[r], sc[r + 1]);
+                if (__ballot(m >= thr[ub]) != 0ull) {
+                    // rare: one RECORD per lane with a hit = (tile, row block, lane half, 16-bit mask of the rows that reach
+                    // the threshold); k_screen_final expands it.  Lanes l and l+32 share the user's list counter.
+                    if (PROF) pn_enter += 1;
+                    u32 hm = 0u;
 #pragma unroll
-                    for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, sc[r]), sc[r + 1]);
-                    if (__ballot(m >= thr[ub]) != 0ull) {
-                        const unsigned long long r0 = PROF_T();
-                        pn_enter += 1;
-                        u32 hm = 0u;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) hm |= (sc[r] >= thr[ub]) ? (1u << r) : 0u;
-                        while (__ballot(hm != 0u) != 0ull) {
-                            const bool pend = hm != 0u;
-                            const int r = pend ? (__ffs((int)hm) - 1) : 0;
-                            hm &= hm - 1u;
-                            float sv = sc[0];
-#pragma unroll
-                            for (int q = 1; q < 16; ++q) sv = (r == q) ? sc[q] : sv;
-                            const int64_t il = (int64_t)tile * TI + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const int32_t g = (int32_t)(p.item_offset + il);
-                            const u32 pv = el_partner32(pend ? 1u : 0u, hi);
-                            const int pos = ucnt[ub] + (hi ? (int)pv : 0);
-                            if (pend && pos < lcap[ub]) sp.lists[lbase[ub] + pos] = el_make_key(sv, g);
-                            ucnt[ub] += (pend ? 1 : 0) + (int)pv;
-                            if (PROF) pn_hits += __popcll(__ballot(pend));
-                        }
-                        if (PROF) rare_t += PROF_T() - r0;
-                    }
+                    for (int r = 15; r >= 0; --r) hm = (hm << 1) | ((sc[r] >= thr[ub]) ? 1u : 0u);
+                    const bool pend = hm != 0u;
+                    const u32 pv = el_partner32(pend ? 1u : 0u, hi);
+                    const int pos = ucnt[ub] + (hi ? (int)pv : 0);
+                    if (pend && pos < lcap[ub])
+                        sp.lists[lbase[ub] + pos] = ((u64)(u32)tile << 18) | ((u64)ib << 17) | ((u64)hi << 16) | (u64)hm;
+                    ucnt[ub] += (pend ? 1 : 0) + (int)pv;
+                    if (PROF) pn_hits += __popcll(__ballot(pend));
                 }
             }
         }
-        if (PROF) {
-            pc_epi += PROF_T() - pt0 - rare_t;
-            pc_rare += rare_t;
-        }
-        buf ^= 1;
+    };
+
+    const unsigned long long pt_begin = PROF_T();
+    if (ntiles > 0) {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        if (step < ntiles) gload(step);
+        mfma_half(0, 0);
+    }
+    int it = 0;
+    for (int tile = 0; tile < ntiles; tile += step, ++it) {
+        const bool has_next = tile + step < ntiles;
+        mfma_half(it, 1);
+        epi_half(tile, 0);
+        if (has_next) lstore(it + 1);
+        __syncthreads();
+        if (tile + 2 * step < ntiles) gload(tile + 2 * step);
+        mfma_half(it + 1, 0);        // (past the last tile this chews on a stale LDS slot; the result is never read)
+        epi_half(tile, 1);
     }
 
     if (MODE == 1) {
@@ -342,10 +341,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     if (PROF && lane == 0) {
         unsigned long long* o = sp.prof + ((int64_t)blockIdx.x * NW + wave) * 8;
         o[0] = PROF_T() - pt_begin;
-        o[1] = pc_stage;
-        o[2] = pc_mfma;
-        o[3] = pc_epi;
-        o[4] = pc_rare;
+        o[1] = 0;
+        o[2] = 0;
+        o[3] = 0;
+        o[4] = 0;
         o[5] = pn_blocks;
         o[6] = pn_enter;
         o[7] = pn_hits;
@@ -457,19 +456,26 @@ __global__ __launch_bounds__(64) void k_screen_final(ScreenParams sp) {
     const u64* list = sp.lists + ur * SCR_SURV + zoff;
     for (int t = lane; t < SCR_SURV; t += 64) surv[t] = 0ull;
     el_wave_lds_sync();
-    int ns = 0;
+    int ns = 0;                                      // surv[] holds ITEM ids (low 32 bits) from here on
     for (int base = 0; base < n; base += 64) {
         const int t = base + lane;
-        u64 key = 0ull;
-        bool keep = false;
-        if (t < n) {
-            key = list[t];
-            keep = !(e1 > e0 && el_row_contains(p.excl_indices, e0, e1, el_key_item(key)));
+        const u64 rec = (t < n) ? list[t] : 0ull;
+        u32 hm = (u32)(rec & 0xffffu);
+        const int64_t row0 = (int64_t)(rec >> 18) * SCR_TI + (int64_t)((rec >> 17) & 1u) * 32 + 4 * (int)((rec >> 16) & 1u);
+        while (__ballot(hm != 0u) != 0ull) {
+            bool keep = false;
+            int32_t g = 0;
+            if (hm != 0u) {
+                const int r = __ffs((int)hm) - 1;
+                hm &= hm - 1u;
+                g = (int32_t)(p.item_offset + row0 + (r & 3) + 8 * (r >> 2));
+                keep = !(e1 > e0 && el_row_contains(p.excl_indices, e0, e1, g));
+            }
+            const u64 b = __ballot(keep);
+            const int pos = ns + __popcll(b & ((1ull << lane) - 1ull));
+            if (keep && pos < SCR_SURV) surv[pos] = (u64)(u32)g;
+            ns += __popcll(b);
         }
-        const u64 b = __ballot(keep);
-        const int pos = ns + __popcll(b & ((1ull << lane) - 1ull));
-        if (keep && pos < SCR_SURV) surv[pos] = key;
-        ns += __popcll(b);
     }
     el_wave_lds_sync();
     if (ns > SCR_SURV || ns < p.k) {                 // window overflow / cannot happen unless flagged: exact fallback
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(64) void k_screen_final(ScreenParams sp) {
         const int t = q * 64 + lane;
         nk[q] = 0ull;
         if (t < ns) {
-            const int32_t g = el_key_item(surv[t]);
+            const int32_t g = (int32_t)(u32)surv[t];
             const float s = el_exact_score(p, user, (int64_t)g - p.item_offset, vec4);
             if (s == s) nk[q] = el_make_key(s, g);
         }
@@ -530,7 +536,7 @@ size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, i
 
 template <int FP, int MODE, int NW, bool PROF>
 static int launch_pass(const ScreenParams& sp, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * SCR_TI * FP * 2 + 2 * SCR_TI * 4;
+    constexpr size_t lds = (size_t)2 * SCR_TI * FP * 2 + 4 * SCR_TI * 4;
     auto kern = k_screen_pass<FP, MODE, NW, PROF>;
     const int64_t n_users = sp.t.u_stop - sp.t.u_start;
     EL_LAUNCH(MODE == 1 ? "k_screen_pass1" : "k_screen_pass2", kern, dim3((unsigned)((n_users + NW * 64 - 1) / (NW * 64))), dim3(NW * 64),
@@ -554,8 +560,7 @@ static int run_passes(ScreenParams& sp, hipStream_t st) {
         double a[8] = {0};
         for (int64_t w = 0; w < nw; ++w)
             for (int q = 0; q < 8; ++q) a[q] += (double)h[w * 8 + q] / (double)nw;
-        fprintf(stderr, "[screen prof] %s per wave: total %.0f  stage %.0f  mfma %.0f  epilogue %.0f  rare %.0f cycles | "
-                "blocks %.0f entered %.0f hits %.0f\n", name, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+        fprintf(stderr, "[screen prof] %s per wave: %.0f cycles | blocks %.0f entered %.0f hits %.0f\n", name, a[0], a[5], a[6], a[7]);
         return 0;
     };
     if (int rc = launch_pass<FP, 1, NW, PROF>(sp, st)) return rc;
