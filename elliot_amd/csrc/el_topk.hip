@@ -27,7 +27,14 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
     u64* keys = reinterpret_cast<u64*>(smem);              // [cap]
     int* cnt_s = reinterpret_cast<int*>(smem + (size_t)cap * 8);  // [1] (+pad), used by el_wave_compact
     const int lane = threadIdx.x;
-    const int64_t user = p.u_start + blockIdx.x;
+    int64_t urel = blockIdx.x;                             // row of out_idx / out_val
+    if (p.ulist) {                                         // (dense rows stay indexed by blockIdx.x)
+        int64_t n = (int64_t)*p.ulist_n;
+        if (p.ulist_max > 0 && n > p.ulist_max) n = p.ulist_max;
+        if ((int64_t)blockIdx.x >= n) return;
+        urel = p.ulist[blockIdx.x];
+    }
+    const int64_t user = p.u_start + urel;
     if (p.only_flagged && p.only_flagged[blockIdx.x] == 0) return;
     const int F = p.F;
     const float* gu = DENSE ? nullptr : p.Gu + user * (int64_t)F;
@@ -43,11 +50,18 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
         ncand = c1 - c0;
     }
     const bool use_excl = (p.excl_indptr != nullptr) && (p.cand_indptr == nullptr);
+    // item-split mode (gridDim.y = nsplit, full-catalogue scan only): this wave takes one slice, writes a partial list
+    int64_t pos_lo = 0, pos_hi = ncand;
+    const bool split = p.nsplit > 1 && !p.cand_indptr;
+    if (split) {
+        pos_lo = ncand * blockIdx.y / p.nsplit;
+        pos_hi = ncand * (blockIdx.y + 1) / p.nsplit;
+    }
     int cnt = 0;
     float tau = -INFINITY;
-    for (int64_t base = 0; base < ncand; base += 64) {
+    for (int64_t base = pos_lo; base < pos_hi; base += 64) {
         int64_t pos = base + lane;
-        bool valid = pos < ncand;
+        bool valid = pos < pos_hi;
         int32_t gitem = -1;
         int64_t il = 0;
         if (valid) {
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
     if (lane == 0) *cnt_s = cnt;
     el_wave_compact(keys, cnt_s, cap, p.k, lane);
     const int nv = cnt < p.k ? cnt : p.k;
-    const int64_t orow = (int64_t)blockIdx.x * p.k;
+    const int64_t orow = split ? ((int64_t)blockIdx.y * p.part_stride + blockIdx.x) * p.k : urel * p.k;
     for (int t = lane; t < p.k; t += 64) {
         int32_t oi;
         float ov;
@@ -97,7 +111,8 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
             oi = el_key_item(key);
             ov = el_key_score(key);
         } else {
-            oi = el_fill_masked(p, e0, e1, c0, c1, t - nv);
+            oi = split ? el_fill_masked_range(p, p.item_offset + pos_lo, p.item_offset + pos_hi, e0, e1, c0, c1, t - nv)
+                       : el_fill_masked(p, e0, e1, c0, c1, t - nv);
             ov = -INFINITY;
         }
         p.out_idx[orow + t] = oi;
@@ -361,16 +376,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
 // =====================================================================================
 // merge of G partial lists per user
 // =====================================================================================
-// row_map / n_rows (optional): only the first min(*n_rows, n_users) rows exist and row u is written to out row row_map[u]
+// row_map / n_rows / row_skip (optional): partial row u belongs to list entry u + row_skip (absent if >= *n_rows) and is
+// written to out row row_map[u + row_skip]
 __global__ __launch_bounds__(64) void k_topk_merge(const int32_t* parts_idx, const float* parts_val, int G,
                                                    int64_t n_users, int k, int cap, int32_t* out_idx,
-                                                   float* out_val, const int32_t* row_map, const int32_t* n_rows) {
+                                                   float* out_val, const int32_t* row_map, const int32_t* n_rows, int row_skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int lane = threadIdx.x;
     const int64_t u = blockIdx.x;
-    if (n_rows && u >= (int64_t)*n_rows) return;
-    const int64_t orow = row_map ? (int64_t)row_map[u] : u;
+    if (n_rows && u + row_skip >= (int64_t)*n_rows) return;
+    const int64_t orow = row_map ? (int64_t)row_map[u + row_skip] : u;
     const int total = G * k;
     for (int t = lane; t < cap; t += 64) {
         u64 key = 0ull;
@@ -624,33 +640,95 @@ int el_topk_launch_mfma(const TopkParams& p, hipStream_t st) {
 }
 
 // ---- exact top-k of a device-side user list (fallback of the screened path) -----------------------------------------
+// Three tiers, all launched unconditionally (the list length lives on the device; surplus workgroups exit at once):
+//   entries [0, 64)        exact scores of the whole catalogue into a dense [64][I] buffer (one thread per (item, entry),
+//                          bandwidth-bound, microseconds) + the dense wave top-k -- a handful of users is a LATENCY problem
+//   entries [64, 64+cap)   fp32 MFMA kernel over LIST_SPLIT item slices + merge
+//   entries beyond         fp32 MFMA kernel, one workgroup per 128 users over the whole catalogue
 static const int LIST_SPLIT = 64;
+static const int LIST_DENSE = 64;
+
+__global__ __launch_bounds__(256) void k_list_scores(TopkParams p, float* __restrict__ preds) {
+    const int slot = blockIdx.y;
+    int n = *p.ulist_n;
+    if (slot >= n) return;
+    const int64_t il = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (il >= p.I_local) return;
+    const int64_t user = p.u_start + p.ulist[slot];
+    const float* gi = p.Gi + il * (int64_t)p.F;
+    const float* gu = p.Gu + user * (int64_t)p.F;
+    float a = 0.f;
+    if ((p.F & 3) == 0 && (((reinterpret_cast<uintptr_t>(p.Gi) | reinterpret_cast<uintptr_t>(p.Gu)) & 15) == 0)) {
+        const float4* gi4 = reinterpret_cast<const float4*>(gi);
+        const float4* gu4 = reinterpret_cast<const float4*>(gu);
+        for (int c = 0; c < p.F / 4; ++c) {
+            const float4 x = gi4[c], y = gu4[c];
+            a = __builtin_fmaf(x.x, y.x, a);
+            a = __builtin_fmaf(x.y, y.y, a);
+            a = __builtin_fmaf(x.z, y.z, a);
+            a = __builtin_fmaf(x.w, y.w, a);
+        }
+    } else {
+        for (int f = 0; f < p.F; ++f) a = __builtin_fmaf(gi[f], gu[f], a);
+    }
+    preds[(int64_t)slot * p.I_local + il] = (p.Bi ? a + p.Bi[il] : a) + 0.0f;
+}
 
 static int64_t list_cap_for(int64_t n_users) {
     int64_t c = n_users / 16;
     if (c < 512) c = 512;
-    return c < n_users ? c : n_users;
+    if (c > n_users) c = n_users;
+    return c < LIST_DENSE ? LIST_DENSE : c;       // (the dense tier borrows the split scratch for its partial lists)
 }
 
 static size_t a256_(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t el_topk_list_scratch_bytes(int64_t n_users, int k) {
-    return 2 * a256_((size_t)LIST_SPLIT * (size_t)list_cap_for(n_users) * (size_t)k * 4);
+size_t el_topk_list_scratch_bytes(int64_t n_users, int64_t I_local, int k) {
+    return 2 * a256_((size_t)LIST_SPLIT * (size_t)list_cap_for(n_users) * (size_t)k * 4) + a256_((size_t)LIST_DENSE * (size_t)I_local * 4);
 }
 
 int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, hipStream_t st) {
     const int64_t n_users = p0.u_stop - p0.u_start;
     const int64_t cap = list_cap_for(n_users);
-    EL_REQUIRE(scratch && scratch_bytes >= el_topk_list_scratch_bytes(n_users, p0.k), "el_topk_run_list: scratch too small");
+    EL_REQUIRE(scratch && scratch_bytes >= el_topk_list_scratch_bytes(n_users, p0.I_local, p0.k), "el_topk_run_list: scratch too small");
     int32_t* part_idx = (int32_t*)scratch;
     float* part_val = (float*)((char*)scratch + a256_((size_t)LIST_SPLIT * (size_t)cap * (size_t)p0.k * 4));
+    float* preds = (float*)((char*)scratch + 2 * a256_((size_t)LIST_SPLIT * (size_t)cap * (size_t)p0.k * 4));
+    if (p0.I_local > 0) {                            // tier 1: entries [0, LIST_DENSE)
+        TopkParams d = p0;
+        d.ulist_skip = 0;
+        d.ulist_max = LIST_DENSE;
+        d.nsplit = 0;
+        EL_LAUNCH("k_list_scores", k_list_scores, dim3((unsigned)((p0.I_local + 255) / 256), LIST_DENSE), dim3(256), 0, st, d, preds);
+        d.preds = preds;
+        d.ld = p0.I_local;
+        // one wave per (entry, item slice) -> partial lists in the split scratch (free until tier 2 runs) -> merge
+        int DS = (int)((p0.I_local + 2047) / 2048);
+        if (DS > LIST_SPLIT) DS = LIST_SPLIT;
+        d.nsplit = DS > 1 ? DS : 0;
+        if (DS > 1) {
+            d.part_stride = LIST_DENSE;
+            d.out_idx = part_idx;
+            d.out_val = part_val;
+        }
+        const int wcap = wave_cap_for_k(p0.k);
+        EL_LAUNCH("k_topk_wave", k_topk_wave<true>, dim3(LIST_DENSE, DS > 1 ? DS : 1), dim3(64), (size_t)wcap * 8 + 16, st, d, wcap);
+        if (DS > 1) {
+            int mcap = next_pow2(DS * p0.k);
+            if (mcap < 64) mcap = 64;
+            EL_LAUNCH("k_topk_merge", k_topk_merge, dim3(LIST_DENSE), dim3(64), (size_t)mcap * 8, st, (const int32_t*)part_idx,
+                      (const float*)part_val, DS, (int64_t)LIST_DENSE, p0.k, mcap, p0.out_idx, p0.out_val, p0.ulist, p0.ulist_n, 0);
+        }
+        EL_CHECK_LAUNCH();
+    }
+    const int skip1 = p0.I_local > 0 ? LIST_DENSE : 0;
     // item slices of >= 4 MFMA tiles (128 items each), at most LIST_SPLIT of them
     int64_t S = (p0.I_local + 511) / 512;
     if (S > LIST_SPLIT) S = LIST_SPLIT;
     if (S < 1) S = 1;
     TopkParams p = p0;
-    p.ulist_skip = 0;
-    p.ulist_max = (int)cap;
+    p.ulist_skip = skip1;
+    p.ulist_max = (int)(skip1 + cap);
     p.nsplit = (int)(S > 1 ? S : 0);
     if (S > 1) {
         p.part_stride = cap;
@@ -662,12 +740,12 @@ int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, 
         int mcap = next_pow2((int)S * p0.k);
         if (mcap < 64) mcap = 64;
         EL_LAUNCH("k_topk_merge", k_topk_merge, dim3((unsigned)cap), dim3(64), (size_t)mcap * 8, st, (const int32_t*)part_idx,
-                  (const float*)part_val, (int)S, cap, p0.k, mcap, p0.out_idx, p0.out_val, p0.ulist, p0.ulist_n);
+                  (const float*)part_val, (int)S, cap, p0.k, mcap, p0.out_idx, p0.out_val, p0.ulist, p0.ulist_n, skip1);
         EL_CHECK_LAUNCH();
     }
-    if (n_users > cap) {                             // more flagged users than the split scratch holds: plain kernel for the rest
+    if (n_users > skip1 + cap) {                     // more flagged users than the split scratch holds: plain kernel for the rest
         TopkParams q = p0;
-        q.ulist_skip = (int)cap;
+        q.ulist_skip = (int)(skip1 + cap);
         q.ulist_max = 0;
         q.nsplit = 0;
         if (int rc = el_topk_launch_mfma(q, st)) return rc;
@@ -797,7 +875,7 @@ extern "C" int el_topk_merge(el_ctx* ctx, void* stream, const int32_t* parts_idx
     int cap = next_pow2(G * k);
     if (cap < 64) cap = 64;
     EL_LAUNCH("k_topk_merge", k_topk_merge, dim3((unsigned)n_users), dim3(64), (size_t)cap * 8, (hipStream_t)stream,
-                       parts_idx, parts_val, G, n_users, k, cap, out_idx, out_val, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                       parts_idx, parts_val, G, n_users, k, cap, out_idx, out_val, (const int32_t*)nullptr, (const int32_t*)nullptr, 0);
     EL_CHECK_LAUNCH();
     return 0;
 }

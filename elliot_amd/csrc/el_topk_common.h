@@ -37,7 +37,7 @@ int el_topk_launch_wave(const TopkParams& p, hipStream_t st);
 int el_topk_launch_mfma(const TopkParams& p, hipStream_t st);
 // defined in el_topk.hip: exact top-k of the users in p.ulist (device list, *p.ulist_n entries), parallel over users AND
 // item slices so that a handful of users does not serialise on one workgroup.  scratch: el_topk_list_scratch_bytes().
-size_t el_topk_list_scratch_bytes(int64_t n_users, int k);
+size_t el_topk_list_scratch_bytes(int64_t n_users, int64_t I_local, int k);
 int el_topk_run_list(const TopkParams& p, void* scratch, size_t scratch_bytes, hipStream_t st);
 
 // ---- one-wave bitonic sort (descending) of n = 2^m u64 keys held in LDS --------------

@@ -59,33 +59,55 @@ __device__ __forceinline__ int el_screen_slot(int row) {
 }
 
 // ---- item side preparation: bf16 image [I][FP] (zero padded), max ||i||, max |bias| ------------------------------
+// One thread per (item, 8-column chunk): 32 B in, 16 B out, the row norm is reduced over the SL = FP/8 lanes of the item.
+template <int FP>
 __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ Gi, const float* __restrict__ Bi, int64_t I,
-                                                     int F, int FP, unsigned short* __restrict__ Gib, float* stats) {
-    const int lane = threadIdx.x & 63;
-    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;   // 16 items per wave
-    u32 nmax = 0u, bmax = 0u;                            // non-negative floats order as their bit patterns
-    for (int t = 0; t < 16; ++t) {
-        const int64_t item = first + t;
-        if (item >= I) break;
-        float ss = 0.f;
-        for (int f = lane; f < FP; f += 64) {
-            const float v = (f < F) ? Gi[item * F + f] : 0.f;
-            Gib[item * FP + f] = (unsigned short)el_f2bf(v);
-            ss += v * v;
+                                                     int F, unsigned short* __restrict__ Gib, float* stats) {
+    constexpr int SL = FP / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t item = t / SL;
+    const int sl = (int)(t % SL);
+    float v[8];
+    float ss = 0.f;
+    const bool live = item < I;
+    if (live) {
+        const float* src = Gi + item * (int64_t)F + sl * 8;
+        if ((F & 3) == 0 && sl * 8 + 8 <= F && ((reinterpret_cast<uintptr_t>(Gi) & 15) == 0)) {
+            const float4 x = reinterpret_cast<const float4*>(src)[0], y = reinterpret_cast<const float4*>(src)[1];
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (sl * 8 + j < F) ? src[j] : 0.f;
         }
-        ss = el_group_sum(ss, 64);
-        float nrm = sqrtf(ss) * 1.001f;
-        if (!(nrm < INFINITY)) nrm = INFINITY;           // NaN / inf rows poison the bound -> every user falls back
-        nmax = max(nmax, __float_as_uint(nrm));
-        if (Bi) {
-            float b = fabsf(Bi[item]);
-            if (!(b < INFINITY)) b = INFINITY;
-            bmax = max(bmax, __float_as_uint(b));
-        }
+        uint4 o;
+        o.x = el_f2bf(v[0]) | (el_f2bf(v[1]) << 16);
+        o.y = el_f2bf(v[2]) | (el_f2bf(v[3]) << 16);
+        o.z = el_f2bf(v[4]) | (el_f2bf(v[5]) << 16);
+        o.w = el_f2bf(v[6]) | (el_f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(Gib + item * FP + sl * 8) = o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
     }
-    if (lane == 0 && first < I) {
-        atomicMax(reinterpret_cast<unsigned int*>(stats), nmax);
-        if (Bi) atomicMax(reinterpret_cast<unsigned int*>(stats) + 1, bmax);
+    ss = el_group_sum(ss, SL);                           // all SL lanes of an item hold its sum of squares
+    float nrm = sqrtf(ss) * 1.001f;
+    if (!(nrm < INFINITY)) nrm = INFINITY;               // NaN / inf rows poison the bound -> every user falls back
+    u32 nmax = live ? __float_as_uint(nrm) : 0u;         // non-negative floats order as their bit patterns
+    u32 bmax = 0u;
+    if (live && Bi && sl == 0) {
+        float b = fabsf(Bi[item]);
+        if (!(b < INFINITY)) b = INFINITY;
+        bmax = __float_as_uint(b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
+        bmax = max(bmax, (u32)__shfl_xor((int)bmax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {                       // same-address atomics serialise in L2: only raise, never re-assert
+        unsigned int* st = reinterpret_cast<unsigned int*>(stats);
+        if (nmax > __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st, nmax);
+        if (bmax > __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + 1, bmax);
     }
 }
 
@@ -356,14 +378,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
 // here (same bf16 operands, fp32 fma chain) and compared with the slot maximum with the fp32 re-association tolerance.
 // (If it is NOT flagged, the arg-max is another item, and that item is unmasked or it would have flagged the slot.)
 template <int FP>
-__global__ __launch_bounds__(64) void k_screen_thr(ScreenParams sp) {
+__global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
     const TopkParams& p = sp.t;
-    const int lane = threadIdx.x;
-    const int64_t ur = blockIdx.x, user = p.u_start + ur;
-    __shared__ float sm[SCR_TI];
-    __shared__ int inv[SCR_TI];
-    __shared__ __attribute__((aligned(16))) float ubf[FP];
-    __shared__ u64 keys[SCR_TI];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ur = (int64_t)blockIdx.x * 4 + wv, user = p.u_start + ur;     // one wave per user, 4 users per workgroup
+    if (user >= p.u_stop) return;
+    __shared__ float sm_[4][SCR_TI];
+    __shared__ int inv_[4][SCR_TI];
+    __shared__ __attribute__((aligned(16))) float ubf_[4][FP];
+    __shared__ u64 keys_[4][SCR_TI];
+    __shared__ int pos_of_[4][SCR_TI];
+    int* pos_of = pos_of_[wv];
+    float* sm = sm_[wv];
+    int* inv = inv_[wv];
+    float* ubf = ubf_[wv];
+    u64* keys = keys_[wv];
     const float M = sp.smax[ur * SCR_TI + lane];
     sm[lane] = M;
     inv[lane] = 0;
@@ -378,42 +407,78 @@ __global__ __launch_bounds__(64) void k_screen_thr(ScreenParams sp) {
     const float nu = sqrtf(ss) * 1.001f;
     float E, tol;
     el_screen_bounds(nu, sp.stats[0], sp.stats[1], p.F, E, tol);
-    el_wave_lds_sync();
-    if (p.excl_indptr) {
-        const int64_t e0 = p.excl_indptr[user], e1 = p.excl_indptr[user + 1];
-        for (int64_t e = e0 + lane; e < e1; e += 64) {
-            const int64_t il = (int64_t)p.excl_indices[e] - p.item_offset;
-            if (il < 0 || il >= p.I_local) continue;
-            if (((il >> 6) % sp.stride) != 0) continue;                  // tile not visited by pass 1
-            const int slot = el_screen_slot((int)(il & 63));
-            const uint4* row = reinterpret_cast<const uint4*>(sp.Gib + il * FP);
-            float a = 0.f;
-#pragma unroll 2
-            for (int c = 0; c < FP / 8; ++c) {
-                const uint4 v = row[c];
-                const float* uu = ubf + c * 8;
-                a = __builtin_fmaf(el_bf2f(v.x & 0xffffu), uu[0], a);
-                a = __builtin_fmaf(el_bf2f(v.x >> 16), uu[1], a);
-                a = __builtin_fmaf(el_bf2f(v.y & 0xffffu), uu[2], a);
-                a = __builtin_fmaf(el_bf2f(v.y >> 16), uu[3], a);
-                a = __builtin_fmaf(el_bf2f(v.z & 0xffffu), uu[4], a);
-                a = __builtin_fmaf(el_bf2f(v.z >> 16), uu[5], a);
-                a = __builtin_fmaf(el_bf2f(v.w & 0xffffu), uu[6], a);
-                a = __builtin_fmaf(el_bf2f(v.w >> 16), uu[7], a);
-            }
-            const float s = a + (p.Bi ? p.Bi[il] : 0.f);
-            if (!(s < sm[slot] - tol)) inv[slot] = 1;                    // NaN lands here too (conservative)
-        }
-    }
-    el_wave_lds_sync();
-    const bool ok = (inv[lane] == 0) && (M > -INFINITY) && (M < INFINITY);
-    keys[lane] = ok ? el_make_key(M, lane) : 0ull;
+    // slots by descending maximum; only the slots near the top can decide T, so the masked items of the best k + 8 slots
+    // are scored first and the rest only if those did not yield k clean slots (the rows are the kernel's HBM traffic)
+    const bool fin = (M > -INFINITY) && (M < INFINITY);
+    pos_of[lane] = -1;
+    keys[lane] = fin ? el_make_key(M, lane) : 0ull;
     el_wave_lds_sync();
     el_wave_bitonic_desc(keys, SCR_TI, lane);
+    const u64 mykey = keys[lane];
+    const int myslot = mykey ? el_key_item(mykey) : 0;
+    if (mykey) pos_of[myslot] = lane;
+    el_wave_lds_sync();
+    int64_t e0 = 0, e1 = 0;
+    if (p.excl_indptr) {
+        e0 = p.excl_indptr[user];
+        e1 = p.excl_indptr[user + 1];
+    }
+    constexpr int SL = FP / 8, LPI = SL < 8 ? SL : 8, PPL = SL / LPI, IPW = 64 / LPI;
+    const int sub = lane % LPI, grp = lane / LPI;
+    int R = p.k + 8 < SCR_TI ? p.k + 8 : SCR_TI;
+    bool good = false;
+    float T = 0.f;
+    for (int lo = 0; lo < SCR_TI && !good; lo = R, R = SCR_TI) {
+        // LPI lanes share one masked item: its 2*FP-byte row is read as consecutive 16 B pieces (coalesced), the partial
+        // dot products are summed over the LPI lanes
+        for (int64_t eb = e0; eb < e1; eb += IPW) {
+            const int64_t e = eb + grp;
+            int64_t il = -1;
+            int slot = 0;
+            if (e < e1) {
+                il = (int64_t)p.excl_indices[e] - p.item_offset;
+                if (il < 0 || il >= p.I_local || ((il >> 6) % sp.stride) != 0) il = -1;   // other shard / tile not visited by pass 1
+                if (il >= 0) {
+                    slot = el_screen_slot((int)(il & 63));
+                    const int ps = pos_of[slot];
+                    if (ps < lo || ps >= R) il = -1;                                      // slot not in this round
+                }
+            }
+            float a = 0.f;
+            if (il >= 0) {
+                const uint4* row = reinterpret_cast<const uint4*>(sp.Gib + il * FP);
+#pragma unroll
+                for (int c = 0; c < PPL; ++c) {
+                    const int piece = c * LPI + sub;
+                    const uint4 v = row[piece];
+                    const float* uu = ubf + piece * 8;
+                    a = __builtin_fmaf(el_bf2f(v.x & 0xffffu), uu[0], a);
+                    a = __builtin_fmaf(el_bf2f(v.x >> 16), uu[1], a);
+                    a = __builtin_fmaf(el_bf2f(v.y & 0xffffu), uu[2], a);
+                    a = __builtin_fmaf(el_bf2f(v.y >> 16), uu[3], a);
+                    a = __builtin_fmaf(el_bf2f(v.z & 0xffffu), uu[4], a);
+                    a = __builtin_fmaf(el_bf2f(v.z >> 16), uu[5], a);
+                    a = __builtin_fmaf(el_bf2f(v.w & 0xffffu), uu[6], a);
+                    a = __builtin_fmaf(el_bf2f(v.w >> 16), uu[7], a);
+                }
+            }
+            a = el_group_sum(a, LPI);
+            if (il >= 0 && sub == 0) {
+                const float sc = a + (p.Bi ? p.Bi[il] : 0.f);
+                if (!(sc < sm[slot] - tol)) inv[slot] = 1;               // NaN lands here too (conservative)
+            }
+        }
+        el_wave_lds_sync();
+        u64 clean = __ballot(mykey != 0ull && lane < R && inv[myslot] == 0);   // bit j: the j-th best slot is clean
+        if (__popcll(clean) >= p.k) {
+            for (int q = 1; q < p.k; ++q) clean &= clean - 1ull;
+            T = el_key_score(keys[__ffsll((long long)clean) - 1]);
+            good = true;
+        }
+    }
     if (lane == 0) {
-        const u64 kk = keys[p.k - 1];                                    // k <= 30 < 64 (eligibility)
-        const bool good = (kk != 0ull) && (E < INFINITY);
-        sp.thr[ur] = good ? (el_key_score(kk) - 2.0f * E) : INFINITY;
+        good = good && (E < INFINITY);
+        sp.thr[ur] = good ? (T - 2.0f * E) : INFINITY;
         sp.ovf[ur] = good ? 0 : 1;
         sp.cnt[ur] = 0;
     }
@@ -440,12 +505,13 @@ __device__ __forceinline__ float el_exact_score(const TopkParams& p, int64_t use
     return (p.Bi ? a + p.Bi[il] : a) + 0.0f;
 }
 
-__global__ __launch_bounds__(64) void k_screen_final(ScreenParams sp) {
+__global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
     const TopkParams& p = sp.t;
-    const int lane = threadIdx.x;
-    const int64_t ur = blockIdx.x, user = p.u_start + ur;
-    if (sp.ovf[ur]) return;
-    __shared__ u64 surv[SCR_SURV];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ur = (int64_t)blockIdx.x * 4 + wv, user = p.u_start + ur;     // one wave per user, 4 users per workgroup
+    if (user >= p.u_stop || sp.ovf[ur]) return;
+    __shared__ u64 surv_[4][SCR_SURV];
+    u64* surv = surv_[wv];
     const int n = sp.cnt[ur];
     int64_t e0 = 0, e1 = 0, zoff = 0;
     if (p.excl_indptr) {
@@ -498,7 +564,7 @@ __global__ __launch_bounds__(64) void k_screen_final(ScreenParams sp) {
 #pragma unroll
     for (int q = 0; q < SCR_SURV / 64; ++q) surv[q * 64 + lane] = nk[q];
     el_wave_lds_sync();
-    el_wave_bitonic_desc(surv, SCR_SURV, lane);
+    el_wave_bitonic_desc(surv, ns <= 64 ? 64 : SCR_SURV, lane);     // keys beyond ns are 0 and sort last
     int nv = 0;
 #pragma unroll
     for (int q = 0; q < SCR_SURV / 64; ++q) nv += __popcll(__ballot(surv[q * 64 + lane] != 0ull));
@@ -531,7 +597,7 @@ size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, i
     const int FP = screen_fp(F);
     if (excl_nnz < 0) excl_nnz = 0;
     return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 4 * a256((size_t)n_users * 4) +
-           a256(el_topk_list_scratch_bytes(n_users, k)) + a256(((size_t)n_users * SCR_SURV + (size_t)excl_nnz) * 8);
+           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * SCR_SURV + (size_t)excl_nnz) * 8);
 }
 
 template <int FP, int MODE, int NW, bool PROF>
@@ -566,7 +632,7 @@ static int run_passes(ScreenParams& sp, hipStream_t st) {
     if (int rc = launch_pass<FP, 1, NW, PROF>(sp, st)) return rc;
     if (PROF) report("pass1");
     auto kthr = k_screen_thr<FP>;
-    EL_LAUNCH("k_screen_thr", kthr, dim3((unsigned)n_users), dim3(64), 0, st, sp);
+    EL_LAUNCH("k_screen_thr", kthr, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
     if (int rc = launch_pass<FP, 2, NW, PROF>(sp, st)) return rc;
     if (PROF) {
         report("pass2");
@@ -574,7 +640,7 @@ static int run_passes(ScreenParams& sp, hipStream_t st) {
         EL_CHECK_HIP(hipFree(sp.prof));
         sp.prof = nullptr;
     }
-    EL_LAUNCH("k_screen_final", k_screen_final, dim3((unsigned)n_users), dim3(64), 0, st, sp);
+    EL_LAUNCH("k_screen_final", k_screen_final, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -604,7 +670,7 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     base += a256((size_t)n_users * 4);
     sp.ulist_n = (int32_t*)(stats + 2);
     void* fb_scratch = base;
-    const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.k);
+    const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.I_local, p.k);
     base += a256(fb_bytes);
     sp.lists = (u64*)base;
     sp.list_cap = (int64_t)(((char*)ws + ws_bytes - base) / 8);      // whatever the caller provisioned for 64*U + nnz
@@ -619,9 +685,15 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
         if (v >= 1 && v <= 8) sp.stride = v;
     }
     EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
-    if (p.I_local > 0)
-        EL_LAUNCH("k_screen_prep", k_screen_prep, dim3((unsigned)((p.I_local + 63) / 64)), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F,
-                  FP, gib, stats);
+    if (p.I_local > 0) {
+        const unsigned pg = (unsigned)((p.I_local * (FP / 8) + 255) / 256);
+        if (FP == 32)
+            EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+        else if (FP == 64)
+            EL_LAUNCH("k_screen_prep", k_screen_prep<64>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+        else
+            EL_LAUNCH("k_screen_prep", k_screen_prep<128>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+    }
     const char* pe = getenv("EL_SCREEN_PROF");
     const bool prof = pe && pe[0] == '1';
     int rc;

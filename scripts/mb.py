@@ -80,6 +80,9 @@ def main():
     Bi = torch.zeros(I, device=dev)
     ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, seed=5)
     pos = ops.DeviceCSR.from_tensors(ip, ix, I)
+    if a.what == "topk":
+        ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)   # warm-up: code load, workspace
+        torch.cuda.synchronize()
     ctx.timing(True)
     if a.what == "topk":
         for _ in range(a.iters):
