@@ -423,16 +423,13 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
         e0 = p.excl_indptr[user];
         e1 = p.excl_indptr[user + 1];
     }
-    constexpr int SL = FP / 8, LPI = SL < 8 ? SL : 8, PPL = SL / LPI, IPW = 64 / LPI;
-    const int sub = lane % LPI, grp = lane / LPI;
     int R = p.k + 8 < SCR_TI ? p.k + 8 : SCR_TI;
     bool good = false;
     float T = 0.f;
     for (int lo = 0; lo < SCR_TI && !good; lo = R, R = SCR_TI) {
-        // LPI lanes share one masked item: its 2*FP-byte row is read as consecutive 16 B pieces (coalesced), the partial
-        // dot products are summed over the LPI lanes
-        for (int64_t eb = e0; eb < e1; eb += IPW) {
-            const int64_t e = eb + grp;
+        // one lane per masked item, 64 in flight: index (coalesced) -> slot -> is the slot in this round? -> bf16 row dot
+        for (int64_t eb = e0; eb < e1; eb += 64) {
+            const int64_t e = eb + lane;
             int64_t il = -1;
             int slot = 0;
             if (e < e1) {
@@ -444,14 +441,13 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
                     if (ps < lo || ps >= R) il = -1;                                      // slot not in this round
                 }
             }
-            float a = 0.f;
             if (il >= 0) {
                 const uint4* row = reinterpret_cast<const uint4*>(sp.Gib + il * FP);
-#pragma unroll
-                for (int c = 0; c < PPL; ++c) {
-                    const int piece = c * LPI + sub;
-                    const uint4 v = row[piece];
-                    const float* uu = ubf + piece * 8;
+                float a = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < FP / 8; ++c) {
+                    const uint4 v = row[c];
+                    const float* uu = ubf + c * 8;
                     a = __builtin_fmaf(el_bf2f(v.x & 0xffffu), uu[0], a);
                     a = __builtin_fmaf(el_bf2f(v.x >> 16), uu[1], a);
                     a = __builtin_fmaf(el_bf2f(v.y & 0xffffu), uu[2], a);
@@ -461,9 +457,6 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
                     a = __builtin_fmaf(el_bf2f(v.w & 0xffffu), uu[6], a);
                     a = __builtin_fmaf(el_bf2f(v.w >> 16), uu[7], a);
                 }
-            }
-            a = el_group_sum(a, LPI);
-            if (il >= 0 && sub == 0) {
                 const float sc = a + (p.Bi ? p.Bi[il] : 0.f);
                 if (!(sc < sm[slot] - tol)) inv[slot] = 1;               // NaN lands here too (conservative)
             }
@@ -485,23 +478,37 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
 }
 
 // ---- exact re-scoring of the survivors + write-out -------------------------------------------------------------------
-__device__ __forceinline__ float el_exact_score(const TopkParams& p, int64_t user, int64_t il, bool vec4) {
+// exact fp32 score (fma chain over f = 0..F-1 from +0, + bias, + 0.0f); gu_s = the user's row staged in LDS.
+// The item row is read 8 x 16 B at a time so that eight requests are in flight instead of one.
+__device__ __forceinline__ float el_exact_score(const TopkParams& p, const float* gu_s, int64_t il, bool vec4) {
     const float* gi = p.Gi + il * (int64_t)p.F;
-    const float* gu = p.Gu + user * (int64_t)p.F;
     float a = 0.f;
-    if (vec4) {                                      // 16 B per lane per request: the rows are read through L1, not re-fetched
+    int f = 0;
+    if (vec4) {
         const float4* gi4 = reinterpret_cast<const float4*>(gi);
-        const float4* gu4 = reinterpret_cast<const float4*>(gu);
-        for (int c = 0; c < p.F / 4; ++c) {
-            const float4 x = gi4[c], y = gu4[c];
+        for (; f + 32 <= p.F; f += 32) {
+            float4 x[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = gi4[(f >> 2) + c];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 y = *reinterpret_cast<const float4*>(gu_s + f + 4 * c);
+                a = __builtin_fmaf(x[c].x, y.x, a);
+                a = __builtin_fmaf(x[c].y, y.y, a);
+                a = __builtin_fmaf(x[c].z, y.z, a);
+                a = __builtin_fmaf(x[c].w, y.w, a);
+            }
+        }
+        for (; f + 4 <= p.F; f += 4) {
+            const float4 x = gi4[f >> 2];
+            const float4 y = *reinterpret_cast<const float4*>(gu_s + f);
             a = __builtin_fmaf(x.x, y.x, a);
             a = __builtin_fmaf(x.y, y.y, a);
             a = __builtin_fmaf(x.z, y.z, a);
             a = __builtin_fmaf(x.w, y.w, a);
         }
-    } else {
-        for (int f = 0; f < p.F; ++f) a = __builtin_fmaf(gi[f], gu[f], a);
     }
+    for (; f < p.F; ++f) a = __builtin_fmaf(gi[f], gu_s[f], a);
     return (p.Bi ? a + p.Bi[il] : a) + 0.0f;
 }
 
@@ -510,8 +517,14 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ur = (int64_t)blockIdx.x * 4 + wv, user = p.u_start + ur;     // one wave per user, 4 users per workgroup
     if (user >= p.u_stop || sp.ovf[ur]) return;
+    constexpr int XC = 512;                          // exclusion rows up to this length are searched in LDS
     __shared__ u64 surv_[4][SCR_SURV];
+    __shared__ int32_t xrow_[4][XC];
+    __shared__ __attribute__((aligned(16))) float gus_[4][128];   // F <= 128 (eligibility)
     u64* surv = surv_[wv];
+    int32_t* xrow = xrow_[wv];
+    float* gu_s = gus_[wv];
+    for (int f = lane; f < p.F; f += 64) gu_s[f] = p.Gu[user * (int64_t)p.F + f];
     const int n = sp.cnt[ur];
     int64_t e0 = 0, e1 = 0, zoff = 0;
     if (p.excl_indptr) {
@@ -521,6 +534,10 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
     }
     const u64* list = sp.lists + ur * SCR_SURV + zoff;
     for (int t = lane; t < SCR_SURV; t += 64) surv[t] = 0ull;
+    const int nx = (int)(e1 - e0);
+    const bool xl = nx <= XC;
+    if (xl)
+        for (int t = lane; t < nx; t += 64) xrow[t] = p.excl_indices[e0 + t];
     el_wave_lds_sync();
     int ns = 0;                                      // surv[] holds ITEM ids (low 32 bits) from here on
     for (int base = 0; base < n; base += 64) {
@@ -535,7 +552,19 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
                 const int r = __ffs((int)hm) - 1;
                 hm &= hm - 1u;
                 g = (int32_t)(p.item_offset + row0 + (r & 3) + 8 * (r >> 2));
-                keep = !(e1 > e0 && el_row_contains(p.excl_indices, e0, e1, g));
+                if (xl) {                                // lower bound in the LDS copy
+                    int a = 0, bnd = nx;
+                    while (a < bnd) {
+                        const int mid = (a + bnd) >> 1;
+                        if (xrow[mid] < g)
+                            a = mid + 1;
+                        else
+                            bnd = mid;
+                    }
+                    keep = !(a < nx && xrow[a] == g);
+                } else {
+                    keep = !el_row_contains(p.excl_indices, e0, e1, g);
+                }
             }
             const u64 b = __ballot(keep);
             const int pos = ns + __popcll(b & ((1ull << lane) - 1ull));
@@ -548,7 +577,7 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
         if (lane == 0) sp.ovf[ur] = 1;
         return;
     }
-    const bool vec4 = (p.F % 4 == 0) && (((reinterpret_cast<uintptr_t>(p.Gi) | reinterpret_cast<uintptr_t>(p.Gu)) & 15) == 0);
+    const bool vec4 = (p.F % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.Gi) & 15) == 0);
     u64 nk[SCR_SURV / 64];
 #pragma unroll
     for (int q = 0; q < SCR_SURV / 64; ++q) {
@@ -556,7 +585,7 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
         nk[q] = 0ull;
         if (t < ns) {
             const int32_t g = (int32_t)(u32)surv[t];
-            const float s = el_exact_score(p, user, (int64_t)g - p.item_offset, vec4);
+            const float s = el_exact_score(p, gu_s, (int64_t)g - p.item_offset, vec4);
             if (s == s) nk[q] = el_make_key(s, g);
         }
     }
