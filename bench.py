@@ -196,6 +196,19 @@ def main():
     loss = pop_loss()
     dt_topk, rep_topk = timed(topk_step, W, K)
 
+    # ---- accuracy metrics from the index tensor: one block of users, synthetic held-out set -------------
+    dt_met = None
+    if world == 1:
+        tip, tix = zipf_csr_device(U, I, dev, mean_log=2.0, sigma_log=0.7, dmin=1, dmax=200, seed=99)
+        held = ops.DeviceTestSet.from_tensors(tip, tix, None)
+        idx_blk, _ = parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, 0, Ub, k, excl=pos, algo=args.topk_algo)
+        msum = torch.zeros(8, dtype=torch.float64, device=dev)
+
+        def metrics_step():
+            ops.rec_metrics(ctx, idx_blk, held, 0.0, k, u_start=0, sums=msum)
+
+        dt_met, rep_met = timed(metrics_step, W, K)
+
     if rank != 0:
         return
     # ---------------- metrics ---------------------------------------------------------------------
@@ -266,6 +279,11 @@ def main():
         "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "scaling": "strong",
                  "roofline": roof_topk},
     }
+    if dt_met is not None:
+        line["metrics"] = {"value": Ub * K / dt_met, "unit": "users/s", "ms_per_step": dt_met / K * 1e3,
+                           "what": f"nDCG/Precision/Recall/HR/MAP/MRR/F1@{k} from the [users, k] index tensor (el_rec_metrics), "
+                                   f"{int(held.nnz)} held-out interactions",
+                           "kernels_ms_per_step": {n: v[1] / K for n, v in rep_met.items()}}
     if world == 1 and not args.no_cpu_baseline:
         host = {"Gu": st.Gu.cpu().numpy(), "Gi": st.Gi.cpu().numpy(), "Bi": st.Bi.cpu().numpy(),
                 "indptr": pos.indptr.cpu().numpy(), "indices": pos.indices.cpu().numpy()}

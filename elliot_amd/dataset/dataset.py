@@ -151,9 +151,10 @@ def load_tsv_dataset(config, path, test_ratio=0.2, seed=42):
                    (te["userId"].values, te["itemId"].values, te["rating"].values))
 
 
-def default_config(top_k=10, cutoffs=None, simple_metrics=("nDCG",), out_dir="./results", config_test=False):
+def default_config(top_k=10, cutoffs=None, simple_metrics=("nDCG",), out_dir="./results", config_test=False,
+                   relevance_threshold=0):
     """The base-namespace fields the plugin layer reads: top_k, evaluation.*, output paths."""
-    ev = SimpleNamespace(simple_metrics=list(simple_metrics), relevance_threshold=0, paired_ttest=False,
+    ev = SimpleNamespace(simple_metrics=list(simple_metrics), relevance_threshold=relevance_threshold, paired_ttest=False,
                          wilcoxon_test=False, complex_metrics=[])
     if cutoffs is not None:
         ev.cutoffs = list(cutoffs)

@@ -55,6 +55,77 @@ class Evaluator:
     def get_needed_recommendations(self):
         return self._needed_recommendations
 
+    # ---- device path: metrics straight from the [users, k] index tensors --------------------------
+    supports_device = True
+
+    def device_sets(self, data, device):
+        """Held-out splits as device CSRs in PRIVATE ids (rows = the model's user order).  Test items the model has no
+        row for get ids >= num_items: never recommended, but they count as relevant items like in the reference."""
+        if getattr(self, "_dev_sets", None) is None:
+            from .. import ops
+            self._dev_sets = {"test": self._split_to_csr(ops, data, self._test_dict_raw(data, False), device)}
+            raw_val = self._test_dict_raw(data, True)
+            self._dev_sets["val"] = self._split_to_csr(ops, data, raw_val, device) if raw_val else None
+        return self._dev_sets
+
+    @staticmethod
+    def _test_dict_raw(data, validation):
+        if validation:
+            return data.get_validation() if hasattr(data, "get_validation") else None
+        return data.get_test()
+
+    @staticmethod
+    def _split_to_csr(ops, data, split, device):
+        pu, pi = data.public_users, data.public_items
+        U, I = data.num_users, data.num_items
+        rows = [[] for _ in range(U)]
+        unknown = {}
+        for u, items in split.items():
+            if u not in pu:
+                continue
+            r = rows[pu[u]]
+            for it, rating in items.items():
+                col = pi.get(it)
+                if col is None:
+                    col = unknown.setdefault(it, I + len(unknown))
+                r.append((col, rating))
+        indptr = np.zeros(U + 1, dtype=np.int64)
+        cols, vals = [], []
+        for u, r in enumerate(rows):
+            r.sort()
+            indptr[u + 1] = indptr[u] + len(r)
+            cols.extend(c for c, _ in r)
+            vals.extend(v for _, v in r)
+        return ops.DeviceTestSet(indptr, np.asarray(cols, dtype=np.int32), np.asarray(vals, dtype=np.float32), device)
+
+    def eval_device(self, ctx, data, blocks):
+        """blocks: iterable of (first_private_user, idx_val, idx_test) with [n, k] int32 device tensors (idx_val may be
+        the same tensor).  Returns the same structure as eval()."""
+        from .. import ops
+        import torch
+        sets = self.device_sets(data, ctx.device)
+        acc = {(sp, c): torch.zeros(8, dtype=torch.float64, device=ctx.device)
+               for sp in ("val", "test") if sets[sp] is not None for c in self._k}
+        for first, idx_val, idx_test in blocks:
+            for (sp, c), sums in acc.items():
+                ops.rec_metrics(ctx, idx_val if sp == "val" else idx_test, sets[sp], self._rel_threshold, c, u_start=first, sums=sums)
+        host = {key: v.cpu().numpy() for key, v in acc.items()}
+
+        def means(sp, c):
+            s = host[(sp, c)]
+            if s[7] == 0:
+                return {}
+            return {m: float(s[ops.METRIC_NAMES.index(m)] / s[7]) for m in self._metrics}
+
+        res = {}
+        for c in self._k:
+            test = means("test", c)
+            val = means("val", c) if sets["val"] is not None else None
+            if not val:
+                val = test
+            res[c] = {"val_results": val, "val_statistical_results": {}, "test_results": test, "test_statistical_results": {}}
+        return res
+
     # ---------------------------------------------------------------------------------------------
     def _eval_split(self, recs, split, cutoff):
         """recs: {public_user: [(public_item, score), ...]}"""

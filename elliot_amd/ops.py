@@ -209,6 +209,64 @@ def topk_merge(ctx, parts_idx, parts_val):
 
 
 # ------------------------------------------------------------------------------------------
+# accuracy metrics on the device
+# ------------------------------------------------------------------------------------------
+METRIC_NAMES = ("nDCG", "Precision", "Recall", "HR", "MAP", "MRR", "F1")
+
+
+def discount_table(cutoff, device):
+    """ln 2 / ln(rank + 2) exactly as relevance.py:71-82 computes it (Python doubles), shipped to the device."""
+    import math
+    return torch.tensor([math.log(2) / math.log(r + 2) for r in range(cutoff)], dtype=torch.float64, device=device)
+
+
+class DeviceTestSet:
+    """Held-out interactions as a device CSR in PRIVATE ids: rows = users, columns ascending, float ratings."""
+
+    def __init__(self, indptr, indices, ratings, device):
+        indptr = np.asarray(indptr, dtype=np.int64)
+        indices = np.asarray(indices, dtype=np.int32)
+        self.nnz = int(indices.shape[0])
+        self.n_rows = int(indptr.shape[0] - 1)
+        self.indptr = torch.from_numpy(indptr).to(device)
+        self.indices = torch.from_numpy(indices if self.nnz else np.zeros(1, np.int32)).to(device)
+        self.ratings = None
+        if ratings is not None:
+            r = np.asarray(ratings, dtype=np.float32)
+            self.ratings = torch.from_numpy(r if self.nnz else np.zeros(1, np.float32)).to(device)
+
+
+    @classmethod
+    def from_tensors(cls, indptr, indices, ratings):
+        self = cls.__new__(cls)
+        self.indptr, self.indices, self.ratings = indptr.contiguous(), indices.contiguous(), ratings
+        self.nnz, self.n_rows = int(indices.shape[0]), int(indptr.shape[0] - 1)
+        return self
+
+
+def rec_metrics(ctx, rec_idx, test, threshold, cutoff, u_start=0, sums=None, per_user=False):
+    """Sums of the seven accuracy metrics over the users of rec_idx's rows (absolute ids u_start ...) that have at
+    least one relevant test item, plus their count: float64[8] on the device (ADDED to `sums` when given)."""
+    n, ld = rec_idx.shape
+    if sums is None:
+        sums = torch.zeros(8, dtype=torch.float64, device=ctx.device)
+    rows = torch.empty((n, 8), dtype=torch.float64, device=ctx.device) if per_user else None
+    need = int(ctx.lib.el_rec_metrics_ws_bytes(int(n)))
+    ws = getattr(ctx, "_metrics_ws", None)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 8), dtype=torch.uint8, device=ctx.device)
+        ctx._metrics_ws = ws
+    disc = discount_table(cutoff, ctx.device)
+    check(ctx.lib.el_rec_metrics(ctx.handle, ctx.stream(), _ptr(rec_idx, torch.int32), int(ld), int(u_start), int(u_start + n),
+                                 _ptr(test.indptr, torch.int64), _ptr(test.indices, torch.int32),
+                                 _ptr(test.ratings, torch.float32), float(threshold), int(cutoff),
+                                 C.c_void_p(disc.data_ptr()), C.c_void_p(sums.data_ptr()),
+                                 C.c_void_p(rows.data_ptr()) if rows is not None else None,
+                                 C.c_void_p(ws.data_ptr()), int(ws.numel())), "el_rec_metrics")
+    return (sums, rows) if per_user else sums
+
+
+# ------------------------------------------------------------------------------------------
 # sampler
 # ------------------------------------------------------------------------------------------
 def bpr_sample(ctx, pos, n, seed, first_sample=0, item_lo=0, item_hi=None, out=None):

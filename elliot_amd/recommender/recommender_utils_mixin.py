@@ -30,15 +30,19 @@ class RecMixin(object):
 
     def evaluate(self, it=None, loss=0):
         if (it is None) or (not (it + 1) % self._validation_rate):
-            recs = self.get_recommendations(self.evaluator.get_needed_recommendations())
-            result_dict = self.evaluator.eval(recs)
+            recs = None
+            if self._device_metrics():
+                result_dict = self._evaluate_on_device(self.evaluator.get_needed_recommendations())
+            else:
+                recs = self.get_recommendations(self.evaluator.get_needed_recommendations())
+                result_dict = self.evaluator.eval(recs)
             self._losses.append(loss)
             self._results.append(result_dict)
             if it is not None:
                 self.logger.info(f'Epoch {(it + 1)}/{self._epochs} loss {loss/(it + 1):.5f}')
             else:
                 self.logger.info('Finished')
-            if self._save_recs:
+            if self._save_recs and recs is not None:
                 self.logger.info(f"Writing recommendations at: {self._config.path_output_rec_result}")
                 fname = f"{self.name}_it={it + 1}.tsv" if it is not None else f"{self.name}.tsv"
                 _compat.store_recommendation(
@@ -53,6 +57,30 @@ class RecMixin(object):
                         self._model.save_weights(self._saving_filepath)
                     else:
                         self.logger.warning("Saving weights FAILED. No model to save.")
+
+    # -- metrics on the device --------------------------------------------------------------
+    def _device_metrics(self):
+        """True when evaluate() can skip the {user: [(item, score)...]} dicts: stand-alone evaluator (inside an Elliot
+        process the genuine Evaluator needs the dicts), nothing to write to disk, not switched off in the config."""
+        return (getattr(self.evaluator, "supports_device", False) and not self._save_recs
+                and getattr(self._config, "device_metrics", True) and hasattr(self, "_model")
+                and hasattr(self._model, "recommend"))
+
+    def _evaluate_on_device(self, k):
+        def blocks():
+            block = self._recommendation_block()
+            for offset in range(0, self._num_users, block):
+                stop = min(offset + block, self._num_users)
+                if not self._negative_sampling:
+                    idx, _ = self._model.recommend(self.get_candidate_mask(), k, offset, stop)
+                    yield offset, idx, idx
+                else:
+                    idx_t, _ = self._model.recommend(self.get_candidate_mask(), k, offset, stop)
+                    idx_v = idx_t
+                    if hasattr(self._data, "val_dict"):
+                        idx_v, _ = self._model.recommend(self.get_candidate_mask(validation=True), k, offset, stop)
+                    yield offset, idx_v, idx_t
+        return self.evaluator.eval_device(self._model.ctx, self._data, blocks())
 
     # -- scoring -------------------------------------------------------------------------------------
     def get_recommendations(self, k: int = 100):

@@ -358,6 +358,25 @@ int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int3
 int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
                       const float* label, int64_t n, int32_t step, float lr_t, double* loss_out);
 
+/* ---- accuracy metrics from the top-k index tensor --------------------------------------
+ * Replaces: get_single_recommendation's dict building (recommender_utils_mixin.py:84-88) + Evaluator.eval
+ * and its metric classes (evaluation/evaluator.py:117-147; metrics/accuracy/ndcg/ndcg.py:68-125;
+ * relevance/relevance.py:49-96; precision.py:66; recall.py:66; hit_rate.py:66; map.py:69-80; mrr.py:63-70;
+ * f1.py:56-68) for users [u_start, u_stop):
+ *   rec_idx   int32 [u_stop-u_start, ld]  item ids as written by el_score_topk (-1 = none); first `cutoff` used
+ *   test CSR  rows by absolute user id, indices ascending, ids in the same id space as rec_idx;
+ *             test_ratings float (NULL = 1.0 each); an item is relevant when rating >= threshold
+ *   discount  device double[cutoff] = ln 2 / ln(rank + 2) (computed by the host so that both sides share it)
+ *   sums      device double[8], ADDED to: sum over the users with >= 1 relevant item of
+ *             nDCG, Precision, Recall, HR, MAP, MRR, F1, and the number of such users (means = sums[m] / sums[7])
+ *   per_user  optional device double[(u_stop-u_start), 8] with the individual rows (last column 0/1 = counted)
+ * fp64 arithmetic; the reduction has a fixed shape (run-to-run identical).  cutoff <= 512.                 */
+size_t el_rec_metrics_ws_bytes(int64_t n_users);
+int el_rec_metrics(el_ctx* ctx, void* stream, const int32_t* rec_idx, int64_t ld, int64_t u_start, int64_t u_stop,
+                   const int64_t* test_indptr, const int32_t* test_indices, const float* test_ratings,
+                   double threshold, int32_t cutoff, const double* discount, double* sums, double* per_user,
+                   void* ws, size_t ws_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,3 +283,26 @@ def test_bprmf_plugin_with_replay_sampler_reproduces_the_reference_run(ctx, tmp_
     for u in range(U):
         assert [it for it, _ in recs[u]] == g["rec_idx"][u].tolist(), u
         assert np.allclose([s for _, s in recs[u]], g["rec_val"][u], rtol=0, atol=1e-12)
+
+
+def test_device_metrics_path_equals_host_evaluator(ctx, tmp_path):
+    """Without save_recs, evaluate() computes the metrics on the device from the [users, k] index tensors
+    (el_rec_metrics); the numbers must be those of the host evaluator on the same lists."""
+    data, cfg = make_data(tmp_path)
+    cfg.evaluation.simple_metrics = ["nDCG", "Precision", "Recall", "HR", "MAP", "MRR", "F1"]
+    cfg.evaluation.relevance_threshold = 2
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=1, batch_size=512,
+                             factors=16, lr=0.01, l_w=0.1, l_b=0.001, seed=42)
+    model = BPRMF_batch(data=data, config=cfg, params=params)
+    assert model._device_metrics()
+    model.train()
+    dev = model._results[-1]
+    host = Evaluator(data, params).eval(model.get_recommendations(10))
+    assert set(dev.keys()) == set(host.keys()) == {10, 5}
+    for c in dev:
+        for split in ("val_results", "test_results"):
+            assert set(dev[c][split].keys()) == set(host[c][split].keys())
+            for m, v in host[c][split].items():
+                assert abs(dev[c][split][m] - v) < 1e-12, (c, split, m, dev[c][split][m], v)
+    cfg.device_metrics = False                       # the switch falls back to the dict path
+    assert not model._device_metrics()
