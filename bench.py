@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--opt", default="adam_tf_dense", choices=["adam_tf_dense", "adam_lazy", "sgd"])
     ap.add_argument("--train-algo", default="auto", choices=["auto", "atomic", "sorted"])
     ap.add_argument("--topk-algo", default="auto", choices=["auto", "screen", "mfma", "simple"])
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "dense"],
+                    help="N > 1: how user-row gradients travel (parallel.pick_exchange)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-topk-users", type=int, default=640)
     return ap.parse_args()
@@ -61,6 +64,14 @@ def dist_setup(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.force_sharded:
+        # one rank, but through RCCL and the N > 1 code path: an API check of the collectives on a 1-GPU box
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ["EL_FORCE_COLLECTIVES"] = "1"
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     return world, rank, local
 
 
@@ -140,8 +151,10 @@ def main():
     lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
     trip = tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3))
     sample_ctr = [0]
+    finish_train = None
+    exchange_used = [None]
     coll = parallel._Collectives()
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
         pos_train = pos
 
@@ -156,8 +169,15 @@ def main():
         # the per-triplet user-gradient rows, identical user-table replicas (elliot_amd/parallel.py)
         sip, six = parallel.shard_csr(indptr, indices, lo, hi)
         pos_train = ops.DeviceCSR.from_tensors(sip, six, hi - lo)
-        be = parallel.HipBackend(ctx, Gu, Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), optimizer=args.opt)
-        trainer = parallel.ShardedBprmf(be, coll)
+        exchange = args.exchange if args.exchange != "auto" else parallel.pick_exchange(U, B, world)
+        exchange_used[0] = exchange
+        if exchange == "dense":
+            # reduce-scatter of the dense user-gradient table, optimiser on the owned user rows, all-gather of the rows
+            be = parallel.HipDenseBackend(ctx, Gu, Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), rank, world, optimizer=args.opt)
+            trainer = parallel.ShardedBprmfDense(be, coll)
+        else:
+            be = parallel.HipBackend(ctx, Gu, Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), optimizer=args.opt)
+            trainer = parallel.ShardedBprmf(be, coll)
         st = be.state
 
         def train_step():
@@ -166,6 +186,7 @@ def main():
             trainer.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b)
 
         pop_loss = trainer.pop_loss
+        finish_train = getattr(trainer, "finish", None)
     del Gu, Gi, Bi
 
     Ub = min(args.topk_block, U)
@@ -177,14 +198,18 @@ def main():
         blk[0] += 1
         parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo=args.topk_algo)
 
-    def timed(fn, warmup, steps):
+    def timed(fn, warmup, steps, finish=None):
         for _ in range(warmup):
             fn()
+        if finish:
+            finish()
         barrier(world)
         ctx.timing(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        if finish:
+            finish()                                                 # a collective still in flight belongs to the timed work
         barrier(world)
         dt = time.perf_counter() - t0
         ctx.timing(False)
@@ -192,7 +217,7 @@ def main():
         return max_over_ranks(dt, world, dev), rep
 
     K, W = args.steps, args.warmup
-    dt_train, rep_train = timed(train_step, W, K)
+    dt_train, rep_train = timed(train_step, W, K, finish_train)
     loss = pop_loss()
     dt_topk, rep_topk = timed(topk_step, W, K)
 
@@ -272,8 +297,10 @@ def main():
                    "users": U, "items": I, "factors": F, "interactions": int(pos.nnz), "batch": B,
                    "batch_per_gpu": B, "optimizer": args.opt, "topk_block": Ub, "k": k,
                    "parallelism": "single" if world == 1 else
-                   f"item-shard x{world}: train = {B} triplets/rank + all-gather of user-gradient rows (weak); "
-                   f"top-k = all users vs I/{world} items per rank + all-gather/merge (strong)"},
+                   f"item-shard x{world}: train = {B} triplets/rank + "
+                   + ("reduce-scatter of the dense user-gradient table, optimiser on U/G user rows, all-gather of the rows"
+                      if exchange_used[0] == "dense" else "all-gather of user-gradient rows")
+                   + f" (weak); top-k = all users vs I/{world} items per rank + all-gather/merge (strong)"},
         "loss_per_pair_last": loss / (B * world * (K + W)),
         "roofline": roof_train,
         "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "scaling": "strong",
@@ -292,4 +319,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

@@ -432,7 +432,8 @@ extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bp
                                           size_t ws_bytes) {
     if (int rc = el_bind(ctx)) return rc;
     bool vec = false, rows_mode = false;
-    if (int rc = el_bprmf_check_state(stp, u, i, j, loss_out, opt, step, &vec, &rows_mode)) return rc;
+    if (int rc = el_bprmf_check_state(stp, u, i, j, loss_out, opt < 0 ? EL_OPT_SGD : opt, step, &vec, &rows_mode)) return rc;
+    if (opt < 0) rows_mode = false;
     if (B <= 0) return 0;
     EL_REQUIRE(B < (1LL << 30), "el_bprmf_train_step_sorted: batch too large");
     const el_bprmf_state st = *stp;
@@ -466,7 +467,16 @@ extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bp
     base.loss_out = loss_out;
     int rc = vec ? launch_segs<4>(base, s, B, w) : launch_segs<1>(base, s, B, w);
     if (rc) return rc;
+    if (opt < 0) return 0;                           // gradients only (el_bprmf_grads)
     return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
+}
+
+// Gradients of one batch into the dense accumulators gGu / gGi / gBi (+ the loss), no optimiser: the first half of the
+// step above.  Used by the multi-GPU "dense" mode: reduce-scatter of gGu over the ranks, optimiser on the owned rows.
+extern "C" int el_bprmf_grads(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
+                              const int32_t* j, int64_t B, float l_w, float l_b, int32_t step, double* loss_out, void* ws,
+                              size_t ws_bytes) {
+    return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -1, step, 0.f, loss_out, ws, ws_bytes);
 }
 
 // =====================================================================================================

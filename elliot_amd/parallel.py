@@ -8,9 +8,11 @@ replicated.
             [Ub, k] partial lists are ALL-GATHERED (8*Ub*k bytes per rank) and merged with the single-GPU ordering
             rule -> identical lists to one GPU.
   training  every rank draws its own triplets with positive AND negative inside its shard (shard-local negative
-            sampling, north_star), computes loss / item-row gradients locally and one user-gradient row per triplet;
-            the (user id, row) pairs are ALL-GATHERED, every rank reduces them by user in the same order and applies
-            the optimiser to its replica of the user table and to its item shard.  G ranks x B triplets are
+            sampling, north_star), computes loss / item-row gradients locally.  User-row gradients are exchanged in one
+            of two ways (pick_exchange): "rows" -- one gradient row per triplet, the (user id, row) pairs are
+            ALL-GATHERED, every rank reduces them by user in the same order and applies the optimiser to its replica of
+            the user table; "dense" -- REDUCE-SCATTER of the dense gradient table, optimiser on the rank's own user rows,
+            ALL-GATHER of the updated rows (ShardedBprmfDense; the choice when B per rank exceeds 2U/G).  G ranks x B triplets are
             mathematically one step on the concatenated batch (sum-loss, gradients add).  Deviation from the reference
             for G > 1 (documented): the triplet distribution is the shard-restricted one, not custom_sampler.py:31-42's.
 
@@ -45,18 +47,46 @@ class _Collectives:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
+        import os
+        # EL_FORCE_COLLECTIVES=1: call the backend even with one rank (API check of the RCCL path on a 1-GPU box)
+        self.always = self.dist is not None and os.environ.get("EL_FORCE_COLLECTIVES") == "1"
 
     def all_gather(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return t
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         self.dist.all_gather_into_tensor(out, t.contiguous())
         return out
 
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             self.dist.all_reduce(t)
         return t
+
+    def reduce_scatter_rows(self, out, full):
+        """out [n, ...] = rank-th row block of the element-wise sum of `full` [world * n, ...] over the ranks."""
+        n = out.shape[0]
+        if self.world == 1 and not self.always:
+            out.copy_(full[:n])
+            return out
+        if self.dist.get_backend() == "gloo":                      # gloo has no reduce-scatter: all-reduce a copy, slice
+            tmp = full.clone()
+            self.dist.all_reduce(tmp)
+            out.copy_(tmp[self.rank * n:(self.rank + 1) * n])
+            return out
+        self.dist.reduce_scatter_tensor(out, full)                  # RCCL reduce-scatter over xGMI
+        return out
+
+    def all_gather_rows_into(self, full, part, async_op=False):
+        """full [world * n, ...] = concatenation of every rank's `part` [n, ...] (part may be full's own row block: the
+        in-place form).  async_op: returns the work handle (None when nothing is in flight); the caller `wait()`s
+        before it touches `full` again, kernels enqueued meanwhile overlap the transfer."""
+        if self.world == 1 and not self.always:
+            if full.data_ptr() != part.data_ptr():
+                full[:part.shape[0]].copy_(part)
+            return None if async_op else full
+        work = self.dist.all_gather_into_tensor(full, part.contiguous(), async_op=async_op)
+        return work if async_op else full
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -65,7 +95,7 @@ class _Collectives:
 def sharded_topk(ctx, coll, Gu, Gi_shard, Bi_shard, item_lo, u_start, u_stop, k, excl=None, algo="auto"):
     """Full-catalogue top-k of users [u_start, u_stop) with the item table sharded over `coll.world` ranks."""
     pi, pv = ops.score_topk(ctx, Gu, Gi_shard, Bi_shard, u_start, u_stop, k, excl=excl, item_offset=item_lo, algo=algo)
-    if coll.world == 1:
+    if coll.world == 1 and not coll.always:
         return pi, pv
     n = u_stop - u_start
     gi = coll.all_gather(pi).reshape(coll.world, n, k)
@@ -125,6 +155,117 @@ class HipBackend:
 
     def local_loss_tensor(self):
         return self.state.loss
+
+
+def user_shard_rows(n_users, world):
+    """Rows per rank of the user table in "dense" mode (the table is padded to world * rows)."""
+    return (n_users + world - 1) // world
+
+
+class HipDenseBackend:
+    """Product backend of the "dense" mode: full (padded) user table replica for the forward pass, dense gradient
+    accumulator gGu [world * Us, F], Adam state only for the rank's own user rows [rank * Us, (rank + 1) * Us)."""
+
+    def __init__(self, ctx, Gu, Gi_shard, Bi_shard, rank, world, optimizer="adam_tf_dense"):
+        import ctypes as C
+        from ._lib import BprmfState
+        if optimizer not in ("adam", "adam_tf_dense", "sgd"):
+            raise ValueError("item-sharded training supports the dense optimisers (adam_tf_dense, sgd)")
+        self.ctx, self.rank, self.world = ctx, rank, world
+        dev = ctx.device
+        U, F = Gu.shape
+        self.U, self.F = int(U), int(F)
+        self.Us = user_shard_rows(self.U, world)
+        Gu_pad = torch.zeros((self.Us * world, F), dtype=torch.float32, device=dev)
+        Gu_pad[:U].copy_(Gu)
+        # state of the gradient pass: whole (padded) user table, local item shard; no optimiser slots needed for Gu
+        self.state = ops.BprmfDeviceState(ctx, Gu_pad, Gi_shard, Bi_shard, optimizer="sgd_dense")
+        del Gu_pad
+        st = self.state
+        self.opt = ops.OPTIMIZERS["sgd_dense" if optimizer == "sgd" else optimizer]
+        adam = self.opt == ops.EL_OPT_ADAM_TF_DENSE
+        lo = rank * self.Us
+        self.Gu_own = st.Gu[lo:lo + self.Us]                        # view: the rows this rank updates
+        self.g_own = torch.zeros((self.Us, F), dtype=torch.float32, device=dev)     # reduce-scatter output
+        z = torch.zeros_like
+        self.mGu = z(self.g_own) if adam else None
+        self.vGu = z(self.g_own) if adam else None
+        self.mGi, self.vGi = (z(st.Gi), z(st.Gi)) if adam else (None, None)
+        self.mBi, self.vBi = (z(st.Bi), z(st.Bi)) if adam else (None, None)
+        p = lambda t: t.data_ptr() if t is not None else None
+        self._apply_c = BprmfState(Gu=p(self.Gu_own), Gi=p(st.Gi), Bi=p(st.Bi), gGu=p(self.g_own), gGi=p(st.gGi), gBi=p(st.gBi),
+                                   mGu=p(self.mGu), vGu=p(self.vGu), mGi=p(self.mGi), vGi=p(self.vGi), mBi=p(self.mBi),
+                                   vBi=p(self.vBi), tGu=None, tGi=None, tBi=None, U=self.Us, I=st.I, F=self.F)
+        self._ws = None
+        self._C = C
+
+    def grads(self, u, i, j, l_w, l_b):
+        C = self._C
+        st, ctx = self.state, self.ctx
+        B = u.numel()
+        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+        ops.check(ctx.lib.el_bprmf_grads(ctx.handle, ctx.stream(), C.byref(st._c), ops._ptr(u, torch.int32),
+                                         ops._ptr(i, torch.int32), ops._ptr(j, torch.int32), int(B), float(l_w), float(l_b),
+                                         int(st.step + 1), ops._ptr(st.loss, torch.float64), C.c_void_p(self._ws.data_ptr()),
+                                         self._ws.numel()), "el_bprmf_grads")
+        return st.gGu
+
+    def apply_own(self, lr):
+        C = self._C
+        st, ctx = self.state, self.ctx
+        st.step += 1
+        ops.check(ctx.lib.el_bprmf_apply(ctx.handle, ctx.stream(), C.byref(self._apply_c), float(lr), int(self.opt),
+                                         int(st.step), float(ops.adam_lr_t(lr, st.step))), "el_bprmf_apply")
+
+    def local_loss_tensor(self):
+        return self.state.loss
+
+
+class ShardedBprmfDense:
+    """BPRMF_batch train step over item shards, "dense" exchange: the all-reduce of user-row gradients split around a
+    sharded optimiser.  Per step and rank: local gradients into the dense accumulator (el_bprmf_grads) -> RCCL
+    REDUCE-SCATTER of gGu (each rank receives the summed gradient of its U/G user rows) -> optimiser on the owned user
+    rows and the local item shard (el_bprmf_apply) -> RCCL ALL-GATHER of the updated user rows into every replica.
+    Traffic per rank 2 (G-1)/G U F 4 bytes, independent of the batch -- versus (G-1) B F 4 bytes for the row exchange of
+    ShardedBprmf -- and the dense TF-Adam pass over the user table shrinks by G.  Same mathematics as one rank with the
+    concatenated batch (the reduction order of the fp32 sums is RCCL's)."""
+
+    def __init__(self, backend, coll=None):
+        self.backend = backend
+        self.coll = coll or _Collectives()
+        self._pending = None
+
+    def finish(self):
+        """The all-gather of a step is left in flight so that the caller's next sampling overlaps it; call this before
+        anything else reads the user table (train_step and pop_loss do it themselves)."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    def train_step(self, u, i_local, j_local, lr, l_w, l_b):
+        be, coll = self.backend, self.coll
+        self.finish()
+        gfull = be.grads(u, i_local, j_local, l_w, l_b)
+        coll.reduce_scatter_rows(be.g_own, gfull)
+        gfull.zero_()                                               # accumulators are zero on entry of every step
+        be.apply_own(lr)
+        self._pending = coll.all_gather_rows_into(be.state.Gu, be.Gu_own, async_op=True)
+
+    def pop_loss(self):
+        self.finish()
+        t = self.backend.local_loss_tensor()
+        tot = self.coll.all_reduce_sum(t.clone())
+        t.zero_()
+        return float(tot.item())
+
+
+def pick_exchange(n_users, batch_per_rank, world):
+    """Bytes moved per rank and step decide: rows = (G-1) B F 4 (all-gather of per-triplet rows), dense = 2 (G-1)/G U F 4."""
+    if world <= 1:
+        return "rows"
+    return "dense" if 2.0 * n_users / world < batch_per_rank else "rows"
 
 
 class ShardedBprmf:

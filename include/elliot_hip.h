@@ -155,6 +155,15 @@ size_t el_rows_segment_sum_ws_bytes(int64_t n, int64_t n_ids);
 int el_rows_segment_sum(el_ctx* ctx, void* stream, const int32_t* ids, const float* rows, int64_t n, int32_t F,
                         int64_t n_ids, float* out, void* ws, size_t ws_bytes);
 
+/* "Dense" multi-GPU mode, step 1: gradients of the rank's batch into the dense accumulators gGu [U,F], gGi, gBi
+ * (sorted segments, exactly the first half of el_bprmf_train_step) + loss; no optimiser.  The caller then
+ * reduce-scatters gGu over the ranks (RCCL), zeroes it, runs el_bprmf_apply on a state that describes its OWN user rows
+ * (Gu/mGu/vGu offset to the shard, gGu = the reduce-scatter output, U = shard rows) and all-gathers the updated rows.
+ * ws: el_bprmf_ws_bytes(B, U, I).                                                                      */
+int el_bprmf_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
+                   const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                   float l_w, float l_b, int32_t step, double* loss_out, void* ws, size_t ws_bytes);
+
 /* Step 4: optimiser alone on (Gu, local Gi, local Bi); opt = EL_OPT_ADAM_TF_DENSE or EL_OPT_SGD.  */
 int el_bprmf_apply(el_ctx* ctx, void* stream, const el_bprmf_state* st, float lr, int opt, int32_t step, float lr_t);
 

@@ -51,6 +51,109 @@ class NumpyBackend:
         return self.loss
 
 
+class NumpyDenseBackend:
+    """Stand-in for parallel.HipDenseBackend: padded user table replica, dense gradient table, optimiser state for the
+    rank's own user rows only."""
+
+    def __init__(self, Gu, Gi, Bi, rank, world):
+        U, F = Gu.shape
+        self.U, self.rank, self.world = U, rank, world
+        self.Us = parallel.user_shard_rows(U, world)
+        Gu_pad = np.zeros((self.Us * world, F), np.float32)
+        Gu_pad[:U] = Gu
+        z = np.zeros_like
+        self.state = type("S", (), {})()
+        self.state.Gu = torch.from_numpy(Gu_pad)                   # torch views: the collectives work on these buffers
+        self.Gi, self.Bi = Gi.copy(), Bi.copy()
+        self.gGu = torch.zeros_like(self.state.Gu)
+        self.gGi, self.gBi = z(self.Gi), z(self.Bi)
+        lo = rank * self.Us
+        self.Gu_own = self.state.Gu[lo:lo + self.Us]
+        self.g_own = torch.zeros((self.Us, F), dtype=torch.float32)
+        self.m = [z(self.Bi), np.zeros((self.Us, F), np.float32), z(self.Gi)]
+        self.v = [z(self.Bi), np.zeros((self.Us, F), np.float32), z(self.Gi)]
+        self.loss = torch.zeros(1, dtype=torch.float64)
+        self.t = 0
+
+    def grads(self, u, i, j, l_w, l_b):
+        u, i, j = (x.numpy().astype(np.int64) for x in (u, i, j))
+        Gu = self.state.Gu.numpy()
+        self.loss += float(ob.forward_loss(Gu, self.Gi, self.Bi, u, i, j, l_w, l_b))
+        dBi, dGu, dGi = ob.gradients(Gu, self.Gi, self.Bi, u, i, j, l_w, l_b)
+        self.gBi += dBi
+        self.gGi += dGi
+        self.gGu += torch.from_numpy(dGu)
+        return self.gGu
+
+    def apply_own(self, lr):
+        self.t += 1
+        own = self.Gu_own.numpy()                                  # shares memory with the padded table
+        for th, g, m, v in zip((self.Bi, own, self.Gi), (self.gBi, self.g_own.numpy(), self.gGi), self.m, self.v):
+            ob.adam_tf_sparse_apply(th, m, v, g, lr, self.t)
+            g[:] = 0
+
+    def local_loss_tensor(self):
+        return self.loss
+
+
+def _dense_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(1)
+        U, I, F, B = 61, 80, 8, 96                                  # U not divisible by the world size: padded rows
+        Gu = rs.normal(scale=0.1, size=(U, F)).astype(np.float32)
+        Gi = rs.normal(scale=0.1, size=(I, F)).astype(np.float32)
+        Bi = rs.normal(scale=0.01, size=I).astype(np.float32)
+        lo, hi = parallel.item_range(I, rank, world)
+        coll = parallel._Collectives()
+        be = NumpyDenseBackend(Gu, Gi[lo:hi], Bi[lo:hi], rank, world)
+        tr = parallel.ShardedBprmfDense(be, coll)
+        ref = ob.BPRMFBatchOracle(Gu, Gi, Bi, 0.01, 0.1, 0.001)
+        for step in range(3):
+            batches = []
+            for r in range(world):
+                brs = np.random.RandomState(200 + 10 * step + r)
+                l, h = parallel.item_range(I, r, world)
+                batches.append((brs.randint(0, U, B), brs.randint(l, h, B), brs.randint(l, h, B)))
+            u, i, j = batches[rank]
+            tr.train_step(torch.from_numpy(u.astype(np.int32)), torch.from_numpy((i - lo).astype(np.int32)),
+                          torch.from_numpy((j - lo).astype(np.int32)), 0.01, 0.1, 0.001)
+            loss = tr.pop_loss()
+            cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+            ref_loss = ref.train_step((cu, ci, cj))
+            assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss), (loss, ref_loss)
+            assert np.abs(be.state.Gu.numpy()[:U] - ref.Gu).max() < 2e-6
+            assert np.abs(be.state.Gu.numpy()[U:]).max() == 0.0                      # padding rows never move
+            assert np.abs(be.Gi - ref.Gi[lo:hi]).max() < 2e-6 and np.abs(be.Bi - ref.Bi[lo:hi]).max() < 2e-6
+            assert float(be.gGu.abs().max()) == 0.0                                  # accumulators zero on exit
+        t = be.state.Gu.clone()
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_item_sharded_training_dense_exchange_world2_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dense_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: 1, 1: 1}
+
+
+def test_pick_exchange():
+    assert parallel.pick_exchange(1_000_000, 1 << 20, 1) == "rows"
+    assert parallel.pick_exchange(1_000_000, 1 << 20, 8) == "dense"       # 8 x 1M triplets touch every user row anyway
+    assert parallel.pick_exchange(10_000_000, 65536, 8) == "rows"          # few triplets, huge table: ship the rows
+    assert parallel.user_shard_rows(61, 2) == 31
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

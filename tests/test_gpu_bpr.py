@@ -207,6 +207,50 @@ def test_item_sharded_hip_path_equals_concatenated_batch(ctx):
             assert not cpu(be.state.gGu).any() and not cpu(be.state.gGi).any()
 
 
+def test_item_sharded_dense_exchange_hip_path_equals_concatenated_batch(ctx):
+    """"dense" exchange with two virtual ranks on one GPU: el_bprmf_grads -> (emulated) reduce-scatter of the dense
+    gradient table -> el_bprmf_apply on the owned user rows -> (emulated) all-gather.  U is odd: padded rows."""
+    from elliot_amd import parallel
+    rs = np.random.RandomState(32)
+    U, I, F, B, G = 701, 400, 64, 3000, 2
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    d = ctx.device
+    bes, rng = [], []
+    for r in range(G):
+        lo, hi = parallel.item_range(I, r, G)
+        rng.append((lo, hi))
+        bes.append(parallel.HipDenseBackend(ctx, torch.from_numpy(Gu).to(d), Gi[lo:hi], Bi[lo:hi], r, G, optimizer="adam_tf_dense"))
+    Us = bes[0].Us
+    assert Us * G == 702 and bes[0].state.Gu.shape[0] == 702
+    orc = ob.BPRMFBatchOracle(Gu, Gi, Bi, lr, l_w, l_b)
+    for step in range(3):
+        batches = [(rs.randint(0, U, B), rs.randint(lo, min(lo + 25, hi), B), rs.randint(lo, hi, B)) for lo, hi in rng]
+        gs = []
+        for be, (lo, hi), (u, i, j) in zip(bes, rng, batches):
+            gs.append(be.grads(torch.from_numpy(u.astype(np.int32)).to(d), torch.from_numpy((i - lo).astype(np.int32)).to(d),
+                               torch.from_numpy((j - lo).astype(np.int32)).to(d), l_w, l_b))
+        gsum = gs[0] + gs[1]                                         # what the reduce-scatter delivers, slice by slice
+        loss = 0.0
+        for r, be in enumerate(bes):
+            be.g_own.copy_(gsum[r * Us:(r + 1) * Us])
+            gs[r].zero_()
+            be.apply_own(lr)
+            loss += be.state.pop_loss()
+        full = torch.cat([be.Gu_own for be in bes])                  # the all-gather
+        for be in bes:
+            be.state.Gu.copy_(full)
+        cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+        exp = orc.train_step((cu, ci, cj))
+        assert abs(loss - exp) <= 1e-4 * abs(exp), (step, loss, exp)
+        assert (np.abs(cpu(bes[0].state.Gu)[:U] - orc.Gu) > 2e-5).mean() < 2e-4
+        assert not cpu(bes[0].state.Gu)[U:].any()
+        for be, (lo, hi) in zip(bes, rng):
+            assert (np.abs(cpu(be.state.Gi) - orc.Gi[lo:hi]) > 2e-5).mean() < 2e-4
+            assert (np.abs(cpu(be.state.Bi) - orc.Bi[lo:hi]) > 2e-5).mean() < 2e-3
+            assert not cpu(be.state.gGu).any() and not cpu(be.state.gGi).any() and not cpu(be.g_own).any()
+
+
 # ---------------------------------------------------------------------------------- exact MT19937 replay
 def test_mt19937_replay_sampler_equals_reference_stream(ctx, golden):
     """The reference's own custom_sampler.Sampler output (tests/golden/sampler_ref.npz, seed 42, batches of 512)."""
