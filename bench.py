@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--topk-algo", default="auto", choices=["auto", "screen", "mfma", "simple"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "dense"],
                     help="N > 1: how user-row gradients travel (parallel.pick_exchange)")
+    ap.add_argument("--topk-shard", default="user", choices=["user", "item"],
+                    help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial top-k")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-topk-users", type=int, default=640)
@@ -193,10 +195,24 @@ def main():
     n_blocks = max(1, U // Ub)
     blk = [0]
 
-    def topk_step():
-        s = (blk[0] % n_blocks) * Ub
-        blk[0] += 1
-        parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo=args.topk_algo)
+    sharded = world > 1 or args.force_sharded
+    topk_by_user = sharded and args.topk_shard == "user"
+    if topk_by_user:
+        # users are independent units: each rank scores ITS blocks of users against the whole catalogue, no collective on
+        # the data path.  The item table (sharded for training) is all-gathered once per evaluation (I F 4 bytes).
+        if finish_train:
+            finish_train()
+        Gi_full, Bi_full = parallel.gather_item_table(coll, st.Gi, st.Bi, I)
+
+        def topk_step():
+            s = ((blk[0] * world + rank) % n_blocks) * Ub
+            blk[0] += 1
+            ops.score_topk(ctx, st.Gu, Gi_full, Bi_full, s, s + Ub, k, excl=pos, algo=args.topk_algo)
+    else:
+        def topk_step():
+            s = (blk[0] % n_blocks) * Ub
+            blk[0] += 1
+            parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo=args.topk_algo)
 
     def timed(fn, warmup, steps, finish=None):
         for _ in range(warmup):
@@ -238,7 +254,7 @@ def main():
         return
     # ---------------- metrics ---------------------------------------------------------------------
     pairs_per_s = world * B * K / dt_train            # B triplets per rank and step
-    users_per_s = Ub * K / dt_topk
+    users_per_s = (world if topk_by_user else 1) * Ub * K / dt_topk
 
     # HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.md), valid for the default workload only
     traffic = {}
@@ -277,7 +293,7 @@ def main():
     # kernel, or one of the two bf16 passes of the screened kernel (the other pass repeats the same flops; results are
     # re-scored in fp32 and bit-identical)
     tn, tsec = dominant(rep_topk)
-    flops = 2.0 * Ub * (hi - lo) * F
+    flops = 2.0 * Ub * (I if topk_by_user else (hi - lo)) * F
     ach_t = flops / tsec / 1e12
     screened = tn.startswith("k_screen")
     peak_t = MFMA_BF16_PEAK_TFLOPS if screened else MFMA_F32_PEAK_TFLOPS
@@ -300,10 +316,14 @@ def main():
                    f"item-shard x{world}: train = {B} triplets/rank + "
                    + ("reduce-scatter of the dense user-gradient table, optimiser on U/G user rows, all-gather of the rows"
                       if exchange_used[0] == "dense" else "all-gather of user-gradient rows")
-                   + f" (weak); top-k = all users vs I/{world} items per rank + all-gather/merge (strong)"},
+                   + " (weak); top-k: see topk.sharding"},
         "loss_per_pair_last": loss / (B * world * (K + W)),
         "roofline": roof_train,
-        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "scaling": "strong",
+        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3,
+                 "scaling": "weak" if (topk_by_user or world == 1) else "strong",
+                 "sharding": ("single" if not sharded else
+                              f"by user: {Ub} users per rank and step vs the whole catalogue (item table all-gathered once per evaluation)"
+                              if topk_by_user else f"by item: all users vs I/{world} items per rank + all-gather/merge of partial lists"),
                  "roofline": roof_topk},
     }
     if dt_met is not None:

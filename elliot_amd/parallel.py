@@ -103,6 +103,25 @@ def sharded_topk(ctx, coll, Gu, Gi_shard, Bi_shard, item_lo, u_start, u_stop, k,
     return ops.topk_merge(ctx, gi, gv)
 
 
+def gather_item_table(coll, Gi_shard, Bi_shard, n_items):
+    """Every rank's item shard -> the whole table on every rank (one RCCL all-gather per evaluation: I F 4 bytes, 51 MB at
+    C2).  With the table whole, full-catalogue top-k shards by USER: independent units, no collective on the data path."""
+    if coll.world == 1 and not coll.always:
+        return Gi_shard, Bi_shard
+    rows = (n_items + coll.world - 1) // coll.world                      # item_range() shards differ by at most one row
+    F = Gi_shard.shape[1]
+    pad = torch.zeros((rows, F + 1), dtype=torch.float32, device=Gi_shard.device)
+    pad[:Gi_shard.shape[0], :F] = Gi_shard
+    pad[:Bi_shard.shape[0], F] = Bi_shard
+    allp = coll.all_gather(pad).reshape(coll.world, rows, F + 1)
+    parts = []
+    for r in range(coll.world):
+        lo, hi = item_range(n_items, r, coll.world)
+        parts.append(allp[r, :hi - lo])
+    full = torch.cat(parts)
+    return full[:, :F].contiguous(), full[:, F].contiguous()
+
+
 # ------------------------------------------------------------------------------------------------------
 # training
 # ------------------------------------------------------------------------------------------------------

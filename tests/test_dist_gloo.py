@@ -230,3 +230,28 @@ def test_shard_csr_and_item_range():
     ip, ix = parallel.shard_csr(indptr, indices, 4, 9)
     assert ip.tolist() == [0, 1, 1, 3] and ix.tolist() == [1, 0, 4]
     assert [parallel.item_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        I, F = 11, 3                                                  # uneven shards: 5 + 6 rows
+        Gi = torch.arange(I * F, dtype=torch.float32).reshape(I, F)
+        Bi = torch.arange(I, dtype=torch.float32) * 10
+        lo, hi = parallel.item_range(I, rank, world)
+        g, b = parallel.gather_item_table(parallel._Collectives(), Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), I)
+        assert torch.equal(g, Gi) and torch.equal(b, Bi)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_item_table_world2_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}
