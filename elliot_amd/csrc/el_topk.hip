@@ -31,8 +31,8 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
     if (p.ulist) {                                         // (dense rows stay indexed by blockIdx.x)
         int64_t n = (int64_t)*p.ulist_n;
         if (p.ulist_max > 0 && n > p.ulist_max) n = p.ulist_max;
-        if ((int64_t)blockIdx.x >= n) return;
-        urel = p.ulist[blockIdx.x];
+        if ((int64_t)blockIdx.x + p.ulist_skip >= n) return;
+        urel = p.ulist[blockIdx.x + p.ulist_skip];
     }
     const int64_t user = p.u_start + urel;
     if (p.only_flagged && p.only_flagged[blockIdx.x] == 0) return;
@@ -648,30 +648,35 @@ int el_topk_launch_mfma(const TopkParams& p, hipStream_t st) {
 static const int LIST_SPLIT = 64;
 static const int LIST_DENSE = 64;
 
+// exact scores of the first min(*ulist_n, LIST_DENSE) listed users against the whole shard: one thread per item keeps its
+// row in registers and walks the users (rows staged in LDS), so the item table is read once.  F <= 128 (screened path).
 __global__ __launch_bounds__(256) void k_list_scores(TopkParams p, float* __restrict__ preds) {
-    const int slot = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* us = reinterpret_cast<float*>(smem);            // [n][F]
     int n = *p.ulist_n;
-    if (slot >= n) return;
+    if (n > LIST_DENSE) n = LIST_DENSE;
+    if (n <= 0) return;
+    const int F = p.F;
+    for (int t = threadIdx.x; t < n * F; t += 256) {
+        const int slot = t / F, f = t - slot * F;
+        us[t] = p.Gu[(p.u_start + p.ulist[slot]) * (int64_t)F + f];
+    }
+    __syncthreads();
     const int64_t il = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (il >= p.I_local) return;
-    const int64_t user = p.u_start + p.ulist[slot];
-    const float* gi = p.Gi + il * (int64_t)p.F;
-    const float* gu = p.Gu + user * (int64_t)p.F;
-    float a = 0.f;
-    if ((p.F & 3) == 0 && (((reinterpret_cast<uintptr_t>(p.Gi) | reinterpret_cast<uintptr_t>(p.Gu)) & 15) == 0)) {
-        const float4* gi4 = reinterpret_cast<const float4*>(gi);
-        const float4* gu4 = reinterpret_cast<const float4*>(gu);
-        for (int c = 0; c < p.F / 4; ++c) {
-            const float4 x = gi4[c], y = gu4[c];
-            a = __builtin_fmaf(x.x, y.x, a);
-            a = __builtin_fmaf(x.y, y.y, a);
-            a = __builtin_fmaf(x.z, y.z, a);
-            a = __builtin_fmaf(x.w, y.w, a);
-        }
-    } else {
-        for (int f = 0; f < p.F; ++f) a = __builtin_fmaf(gi[f], gu[f], a);
+    float gi[128];
+    const float* row = p.Gi + il * (int64_t)F;
+#pragma unroll
+    for (int f = 0; f < 128; ++f) gi[f] = f < F ? row[f] : 0.f;
+    const float bias = p.Bi ? p.Bi[il] : 0.f;
+    for (int slot = 0; slot < n; ++slot) {
+        const float* gu = us + slot * F;
+        float a = 0.f;
+#pragma unroll
+        for (int f = 0; f < 128; ++f)
+            if (f < F) a = __builtin_fmaf(gi[f], gu[f], a);
+        preds[(int64_t)slot * p.I_local + il] = (p.Bi ? a + bias : a) + 0.0f;
     }
-    preds[(int64_t)slot * p.I_local + il] = (p.Bi ? a + p.Bi[il] : a) + 0.0f;
 }
 
 static int64_t list_cap_for(int64_t n_users) {
@@ -699,7 +704,9 @@ int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, 
         d.ulist_skip = 0;
         d.ulist_max = LIST_DENSE;
         d.nsplit = 0;
-        EL_LAUNCH("k_list_scores", k_list_scores, dim3((unsigned)((p0.I_local + 255) / 256), LIST_DENSE), dim3(256), 0, st, d, preds);
+        EL_REQUIRE(p0.F <= 128, "el_topk_run_list: F <= 128");
+        EL_LAUNCH("k_list_scores", k_list_scores, dim3((unsigned)((p0.I_local + 255) / 256)), dim3(256), (size_t)LIST_DENSE * p0.F * 4, st, d,
+                  preds);
         d.preds = preds;
         d.ld = p0.I_local;
         // one wave per (entry, item slice) -> partial lists in the split scratch (free until tier 2 runs) -> merge
@@ -722,6 +729,40 @@ int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, 
         EL_CHECK_LAUNCH();
     }
     const int skip1 = p0.I_local > 0 ? LIST_DENSE : 0;
+    if (!mfma_eligible(p0.F, p0.k, p0.cand_indptr)) {       // large k: the wave kernel takes the rest of the list
+        if (n_users > skip1) {
+            const int wcap = wave_cap_for_k(p0.k);
+            int WS = (int)((p0.I_local + 1023) / 1024);             // item slices: one wave per (entry, slice) + merge
+            if (WS > LIST_SPLIT) WS = LIST_SPLIT;
+            while (WS > 1 && WS * p0.k > 8192) --WS;                // merge buffer limit
+            TopkParams q = p0;
+            q.ulist_skip = skip1;
+            q.ulist_max = (int)(skip1 + cap);
+            q.nsplit = WS > 1 ? WS : 0;
+            if (WS > 1) {
+                q.part_stride = cap;
+                q.out_idx = part_idx;
+                q.out_val = part_val;
+            }
+            const int64_t rows = (n_users - skip1) < cap ? (n_users - skip1) : cap;
+            EL_LAUNCH("k_topk_wave", k_topk_wave<false>, dim3((unsigned)rows, WS > 1 ? WS : 1), dim3(64), (size_t)wcap * 8 + 16, st, q, wcap);
+            if (WS > 1) {
+                int mcap = next_pow2(WS * p0.k);
+                if (mcap < 64) mcap = 64;
+                EL_LAUNCH("k_topk_merge", k_topk_merge, dim3((unsigned)rows), dim3(64), (size_t)mcap * 8, st, (const int32_t*)part_idx,
+                          (const float*)part_val, WS, cap, p0.k, mcap, p0.out_idx, p0.out_val, p0.ulist, p0.ulist_n, skip1);
+            }
+            if (n_users > skip1 + cap) {                             // beyond the split scratch: unsplit
+                TopkParams r = p0;
+                r.ulist_skip = (int)(skip1 + cap);
+                r.ulist_max = 0;
+                r.nsplit = 0;
+                EL_LAUNCH("k_topk_wave", k_topk_wave<false>, dim3((unsigned)(n_users - skip1 - cap)), dim3(64), (size_t)wcap * 8 + 16, st, r, wcap);
+            }
+            EL_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     // item slices of >= 4 MFMA tiles (128 items each), at most LIST_SPLIT of them
     int64_t S = (p0.I_local + 511) / 512;
     if (S > LIST_SPLIT) S = LIST_SPLIT;
@@ -788,7 +829,7 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
         p.dbg = e ? atoi(e) : 0;
     }
     const bool selig = el_topk_screen_eligible(F, k, cand_indptr);
-    if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=128, k<=30 and no candidate list");
+    if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=128, k<=128 and no candidate list");
     if (algo == EL_TOPK_SCREEN ||
         (algo == EL_TOPK_AUTO && selig && ws != nullptr && ws_bytes >= el_topk_screen_ws_bytes(u_stop - u_start, I_local, F, k, 0)))
         return el_topk_screen_run(p, ws, ws_bytes, st);

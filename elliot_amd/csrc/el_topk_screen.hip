@@ -36,7 +36,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define SCR_TI 64        // items per tile == slots per user
-#define SCR_SURV 128     // unmasked hits a user may have before it is sent to the exact fallback
 
 __device__ __forceinline__ u32 el_f2bf(float x) {
     u32 b = __float_as_uint(x);
@@ -123,6 +122,10 @@ struct ScreenParams {
     int64_t list_cap;            // entries in `lists`
     int32_t* ulist;              // [n_users] flagged users (relative ids), filled by k_screen_flags
     int32_t* ulist_n;            // [1]
+    float* Tg;                   // [n_users] the threshold guess T (thr = T - 2E); k_screen_final verifies it
+    float* Eu;                   // [n_users] E_u
+    int kA;                      // T = kA-th largest clean slot maximum (== k with stride 1: T is then rigorous)
+    int surv;                    // unmasked hits a user may have before it is sent to the exact fallback (128 or 512)
     int stride;                  // pass 1 visits tiles t with t % stride == 0
     unsigned long long* prof;    // EL_SCREEN_PROF=1: [n_waves][8] cycle / event counters (developer tool)
 };
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
                 nz = p.excl_indptr[user + 1] - z0;
                 zoff = z0 - p.excl_indptr[p.u_start];
             }
-            lbase[ub] = ur * SCR_SURV + zoff;
-            int64_t cap = SCR_SURV + nz;
+            lbase[ub] = ur * sp.surv + zoff;
+            int64_t cap = sp.surv + nz;
             if (lbase[ub] + cap > sp.list_cap) cap = sp.list_cap - lbase[ub];     // undersized workspace: flag, never write OOB
             lcap[ub] = (int)(cap < 0 ? 0 : (cap > 0x3fffffff ? 0x3fffffff : cap));
         }
@@ -423,7 +426,8 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
         e0 = p.excl_indptr[user];
         e1 = p.excl_indptr[user + 1];
     }
-    int R = p.k + 8 < SCR_TI ? p.k + 8 : SCR_TI;
+    const int kA = sp.kA;
+    int R = kA + 8 < SCR_TI ? kA + 8 : SCR_TI;
     bool good = false;
     float T = 0.f;
     for (int lo = 0; lo < SCR_TI && !good; lo = R, R = SCR_TI) {
@@ -463,8 +467,8 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
         }
         el_wave_lds_sync();
         u64 clean = __ballot(mykey != 0ull && lane < R && inv[myslot] == 0);   // bit j: the j-th best slot is clean
-        if (__popcll(clean) >= p.k) {
-            for (int q = 1; q < p.k; ++q) clean &= clean - 1ull;
+        if (__popcll(clean) >= kA) {
+            for (int q = 1; q < kA; ++q) clean &= clean - 1ull;
             T = el_key_score(keys[__ffsll((long long)clean) - 1]);
             good = true;
         }
@@ -472,6 +476,8 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
     if (lane == 0) {
         good = good && (E < INFINITY);
         sp.thr[ur] = good ? (T - 2.0f * E) : INFINITY;
+        sp.Tg[ur] = T;
+        sp.Eu[ur] = E;
         sp.ovf[ur] = good ? 0 : 1;
         sp.cnt[ur] = 0;
     }
@@ -512,6 +518,7 @@ __device__ __forceinline__ float el_exact_score(const TopkParams& p, const float
     return (p.Bi ? a + p.Bi[il] : a) + 0.0f;
 }
 
+template <int SCR_SURV>
 __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
     const TopkParams& p = sp.t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
     for (int q = 0; q < SCR_SURV / 64; ++q) {
         const int t = q * 64 + lane;
         nk[q] = 0ull;
-        if (t < ns) {
+        if (q * 64 < ns && t < ns) {
             const int32_t g = (int32_t)(u32)surv[t];
             const float s = el_exact_score(p, gu_s, (int64_t)g - p.item_offset, vec4);
             if (s == s) nk[q] = el_make_key(s, g);
@@ -593,7 +600,9 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
 #pragma unroll
     for (int q = 0; q < SCR_SURV / 64; ++q) surv[q * 64 + lane] = nk[q];
     el_wave_lds_sync();
-    el_wave_bitonic_desc(surv, ns <= 64 ? 64 : SCR_SURV, lane);     // keys beyond ns are 0 and sort last
+    int n2 = 64;
+    while (n2 < ns) n2 <<= 1;
+    el_wave_bitonic_desc(surv, n2, lane);                           // keys beyond ns are 0 and sort last
     int nv = 0;
 #pragma unroll
     for (int q = 0; q < SCR_SURV / 64; ++q) nv += __popcll(__ballot(surv[q * 64 + lane] != 0ull));
@@ -601,11 +610,17 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
         if (lane == 0) sp.ovf[ur] = 1;
         return;
     }
+    // the threshold was a guess unless pass 1 saw every tile (kA == k): it was good enough iff k survivors have an exact
+    // score >= T - E, because every item that is NOT a survivor has s' < T - 2E, hence an exact score < T - E
+    if (!(el_key_score(surv[p.k - 1]) >= sp.Tg[ur] - sp.Eu[ur])) {
+        if (lane == 0) sp.ovf[ur] = 1;
+        return;
+    }
     const int64_t orow = ur * (int64_t)p.k;
-    if (lane < p.k) {
-        const u64 kk = surv[lane];
-        p.out_idx[orow + lane] = el_key_item(kk);
-        p.out_val[orow + lane] = el_key_score(kk);
+    for (int t = lane; t < p.k; t += 64) {
+        const u64 kk = surv[t];
+        p.out_idx[orow + t] = el_key_item(kk);
+        p.out_val[orow + t] = el_key_score(kk);
     }
 }
 
@@ -620,13 +635,15 @@ static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int screen_fp(int F) { return F <= 32 ? 32 : (F <= 64 ? 64 : 128); }
 
-bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 128 && k >= 1 && k <= 30; }
+bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 128 && k >= 1 && k <= 128; }
+
+static int screen_surv(int k) { return k <= 12 ? 128 : 512; }
 
 size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, int64_t excl_nnz) {
     const int FP = screen_fp(F);
     if (excl_nnz < 0) excl_nnz = 0;
-    return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 4 * a256((size_t)n_users * 4) +
-           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * SCR_SURV + (size_t)excl_nnz) * 8);
+    return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 6 * a256((size_t)n_users * 4) +
+           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * screen_surv(k) + (size_t)excl_nnz) * 8);
 }
 
 template <int FP, int MODE, int NW, bool PROF>
@@ -669,7 +686,10 @@ static int run_passes(ScreenParams& sp, hipStream_t st) {
         EL_CHECK_HIP(hipFree(sp.prof));
         sp.prof = nullptr;
     }
-    EL_LAUNCH("k_screen_final", k_screen_final, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
+    if (sp.surv == 128)
+        EL_LAUNCH("k_screen_final", k_screen_final<128>, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
+    else
+        EL_LAUNCH("k_screen_final", k_screen_final<512>, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -697,6 +717,11 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     base += a256((size_t)n_users * 4);
     sp.ulist = (int32_t*)base;
     base += a256((size_t)n_users * 4);
+    sp.Tg = (float*)base;
+    base += a256((size_t)n_users * 4);
+    sp.Eu = (float*)base;
+    base += a256((size_t)n_users * 4);
+    sp.surv = screen_surv(p.k);
     sp.ulist_n = (int32_t*)(stats + 2);
     void* fb_scratch = base;
     const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.I_local, p.k);
@@ -707,11 +732,26 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     sp.stats = stats;
     sp.prof = nullptr;
     const int ntiles = (int)((p.I_local + SCR_TI - 1) / SCR_TI);
-    sp.stride = 1;   // 2 halves pass 1 but doubles the hits of pass 2 / final: a wash on MI355X (EL_SCREEN_STRIDE to experiment)
-    (void)ntiles;
+    // Pass 1 over every tile with T = k-th largest clean slot maximum is rigorous (k <= 12: ~25 hits per user).  Larger k
+    // cannot get k clean slots out of 64, so pass 1 sees every `stride`-th tile only and T = kA-th largest clean maximum of
+    // that sample is a GUESS aimed at rank ~1.15 k of the catalogue; k_screen_final verifies it per user.
+    sp.stride = 1;
+    sp.kA = p.k;
+    if (p.k > 12) {
+        int sd = (int)(1.15 * p.k / 24.0 + 0.5);                // kA ~ 20-30 of the 64 slots: a 1/sd sample has rank sd(kA + 1/2)
+        sd = sd < 2 ? 2 : (sd > 8 ? 8 : sd);                    //   +- sd sqrt(kA (1 - 1/sd)) in the catalogue
+        while (sd > 1 && ntiles < 48 * sd) --sd;                // small catalogues: sample more of it
+        sp.stride = sd;
+        sp.kA = (int)((1.15 * p.k) / sd + 0.999) + 2;
+        if (sp.kA > 40) sp.kA = 40;                              // (tiny catalogues: the verification decides)
+    }
     if (const char* se = getenv("EL_SCREEN_STRIDE")) {
         const int v = atoi(se);
-        if (v >= 1 && v <= 8) sp.stride = v;
+        if (v >= 1 && v <= 16) sp.stride = v;
+    }
+    if (const char* se = getenv("EL_SCREEN_KA")) {
+        const int v = atoi(se);
+        if (v >= 1 && v <= 56) sp.kA = v;
     }
     EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
     if (p.I_local > 0) {

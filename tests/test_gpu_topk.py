@@ -39,8 +39,8 @@ def run_gpu(ctx, Gu, Gi, Bi, u0, u1, k, excl=None, cand=None, item_offset=0, alg
 @pytest.mark.parametrize("algo", ["simple", "mfma", "screen"])
 @pytest.mark.parametrize("F,k", [(64, 10), (128, 10), (10, 10), (128, 1), (32, 14), (200, 10), (256, 10), (64, 32), (128, 40), (12, 5)])
 def test_topk_matches_oracle_bitexact(ctx, algo, F, k):
-    if algo == "screen" and (F > 128 or k > 30):
-        pytest.skip("screened kernel: F <= 128, k <= 30")
+    if algo == "screen" and (F > 128 or k > 128):
+        pytest.skip("screened kernel: F <= 128, k <= 128")
     rs = np.random.RandomState(100 + F + k)
     U, I = 300, 1000 + F        # ragged last user block (300 = 2*128 + 44) and ragged last item tile
     Gu, Gi, Bi = make(rs, U, I, F)
@@ -220,11 +220,13 @@ def test_screened_topk_large_random_block(ctx):
     assert_topk_equal("topk_screen_large", gi, gv, ei, ev)
 
 
-def test_screened_topk_all_users_fall_back(ctx):
-    """Every item identical -> every score of a user ties -> every user is flagged: exercises the item-split list
-    fallback (first 512 flagged users) and the plain list kernel (the rest)."""
+@pytest.mark.parametrize("k", [10, 50])
+def test_screened_topk_all_users_fall_back(ctx, k):
+    """Every item identical -> every score of a user ties -> every user is flagged: exercises all fallback tiers (dense
+    scores for the first 64 users, item-split kernels for the next 512, the plain list kernel for the rest; fp32 MFMA
+    kernels for k <= 40, wave kernels above)."""
     rs = np.random.RandomState(23)
-    U, I, F, k = 700, 3000, 32, 10
+    U, I, F = 700, 3000, 32
     Gu = rs.normal(scale=0.1, size=(U, F)).astype(np.float32)
     Gi = np.repeat(rs.normal(scale=0.1, size=(1, F)).astype(np.float32), I, axis=0)
     Bi = np.zeros(I, np.float32)
@@ -244,3 +246,18 @@ def test_screened_topk_nonfinite_inputs_fall_back(ctx):
     ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
     gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
     assert_topk_equal("topk_screen_nonfinite", gi, gv, ei, ev)
+
+
+@pytest.mark.parametrize("F,k,I", [(64, 100, 20000), (128, 50, 9000), (32, 128, 6000), (128, 20, 3000)])
+def test_screened_topk_large_k_guess_and_verify(ctx, F, k, I):
+    """k > 12: the threshold is a guess from a strided pass 1, verified per user by k_screen_final (exact fallback when
+    the guess was too high).  Results must still be bit-identical."""
+    rs = np.random.RandomState(F + k)
+    U = 400
+    Gu = rs.normal(scale=0.1, size=(U, F)).astype(np.float32)
+    Gi = rs.normal(scale=0.1, size=(I, F)).astype(np.float32)
+    Bi = rs.normal(scale=0.01, size=I).astype(np.float32)
+    excl = random_excl(rs, U, I, 0, 200)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
+    assert_topk_equal(f"topk_screen_k{k}", gi, gv, ei, ev)
