@@ -637,13 +637,54 @@ static int screen_fp(int F) { return F <= 32 ? 32 : (F <= 64 ? 64 : 128); }
 
 bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 128 && k >= 1 && k <= 128; }
 
-static int screen_surv(int k) { return k <= 12 ? 128 : 512; }
+// How the threshold T is obtained (see the header comment and DESIGN.md 3.1b):
+//   small catalogue (< 192 tiles), k <= 12   pass 1 over every tile, T = k-th largest clean slot maximum: rigorous
+//   k <= 12                                   a full pass 1 is half of the run time: every 4th (8th from 300 K items) tile, a GUESS
+//   k  > 12                                   64 slots cannot yield k clean maxima: every stride-th tile (2..8), a GUESS
+// A guess is the kA-th largest clean slot maximum of the sample, aimed at rank ~1.15 k (+ margin) of the catalogue;
+// k_screen_final verifies it per user (exact fallback otherwise).  surv = unmasked hits a user may have.
+struct ScreenPolicy {
+    int stride, kA, surv;
+};
+
+static ScreenPolicy screen_policy(int k, int64_t I_local) {
+    const int ntiles = (int)((I_local + SCR_TI - 1) / SCR_TI);
+    ScreenPolicy q;
+    q.stride = 1;
+    q.kA = k;
+    q.surv = 128;
+    if (k <= 12) {
+        const int sd = I_local >= 300000 ? 8 : (ntiles >= 192 ? 4 : 1);
+        if (sd > 1) {
+            q.stride = sd;
+            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd == 8 ? 4 : 5);
+        }
+    } else {
+        int sd = (int)(1.15 * k / 24.0 + 0.5);                  // kA ~ 20-30 of the 64 slots: a 1/sd sample has rank sd(kA + 1/2)
+        sd = sd < 2 ? 2 : (sd > 8 ? 8 : sd);                    //   +- sd sqrt(kA (1 - 1/sd)) in the catalogue
+        while (sd > 1 && ntiles < 48 * sd) --sd;                // small catalogues: sample more of it
+        q.stride = sd;
+        q.kA = (int)((1.15 * k) / sd + 0.999) + 2;
+        if (q.kA > 40) q.kA = 40;                               // (tiny catalogues: the verification decides)
+        q.surv = 512;
+    }
+    if (const char* se = getenv("EL_SCREEN_STRIDE")) {
+        const int v = atoi(se);
+        if (v >= 1 && v <= 16) q.stride = v;
+    }
+    if (const char* se = getenv("EL_SCREEN_KA")) {
+        const int v = atoi(se);
+        if (v >= 1 && v <= 56) q.kA = v;
+    }
+    if (q.stride > 1 || q.kA != k) q.surv = 512;
+    return q;
+}
 
 size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, int64_t excl_nnz) {
     const int FP = screen_fp(F);
     if (excl_nnz < 0) excl_nnz = 0;
     return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 6 * a256((size_t)n_users * 4) +
-           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * screen_surv(k) + (size_t)excl_nnz) * 8);
+           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * screen_policy(k, I_local).surv + (size_t)excl_nnz) * 8);
 }
 
 template <int FP, int MODE, int NW, bool PROF>
@@ -721,7 +762,10 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     base += a256((size_t)n_users * 4);
     sp.Eu = (float*)base;
     base += a256((size_t)n_users * 4);
-    sp.surv = screen_surv(p.k);
+    const ScreenPolicy pol = screen_policy(p.k, p.I_local);
+    sp.surv = pol.surv;
+    sp.stride = pol.stride;
+    sp.kA = pol.kA;
     sp.ulist_n = (int32_t*)(stats + 2);
     void* fb_scratch = base;
     const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.I_local, p.k);
@@ -731,28 +775,6 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     sp.Gib = gib;
     sp.stats = stats;
     sp.prof = nullptr;
-    const int ntiles = (int)((p.I_local + SCR_TI - 1) / SCR_TI);
-    // Pass 1 over every tile with T = k-th largest clean slot maximum is rigorous (k <= 12: ~25 hits per user).  Larger k
-    // cannot get k clean slots out of 64, so pass 1 sees every `stride`-th tile only and T = kA-th largest clean maximum of
-    // that sample is a GUESS aimed at rank ~1.15 k of the catalogue; k_screen_final verifies it per user.
-    sp.stride = 1;
-    sp.kA = p.k;
-    if (p.k > 12) {
-        int sd = (int)(1.15 * p.k / 24.0 + 0.5);                // kA ~ 20-30 of the 64 slots: a 1/sd sample has rank sd(kA + 1/2)
-        sd = sd < 2 ? 2 : (sd > 8 ? 8 : sd);                    //   +- sd sqrt(kA (1 - 1/sd)) in the catalogue
-        while (sd > 1 && ntiles < 48 * sd) --sd;                // small catalogues: sample more of it
-        sp.stride = sd;
-        sp.kA = (int)((1.15 * p.k) / sd + 0.999) + 2;
-        if (sp.kA > 40) sp.kA = 40;                              // (tiny catalogues: the verification decides)
-    }
-    if (const char* se = getenv("EL_SCREEN_STRIDE")) {
-        const int v = atoi(se);
-        if (v >= 1 && v <= 16) sp.stride = v;
-    }
-    if (const char* se = getenv("EL_SCREEN_KA")) {
-        const int v = atoi(se);
-        if (v >= 1 && v <= 56) sp.kA = v;
-    }
     EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
     if (p.I_local > 0) {
         const unsigned pg = (unsigned)((p.I_local * (FP / 8) + 255) / 256);
