@@ -150,7 +150,7 @@ __device__ __forceinline__ float el_vmax3(float a, float b, float c) {
 //
 // the epilogue E of one half tile is VALU work issued while the matrix core runs the other half; the bias enters as the
 // C operand of the first MFMA of a chain (s' = bias + sum, no VALU add).  LDS: two item tiles, a ring of four bias rows.
-template <int FP, int MODE, int NW, bool PROF>
+template <int FP, int MODE, int NW, int NSUB, bool PROF>
 __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     constexpr int NT = NW * 64;
     constexpr int TI = SCR_TI;
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     constexpr int UPB = NW * 64;
     const TopkParams& p = sp.t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* tiles = smem;                                              // [2][TILEB]
-    float* Bs = reinterpret_cast<float*>(smem + 2 * TILEB);          // [4][TI] bias, -inf past the end of the catalogue
+    char* tiles = smem;                                              // [2][NSUB][TILEB]: NSUB 64-item tiles per barrier
+    float* Bs = reinterpret_cast<float*>(smem + 2 * NSUB * TILEB);   // [4][NSUB][TI] bias, -inf past the end of the catalogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
@@ -228,39 +228,50 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     // ---- item tile staging -------------------------------------------------------------------------------------------
     const int ntiles = (int)((I + TI - 1) / TI);
     const int step = (MODE == 1) ? sp.stride : 1;
-    uint4 pre[NPC];
-    float pre_bias = 0.f;
-    auto gload = [&](int tile) {
+    const int nv = (ntiles + step - 1) / step;              // tiles this pass visits: 0, step, 2 step, ...
+    const int ng = (nv + NSUB - 1) / NSUB;                  // staged groups of NSUB visited tiles
+    uint4 pre[NSUB][NPC];
+    float pre_bias[NSUB];
+    auto gload = [&](int g) {
 #pragma unroll
-        for (int q = 0; q < NPC; ++q) {
-            const int piece = q * NT + tid;
-            const int r = piece / SL, sl = piece % SL;
-            const int64_t item = (int64_t)tile * TI + r;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (piece < TI * SL && item < I) v = *reinterpret_cast<const uint4*>(sp.Gib + item * FP + sl * 8);
-            pre[q] = v;
-        }
-        if (tid < TI) {
-            const int64_t item = (int64_t)tile * TI + tid;
-            pre_bias = (item < I) ? (p.Bi ? p.Bi[item] : 0.f) : -INFINITY;
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int64_t tile = (int64_t)(g * NSUB + sub) * step;
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int piece = q * NT + tid;
+                const int r = piece / SL, sl = piece % SL;
+                const int64_t item = tile * TI + r;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (piece < TI * SL && item < I) v = *reinterpret_cast<const uint4*>(sp.Gib + item * FP + sl * 8);
+                pre[sub][q] = v;
+            }
+            pre_bias[sub] = 0.f;
+            if (tid < TI) {
+                const int64_t item = tile * TI + tid;
+                pre_bias[sub] = (item < I) ? (p.Bi ? p.Bi[item] : 0.f) : -INFINITY;
+            }
         }
     };
-    auto lstore = [&](int it) {
+    auto lstore = [&](int g) {
 #pragma unroll
-        for (int q = 0; q < NPC; ++q) {
-            const int piece = q * NT + tid;
-            const int r = piece / SL, sl = piece % SL;
-            if (piece < TI * SL)
-                *reinterpret_cast<uint4*>(tiles + (it & 1) * TILEB + r * ROWB + ((sl ^ ((r / RPB) & SWZ)) << 4)) = pre[q];
+        for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int piece = q * NT + tid;
+                const int r = piece / SL, sl = piece % SL;
+                if (piece < TI * SL)
+                    *reinterpret_cast<uint4*>(tiles + ((g & 1) * NSUB + sub) * TILEB + r * ROWB + ((sl ^ ((r / RPB) & SWZ)) << 4)) =
+                        pre[sub][q];
+            }
+            if (tid < TI) Bs[((g & 3) * NSUB + sub) * TI + tid] = pre_bias[sub];
         }
-        if (tid < TI) Bs[(it & 3) * TI + tid] = pre_bias;
     };
 
     floatx16 acc[2][2];
-    // 2 x NKS MFMAs of item row block ib of the tile staged in slot `it`
-    auto mfma_half = [&](int it, int ib) {
+    // 2 x NKS MFMAs of item row block ib of sub-tile `sub` of staged group g
+    auto mfma_half = [&](int g, int sub, int ib) {
         // bias of this lane's 16 accumulator rows: rows ib*32 + 8q + 4hi + {0..3} are r = 4q..4q+3
-        const float* bb = Bs + (it & 3) * TI + ib * 32 + 4 * hi;
+        const float* bb = Bs + ((g & 3) * NSUB + sub) * TI + ib * 32 + 4 * hi;
         floatx16 b16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
             b16[4 * q + 3] = v[3];
         }
         const int row = ib * 32 + col;
-        const char* rb = tiles + (it & 1) * TILEB + row * ROWB;
+        const char* rb = tiles + ((g & 1) * NSUB + sub) * TILEB + row * ROWB;
         const int key = (row / RPB) & SWZ;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -316,23 +327,29 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     };
 
     const unsigned long long pt_begin = PROF_T();
-    if (ntiles > 0) {
+    if (ng > 0) {
         gload(0);
         lstore(0);
         __syncthreads();
-        if (step < ntiles) gload(step);
-        mfma_half(0, 0);
+        if (1 < ng) gload(1);
+        mfma_half(0, 0, 0);
     }
-    int it = 0;
-    for (int tile = 0; tile < ntiles; tile += step, ++it) {
-        const bool has_next = tile + step < ntiles;
-        mfma_half(it, 1);
-        epi_half(tile, 0);
-        if (has_next) lstore(it + 1);
+    for (int g = 0; g < ng; ++g) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int tile = (g * NSUB + sub) * step;            // (a tile past the end is all padding: bias -inf, no effect)
+            mfma_half(g, sub, 1);
+            epi_half(tile, 0);
+            if (sub + 1 < NSUB) {
+                mfma_half(g, sub + 1, 0);
+                epi_half(tile, 1);
+            }
+        }
+        if (g + 1 < ng) lstore(g + 1);
         __syncthreads();
-        if (tile + 2 * step < ntiles) gload(tile + 2 * step);
-        mfma_half(it + 1, 0);        // (past the last tile this chews on a stale LDS slot; the result is never read)
-        epi_half(tile, 1);
+        if (g + 2 < ng) gload(g + 2);
+        mfma_half(g + 1, 0, 0);      // (past the last group this chews on a stale LDS slot; the result is never read)
+        epi_half((g * NSUB + NSUB - 1) * step, 1);
     }
 
     if (MODE == 1) {
@@ -689,8 +706,10 @@ size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, i
 
 template <int FP, int MODE, int NW, bool PROF>
 static int launch_pass(const ScreenParams& sp, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * SCR_TI * FP * 2 + 4 * SCR_TI * 4;
-    auto kern = k_screen_pass<FP, MODE, NW, PROF>;
+    constexpr int NSUB = MODE == 2 ? 2 : 1;     // pass 2: two tiles per barrier average out the record path (-8 %); pass 1 is uniform
+    constexpr size_t lds = (size_t)NSUB * (2 * SCR_TI * FP * 2 + 4 * SCR_TI * 4);
+    auto kern = k_screen_pass<FP, MODE, NW, NSUB, PROF>;
+    if (lds > 65536) EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t n_users = sp.t.u_stop - sp.t.u_start;
     EL_LAUNCH(MODE == 1 ? "k_screen_pass1" : "k_screen_pass2", kern, dim3((unsigned)((n_users + NW * 64 - 1) / (NW * 64))), dim3(NW * 64),
               lds, st, sp);
