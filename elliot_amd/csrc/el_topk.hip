@@ -35,7 +35,6 @@ __global__ __launch_bounds__(64) void k_topk_wave(TopkParams p, int cap) {
         urel = p.ulist[blockIdx.x + p.ulist_skip];
     }
     const int64_t user = p.u_start + urel;
-    if (p.only_flagged && p.only_flagged[blockIdx.x] == 0) return;
     const int F = p.F;
     const float* gu = DENSE ? nullptr : p.Gu + user * (int64_t)F;
     int64_t e0 = 0, e1 = 0, c0 = 0, c1 = 0;
@@ -143,7 +142,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
     float* Bs = As + 2 * BI * LDA;                             // [2][BI] bias
     float* Bm = Bs + 2 * BI;                                   // [2][4] per-wave max of the staged bias tile
     u64* keys = reinterpret_cast<u64*>(smem + A_FLOATS * 4);   // [UPB][CAP]
-    int* cnts = reinterpret_cast<int*>(keys + UPB * CAP);      // [UPB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
@@ -236,7 +234,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_score_topk_mfma(TopkParams p, 
     };
 
     u64* wkeys = keys + (size_t)wave * 32 * CAP;
-    int* wcnts = cnts + wave * 32;
 
     int buf = 0;
     if (ntiles > tile0) gload(tile0, 0);
@@ -566,12 +563,6 @@ static int wave_cap_for_k(int k) {
     return cap < 128 ? 128 : cap;
 }
 
-int el_topk_launch_wave(const TopkParams& p, hipStream_t st) {
-    const int cap = wave_cap_for_k(p.k);
-    EL_LAUNCH("k_topk_wave", k_topk_wave<false>, dim3((unsigned)(p.u_stop - p.u_start)), dim3(64), (size_t)cap * 8 + 16, st, p, cap);
-    EL_CHECK_LAUNCH();
-    return 0;
-}
 
 static bool mfma_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 256 && k >= 1 && k <= 40; }
 
@@ -589,7 +580,7 @@ extern "C" size_t el_score_topk_ws_bytes(int64_t n_users, int64_t I_local, int32
 template <int FP, int NIB, int CAP, int KC, int NW, int OCC>
 static int launch_mfma(const TopkParams& p, int vec, hipStream_t st) {
     constexpr int LDA = KC + 1, BI = 32 * NIB, UPB = NW * 32;
-    constexpr size_t lds = (size_t)(2 * BI * LDA + 2 * BI + 8) * 4 + (size_t)UPB * CAP * 8 + UPB * 4;
+    constexpr size_t lds = (size_t)(2 * BI * LDA + 2 * BI + 8) * 4 + (size_t)UPB * CAP * 8;
     auto kern = k_score_topk_mfma<FP, NIB, CAP, KC, NW, OCC>;
     EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t n_users = p.u_stop - p.u_start;

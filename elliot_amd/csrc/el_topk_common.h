@@ -21,7 +21,6 @@ struct TopkParams {
     const float* preds;
     int64_t ld;
     int dbg;  // experiment switches (EL_TOPK_DEBUG): 1 = skip the fused selection (GEMM-only timing)
-    const int32_t* only_flagged;  // wave kernel: if set, only users with only_flagged[user - u_start] != 0 are processed
     const int32_t* ulist;         // MFMA kernel: if set, process users u_start + ulist[skip .. min(*ulist_n, max)) instead of the range
     const int32_t* ulist_n;
     int ulist_skip, ulist_max;    // (ulist_max == 0: no upper limit)
@@ -31,8 +30,6 @@ struct TopkParams {
     int64_t part_stride;
 };
 
-// defined in el_topk.hip: wave-per-user kernel over [u_start, u_stop) (optionally only flagged users)
-int el_topk_launch_wave(const TopkParams& p, hipStream_t st);
 // defined in el_topk.hip: fp32 MFMA kernel (must be eligible: F <= 256, k <= 40, no candidate list); honours p.ulist
 int el_topk_launch_mfma(const TopkParams& p, hipStream_t st);
 // defined in el_topk.hip: exact top-k of the users in p.ulist (device list, *p.ulist_n entries), parallel over users AND
