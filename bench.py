@@ -51,6 +51,8 @@ def parse():
                     help="N > 1: how user-row gradients travel (parallel.pick_exchange)")
     ap.add_argument("--topk-shard", default="user", choices=["user", "item"],
                     help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial top-k")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="draw the triplets of step t+1 on a side stream during step t (measured: no gain, the step is HBM-bound)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-topk-users", type=int, default=640)
@@ -75,6 +77,51 @@ def dist_setup(args):
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     return world, rank, local
+
+
+class PrefetchSampler:
+    """BPR triplets of step t+1 are drawn on a side stream while step t trains: the sampler (custom_sampler.py:31-46) does not
+    depend on the model, so a training loop can always run it one batch ahead.  Two triplet buffers, events both ways."""
+
+    def __init__(self, ctx, pos, B, seed, enabled=True):
+        dev = ctx.device
+        self.ctx, self.pos, self.B, self.seed, self.enabled = ctx, pos, B, seed, enabled
+        self.bufs = [tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3)) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [None, None]
+        self.cur, self.ctr = 0, 0
+        if enabled:
+            self._issue(0)
+
+    def _draw(self, b):
+        ops.bpr_sample(self.ctx, self.pos, self.B, seed=self.seed, first_sample=self.ctr, out=self.bufs[b])
+        self.ctr += self.B
+
+    def _issue(self, b):
+        self.side.wait_stream(torch.cuda.current_stream())           # (first use / anything the caller queued before)
+        with torch.cuda.stream(self.side):
+            if self.free[b] is not None:
+                self.side.wait_event(self.free[b])                    # the training step that read this buffer is done
+            self._draw(b)
+            self.ready[b].record(self.side)
+
+    def next(self):
+        """Triplets of this step (valid on the current stream)."""
+        b = self.cur
+        if not self.enabled:
+            self._draw(b)
+            return self.bufs[b], b
+        torch.cuda.current_stream().wait_event(self.ready[b])
+        self.cur ^= 1
+        self._issue(self.cur)                                         # next batch: overlaps this step's kernels
+        return self.bufs[b], b
+
+    def release(self, b):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.free[b] = ev
 
 
 def barrier(world):
@@ -151,7 +198,6 @@ def main():
     # item shard of this rank (north_star: tables shard by item; N=1 -> the whole catalogue)
     lo, hi = parallel.item_range(I, rank, world)
     lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
-    trip = tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3))
     sample_ctr = [0]
     finish_train = None
     exchange_used = [None]
@@ -160,10 +206,12 @@ def main():
         st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
         pos_train = pos
 
+        sampler = PrefetchSampler(ctx, pos, B, 42, enabled=args.prefetch)
+
         def train_step():
-            ops.bpr_sample(ctx, pos, B, seed=42, first_sample=sample_ctr[0], out=trip)
-            sample_ctr[0] += B
-            st.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b, algo=args.train_algo)
+            t, b = sampler.next()
+            st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
+            sampler.release(b)
 
         pop_loss = st.pop_loss
     else:
@@ -182,10 +230,12 @@ def main():
             trainer = parallel.ShardedBprmf(be, coll)
         st = be.state
 
+        sampler = PrefetchSampler(ctx, pos_train, B, 42 + rank, enabled=args.prefetch)
+
         def train_step():
-            ops.bpr_sample(ctx, pos_train, B, seed=42 + rank, first_sample=sample_ctr[0], out=trip)
-            sample_ctr[0] += B
-            trainer.train_step(trip[0], trip[1], trip[2], lr, l_w, l_b)
+            t, b = sampler.next()
+            trainer.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+            sampler.release(b)
 
         pop_loss = trainer.pop_loss
         finish_train = getattr(trainer, "finish", None)
