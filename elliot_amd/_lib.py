@@ -124,6 +124,8 @@ PROTOTYPES = {
     "el_pointwise_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
                                       C.c_int64, _i32p, _i32p, _f32p]),
     "el_nmf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, C.c_int64, _f32p]),
+    "el_nmf_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, _f32p, C.c_int64, C.c_int64, _f64p]),
+    "el_nmf_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_int32, C.c_float]),
     "el_nmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, _f32p, C.c_int64,
                                     C.c_int32, C.c_float, _f64p]),
     "el_dense_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

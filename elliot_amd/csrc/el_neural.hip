@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_nmf_gather(el_nmf_state st, const int32
 // ---- head: logit, probability, BCE, d logit, head gradients --------------------------------------------------
 // one wave per sample.  mode 0: forward only (out_prob[b] = p).  mode 1: training.
 __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* __restrict__ label, int64_t n, int mode,
-                                                  float* out_prob, double* loss_out) {
+                                                  float* out_prob, double* loss_out, int64_t n_div) {
     __shared__ float wsum[4];
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
     if (active) {
         const float t = label[b];
         const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);          // keras backend epsilon clipping
-        if (lane == 0) myloss = -(t * logf(pc) + (1.0f - t) * logf(1.0f - pc)) / (float)n;
+        if (lane == 0) myloss = -(t * logf(pc) + (1.0f - t) * logf(1.0f - pc)) / (float)n_div;
         // d/dlogit: zero where the clip is active
-        if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n;
+        if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n_div;
         if (lane == 0) st.dlogit[b] = dlogit;
         for (int f = lane; f < F; f += 64) atomicAdd(st.ghw + f, dlogit * st.MF[b * F + f]);
         if (st.use_mlp) {
@@ -273,24 +273,21 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st,
     EL_REQUIRE(u && i && out_prob, "el_nmf_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
-    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, nullptr, n, 0, out_prob, nullptr);
+    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, (const float*)nullptr, n, 0, out_prob, (double*)nullptr, n);
     EL_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
-                                 const float* label, int64_t n, int32_t step, float lr_t, double* loss_out) {
-    if (int rc = el_bind(ctx)) return rc;
-    if (n == 0) return 0;
-    if (int rc = nmf_check(st, n, true)) return rc;
-    EL_REQUIRE(u && i && label && loss_out && step >= 1, "el_nmf_train_step: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+// forward, BinaryCrossentropy (mean over n_div samples: n_div = n, or the global batch when several ranks share a step),
+// backward: every gradient buffer of the state is complete on exit
+static int nmf_grads(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, const float* label,
+                     int64_t n, int64_t n_div, double* loss_out) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
     EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
     if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
-    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out);
+    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out, n_div);
     if (st->use_mlp) {
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
@@ -306,7 +303,14 @@ extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* 
         }
     }
     EL_LAUNCH("k_nmf_scatter", k_nmf_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
-    // optimiser
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// Keras Adam on every variable (dense apply; the embedding gradients are dense accumulators, zero again on exit)
+static int nmf_apply(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, float lr_t) {
+    const int F = st->use_mf ? st->F : 0;
+    const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     const int64_t rows[4] = {st->U, st->I, st->U, st->I};
     const int64_t dims[4] = {st->F, st->F, st->E, st->E};
@@ -333,4 +337,29 @@ extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* 
                   lr_t, b1, b2, eps, 0);
     EL_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                                 const float* label, int64_t n, int32_t step, float lr_t, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (n == 0) return 0;
+    if (int rc = nmf_check(st, n, true)) return rc;
+    EL_REQUIRE(u && i && label && loss_out && step >= 1, "el_nmf_train_step: bad arguments");
+    if (int rc = nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n, loss_out)) return rc;
+    return nmf_apply(ctx, (hipStream_t)stream, st, lr_t);
+}
+
+extern "C" int el_nmf_grads(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                            const float* label, int64_t n, int64_t n_global, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = nmf_check(st, n, true)) return rc;
+    EL_REQUIRE(n >= 1 && n_global >= n && u && i && label && loss_out, "el_nmf_grads: bad arguments");
+    return nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n_global, loss_out);
+}
+
+extern "C" int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step, float lr_t) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = nmf_check(st, 1, true)) return rc;
+    EL_REQUIRE(step >= 1, "el_nmf_apply: step >= 1");
+    return nmf_apply(ctx, (hipStream_t)stream, st, lr_t);
 }

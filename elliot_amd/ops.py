@@ -656,6 +656,27 @@ class NmfDeviceState:
                                              float(adam_lr_t(lr, self.step)), _ptr(self.loss, torch.float64)),
               "el_nmf_train_step")
 
+    def grads(self, u, i, label, n_global=None):
+        """Forward + loss + backward only (multi-GPU: the BCE mean runs over n_global samples); gradients stay in the
+        state's buffers (replicated_grads() lists the ones a data-parallel caller has to all-reduce)."""
+        n = u.numel()
+        check(self.ctx.lib.el_nmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                        _ptr(i, torch.int32), _ptr(label, torch.float32), int(n),
+                                        int(n if n_global is None else n_global), _ptr(self.loss, torch.float64)), "el_nmf_grads")
+
+    def apply(self, lr):
+        self.step += 1
+        check(self.ctx.lib.el_nmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self.step),
+                                        float(adam_lr_t(lr, self.step))), "el_nmf_apply")
+
+    def replicated_grads(self):
+        """Gradient tensors of the variables every rank holds a full copy of: user tables, Dense layers, head."""
+        out = [g for t, g in zip((0, 2), (self.gtab[0], self.gtab[2])) if g is not None]
+        out += list(self.gW) + list(self.gb) + [self.ghw]
+        if self.head_bias:
+            out.append(self.ghb)
+        return out
+
     def forward(self, u, i, out=None):
         n = u.numel()
         if out is None:

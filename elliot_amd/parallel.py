@@ -308,3 +308,35 @@ class ShardedBprmf:
         tot = self.coll.all_reduce_sum(t.clone())
         t.zero_()
         return float(tot.item())
+
+
+# ------------------------------------------------------------------------------------------------------
+# NeuMF / GMF: data parallel over samples, item tables sharded, RCCL all-reduce of the shared gradients
+# ------------------------------------------------------------------------------------------------------
+class ShardedNmf:
+    """One NeuMF / GMF step over G ranks.  Rank r owns the item rows [lo_r, hi_r) of both item tables (+ their Adam
+    state) and draws its n samples with the item inside its shard; user tables, Dense layers and the head are replicated.
+    Per step: el_nmf_grads with the BinaryCrossentropy mean over the GLOBAL batch (sum of all ranks' n) -> RCCL
+    all-reduce (sum) of the gradients of the replicated variables -> el_nmf_apply (Keras Adam) on every rank: G ranks x n
+    samples are exactly one reference-semantics step on the concatenated batch, and the replicas stay identical because
+    every rank applies the same reduced gradients.  `backend` = ops.NmfDeviceState built from weights whose "Imf" /
+    "Imlp" hold only the local shard (item ids passed in are shard-local), or a stand-in with the same four methods."""
+
+    def __init__(self, backend, coll=None):
+        self.backend = backend
+        self.coll = coll or _Collectives()
+
+    def train_step(self, u, i_local, label, lr, n_global=None):
+        be, coll = self.backend, self.coll
+        if n_global is None:
+            n_global = coll.world * int(u.shape[0])
+        be.grads(u, i_local, label, n_global)
+        for g in be.replicated_grads():
+            coll.all_reduce_sum(g)
+        be.apply(lr)
+
+    def pop_loss(self):
+        t = self.backend.loss
+        tot = self.coll.all_reduce_sum(t.clone())
+        t.zero_()
+        return float(tot.item())

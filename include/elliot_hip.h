@@ -367,6 +367,15 @@ int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int3
 int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
                       const float* label, int64_t n, int32_t step, float lr_t, double* loss_out);
 
+/* Multi-GPU form of the step (data parallel over samples, item tables sharded): el_nmf_grads = forward +
+ * loss + backward with the BinaryCrossentropy mean taken over n_global samples (the sum of all ranks' n), every gradient
+ * buffer of the state complete on exit; the caller all-reduces the gradients of the replicated variables (user tables,
+ * Dense layers, head) over RCCL; el_nmf_apply = Keras Adam on every variable.  grads + apply with n_global = n is
+ * el_nmf_train_step.                                                                                            */
+int el_nmf_grads(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+                 const float* label, int64_t n, int64_t n_global, double* loss_out);
+int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step, float lr_t);
+
 /* ---- accuracy metrics from the top-k index tensor --------------------------------------
  * Replaces: get_single_recommendation's dict building (recommender_utils_mixin.py:84-88) + Evaluator.eval
  * and its metric classes (evaluation/evaluator.py:117-147; metrics/accuracy/ndcg/ndcg.py:68-125;

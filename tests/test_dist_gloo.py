@@ -255,3 +255,96 @@ def test_gather_item_table_world2_gloo():
     out = mgr.dict()
     mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+class NumpyNmfBackend:
+    """Stand-in for ops.NmfDeviceState in parallel.ShardedNmf: local item shard, replicated user tables / MLP / head."""
+
+    def __init__(self, w, lr):
+        from oracle import neumf as on
+        self.on = on
+        self.orc = on.NeuMFOracle(w, lr)
+        self.loss = torch.zeros(1, dtype=torch.float64)
+        self.g = None
+
+    def grads(self, u, i, label, n_global):
+        on, w = self.on, self.orc.w
+        u, i, y = u.numpy().astype(np.int64), i.numpy().astype(np.int64), label.numpy()
+        c = on.forward(w, u, i)
+        scale = np.float32(len(y) / n_global)
+        self.loss += on.bce(c["p"], y) * float(scale)
+        g = on.gradients(w, c, u, i, y)
+        self.g = {k: ([torch.from_numpy((x * scale).astype(np.float32)) for x in v] if isinstance(v, list)
+                      else torch.from_numpy((v * scale).astype(np.float32))) for k, v in g.items()}
+
+    def replicated_grads(self):
+        out = [self.g[k] for k in ("Umf", "Umlp") if k in self.g]
+        out += list(self.g.get("W", [])) + list(self.g.get("b", [])) + [self.g["hw"]]
+        if "hb" in self.g:
+            out.append(self.g["hb"])
+        return out
+
+    def apply(self, lr):
+        o = self.orc
+        o.t += 1
+        from oracle.bprmf_batch import adam_tf_sparse_apply
+        npg = lambda t: t.numpy()
+        for k in ("Umf", "Imf", "Umlp", "Imlp"):
+            if k in o.w:
+                adam_tf_sparse_apply(o.w[k], o.m[k], o.v[k], npg(self.g[k]), o.lr, o.t)
+        if "W" in o.w:
+            for l in range(len(o.w["W"])):
+                o._dense(o.w["W"][l], o.m["W"][l], o.v["W"][l], npg(self.g["W"][l]))
+                o._dense(o.w["b"][l], o.m["b"][l], o.v["b"][l], npg(self.g["b"][l]))
+        o._dense(o.w["hw"], o.m["hw"], o.v["hw"], npg(self.g["hw"]))
+        if "hb" in o.w:
+            o._dense(o.w["hb"], o.m["hb"], o.v["hb"], npg(self.g["hb"]))
+
+
+def _nmf_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import neumf as on
+        U, I, F, n = 40, 30, 8, 64
+        w = on.init_neumf(U, I, F, seed=3)
+        lo, hi = parallel.item_range(I, rank, world)
+        wl = {k: ([x.copy() for x in v] if isinstance(v, list) else v.copy()) for k, v in w.items()}
+        wl["Imf"], wl["Imlp"] = w["Imf"][lo:hi].copy(), w["Imlp"][lo:hi].copy()
+        be = NumpyNmfBackend(wl, 0.01)
+        tr = parallel.ShardedNmf(be, parallel._Collectives())
+        ref = on.NeuMFOracle(w, 0.01)
+        for step in range(3):
+            batches = []
+            for r in range(world):
+                brs = np.random.RandomState(300 + 10 * step + r)
+                l, h = parallel.item_range(I, r, world)
+                batches.append((brs.randint(0, U, n), brs.randint(l, h, n), brs.randint(0, 2, n).astype(np.float32)))
+            u, i, y = batches[rank]
+            tr.train_step(torch.from_numpy(u.astype(np.int32)), torch.from_numpy((i - lo).astype(np.int32)), torch.from_numpy(y), 0.01)
+            loss = tr.pop_loss()
+            cu, ci, cy = (np.concatenate([b[x] for b in batches]) for x in range(3))
+            ref_loss = ref.train_step(cu, ci, cy)
+            assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+            o = be.orc.w
+            assert np.abs(o["Umf"] - ref.w["Umf"]).max() < 3e-6 and np.abs(o["Umlp"] - ref.w["Umlp"]).max() < 3e-6
+            assert np.abs(o["Imf"] - ref.w["Imf"][lo:hi]).max() < 3e-6 and np.abs(o["Imlp"] - ref.w["Imlp"][lo:hi]).max() < 3e-6
+            for a, b in zip(o["W"] + o["b"] + [o["hw"]], ref.w["W"] + ref.w["b"] + [ref.w["hw"]]):
+                assert np.abs(a - b).max() < 3e-6
+        t = torch.from_numpy(be.orc.w["Umlp"].copy())
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_neumf_sharded_step_world2_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nmf_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}

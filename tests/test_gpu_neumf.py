@@ -77,3 +77,47 @@ def test_pointwise_sampler_invariants(ctx):
     assert cnt.std() < 1.25 * np.sqrt(n / U)
     u2, i2, y2 = (cpu(t) for t in ops.pointwise_sample(ctx, pos, 100, seed=42, first_sample=500))
     assert np.array_equal(u2, u[500:600]) and np.array_equal(i2, i[500:600]) and np.array_equal(y2, y[500:600])
+
+
+def test_neumf_item_sharded_hip_path_equals_concatenated_batch(ctx):
+    """Two virtual ranks on one GPU (the all-reduce is emulated with torch adds): el_nmf_grads with the global-batch
+    mean + reduced gradients of the replicated variables + el_nmf_apply == ONE step on the concatenated batch."""
+    from elliot_amd import parallel
+    U, I, F, n, G, lr = 120, 90, 16, 400, 2, 0.002
+    w = on.init_neumf(U, I, F, 11)
+    d = ctx.device
+    sts, rng = [], []
+    for r in range(G):
+        lo, hi = parallel.item_range(I, r, G)
+        rng.append((lo, hi))
+        wl = {k: ([x.copy() for x in v] if isinstance(v, list) else v.copy()) for k, v in w.items()}
+        wl["Imf"], wl["Imlp"] = w["Imf"][lo:hi].copy(), w["Imlp"][lo:hi].copy()
+        sts.append(ops.NmfDeviceState(ctx, wl, max_batch=n))
+    orc = on.NeuMFOracle(w, lr)
+    rs = np.random.RandomState(5)
+    for step in range(3):
+        batches = [(rs.randint(0, U, n), rs.randint(lo, hi, n), rs.randint(0, 2, n).astype(np.float32)) for lo, hi in rng]
+        for st, (lo, hi), (u, i, y) in zip(sts, rng, batches):
+            st.grads(torch.from_numpy(u.astype(np.int32)).to(d), torch.from_numpy((i - lo).astype(np.int32)).to(d),
+                     torch.from_numpy(y).to(d), n_global=G * n)
+        lists = [st.replicated_grads() for st in sts]
+        for gs in zip(*lists):                                   # the all-reduce
+            tot = gs[0] + gs[1]
+            for g in gs:
+                g.copy_(tot)
+        loss = 0.0
+        for st in sts:
+            st.apply(lr)
+            loss += st.pop_loss()
+        cu, ci, cy = (np.concatenate([b[x] for b in batches]) for x in range(3))
+        exp = orc.train_step(cu, ci, cy)
+        assert abs(loss - exp) <= 1e-4 * max(abs(exp), 1e-3), (step, loss, exp)
+        w0, w1 = sts[0].weights(), sts[1].weights()
+        for k in ("Umf", "Umlp", "hw"):
+            assert np.array_equal(w0[k], w1[k]), k                 # replicas identical
+            err = np.abs(w0[k] - orc.w[k])
+            assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (step, k, float(err.max()))
+        for st, (lo, hi), wr in zip(sts, rng, (w0, w1)):
+            for k in ("Imf", "Imlp"):
+                err = np.abs(wr[k] - orc.w[k][lo:hi])
+                assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (step, k, float(err.max()))
