@@ -119,7 +119,8 @@ struct ScreenParams {
     int32_t* cnt;                // [n_users] hits appended in pass 2
     int32_t* ovf;                // [n_users] 1 = recompute with the exact wave kernel
     u64* lists;                  // user u: [64 * (u - u_start) + indptr[u] - indptr[u_start], +64 + nnz_u)
-    int64_t list_cap;            // entries in `lists`
+    float* lsc;                  // per record: the lane's best s' (exact for the record's item when its mask has one bit)
+    int64_t list_cap;            // entries in `lists` / `lsc`
     int32_t* ulist;              // [n_users] flagged users (relative ids), filled by k_screen_flags
     int32_t* ulist_n;            // [1]
     float* Tg;                   // [n_users] the threshold guess T (thr = T - 2E); k_screen_final verifies it
@@ -317,8 +318,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
                     const bool pend = hm != 0u;
                     const u32 pv = el_partner32(pend ? 1u : 0u, hi);
                     const int pos = ucnt[ub] + (hi ? (int)pv : 0);
-                    if (pend && pos < lcap[ub])
+                    if (pend && pos < lcap[ub]) {
                         sp.lists[lbase[ub] + pos] = ((u64)(u32)tile << 18) | ((u64)ib << 17) | ((u64)hi << 16) | (u64)hm;
+                        sp.lsc[lbase[ub] + pos] = m;
+                    }
                     ucnt[ub] += (pend ? 1 : 0) + (int)pv;
                     if (PROF) pn_hits += __popcll(__ballot(pend));
                 }
@@ -557,17 +560,20 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
         zoff = e0 - p.excl_indptr[p.u_start];
     }
     const u64* list = sp.lists + ur * SCR_SURV + zoff;
+    const float* lsc = sp.lsc + ur * SCR_SURV + zoff;
     for (int t = lane; t < SCR_SURV; t += 64) surv[t] = 0ull;
     const int nx = (int)(e1 - e0);
     const bool xl = nx <= XC;
     if (xl)
         for (int t = lane; t < nx; t += 64) xrow[t] = p.excl_indices[e0 + t];
     el_wave_lds_sync();
-    int ns = 0;                                      // surv[] holds ITEM ids (low 32 bits) from here on
+    // ---- records -> unmasked candidates, keyed by s' (known exactly when the record holds one item, else +inf) ----------
+    int ns = 0, nunk = 0;
     for (int base = 0; base < n; base += 64) {
         const int t = base + lane;
         const u64 rec = (t < n) ? list[t] : 0ull;
         u32 hm = (u32)(rec & 0xffffu);
+        const float sc = (t < n && __popc(hm) == 1) ? lsc[t] : INFINITY;
         const int64_t row0 = (int64_t)(rec >> 18) * SCR_TI + (int64_t)((rec >> 17) & 1u) * 32 + 4 * (int)((rec >> 16) & 1u);
         while (__ballot(hm != 0u) != 0ull) {
             bool keep = false;
@@ -592,14 +598,29 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
             }
             const u64 b = __ballot(keep);
             const int pos = ns + __popcll(b & ((1ull << lane) - 1ull));
-            if (keep && pos < SCR_SURV) surv[pos] = (u64)(u32)g;
+            if (keep && pos < SCR_SURV) surv[pos] = el_make_key(sc, g);
             ns += __popcll(b);
+            nunk += __popcll(__ballot(keep && !(sc < INFINITY)));
         }
     }
     el_wave_lds_sync();
     if (ns > SCR_SURV || ns < p.k) {                 // window overflow / cannot happen unless flagged: exact fallback
         if (lane == 0) sp.ovf[ur] = 1;
         return;
+    }
+    // ---- second-level screen on s': with t' = the k-th largest KNOWN s' of these unmasked candidates, every member of the
+    // exact top-k has s' >= t' - 2E (same lemma as for T); candidates of unknown s' (+inf) sort first and always stay
+    {
+        int n2 = 64;
+        while (n2 < ns) n2 <<= 1;
+        el_wave_bitonic_desc(surv, n2, lane);
+        if (nunk + p.k <= ns) {
+            const float cut = el_key_score(surv[nunk + p.k - 1]) - 2.0f * sp.Eu[ur];
+            int keep = 0;
+            for (int t = lane; t < ns; t += 64) keep += (el_key_score(surv[t]) >= cut) ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) keep += __shfl_xor(keep, o, 64);
+            ns = keep;                               // sorted: the kept candidates are a prefix
+        }
     }
     const bool vec4 = (p.F % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.Gi) & 15) == 0);
     u64 nk[SCR_SURV / 64];
@@ -608,7 +629,7 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
         const int t = q * 64 + lane;
         nk[q] = 0ull;
         if (q * 64 < ns && t < ns) {
-            const int32_t g = (int32_t)(u32)surv[t];
+            const int32_t g = el_key_item(surv[t]);
             const float s = el_exact_score(p, gu_s, (int64_t)g - p.item_offset, vec4);
             if (s == s) nk[q] = el_make_key(s, g);
         }
@@ -701,7 +722,7 @@ size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, i
     const int FP = screen_fp(F);
     if (excl_nnz < 0) excl_nnz = 0;
     return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 6 * a256((size_t)n_users * 4) +
-           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * screen_policy(k, I_local).surv + (size_t)excl_nnz) * 8);
+           a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * screen_policy(k, I_local).surv + (size_t)excl_nnz) * 12);
 }
 
 template <int FP, int MODE, int NW, bool PROF>
@@ -789,8 +810,9 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     void* fb_scratch = base;
     const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.I_local, p.k);
     base += a256(fb_bytes);
+    sp.list_cap = (int64_t)(((char*)ws + ws_bytes - base) / 12) & ~(int64_t)31;   // whatever the caller provisioned for surv*U + nnz
     sp.lists = (u64*)base;
-    sp.list_cap = (int64_t)(((char*)ws + ws_bytes - base) / 8);      // whatever the caller provisioned for 64*U + nnz
+    sp.lsc = (float*)(base + (size_t)sp.list_cap * 8);
     sp.Gib = gib;
     sp.stats = stats;
     sp.prof = nullptr;
