@@ -247,17 +247,22 @@ def main():
 
     sharded = world > 1 or args.force_sharded
     topk_by_user = sharded and args.topk_shard == "user"
-    if topk_by_user:
-        # users are independent units: each rank scores ITS blocks of users against the whole catalogue, no collective on
-        # the data path.  The item table (sharded for training) is all-gathered once per evaluation (I F 4 bytes).
-        if finish_train:
-            finish_train()
-        Gi_full, Bi_full = parallel.gather_item_table(coll, st.Gi, st.Bi, I)
+    full_items = {}
 
+    def prepare_topk():
+        """After training, before the evaluation: with user-sharded top-k the item table (sharded for training) is
+        all-gathered ONCE per evaluation (I F 4 bytes); the per-block work then has no collective."""
+        if topk_by_user:
+            if finish_train:
+                finish_train()
+            full_items["Gi"], full_items["Bi"] = parallel.gather_item_table(coll, st.Gi, st.Bi, I)
+
+    if topk_by_user:
+        # users are independent units: each rank scores ITS blocks of users against the whole catalogue
         def topk_step():
             s = ((blk[0] * world + rank) % n_blocks) * Ub
             blk[0] += 1
-            ops.score_topk(ctx, st.Gu, Gi_full, Bi_full, s, s + Ub, k, excl=pos, algo=args.topk_algo)
+            ops.score_topk(ctx, st.Gu, full_items["Gi"], full_items["Bi"], s, s + Ub, k, excl=pos, algo=args.topk_algo)
     else:
         def topk_step():
             s = (blk[0] % n_blocks) * Ub
@@ -285,6 +290,7 @@ def main():
     K, W = args.steps, args.warmup
     dt_train, rep_train = timed(train_step, W, K, finish_train)
     loss = pop_loss()
+    prepare_topk()
     dt_topk, rep_topk = timed(topk_step, W, K)
 
     # ---- accuracy metrics from the index tensor: one block of users, synthetic held-out set -------------
