@@ -1,0 +1,145 @@
+"""Full BASELINE size (configs[1]: 1 M users x 100 K items, d = 128, ~78 M interactions, B = 1 M triplets) through
+size-independent properties -- the oracle cannot be run at this size, the properties can:
+
+  top-k     two independent kernels (bf16-screened / fp32 MFMA) agree bit for bit on a whole 131 072-user block; the
+            lists are ordered (score desc, item asc), exclude every train item, and their scores are the exact fp32
+            fma chain (C oracle on a sample of users); item shards + merge == one shard; the call is idempotent
+  sampler   every triplet is valid (i in pos(u), j not in pos(u)), users ~ uniform
+  training  the batch loss equals an independent fp64 evaluation of BPRMF_batch_model.py:65-75 on the same triplets
+            (1e-4, the north_star tolerance); at Adam step 1 an untouched row does not move and a touched entry moves
+            by at most lr (|m/(sqrt(v)+eps)| <= 1 with m = (1-b1) g, v = (1-b2) g^2)
+  metrics   sums over two different block partitions of the users agree (checksum of checksums)
+"""
+import numpy as np
+import pytest
+import torch
+
+from elliot_amd import ops
+from elliot_amd.synthetic import zipf_csr_device
+from oracle import cref
+from tests.gpu_util import cpu
+
+pytestmark = pytest.mark.gpu
+
+U, I, F, B, K, UB = 1_000_000, 100_000, 128, 1 << 20, 10, 131072
+
+
+@pytest.fixture(scope="module")
+def world(ctx):
+    dev = ctx.device
+    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+    pos = ops.DeviceCSR.from_tensors(indptr, indices, I)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * (6.0 / (U + F)) ** 0.5
+    Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * (6.0 / (I + F)) ** 0.5
+    Bi = (torch.rand(I, generator=g, device=dev) - 0.5) * 0.01
+    st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    return {"pos": pos, "st": st}
+
+
+def _row_members(pos, users, items):
+    """items[r, c] in row users[r] of the CSR?  (device, vectorised binary search)"""
+    lo = pos.indptr[users.long()][:, None].expand_as(items).clone()
+    hi = pos.indptr[users.long() + 1][:, None].expand_as(items).clone()
+    it = items.to(torch.int32)
+    for _ in range(12):                               # rows have <= 2000 entries
+        mid = (lo + hi) // 2
+        v = pos.indices[mid.clamp(max=pos.indices.numel() - 1)]
+        go = (v < it) & (lo < hi)
+        lo = torch.where(go, mid + 1, lo)
+        hi = torch.where(go | (lo >= hi), hi, mid)
+    found = (lo < pos.indptr[users.long() + 1][:, None]) & (pos.indices[lo.clamp(max=pos.indices.numel() - 1)] == it)
+    return found
+
+
+def test_fullsize_sampler_and_train_step_properties(ctx, world):
+    pos, st = world["pos"], world["st"]
+    u, i, j = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=0)
+    assert int(u.min()) >= 0 and int(u.max()) < U and int(j.min()) >= 0 and int(j.max()) < I
+    assert bool(_row_members(pos, u, i[:, None]).all()), "a positive is not a train item of its user"
+    assert not bool(_row_members(pos, u, j[:, None]).any()), "a negative is a train item of its user"
+    cnt = torch.bincount(u.long(), minlength=U).double()
+    assert abs(float(cnt.mean()) - B / U) < 1e-9 and float(cnt.max()) < 25         # uniform over users (custom_sampler.py:32)
+
+    lr, l_w, l_b = 0.001, 0.1, 0.001
+    Gu0, Gi0, Bi0 = st.Gu.clone(), st.Gi.clone(), st.Bi.clone()
+    st.train_step(u, i, j, lr, l_w, l_b)
+    loss = st.pop_loss()
+    gu, gi, gj = Gu0[u.long()].double(), Gi0[i.long()].double(), Gi0[j.long()].double()
+    bi, bj = Bi0[i.long()].double(), Bi0[j.long()].double()
+    d = (bi + (gu * gi).sum(1)) - (bj + (gu * gj).sum(1))
+    ref = (torch.nn.functional.softplus(-d.clamp(-80.0, 1e8)).sum()
+           + l_w * 0.5 * ((gu * gu).sum() + (gi * gi).sum() + (gj * gj).sum())
+           + l_b * 0.5 * (bi * bi).sum() + (l_b / 10) * 0.5 * (bj * bj).sum())
+    assert abs(loss - float(ref)) <= 1e-4 * abs(float(ref)), (loss, float(ref))
+    # Adam step 1
+    touched_u = torch.zeros(U, dtype=torch.bool, device=ctx.device)
+    touched_u[u.long()] = True
+    du = (st.Gu - Gu0).abs()
+    assert float(du[~touched_u].max()) == 0.0
+    assert float(du.max()) <= lr * (1 + 1e-3)
+    assert float(du[touched_u].max()) > 0.5 * lr
+    touched_i = torch.zeros(I, dtype=torch.bool, device=ctx.device)
+    touched_i[i.long()] = True
+    touched_i[j.long()] = True
+    di = (st.Gi - Gi0).abs()
+    assert float(di.max()) <= lr * (1 + 1e-3)
+    if bool((~touched_i).any()):
+        assert float(di[~touched_i].max()) == 0.0
+    assert not bool(st.gGu.any()) and not bool(st.gGi.any())                      # accumulators zero on exit
+    world["trained"] = True
+
+
+def test_fullsize_topk_properties(ctx, world):
+    pos, st = world["pos"], world["st"]
+    s0 = 3 * UB
+    i_scr, v_scr = ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s0, s0 + UB, K, excl=pos, algo="screen")
+    i_mf, v_mf = ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s0, s0 + UB, K, excl=pos, algo="mfma")
+    torch.cuda.synchronize()
+    assert torch.equal(i_scr, i_mf), "screened and fp32 MFMA kernels disagree on the index lists"
+    assert torch.equal(v_scr.view(torch.int32), v_mf.view(torch.int32)), "screened and fp32 MFMA kernels disagree on the score bits"
+    # ordering (score desc, item asc), range, exclusions
+    assert bool((v_scr[:, :-1] >= v_scr[:, 1:]).all())
+    tie = v_scr[:, :-1] == v_scr[:, 1:]
+    assert bool((i_scr[:, :-1][tie] < i_scr[:, 1:][tie]).all())
+    assert int(i_scr.min()) >= 0 and int(i_scr.max()) < I
+    users = torch.arange(s0, s0 + UB, device=ctx.device, dtype=torch.int32)
+    assert not bool(_row_members(pos, users, i_scr).any()), "a train item was recommended"
+    # scores are the exact chain: C oracle on a sample of users (full catalogue, the oracle's own top-k)
+    sample = np.arange(s0, s0 + 96)
+    ip = cpu(pos.indptr[s0:s0 + 97])
+    ix = cpu(pos.indices[int(ip[0]):int(ip[-1])])
+    ei, ev = cref.score_topk_f32(cpu(st.Gu[s0:s0 + 96]), cpu(st.Gi), cpu(st.Bi), 0, 96, K, excl=(ip - ip[0], ix))
+    assert np.array_equal(cpu(i_scr[:96]), ei) and np.array_equal(cpu(v_scr[:96]), ev), sample[:3]
+    # idempotence
+    i2, v2 = ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s0, s0 + UB, K, excl=pos, algo="screen")
+    assert torch.equal(i2, i_scr) and torch.equal(v2.view(torch.int32), v_scr.view(torch.int32))
+    # item shards + merge == one shard (a quarter of the block is enough)
+    n = UB // 4
+    parts_i, parts_v = [], []
+    for lo, hi in ((0, 37_000), (37_000, I)):
+        pi, pv = ops.score_topk(ctx, st.Gu, st.Gi[lo:hi].contiguous(), st.Bi[lo:hi].contiguous(), s0, s0 + n, K, excl=pos,
+                                item_offset=lo, algo="auto")
+        parts_i.append(pi)
+        parts_v.append(pv)
+    mi, mv = ops.topk_merge(ctx, torch.stack(parts_i), torch.stack(parts_v))
+    assert torch.equal(mi, i_scr[:n]) and torch.equal(mv.view(torch.int32), v_scr[:n].view(torch.int32))
+    world["idx"] = i_scr
+    world["s0"] = s0
+
+
+def test_fullsize_metrics_checksum(ctx, world):
+    if "idx" not in world:
+        pytest.skip("needs the top-k block of the previous test")
+    idx, s0 = world["idx"], world["s0"]
+    tip, tix = zipf_csr_device(U, I, ctx.device, mean_log=2.0, sigma_log=0.7, dmin=1, dmax=200, seed=99)
+    held = ops.DeviceTestSet.from_tensors(tip, tix, None)
+    whole = cpu(ops.rec_metrics(ctx, idx, held, 0.0, K, u_start=s0))
+    acc = torch.zeros(8, dtype=torch.float64, device=ctx.device)
+    for a in range(0, UB, 30_000):                                           # ragged partition
+        b = min(UB, a + 30_000)
+        ops.rec_metrics(ctx, idx[a:b].contiguous(), held, 0.0, K, u_start=s0 + a, sums=acc)
+    torch.cuda.synchronize()
+    assert np.allclose(whole, cpu(acc), rtol=1e-12, atol=0)
+    assert whole[7] > 0.5 * UB and np.all(whole[:7] >= 0) and np.all(whole[:7] <= whole[7])
