@@ -1,64 +1,51 @@
-"""BPRMF plugin -- drop-in for elliot/recommender/latent_factor_models/BPRMF/BPRMF.py:19-129 (per-sample SGD,
-fp64).  Same YAML keys and defaults (:63-76); the reference forces batch_size = 1 (:80) and calls train_step
-`transactions` times per epoch -- here the epoch's triplets are drawn in one device call and applied in
-dependency levels, which yields the same parameters as the sequential loop on the same triplet sequence.
+"""BPRMF plugin (YAML key `external.BPRMF`): per-sample SGD in fp64, the NumPy-semantics model.
+
+Contract of elliot/recommender/latent_factor_models/BPRMF/BPRMF.py:19-129: the ten hyper-parameters below with the
+reference's defaults (:63-76; the four `update_*` switches are read and never used there either), `batch_size` forced to 1
+(:80), `transactions` triplets per epoch, no loss value passed to evaluate() (:129).  Here the epoch's triplets come from
+one device call and are applied in dependency levels, which gives the parameters of the sequential loop on the same
+triplet sequence.  Extra optional keys: `sampler` (philox | replay), `hogwild`, `gpu`.
 """
-from ....dataset.samplers import custom_sampler as cs
-from ...base_recommender_model import BaseRecommenderModel, init_charger
-from ...recommender_utils_mixin import RecMixin
 from .... import ops
+from ....dataset.samplers import custom_sampler
+from ...base_recommender_model import BaseRecommenderModel, init_charger, param
+from ...recommender_utils_mixin import RecMixin
 from .BPRMF_model import MFModel
 
 
 class BPRMF(RecMixin, BaseRecommenderModel):
-    r"""Bayesian Personalized Ranking with Matrix Factorization (https://arxiv.org/abs/1205.2618).
-
-    .. code:: yaml
-
-      models:
-        external.BPRMF:
-          meta:
-            save_recs: True
-          epochs: 10
-          factors: 10
-          lr: 0.001
-          bias_regularization: 0
-          user_regularization: 0.0025
-          positive_item_regularization: 0.0025
-          negative_item_regularization: 0.0025
-    """
+    """BPR matrix factorisation, one triplet at a time (Rendle et al., https://arxiv.org/abs/1205.2618)."""
 
     @init_charger
     def __init__(self, data, config, params, *args, **kwargs):
         self._params_list = [
-            ("_factors", "factors", "f", 10, int, None),
-            ("_learning_rate", "lr", "lr", 0.05, None, None),
-            ("_bias_regularization", "bias_regularization", "bias_reg", 0, None, None),
-            ("_user_regularization", "user_regularization", "u_reg", 0.0025, None, None),
-            ("_positive_item_regularization", "positive_item_regularization", "pos_i_reg", 0.0025, None, None),
-            ("_negative_item_regularization", "negative_item_regularization", "neg_i_reg", 0.00025, None, None),
-            ("_update_negative_item_factors", "update_negative_item_factors", "up_neg_i_f", True, None, None),
-            ("_update_users", "update_users", "up_u", True, None, None),
-            ("_update_items", "update_items", "up_i", True, None, None),
-            ("_update_bias", "update_bias", "up_b", True, None, None),   # read but unused, as in the reference
+            param("factors", "f", 10, int),
+            param("lr", "lr", 0.05, attr="_learning_rate"),
+            param("bias_regularization", "bias_reg", 0),
+            param("user_regularization", "u_reg", 0.0025),
+            param("positive_item_regularization", "pos_i_reg", 0.0025),
+            param("negative_item_regularization", "neg_i_reg", 0.00025),
+            param("update_negative_item_factors", "up_neg_i_f", True),
+            param("update_users", "up_u", True),
+            param("update_items", "up_i", True),
+            param("update_bias", "up_b", True),
         ]
         self.autoset_params()
-        self._batch_size = 1                                           # BPRMF.py:80
+        self._batch_size = 1
         self._ctx = ops.get_context(max(int(getattr(self._config, "gpu", 0) or 0), 0))
         self._model = MFModel(self._factors, self._data, self._learning_rate, self._user_regularization,
                               self._bias_regularization, self._positive_item_regularization,
                               self._negative_item_regularization, self._seed, ctx=self._ctx,
                               hogwild=bool(getattr(self._params, "hogwild", False)),
                               init_weights=kwargs.get("init_weights"))
-        # `sampler: replay` -> the reference's exact MT19937 triplet stream (seed-exact runs); default: Philox
         if getattr(self._params, "sampler", "philox") == "replay":
-            self._sampler = cs.Sampler(self._data.i_train_dict, ctx=self._ctx, replay=True)
+            self._sampler = custom_sampler.Sampler(self._data.i_train_dict, ctx=self._ctx, replay=True)
         else:
-            self._sampler = cs.Sampler(self._data.sp_i_train, ctx=self._ctx)
+            self._sampler = custom_sampler.Sampler(self._data.sp_i_train, ctx=self._ctx)
 
     @property
     def name(self):
-        return "BPRMF" + f"_{self.get_base_params_shortcut()}" + f"_{self.get_params_shortcut()}"
+        return "_".join(["BPRMF", self.get_base_params_shortcut(), self.get_params_shortcut()])
 
     def _recommendation_block(self):
         return 65536
@@ -66,10 +53,10 @@ class BPRMF(RecMixin, BaseRecommenderModel):
     def train(self):
         if self._restore:
             return self.restore_weights()
-        print(f"Transactions: {self._data.transactions}")
+        n = self._data.transactions
+        print(f"Transactions: {n}")
         for it in self.iterate(self._epochs):
             print(f"\n********** Iteration: {it + 1}")
-            # one epoch = `transactions` triplets (BPRMF.py:121-127), drawn in one sampler call
-            for batch in self._sampler.step(self._data.transactions, self._data.transactions):
-                self._model.train_step(batch)
-            self.evaluate(it)                                          # loss is not computed by this variant (:129)
+            for epoch_triplets in self._sampler.step(n, n):            # the whole epoch in one sampler call
+                self._model.train_step(epoch_triplets)
+            self.evaluate(it)

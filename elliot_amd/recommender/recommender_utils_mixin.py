@@ -16,47 +16,56 @@ from . import _compat
 
 class RecMixin(object):
 
+    # -- training loop and per-epoch evaluation ------------------------------------------------------------------
     def train(self):
         if self._restore:
             return self.restore_weights()
+        steps_per_epoch = int(self._data.transactions // self._batch_size)
         for it in self.iterate(self._epochs):
-            loss, steps = 0, 0
-            with tqdm(total=int(self._data.transactions // self._batch_size), disable=not self._verbose) as t:
+            epoch_loss = 0
+            with tqdm(total=steps_per_epoch, disable=not self._verbose) as bar:
                 for batch in self._sampler.step(self._data.transactions, self._batch_size):
-                    steps += 1
-                    loss += self._model.train_step(batch)
-                    t.update()
-            self.evaluate(it, float(loss) / (it + 1))
+                    epoch_loss += self._model.train_step(batch)
+                    bar.update()
+            self.evaluate(it, float(epoch_loss) / (it + 1))          # the reference's normalisation (BPRMF_batch.py:109)
 
     def evaluate(self, it=None, loss=0):
-        if (it is None) or (not (it + 1) % self._validation_rate):
-            recs = None
-            if self._device_metrics():
-                result_dict = self._evaluate_on_device(self.evaluator.get_needed_recommendations())
-            else:
-                recs = self.get_recommendations(self.evaluator.get_needed_recommendations())
-                result_dict = self.evaluator.eval(recs)
-            self._losses.append(loss)
-            self._results.append(result_dict)
-            if it is not None:
-                self.logger.info(f'Epoch {(it + 1)}/{self._epochs} loss {loss/(it + 1):.5f}')
-            else:
-                self.logger.info('Finished')
-            if self._save_recs and recs is not None:
-                self.logger.info(f"Writing recommendations at: {self._config.path_output_rec_result}")
-                fname = f"{self.name}_it={it + 1}.tsv" if it is not None else f"{self.name}.tsv"
-                _compat.store_recommendation(
-                    recs[1], os.path.abspath(os.sep.join([self._config.path_output_rec_result, fname])))
-            if (len(self._results) - 1) == self.get_best_arg():
-                if it is not None:
-                    self._params.best_iteration = it + 1
-                self.logger.info("******************************************")
-                self.best_metric_value = self._results[-1][self._validation_k]["val_results"][self._validation_metric]
-                if self._save_weights:
-                    if hasattr(self, "_model"):
-                        self._model.save_weights(self._saving_filepath)
-                    else:
-                        self.logger.warning("Saving weights FAILED. No model to save.")
+        """Called after every epoch (it = epoch index) and once after a restore (it = None)."""
+        due = it is None or (it + 1) % self._validation_rate == 0
+        if not due:
+            return
+        needed = self.evaluator.get_needed_recommendations()
+        recs = None
+        if self._device_metrics():
+            outcome = self._evaluate_on_device(needed)
+        else:
+            recs = self.get_recommendations(needed)
+            outcome = self.evaluator.eval(recs)
+        self._losses.append(loss)
+        self._results.append(outcome)
+        self.logger.info("Finished" if it is None else f"Epoch {(it + 1)}/{self._epochs} loss {loss/(it + 1):.5f}")
+        if self._save_recs and recs is not None:
+            self._write_recs(recs[1], it)
+        if self.get_best_arg() == len(self._results) - 1:           # this evaluation is the best so far
+            self._on_new_best(it)
+
+    def _write_recs(self, recs_test, it):
+        folder = self._config.path_output_rec_result
+        self.logger.info(f"Writing recommendations at: {folder}")
+        stem = self.name if it is None else f"{self.name}_it={it + 1}"
+        _compat.store_recommendation(recs_test, os.path.abspath(os.path.join(folder, stem + ".tsv")))
+
+    def _on_new_best(self, it):
+        if it is not None:
+            self._params.best_iteration = it + 1
+        self.logger.info("******************************************")
+        self.best_metric_value = self._validation_value(self._results[-1])
+        if not self._save_weights:
+            return
+        if hasattr(self, "_model"):
+            self._model.save_weights(self._saving_filepath)
+        else:
+            self.logger.warning("Saving weights FAILED. No model to save.")
 
     # -- metrics on the device (SURVEY 8f N1) --------------------------------------------------------------
     def _device_metrics(self):
@@ -147,26 +156,32 @@ class RecMixin(object):
         except Exception as ex:
             raise Exception(f"Error in model restoring operation! {ex}")
 
-    # -- bookkeeping (identical contracts to :111-136) ----------------------------------------------------
-    def get_loss(self):
-        if self._optimize_internal_loss:
-            return min(self._losses)
-        return -max(r[self._validation_k]["val_results"][self._validation_metric] for r in self._results)
-
-    def get_params(self):
-        return self._params.__dict__
-
-    def get_results(self):
-        return self._results[self.get_best_arg()]
+    # -- what the experiment driver reads back (contracts of the reference's :111-136) ---------------------------
+    def _validation_value(self, result):
+        return result[self._validation_k]["val_results"][self._validation_metric]
 
     def get_best_arg(self):
         if self._optimize_internal_loss:
             return np.argmin(self._losses)
-        return np.argmax([r[self._validation_k]["val_results"][self._validation_metric] for r in self._results])
+        return np.argmax([self._validation_value(r) for r in self._results])
+
+    def get_loss(self):
+        """What hyperopt minimises: the internal loss, or minus the best validation metric."""
+        if self._optimize_internal_loss:
+            return min(self._losses)
+        return -max(self._validation_value(r) for r in self._results)
+
+    def get_results(self):
+        return self._results[self.get_best_arg()]
+
+    def get_params(self):
+        return self._params.__dict__
 
     def iterate(self, epochs):
-        for iteration in range(epochs):
-            if self._early_stopping.stop(self._losses[:], self._results):
-                self.logger.info(f"Met Early Stopping conditions: {self._early_stopping}")
-                break
-            yield iteration
+        """Epoch indices until the early-stopping rule fires (it is consulted BEFORE every epoch)."""
+        done = 0
+        while done < epochs and not self._early_stopping.stop(self._losses[:], self._results):
+            yield done
+            done += 1
+        if done < epochs:
+            self.logger.info(f"Met Early Stopping conditions: {self._early_stopping}")
