@@ -670,6 +670,21 @@ __global__ __launch_bounds__(256) void k_list_scores(TopkParams p, float* __rest
     }
 }
 
+// same result for any F: one thread per (item, listed user), the item row is re-read per user (L2)
+__global__ __launch_bounds__(256) void k_list_scores_wide(TopkParams p, float* __restrict__ preds) {
+    const int slot = blockIdx.y;
+    int n = *p.ulist_n;
+    if (n > LIST_DENSE) n = LIST_DENSE;
+    if (slot >= n) return;
+    const int64_t il = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (il >= p.I_local) return;
+    const float* gi = p.Gi + il * (int64_t)p.F;
+    const float* gu = p.Gu + (p.u_start + p.ulist[slot]) * (int64_t)p.F;
+    float a = 0.f;
+    for (int f = 0; f < p.F; ++f) a = __builtin_fmaf(gi[f], gu[f], a);
+    preds[(int64_t)slot * p.I_local + il] = (p.Bi ? a + p.Bi[il] : a) + 0.0f;
+}
+
 static int64_t list_cap_for(int64_t n_users) {
     int64_t c = n_users / 16;
     if (c < 512) c = 512;
@@ -695,9 +710,11 @@ int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, 
         d.ulist_skip = 0;
         d.ulist_max = LIST_DENSE;
         d.nsplit = 0;
-        EL_REQUIRE(p0.F <= 128, "el_topk_run_list: F <= 128");
-        EL_LAUNCH("k_list_scores", k_list_scores, dim3((unsigned)((p0.I_local + 255) / 256)), dim3(256), (size_t)LIST_DENSE * p0.F * 4, st, d,
-                  preds);
+        if (p0.F <= 128)
+            EL_LAUNCH("k_list_scores", k_list_scores, dim3((unsigned)((p0.I_local + 255) / 256)), dim3(256), (size_t)LIST_DENSE * p0.F * 4, st,
+                      d, preds);
+        else
+            EL_LAUNCH("k_list_scores", k_list_scores_wide, dim3((unsigned)((p0.I_local + 255) / 256), LIST_DENSE), dim3(256), 0, st, d, preds);
         d.preds = preds;
         d.ld = p0.I_local;
         // one wave per (entry, item slice) -> partial lists in the split scratch (free until tier 2 runs) -> merge
@@ -820,7 +837,7 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
         p.dbg = e ? atoi(e) : 0;
     }
     const bool selig = el_topk_screen_eligible(F, k, cand_indptr);
-    if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=128, k<=128 and no candidate list");
+    if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=256, k<=128 and no candidate list");
     if (algo == EL_TOPK_SCREEN ||
         (algo == EL_TOPK_AUTO && selig && ws != nullptr && ws_bytes >= el_topk_screen_ws_bytes(u_stop - u_start, I_local, F, k, 0)))
         return el_topk_screen_run(p, ws, ws_bytes, st);

@@ -151,7 +151,7 @@ __device__ __forceinline__ float el_vmax3(float a, float b, float c) {
 //
 // the epilogue E of one half tile is VALU work issued while the matrix core runs the other half; the bias enters as the
 // C operand of the first MFMA of a chain (s' = bias + sum, no VALU add).  LDS: two item tiles, a ring of four bias rows.
-template <int FP, int MODE, int NW, int NSUB, bool PROF>
+template <int FP, int MODE, int NW, int NSUB, int UB, bool PROF>
 __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     constexpr int NT = NW * 64;
     constexpr int TI = SCR_TI;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     constexpr int TILEB = TI * ROWB;
     constexpr int NPC = (TI * SL + NT - 1) / NT;  // 16-byte pieces per thread per tile
     constexpr int NKS = FP / 16;                // MFMA k-steps
-    constexpr int UPB = NW * 64;
+    constexpr int UPB = NW * UB * 32;             // UB = 32-user column blocks per wave (2; 1 for FP = 256: register budget)
     const TopkParams& p = sp.t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tiles = smem;                                              // [2][NSUB][TILEB]: NSUB 64-item tiles per barrier
@@ -172,16 +172,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     const int hi = lane >> 5, col = lane & 31;
     const int F = p.F;
     const int64_t I = p.I_local;
-    const int64_t ublock = p.u_start + (int64_t)blockIdx.x * UPB + wave * 64;
+    const int64_t ublock = p.u_start + (int64_t)blockIdx.x * UPB + wave * (UB * 32);
 
     // ---- resident user fragments (bf16) ------------------------------------------------------------------------------
-    bf16x8 bfr[2][NKS];
-    bool uvalid[2];
-    float thr[2] = {INFINITY, INFINITY};
-    int ucnt[2] = {0, 0}, lcap[2] = {0, 0};
-    int64_t lbase[2] = {0, 0};
+    bf16x8 bfr[UB][NKS];
+    bool uvalid[UB];
+    float thr[UB];
+    int ucnt[UB], lcap[UB];
+    int64_t lbase[UB];
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
+    for (int ub = 0; ub < UB; ++ub) {
+        thr[ub] = INFINITY;
+        ucnt[ub] = lcap[ub] = 0;
+        lbase[ub] = 0;
+    }
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
         const int64_t user = ublock + ub * 32 + col;
         uvalid[ub] = user < p.u_stop;
         const float* gu = p.Gu + (uvalid[ub] ? user : p.u_start) * (int64_t)F;
@@ -216,10 +222,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
             lcap[ub] = (int)(cap < 0 ? 0 : (cap > 0x3fffffff ? 0x3fffffff : cap));
         }
     }
-    floatx16 mx[2][2];
+    floatx16 mx[UB][2];
     if (MODE == 1) {
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
+        for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
         }
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[UB][2];
     // 2 x NKS MFMAs of item row block ib of sub-tile `sub` of staged group g
     auto mfma_half = [&](int g, int sub, int ib) {
         // bias of this lane's 16 accumulator rows: rows ib*32 + 8q + 4hi + {0..3} are r = 4q..4q+3
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
         for (int ks = 0; ks < NKS; ++ks) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + (((ks * 2 + hi) ^ key) << 4));
 #pragma unroll
-            for (int ub = 0; ub < 2; ++ub)
+            for (int ub = 0; ub < UB; ++ub)
                 acc[ub][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[ub][ks], ks == 0 ? b16 : acc[ub][ib], 0, 0, 0);
         }
     };
@@ -297,9 +303,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     unsigned long long pn_enter = 0, pn_hits = 0, pn_blocks = 0;
     // epilogue of item row block ib of tile `tile` (scores in acc[.][ib])
     auto epi_half = [&](int tile, int ib) {
-        if (PROF) pn_blocks += 2;
+        if (PROF) pn_blocks += UB;
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub) {
+        for (int ub = 0; ub < UB; ++ub) {
             const floatx16& sc = acc[ub][ib];                          // s' (a padded row carries -inf)
             if (MODE == 1) {
 #pragma unroll
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
 
     if (MODE == 1) {
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub) {
+        for (int ub = 0; ub < UB; ++ub) {
             const int64_t user = ublock + ub * 32 + col;
             if (!uvalid[ub]) continue;
             float* o = sp.smax + (user - p.u_start) * SCR_TI + hi * 16;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
         }
     } else {
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub) {
+        for (int ub = 0; ub < UB; ++ub) {
             const int64_t user = ublock + ub * 32 + col;
             if (!uvalid[ub] || hi) continue;
             const int64_t ur = user - p.u_start;
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
     constexpr int XC = 512;                          // exclusion rows up to this length are searched in LDS
     __shared__ u64 surv_[4][SCR_SURV];
     __shared__ int32_t xrow_[4][XC];
-    __shared__ __attribute__((aligned(16))) float gus_[4][128];   // F <= 128 (eligibility)
+    __shared__ __attribute__((aligned(16))) float gus_[4][256];   // F <= 256 (eligibility)
     u64* surv = surv_[wv];
     int32_t* xrow = xrow_[wv];
     float* gu_s = gus_[wv];
@@ -671,9 +677,9 @@ __global__ __launch_bounds__(256) void k_screen_flags(ScreenParams sp, int64_t n
 // ---- host ------------------------------------------------------------------------------------------------------------
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int screen_fp(int F) { return F <= 32 ? 32 : (F <= 64 ? 64 : 128); }
+static int screen_fp(int F) { return F <= 32 ? 32 : (F <= 64 ? 64 : (F <= 128 ? 128 : 256)); }
 
-bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 128 && k >= 1 && k <= 128; }
+bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nullptr && F >= 1 && F <= 256 && k >= 1 && k <= 128; }
 
 // How the threshold T is obtained (see the header comment and DESIGN.md 3.1b):
 //   small catalogue (< 192 tiles), k <= 12   pass 1 over every tile, T = k-th largest clean slot maximum: rigorous
@@ -727,13 +733,14 @@ size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, i
 
 template <int FP, int MODE, int NW, bool PROF>
 static int launch_pass(const ScreenParams& sp, hipStream_t st) {
-    constexpr int NSUB = MODE == 2 ? 2 : 1;     // pass 2: two tiles per barrier average out the record path (-8 %); pass 1 is uniform
+    constexpr int NSUB = (MODE == 2 && FP <= 128) ? 2 : 1;   // pass 2: two tiles per barrier average out the record path (-8 %)
+    constexpr int UB = FP <= 128 ? 2 : 1;                    // FP = 256: the resident user fragments allow 32 users per wave
     constexpr size_t lds = (size_t)NSUB * (2 * SCR_TI * FP * 2 + 4 * SCR_TI * 4);
-    auto kern = k_screen_pass<FP, MODE, NW, NSUB, PROF>;
+    auto kern = k_screen_pass<FP, MODE, NW, NSUB, UB, PROF>;
     if (lds > 65536) EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t n_users = sp.t.u_stop - sp.t.u_start;
-    EL_LAUNCH(MODE == 1 ? "k_screen_pass1" : "k_screen_pass2", kern, dim3((unsigned)((n_users + NW * 64 - 1) / (NW * 64))), dim3(NW * 64),
-              lds, st, sp);
+    constexpr int UPB = NW * UB * 32;
+    EL_LAUNCH(MODE == 1 ? "k_screen_pass1" : "k_screen_pass2", kern, dim3((unsigned)((n_users + UPB - 1) / UPB)), dim3(NW * 64), lds, st, sp);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -741,7 +748,8 @@ static int launch_pass(const ScreenParams& sp, hipStream_t st) {
 template <int FP, int NW, bool PROF>
 static int run_passes(ScreenParams& sp, hipStream_t st) {
     const int64_t n_users = sp.t.u_stop - sp.t.u_start;
-    const int64_t nw = ((n_users + NW * 64 - 1) / (NW * 64)) * NW;
+    constexpr int UPB_ = NW * (FP <= 128 ? 2 : 1) * 32;
+    const int64_t nw = ((n_users + UPB_ - 1) / UPB_) * NW;
     unsigned long long* h = nullptr;
     if (PROF) {
         EL_CHECK_HIP(hipMalloc((void**)&sp.prof, (size_t)nw * 64));
@@ -823,8 +831,10 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
             EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
         else if (FP == 64)
             EL_LAUNCH("k_screen_prep", k_screen_prep<64>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
-        else
+        else if (FP == 128)
             EL_LAUNCH("k_screen_prep", k_screen_prep<128>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+        else
+            EL_LAUNCH("k_screen_prep", k_screen_prep<256>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
     }
     const char* pe = getenv("EL_SCREEN_PROF");
     const bool prof = pe && pe[0] == '1';
@@ -834,8 +844,10 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
         rc = SCR_RUN(32);
     else if (FP == 64)
         rc = SCR_RUN(64);
-    else
+    else if (FP == 128)
         rc = SCR_RUN(128);
+    else
+        rc = SCR_RUN(256);
 #undef SCR_RUN
     if (rc) return rc;
     // exact recomputation of the flagged users by the fp32 MFMA kernel (a grid of early exits when nothing is flagged)

@@ -211,7 +211,7 @@ enum {
     EL_TOPK_AUTO = 0,   /* SCREEN when eligible and a workspace is given, else MFMA, else the wave kernel */
     EL_TOPK_MFMA = 1,   /* force the fp32 kernel, v_mfma_f32_32x32x2_f32 (F<=256, k<=40)                */
     EL_TOPK_SIMPLE = 2, /* force the wave-per-user VALU kernel (any F, k<=4032, candidate protocol)     */
-    EL_TOPK_SCREEN = 3  /* force the bf16-screened / fp32-exact kernels (F<=128, k<=128); same results  */
+    EL_TOPK_SCREEN = 3  /* force the bf16-screened / fp32-exact kernels (F<=256, k<=128); same results  */
 };
 
 /* Replaces: BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) and
