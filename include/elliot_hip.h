@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 1
+#define EL_ABI_VERSION 2   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points */
 
 /* ---- context ---------------------------------------------------------------- */
 
