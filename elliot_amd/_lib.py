@@ -51,7 +51,7 @@ class VaeState(C.Structure):
         ("w", C.c_void_p * 8), ("g", C.c_void_p * 8), ("m", C.c_void_p * 8), ("v", C.c_void_p * 8),
         ("h", _f32p), ("mv", _f32p), ("z", _f32p), ("dz", _f32p), ("h2", _f32p), ("logits", _f32p),
         ("dh2", _f32p), ("dmv", _f32p), ("dh", _f32p), ("rnorm", _f32p),
-        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("dae", C.c_int32),
     ]
 
 

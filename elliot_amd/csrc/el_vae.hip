@@ -251,7 +251,7 @@ static int vae_check(const el_vae_state* st, int64_t B) {
     EL_REQUIRE(st->H <= 1024, "el_vae: intermediate_dim > 1024 unsupported in this build");
     EL_REQUIRE(B >= 1 && B <= st->Bmax, "el_vae: batch %lld exceeds Bmax %lld", (long long)B, (long long)st->Bmax);
     for (int t = 0; t < 8; ++t) EL_REQUIRE(st->w[t] != nullptr, "el_vae: null weight %d", t);
-    EL_REQUIRE(st->h && st->mv && st->z && st->h2 && st->logits && st->rnorm, "el_vae: null activation buffer");
+    EL_REQUIRE(st->h && (st->dae || st->mv) && st->z && st->h2 && st->logits && st->rnorm, "el_vae: null activation buffer");
     return 0;
 }
 
@@ -278,8 +278,13 @@ static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const
     const int H = st->H, L = st->L;
     const int64_t I = st->I;
     EL_VAE_ENC1(k_vae_enc1, rows, indptr, indices, st->w[0], st->w[1], B, H, rate, seed, step, st->h, st->rnorm);
-    if (int rc = el_gemm_f32(ctx, s, 0, 0, B, 2 * L, H, st->h, H, st->w[2], 2 * L, st->mv, 2 * L, st->w[3], 0, st->ws, st->ws_bytes)) return rc;
-    EL_LAUNCH("k_vae_sample", k_vae_sample, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->mv, eps, B, L, anneal, st->z, loss_out);
+    if (st->dae) {
+        // MultiDAE encoder (multi_dae_model.py:32-51): z = tanh(h Wm + bm), no log-variance head, no sampling, no KL
+        if (int rc = el_gemm_f32(ctx, s, 0, 0, B, L, H, st->h, H, st->w[2], L, st->z, L, st->w[3], 1 /*tanh*/, st->ws, st->ws_bytes)) return rc;
+    } else {
+        if (int rc = el_gemm_f32(ctx, s, 0, 0, B, 2 * L, H, st->h, H, st->w[2], 2 * L, st->mv, 2 * L, st->w[3], 0, st->ws, st->ws_bytes)) return rc;
+        EL_LAUNCH("k_vae_sample", k_vae_sample, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->mv, eps, B, L, anneal, st->z, loss_out);
+    }
     if (int rc = el_gemm_f32(ctx, s, 0, 0, B, H, L, st->z, L, st->w[4], H, st->h2, H, st->w[5], 1 /*tanh*/, st->ws, st->ws_bytes)) return rc;
     if (int rc = el_gemm_f32(ctx, s, 0, 0, B, I, H, st->h2, H, st->w[6], I, st->logits, I, st->w[7], 0, st->ws, st->ws_bytes)) return rc;
     EL_CHECK_LAUNCH();
@@ -293,7 +298,7 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
     if (int rc = vae_check(st, B)) return rc;
     EL_REQUIRE(indptr && indices && rows && loss_out && step >= 1, "el_vae_train_step: bad arguments");
     for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t] && st->m[t] && st->v[t], "el_vae_train_step: optimiser buffers missing");
-    EL_REQUIRE(st->dh2 && st->dmv && st->dh, "el_vae_train_step: backward buffers missing");
+    EL_REQUIRE(st->dh2 && (st->dae || st->dmv) && st->dh && st->dz, "el_vae_train_step: backward buffers missing");
     hipStream_t s = (hipStream_t)stream;
     const int H = st->H, L = st->L;
     const int64_t I = st->I;
@@ -310,10 +315,17 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
     if (int rc = colsum(s, st->dh2, B, H, st->g[5])) return rc;
     // dz reuses the z buffer after dW3 consumed z
     if (int rc = el_gemm_f32(ctx, s, 0, 1, B, L, H, st->dh2, H, st->w[4], H, st->dz, L, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dz = dh2pre W3^T
-    EL_LAUNCH("k_vae_dmv", k_vae_dmv, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->dz, st->mv, eps, B, L, anneal, st->dmv);
-    if (int rc = el_gemm_f32(ctx, s, 1, 0, H, 2 * L, B, st->h, H, st->dmv, 2 * L, st->g[2], 2 * L, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dWmv
-    if (int rc = colsum(s, st->dmv, B, 2 * L, st->g[3])) return rc;
-    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, 2 * L, st->dmv, 2 * L, st->w[2], 2 * L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dh = dmv Wmv^T
+    if (st->dae) {
+        EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * L, ctx)), dim3(256), 0, s, st->dz, st->z, B * L);                       // through tanh
+        if (int rc = el_gemm_f32(ctx, s, 1, 0, H, L, B, st->h, H, st->dz, L, st->g[2], L, nullptr, 0, st->ws, st->ws_bytes)) return rc;    // dWm
+        if (int rc = colsum(s, st->dz, B, L, st->g[3])) return rc;
+        if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, L, st->dz, L, st->w[2], L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dh
+    } else {
+        EL_LAUNCH("k_vae_dmv", k_vae_dmv, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->dz, st->mv, eps, B, L, anneal, st->dmv);
+        if (int rc = el_gemm_f32(ctx, s, 1, 0, H, 2 * L, B, st->h, H, st->dmv, 2 * L, st->g[2], 2 * L, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dWmv
+        if (int rc = colsum(s, st->dmv, B, 2 * L, st->g[3])) return rc;
+        if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, 2 * L, st->dmv, 2 * L, st->w[2], 2 * L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dh = dmv Wmv^T
+    }
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh, st->h, B * H);
     if (int rc = colsum(s, st->dh, B, H, st->g[1])) return rc;
     // dW1 = xd^T dhpre with xd the dense image of the batch (the logits buffer is free again: dl was consumed)
@@ -322,7 +334,8 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
               dropout_rate, (u64)dropout_seed, (u32)step, st->logits);
     if (int rc = el_gemm_f32(ctx, s, 1, 0, I, H, B, st->logits, I, st->dh, H, st->g[0], H, nullptr, 0, st->ws, st->ws_bytes)) return rc;
     // Adam on the ten variables (W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4)
-    const int64_t sizes[8] = {I * H, H, (int64_t)H * 2 * L, 2 * L, (int64_t)L * H, H, (int64_t)H * I, I};
+    const int64_t LL = st->dae ? L : 2 * L;
+    const int64_t sizes[8] = {I * H, H, (int64_t)H * LL, LL, (int64_t)L * H, H, (int64_t)H * I, I};
     for (int t = 0; t < 8; ++t) {
         EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(grid1d(sizes[t], ctx)), dim3(256), 0, s, st->w[t], st->g[t],
                   st->m[t], st->v[t], sizes[t], lr_t, 0.9f, 0.999f, 1e-7f, 0);

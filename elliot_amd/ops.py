@@ -505,9 +505,13 @@ class VaeDeviceState:
         self.I, self.H = W1.shape
         self.L = int(weights["Wm"].shape[1])
         self.Bmax = int(max_batch)
-        t = {"W1": W1, "b1": f(weights["b1"]),
-             "Wmv": torch.cat([f(weights["Wm"]), f(weights["Wv"])], dim=1).contiguous(),
-             "bmv": torch.cat([f(weights["bm"]), f(weights["bv"])]).contiguous(),
+        self.dae = "Wv" not in weights          # MultiDAE: mean head only, tanh on it, no sampling / KL (multi_dae_model.py)
+        if self.dae:
+            wmv, bmv = f(weights["Wm"]), f(weights["bm"])
+        else:
+            wmv = torch.cat([f(weights["Wm"]), f(weights["Wv"])], dim=1).contiguous()
+            bmv = torch.cat([f(weights["bm"]), f(weights["bv"])]).contiguous()
+        t = {"W1": W1, "b1": f(weights["b1"]), "Wmv": wmv, "bmv": bmv,
              "W3": f(weights["W3"]), "b3": f(weights["b3"]), "W4": W4, "b4": f(weights["b4"])}
         self.w = [t[n] for n in self.ORDER]
         self.g = [torch.zeros_like(x) for x in self.w]
@@ -527,12 +531,15 @@ class VaeDeviceState:
                                 h=self.h.data_ptr(), mv=self.mv.data_ptr(), z=self.z.data_ptr(), dz=self.dz.data_ptr(),
                                 h2=self.h2.data_ptr(), logits=self.logits.data_ptr(), dh2=self.dh2.data_ptr(),
                                 dmv=self.dmv.data_ptr(), dh=self.dh.data_ptr(), rnorm=self.rnorm.data_ptr(),
-                                ws=self._ws.data_ptr(), ws_bytes=self._ws.numel())
+                                ws=self._ws.data_ptr(), ws_bytes=self._ws.numel(), dae=int(self.dae))
 
     def weights(self):
         """Host copies keyed like the constructor argument."""
         L = self.L
         w = {n: x.cpu().numpy() for n, x in zip(self.ORDER, self.w)}
+        if self.dae:
+            return {"W1": w["W1"], "b1": w["b1"], "Wm": w["Wmv"], "bm": w["bmv"], "W3": w["W3"], "b3": w["b3"],
+                    "W4": w["W4"], "b4": w["b4"]}
         return {"W1": w["W1"], "b1": w["b1"], "Wm": w["Wmv"][:, :L].copy(), "Wv": w["Wmv"][:, L:].copy(),
                 "bm": w["bmv"][:L].copy(), "bv": w["bmv"][L:].copy(), "W3": w["W3"], "b3": w["b3"], "W4": w["W4"],
                 "b4": w["b4"]}

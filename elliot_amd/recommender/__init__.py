@@ -4,7 +4,8 @@ from .recommender_utils_mixin import RecMixin
 from .latent_factor_models.BPRMF_batch.BPRMF_batch import BPRMF_batch
 from .latent_factor_models.BPRMF.BPRMF import BPRMF
 from .autoencoders.vae.multi_vae import MultiVAE
+from .autoencoders.dae.multi_dae import MultiDAE
 from .neural.NeuMF.neural_matrix_factorization import NeuMF
 from .neural.GeneralizedMF.generalized_matrix_factorization import GMF
 
-__all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF", "MultiVAE", "NeuMF", "GMF"]
+__all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF", "MultiVAE", "MultiDAE", "NeuMF", "GMF"]

@@ -304,6 +304,9 @@ typedef struct el_vae_state {
     float* rnorm;    /* [Bmax]     1/||x_b||                    */
     void* ws;        /* split-K workspace (may be NULL)         */
     size_t ws_bytes;
+    int32_t dae;     /* 1: MultiDAE (autoencoders/dae/multi_dae_model.py:19-139): the encoder head is
+                      * z = tanh(h Wm + bm) with w[2] = Wm [H,L], w[3] = bm [L] (mv / dmv unused), no sampling,
+                      * no KL; eps / anneal are ignored                                                  */
 } el_vae_state;
 
 /* Replaces: VariationalAutoEncoder.train_step (multi_vae_model.py:125-142) on the batch whose rows

@@ -89,3 +89,38 @@ def test_vae_train_steps_and_predict_match_oracle(ctx, rate):
     ref = ov.log_softmax(ov.forward(w_dev, X[rows], eps, dtype=np.float64)["logits"])
     assert np.abs(pred - ref).max() < 1e-4
     assert np.abs(np.exp(pred).sum(1) - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.3])
+def test_dae_train_steps_and_predict_match_oracle(ctx, rate):
+    """Mult-DAE mode of the same kernels (el_vae_state.dae = 1): tanh latent layer, no sampling, no KL."""
+    from oracle import multi_dae as od
+    rs = np.random.RandomState(12)
+    U, I, H, L, B = 300, 700, 64, 16, 128
+    X = (rs.rand(U, I) < 0.04).astype(np.float32)
+    X[np.arange(U), rs.randint(0, I, U)] = 1.0
+    m = sp.csr_matrix(X)
+    m.sort_indices()
+    w0 = od.init_weights(I, H, L, 42)
+    for k in ("b1", "bm", "b3", "b4"):
+        w0[k] = rs.normal(scale=0.01, size=w0[k].shape).astype(np.float32)
+    lr = 0.001
+    st = ops.VaeDeviceState(ctx, w0, max_batch=B)
+    assert st.dae
+    orc = od.MultiDAEOracle(w0, lr)
+    csr = ops.DeviceCSR(m.indptr, m.indices, I, ctx.device)
+    d = ctx.device
+    for s in range(5):
+        rows = rs.permutation(U)[:B if s != 3 else 37].astype(np.int32)
+        st.train_step(csr, torch.from_numpy(rows).to(d), lr, 0.0, eps=None, dropout_rate=rate, dropout_seed=42)
+        got = st.pop_loss()
+        exp = orc.train_step(X[rows], drop_scale_matrix(rows, I, rate, 42, s + 1) if rate > 0 else None)
+        assert abs(got - exp) <= 1e-4 * abs(exp), (s, got, exp)
+        gw = st.weights()
+        for k in od.NAMES:
+            err = np.abs(gw[k] - orc.w[k])
+            assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()), float((err > 2e-5).mean()))
+    rows = np.arange(40, 40 + 64, dtype=np.int32)
+    pred = cpu(st.predict(csr, torch.from_numpy(rows).to(d)))
+    ref = od.log_softmax(od.forward(st.weights(), X[rows], dtype=np.float64)["logits"])
+    assert np.abs(pred - ref).max() < 1e-4

@@ -204,6 +204,40 @@ def test_multivae_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
     assert hits >= 0.97 * U          # fp32 vs fp64 scores: only near-ties at the k-th place may differ
 
 
+def test_multidae_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
+    """MultiDAE as a sibling of MultiVAE on the same kernels (dae mode)."""
+    import random
+    from elliot_amd.recommender import MultiDAE
+    from oracle import multi_dae as od
+    data, cfg = make_data(tmp_path)
+    U, I = data.num_users, data.num_items
+    H, L, B, epochs, lr = 32, 8, 64, 2, 0.001
+    w0 = od.init_weights(I, H, L, 7)
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=epochs, batch_size=B, intermediate_dim=H,
+                             latent_dim=L, lr=lr, dropout_pkeep=1, seed=42)
+    model = MultiDAE(data=data, config=cfg, params=params, init_weights=w0)
+    assert model.name.startswith("MultiDAE_seed=42_e=2_bs=64_intermediate_dim=32_latent_dim=8_reg_lambda=0$01")
+    model.train()
+    X = data.sp_i_train.toarray().astype(np.float32)
+    orc = od.MultiDAEOracle(w0, lr)
+    random.seed(42)
+    losses = []
+    for it in range(epochs):
+        order = random.sample(range(U), U)
+        tot = 0.0
+        for s in range(0, U, B):
+            tot += orc.train_step(X[order[s:s + B]])
+        losses.append(tot / (it + 1))
+    for got, exp in zip(model._losses, losses):
+        assert abs(got - exp) <= 1e-4 * abs(exp), (model._losses, losses)
+    gw = model._model.state.weights()
+    assert set(gw.keys()) == set(od.NAMES)
+    for k in od.NAMES:
+        assert (np.abs(gw[k] - orc.w[k]) > 5e-5).mean() < 5e-3, k
+    res = model.get_results()
+    assert set(res.keys()) == {10, 5} and 0.0 <= res[10]["test_results"]["nDCG"] <= 1.0
+
+
 def test_neumf_and_gmf_plugins_end_to_end(ctx, tmp_path):
     import random
     from elliot_amd.recommender import GMF, NeuMF

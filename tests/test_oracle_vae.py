@@ -45,3 +45,27 @@ def test_vae_adam_dense_step_known_answer():
     nz = np.abs(d) > 0
     assert nz.any() and np.allclose(np.abs(d[nz]), 0.001, rtol=2e-2)
     assert np.array_equal(before["W1"][3], o.w["W1"][3])     # item 3 never appears in the batch -> zero gradient row
+
+
+def test_dae_loss_and_gradients_match_autograd():
+    """oracle/multi_dae.py (Mult-DAE: tanh on the latent layer, no sampling, no KL) against torch autograd."""
+    from oracle import multi_dae as od
+    rs = np.random.RandomState(1)
+    B, I, H, L = 6, 19, 8, 4
+    w = {k: rs.normal(scale=0.3, size=v.shape) for k, v in od.init_weights(I, H, L, 1).items()}
+    x = (rs.rand(B, I) < 0.3).astype(np.float64)
+    x[0, :] = 0
+    x[0, 2] = 1
+    drop = (rs.rand(B, I) > 0.25) / 0.75
+    c = od.forward(w, x, drop, dtype=np.float64)
+    loss, g = od.loss_from(c), od.gradients(w, c)
+    tw = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    tx, td = torch.tensor(x), torch.tensor(drop)
+    xn = tx / torch.sqrt(torch.clamp((tx * tx).sum(1, keepdim=True), min=1e-12)) * td
+    z = torch.tanh(torch.tanh(xn @ tw["W1"] + tw["b1"]) @ tw["Wm"] + tw["bm"])
+    logits = torch.tanh(z @ tw["W3"] + tw["b3"]) @ tw["W4"] + tw["b4"]
+    tl = -torch.mean(torch.sum(torch.log_softmax(logits, 1) * tx, 1))
+    tl.backward()
+    assert abs(float(tl.detach()) - loss) < 1e-12
+    for k in od.NAMES:
+        assert np.abs(g[k] - tw[k].grad.numpy()).max() < 1e-12, k
