@@ -261,3 +261,38 @@ def test_screened_topk_large_k_guess_and_verify(ctx, F, k, I):
     ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
     gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
     assert_topk_equal(f"topk_screen_k{k}", gi, gv, ei, ev)
+
+
+def test_topk_fuzz_all_algorithms_against_oracle(ctx):
+    """Random shapes and degenerate corners (tiny catalogues, k >= #unmasked, rows masked completely, F = 1, huge or tiny
+    scores, constant columns): every eligible algorithm must return the oracle's lists bit for bit."""
+    rs = np.random.RandomState(2024)
+    corner = [dict(U=3, I=1, F=1, k=1), dict(U=70, I=5, F=3, k=10), dict(U=65, I=64, F=16, k=64), dict(U=33, I=63, F=7, k=5),
+              dict(U=129, I=65, F=130, k=12), dict(U=200, I=12288, F=24, k=9), dict(U=90, I=12287, F=40, k=13)]
+    cases = corner + [dict(U=int(rs.randint(1, 400)), I=int(rs.choice([rs.randint(1, 300), rs.randint(300, 6000)])),
+                           F=int(rs.choice([1, 2, 5, 8, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 300])),
+                           k=int(rs.choice([1, 2, 5, 10, 11, 20, 37, 64, 100, 128]))) for _ in range(28)]
+    for n, c in enumerate(cases):
+        U, I, F, k = c["U"], c["I"], c["F"], c["k"]
+        scale = float(rs.choice([1e-3, 1.0, 50.0]))
+        Gu = (rs.normal(size=(U, F)) * scale).astype(np.float32)
+        Gi = (rs.normal(size=(I, F)) * scale).astype(np.float32)
+        if n % 3 == 0 and I > 4:
+            Gi[rs.randint(0, I, size=max(1, I // 3))] = Gi[0]            # many exact ties
+        Bi = None if n % 4 == 0 else (rs.normal(size=I) * scale).astype(np.float32)
+        hi = int(rs.choice([0, 3, min(I, 40), I]))
+        excl = random_excl(rs, U, I, 0, hi)
+        if n % 5 == 0 and U > 2:                                          # a user with everything masked
+            rows = [excl[1][excl[0][u]:excl[0][u + 1]] for u in range(U)]
+            rows[1] = np.arange(I, dtype=np.int32)
+            ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+            excl = (ip, np.concatenate(rows).astype(np.int32))
+        ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+        algos = ["simple"]
+        if F <= 256 and k <= 40:
+            algos.append("mfma")
+        if F <= 256 and k <= 128:
+            algos += ["screen", "auto"]
+        for algo in algos:
+            gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo=algo)
+            assert_topk_equal(f"fuzz_{n}_{algo}_U{U}_I{I}_F{F}_k{k}", gi, gv, ei, ev)
