@@ -11,23 +11,27 @@
 //   If T is ANY value such that k unmasked items have s' >= T, every member of the exact top-k has s' >= T - 2 E_u.
 //        (k items have s >= T - E_u, so the k-th exact score s_(k) >= T - E_u, and a member has s' >= s - E_u.)
 //
-// Selection in a stream is VALU work that the 16x faster matrix cores no longer hide, so the pass is done twice:
+// Selection in a stream is VALU work that the 16x faster matrix cores no longer hide, so the catalogue is passed twice:
 //
-//   pass 1  k_screen_pass<MODE 1>  s' for all (user, item) pairs; the only epilogue is a running max per ACCUMULATOR
-//           POSITION: item tile row (64 of them) -> 64 disjoint item groups per user, one max each ("slot maxima").
+//   pass 1  k_screen_pass<MODE 1>  s' for (user, item) pairs over every stride-th item tile; the only epilogue is a running
+//           max per ACCUMULATOR POSITION: item tile row (64 of them) -> 64 disjoint item groups per user ("slot maxima").
 //   thr     k_screen_thr           per user: slots whose maximum may belong to a masked (train) item are dropped -- the
-//           masked items are few, their s' is recomputed on the VALU and compared with a tolerance; T = k-th largest
-//           surviving slot maximum (k distinct unmasked items reach it), thr = T - 2 E_u.  T is the ~(k+2)-th best score
-//           of the catalogue, so the window holds k + a few items.
-//   pass 2  k_screen_pass<MODE 2>  the same GEMM (bit-identical s'), epilogue = max over the 16 accumulators of a lane
-//           against the FINAL threshold; the rare hit is appended to the user's list (64 + nnz_u slots, masked or not).
-//   final   k_screen_final         per user: drop masked hits, exact fp32 chain for the survivors, sort, write.
-//   Users with fewer than k clean slots, a non-finite bound, or more than 64 unmasked hits (pathological ties) are
-//   flagged and recomputed by the wave-per-user kernel, so the result is exact for every input.
+//           masked items of the best slots are re-scored on the VALU and compared with a tolerance; T = kA-th largest
+//           surviving slot maximum, thr = T - 2 E_u.  With stride 1 and kA = k, T is RIGOROUS (k distinct unmasked items
+//           reach it); otherwise T is a GUESS aimed at rank ~3k that k_screen_final verifies (screen_policy below).
+//   pass 2  k_screen_pass<MODE 2>  the GEMM over every tile (bit-identical s'), epilogue = max over the 16 accumulators of a
+//           lane against thr; the rare hit appends one record (tile, row block, row mask) + its s' to the user's list
+//           (surv + nnz_u slots, masked or not).
+//   final   k_screen_final         per user: expand records, drop masked items, second-level screen on the recorded s',
+//           exact fp32 chain for what is left, sort, VERIFY: k candidates with an exact score >= T - E_u prove that no
+//           non-candidate (s' < T - 2 E_u, hence exact < T - E_u) belongs to the top-k; write.
+//   Users that fail the verification, have fewer than kA clean slots, a non-finite bound, or more than `surv` unmasked hits
+//   are flagged and recomputed exactly (el_topk_run_list in el_topk.hip), so the result is exact for every input.
 //
-// Geometry of a pass: 512 threads = 8 waves, 64 users per wave (2 MFMA column blocks) -> 512 users per workgroup share
-// one 64-item bf16 tile.  A operand (items): 16 B per lane straight out of an XOR-swizzled LDS image (conflict-free
-// ds_read_b128); B operand (users): resident in VGPRs for the whole kernel.
+// Geometry of a pass: 512 threads = 8 waves, 64 users per wave (2 MFMA column blocks; 1 above 128 factors) -> 512 users per
+// workgroup share the staged 64-item bf16 tiles.  A operand (items): 16 B per lane straight out of an XOR-swizzled LDS
+// image (conflict-free ds_read_b128); B operand (users): resident in VGPRs for the whole kernel; bias = C operand of the
+// first MFMA of a chain; MFMA of one half tile is issued under the VALU epilogue of the other.
 #include <stdio.h>
 #include <stdlib.h>
 #include "el_topk_common.h"
