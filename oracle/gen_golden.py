@@ -8,6 +8,7 @@ is written there).  The reference modules are loaded BY FILE PATH because import
   bprmf_sgd_trace.npz   MFModel init + N sequential update_factors calls (BPRMF_model.py:40-56,91-117)
   bprmf_sgd_topk.npz    MFModel.get_user_predictions (BPRMF_model.py:70-85)
   ndcg_ref.npz          elliot.evaluation nDCG/Precision/Recall/HR on fixed recs (evaluator oracle)
+  bprmf_e2e_ref.npz     one epoch of the reference BPRMF loop + its recommendations; bprmf_ref_weights.pkl = its checkpoint
 
 Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
 """
@@ -154,6 +155,8 @@ def gen_bprmf_end_to_end(cs, mfm):
                         lists_items=li, P=model._user_factors, Q=model._item_factors, b=model._item_bias,
                         rec_idx=ridx, rec_val=rval, stream=np.asarray(stream, np.int32), factors=F, k=k)
     print("bprmf_e2e_ref.npz: reference epoch of", T, "triplets,", U, "users")
+    # the reference's own checkpoint of that model (MFModel.save_weights, BPRMF_model.py:133-139): on-disk format fixture
+    model.save_weights(os.path.join(OUT, "bprmf_ref_weights.pkl"))
 
 
 def gen_splitter():

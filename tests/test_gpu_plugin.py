@@ -319,6 +319,35 @@ def test_bprmf_plugin_with_replay_sampler_reproduces_the_reference_run(ctx, tmp_
         assert np.allclose([s for _, s in recs[u]], g["rec_val"][u], rtol=0, atol=1e-12)
 
 
+def test_reference_checkpoint_loads_and_recommends_identically(ctx, tmp_path, golden):
+    """On-disk format: a checkpoint written by the REFERENCE's MFModel.save_weights (BPRMF_model.py:119-139,
+    fixture tests/golden/bprmf_ref_weights.pkl from oracle/gen_golden.py) restores into our model and yields the
+    reference's own recommendation lists; our save_weights writes the same dict layout."""
+    import pickle
+    g = golden("bprmf_e2e_ref.npz")
+    ref_ckpt = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bprmf_ref_weights.pkl")
+    U, I = g["P"].shape[0], g["Q"].shape[0]
+    cfg = default_config(top_k=10, cutoffs=[10], simple_metrics=["nDCG"], out_dir=str(tmp_path))
+    os.makedirs(cfg.path_output_rec_weight, exist_ok=True)
+    test = (np.array([0]), np.array([0]), np.array([1.0]))
+    data = DataSet(cfg, (g["train_u"], g["train_i"], g["train_r"]), test, public_users=np.arange(U), public_items=np.arange(I))
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=1, factors=int(g["factors"]), seed=7)
+    model = BPRMF(data=data, config=cfg, params=params)                    # different seed: untrained, unrelated weights
+    model._model.load_weights(ref_ckpt)
+    _, recs = model.get_recommendations(10)
+    for u in range(U):
+        assert [it for it, _ in recs[u]] == g["rec_idx"][u].tolist(), u
+        assert np.allclose([s for _, s in recs[u]], g["rec_val"][u], rtol=0, atol=1e-12)
+    out = os.path.join(str(tmp_path), "ours.pkl")
+    model._model.save_weights(out)
+    ours, theirs = pickle.load(open(out, "rb")), pickle.load(open(ref_ckpt, "rb"))
+    assert set(ours.keys()) == set(theirs.keys())
+    for k in theirs:
+        assert np.asarray(ours[k]).shape == np.asarray(theirs[k]).shape and np.asarray(ours[k]).dtype == np.asarray(theirs[k]).dtype, k
+        if k != "_user_bias":
+            assert np.array_equal(np.asarray(ours[k]), np.asarray(theirs[k])), k
+
+
 def test_device_metrics_path_equals_host_evaluator(ctx, tmp_path):
     """Without save_recs, evaluate() computes the metrics on the device from the [users, k] index tensors
     (el_rec_metrics); the numbers must be those of the host evaluator on the same lists."""
