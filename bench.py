@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--opt", default="adam_tf_dense", choices=["adam_tf_dense", "adam_lazy", "sgd"])
     ap.add_argument("--train-algo", default="auto", choices=["auto", "atomic", "sorted"])
     ap.add_argument("--topk-algo", default="auto", choices=["auto", "screen", "mfma", "simple"])
+    ap.add_argument("--shard", default="user", choices=["user", "item"],
+                    help="N > 1: shard the USER table (item table replicated, all-reduce of item gradients) or the ITEM table "
+                         "(north_star's formulation: user table replicated, user-gradient exchange per --exchange)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "dense"],
                     help="N > 1: how user-row gradients travel (parallel.pick_exchange)")
     ap.add_argument("--topk-shard", default="user", choices=["user", "item"],
@@ -214,6 +217,25 @@ def main():
             sampler.release(b)
 
         pop_loss = st.pop_loss
+    elif args.shard == "user":
+        # USER shards: the rank owns the user rows [ulo, uhi) and a replica of the item table; B triplets per rank for its
+        # own users (items: the whole catalogue, the reference's sampling distribution), all-reduce of the item gradients
+        ulo, uhi = parallel.user_range(U, rank, world)
+        uip = (indptr[ulo:uhi + 1] - indptr[ulo]).contiguous()
+        uix = indices[int(indptr[ulo]):int(indptr[uhi])].contiguous()
+        pos_train = ops.DeviceCSR.from_tensors(uip, uix, I)
+        be = parallel.HipUserShardBackend(ctx, Gu[ulo:uhi], Gi, Bi, optimizer=args.opt)
+        trainer = parallel.ShardedBprmfByUser(be, coll)
+        st = be.state
+        exchange_used[0] = "user"
+        sampler = PrefetchSampler(ctx, pos_train, B, 42 + rank, enabled=args.prefetch)
+
+        def train_step():
+            t, b = sampler.next()
+            trainer.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+            sampler.release(b)
+
+        pop_loss = trainer.pop_loss
     else:
         # item-sharded training: B triplets PER RANK with positive and negative inside the rank's shard, all-gather of
         # the per-triplet user-gradient rows, identical user-table replicas (elliot_amd/parallel.py)
@@ -246,7 +268,8 @@ def main():
     blk = [0]
 
     sharded = world > 1 or args.force_sharded
-    topk_by_user = sharded and args.topk_shard == "user"
+    user_sharded = sharded and args.shard == "user"
+    topk_by_user = sharded and args.topk_shard == "user" and not user_sharded
     full_items = {}
 
     def prepare_topk():
@@ -257,7 +280,17 @@ def main():
                 finish_train()
             full_items["Gi"], full_items["Bi"] = parallel.gather_item_table(coll, st.Gi, st.Bi, I)
 
-    if topk_by_user:
+    if user_sharded:
+        # the rank owns its users' rows and a replica of the item table: top-k of ITS users, no collective at all
+        n_local = st.U
+        Ub = min(Ub, n_local)
+        n_blocks = max(1, n_local // Ub)
+
+        def topk_step():
+            s = (blk[0] % n_blocks) * Ub
+            blk[0] += 1
+            ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s, s + Ub, k, excl=pos_train, algo=args.topk_algo)
+    elif topk_by_user:
         # users are independent units: each rank scores ITS blocks of users against the whole catalogue
         def topk_step():
             s = ((blk[0] * world + rank) % n_blocks) * Ub
@@ -310,7 +343,7 @@ def main():
         return
     # ---------------- metrics ---------------------------------------------------------------------
     pairs_per_s = world * B * K / dt_train            # B triplets per rank and step
-    users_per_s = (world if topk_by_user else 1) * Ub * K / dt_topk
+    users_per_s = (world if (topk_by_user or user_sharded) else 1) * Ub * K / dt_topk
 
     # HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.md), valid for the default workload only
     traffic = {}
@@ -327,10 +360,12 @@ def main():
         return name, rep[name][1] / rep[name][0] * 1e-3   # seconds per launch
 
     # train roofline: algorithmic bytes of the dominant kernel (DESIGN.md "algorithmic bytes")
-    n_params = (U + (hi - lo)) * F + (hi - lo)
+    rows_u, rows_i = int(st.Gu.shape[0]), int(st.Gi.shape[0])  # what this rank's optimiser pass actually covers
+    if exchange_used[0] == "dense":
+        rows_u = be.Us
     alg = {
-        "k_adam_dense_Gu": 24.0 * U * F,                      # theta, m, v read + write
-        "k_adam_dense_Gi": 24.0 * (hi - lo) * F,
+        "k_adam_dense_Gu": 24.0 * rows_u * F,                 # theta, m, v read + write
+        "k_adam_dense_Gi": 24.0 * rows_i * F,
         "k_bprmf_fwd_bwd": B * (24.0 * F + 28.0),             # 3 rows read + 3 gradient rows written (+ idx, bias)
         "k_bpr_user_seg": B * (16.0 * F + 28.0),              # gamma_u, gamma_i, gamma_j read + dGu row written
         "k_bpr_item_seg": 2.0 * B * (8.0 * F + 12.0),         # gamma_u(b) read + dGi row written, per occurrence
@@ -349,7 +384,7 @@ def main():
     # kernel, or one of the two bf16 passes of the screened kernel (the other pass repeats the same flops; results are
     # re-scored in fp32 and bit-identical)
     tn, tsec = dominant(rep_topk)
-    flops = 2.0 * Ub * (I if topk_by_user else (hi - lo)) * F
+    flops = 2.0 * Ub * (I if (topk_by_user or user_sharded) else (hi - lo)) * F
     ach_t = flops / tsec / 1e12
     screened = tn.startswith("k_screen")
     peak_t = MFMA_BF16_PEAK_TFLOPS if screened else MFMA_F32_PEAK_TFLOPS
@@ -369,6 +404,8 @@ def main():
                    "users": U, "items": I, "factors": F, "interactions": int(pos.nnz), "batch": B,
                    "batch_per_gpu": B, "optimizer": args.opt, "topk_block": Ub, "k": k,
                    "parallelism": "single" if world == 1 else
+                   (f"user-shard x{world}: train = {B} triplets/rank for the rank's own users (item table replicated) + "
+                    f"all-reduce of the item gradients ({I * (F + 1) * 4 / 1e6:.0f} MB)") if exchange_used[0] == "user" else
                    f"item-shard x{world}: train = {B} triplets/rank + "
                    + ("reduce-scatter of the dense user-gradient table, optimiser on U/G user rows, all-gather of the rows"
                       if exchange_used[0] == "dense" else "all-gather of user-gradient rows")
@@ -376,8 +413,10 @@ def main():
         "loss_per_pair_last": loss / (B * world * (K + W)),
         "roofline": roof_train,
         "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3,
-                 "scaling": "weak" if (topk_by_user or world == 1) else "strong",
+                 "scaling": "weak" if (topk_by_user or user_sharded or world == 1) else "strong",
                  "sharding": ("single" if not sharded else
+                              f"by user: each rank scores {Ub}-user blocks of the users it owns against its replica of the item table, no collective"
+                              if user_sharded else
                               f"by user: {Ub} users per rank and step vs the whole catalogue (item table all-gathered once per evaluation)"
                               if topk_by_user else f"by item: all users vs I/{world} items per rank + all-gather/merge of partial lists"),
                  "roofline": roof_topk},

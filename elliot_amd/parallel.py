@@ -1,4 +1,9 @@
-"""Item-sharded multi-GPU execution -- new design, the reference is single-device.
+"""Multi-GPU execution -- new design, the reference is single-device.
+
+Two ways to cut the BPR-MF step over G ranks live here: by USER (ShardedBprmfByUser: user rows sharded, item table
+replicated, all-reduce of the 51 MB item gradient; what bench.py uses) and by ITEM (north_star's formulation, below).
+
+Item shards:
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the MI355X node, "gloo" in the CPU
 tests).  Rank r owns the item range [lo_r, hi_r): its rows of Gi / Bi and their optimiser state; the user table is
@@ -274,6 +279,76 @@ class ShardedBprmfDense:
 
     def pop_loss(self):
         self.finish()
+        t = self.backend.local_loss_tensor()
+        tot = self.coll.all_reduce_sum(t.clone())
+        t.zero_()
+        return float(tot.item())
+
+
+def user_range(n_users, rank, world):
+    return (n_users * rank) // world, (n_users * (rank + 1)) // world
+
+
+class HipUserShardBackend:
+    """Product backend of the user-sharded step: the rank's user rows (+ their optimiser state) and a full replica of
+    the item table (+ identical optimiser state on every rank)."""
+
+    def __init__(self, ctx, Gu_shard, Gi, Bi, optimizer="adam_tf_dense"):
+        if optimizer not in ("adam", "adam_tf_dense", "sgd"):
+            raise ValueError("sharded training supports the dense optimisers (adam_tf_dense, sgd)")
+        self.ctx = ctx
+        self.state = ops.BprmfDeviceState(ctx, Gu_shard, Gi, Bi, optimizer="sgd_dense" if optimizer == "sgd" else optimizer)
+        self._ws = None
+
+    def grads(self, u_local, i, j, l_w, l_b):
+        import ctypes as C
+        st, ctx = self.state, self.ctx
+        B = u_local.numel()
+        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+        ops.check(ctx.lib.el_bprmf_grads(ctx.handle, ctx.stream(), C.byref(st._c), ops._ptr(u_local, torch.int32),
+                                         ops._ptr(i, torch.int32), ops._ptr(j, torch.int32), int(B), float(l_w), float(l_b),
+                                         int(st.step + 1), ops._ptr(st.loss, torch.float64), C.c_void_p(self._ws.data_ptr()),
+                                         self._ws.numel()), "el_bprmf_grads")
+
+    def item_grads(self):
+        return [self.state.gGi, self.state.gBi]
+
+    def apply(self, lr):
+        import ctypes as C
+        st, ctx = self.state, self.ctx
+        st.step += 1
+        ops.check(ctx.lib.el_bprmf_apply(ctx.handle, ctx.stream(), C.byref(st._c), float(lr), int(st.opt), int(st.step),
+                                         float(ops.adam_lr_t(lr, st.step))), "el_bprmf_apply")
+
+    def local_loss_tensor(self):
+        return self.state.loss
+
+
+class ShardedBprmfByUser:
+    """BPRMF_batch train step with the USER table sharded and the item table replicated -- the cheap way round when
+    U >> I (every BASELINE configuration: U / I = 10).  Rank r owns the user rows [ulo_r, uhi_r) with their optimiser
+    state and draws its B triplets for ITS users (u uniform in the shard, i in pos(u), j anywhere in the catalogue: over
+    the ranks that is exactly the reference's sampling distribution, custom_sampler.py:31-42 -- no shard-restricted
+    negatives).  User-row gradients never leave the rank; the item-side gradients gGi [I,F], gBi [I] are ALL-REDUCED
+    (RCCL, I F 4 bytes = 51 MB at C2, versus 2 (G-1)/G U F 4 = 0.9 GB for the user-gradient exchange of the item-sharded
+    forms) and every rank applies the same Adam step to its item replica.  G ranks x B triplets are one
+    reference-semantics step on the concatenated batch.  Full-catalogue top-k then needs no collective at all: each rank
+    scores the users it owns."""
+
+    def __init__(self, backend, coll=None):
+        self.backend = backend
+        self.coll = coll or _Collectives()
+
+    def train_step(self, u_local, i, j, lr, l_w, l_b):
+        be, coll = self.backend, self.coll
+        be.grads(u_local, i, j, l_w, l_b)
+        for g in be.item_grads():
+            coll.all_reduce_sum(g)
+        be.apply(lr)
+
+    def pop_loss(self):
         t = self.backend.local_loss_tensor()
         tot = self.coll.all_reduce_sum(t.clone())
         t.zero_()

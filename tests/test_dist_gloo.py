@@ -348,3 +348,85 @@ def test_neumf_sharded_step_world2_gloo():
     out = mgr.dict()
     mp.spawn(_nmf_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+class NumpyUserShardBackend:
+    """Stand-in for parallel.HipUserShardBackend: local user rows, full item replica."""
+
+    def __init__(self, Gu_shard, Gi, Bi):
+        self.Gu, self.Gi, self.Bi = Gu_shard.copy(), Gi.copy(), Bi.copy()
+        z = np.zeros_like
+        self.gGu = z(self.Gu)
+        self.gGi, self.gBi = torch.zeros(Gi.shape, dtype=torch.float32), torch.zeros(Bi.shape, dtype=torch.float32)
+        self.m = [z(self.Bi), z(self.Gu), z(self.Gi)]
+        self.v = [z(self.Bi), z(self.Gu), z(self.Gi)]
+        self.loss = torch.zeros(1, dtype=torch.float64)
+        self.t = 0
+
+    def grads(self, u, i, j, l_w, l_b):
+        u, i, j = (x.numpy().astype(np.int64) for x in (u, i, j))
+        self.loss += float(ob.forward_loss(self.Gu, self.Gi, self.Bi, u, i, j, l_w, l_b))
+        dBi, dGu, dGi = ob.gradients(self.Gu, self.Gi, self.Bi, u, i, j, l_w, l_b)
+        self.gGu += dGu
+        self.gGi += torch.from_numpy(dGi.astype(np.float32))
+        self.gBi += torch.from_numpy(dBi.astype(np.float32))
+
+    def item_grads(self):
+        return [self.gGi, self.gBi]
+
+    def apply(self, lr):
+        self.t += 1
+        for th, g, m, v in zip((self.Bi, self.Gu, self.Gi), (self.gBi.numpy(), self.gGu, self.gGi.numpy()), self.m, self.v):
+            ob.adam_tf_sparse_apply(th, m, v, g, lr, self.t)
+            g[:] = 0
+
+    def local_loss_tensor(self):
+        return self.loss
+
+
+def _user_shard_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(2)
+        U, I, F, B = 61, 80, 8, 96
+        Gu = rs.normal(scale=0.1, size=(U, F)).astype(np.float32)
+        Gi = rs.normal(scale=0.1, size=(I, F)).astype(np.float32)
+        Bi = rs.normal(scale=0.01, size=I).astype(np.float32)
+        ulo, uhi = parallel.user_range(U, rank, world)
+        be = NumpyUserShardBackend(Gu[ulo:uhi], Gi, Bi)
+        tr = parallel.ShardedBprmfByUser(be, parallel._Collectives())
+        ref = ob.BPRMFBatchOracle(Gu, Gi, Bi, 0.01, 0.1, 0.001)
+        for step in range(3):
+            batches = []
+            for r in range(world):
+                brs = np.random.RandomState(400 + 10 * step + r)
+                l, h = parallel.user_range(U, r, world)
+                batches.append((brs.randint(l, h, B), brs.randint(0, I, B), brs.randint(0, I, B)))   # items: whole catalogue
+            u, i, j = batches[rank]
+            tr.train_step(torch.from_numpy((u - ulo).astype(np.int32)), torch.from_numpy(i.astype(np.int32)),
+                          torch.from_numpy(j.astype(np.int32)), 0.01, 0.1, 0.001)
+            loss = tr.pop_loss()
+            cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+            ref_loss = ref.train_step((cu, ci, cj))
+            assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss), (loss, ref_loss)
+            assert np.abs(be.Gu - ref.Gu[ulo:uhi]).max() < 2e-6
+            assert np.abs(be.Gi - ref.Gi).max() < 2e-6 and np.abs(be.Bi - ref.Bi).max() < 2e-6
+        t = torch.from_numpy(be.Gi.copy())                           # item replicas bit-identical across ranks
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_user_sharded_training_world2_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_user_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}
+    assert [parallel.user_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]

@@ -251,6 +251,43 @@ def test_item_sharded_dense_exchange_hip_path_equals_concatenated_batch(ctx):
             assert not cpu(be.state.gGu).any() and not cpu(be.state.gGi).any() and not cpu(be.g_own).any()
 
 
+def test_user_sharded_hip_path_equals_concatenated_batch(ctx):
+    """User shards (parallel.ShardedBprmfByUser) with two virtual ranks on one GPU: local user rows, full item replicas,
+    the all-reduce of the item gradients emulated with a torch add: one reference-semantics step on the concatenated batch,
+    item replicas bit-identical."""
+    from elliot_amd import parallel
+    rs = np.random.RandomState(33)
+    U, I, F, B, G = 701, 400, 64, 3000, 2
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    d = ctx.device
+    rng = [parallel.user_range(U, r, G) for r in range(G)]
+    bes = [parallel.HipUserShardBackend(ctx, Gu[lo:hi], Gi, Bi, optimizer="adam_tf_dense") for lo, hi in rng]
+    orc = ob.BPRMFBatchOracle(Gu, Gi, Bi, lr, l_w, l_b)
+    for step in range(3):
+        batches = [(rs.randint(lo, hi, B), rs.randint(0, 25, B), rs.randint(0, I, B)) for lo, hi in rng]    # hot positives
+        for be, (lo, hi), (u, i, j) in zip(bes, rng, batches):
+            be.grads(torch.from_numpy((u - lo).astype(np.int32)).to(d), torch.from_numpy(i.astype(np.int32)).to(d),
+                     torch.from_numpy(j.astype(np.int32)).to(d), l_w, l_b)
+        for gs in zip(*[be.item_grads() for be in bes]):             # the all-reduce
+            tot = gs[0] + gs[1]
+            for g in gs:
+                g.copy_(tot)
+        loss = 0.0
+        for be in bes:
+            be.apply(lr)
+            loss += be.state.pop_loss()
+        cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+        exp = orc.train_step((cu, ci, cj))
+        assert abs(loss - exp) <= 1e-4 * abs(exp), (step, loss, exp)
+        assert torch.equal(bes[0].state.Gi, bes[1].state.Gi) and torch.equal(bes[0].state.Bi, bes[1].state.Bi)
+        assert (np.abs(cpu(bes[0].state.Gi) - orc.Gi) > 2e-5).mean() < 2e-4
+        assert (np.abs(cpu(bes[0].state.Bi) - orc.Bi) > 2e-5).mean() < 2e-3
+        for be, (lo, hi) in zip(bes, rng):
+            assert (np.abs(cpu(be.state.Gu) - orc.Gu[lo:hi]) > 2e-5).mean() < 2e-4
+            assert not cpu(be.state.gGu).any() and not cpu(be.state.gGi).any()
+
+
 # ---------------------------------------------------------------------------------- exact MT19937 replay
 def test_mt19937_replay_sampler_equals_reference_stream(ctx, golden):
     """The reference's own custom_sampler.Sampler output (tests/golden/sampler_ref.npz, seed 42, batches of 512)."""
