@@ -456,7 +456,12 @@ static int launch_rows_apply(const el_bprmf_state& st, const int32_t* u, const i
 
 static unsigned stream_grid(el_ctx* ctx, int64_t n_threads) {
     int64_t blocks = (n_threads + 255) / 256;
-    int64_t cap = (int64_t)ctx->cus * 8;
+    static const int mult = [] {
+        const char* e = getenv("EL_STREAM_GRID_MULT");      // workgroups per CU of the streaming passes (experiments)
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 64) ? v : 8;
+    }();
+    int64_t cap = (int64_t)ctx->cus * mult;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
