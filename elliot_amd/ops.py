@@ -746,9 +746,11 @@ class NmfDeviceState:
         check(self.ctx.lib.el_nmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self.step),
                                         float(adam_lr_t(lr, self.step))), "el_nmf_apply")
 
-    def replicated_grads(self):
-        """Gradient tensors of the variables every rank holds a full copy of: user tables, Dense layers, head."""
-        out = [g for t, g in zip((0, 2), (self.gtab[0], self.gtab[2])) if g is not None]
+    def replicated_grads(self, shard="user"):
+        """Gradient tensors of the variables every rank holds a full copy of: Dense layers, head, and the embedding tables
+        that are NOT sharded -- the item tables with user shards (shard="user"), the user tables with item shards."""
+        keep = (1, 3) if shard == "user" else (0, 2)
+        out = [self.gtab[t] for t in keep if self.gtab[t] is not None]
         out += list(self.gW) + list(self.gb) + [self.ghw]
         if self.head_bias:
             out.append(self.ghb)

@@ -389,24 +389,33 @@ class ShardedBprmf:
 # NeuMF / GMF: data parallel over samples, item tables sharded, RCCL all-reduce of the shared gradients
 # ------------------------------------------------------------------------------------------------------
 class ShardedNmf:
-    """One NeuMF / GMF step over G ranks.  Rank r owns the item rows [lo_r, hi_r) of both item tables (+ their Adam
-    state) and draws its n samples with the item inside its shard; user tables, Dense layers and the head are replicated.
-    Per step: el_nmf_grads with the BinaryCrossentropy mean over the GLOBAL batch (sum of all ranks' n) -> RCCL
-    all-reduce (sum) of the gradients of the replicated variables -> el_nmf_apply (Keras Adam) on every rank: G ranks x n
-    samples are exactly one reference-semantics step on the concatenated batch, and the replicas stay identical because
-    every rank applies the same reduced gradients.  `backend` = ops.NmfDeviceState built from weights whose "Imf" /
-    "Imlp" hold only the local shard (item ids passed in are shard-local), or a stand-in with the same four methods."""
+    """One NeuMF / GMF step over G ranks, data parallel over samples with one kind of embedding table sharded:
 
-    def __init__(self, backend, coll=None):
+      shard="user" (default)  rank r owns the rows [ulo_r, uhi_r) of both USER tables (+ Adam state) and draws its samples
+                              for its own users (any item: the reference's sampling distribution); item tables, Dense
+                              layers and head are replicated.  All-reduced per step: 2 I F 4 bytes + the MLP.
+      shard="item"            north_star's formulation: item rows sharded, samples restricted to the shard's items, user
+                              tables replicated (2 U F 4 bytes all-reduced per step -- 10x more when U = 10 I).
+
+    Per step: el_nmf_grads with the BinaryCrossentropy mean over the GLOBAL batch (sum of all ranks' n) -> RCCL all-reduce
+    (sum) of the gradients of the replicated variables -> el_nmf_apply (Keras Adam) on every rank: G ranks x n samples are
+    exactly one reference-semantics step on the concatenated batch, and the replicas stay identical because every rank
+    applies the same reduced gradients.  `backend` = ops.NmfDeviceState built from weights whose sharded tables hold only
+    the local rows (ids of that kind passed in are shard-local), or a stand-in with the same four methods."""
+
+    def __init__(self, backend, coll=None, shard="user"):
+        if shard not in ("user", "item"):
+            raise ValueError("shard must be 'user' or 'item'")
         self.backend = backend
         self.coll = coll or _Collectives()
+        self.shard = shard
 
-    def train_step(self, u, i_local, label, lr, n_global=None):
+    def train_step(self, u, i, label, lr, n_global=None):
         be, coll = self.backend, self.coll
         if n_global is None:
             n_global = coll.world * int(u.shape[0])
-        be.grads(u, i_local, label, n_global)
-        for g in be.replicated_grads():
+        be.grads(u, i, label, n_global)
+        for g in be.replicated_grads(self.shard):
             coll.all_reduce_sum(g)
         be.apply(lr)
 

@@ -277,8 +277,8 @@ class NumpyNmfBackend:
         self.g = {k: ([torch.from_numpy((x * scale).astype(np.float32)) for x in v] if isinstance(v, list)
                       else torch.from_numpy((v * scale).astype(np.float32))) for k, v in g.items()}
 
-    def replicated_grads(self):
-        out = [self.g[k] for k in ("Umf", "Umlp") if k in self.g]
+    def replicated_grads(self, shard="user"):
+        out = [self.g[k] for k in (("Imf", "Imlp") if shard == "user" else ("Umf", "Umlp")) if k in self.g]
         out += list(self.g.get("W", [])) + list(self.g.get("b", [])) + [self.g["hw"]]
         if "hb" in self.g:
             out.append(self.g["hb"])
@@ -301,38 +301,45 @@ class NumpyNmfBackend:
             o._dense(o.w["hb"], o.m["hb"], o.v["hb"], npg(self.g["hb"]))
 
 
-def _nmf_worker(rank, world, port, out):
+def _nmf_worker(rank, world, port, out, shard="item"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import neumf as on
-        U, I, F, n = 40, 30, 8, 64
+        U, I, F, n = 41, 30, 8, 64
         w = on.init_neumf(U, I, F, seed=3)
-        lo, hi = parallel.item_range(I, rank, world)
+        by_user = shard == "user"
+        rng = (lambda r: parallel.user_range(U, r, world)) if by_user else (lambda r: parallel.item_range(I, r, world))
+        lo, hi = rng(rank)
         wl = {k: ([x.copy() for x in v] if isinstance(v, list) else v.copy()) for k, v in w.items()}
-        wl["Imf"], wl["Imlp"] = w["Imf"][lo:hi].copy(), w["Imlp"][lo:hi].copy()
+        for k in (("Umf", "Umlp") if by_user else ("Imf", "Imlp")):
+            wl[k] = w[k][lo:hi].copy()
         be = NumpyNmfBackend(wl, 0.01)
-        tr = parallel.ShardedNmf(be, parallel._Collectives())
+        tr = parallel.ShardedNmf(be, parallel._Collectives(), shard=shard)
         ref = on.NeuMFOracle(w, 0.01)
         for step in range(3):
             batches = []
             for r in range(world):
                 brs = np.random.RandomState(300 + 10 * step + r)
-                l, h = parallel.item_range(I, r, world)
-                batches.append((brs.randint(0, U, n), brs.randint(l, h, n), brs.randint(0, 2, n).astype(np.float32)))
+                l, h = rng(r)
+                us = brs.randint(l, h, n) if by_user else brs.randint(0, U, n)
+                its = brs.randint(0, I, n) if by_user else brs.randint(l, h, n)
+                batches.append((us, its, brs.randint(0, 2, n).astype(np.float32)))
             u, i, y = batches[rank]
-            tr.train_step(torch.from_numpy(u.astype(np.int32)), torch.from_numpy((i - lo).astype(np.int32)), torch.from_numpy(y), 0.01)
+            ul, il = (u - lo, i) if by_user else (u, i - lo)
+            tr.train_step(torch.from_numpy(ul.astype(np.int32)), torch.from_numpy(il.astype(np.int32)), torch.from_numpy(y), 0.01)
             loss = tr.pop_loss()
             cu, ci, cy = (np.concatenate([b[x] for b in batches]) for x in range(3))
             ref_loss = ref.train_step(cu, ci, cy)
             assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
             o = be.orc.w
-            assert np.abs(o["Umf"] - ref.w["Umf"]).max() < 3e-6 and np.abs(o["Umlp"] - ref.w["Umlp"]).max() < 3e-6
-            assert np.abs(o["Imf"] - ref.w["Imf"][lo:hi]).max() < 3e-6 and np.abs(o["Imlp"] - ref.w["Imlp"][lo:hi]).max() < 3e-6
+            su, si = (slice(lo, hi), slice(None)) if by_user else (slice(None), slice(lo, hi))
+            assert np.abs(o["Umf"] - ref.w["Umf"][su]).max() < 3e-6 and np.abs(o["Umlp"] - ref.w["Umlp"][su]).max() < 3e-6
+            assert np.abs(o["Imf"] - ref.w["Imf"][si]).max() < 3e-6 and np.abs(o["Imlp"] - ref.w["Imlp"][si]).max() < 3e-6
             for a, b in zip(o["W"] + o["b"] + [o["hw"]], ref.w["W"] + ref.w["b"] + [ref.w["hw"]]):
                 assert np.abs(a - b).max() < 3e-6
-        t = torch.from_numpy(be.orc.w["Umlp"].copy())
+        t = torch.from_numpy(be.orc.w["Imlp" if by_user else "Umlp"].copy())       # a replicated table: identical everywhere
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         assert all(torch.equal(gathered[0], g) for g in gathered)
@@ -341,12 +348,13 @@ def _nmf_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_neumf_sharded_step_world2_gloo():
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("shard", ["user", "item"])
+def test_neumf_sharded_step_world2_gloo(shard):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_nmf_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_nmf_worker, args=(2, port, out, shard), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
 
 

@@ -100,7 +100,7 @@ def test_neumf_item_sharded_hip_path_equals_concatenated_batch(ctx):
         for st, (lo, hi), (u, i, y) in zip(sts, rng, batches):
             st.grads(torch.from_numpy(u.astype(np.int32)).to(d), torch.from_numpy((i - lo).astype(np.int32)).to(d),
                      torch.from_numpy(y).to(d), n_global=G * n)
-        lists = [st.replicated_grads() for st in sts]
+        lists = [st.replicated_grads("item") for st in sts]
         for gs in zip(*lists):                                   # the all-reduce
             tot = gs[0] + gs[1]
             for g in gs:
