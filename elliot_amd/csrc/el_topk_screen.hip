@@ -737,7 +737,7 @@ size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, i
 
 template <int FP, int MODE, int NW, bool PROF>
 static int launch_pass(const ScreenParams& sp, hipStream_t st) {
-    constexpr int NSUB = (MODE == 2 && FP <= 128) ? 2 : 1;   // pass 2: two tiles per barrier average out the record path (-8 %)
+    constexpr int NSUB = (MODE == 2 && FP <= 128) ? 4 : 1;   // pass 2: four tiles per barrier average out the record path (-10 %)
     constexpr int UB = FP <= 128 ? 2 : 1;                    // FP = 256: the resident user fragments allow 32 users per wave
     constexpr size_t lds = (size_t)NSUB * (2 * SCR_TI * FP * 2 + 4 * SCR_TI * 4);
     auto kern = k_screen_pass<FP, MODE, NW, NSUB, UB, PROF>;
