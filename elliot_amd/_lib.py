@@ -73,6 +73,20 @@ class NmfState(C.Structure):
     ]
 
 
+class PwmfState(C.Structure):
+    _fields_ = [
+        ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32), ("kind", C.c_int32), ("alpha", C.c_float), ("l_w", C.c_float),
+        ("Gu", _f32p), ("Gi", _f32p), ("Bu", _f32p), ("Bi", _f32p),
+        ("gGu", _f32p), ("gGi", _f32p), ("gBu", _f32p), ("gBi", _f32p),
+        ("mGu", _f32p), ("mGi", _f32p), ("mBu", _f32p), ("mBi", _f32p),
+        ("vGu", _f32p), ("vGi", _f32p), ("vBu", _f32p), ("vBi", _f32p),
+    ]
+
+
+EL_PW_MSE, EL_PW_MSE_SIGMOID, EL_PW_LOGISTIC = 0, 1, 2
+EL_PW_ADAM, EL_PW_ADAGRAD = 0, 1
+EL_PW_BOTH, EL_PW_ITEMS, EL_PW_USERS = 0, 1, 2
+
 # name -> (restype, argtypes); mirrors include/elliot_hip.h one to one
 PROTOTYPES = {
     "el_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -128,6 +142,12 @@ PROTOTYPES = {
     "el_nmf_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_int32, C.c_float]),
     "el_nmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, _f32p, C.c_int64,
                                     C.c_int32, C.c_float, _f64p]),
+    "el_pwmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "el_pwmf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, C.c_int64, _f32p]),
+    "el_pwmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, _f32p, C.c_int64, C.c_int,
+                                     C.c_int, C.c_int32, C.c_float, _f64p, C.c_void_p, C.c_size_t]),
+    "el_pwmf_link_values": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int32, C.c_int, _f32p,
+                                      C.c_int64]),
     "el_dense_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p]),
 }

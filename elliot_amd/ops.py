@@ -768,3 +768,139 @@ class NmfDeviceState:
         v = float(self.loss.item())
         self.loss.zero_()
         return v
+
+
+# ------------------------------------------------------------------------------------------
+# point-wise factor models: MF, PMF, FunkSVD, LogisticMF
+# ------------------------------------------------------------------------------------------
+PW_KINDS = {"mse": _lib.EL_PW_MSE, "mse_sigmoid": _lib.EL_PW_MSE_SIGMOID, "logistic": _lib.EL_PW_LOGISTIC}
+PW_OPTS = {"adam": _lib.EL_PW_ADAM, "adagrad": _lib.EL_PW_ADAGRAD}
+PW_SIDES = {"both": _lib.EL_PW_BOTH, "items": _lib.EL_PW_ITEMS, "users": _lib.EL_PW_USERS}
+_PW_MARGIN, _PW_MAX_LIST, _PW_DENSE_ROWS = 16, 4032, 4096
+
+
+class PwmfDeviceState:
+    """Variables + optimiser slots of one point-wise factor model in HBM (include/elliot_hip.h, el_pwmf_state).
+
+    Gu [U,F], Gi [I,F], optional biases Bu [U] / Bi [I] (both or neither); kind: "mse" (MF, FunkSVD), "mse_sigmoid"
+    (PMF), "logistic" (LogisticMF, with alpha / l_w); optimizer "adam" (TF sparse-apply semantics) or "adagrad"."""
+
+    def __init__(self, ctx, Gu, Gi, Bu=None, Bi=None, kind="mse", optimizer="adam", alpha=0.0, l_w=0.0):
+        self.ctx, dev = ctx, ctx.device
+        f = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        if (Bu is None) != (Bi is None):
+            raise ValueError("Bu and Bi go together")
+        self.Gu, self.Gi, self.Bu, self.Bi = f(Gu), f(Gi), f(Bu), f(Bi)
+        if self.Bu is not None:
+            self.Bu, self.Bi = self.Bu.reshape(-1).contiguous(), self.Bi.reshape(-1).contiguous()
+        self.U, self.F = self.Gu.shape
+        self.I = self.Gi.shape[0]
+        self.kind, self.optimizer = kind, optimizer
+        self.alpha, self.l_w = float(alpha), float(l_w)
+        adam = optimizer == "adam"
+        z = lambda t: None if t is None else torch.zeros_like(t)
+        slot = (lambda t: z(t)) if adam else (lambda t: None if t is None else torch.full_like(t, 0.1))
+        names = ("Gu", "Gi", "Bu", "Bi")
+        for n in names:
+            t = getattr(self, n)
+            setattr(self, "g" + n, z(t))
+            setattr(self, "m" + n, slot(t))
+            setattr(self, "v" + n, z(t) if adam else None)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.step = 0
+        self._ws = None
+        p = lambda t: None if t is None else t.data_ptr()
+        self._c = _lib.PwmfState(U=self.U, I=self.I, F=self.F, kind=PW_KINDS[kind], alpha=self.alpha, l_w=self.l_w,
+                                 **{pre + n: p(getattr(self, pre + n)) for pre in ("", "g", "m", "v") for n in names})
+
+    def _workspace(self, n):
+        need = int(self.ctx.lib.el_pwmf_ws_bytes(int(n), int(self.U), int(self.I)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+        return C.c_void_p(self._ws.data_ptr()), need
+
+    def train_step(self, u, i, label, lr, side="both"):
+        self.step += 1
+        n = u.numel()
+        ws, need = self._workspace(n)
+        lr_t = adam_lr_t(lr, self.step) if self.optimizer == "adam" else float(lr)
+        check(self.ctx.lib.el_pwmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                              _ptr(i, torch.int32), _ptr(label, torch.float32), int(n),
+                                              PW_OPTS[self.optimizer], PW_SIDES[side], int(self.step), float(lr_t),
+                                              _ptr(self.loss, torch.float64), ws, need), "el_pwmf_train_step")
+
+    def forward(self, u, i, out=None):
+        n = u.numel()
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.ctx.device)
+        check(self.ctx.lib.el_pwmf_forward(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                           _ptr(i, torch.int32), int(n), _ptr(out, torch.float32)), "el_pwmf_forward")
+        return out
+
+    def pop_loss(self):
+        v = float(self.loss.item())
+        self.loss.zero_()
+        return v
+
+    def weights(self):
+        out = {"Gu": self.Gu.cpu().numpy(), "Gi": self.Gi.cpu().numpy(), "step": self.step}
+        if self.Bu is not None:
+            out["Bu"], out["Bi"] = self.Bu.cpu().numpy(), self.Bi.cpu().numpy()
+        for pre in ("m", "v"):
+            for n in ("Gu", "Gi", "Bu", "Bi"):
+                t = getattr(self, pre + n)
+                if t is not None:
+                    out[pre + n] = t.cpu().numpy()
+        return out
+
+    def load(self, d):
+        for key, val in d.items():
+            if key == "step":
+                self.step = int(val)
+            elif getattr(self, key, None) is not None:
+                getattr(self, key).copy_(torch.from_numpy(np.asarray(val, dtype=np.float32)).reshape(getattr(self, key).shape))
+
+    # -- full-catalogue scores -> masked top-k ------------------------------------------------------------------
+    def _link(self, vals, k, u_start):
+        check(self.ctx.lib.el_pwmf_link_values(self.ctx.handle, self.ctx.stream(), _ptr(vals, torch.float32),
+                                               int(vals.shape[0]), int(vals.stride(0)), int(k), PW_KINDS[self.kind],
+                                               _ptr(self.Bu, torch.float32), int(u_start)), "el_pwmf_link_values")
+
+    def recommend(self, u_start, u_stop, k, excl=None, cand=None):
+        """get_recs + get_top_k of the reference models (e.g. matrix_factorization.py:99-113 +
+        matrix_factorization_model.py:100-101) for users [u_start, u_stop): the fused scoring kernel ranks by
+        Bi[i] + <Gu[u], Gi[i]>; the model's score is link(that + Bu[u]) with a monotone link, so the ranking is the same
+        except where distinct raw scores round to ONE linked float -- tf.nn.top_k orders those by item index.  The list is
+        therefore taken `margin` entries longer, linked, re-ranked by (value desc, index asc) and cut; a row whose k-th
+        value still equals its last one is redone with a longer list (and, past 4032 entries, from dense scores)."""
+        plain = self.kind != "mse_sigmoid" and self.Bu is None
+        if plain:
+            return score_topk(self.ctx, self.Gu, self.Gi, None, u_start, u_stop, k, excl=excl, cand=cand)
+        kk = min(self.I, k + _PW_MARGIN)
+        while True:
+            idx, val = score_topk(self.ctx, self.Gu, self.Gi, self.Bi, u_start, u_stop, kk, excl=excl, cand=cand)
+            self._link(val, kk, u_start)
+            if kk >= self.I:
+                break
+            open_rows = (val[:, k - 1] == val[:, kk - 1]) & (val[:, k - 1] > float("-inf"))
+            if not bool(open_rows.any()):
+                break
+            if kk >= _PW_MAX_LIST:
+                return self._recommend_dense(u_start, u_stop, k, excl, cand)
+            kk = min(self.I, _PW_MAX_LIST, kk * 4)
+        order = torch.sort(idx, dim=1, stable=True).indices                       # index asc ...
+        val = torch.gather(val, 1, order)
+        by_val = torch.sort(val, dim=1, descending=True, stable=True)             # ... then value desc, stable
+        idx = torch.gather(torch.gather(idx, 1, order), 1, by_val.indices)
+        return idx[:, :k].contiguous(), by_val.values[:, :k].contiguous()
+
+    def _recommend_dense(self, u_start, u_stop, k, excl, cand):
+        out_i, out_v = [], []
+        for s in range(u_start, u_stop, _PW_DENSE_ROWS):
+            e = min(s + _PW_DENSE_ROWS, u_stop)
+            preds = gemm(self.ctx, self.Gu[s:e], self.Gi, transB=True, bias=self.Bi)
+            self._link(preds, self.I, s)
+            bi, bv = dense_topk(self.ctx, preds, s, e, k, excl=excl, cand=cand)
+            out_i.append(bi)
+            out_v.append(bv)
+        return torch.cat(out_i), torch.cat(out_v)

@@ -34,7 +34,8 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 2   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points */
+#define EL_ABI_VERSION 3   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
+                            * 3: el_pwmf_* (point-wise factor models)                                                    */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -378,6 +379,61 @@ int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const i
 int el_nmf_grads(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
                  const float* label, int64_t n, int64_t n_global, double* loss_out);
 int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step, float lr_t);
+
+/* ---- point-wise factor models: MF, PMF, FunkSVD, LogisticMF -----------------------------
+ * One kernel family for the reference's TF models that score a (user, item) sample with a dot product of two
+ * embedding rows (+ optional user / item bias), push it through a link, and fit it to the sampler's 0/1 label:
+ *   EL_PW_MSE          out = <Gu[u],Gi[i]> (+ Bu[u] + Bi[i]);  loss = mean_b (y - out)^2
+ *                      MF       latent_factor_models/MF/matrix_factorization_model.py:52-71   (no biases)
+ *                      FunkSVD  latent_factor_models/FunkSVD/funk_svd_model.py:62-85          (both biases)
+ *   EL_PW_MSE_SIGMOID  out = sigmoid(<Gu[u],Gi[i]>);           loss = mean_b (y - out)^2
+ *                      PMF      latent_factor_models/PMF/probabilistic_matrix_factorization_model.py:64-89
+ *                      (its GaussianNoise layer is called without training=True, hence inactive)
+ *   EL_PW_LOGISTIC     x = <Gu[u],Gi[i]> + Bu[u] + Bi[i];      loss = sum_b -(alpha y x - (1 + alpha y) softplus(x))
+ *                                                                     + l_w (|Gu[u_b]|^2 + |Gi[i_b]|^2) / 2
+ *                      LogisticMF latent_factor_models/LogisticMF/logistic_matrix_factorization_model.py:52-85
+ * (the Keras embeddings_regularizer of MF / PMF / FunkSVD never reaches their tape loss, so those have no L2 term).
+ * Duplicate rows of a batch are reduced in sorted segments (stable radix sort -> deterministic sums), as TF's
+ * IndexedSlices de-duplication does, then the optimiser runs over the whole table:
+ *   EL_PW_ADAM     Keras Adam, TF 2.3 sparse-apply semantics: every row's m, v decay and move each step
+ *                  (beta1 .9, beta2 .999, eps 1e-7); slots m*, v*;  lr_t = lr sqrt(1-beta2^t)/(1-beta1^t)
+ *   EL_PW_ADAGRAD  Keras Adagrad: acc += g^2, theta -= lr g / (sqrt(acc) + 1e-7); slot m* = acc (start 0.1), lr_t = lr
+ * side: EL_PW_BOTH updates user and item variables, EL_PW_ITEMS only (Gi, Bi), EL_PW_USERS only (Gu, Bu) -- LogisticMF
+ * alternates the two (logistic_matrix_factorization.py:96-110).                                                  */
+enum { EL_PW_MSE = 0, EL_PW_MSE_SIGMOID = 1, EL_PW_LOGISTIC = 2 };
+enum { EL_PW_ADAM = 0, EL_PW_ADAGRAD = 1 };
+enum { EL_PW_BOTH = 0, EL_PW_ITEMS = 1, EL_PW_USERS = 2 };
+
+typedef struct el_pwmf_state {
+    int64_t U, I;
+    int32_t F;
+    int32_t kind;            /* EL_PW_MSE | EL_PW_MSE_SIGMOID | EL_PW_LOGISTIC                              */
+    float alpha, l_w;        /* EL_PW_LOGISTIC only                                                          */
+    float* Gu; float* Gi;    /* [U,F], [I,F]                                                                 */
+    float* Bu; float* Bi;    /* [U], [I]; both NULL = no bias terms (MF, PMF)                                */
+    float* gGu; float* gGi; float* gBu; float* gBi;   /* dense gradient accumulators, zero on entry and exit */
+    float* mGu; float* mGi; float* mBu; float* mBi;   /* Adam m / Adagrad accumulator                        */
+    float* vGu; float* vGi; float* vBu; float* vBi;   /* Adam v (NULL for Adagrad)                           */
+} el_pwmf_state;
+
+size_t el_pwmf_ws_bytes(int64_t n, int64_t U, int64_t I);
+
+/* out[b] = link(score of (u[b], i[b])): model.predict / get_recs on an explicit pair list
+ * (matrix_factorization_model.py:74-99).  EL_PW_LOGISTIC returns x (predict_batch has no link, :88-89).         */
+int el_pwmf_forward(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int32_t* u, const int32_t* i,
+                    int64_t n, float* out);
+
+/* One train_step on n samples; label float[n]; step = 1-based optimiser iteration; loss_out: device double[1],
+ * the batch loss is ADDED.  ws: el_pwmf_ws_bytes(n, U, I).                                                      */
+int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int32_t* u, const int32_t* i,
+                       const float* label, int64_t n, int opt, int side, int32_t step, float lr_t,
+                       double* loss_out, void* ws, size_t ws_bytes);
+
+/* Turn the top-k values of el_score_topk (Bi[i] + <Gu[u],Gi[i]>) into the model's scores, in place:
+ * vals[r, c] <- link(vals[r, c] + Bu[u_start + r]) (Bu may be NULL; -inf padding stays -inf).  The link is monotone,
+ * so the ranking can only change where distinct inputs collapse to one float -- the host re-ranks those (ops.py). */
+int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64_t n_rows, int64_t ld, int32_t k, int kind,
+                        const float* Bu, int64_t u_start);
 
 /* ---- accuracy metrics from the top-k index tensor --------------------------------------
  * Replaces: get_single_recommendation's dict building (recommender_utils_mixin.py:84-88) + Evaluator.eval

@@ -15,7 +15,7 @@ from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["topk", "train", "vae", "gemm"])
+    ap.add_argument("what", choices=["topk", "train", "vae", "gemm", "pwmf"])
     ap.add_argument("--users", type=int, default=131072)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--factors", type=int, default=128)
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--opt", default="adam_tf_dense")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-excl", action="store_true")
+    ap.add_argument("--model", default="FunkSVD", choices=["MF", "PMF", "FunkSVD", "LogisticMF"])
     a = ap.parse_args()
     os.environ["EL_TOPK_VARIANT"] = str(a.variant)
     ctx = ops.get_context(0)
@@ -80,6 +81,33 @@ def main():
     Bi = torch.zeros(I, device=dev)
     ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, seed=5)
     pos = ops.DeviceCSR.from_tensors(ip, ix, I)
+    if a.what == "pwmf":
+        kind, bias, opt = {"MF": ("mse", False, "adam"), "PMF": ("mse_sigmoid", False, "adam"), "FunkSVD": ("mse", True, "adam"),
+                           "LogisticMF": ("logistic", True, "adagrad")}[a.model]
+        st = ops.PwmfDeviceState(ctx, Gu.cpu().numpy(), Gi.cpu().numpy(), torch.zeros(U).numpy() if bias else None,
+                                 torch.zeros(I).numpy() if bias else None, kind=kind, optimizer=opt, alpha=0.5, l_w=0.01)
+        ctx.timing(True)
+        for it in range(a.iters + 2):
+            if it == 2:
+                torch.cuda.synchronize(); ctx.timing_report(); t0 = time.perf_counter()
+            u, i, y = ops.pointwise_sample(ctx, pos, a.batch, seed=3, first_sample=it * a.batch)
+            st.train_step(u, i, y, 0.001, side=("items" if it % 2 else "users") if kind == "logistic" else "both")
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.iters
+        rep, tot = ctx.timing_report(), 0
+        for n, (c, ms) in rep.items():
+            print(f"{n}: {ms / a.iters:.4f} ms/step ({c} launches)")
+            tot += ms / a.iters
+        print(f"{a.model}: kernels {tot:.4f} ms/step, wall {dt * 1e3:.4f} ms/step -> {a.batch / dt / 1e6:.1f} M samples/s")
+        idx, val = st.recommend(0, min(U, 131072), a.k, excl=pos)
+        torch.cuda.synchronize(); ctx.timing_report()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            st.recommend(0, min(U, 131072), a.k, excl=pos)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.iters
+        print(f"{a.model}: recommend {min(U, 131072)} users in {dt * 1e3:.3f} ms -> {min(U, 131072) / dt / 1e6:.2f} M users/s")
+        return
     if a.what == "topk":
         ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)   # warm-up: code load, workspace
         torch.cuda.synchronize()

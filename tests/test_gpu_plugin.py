@@ -369,3 +369,84 @@ def test_device_metrics_path_equals_host_evaluator(ctx, tmp_path):
                 assert abs(dev[c][split][m] - v) < 1e-12, (c, split, m, dev[c][split][m], v)
     cfg.device_metrics = False                       # the switch falls back to the dict path
     assert not model._device_metrics()
+
+
+POINTWISE = {  # plugin -> (extra YAML params, file-name prefix, oracle kind / biases / optimiser / oracle kwargs)
+    "MF": (dict(factors=8, lr=0.01, reg=0.1), "MF_seed=42_e=2_bs=256_factors=8_lr=0$01_reg=0$1", ("mse", False, "adam", {})),
+    "PMF": (dict(factors=8, lr=0.01, reg=0.0025, gaussian_variance=0.1),
+            "PMF_seed=42_e=2_bs=256_lr=0$01_factors=8_reg=0$0025_gvar=0$1", ("mse_sigmoid", False, "adam", {})),
+    "FunkSVD": (dict(factors=8, lr=0.01, reg_w=0.1, reg_b=0.001),
+                "FunkSVD_seed=42_e=2_bs=256_factors=8_lr=0$01_reg_w=0$1_reg_b=0$001", ("mse", True, "adam", {})),
+    "LogisticMatrixFactorization": (dict(factors=8, lr=0.05, reg=0.1, alpha=0.5),
+                                    "LMF_seed=42_e=2_bs=256_lr=0$05_factors=8_reg=0$1_alpha=0$5",
+                                    ("logistic", True, "adagrad", dict(alpha=0.5, l_w=0.1))),
+}
+
+
+@pytest.mark.parametrize("plugin", list(POINTWISE))
+def test_pointwise_plugins_end_to_end_match_cpu_replay(ctx, tmp_path, plugin):
+    """MF / PMF / FunkSVD / LogisticMF driven as ModelCoordinator drives them; the device sampler's batches
+    are replayed through oracle/pointwise_mf.py."""
+    import elliot_amd.recommender as rec
+    from elliot_amd.dataset.samplers import pointwise_pos_neg_sampler
+    from oracle import pointwise_mf as pw
+    data, cfg = make_data(tmp_path)
+    U, I, F, B, epochs = data.num_users, data.num_items, 8, 256, 2
+    extra, prefix, (kind, biases, opt, okw) = POINTWISE[plugin]
+    rs = np.random.RandomState(3)
+    w0 = {"Gu": rs.normal(scale=0.2, size=(U, F)).astype(np.float32), "Gi": rs.normal(scale=0.2, size=(I, F)).astype(np.float32)}
+    if biases:
+        w0["Bu"], w0["Bi"] = rs.normal(scale=0.05, size=U).astype(np.float32), rs.normal(scale=0.05, size=I).astype(np.float32)
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False, save_weights=True), epochs=epochs, batch_size=B, seed=42, **extra)
+    model = getattr(rec, plugin)(data=data, config=cfg, params=params, init_weights=w0)
+    assert model.name == prefix, model.name
+    model.train()
+    # replay
+    orc = pw.PointwiseOracle(w0, kind, extra["lr"], optimizer=opt, **okw)
+    sampler = pointwise_pos_neg_sampler.Sampler(data.sp_i_train, ctx=ctx)
+    losses = []
+    for it in range(epochs):
+        tot = 0.0
+        for side in (("items", "users") if kind == "logistic" else ("both",)):
+            for u, i, y in sampler.step(data.transactions, B):
+                tot += orc.train_step((u.cpu().numpy(), i.cpu().numpy(), y.cpu().numpy()), side=side)
+        losses.append(tot / (it + 1))
+    for got, exp in zip(model._losses, losses):
+        assert abs(got - exp) <= 2e-4 * abs(exp), (model._losses, losses)
+    gw = model._model.get_model_state()
+    for k, v in orc.w.items():
+        assert (np.abs(gw[k].reshape(v.shape) - v) > 5e-5).mean() < 5e-3, k
+    # recommendation lists = masked top-k of the oracle's score table on the device weights
+    _, recs = model.get_recommendations(10)
+    ref = pw.PointwiseOracle({k: gw[k] for k in orc.w}, kind, 0.0, optimizer=opt).predict_all(0, U).astype(np.float64)
+    m = data.sp_i_train
+    agree = 0
+    for u in range(U):
+        masked = ref[u].copy()
+        masked[m.indices[m.indptr[u]:m.indptr[u + 1]]] = -np.inf
+        top = np.lexsort((np.arange(I), -masked))[:10]
+        got = recs[data.private_users[u]]
+        agree += [it for it, _ in got] == [data.private_items[int(i)] for i in top]
+        assert np.abs(np.array([s for _, s in got]) - masked[top]).max() < 2e-6
+    assert agree >= 0.97 * U
+    res = model.get_results()
+    assert set(res.keys()) == {10, 5} and 0.0 <= res[10]["test_results"]["nDCG"] <= 1.0
+    # checkpoint written at the best epoch restores into a fresh model
+    fresh = getattr(rec, plugin)(data=data, config=cfg, params=params)
+    fresh._model.load_weights(model._saving_filepath)
+    a, b = fresh._model.recommend(None, 5, 0, U), model._model.recommend(None, 5, 0, U)
+    if model.get_best_arg() == epochs - 1:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_pointwise_plugins_learn(ctx, tmp_path):
+    """Default initialisers + the device sampler: the epoch loss falls and ranking quality beats a random ranking."""
+    from elliot_amd.recommender import MF, PMF, FunkSVD
+    data, cfg = make_data(tmp_path)
+    for cls, lr in ((MF, 0.02), (FunkSVD, 0.02), (PMF, 0.05)):
+        params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=12, batch_size=512, factors=16, lr=lr, seed=42)
+        m = cls(data=data, config=cfg, params=params)
+        m.train()
+        per_epoch = [l * (n + 1) for n, l in enumerate(m._losses)]
+        assert per_epoch[-1] < per_epoch[0], (cls.__name__, per_epoch)
+        assert m.get_results()[10]["test_results"]["Recall"] > 2 * 10 / data.num_items, cls.__name__
