@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256) void k_bpr_prep(const int32_t* __restrict__ u,
     valI[B + t] = (u32)t | 0x80000000u;
 }
 
+#define BPR_USTG 16   // positions per LDS stage, user segments (6 words each)
+#define BPR_ISTG 64   // item segments (3 words each)
+
 struct SegParams {
     el_bprmf_state st;
     const int32_t* bi;   // item of positive per triplet
@@ -110,95 +113,108 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
             }
             if (sub == 0 && p.st.tGu) p.st.tGu[cur] = p.step;
         };
-        // Positions are processed SUB at a time: all index loads, then all row gathers of the sub-block are issued
-        // before the (order-dependent) accumulation, so a lane group keeps SUB*3 row loads in flight instead of one
-        // dependent chain per position (the kernel is latency-bound otherwise).
+        // The index chain of a position is three dependent loads deep (sorted key / triplet -> i, j -> Bi[i], Bi[j]); a group
+        // stages BPR_USTG positions at once in LDS (one lane per position: all chains in flight together), then walks them
+        // SUB at a time with only the row gathers left on the critical path (SUB*3 row loads in flight per lane).
+        extern __shared__ unsigned char seg_lds[];
+        const int gl = (int)(threadIdx.x / lpt), ngl = 256 / lpt;
+        u32* s_key = reinterpret_cast<u32*>(seg_lds) + (0 * ngl + gl) * BPR_USTG;
+        u32* s_b = reinterpret_cast<u32*>(seg_lds) + (1 * ngl + gl) * BPR_USTG;
+        u32* s_i = reinterpret_cast<u32*>(seg_lds) + (2 * ngl + gl) * BPR_USTG;
+        u32* s_j = reinterpret_cast<u32*>(seg_lds) + (3 * ngl + gl) * BPR_USTG;
+        float* s_bi = reinterpret_cast<float*>(seg_lds) + (4 * ngl + gl) * BPR_USTG;
+        float* s_bj = reinterpret_cast<float*>(seg_lds) + (5 * ngl + gl) * BPR_USTG;
         constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
-        for (int64_t base = p0; base < p1; base += SUB) {
-            int64_t keyv[SUB], bv[SUB];
-            int32_t iv[SUB], jv[SUB];
-            bool okv[SUB];
-#pragma unroll
-            for (int t = 0; t < SUB; ++t) {
-                okv[t] = base + t < p1;
-                keyv[t] = okv[t] ? (int64_t)p.keys[base + t] : -2;
-                bv[t] = okv[t] ? (int64_t)p.vals[base + t] : 0;
+        for (int64_t sbase = p0; sbase < p1; sbase += BPR_USTG) {
+            const int cs = (int)((p1 - sbase < BPR_USTG) ? p1 - sbase : BPR_USTG);
+            for (int t = sub; t < cs; t += lpt) {
+                const u32 b = p.vals[sbase + t];
+                const int32_t ii = p.bi[b], jj = p.bj[b];
+                s_key[t] = p.keys[sbase + t];
+                s_b[t] = b;
+                s_i[t] = (u32)ii;
+                s_j[t] = (u32)jj;
+                s_bi[t] = p.st.Bi[ii];
+                s_bj[t] = p.st.Bi[jj];
             }
+            el_wave_lds_sync();
+            for (int base = 0; base < cs; base += SUB) {
+                int64_t keyv[SUB];
+                bool okv[SUB];
+                float rgu[SUB][CPL][VW], rgi[SUB][CPL][VW], rgj[SUB][CPL][VW];
 #pragma unroll
-            for (int t = 0; t < SUB; ++t) {
-                iv[t] = okv[t] ? p.bi[bv[t]] : 0;
-                jv[t] = okv[t] ? p.bj[bv[t]] : 0;
-            }
-            float rgu[SUB][CPL][VW], rgi[SUB][CPL][VW], rgj[SUB][CPL][VW], rbi[SUB], rbj[SUB];
+                for (int t = 0; t < SUB; ++t) {
+                    okv[t] = base + t < cs;
+                    const int tt = okv[t] ? base + t : base;
+                    keyv[t] = (int64_t)s_key[tt];
+                    const float* pu = p.st.Gu + keyv[t] * F;
+                    const float* pi = p.st.Gi + (int64_t)s_i[tt] * F;
+                    const float* pj = p.st.Gi + (int64_t)s_j[tt] * F;
 #pragma unroll
-            for (int t = 0; t < SUB; ++t) {
-                const float* pu = p.st.Gu + (okv[t] ? keyv[t] : 0) * F;
-                const float* pi = p.st.Gi + (int64_t)iv[t] * F;
-                const float* pj = p.st.Gi + (int64_t)jv[t] * F;
+                    for (int q = 0; q < CPL; ++q) {
+                        const int e = (sub + q * lpt) * VW;
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    const int e = (sub + q * lpt) * VW;
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) rgu[t][q][x] = rgi[t][q][x] = rgj[t][q][x] = 0.f;
-                    if (okv[t] && e < F) {
-                        ldv<VW>(pu + e, rgu[t][q]);
-                        ldv<VW>(pi + e, rgi[t][q]);
-                        ldv<VW>(pj + e, rgj[t][q]);
+                        for (int x = 0; x < VW; ++x) rgu[t][q][x] = rgi[t][q][x] = rgj[t][q][x] = 0.f;
+                        if (okv[t] && e < F) {
+                            ldv<VW>(pu + e, rgu[t][q]);
+                            ldv<VW>(pi + e, rgi[t][q]);
+                            ldv<VW>(pj + e, rgj[t][q]);
+                        }
                     }
                 }
-                rbi[t] = okv[t] ? p.st.Bi[iv[t]] : 0.f;
-                rbj[t] = okv[t] ? p.st.Bi[jv[t]] : 0.f;
-            }
 #pragma unroll
-            for (int t = 0; t < SUB; ++t) {
-                if (!okv[t]) continue;                       // group-uniform
-                const int64_t pos = base + t, key = keyv[t], b = bv[t];
-                if (key != cur) {
-                    if (cur >= 0) flush(true);
-                    cur = key;
-                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
-                    cnt = 0;
-                    nu = 0.f;
+                for (int t = 0; t < SUB; ++t) {
+                    if (!okv[t]) continue;                       // group-uniform
+                    const int64_t pos = sbase + base + t, key = keyv[t];
+                    const int64_t b = (int64_t)s_b[base + t];
+                    if (key != cur) {
+                        if (cur >= 0) flush(true);
+                        cur = key;
+                        started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                        cnt = 0;
+                        nu = 0.f;
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                            for (int x = 0; x < VW; ++x) {
+                                gu[q][x] = rgu[t][q][x];
+                                acc[q][x] = 0.f;
+                                nu += gu[q][x] * gu[q][x];
+                            }
+                        nu = el_group_sum(nu, lpt);
+                    }
+                    float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
 #pragma unroll
                     for (int q = 0; q < CPL; ++q)
 #pragma unroll
                         for (int x = 0; x < VW; ++x) {
-                            gu[q][x] = rgu[t][q][x];
-                            acc[q][x] = 0.f;
-                            nu += gu[q][x] * gu[q][x];
+                            dpi += gu[q][x] * rgi[t][q][x];
+                            dpj += gu[q][x] * rgj[t][q][x];
+                            ni += rgi[t][q][x] * rgi[t][q][x];
+                            nj += rgj[t][q][x] * rgj[t][q][x];
                         }
-                    nu = el_group_sum(nu, lpt);
-                }
-                float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) {
-                        dpi += gu[q][x] * rgi[t][q][x];
-                        dpj += gu[q][x] * rgj[t][q][x];
-                        ni += rgi[t][q][x] * rgi[t][q][x];
-                        nj += rgj[t][q][x] * rgj[t][q][x];
+                    dpi = el_group_sum(dpi, lpt);
+                    dpj = el_group_sum(dpj, lpt);
+                    ni = el_group_sum(ni, lpt);
+                    nj = el_group_sum(nj, lpt);
+                    const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
+                    const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
+                    const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+                    float sb = 0.f;
+                    if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+                    if (sub == 0) {
+                        p.s[b] = sb;
+                        myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
+                                  (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
                     }
-                dpi = el_group_sum(dpi, lpt);
-                dpj = el_group_sum(dpj, lpt);
-                ni = el_group_sum(ni, lpt);
-                nj = el_group_sum(nj, lpt);
-                const float beta_i = rbi[t], beta_j = rbj[t];
-                const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
-                const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
-                float sb = 0.f;
-                if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
-                if (sub == 0) {
-                    p.s[b] = sb;
-                    myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
-                              (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) acc[q][x] += sb * (rgi[t][q][x] - rgj[t][q][x]);
+                    cnt++;
                 }
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) acc[q][x] += sb * (rgi[t][q][x] - rgj[t][q][x]);
-                cnt++;
             }
+            el_wave_lds_sync();
         }
         flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
     }
@@ -261,64 +277,74 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
             }
         }
     };
+    // staged index chains, as in k_bpr_user_seg: BPR_ISTG positions per stage (key, payload -> s_b, u_b)
+    extern __shared__ unsigned char seg_lds[];
+    const int gl = (int)(threadIdx.x / lpt), ngl = 256 / lpt;
+    u32* s_key = reinterpret_cast<u32*>(seg_lds) + (0 * ngl + gl) * BPR_ISTG;
+    u32* s_u = reinterpret_cast<u32*>(seg_lds) + (1 * ngl + gl) * BPR_ISTG;
+    float* s_cf = reinterpret_cast<float*>(seg_lds) + (2 * ngl + gl) * BPR_ISTG;      // +s_b (positive item) / -s_b (negative)
     constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
-    for (int64_t base = p0; base < p1; base += SUB) {
-        int64_t keyv[SUB];
-        u32 payv[SUB];
-        bool okv[SUB];
-#pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            okv[t] = base + t < p1;
-            keyv[t] = okv[t] ? (int64_t)p.keys[base + t] : -2;
-            payv[t] = okv[t] ? p.vals[base + t] : 0u;
+    for (int64_t sbase = p0; sbase < p1; sbase += BPR_ISTG) {
+        const int cs = (int)((p1 - sbase < BPR_ISTG) ? p1 - sbase : BPR_ISTG);
+        for (int t = sub; t < cs; t += lpt) {
+            const u32 pay = p.vals[sbase + t];
+            const int64_t b = (int64_t)(pay & 0x7fffffffu);
+            const float sb = p.s[b];
+            s_key[t] = p.keys[sbase + t] | (pay & 0x80000000u);      // item ids < 2^31: the top bit carries the role
+            s_u[t] = (u32)p.bu[b];
+            s_cf[t] = (pay >> 31) ? -sb : sb;
         }
-        float sbv[SUB];
-        int32_t uv[SUB];
+        el_wave_lds_sync();
+        for (int base = 0; base < cs; base += SUB) {
+            int64_t keyv[SUB];
+            float cfv[SUB];
+            bool negv[SUB], okv[SUB];
+            float rr[SUB][CPL][VW];
 #pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            const int64_t b = (int64_t)(payv[t] & 0x7fffffffu);
-            sbv[t] = okv[t] ? p.s[b] : 0.f;
-            uv[t] = okv[t] ? p.bu[b] : 0;
-        }
-        float rr[SUB][CPL][VW];
+            for (int t = 0; t < SUB; ++t) {
+                okv[t] = base + t < cs;
+                const int tt = okv[t] ? base + t : base;
+                const u32 kk = s_key[tt];
+                keyv[t] = (int64_t)(kk & 0x7fffffffu);
+                negv[t] = (kk >> 31) != 0u;
+                cfv[t] = s_cf[tt];
+                const float* pu = p.st.Gu + (int64_t)s_u[tt] * F;
 #pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            const float* pu = p.st.Gu + (int64_t)uv[t] * F;
+                for (int q = 0; q < CPL; ++q) {
+                    const int e = (sub + q * lpt) * VW;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                const int e = (sub + q * lpt) * VW;
-#pragma unroll
-                for (int x = 0; x < VW; ++x) rr[t][q][x] = 0.f;
-                if (okv[t] && e < F) ldv<VW>(pu + e, rr[t][q]);
+                    for (int x = 0; x < VW; ++x) rr[t][q][x] = 0.f;
+                    if (okv[t] && e < F) ldv<VW>(pu + e, rr[t][q]);
+                }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            if (!okv[t]) continue;
-            const int64_t pos = base + t, key = keyv[t];
-            if (key != cur) {
-                if (cur >= 0) flush(true);
-                cur = key;
-                started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
-                cpos = cneg = 0;
-                bacc = 0.f;
+            for (int t = 0; t < SUB; ++t) {
+                if (!okv[t]) continue;
+                const int64_t pos = sbase + base + t, key = keyv[t];
+                if (key != cur) {
+                    if (cur >= 0) flush(true);
+                    cur = key;
+                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                    cpos = cneg = 0;
+                    bacc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+                }
+                const float coef = cfv[t];
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+                    for (int x = 0; x < VW; ++x) acc[q][x] += coef * rr[t][q][x];
+                bacc += coef;
+                if (negv[t])
+                    cneg++;
+                else
+                    cpos++;
             }
-            const bool neg = (payv[t] >> 31) != 0u;
-            const float coef = neg ? -sbv[t] : sbv[t];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                for (int x = 0; x < VW; ++x) acc[q][x] += coef * rr[t][q][x];
-            bacc += coef;
-            if (neg)
-                cneg++;
-            else
-                cpos++;
         }
+        el_wave_lds_sync();
     }
     flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
 }
@@ -413,10 +439,11 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     pi.lpt = lpt;
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
+    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 3 * 4;
 #define EL_SEG(CPL_)                                                                                      \
     do {                                                                                                  \
-        EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), 0, s, pu);         \
-        EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_>), dim3(gridI), dim3(256), 0, s, pi);         \
+        EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), ldsU, s, pu);      \
+        EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi);      \
     } while (0)
     if (cpl == 1) EL_SEG(1);
     else if (cpl == 2) EL_SEG(2);
@@ -676,7 +703,8 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     pi.lpt = lpt;
     const int64_t gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridI = (unsigned)((gi * lpt + 255) / 256);
-#define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_>), dim3(gridI), dim3(256), 0, s, pi)
+    const size_t ldsI = (size_t)(256 / lpt) * BPR_ISTG * 3 * 4;
+#define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi)
     if (vec) {
         if (cpl == 1) EL_IS(4, 1); else if (cpl == 2) EL_IS(4, 2); else EL_IS(4, 4);
     } else {

@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void k_pw_fwd(PwFwd p) {
     }
 }
 
+#define PW_STG 64
+
 struct PwSeg {
     const u32* keys;          // sorted row ids of THIS side
     const u32* vals;          // sample of each sorted position
@@ -201,54 +203,68 @@ __global__ __launch_bounds__(256) void k_pw_seg(PwSeg p) {
                 atomicAdd(p.gb + cur, bacc);
         }
     };
+    // The index chain of a position (sorted key, sample -> coefficient and the other table's row id) is two dependent
+    // global loads deep; walking it position by position in front of every row gather made this kernel latency-bound.
+    // A group therefore stages PW_STG positions at once (all chains in flight together, coalesced) in LDS and walks them
+    // from there, so that only the row gathers remain on the critical path.
+    __shared__ u32 s_key[32][PW_STG];
+    __shared__ u32 s_oth[32][PW_STG];
+    __shared__ float s_cf[32][PW_STG];
+    const int gl = (int)(threadIdx.x / lpt);
     constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);     // positions whose row loads are in flight together
-    for (int64_t base = p0; base < p1; base += SUB) {
-        int64_t keyv[SUB];
-        float cv[SUB];
-        int32_t ov[SUB];
-        bool okv[SUB];
-#pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            okv[t] = base + t < p1;
-            keyv[t] = okv[t] ? (int64_t)p.keys[base + t] : -2;
-            const int64_t b = okv[t] ? (int64_t)p.vals[base + t] : 0;
-            cv[t] = okv[t] ? p.coef[b] : 0.f;
-            ov[t] = okv[t] ? p.other_ids[b] : 0;
+    for (int64_t sbase = p0; sbase < p1; sbase += PW_STG) {
+        const int cs = (int)((p1 - sbase < PW_STG) ? p1 - sbase : PW_STG);
+        for (int t = sub; t < cs; t += lpt) {
+            const int64_t b = (int64_t)p.vals[sbase + t];
+            s_key[gl][t] = p.keys[sbase + t];
+            s_cf[gl][t] = p.coef[b];
+            s_oth[gl][t] = (u32)p.other_ids[b];
         }
-        float rr[SUB][CPL][VW];
+        el_wave_lds_sync();
+        for (int base = 0; base < cs; base += SUB) {
+            int64_t keyv[SUB];
+            float cv[SUB];
+            bool okv[SUB];
+            float rr[SUB][CPL][VW];
 #pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            const float* po = p.other + (int64_t)ov[t] * F;
+            for (int t = 0; t < SUB; ++t) {
+                okv[t] = base + t < cs;
+                const int tt = okv[t] ? base + t : base;
+                keyv[t] = (int64_t)s_key[gl][tt];
+                cv[t] = s_cf[gl][tt];
+                const float* po = p.other + (int64_t)s_oth[gl][tt] * F;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                const int e = (sub + q * lpt) * VW;
+                for (int q = 0; q < CPL; ++q) {
+                    const int e = (sub + q * lpt) * VW;
 #pragma unroll
-                for (int x = 0; x < VW; ++x) rr[t][q][x] = 0.f;
-                if (okv[t] && e < F) pw_ld<VW>(po + e, rr[t][q]);
+                    for (int x = 0; x < VW; ++x) rr[t][q][x] = 0.f;
+                    if (okv[t] && e < F) pw_ld<VW>(po + e, rr[t][q]);
+                }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < SUB; ++t) {
-            if (!okv[t]) continue;
-            const int64_t pos = base + t, key = keyv[t];
-            if (key != cur) {
-                if (cur >= 0) flush(true);
-                cur = key;
-                started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
-                cnt = 0;
-                bacc = 0.f;
+            for (int t = 0; t < SUB; ++t) {
+                if (!okv[t]) continue;
+                const int64_t pos = sbase + base + t, key = keyv[t];
+                if (key != cur) {
+                    if (cur >= 0) flush(true);
+                    cur = key;
+                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                    cnt = 0;
+                    bacc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+                }
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+                    for (int x = 0; x < VW; ++x) acc[q][x] = fmaf(cv[t], rr[t][q][x], acc[q][x]);
+                bacc += cv[t];
+                ++cnt;
             }
-#pragma unroll
-            for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                for (int x = 0; x < VW; ++x) acc[q][x] = fmaf(cv[t], rr[t][q][x], acc[q][x]);
-            bacc += cv[t];
-            ++cnt;
         }
+        el_wave_lds_sync();
     }
     flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
 }
