@@ -69,8 +69,15 @@ def dist_setup(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("EL_BENCH_SHARED_GPU") == "1":
+            # development check of the N > 1 control flow on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL
+            # (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif args.force_sharded:
         # one rank, but through RCCL and the N > 1 code path: an API check of the collectives on a 1-GPU box
         import torch.distributed as dist
