@@ -425,7 +425,10 @@ class BprmfDeviceState:
             self.mGu = z(self.Gu) if adam else None
             self.vGu = z(self.Gu) if adam else None
             self.layout_gap = None
-        self.gGi, self.gBi = z(self.Gi), z(self.Bi)
+        # item-side gradients in ONE buffer (gGi rows, then gBi): a data-parallel caller all-reduces `item_grad_flat` once
+        self.item_grad_flat = torch.zeros(self.I * self.F + self.I, dtype=torch.float32, device=dev)
+        self.gGi = self.item_grad_flat[:self.I * self.F].view(self.I, self.F)
+        self.gBi = self.item_grad_flat[self.I * self.F:]
         self.mGi = z(self.Gi) if adam else None
         self.vGi = z(self.Gi) if adam else None
         self.mBi = z(self.Bi) if adam else None

@@ -63,10 +63,13 @@ class _Collectives:
         self.dist.all_gather_into_tensor(out, t.contiguous())
         return out
 
-    def all_reduce_sum(self, t):
+    def all_reduce_sum(self, t, async_op=False):
+        """In-place sum over the ranks.  async_op: returns the work handle (None when nothing is in flight); kernels the
+        caller enqueues before `wait()` overlap the collective (RCCL runs it on its own stream)."""
         if self.world > 1 or self.always:
-            self.dist.all_reduce(t)
-        return t
+            work = self.dist.all_reduce(t, async_op=async_op)
+            return work if async_op else t
+        return None if async_op else t
 
     def reduce_scatter_rows(self, out, full):
         """out [n, ...] = rank-th row block of the element-wise sum of `full` [world * n, ...] over the ranks."""
@@ -313,14 +316,32 @@ class HipUserShardBackend:
                                          self._ws.numel()), "el_bprmf_grads")
 
     def item_grads(self):
-        return [self.state.gGi, self.state.gBi]
+        return [self.state.item_grad_flat]                    # gGi rows + gBi in one buffer: one collective per step
 
-    def apply(self, lr):
+    def _apply(self, c_state, lr):
         import ctypes as C
         st, ctx = self.state, self.ctx
-        st.step += 1
-        ops.check(ctx.lib.el_bprmf_apply(ctx.handle, ctx.stream(), C.byref(st._c), float(lr), int(st.opt), int(st.step),
+        ops.check(ctx.lib.el_bprmf_apply(ctx.handle, ctx.stream(), C.byref(c_state), float(lr), int(st.opt), int(st.step),
                                          float(ops.adam_lr_t(lr, st.step))), "el_bprmf_apply")
+
+    def apply(self, lr):
+        self.state.step += 1
+        self._apply(self.state._c, lr)
+
+    def begin_step(self):
+        self.state.step += 1
+
+    def apply_users(self, lr):
+        """Optimiser on the rank's own user rows only (needs no remote data: overlaps the item-gradient all-reduce)."""
+        if not hasattr(self, "_c_users"):
+            clone = lambda c: type(c).from_buffer_copy(c)
+            self._c_users, self._c_items = clone(self.state._c), clone(self.state._c)
+            self._c_users.I = 0                                 # zero-length item passes
+            self._c_items.U = 0
+        self._apply(self._c_users, lr)
+
+    def apply_items(self, lr):
+        self._apply(self._c_items, lr)
 
     def local_loss_tensor(self):
         return self.state.loss
@@ -344,9 +365,18 @@ class ShardedBprmfByUser:
     def train_step(self, u_local, i, j, lr, l_w, l_b):
         be, coll = self.backend, self.coll
         be.grads(u_local, i, j, l_w, l_b)
-        for g in be.item_grads():
-            coll.all_reduce_sum(g)
-        be.apply(lr)
+        if not hasattr(be, "apply_users"):                      # test backends: plain order
+            for g in be.item_grads():
+                coll.all_reduce_sum(g)
+            be.apply(lr)
+            return
+        works = [coll.all_reduce_sum(g, async_op=True) for g in be.item_grads()]
+        be.begin_step()
+        be.apply_users(lr)                                      # the rank's own rows: runs under the all-reduce
+        for w in works:
+            if w is not None:
+                w.wait()
+        be.apply_items(lr)
 
     def pop_loss(self):
         t = self.backend.local_loss_tensor()

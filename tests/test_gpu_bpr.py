@@ -275,7 +275,12 @@ def test_user_sharded_hip_path_equals_concatenated_batch(ctx):
                 g.copy_(tot)
         loss = 0.0
         for be in bes:
-            be.apply(lr)
+            if step == 1:
+                be.apply(lr)                                         # one call ...
+            else:
+                be.begin_step()                                      # ... or the split form ShardedBprmfByUser overlaps
+                be.apply_users(lr)                                   # with the collective: same update
+                be.apply_items(lr)
             loss += be.state.pop_loss()
         cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
         exp = orc.train_step((cu, ci, cj))
