@@ -142,6 +142,10 @@ PROTOTYPES = {
     "el_nmf_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_int32, C.c_float]),
     "el_nmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, _f32p, C.c_int64,
                                     C.c_int32, C.c_float, _f64p]),
+    "el_bprmf_train_loop_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "el_bprmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i64p, _i32p, C.c_uint64, C.c_uint64,
+                                      C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,
+                                      _f64p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "el_pwmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "el_pwmf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, C.c_int64, _f32p]),
     "el_pwmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, _f32p, C.c_int64, C.c_int,

@@ -130,10 +130,10 @@ __device__ __forceinline__ float el_softplus(float x) {
 // forward + backward of one batch; gradients are scatter-ADDED into the dense accumulators
 // gGu/gGi/gBi (duplicates sum, as OptimizerV2 de-duplicates IndexedSlices by segment-sum).
 template <int VW, int CPL>
-__global__ __launch_bounds__(256) void k_bprmf_fwd_bwd(el_bprmf_state st, const int32_t* __restrict__ bu,
-                                                       const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
-                                                       int64_t B, float l_w, float l_b, int lpt, int32_t step,
-                                                       double* loss_out) {
+__device__ __forceinline__ void bprmf_fwd_bwd_body(const el_bprmf_state& st, const int32_t* __restrict__ bu,
+                                                   const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
+                                                   int64_t B, float l_w, float l_b, int lpt, int32_t step,
+                                                   double* loss_out) {
     const int F = st.F;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t b = gid / lpt;
@@ -229,6 +229,45 @@ __global__ __launch_bounds__(256) void k_bprmf_fwd_bwd(el_bprmf_state st, const 
     }
 }
 
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bprmf_fwd_bwd(el_bprmf_state st, const int32_t* __restrict__ bu,
+                                                       const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
+                                                       int64_t B, float l_w, float l_b, int lpt, int32_t step,
+                                                       double* loss_out) {
+    bprmf_fwd_bwd_body<VW, CPL>(st, bu, bi_, bj, B, l_w, l_b, lpt, step, loss_out);
+}
+
+// ---- graph-replayable forms (el_bprmf_train_loop) -----------------------------------------------------------------
+// A captured launch cannot take this step's batch offset or Adam step size by value, so both live in device memory:
+// ctl[0] is read by the gradient kernel (and copied to ctl[1]), ctl[1] by the optimiser kernel, whose first thread then
+// writes the NEXT step into ctl[0] -- no kernel ever reads a word that a concurrently running block writes.
+struct LoopCtl {
+    int64_t off;   // first triplet of the step inside the sampled chunk
+    int64_t cn;    // triplets in the chunk
+    int32_t k;     // index into lr_tab
+    int32_t pad;
+};
+
+template <int VW, int CPL>
+__global__ __launch_bounds__(256) void k_bprmf_fwd_bwd_g(el_bprmf_state st, const int32_t* __restrict__ bu,
+                                                         const int32_t* __restrict__ bi_, const int32_t* __restrict__ bj,
+                                                         int64_t B, float l_w, float l_b, int lpt, double* loss_out,
+                                                         LoopCtl* ctl) {
+    const LoopCtl c = ctl[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[1] = c;
+    const int64_t left = c.cn - c.off;
+    if (left <= 0) return;                                     // padding step of the last replay
+    const int64_t n = left < B ? left : B;
+    bprmf_fwd_bwd_body<VW, CPL>(st, bu + c.off, bi_ + c.off, bj + c.off, n, l_w, l_b, lpt, 0, loss_out);
+}
+
+__global__ void k_loop_ctl_set(LoopCtl* ctl, int64_t cn, int32_t k) {
+    ctl[0].off = 0;
+    ctl[0].cn = cn;
+    ctl[0].k = k;
+    ctl[1] = ctl[0];
+}
+
 // Keras-2.3 Adam, sparse-apply arithmetic, one element:
 //   m <- m*b1 ; m += g*(1-b1) ; v <- v*b2 ; v += (g*g)*(1-b2) ; theta -= (lr_t*m)/(sqrt(v)+eps)
 __device__ __forceinline__ void el_adam_elem(float& th, float& m, float& v, float g, float lr_t, float b1, float b2,
@@ -317,6 +356,32 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ th, floa
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                     float lr_t, float b1, float b2, float eps) {
     adam_dense_body<true, 2>(th, g, m, v, n, lr_t, b1, b2, eps);
+}
+
+// Small models (ML-1M: 0.6 M parameters): the three dense passes are launch-bound, so they share one launch.
+struct AdamTriple {
+    float* th[3];
+    float* g[3];
+    float* m[3];
+    float* v[3];
+    int64_t n[3];
+};
+__global__ __launch_bounds__(256) void k_adam_dense3(AdamTriple t, float lr_t, float b1, float b2, float eps) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) adam_dense_body<false, 1>(t.th[k], t.g[k], t.m[k], t.v[k], t.n[k], lr_t, b1, b2, eps);
+}
+
+__global__ __launch_bounds__(256) void k_adam_dense3_g(AdamTriple t, const float* __restrict__ lr_tab, float b1, float b2,
+                                                       float eps, LoopCtl* ctl, int64_t B) {
+    const LoopCtl c = ctl[1];
+    if (c.off >= c.cn) return;                                 // padding step: no batch, no optimiser iteration
+    const float lr_t = lr_tab[c.k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) adam_dense_body<false, 1>(t.th[k], t.g[k], t.m[k], t.v[k], t.n[k], lr_t, b1, b2, eps);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[0].off = c.off + B;
+        ctl[0].k = c.k + 1;
+    }
 }
 
 // touched-row pass (EL_OPT_ADAM_LAZY / EL_OPT_SGD): one lane group per batch entry and
@@ -500,6 +565,15 @@ int el_bprmf_apply_optimizer(el_ctx* ctx, hipStream_t s, const el_bprmf_state& s
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     if (opt == EL_OPT_ADAM_TF_DENSE) {
         const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
+        auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        if (nu + ni <= (4LL << 20) && al16(st.Gu) && al16(st.gGu) && al16(st.mGu) && al16(st.vGu) && al16(st.Gi) && al16(st.gGi) &&
+            al16(st.mGi) && al16(st.vGi) && al16(st.Bi) && al16(st.gBi) && al16(st.mBi) && al16(st.vBi)) {
+            AdamTriple t = {{st.Gu, st.Gi, st.Bi}, {st.gGu, st.gGi, st.gBi}, {st.mGu, st.mGi, st.mBi}, {st.vGu, st.vGi, st.vBi}, {nu, ni, st.I}};
+            const int64_t big = nu > ni ? nu : ni;
+            EL_LAUNCH("k_adam_dense3", k_adam_dense3, dim3(stream_grid(ctx, big / 4 + 1)), dim3(256), 0, s, t, lr_t, b1, b2, eps);
+            EL_CHECK_LAUNCH();
+            return 0;
+        }
         EL_LAUNCH("k_adam_dense_Gu", k_adam_dense, dim3(stream_grid(ctx, nu / 4 + 1)), dim3(256), 0, s, st.Gu, st.gGu, st.mGu, st.vGu, nu, lr_t, b1, b2, eps);
         EL_LAUNCH("k_adam_dense_Gi", k_adam_dense, dim3(stream_grid(ctx, ni / 4 + 1)), dim3(256), 0, s, st.Gi, st.gGi, st.mGi, st.vGi, ni, lr_t, b1, b2, eps);
         EL_LAUNCH("k_adam_dense_Bi", k_adam_dense, dim3(stream_grid(ctx, st.I / 4 + 1)), dim3(256), 0, s, st.Bi, st.gBi, st.mBi, st.vBi, st.I, lr_t, b1, b2, eps);
@@ -727,5 +801,164 @@ extern "C" int el_bprsgd_levels_host(const int32_t* u, const int32_t* i, const i
     for (int32_t l = 1; l <= maxl; ++l) cur[l] = level_start[l - 1];
     for (int64_t t = 0; t < n; ++t) order[cur[lev[t]]++] = (int32_t)t;
     *n_levels = maxl;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// The epoch loop of BPRMF_batch.train (BPRMF_batch.py:100-109) without host round trips: sampler.step + train_step for
+// consecutive batches from one call.  At the reference's default batch size (512) a step is two microsecond kernels;
+// what an epoch used to consist of was the Python / ctypes cost per step (~40 us) and a sampler launch whose 15 us
+// chain of dependent CSR probes nothing overlapped.  Here
+//   * the sampler does not read the model, so the triplets of up to LOOP_CHUNK/B batches come from ONE launch
+//     (sample t of the epoch is Philox counter first_sample + t whichever launch draws it);
+//   * the small-batch step (atomic gradient kernel + the fused three-tensor Adam) is captured ONCE in a hipGraph of
+//     LOOP_GRAPH_STEPS steps whose per-step scalars (batch offset, Adam step size) live in device memory (LoopCtl), and
+//     replayed -- one hipGraphLaunch per 32 steps instead of 64 kernel launches;
+//   * large batches (sorted path) and the other optimisers run the same kernels eagerly.
+// ---------------------------------------------------------------------------------------
+static const int64_t LOOP_CHUNK = 4 << 20;     // triplets per sampler launch (48 MB of indices)
+static const int LOOP_GRAPH_STEPS = 32;
+
+static int64_t loop_cap(int64_t events, int64_t B) {
+    int64_t most = (LOOP_CHUNK / B) * B;
+    if (most < B) most = B;
+    const int64_t want = ((events + B - 1) / B) * B;
+    return want < most ? (want < B ? B : want) : most;
+}
+static size_t loop_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t el_bprmf_train_loop_ws_bytes(int64_t events, int64_t B) {
+    if (events <= 0 || B <= 0) return 0;
+    const int64_t steps = (events + B - 1) / B;
+    return loop_align((size_t)loop_cap(events, B) * 12) + loop_align((size_t)steps * 4) + 256;
+}
+
+struct LoopGraphKey {
+    el_bprmf_state st;
+    const int32_t* bu;
+    int64_t cap, B;
+    float l_w, l_b;
+    double* loss_out;
+    const float* lr_tab;
+    LoopCtl* ctl;
+    int vec, lpt, cpl;
+    unsigned grid_f, grid_a;
+};
+
+template <int VW>
+static void launch_fwd_g(int cpl, unsigned grid, hipStream_t s, const el_bprmf_state& st, const int32_t* bu, const int32_t* bi,
+                         const int32_t* bj, int64_t B, float l_w, float l_b, int lpt, double* loss_out, LoopCtl* ctl) {
+    if (cpl == 1) hipLaunchKernelGGL((k_bprmf_fwd_bwd_g<VW, 1>), dim3(grid), dim3(256), 0, s, st, bu, bi, bj, B, l_w, l_b, lpt, loss_out, ctl);
+    else if (cpl == 2) hipLaunchKernelGGL((k_bprmf_fwd_bwd_g<VW, 2>), dim3(grid), dim3(256), 0, s, st, bu, bi, bj, B, l_w, l_b, lpt, loss_out, ctl);
+    else hipLaunchKernelGGL((k_bprmf_fwd_bwd_g<VW, 4>), dim3(grid), dim3(256), 0, s, st, bu, bi, bj, B, l_w, l_b, lpt, loss_out, ctl);
+}
+
+// (Re)build the LOOP_GRAPH_STEPS-step graph when the launch parameters differ from the cached ones.
+static int loop_graph_get(el_ctx* ctx, hipStream_t s, const LoopGraphKey& key, const AdamTriple& t, const int32_t* bi,
+                          const int32_t* bj) {
+    if (ctx->loop_graph_exec && ctx->loop_graph_key.size() == sizeof(key) && memcmp(ctx->loop_graph_key.data(), &key, sizeof(key)) == 0)
+        return 0;
+    if (ctx->loop_graph_exec) {
+        (void)hipGraphExecDestroy((hipGraphExec_t)ctx->loop_graph_exec);
+        ctx->loop_graph_exec = nullptr;
+    }
+    hipStream_t cs = nullptr;                                   // a capture stream of our own: `s` may be the null stream
+    EL_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        for (int k = 0; k < LOOP_GRAPH_STEPS; ++k) {
+            if (key.vec) launch_fwd_g<4>(key.cpl, key.grid_f, cs, key.st, key.bu, bi, bj, key.B, key.l_w, key.l_b, key.lpt, key.loss_out, key.ctl);
+            else launch_fwd_g<1>(key.cpl, key.grid_f, cs, key.st, key.bu, bi, bj, key.B, key.l_w, key.l_b, key.lpt, key.loss_out, key.ctl);
+            hipLaunchKernelGGL(k_adam_dense3_g, dim3(key.grid_a), dim3(256), 0, cs, t, key.lr_tab, 0.9f, 0.999f, 1e-7f, key.ctl, key.B);
+        }
+        e = hipStreamEndCapture(cs, &graph);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(cs);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        el_set_error("el_bprmf_train_loop: graph capture failed: %s", hipGetErrorString(e));
+        return 1;
+    }
+    ctx->loop_graph_exec = exec;
+    ctx->loop_graph_key.assign((const unsigned char*)&key, (const unsigned char*)&key + sizeof(key));
+    (void)s;
+    return 0;
+}
+
+extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int64_t* pos_indptr,
+                                   const int32_t* pos_indices, uint64_t seed, uint64_t first_sample, int64_t events,
+                                   int64_t B, float lr, float l_w, float l_b, int opt, int32_t first_step,
+                                   const float* lr_t_host, double* loss_out, int algo, void* ws, size_t ws_bytes,
+                                   void* loop_ws, size_t loop_ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(stp != nullptr && B >= 1 && events >= 0, "el_bprmf_train_loop: bad arguments");
+    if (events == 0) return 0;
+    const size_t need = el_bprmf_train_loop_ws_bytes(events, B);
+    EL_REQUIRE(loop_ws != nullptr && loop_ws_bytes >= need, "el_bprmf_train_loop: loop workspace too small (%zu < %zu)", loop_ws_bytes, need);
+    const bool adam = (opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_ADAM_LAZY);
+    EL_REQUIRE(!adam || lr_t_host != nullptr, "el_bprmf_train_loop: lr_t_host is required for the Adam modes");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cap = loop_cap(events, B), steps = (events + B - 1) / B;
+    int32_t* bu = (int32_t*)loop_ws;
+    int32_t* bi = bu + cap;
+    int32_t* bj = bu + 2 * cap;
+    float* lr_tab = (float*)((char*)loop_ws + loop_align((size_t)cap * 12));
+    LoopCtl* ctl = (LoopCtl*)((char*)lr_tab + loop_align((size_t)steps * 4));
+
+    // graph form: small batch (the atomic gradient kernel is what AUTO picks below 2048), TF-dense Adam on a model small
+    // enough for the fused three-tensor pass, no per-kernel timing requested
+    static const bool graphs_on = [] { const char* e = getenv("EL_LOOP_GRAPH"); return !(e && atoi(e) == 0); }();
+    const el_bprmf_state& st = *stp;
+    bool use_graph = graphs_on && !ctx->timing && opt == EL_OPT_ADAM_TF_DENSE && steps >= 4 &&
+                     (algo == EL_BPR_ATOMIC || (algo == EL_BPR_AUTO && B < 2048));
+    const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    use_graph = use_graph && nu + ni <= (4LL << 20) && st.mGu && st.vGu && st.mGi && st.vGi && st.mBi && st.vBi && al16(st.Gu) &&
+                al16(st.gGu) && al16(st.mGu) && al16(st.vGu) && al16(st.Gi) && al16(st.gGi) && al16(st.mGi) && al16(st.vGi) &&
+                al16(st.Bi) && al16(st.gBi) && al16(st.mBi) && al16(st.vBi);
+    if (use_graph) {
+        bool vec = false, rows_mode = false;
+        if (int rc = el_bprmf_check_state(stp, bu, bi, bj, loss_out, opt, first_step, &vec, &rows_mode)) return rc;
+        LoopGraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.st = st;
+        key.st.tGu = key.st.tGi = key.st.tBi = nullptr;
+        key.bu = bu, key.cap = cap, key.B = B, key.l_w = l_w, key.l_b = l_b, key.loss_out = loss_out, key.lr_tab = lr_tab, key.ctl = ctl;
+        key.vec = vec ? 1 : 0;
+        key.lpt = el_pick_lpt(st.F, vec ? 4 : 1, &key.cpl);
+        EL_REQUIRE(key.cpl <= 4, "el_bprmf_train_loop: F=%d too large for this build", st.F);
+        key.grid_f = (unsigned)((B * key.lpt + 255) / 256);
+        const int64_t big = nu > ni ? nu : ni;
+        key.grid_a = stream_grid(ctx, big / 4 + 1);
+        AdamTriple t = {{st.Gu, st.Gi, st.Bi}, {st.gGu, st.gGi, st.gBi}, {st.mGu, st.mGi, st.mBi}, {st.vGu, st.vGi, st.vBi}, {nu, ni, st.I}};
+        if (loop_graph_get(ctx, s, key, t, bi, bj)) use_graph = false;     // capture unavailable: eager path, same results
+        else EL_CHECK_HIP(hipMemcpyAsync(lr_tab, lr_t_host, (size_t)steps * 4, hipMemcpyHostToDevice, s));
+    }
+
+    int64_t k = 0;
+    for (int64_t c0 = 0; c0 < events; c0 += cap) {
+        const int64_t cn = (events - c0 < cap) ? events - c0 : cap;
+        if (int rc = el_bpr_sample(ctx, stream, pos_indptr, pos_indices, st.U, st.I, 0, st.I, seed, first_sample + (uint64_t)c0,
+                                   cn, bu, bi, bj))
+            return rc;
+        const int64_t csteps = (cn + B - 1) / B;
+        if (use_graph) {
+            hipLaunchKernelGGL(k_loop_ctl_set, dim3(1), dim3(1), 0, s, ctl, cn, (int32_t)k);
+            for (int64_t g = 0; g < csteps; g += LOOP_GRAPH_STEPS) EL_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)ctx->loop_graph_exec, s));
+            k += csteps;
+            continue;
+        }
+        for (int64_t off = 0; off < cn; off += B, ++k) {
+            const int64_t n = (cn - off < B) ? cn - off : B;
+            if (int rc = el_bprmf_train_step(ctx, stream, stp, bu + off, bi + off, bj + off, n, lr, l_w, l_b, opt,
+                                             first_step + (int32_t)k, adam ? lr_t_host[k] : 0.f, loss_out, algo, ws, ws_bytes))
+                return rc;
+        }
+    }
+    EL_CHECK_LAUNCH();
     return 0;
 }

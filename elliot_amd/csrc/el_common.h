@@ -23,6 +23,9 @@ struct el_ctx {
     bool timing;
     std::vector<el_timing_rec> pending;
     std::vector<hipEvent_t> pool;
+    // el_bprmf_train_loop: the captured small-batch step sequence (hipGraphExec_t) and the launch parameters it was built for
+    void* loop_graph_exec = nullptr;
+    std::vector<unsigned char> loop_graph_key;
 };
 
 extern thread_local el_ctx* g_el_cur_ctx;

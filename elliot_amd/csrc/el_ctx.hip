@@ -46,6 +46,7 @@ extern "C" int el_ctx_destroy(el_ctx* ctx) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    if (ctx->loop_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->loop_graph_exec);
     delete ctx;
     return 0;
 }

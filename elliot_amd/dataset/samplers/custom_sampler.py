@@ -44,6 +44,16 @@ class Sampler:
             lists = [list(set(indexed_ratings[u])) for u in indexed_ratings]      # custom_sampler.py:21
             self._replay = ops.MtReplaySampler(self.ctx, lists, self.pos, seed=42)
 
+    @property
+    def philox(self):
+        """True when batches come from the counter-based device sampler (an epoch can then be drawn inside the library)."""
+        return self._replay is None
+
+    def advance(self, n):
+        """Account for n samples drawn on the caller's behalf (BprmfDeviceState.train_loop); returns the old offset."""
+        first, self._drawn = self._drawn, self._drawn + int(n)
+        return first
+
     def step(self, events: int, batch_size: int):
         for start in range(0, events, batch_size):
             n = min(start + batch_size, events) - start

@@ -426,9 +426,10 @@ class BprmfDeviceState:
             self.vGu = z(self.Gu) if adam else None
             self.layout_gap = None
         # item-side gradients in ONE buffer (gGi rows, then gBi): a data-parallel caller all-reduces `item_grad_flat` once
-        self.item_grad_flat = torch.zeros(self.I * self.F + self.I, dtype=torch.float32, device=dev)
+        rows_end = (self.I * self.F + 3) // 4 * 4                       # gBi starts on a 16-byte boundary
+        self.item_grad_flat = torch.zeros(rows_end + self.I, dtype=torch.float32, device=dev)
         self.gGi = self.item_grad_flat[:self.I * self.F].view(self.I, self.F)
-        self.gBi = self.item_grad_flat[self.I * self.F:]
+        self.gBi = self.item_grad_flat[rows_end:]
         self.mGi = z(self.Gi) if adam else None
         self.vGi = z(self.Gi) if adam else None
         self.mBi = z(self.Bi) if adam else None
@@ -468,6 +469,32 @@ class BprmfDeviceState:
                                                self.opt, int(self.step), float(lr_t), _ptr(self.loss, torch.float64),
                                                algo, ws, ws_bytes),
               "el_bprmf_train_step")
+
+    def train_loop(self, pos, events, B, seed, first_sample, lr, l_w, l_b, algo="auto"):
+        """One epoch of `for batch in sampler.step(events, B): train_step(batch)` (BPRMF_batch.py:100-109) from a single
+        library call: the same Philox stream and the same kernels as the per-batch calls, no host round trip in between."""
+        steps = (int(events) + int(B) - 1) // int(B)
+        if steps == 0:
+            return 0
+        if pos.n_rows != self.U or pos.n_cols != self.I:
+            raise ValueError("train_loop: the positives' CSR must describe this state's users x items")
+        algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
+        lr_t = np.array([adam_lr_t(lr, self.step + 1 + k) for k in range(steps)], dtype=np.float32)
+        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))) if B >= 2048 else 0
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+        lneed = int(self.ctx.lib.el_bprmf_train_loop_ws_bytes(int(events), int(B)))
+        buf = getattr(self, "_loop_ws", None)
+        if buf is None or buf.numel() != lneed:                          # (a stable address keeps the captured graph valid)
+            buf = self._loop_ws = torch.empty(lneed, dtype=torch.uint8, device=self.ctx.device)
+        check(self.ctx.lib.el_bprmf_train_loop(
+            self.ctx.handle, self.ctx.stream(), C.byref(self._c), *_csr_ptrs(pos), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            int(first_sample), int(events), int(B), float(lr), float(l_w), float(l_b), self.opt, int(self.step + 1),
+            lr_t.ctypes.data_as(C.c_void_p), _ptr(self.loss, torch.float64), algo,
+            C.c_void_p(self._ws.data_ptr()) if need else None, self._ws.numel() if need else 0,
+            C.c_void_p(buf.data_ptr()), lneed), "el_bprmf_train_loop")
+        self.step += steps
+        return steps
 
     def pop_loss(self):
         v = float(self.loss.item())

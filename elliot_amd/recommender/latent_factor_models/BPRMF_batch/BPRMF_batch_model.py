@@ -62,6 +62,13 @@ class BPRMF_batch_model:
         self.state.train_step(u, i, j, self._learning_rate, self._l_w, self._l_b)
         return DeferredLoss(self.state)
 
+    def train_epoch(self, sampler, events, batch_size):
+        """The whole `for batch in sampler.step(events, batch_size): train_step(batch)` loop of BPRMF_batch.train
+        (:100-109) in one library call (el_bprmf_train_loop); same triplets, same updates."""
+        first = sampler.advance(events)
+        self.state.train_loop(sampler.pos, events, batch_size, sampler.seed, first, self._learning_rate, self._l_w, self._l_b)
+        return DeferredLoss(self.state)
+
     # -- scoring ----------------------------------------------------------------------------------------
     def recommend(self, mask, k, start, stop, item_offset=0):
         """predict (:83-84) + get_top_k (:87-88) fused: top-k of users [start, stop) under `mask`

@@ -21,12 +21,17 @@ class RecMixin(object):
         if self._restore:
             return self.restore_weights()
         steps_per_epoch = int(self._data.transactions // self._batch_size)
+        fused = (hasattr(self._model, "train_epoch") and getattr(self._sampler, "philox", False)
+                 and getattr(self._config, "fused_epoch", True) and not self._verbose)
         for it in self.iterate(self._epochs):
             epoch_loss = 0
-            with tqdm(total=steps_per_epoch, disable=not self._verbose) as bar:
-                for batch in self._sampler.step(self._data.transactions, self._batch_size):
-                    epoch_loss += self._model.train_step(batch)
-                    bar.update()
+            if fused:                                                 # the same loop, inside the library (no per-batch host work)
+                epoch_loss = self._model.train_epoch(self._sampler, self._data.transactions, self._batch_size)
+            else:
+                with tqdm(total=steps_per_epoch, disable=not self._verbose) as bar:
+                    for batch in self._sampler.step(self._data.transactions, self._batch_size):
+                        epoch_loss += self._model.train_step(batch)
+                        bar.update()
             self.evaluate(it, float(epoch_loss) / (it + 1))          # the reference's normalisation (BPRMF_batch.py:109)
 
     def evaluate(self, it=None, loss=0):

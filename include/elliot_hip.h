@@ -35,7 +35,7 @@ extern "C" {
 typedef struct el_ctx el_ctx;
 
 #define EL_ABI_VERSION 3   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
-                            * 3: el_pwmf_* (point-wise factor models)                                                    */
+                            * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop                               */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -149,6 +149,23 @@ int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                          const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                          float l_w, float l_b, int32_t step, float* dU, double* loss_out,
                          void* ws, size_t ws_bytes);
+
+/* Replaces: one epoch of BPRMF_batch.train (BPRMF_batch.py:100-109): `for batch in sampler.step(events, B):
+ * loss += model.train_step(batch)` for the batches [0,B), [B,2B), ... of `events` samples (the last one may be short),
+ * launched back to back from this one call -- el_bpr_sample(first_sample + start) + el_bprmf_train_step per batch.
+ *   first_step : optimiser iteration of the first batch (1-based); lr_t_host[k] = bias-corrected step size of batch k
+ *   ws         : as for el_bprmf_train_step(B);  loop_ws: el_bprmf_train_loop_ws_bytes(events, B) bytes of device
+ *                scratch (triplets of up to 4M samples per sampler launch -- the sampler does not read the model --, the
+ *                step-size table, a control block)
+ * Same arithmetic and the same Philox stream as the per-batch calls.  Small batches with EL_OPT_ADAM_TF_DENSE on a
+ * small model (the reference's ML-1M defaults) replay a hipGraph of 32 captured steps whose per-step scalars live in
+ * device memory (EL_LOOP_GRAPH=0 disables it); everything else launches the per-batch kernels eagerly.            */
+size_t el_bprmf_train_loop_ws_bytes(int64_t events, int64_t B);
+int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_state* st,
+                        const int64_t* pos_indptr, const int32_t* pos_indices, uint64_t seed, uint64_t first_sample,
+                        int64_t events, int64_t B, float lr, float l_w, float l_b, int opt, int32_t first_step,
+                        const float* lr_t_host, double* loss_out, int algo, void* ws, size_t ws_bytes,
+                        void* loop_ws, size_t loop_ws_bytes);
 
 /* Step 3: out[ids[p],:] += rows[p,:], p in [0,n) -- the gathered (user id, gradient row) pairs of all ranks
  * reduced into the dense accumulator (stable sort by id: every rank sums in the same order).        */

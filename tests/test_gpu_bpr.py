@@ -319,3 +319,44 @@ def test_mt19937_replay_sampler_equals_reference_stream(ctx, golden):
     nxt = s.sample(100)
     exp = np.array([o.sample() for _ in range(100)])
     assert np.array_equal(cpu(nxt[0]), exp[:, 0]) and np.array_equal(cpu(nxt[2]), exp[:, 2])
+
+
+# ---------------------------------------------------------------------------------- epoch loop inside the library
+@pytest.mark.parametrize("B,algo,exact,timed", [(4096, "sorted", True, False), (512, "auto", False, False),
+                                                (300, "atomic", False, False), (512, "auto", False, True)])
+def test_train_loop_equals_per_batch_calls(ctx, B, algo, exact, timed):
+    """el_bprmf_train_loop = sampler.step + train_step per batch (same Philox offsets, same kernels, short last batch).
+    Small batches replay the captured hipGraph (per-step scalars in device memory); with per-kernel timing switched on the
+    same loop runs eagerly (timed=True); large batches take the sorted path eagerly."""
+    from elliot_amd.synthetic import zipf_csr
+    rs = np.random.RandomState(5)
+    U, I, F = 3000, 900, 32
+    indptr, indices = zipf_csr(U, I, mean_log=2.0, sigma_log=0.6, dmin=1, dmax=80, seed=2)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    events, lr, l_w, l_b = 5 * B + B // 3, 0.003, 0.05, 0.001
+    a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    for epoch in range(2):
+        first = 1000 + epoch * events
+        for start in range(0, events, B):
+            n = min(B, events - start)
+            u, i, j = ops.bpr_sample(ctx, pos, n, seed=7, first_sample=first + start)
+            a.train_step(u, i, j, lr, l_w, l_b, algo=algo)
+        ctx.timing(timed)
+        steps = b.train_loop(pos, events, B, 7, first, lr, l_w, l_b, algo=algo)
+        if timed:
+            names = set(ctx.timing_report())
+            assert "k_bprmf_fwd_bwd" in names and "k_adam_dense3" in names, names
+        ctx.timing(False)
+        assert steps == 6 and a.step == b.step
+        la, lb = a.pop_loss(), b.pop_loss()
+        assert abs(la - lb) <= (1e-8 if exact else 1e-6) * abs(la), (la, lb)     # hot rows that cross chunks: atomics order
+        for name in ("Gu", "Gi", "Bi", "mGu", "vGi"):
+            x, y = cpu(getattr(a, name)), cpu(getattr(b, name))
+            if exact:
+                assert np.abs(x - y).max() < 1e-7, name          # chunk-crossing hot rows: atomics order only
+            else:
+                assert np.abs(x - y).max() < 1e-5, name
+    with pytest.raises(ValueError):
+        b.train_loop(ops.DeviceCSR(indptr[:11], indices[:indptr[10]], I, ctx.device), events, B, 7, 0, lr, l_w, l_b)
