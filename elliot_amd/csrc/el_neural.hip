@@ -136,49 +136,68 @@ __global__ __launch_bounds__(256) void k_nmf_gather(el_nmf_state st, const int32
 }
 
 // ---- head: logit, probability, BCE, d logit, head gradients --------------------------------------------------
-// one wave per sample.  mode 0: forward only (out_prob[b] = p).  mode 1: training.
+// One wave per sample, persistent waves.  mode 0: forward only (out_prob[b] = p).  mode 1: training.
+// The head-weight gradient ghw[f] = sum_b dlogit_b cat[b, f] is a reduction over the WHOLE batch onto F + Hl addresses:
+// every wave keeps its share in registers (feature f = lane + 64 q), the four waves of a workgroup are combined in LDS and
+// each workgroup issues one atomic per feature -- per-sample atomics on those few addresses cost 6.4 ms at B = 262 144.
+#define NMF_HEAD_Q 16                                    // features per lane held in registers: F + Hl <= 1024
 __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* __restrict__ label, int64_t n, int mode,
                                                   float* out_prob, double* loss_out, int64_t n_div) {
     __shared__ float wsum[4];
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool active = b < n;
+    __shared__ float facc[4][64 * NMF_HEAD_Q];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int F = st.use_mf ? st.F : 0;
     const int Hl = st.use_mlp ? st.units[st.n_layers - 1] : 0;
-    const float* hlast = st.use_mlp ? st.act[st.n_layers - 1] + b * (int64_t)Hl : nullptr;
-    float part = 0.f;
-    if (active) {
-        for (int f = lane; f < F; f += 64) part += st.MF[b * F + f] * st.hw[f];
-        for (int f = lane; f < Hl; f += 64) part += hlast[f] * st.hw[F + f];
-    }
-    const float logit = el_group_sum(part, 64) + (st.head_bias ? st.hb[0] : 0.f);
-    const float p = 1.0f / (1.0f + expf(-logit));
-    float myloss = 0.f;
-    if (mode == 0) {
-        if (active && lane == 0) out_prob[b] = p;
-        return;
-    }
-    float dlogit = 0.f;
-    if (active) {
-        const float t = label[b];
-        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);          // keras backend epsilon clipping
-        if (lane == 0) myloss = -(t * logf(pc) + (1.0f - t) * logf(1.0f - pc)) / (float)n_div;
-        // d/dlogit: zero where the clip is active
-        if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n_div;
-        if (lane == 0) st.dlogit[b] = dlogit;
-        for (int f = lane; f < F; f += 64) atomicAdd(st.ghw + f, dlogit * st.MF[b * F + f]);
-        if (st.use_mlp) {
-            float* dh = st.dact[st.n_layers - 1] + b * (int64_t)Hl;
-            for (int f = lane; f < Hl; f += 64) {
-                atomicAdd(st.ghw + F + f, dlogit * hlast[f]);
-                dh[f] = dlogit * st.hw[F + f];
+    const int NF = F + Hl;
+    const float hbias = st.head_bias ? st.hb[0] : 0.f;
+    float acc[NMF_HEAD_Q];
+#pragma unroll
+    for (int q = 0; q < NMF_HEAD_Q; ++q) acc[q] = 0.f;
+    float bacc = 0.f, myloss = 0.f;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n; b += (int64_t)gridDim.x * 4) {
+        const float* hlast = st.use_mlp ? st.act[st.n_layers - 1] + b * (int64_t)Hl : nullptr;
+        float val[NMF_HEAD_Q];
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < NMF_HEAD_Q; ++q) {
+            const int f = lane + 64 * q;
+            val[q] = 0.f;
+            if (f < NF) {
+                val[q] = f < F ? st.MF[b * F + f] : hlast[f - F];
+                part += val[q] * st.hw[f];
             }
         }
-        if (st.head_bias && lane == 0) atomicAdd(st.ghb, dlogit);
+        const float logit = el_group_sum(part, 64) + hbias;
+        const float p = 1.0f / (1.0f + expf(-logit));
+        if (mode == 0) {
+            if (lane == 0) out_prob[b] = p;
+            continue;
+        }
+        const float t = label[b];
+        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);          // keras backend epsilon clipping
+        if (lane == 0) myloss += -(t * logf(pc) + (1.0f - t) * logf(1.0f - pc)) / (float)n_div;
+        float dlogit = 0.f;                                             // d/dlogit: zero where the clip is active
+        if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n_div;
+        if (lane == 0) st.dlogit[b] = dlogit;
+#pragma unroll
+        for (int q = 0; q < NMF_HEAD_Q; ++q) acc[q] += dlogit * val[q];
+        if (st.use_mlp) {
+            float* dh = st.dact[st.n_layers - 1] + b * (int64_t)Hl;
+            for (int f = lane; f < Hl; f += 64) dh[f] = dlogit * st.hw[F + f];
+        }
+        bacc += dlogit;
     }
+    if (mode == 0) return;
+#pragma unroll
+    for (int q = 0; q < NMF_HEAD_Q; ++q) facc[wv][lane + 64 * q] = acc[q];
     float wl = el_group_sum(myloss, 64);
-    if (lane == 0) wsum[threadIdx.x >> 6] = wl;
+    if (lane == 0) wsum[wv] = wl;
     __syncthreads();
+    for (int f = threadIdx.x; f < NF; f += 256) {
+        const float g = (facc[0][f] + facc[1][f]) + (facc[2][f] + facc[3][f]);
+        if (g != 0.f) atomicAdd(st.ghw + f, g);
+    }
+    if (st.head_bias && lane == 0 && bacc != 0.f) atomicAdd(st.ghb, bacc);
     if (threadIdx.x == 0 && loss_out) {
         const double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
         if (tot != 0.0) atomicAdd(loss_out, tot);
@@ -190,6 +209,36 @@ __global__ __launch_bounds__(256) void k_relu_bwd(float* __restrict__ d, const f
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
         if (!(y[t] > 0.f)) d[t] = 0.f;
+}
+
+// relu backward + bias gradient in one pass over d [n, units]:  d <- d * (y > 0);  gb[c] += sum_b d[b, c]
+// (gb zeroed by the caller).  A workgroup owns the column block blockIdx.x (W = min(units, 256) columns, 256 / W rows at a
+// time) and walks the rows blockIdx.y, blockIdx.y + gridDim.y, ...; the column sums stay in registers until the end.
+__global__ __launch_bounds__(256) void k_relu_bwd_colsum(float* __restrict__ d, const float* __restrict__ y, int64_t n,
+                                                         int64_t units, float* __restrict__ gb) {
+    __shared__ float part[256];
+    const int W = units < 256 ? (int)units : 256, R = 256 / W;
+    const int tc = threadIdx.x % W, tr = threadIdx.x / W;
+    const int64_t c = (int64_t)blockIdx.x * W + tc;
+    float s = 0.f;
+    if (tr < R && c < units) {
+        for (int64_t b = (int64_t)blockIdx.y * R + tr; b < n; b += (int64_t)gridDim.y * R) {
+            const int64_t e = b * units + c;
+            float v = d[e];
+            if (!(y[e] > 0.f)) {
+                v = 0.f;
+                d[e] = 0.f;
+            }
+            s += v;
+        }
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (tr == 0 && c < units) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += part[r * W + tc];
+        if (t != 0.f) atomicAdd(gb + c, t);
+    }
 }
 
 // embedding gradients (IndexedSlices, duplicates summed): scatter-add one row per sample and table
@@ -230,11 +279,18 @@ static unsigned g1(int64_t n, el_ctx* ctx) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
+static unsigned head_grid(int64_t n, el_ctx* ctx) {
+    const int64_t want = (n + 3) / 4, cap = (int64_t)ctx->cus * 8;
+    return (unsigned)(want < cap ? want : cap);
+}
+
 static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
     EL_REQUIRE(st != nullptr, "el_nmf: null state");
     EL_REQUIRE(st->use_mf || st->use_mlp, "el_nmf: mf_train and mlp_train can not be False at the same time");
     EL_REQUIRE(n >= 1 && n <= st->Bmax, "el_nmf: %lld samples exceed Bmax %lld", (long long)n, (long long)st->Bmax);
     EL_REQUIRE(st->hw != nullptr && st->dlogit != nullptr, "el_nmf: head buffers missing");
+    EL_REQUIRE((st->use_mf ? st->F : 0) + (st->use_mlp ? st->units[st->n_layers > 0 ? st->n_layers - 1 : 0] : 0) <= 64 * NMF_HEAD_Q,
+               "el_nmf: head input wider than %d features", 64 * NMF_HEAD_Q);
     if (st->use_mf) EL_REQUIRE(st->tab[0] && st->tab[1] && st->MF && st->F >= 1, "el_nmf: MF tables missing");
     if (st->use_mlp) {
         EL_REQUIRE(st->tab[2] && st->tab[3] && st->X0 && st->E >= 1, "el_nmf: MLP tables missing");
@@ -273,7 +329,7 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st,
     EL_REQUIRE(u && i && out_prob, "el_nmf_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
-    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, (const float*)nullptr, n, 0, out_prob, (double*)nullptr, n);
+    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, (const float*)nullptr, n, 0, out_prob, (double*)nullptr, n);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -287,17 +343,22 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const i
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
     EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
     if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
-    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out, n_div);
+    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out, n_div);
     if (st->use_mlp) {
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
             const float* in = (l == 0) ? st->X0 : st->act[l - 1];
             const int64_t kin = (l == 0) ? 2 * (int64_t)st->E : st->units[l - 1];
-            EL_LAUNCH("k_relu_bwd", k_relu_bwd, dim3(g1(n * units, ctx)), dim3(256), 0, s, st->dact[l], st->act[l], n * units);
-            if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
             EL_CHECK_HIP(hipMemsetAsync(st->gb[l], 0, (size_t)units * 4, s));
-            EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((units + 255) / 256), (unsigned)((n + 31) / 32)), dim3(256), 0, s,
-                      st->dact[l], n, units, units, st->gb[l]);
+            {
+                const int W = units < 256 ? (int)units : 256, R = 256 / W;
+                const unsigned gx = (unsigned)((units + W - 1) / W);
+                int64_t gy = ((int64_t)ctx->cus * 8 + gx - 1) / gx, rows = (n + R - 1) / R;
+                if (gy > rows) gy = rows;
+                EL_LAUNCH("k_relu_bwd_colsum", k_relu_bwd_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], st->act[l], n,
+                          units, st->gb[l]);
+            }
+            if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
             float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
             if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, st->ws_bytes)) return rc;
         }

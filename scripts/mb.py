@@ -15,7 +15,7 @@ from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["topk", "train", "vae", "gemm", "pwmf"])
+    ap.add_argument("what", choices=["topk", "train", "vae", "gemm", "pwmf", "nmf"])
     ap.add_argument("--users", type=int, default=131072)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--factors", type=int, default=128)
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--opt", default="adam_tf_dense")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-excl", action="store_true")
-    ap.add_argument("--model", default="FunkSVD", choices=["MF", "PMF", "FunkSVD", "LogisticMF"])
+    ap.add_argument("--model", default="FunkSVD", choices=["MF", "PMF", "FunkSVD", "LogisticMF", "NeuMF", "GMF"])
     a = ap.parse_args()
     os.environ["EL_TOPK_VARIANT"] = str(a.variant)
     ctx = ops.get_context(0)
@@ -81,6 +81,28 @@ def main():
     Bi = torch.zeros(I, device=dev)
     ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, seed=5)
     pos = ops.DeviceCSR.from_tensors(ip, ix, I)
+    if a.what == "nmf":
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import neumf as on
+        w = on.init_neumf(U, I, F, 3) if a.model != "GMF" else on.init_gmf(U, I, F, 3)
+        st = ops.NmfDeviceState(ctx, w, max_batch=a.batch)
+        ctx.timing(True)
+        for it in range(a.iters + 2):
+            if it == 2:
+                torch.cuda.synchronize(); ctx.timing_report(); t0 = time.perf_counter()
+            u, i, y = ops.pointwise_sample(ctx, pos, a.batch, seed=3, first_sample=it * a.batch)
+            st.train_step(u, i, y, 0.001)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.iters
+        rep, tot = ctx.timing_report(), 0
+        for n, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
+            print(f"{n}: {ms / a.iters:.4f} ms/step ({c // a.iters} launches/step)")
+            tot += ms / a.iters
+        units = [4 * F, 2 * F, F]
+        flops = a.batch * 2.0 * (2 * F * units[0] + units[0] * units[1] + units[1] * units[2]) * 3
+        print(f"NeuMF F={F} B={a.batch}: kernels {tot:.3f} ms/step, wall {dt * 1e3:.3f} ms/step -> {a.batch / dt / 1e6:.1f} M samples/s, "
+              f"MLP {flops / (tot * 1e-3) / 1e12:.1f} TFLOP/s over the step")
+        return
     if a.what == "pwmf":
         kind, bias, opt = {"MF": ("mse", False, "adam"), "PMF": ("mse_sigmoid", False, "adam"), "FunkSVD": ("mse", True, "adam"),
                            "LogisticMF": ("logistic", True, "adagrad")}[a.model]

@@ -60,7 +60,7 @@ def test_gradients_match_autograd():
     tGu, tGi, tBi = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (Gu, Gi, Bi))
     loss = torch_loss(tGu, tGi, tBi, torch.tensor(u), torch.tensor(i), torch.tensor(j), l_w, l_b)
     loss.backward()
-    assert abs(float(loss) - float(ob.forward_loss(Gu, Gi, Bi, u, i, j, l_w, l_b, dtype=np.float64))) < 1e-10
+    assert abs(float(loss.detach()) - float(ob.forward_loss(Gu, Gi, Bi, u, i, j, l_w, l_b, dtype=np.float64))) < 1e-10
     assert np.abs(dGu - tGu.grad.numpy()).max() < 1e-12
     assert np.abs(dGi - tGi.grad.numpy()).max() < 1e-12
     assert np.abs(dBi - tBi.grad.numpy()).max() < 1e-12
