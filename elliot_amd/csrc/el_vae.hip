@@ -47,22 +47,37 @@ __global__ __launch_bounds__(256) void k_vae_enc1(const int32_t* __restrict__ ro
 #pragma unroll
     for (int q = 0; q < CPL; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
     const int H4 = H >> 2;
-    for (int64_t e = r0 + wave; e < r1; e += 4) {
-        const int32_t item = indices[e];
-        const float w = nrm * vae_drop_scale(rate, seed, step, (u32)user, (u32)item);
-        if (w == 0.f) continue;
-        const float4* wr = reinterpret_cast<const float4*>(W1 + (int64_t)item * H);
+    // ENC_U nonzeros of a wave are in flight together: a heavy row (thousands of items) is a chain of dependent
+    // index -> W1-row loads, and with one workgroup per batch row that chain, not bandwidth, was the kernel's duration
+    constexpr int ENC_U = 4;
+    for (int64_t e0 = r0 + wave * ENC_U; e0 < r1; e0 += 4 * ENC_U) {
+        float wv[ENC_U];
+        const float4* wr[ENC_U];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const int c = lane + q * 64;
-            if (c < H4) {
-                const float4 t = wr[c];
-                acc[q][0] += w * t.x;
-                acc[q][1] += w * t.y;
-                acc[q][2] += w * t.z;
-                acc[q][3] += w * t.w;
-            }
+        for (int t = 0; t < ENC_U; ++t) {
+            const int64_t e = e0 + t;
+            const int32_t item = e < r1 ? indices[e] : 0;
+            wv[t] = e < r1 ? nrm * vae_drop_scale(rate, seed, step, (u32)user, (u32)item) : 0.f;
+            wr[t] = reinterpret_cast<const float4*>(W1 + (int64_t)item * H);
         }
+        float4 tv[ENC_U][CPL];
+#pragma unroll
+        for (int t = 0; t < ENC_U; ++t)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int c = lane + q * 64;
+                tv[t][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wv[t] != 0.f && c < H4) tv[t][q] = wr[t][c];
+            }
+#pragma unroll
+        for (int t = 0; t < ENC_U; ++t)                       // same summation order as one nonzero at a time
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                acc[q][0] += wv[t] * tv[t][q].x;
+                acc[q][1] += wv[t] * tv[t][q].y;
+                acc[q][2] += wv[t] * tv[t][q].z;
+                acc[q][3] += wv[t] * tv[t][q].w;
+            }
     }
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
