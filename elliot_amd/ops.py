@@ -934,3 +934,61 @@ class PwmfDeviceState:
             out_i.append(bi)
             out_v.append(bv)
         return torch.cat(out_i), torch.cat(out_v)
+
+
+# ------------------------------------------------------------------------------------------
+# Collaborative Metric Learning
+# ------------------------------------------------------------------------------------------
+class CmlDeviceState(BprmfDeviceState):
+    """CML_model's variables (Gu, Gi, Bi) + Adam slots: the BPR state with the metric-learning step and scoring."""
+
+    def __init__(self, ctx, Gu, Gi, Bi):
+        super().__init__(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+        self._cml_ws = None
+        self._items2 = None
+
+    def train_step(self, u, i, j, lr, l_w, l_b, margin):
+        self.step += 1
+        B = u.numel()
+        need = int(self.ctx.lib.el_cml_ws_bytes(int(B)))
+        if self._cml_ws is None or self._cml_ws.numel() < need:
+            self._cml_ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+        check(self.ctx.lib.el_cml_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                             _ptr(i, torch.int32), _ptr(j, torch.int32), int(B), float(l_w), float(l_b),
+                                             float(margin), int(self.step), float(adam_lr_t(lr, self.step)),
+                                             _ptr(self.loss, torch.float64), C.c_void_p(self._cml_ws.data_ptr()), need),
+              "el_cml_train_step")
+        self._items2 = None
+
+    def _item_side(self):
+        if self._items2 is None:
+            Gi2, Bi2 = torch.empty_like(self.Gi), torch.empty_like(self.Bi)
+            check(self.ctx.lib.el_cml_prepare_items(self.ctx.handle, self.ctx.stream(), _ptr(self.Gi, torch.float32),
+                                                    _ptr(self.Bi, torch.float32), int(self.I), int(self.F), _ptr(Gi2), _ptr(Bi2)),
+                  "el_cml_prepare_items")
+            self._items2 = (Gi2, Bi2)
+        return self._items2
+
+    def rescore(self, idx, u_start):
+        val = torch.empty(idx.shape, dtype=torch.float32, device=self.ctx.device)
+        check(self.ctx.lib.el_cml_rescore(self.ctx.handle, self.ctx.stream(), _ptr(self.Gu, torch.float32),
+                                          _ptr(self.Gi, torch.float32), _ptr(self.Bi, torch.float32), int(self.F),
+                                          _ptr(idx, torch.int32), int(idx.shape[0]), int(idx.stride(0)), int(idx.shape[1]),
+                                          int(u_start), _ptr(val)), "el_cml_rescore")
+        return val
+
+    def recommend(self, u_start, u_stop, k, excl=None, cand=None):
+        """CML_model.predict + get_top_k (CML_model.py:97-106): the fused kernel ranks by (Bi - |Gi|^2) + <Gu, 2 Gi>, which is
+        the score plus the per-user constant |Gu[u]|^2; the k + 16 best are re-scored with the reference's own formula
+        -sum (u - i)^2 + b_i and re-ranked by (value desc, index asc), so values and order are those of the direct
+        evaluation (the two formulas differ by fp32 rounding only; a difference that straddles rank k + 16 is not seen)."""
+        Gi2, Bi2 = self._item_side()
+        kk = min(self.I, k + _PW_MARGIN)
+        idx, raw = score_topk(self.ctx, self.Gu, Gi2, Bi2, u_start, u_stop, kk, excl=excl, cand=cand)
+        val = self.rescore(idx, u_start)
+        val = torch.where(raw == float("-inf"), raw, val)           # -inf padding (masked items) stays padding
+        order = torch.sort(idx, dim=1, stable=True).indices
+        val_o = torch.gather(val, 1, order)
+        by_val = torch.sort(val_o, dim=1, descending=True, stable=True)
+        idx_o = torch.gather(torch.gather(idx, 1, order), 1, by_val.indices)
+        return idx_o[:, :k].contiguous(), by_val.values[:, :k].contiguous()

@@ -7,6 +7,7 @@ from .latent_factor_models.MF.matrix_factorization import MF
 from .latent_factor_models.PMF.probabilistic_matrix_factorization import PMF
 from .latent_factor_models.FunkSVD.funk_svd import FunkSVD
 from .latent_factor_models.LogisticMF.logistic_matrix_factorization import LMF, LogisticMatrixFactorization
+from .latent_factor_models.CML.CML import CML
 from .generic.Proxy.Proxy import ProxyRecommender
 from .autoencoders.vae.multi_vae import MultiVAE
 from .autoencoders.dae.multi_dae import MultiDAE
@@ -14,4 +15,4 @@ from .neural.NeuMF.neural_matrix_factorization import NeuMF
 from .neural.GeneralizedMF.generalized_matrix_factorization import GMF
 
 __all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF", "MultiVAE", "MultiDAE", "NeuMF", "GMF",
-           "MF", "PMF", "FunkSVD", "LogisticMatrixFactorization", "LMF", "ProxyRecommender"]
+           "MF", "PMF", "FunkSVD", "LogisticMatrixFactorization", "LMF", "CML", "ProxyRecommender"]

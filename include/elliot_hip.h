@@ -35,7 +35,7 @@ extern "C" {
 typedef struct el_ctx el_ctx;
 
 #define EL_ABI_VERSION 3   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
-                            * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop                               */
+                            * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*                     */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -451,6 +451,28 @@ int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state* st, const
  * so the ranking can only change where distinct inputs collapse to one float -- the host re-ranks those (ops.py). */
 int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64_t n_rows, int64_t ld, int32_t k, int kind,
                         const float* Bu, int64_t u_start);
+
+/* ---- Collaborative Metric Learning ---------------------------------------------------------
+ * Replaces: CML_model.train_step (latent_factor_models/CML/CML_model.py:69-95) on BPR triplets u,i,j int32[B], with the
+ * reference's shapes taken literally: the squared distances keep their [B,1] shape while the squeezed biases are [B], so
+ * score = -dist + beta is a [B,B] matrix (:60-66) and the hinge sums over all pairs (triplet a's distances, triplet b's
+ * biases):  loss = sum_{a,b} max(margin - clip(D_a + E_b, -80, 1e8), 0) + l_w (|u|^2+|i|^2+|j|^2)/2 + l_b b_i^2/2 + l_b b_j^2/20,
+ * D_a = |u_a - j_a|^2 - |u_a - i_a|^2, E_b = b(i_b) - b(j_b).  Evaluated in O(B log B) (two float sorts + binary searches;
+ * el_cml.hip).  Variables, gradient accumulators and Adam slots are an el_bprmf_state (Gu, Gi, Bi); optimiser = Keras
+ * Adam with TF 2.3 sparse-apply semantics (EL_OPT_ADAM_TF_DENSE).  loss_out: device double[1], ADDED to.            */
+size_t el_cml_ws_bytes(int64_t B);
+int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i,
+                      const int32_t* j, int64_t B, float l_w, float l_b, float margin, int32_t step, float lr_t,
+                      double* loss_out, void* ws, size_t ws_bytes);
+
+/* Replaces: CML_model.predict (:97-102), score(u,i) = -|Gu[u] - Gi[i]|^2 + Bi[i], through the fused scoring kernel:
+ * el_cml_prepare_items writes Gi2 = 2 Gi and Bi2 = Bi - |Gi|^2, so that el_score_topk(Gu, Gi2, Bi2) ranks by
+ * score + |Gu[u]|^2 (a per-user constant); el_cml_rescore then evaluates the reference's formula directly for the listed
+ * candidates (idx int32[n_rows, ld], first kk columns; -1 -> -inf) and the host re-ranks them (ops.py).            */
+int el_cml_prepare_items(el_ctx* ctx, void* stream, const float* Gi, const float* Bi, int64_t I, int32_t F,
+                         float* Gi2, float* Bi2);
+int el_cml_rescore(el_ctx* ctx, void* stream, const float* Gu, const float* Gi, const float* Bi, int32_t F,
+                   const int32_t* idx, int64_t n_rows, int64_t ld, int32_t kk, int64_t u_start, float* val);
 
 /* ---- accuracy metrics from the top-k index tensor --------------------------------------
  * Replaces: get_single_recommendation's dict building (recommender_utils_mixin.py:84-88) + Evaluator.eval

@@ -1,0 +1,116 @@
+"""GPU parity: Collaborative Metric Learning (el_cml_*) against oracle/cml.py -- the reference's [B,B] broadcast hinge
+evaluated by sorting, the direct-formula scoring, and the plugin end to end."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from elliot_amd import ops
+from oracle import cml as oc
+from tests.gpu_util import cpu, random_excl
+
+pytestmark = pytest.mark.gpu
+
+
+def tables(rs, U, I, F, scale=0.3):
+    return (rs.normal(scale=scale, size=(U, F)).astype(np.float32), rs.normal(scale=scale, size=(I, F)).astype(np.float32),
+            rs.normal(scale=0.2, size=I).astype(np.float32))
+
+
+def dev(ctx, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(ctx.device)
+
+
+@pytest.mark.parametrize("F,margin,scale", [(8, 0.5, 0.3), (10, 0.5, 0.3), (64, 0.2, 0.1), (200, 1.5, 0.05), (16, 0.5, 4.0)])
+def test_train_steps_match_oracle(ctx, F, margin, scale):
+    """scale 4.0: distances of order 100 put many pairs outside the -80 clip (constant terms, zero gradient)."""
+    rs = np.random.RandomState(F)
+    U, I, B, lr, l_w, l_b = 150, 120, 700, 0.01, 0.01, 0.02
+    Gu, Gi, Bi = tables(rs, U, I, F, scale)
+    st = ops.CmlDeviceState(ctx, Gu, Gi, Bi)
+    orc = oc.CMLOracle(Gu, Gi, Bi, lr, l_w, l_b, margin)
+    for s in range(4):
+        n = B if s != 2 else 33
+        u, i, j = rs.randint(0, U, n), rs.randint(0, min(I, 40), n), rs.randint(0, I, n)
+        st.train_step(dev(ctx, u), dev(ctx, i), dev(ctx, j), lr, l_w, l_b, margin)
+        got, exp = st.pop_loss(), orc.train_step((u, i, j))
+        assert abs(got - exp) <= 1e-4 * abs(exp), (s, got, exp)
+        for name, ref in (("Gu", orc.Gu), ("Gi", orc.Gi), ("Bi", orc.Bi)):
+            err = np.abs(cpu(getattr(st, name)) - ref)
+            # a pair sitting within rounding of the hinge flips one unit of a coefficient; Adam turns that into <= lr
+            assert (err > 5e-5).mean() < 5e-3 and err.max() < 5 * lr, (s, name, float(err.max()), float((err > 5e-5).mean()))
+        assert not cpu(st.gGu).any() and not cpu(st.gGi).any() and not cpu(st.gBi).any()
+
+
+def test_large_batch_counts(ctx):
+    """B = 20000: 4e8 pairs -- the counts come from sorted searches, the oracle loops over row blocks of the [B,B] matrix."""
+    rs = np.random.RandomState(1)
+    U, I, F, B, margin = 3000, 800, 32, 20000, 0.5
+    Gu, Gi, Bi = tables(rs, U, I, F, 0.2)
+    st = ops.CmlDeviceState(ctx, Gu, Gi, Bi)
+    u, i, j = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, I, B)
+    st.train_step(dev(ctx, u), dev(ctx, i), dev(ctx, j), 0.001, 0.0, 0.0, margin)
+    got = st.pop_loss()
+    D = (np.sum((Gu[u] - Gi[j]) ** 2, -1) - np.sum((Gu[u] - Gi[i]) ** 2, -1)).astype(np.float64)
+    E = (Bi[i] - Bi[j]).astype(np.float64)
+    exp = 0.0
+    for a0 in range(0, B, 2000):
+        diff = np.clip(D[a0:a0 + 2000, None] + E[None, :], -80, 1e8)
+        exp += np.maximum(margin - diff, 0).sum()
+    assert abs(got - exp) <= 2e-5 * exp, (got, exp)
+
+
+def test_recommend_values_are_the_direct_formula(ctx):
+    rs = np.random.RandomState(4)
+    U, I, F, k = 300, 1100, 32, 10
+    Gu, Gi, Bi = tables(rs, U, I, F, 0.3)
+    st = ops.CmlDeviceState(ctx, Gu, Gi, Bi)
+    indptr, indices = random_excl(rs, U, I, 0, 30)
+    excl = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    idx, val = (cpu(t) for t in st.recommend(0, U, k, excl=excl))
+    scores = oc.CMLOracle(Gu, Gi, Bi, 0, 0, 0, 0).predict(0, U).astype(np.float64)
+    for r in range(U):
+        scores[r, indices[indptr[r]:indptr[r + 1]]] = -np.inf
+    order = np.lexsort((np.arange(I)[None, :].repeat(U, 0), -scores), axis=1)[:, :k]
+    exp = np.take_along_axis(scores, order, 1)
+    assert np.abs(val - exp).max() < 5e-6
+    assert np.abs(np.take_along_axis(scores, idx.astype(np.int64), 1) - exp).max() < 5e-6
+    assert (idx == order).mean() > 0.999
+    assert (np.diff(val, axis=1) <= 0).all()
+    # few admissible items: -inf padding survives the re-scoring
+    cptr, cidx = random_excl(rs, U, I, 2, 6)
+    cand = ops.DeviceCSR(cptr, cidx, I, ctx.device)
+    idx, val = (cpu(t) for t in st.recommend(0, U, k, cand=cand))
+    for r in range(U):
+        n = cptr[r + 1] - cptr[r]
+        assert np.isin(idx[r, :n], cidx[cptr[r]:cptr[r + 1]]).all() and np.isinf(val[r, n:]).all() and np.isfinite(val[r, :n]).all()
+
+
+def test_cml_plugin_end_to_end(ctx, tmp_path):
+    from elliot_amd.dataset.samplers import custom_sampler
+    from elliot_amd.recommender import CML
+    from tests.test_gpu_plugin import make_data
+    data, cfg = make_data(tmp_path)
+    U, I, F, B, epochs, lr = data.num_users, data.num_items, 16, 512, 2, 0.01
+    rs = np.random.RandomState(0)
+    w0 = (rs.uniform(-0.05, 0.05, (U, F)).astype(np.float32), rs.uniform(-0.05, 0.05, (I, F)).astype(np.float32),
+          rs.uniform(-0.05, 0.05, I).astype(np.float32))
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False), epochs=epochs, batch_size=B, seed=42, factors=F, lr=lr, l_w=0.001,
+                             l_b=0.001, margin=0.5)
+    model = CML(data=data, config=cfg, params=params, init_weights=w0)
+    assert model.name == "CML_seed=42_e=2_bs=512_factors=16_lr=0$01_l_w=0$001_l_b=0$001_margin=0$5"
+    model.train()
+    orc = oc.CMLOracle(*w0, lr, 0.001, 0.001, 0.5)
+    sampler = custom_sampler.Sampler(data.sp_i_train, ctx=ctx)
+    losses = []
+    for it in range(epochs):
+        tot = 0.0
+        for u, i, j in sampler.step(data.transactions, B):
+            tot += orc.train_step((u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()))
+        losses.append(tot / (it + 1))
+    for got, exp in zip(model._losses, losses):
+        assert abs(got - exp) <= 2e-4 * abs(exp), (model._losses, losses)
+    assert (np.abs(cpu(model._model.state.Gi) - orc.Gi) > 1e-4).mean() < 1e-2
+    res = model.get_results()
+    assert set(res.keys()) == {10, 5} and 0.0 <= res[10]["test_results"]["nDCG"] <= 1.0
