@@ -4,10 +4,8 @@ Filtering, https://arxiv.org/abs/1802.05814.
 Contract of elliot/recommender/autoencoders/dae/multi_dae.py:19-105: hyper-parameters `intermediate_dim`, `latent_dim`,
 `reg_lambda`, `lr`, `dropout_pkeep` (+ base keys); `batch_size` < 1 means all users; dropout rate = 1 - dropout_pkeep;
 the epoch loss is handed to evaluate() as sum / (epoch + 1) (:105).  SURVEY 8f row N3: a sibling of MultiVAE on the same
-kernels.
+kernels; the epoch loop is RecMixin.train() over the users instead of the interactions.
 """
-from tqdm import tqdm
-
 from .... import ops
 from ....dataset.samplers import sparse_sampler
 from ...base_recommender_model import BaseRecommenderModel, init_charger, param
@@ -44,14 +42,5 @@ class MultiDAE(RecMixin, BaseRecommenderModel):
     def _recommendation_block(self):
         return self._score_block
 
-    def train(self):
-        if self._restore:
-            return self.restore_weights()
-        batches_per_epoch = int(self._num_users // self._batch_size)
-        for it in self.iterate(self._epochs):
-            epoch_loss = 0
-            with tqdm(total=batches_per_epoch, disable=not self._verbose) as bar:
-                for user_rows in self._sampler.step(self._num_users, self._batch_size):
-                    epoch_loss += self._model.train_step(user_rows)
-                    bar.update()
-            self.evaluate(it, float(epoch_loss) / (it + 1))
+    def _epoch_events(self):
+        return self._num_users                                        # one pass over the users (multi_dae.py:95-103)

@@ -17,19 +17,24 @@ from . import _compat
 class RecMixin(object):
 
     # -- training loop and per-epoch evaluation ------------------------------------------------------------------
+    def _epoch_events(self):
+        """Samples one epoch draws from the sampler: the train interactions (BPR / point-wise models, BPRMF_batch.py:103);
+        the auto-encoders override it with the number of users."""
+        return self._data.transactions
+
     def train(self):
         if self._restore:
             return self.restore_weights()
-        steps_per_epoch = int(self._data.transactions // self._batch_size)
+        events = self._epoch_events()
         fused = (hasattr(self._model, "train_epoch") and getattr(self._sampler, "philox", False)
                  and getattr(self._config, "fused_epoch", True) and not self._verbose)
         for it in self.iterate(self._epochs):
             epoch_loss = 0
             if fused:                                                 # the same loop, inside the library (no per-batch host work)
-                epoch_loss = self._model.train_epoch(self._sampler, self._data.transactions, self._batch_size)
+                epoch_loss = self._model.train_epoch(self._sampler, events, self._batch_size)
             else:
-                with tqdm(total=steps_per_epoch, disable=not self._verbose) as bar:
-                    for batch in self._sampler.step(self._data.transactions, self._batch_size):
+                with tqdm(total=int(events // self._batch_size), disable=not self._verbose) as bar:
+                    for batch in self._sampler.step(events, self._batch_size):
                         epoch_loss += self._model.train_step(batch)
                         bar.update()
             self.evaluate(it, float(epoch_loss) / (it + 1))          # the reference's normalisation (BPRMF_batch.py:109)
