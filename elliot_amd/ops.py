@@ -833,6 +833,13 @@ class PwmfDeviceState:
         names = ("Gu", "Gi", "Bu", "Bi")
         for n in names:
             t = getattr(self, n)
+            if n == "Gu" and adam and self.U * self.F * 4 >= (64 << 20):
+                # the dense Adam pass streams theta, g, m, v of the user table at once: one allocation, tuned distance
+                gap = tune_table_layout(ctx, self.U, self.F)
+                (th, self.gGu, self.mGu, self.vGu), self._user_block = _strided_tables(self.U, self.F, 4, gap, dev)
+                th.copy_(self.Gu)
+                self.Gu = th
+                continue
             setattr(self, "g" + n, z(t))
             setattr(self, "m" + n, slot(t))
             setattr(self, "v" + n, z(t) if adam else None)
