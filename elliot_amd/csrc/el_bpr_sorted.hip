@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_bpr_prep(const int32_t* __restrict__ u,
 }
 
 #define BPR_USTG 16   // positions per LDS stage, user segments (6 words each)
-#define BPR_ISTG 64   // item segments (3 words each)
+#define BPR_ISTG 64   // item segments (4 words each)
 
 struct SegParams {
     el_bprmf_state st;
@@ -68,7 +68,9 @@ struct SegParams {
     const int32_t* bu;   // user
     const u32* keys;     // sorted row ids
     const u32* vals;     // sorted payloads
-    float* s;            // [B] dloss/dd per triplet
+    float* s;            // [B] dloss/dd per triplet (BPR: written by the user segments; CML: dloss/dD, given)
+    const float* s2;     // CML only: dloss/dE per triplet (the bias-side coefficient)
+    int cml;             // 0: BPR (the user segments compute the forward pass), 1: CML (coefficients given, el_cml.hip)
     int64_t n;           // number of sorted entries (B or 2B)
     int chunk;           // positions per lane group
     int lpt;
@@ -183,29 +185,33 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
                             }
                         nu = el_group_sum(nu, lpt);
                     }
-                    float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                        for (int x = 0; x < VW; ++x) {
-                            dpi += gu[q][x] * rgi[t][q][x];
-                            dpj += gu[q][x] * rgj[t][q][x];
-                            ni += rgi[t][q][x] * rgi[t][q][x];
-                            nj += rgj[t][q][x] * rgj[t][q][x];
-                        }
-                    dpi = el_group_sum(dpi, lpt);
-                    dpj = el_group_sum(dpj, lpt);
-                    ni = el_group_sum(ni, lpt);
-                    nj = el_group_sum(nj, lpt);
-                    const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
-                    const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
-                    const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
                     float sb = 0.f;
-                    if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
-                    if (sub == 0) {
-                        p.s[b] = sb;
-                        myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
-                                  (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+                    if (p.cml) {
+                        sb = 2.0f * p.s[b];                          // d|u-j|^2/du - d|u-i|^2/du = 2 (i - j), times dloss/dD_b
+                    } else {
+                        float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                            for (int x = 0; x < VW; ++x) {
+                                dpi += gu[q][x] * rgi[t][q][x];
+                                dpj += gu[q][x] * rgj[t][q][x];
+                                ni += rgi[t][q][x] * rgi[t][q][x];
+                                nj += rgj[t][q][x] * rgj[t][q][x];
+                            }
+                        dpi = el_group_sum(dpi, lpt);
+                        dpj = el_group_sum(dpj, lpt);
+                        ni = el_group_sum(ni, lpt);
+                        nj = el_group_sum(nj, lpt);
+                        const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
+                        const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
+                        const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+                        if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+                        if (sub == 0) {
+                            p.s[b] = sb;
+                            myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
+                                      (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < CPL; ++q)
@@ -241,12 +247,13 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
     int64_t cur = -1;
     bool started_inside = false;
     float acc[CPL][VW];
-    float bacc = 0.f;
+    float bacc = 0.f, bacc2 = 0.f;
     int cpos = 0, cneg = 0;
     auto flush = [&](bool ends_inside) {
         const float* pr = p.st.Gi + cur * F;
         float* g = p.st.gGi + cur * F;
-        const float w = (float)(cpos + cneg) * p.l_w;
+        // CML: d/di of +-|u - i|^2 adds -(sum of the coefficients) times the row itself
+        const float w = (float)(cpos + cneg) * p.l_w - (p.cml ? bacc : 0.f);
         const bool plain = started_inside && ends_inside;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
         }
         if (sub == 0) {
             const float beta = p.st.Bi[cur];
-            const float gb = bacc + p.l_b * (float)cpos * beta + (p.l_b / 10.0f) * (float)cneg * beta;
+            const float gb = (p.cml ? bacc2 : bacc) + p.l_b * (float)cpos * beta + (p.l_b / 10.0f) * (float)cneg * beta;
             if (plain)
                 p.st.gBi[cur] = gb;
             else
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
     u32* s_key = reinterpret_cast<u32*>(seg_lds) + (0 * ngl + gl) * BPR_ISTG;
     u32* s_u = reinterpret_cast<u32*>(seg_lds) + (1 * ngl + gl) * BPR_ISTG;
     float* s_cf = reinterpret_cast<float*>(seg_lds) + (2 * ngl + gl) * BPR_ISTG;      // +s_b (positive item) / -s_b (negative)
+    float* s_cf2 = reinterpret_cast<float*>(seg_lds) + (3 * ngl + gl) * BPR_ISTG;     // CML: +-dloss/dE_b
     constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
     for (int64_t sbase = p0; sbase < p1; sbase += BPR_ISTG) {
         const int cs = (int)((p1 - sbase < BPR_ISTG) ? p1 - sbase : BPR_ISTG);
@@ -293,6 +301,11 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
             s_key[t] = p.keys[sbase + t] | (pay & 0x80000000u);      // item ids < 2^31: the top bit carries the role
             s_u[t] = (u32)p.bu[b];
             s_cf[t] = (pay >> 31) ? -sb : sb;
+            if (p.cml) {
+                const float e2 = p.s2[b];
+                s_cf[t] = (pay >> 31) ? -2.0f * sb : 2.0f * sb;      // dD/di = 2 (u - i), dD/dj = -2 (u - j)
+                s_cf2[t] = (pay >> 31) ? -e2 : e2;
+            }
         }
         el_wave_lds_sync();
         for (int base = 0; base < cs; base += SUB) {
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
                     cur = key;
                     started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
                     cpos = cneg = 0;
-                    bacc = 0.f;
+                    bacc = bacc2 = 0.f;
 #pragma unroll
                     for (int q = 0; q < CPL; ++q)
 #pragma unroll
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
 #pragma unroll
                     for (int x = 0; x < VW; ++x) acc[q][x] += coef * rr[t][q][x];
                 bacc += coef;
+                if (p.cml) bacc2 += s_cf2[base + t];
                 if (negv[t])
                     cneg++;
                 else
@@ -439,7 +453,7 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     pi.lpt = lpt;
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
-    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 3 * 4;
+    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
 #define EL_SEG(CPL_)                                                                                      \
     do {                                                                                                  \
         EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), ldsU, s, pu);      \
@@ -496,6 +510,34 @@ extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bp
     if (rc) return rc;
     if (opt < 0) return 0;                           // gradients only (el_bprmf_grads)
     return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
+}
+
+// CML (el_cml.hip): the same sort + segment walk with the per-triplet coefficients given (cD = dloss/dD, cE = dloss/dE)
+// instead of computed by the user segments.  ws: el_bprmf_ws_bytes(B, U, I).
+int el_bpr_sorted_cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, const int32_t* u, const int32_t* i,
+                            const int32_t* j, int64_t B, float l_w, float l_b, float* cD, const float* cE, void* ws,
+                            size_t ws_bytes) {
+    SortedWs w;
+    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
+    EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_cml_train_step: segment workspace too small (%zu < %zu)", ws_bytes, w.total);
+    EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
+              w.keyI_in, w.valI_in);
+    {
+        ElKernelTimer t("rocprim_radix_sort_pairs", s);
+        size_t tb = w.tmp_bytes;
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)B, 0, bits_for(st.U), s));
+        tb = w.tmp_bytes;
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)(2 * B), 0, bits_for(st.I), s));
+    }
+    SegParams base;
+    memset(&base, 0, sizeof(base));
+    base.st = st;
+    base.st.tGu = base.st.tGi = base.st.tBi = nullptr;
+    base.bi = i, base.bj = j, base.bu = u;
+    base.s = cD, base.s2 = cE, base.cml = 1;
+    base.l_w = l_w, base.l_b = l_b;
+    const bool vec = st.F % 4 == 0 && (((uintptr_t)st.Gu | (uintptr_t)st.Gi | (uintptr_t)st.gGu | (uintptr_t)st.gGi) & 15) == 0;
+    return vec ? launch_segs<4>(base, s, B, w) : launch_segs<1>(base, s, B, w);
 }
 
 // Gradients of one batch into the dense accumulators gGu / gGi / gBi (+ the loss), no optimiser: the first half of the
@@ -703,7 +745,7 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     pi.lpt = lpt;
     const int64_t gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridI = (unsigned)((gi * lpt + 255) / 256);
-    const size_t ldsI = (size_t)(256 / lpt) * BPR_ISTG * 3 * 4;
+    const size_t ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
 #define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi)
     if (vec) {
         if (cpl == 1) EL_IS(4, 1); else if (cpl == 2) EL_IS(4, 2); else EL_IS(4, 4);

@@ -957,7 +957,7 @@ class CmlDeviceState(BprmfDeviceState):
     def train_step(self, u, i, j, lr, l_w, l_b, margin):
         self.step += 1
         B = u.numel()
-        need = int(self.ctx.lib.el_cml_ws_bytes(int(B)))
+        need = int(self.ctx.lib.el_cml_ws_bytes(int(B), int(self.U), int(self.I)))
         if self._cml_ws is None or self._cml_ws.numel() < need:
             self._cml_ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         check(self.ctx.lib.el_cml_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),

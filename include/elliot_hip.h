@@ -460,7 +460,7 @@ int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64_t n_rows, 
  * D_a = |u_a - j_a|^2 - |u_a - i_a|^2, E_b = b(i_b) - b(j_b).  Evaluated in O(B log B) (two float sorts + binary searches;
  * el_cml.hip).  Variables, gradient accumulators and Adam slots are an el_bprmf_state (Gu, Gi, Bi); optimiser = Keras
  * Adam with TF 2.3 sparse-apply semantics (EL_OPT_ADAM_TF_DENSE).  loss_out: device double[1], ADDED to.            */
-size_t el_cml_ws_bytes(int64_t B);
+size_t el_cml_ws_bytes(int64_t B, int64_t U, int64_t I);
 int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i,
                       const int32_t* j, int64_t B, float l_w, float l_b, float margin, int32_t step, float lr_t,
                       double* loss_out, void* ws, size_t ws_bytes);

@@ -114,3 +114,22 @@ def test_cml_plugin_end_to_end(ctx, tmp_path):
     assert (np.abs(cpu(model._model.state.Gi) - orc.Gi) > 1e-4).mean() < 1e-2
     res = model.get_results()
     assert set(res.keys()) == {10, 5} and 0.0 <= res[10]["test_results"]["nDCG"] <= 1.0
+
+
+def test_sorted_gradient_path_matches_oracle(ctx):
+    """B >= 2048: row gradients through the sorted segment kernels of the BPR path (coefficients given), hot items included."""
+    rs = np.random.RandomState(11)
+    U, I, F, B, lr, l_w, l_b, margin = 900, 500, 32, 4096, 0.01, 0.01, 0.02, 0.5
+    Gu, Gi, Bi = tables(rs, U, I, F, 0.3)
+    st = ops.CmlDeviceState(ctx, Gu, Gi, Bi)
+    orc = oc.CMLOracle(Gu, Gi, Bi, lr, l_w, l_b, margin)
+    for s in range(3):
+        u, j = rs.randint(0, U, B), rs.randint(0, I, B)
+        i = np.where(rs.rand(B) < 0.3, 5, rs.randint(0, I, B))          # item 5 owns ~30 % of the positives: chunk-crossing segment
+        st.train_step(dev(ctx, u), dev(ctx, i), dev(ctx, j), lr, l_w, l_b, margin)
+        got, exp = st.pop_loss(), orc.train_step((u, i, j))
+        assert abs(got - exp) <= 1e-4 * abs(exp), (s, got, exp)
+        for name, ref in (("Gu", orc.Gu), ("Gi", orc.Gi), ("Bi", orc.Bi)):
+            err = np.abs(cpu(getattr(st, name)) - ref)
+            assert (err > 5e-5).mean() < 5e-3 and err.max() < 5 * lr, (s, name, float(err.max()), float((err > 5e-5).mean()))
+        assert not cpu(st.gGu).any() and not cpu(st.gGi).any() and not cpu(st.gBi).any()
