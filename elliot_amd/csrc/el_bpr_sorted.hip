@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
         int64_t cur = -1;
         bool started_inside = false;
         float gu[CPL][VW], acc[CPL][VW];
-        float nu = 0.f;
         int cnt = 0;
         auto flush = [&](bool ends_inside) {
             float* g = p.st.gGu + cur * F;
@@ -174,43 +173,39 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
                         cur = key;
                         started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
                         cnt = 0;
-                        nu = 0.f;
 #pragma unroll
                         for (int q = 0; q < CPL; ++q)
 #pragma unroll
                             for (int x = 0; x < VW; ++x) {
                                 gu[q][x] = rgu[t][q][x];
                                 acc[q][x] = 0.f;
-                                nu += gu[q][x] * gu[q][x];
                             }
-                        nu = el_group_sum(nu, lpt);
                     }
                     float sb = 0.f;
                     if (p.cml) {
                         sb = 2.0f * p.s[b];                          // d|u-j|^2/du - d|u-i|^2/du = 2 (i - j), times dloss/dD_b
                     } else {
-                        float dpi = 0.f, dpj = 0.f, ni = 0.f, nj = 0.f;
+                        // only the two dot products have to be known to the whole group; the squared norms feed nothing but
+                        // the batch loss, so every lane adds its own share and the loss reduction at the end sums them
+                        float dpi = 0.f, dpj = 0.f, nsq = 0.f;
 #pragma unroll
                         for (int q = 0; q < CPL; ++q)
 #pragma unroll
                             for (int x = 0; x < VW; ++x) {
                                 dpi += gu[q][x] * rgi[t][q][x];
                                 dpj += gu[q][x] * rgj[t][q][x];
-                                ni += rgi[t][q][x] * rgi[t][q][x];
-                                nj += rgj[t][q][x] * rgj[t][q][x];
+                                nsq += gu[q][x] * gu[q][x] + rgi[t][q][x] * rgi[t][q][x] + rgj[t][q][x] * rgj[t][q][x];
                             }
                         dpi = el_group_sum(dpi, lpt);
                         dpj = el_group_sum(dpj, lpt);
-                        ni = el_group_sum(ni, lpt);
-                        nj = el_group_sum(nj, lpt);
                         const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
                         const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
                         const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
                         if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+                        myloss += p.l_w * 0.5f * nsq;
                         if (sub == 0) {
                             p.s[b] = sb;
-                            myloss += el_softplus_s(-dc) + p.l_w * 0.5f * (nu + ni + nj) + p.l_b * 0.5f * beta_i * beta_i +
-                                      (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+                            myloss += el_softplus_s(-dc) + p.l_b * 0.5f * beta_i * beta_i + (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
                         }
                     }
 #pragma unroll
