@@ -47,14 +47,14 @@ __device__ __forceinline__ float el_softplus_s(float x) {
 
 __global__ __launch_bounds__(256) void k_bpr_prep(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
                                                   const int32_t* __restrict__ j, int64_t B, u32* keyU, u32* valU,
-                                                  u32* keyI, u32* valI) {
+                                                  u32* keyI, u32* valI, u32 item_key_off) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
     keyU[t] = (u32)u[t];
     valU[t] = (u32)t;
-    keyI[t] = (u32)i[t];
+    keyI[t] = (u32)i[t] + item_key_off;
     valI[t] = (u32)t;
-    keyI[B + t] = (u32)j[t];
+    keyI[B + t] = (u32)j[t] + item_key_off;
     valI[B + t] = (u32)t | 0x80000000u;
 }
 
@@ -66,7 +66,8 @@ struct SegParams {
     const int32_t* bi;   // item of positive per triplet
     const int32_t* bj;   // negative
     const int32_t* bu;   // user
-    const u32* keys;     // sorted row ids
+    const u32* keys;     // sorted row ids (+ key_off)
+    u32 key_off;         // items are sorted in ONE radix sort behind the users, as U + item
     const u32* vals;     // sorted payloads
     float* s;            // [B] dloss/dd per triplet (BPR: written by the user segments; CML: dloss/dD, given)
     const float* s2;     // CML only: dloss/dE per triplet (the bias-side coefficient)
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
             const u32 pay = p.vals[sbase + t];
             const int64_t b = (int64_t)(pay & 0x7fffffffu);
             const float sb = p.s[b];
-            s_key[t] = p.keys[sbase + t] | (pay & 0x80000000u);      // item ids < 2^31: the top bit carries the role
+            s_key[t] = (p.keys[sbase + t] - p.key_off) | (pay & 0x80000000u);   // item ids < 2^31: the top bit carries the role
             s_u[t] = (u32)p.bu[b];
             s_cf[t] = (pay >> 31) ? -sb : sb;
             if (p.cml) {
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
                 if (key != cur) {
                     if (cur >= 0) flush(true);
                     cur = key;
-                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)(p.keys[pos - 1] - p.key_off) != key);
                     cpos = cneg = 0;
                     bacc = bacc2 = 0.f;
 #pragma unroll
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
         }
         el_wave_lds_sync();
     }
-    flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
+    flush(p1 == p.n || (int64_t)(p.keys[p1] - p.key_off) != cur);
 }
 
 // ---- host ---------------------------------------------------------------------------------
@@ -396,22 +397,34 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
         off += align256(bytes);
         return p;
     };
-    w->keyU_in = (u32*)take((size_t)B * 4);
-    w->valU_in = (u32*)take((size_t)B * 4);
-    w->keyU = (u32*)take((size_t)B * 4);
-    w->valU = (u32*)take((size_t)B * 4);
-    w->keyI_in = (u32*)take((size_t)B * 8);
-    w->valI_in = (u32*)take((size_t)B * 8);
-    w->keyI = (u32*)take((size_t)B * 8);
-    w->valI = (u32*)take((size_t)B * 8);
+    // users [0, B) and items [B, 3B) share one array each, so that one radix sort of 3B keys (users as u, items as
+    // U + item) orders both sides: half the launches of two sorts, and these small sorts are launch-bound
+    u32** slots[4] = {&w->keyU_in, &w->valU_in, &w->keyU, &w->valU};
+    u32** islots[4] = {&w->keyI_in, &w->valI_in, &w->keyI, &w->valI};
+    for (int k = 0; k < 4; ++k) {
+        *slots[k] = (u32*)take((size_t)B * 12);
+        *islots[k] = base ? *slots[k] + B : nullptr;
+    }
     w->s = (float*)take((size_t)B * 4);
     size_t t1 = 0, t2 = 0;
     u32* np = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, t1, np, np, np, np, (unsigned)B, 0, bits_for(U), (hipStream_t)0) != hipSuccess) return 1;
+    if (rocprim::radix_sort_pairs(nullptr, t1, np, np, np, np, (unsigned)(3 * B), 0, bits_for(U + I), (hipStream_t)0) != hipSuccess) return 1;
     if (rocprim::radix_sort_pairs(nullptr, t2, np, np, np, np, (unsigned)(2 * B), 0, bits_for(I), (hipStream_t)0) != hipSuccess) return 1;
     w->tmp_bytes = t1 > t2 ? t1 : t2;
     w->tmp = take(w->tmp_bytes);
     w->total = off;
+    return 0;
+}
+
+// (u, b), (U + i, b), (U + j, b | neg) -> one stable radix sort: the first B sorted entries are the user side, the next 2B
+// the item side (every user key is below every item key)
+static int sort_batch(hipStream_t s, const SortedWs& w, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                      int64_t U, int64_t I) {
+    EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
+              w.keyI_in, w.valI_in, (u32)U);
+    ElKernelTimer t("rocprim_radix_sort_pairs", s);
+    size_t tb = w.tmp_bytes;
+    EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)(3 * B), 0, bits_for(U + I), s));
     return 0;
 }
 
@@ -443,6 +456,7 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     SegParams pi = base;
     pi.keys = w.keyI;
     pi.vals = w.valI;
+    pi.key_off = (u32)base.st.U;
     pi.n = 2 * B;
     pi.chunk = item_chunk_for(B);
     pi.lpt = lpt;
@@ -478,17 +492,7 @@ extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bp
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_train_step_sorted: workspace too small (%zu < %zu)",
                ws_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in,
-              w.valU_in, w.keyI_in, w.valI_in);
-    {
-        ElKernelTimer t("rocprim_radix_sort_pairs", s);
-        size_t tb = w.tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)B, 0,
-                                               bits_for(st.U), s));
-        tb = w.tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)(2 * B), 0,
-                                               bits_for(st.I), s));
-    }
+    if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
     SegParams base;
     memset(&base, 0, sizeof(base));
     base.st = st;
@@ -515,15 +519,7 @@ int el_bpr_sorted_cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st
     SortedWs w;
     EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_cml_train_step: segment workspace too small (%zu < %zu)", ws_bytes, w.total);
-    EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
-              w.keyI_in, w.valI_in);
-    {
-        ElKernelTimer t("rocprim_radix_sort_pairs", s);
-        size_t tb = w.tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)B, 0, bits_for(st.U), s));
-        tb = w.tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)(2 * B), 0, bits_for(st.I), s));
-    }
+    if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
     SegParams base;
     memset(&base, 0, sizeof(base));
     base.st = st;
@@ -714,7 +710,7 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
 #undef EL_TR
     // item side: sorted segments over the local shard
     EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
-              w.keyI_in, w.valI_in);
+              w.keyI_in, w.valI_in, 0u);
     {
         ElKernelTimer t("rocprim_radix_sort_pairs", s);
         size_t tb = w.tmp_bytes;
