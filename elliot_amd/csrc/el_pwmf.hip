@@ -3,7 +3,7 @@
 // One step = five launches + the optimiser passes:
 //   1. k_pw_fwd        one lane group per sample: gather gamma_u, gamma_i (+ biases), x = <gamma_u, gamma_i> + b,
 //                      link, loss, c_b = dloss/dx; also emits the (row id, sample) sort pairs
-//   2. rocprim radix sort of (user, b) and (item, b)   (stable -> a segment is summed in batch order)
+//   2. ONE rocprim radix sort of (user, b) and (U + item, b)   (stable -> a segment is summed in batch order)
 //   3. k_pw_seg (users) dGu[u] = sum_{b in segment} c_b gamma_i(b) (+ cnt l_w gamma_u),  dBu[u] = sum c_b
 //      k_pw_seg (items) dGi[i] = sum_{b in segment} c_b gamma_u(b) (+ cnt l_w gamma_i),  dBi[i] = sum c_b
 //      Segments are cut into chunks of `chunk` sorted positions per lane group; a segment that lives inside one chunk is
@@ -54,6 +54,7 @@ struct PwFwd {
     float* coef;          // [n] dloss/dx
     float* out;           // forward-only output
     u32 *keyU, *valU, *keyI, *valI;
+    u32 item_key_off;     // both sides are ordered by ONE radix sort: users as u, items as U + i
     int64_t n;
     int lpt;
     float inv_n;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_pw_fwd(PwFwd p) {
                 }
                 p.coef[b] = c;
                 p.keyU[b] = (u32)u, p.valU[b] = (u32)b;
-                p.keyI[b] = (u32)i, p.valI[b] = (u32)b;
+                p.keyI[b] = (u32)i + p.item_key_off, p.valI[b] = (u32)b;
             }
         }
     }
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void k_pw_fwd(PwFwd p) {
 #define PW_STG 64
 
 struct PwSeg {
-    const u32* keys;          // sorted row ids of THIS side
+    const u32* keys;          // sorted row ids of THIS side (+ key_off)
+    u32 key_off;
     const u32* vals;          // sample of each sorted position
     const float* coef;        // [n]
     const int32_t* other_ids; // the sample's row in the other table
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_pw_seg(PwSeg p) {
         const int cs = (int)((p1 - sbase < PW_STG) ? p1 - sbase : PW_STG);
         for (int t = sub; t < cs; t += lpt) {
             const int64_t b = (int64_t)p.vals[sbase + t];
-            s_key[gl][t] = p.keys[sbase + t];
+            s_key[gl][t] = p.keys[sbase + t] - p.key_off;
             s_cf[gl][t] = p.coef[b];
             s_oth[gl][t] = (u32)p.other_ids[b];
         }
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_pw_seg(PwSeg p) {
                 if (key != cur) {
                     if (cur >= 0) flush(true);
                     cur = key;
-                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
+                    started_inside = (pos > p0) || (pos == 0) || ((int64_t)(p.keys[pos - 1] - p.key_off) != key);
                     cnt = 0;
                     bacc = 0.f;
 #pragma unroll
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void k_pw_seg(PwSeg p) {
         }
         el_wave_lds_sync();
     }
-    flush(p1 == p.n || (int64_t)p.keys[p1] != cur);
+    flush(p1 == p.n || (int64_t)(p.keys[p1] - p.key_off) != cur);
 }
 
 // Keras Adagrad over a whole variable; rows without a gradient are left as they are (g = 0 changes nothing), which is
@@ -319,14 +321,21 @@ int carve(int64_t n, int64_t U, int64_t I, char* base, PwWs* w) {
         off += align256(bytes);
         return p;
     };
-    u32** slots[8] = {&w->keyU_in, &w->valU_in, &w->keyU, &w->valU, &w->keyI_in, &w->valI_in, &w->keyI, &w->valI};
-    for (auto s : slots) *s = (u32*)take((size_t)n * 4);
+    u32** slots[4] = {&w->keyU_in, &w->valU_in, &w->keyU, &w->valU};      // users [0, n), items [n, 2n) of one array each
+    u32** islots[4] = {&w->keyI_in, &w->valI_in, &w->keyI, &w->valI};
+    for (int k = 0; k < 4; ++k) {
+        *slots[k] = (u32*)take((size_t)n * 8);
+        *islots[k] = base ? *slots[k] + n : nullptr;
+    }
     w->coef = (float*)take((size_t)n * 4);
-    size_t t1 = 0, t2 = 0;
+    size_t t1 = 0, t2 = 0, t3 = 0;
     u32* np = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, t1, np, np, np, np, (unsigned)n, 0, bits_for(U), (hipStream_t)0) != hipSuccess) return 1;
-    if (rocprim::radix_sort_pairs(nullptr, t2, np, np, np, np, (unsigned)n, 0, bits_for(I), (hipStream_t)0) != hipSuccess) return 1;
-    w->tmp_bytes = t1 > t2 ? t1 : t2;
+    if (rocprim::radix_sort_pairs(nullptr, t1, np, np, np, np, (unsigned)(2 * n), 0, bits_for(U + I), (hipStream_t)0) != hipSuccess) return 1;
+    if (rocprim::radix_sort_pairs(nullptr, t2, np, np, np, np, (unsigned)n, 0, bits_for(U), (hipStream_t)0) != hipSuccess) return 1;
+    if (rocprim::radix_sort_pairs(nullptr, t3, np, np, np, np, (unsigned)n, 0, bits_for(U + I), (hipStream_t)0) != hipSuccess) return 1;
+    if (t2 > t1) t1 = t2;
+    if (t3 > t1) t1 = t3;
+    w->tmp_bytes = t1;
     w->tmp = take(w->tmp_bytes);
     w->total = off;
     return 0;
@@ -450,6 +459,7 @@ extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state
     memset(&f, 0, sizeof(f));
     f.st = st, f.bu = u, f.bi = i, f.label = label, f.coef = w.coef, f.n = n;
     f.keyU = w.keyU_in, f.valU = w.valU_in, f.keyI = w.keyI_in, f.valI = w.valI_in;
+    f.item_key_off = (u32)st.U;
     f.inv_n = 1.0f / (float)n;
     f.loss_out = loss_out;
     if (int rc = vec ? launch_fwd<4, true>(f, s) : launch_fwd<1, true>(f, s)) return rc;
@@ -458,19 +468,20 @@ extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state
     {
         ElKernelTimer t("rocprim_radix_sort_pairs", s);
         size_t tb = w.tmp_bytes;
-        if (do_users)
+        if (do_users && do_items)                                  // one sort orders both sides (every user key < every item key)
+            EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)(2 * n), 0, bits_for(st.U + st.I), s));
+        else if (do_users)
             EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)n, 0, bits_for(st.U), s));
-        tb = w.tmp_bytes;
-        if (do_items)
-            EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)n, 0, bits_for(st.I), s));
+        else
+            EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyI_in, w.keyI, w.valI_in, w.valI, (unsigned)n, 0, bits_for(st.U + st.I), s));
     }
     const float l_w = st.kind == EL_PW_LOGISTIC ? st.l_w : 0.f;
     if (do_users) {
-        PwSeg p = {w.keyU, w.valU, w.coef, i, st.Gi, st.Gu, st.gGu, st.gBu, n, st.F, user_chunk(n), 0, l_w};
+        PwSeg p = {w.keyU, 0u, w.valU, w.coef, i, st.Gi, st.Gu, st.gGu, st.gBu, n, st.F, user_chunk(n), 0, l_w};
         if (int rc = vec ? launch_seg<4>(p, "k_pw_seg_users", s) : launch_seg<1>(p, "k_pw_seg_users", s)) return rc;
     }
     if (do_items) {
-        PwSeg p = {w.keyI, w.valI, w.coef, u, st.Gu, st.Gi, st.gGi, st.gBi, n, st.F, item_chunk(n), 0, l_w};
+        PwSeg p = {w.keyI, (u32)st.U, w.valI, w.coef, u, st.Gu, st.Gi, st.gGi, st.gBi, n, st.F, item_chunk(n), 0, l_w};
         if (int rc = vec ? launch_seg<4>(p, "k_pw_seg_items", s) : launch_seg<1>(p, "k_pw_seg_items", s)) return rc;
     }
     if (do_users) {
