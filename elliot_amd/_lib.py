@@ -70,6 +70,7 @@ class NmfState(C.Structure):
         ("X0", _f32p), ("dX0", _f32p), ("MF", _f32p), ("dlogit", _f32p),
         ("act", _P4), ("dact", _P4),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("dropout", C.c_float), ("drop_step", C.c_int32), ("drop_seed", C.c_uint64),
     ]
 
 

@@ -241,6 +241,29 @@ __global__ __launch_bounds__(256) void k_relu_bwd_colsum(float* __restrict__ d, 
     }
 }
 
+// keras Dropout in training mode, in place on x [n, width]: Philox counter (row, column / 4, step, layer) -> four uniforms.
+// The same call on the gradient of x reproduces the mask in the backward pass (nothing is stored).
+__global__ __launch_bounds__(256) void k_nmf_dropout(float* __restrict__ x, int64_t n, int width, float rate, u64 seed, u32 step,
+                                                     u32 layer) {
+    const int w4 = (width + 3) >> 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * w4) return;
+    const int64_t b = t / w4;
+    const int c4 = (int)(t - b * w4);
+    const el_philox4 r = el_philox4x32_10((u32)b, (u32)c4, step, layer, (u32)seed, (u32)(seed >> 32));
+    const u32 rv[4] = {r.x, r.y, r.z, r.w};
+    const float keep = 1.0f / (1.0f - rate);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        if (c < width) {
+            const float uni = (float)(rv[k] >> 8) * (1.0f / 16777216.0f);
+            float* px = x + b * width + c;
+            *px = uni < rate ? 0.f : *px * keep;
+        }
+    }
+}
+
 // embedding gradients (IndexedSlices, duplicates summed): scatter-add one row per sample and table
 __global__ __launch_bounds__(256) void k_nmf_scatter(el_nmf_state st, const int32_t* __restrict__ bu,
                                                      const int32_t* __restrict__ bi, int64_t n) {
@@ -289,6 +312,7 @@ static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
     EL_REQUIRE(st->use_mf || st->use_mlp, "el_nmf: mf_train and mlp_train can not be False at the same time");
     EL_REQUIRE(n >= 1 && n <= st->Bmax, "el_nmf: %lld samples exceed Bmax %lld", (long long)n, (long long)st->Bmax);
     EL_REQUIRE(st->hw != nullptr && st->dlogit != nullptr, "el_nmf: head buffers missing");
+    EL_REQUIRE(st->dropout >= 0.f && st->dropout < 1.f, "el_nmf: dropout must be in [0, 1)");
     EL_REQUIRE((st->use_mf ? st->F : 0) + (st->use_mlp ? st->units[st->n_layers > 0 ? st->n_layers - 1 : 0] : 0) <= 64 * NMF_HEAD_Q,
                "el_nmf: head input wider than %d features", 64 * NMF_HEAD_Q);
     if (st->use_mf) EL_REQUIRE(st->tab[0] && st->tab[1] && st->MF && st->F >= 1, "el_nmf: MF tables missing");
@@ -304,12 +328,21 @@ static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
     return 0;
 }
 
-static int nmf_forward(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n) {
+static void nmf_dropout(hipStream_t s, const el_nmf_state* st, float* x, int64_t n, int64_t width, int layer) {
+    const int64_t threads = n * ((width + 3) / 4);
+    EL_LAUNCH("k_nmf_dropout", k_nmf_dropout, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, n, (int)width, st->dropout,
+              (u64)st->drop_seed, (u32)st->drop_step, (u32)layer);
+}
+
+static int nmf_forward(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n,
+                       bool train = false) {
     EL_LAUNCH("k_nmf_gather", k_nmf_gather, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
+    const bool drop = train && st->dropout > 0.f;
     if (st->use_mlp) {
-        const float* in = st->X0;
+        float* in = st->X0;
         int64_t kin = 2 * (int64_t)st->E;
         for (int l = 0; l < st->n_layers; ++l) {
+            if (drop) nmf_dropout(s, st, in, n, kin, l);            // Dropout in front of Dense l: the input buffer itself is dropped
             if (int rc = el_gemm_f32(ctx, s, 0, 0, n, st->units[l], kin, in, kin, st->W[l], st->units[l], st->act[l],
                                      st->units[l], st->b[l], 2 /*relu*/, st->ws, st->ws_bytes)) return rc;
             in = st->act[l];
@@ -340,7 +373,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const i
                      int64_t n, int64_t n_div, double* loss_out) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
-    if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
+    if (int rc = nmf_forward(ctx, s, st, u, i, n, true)) return rc;
     EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
     if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
     EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out, n_div);
@@ -361,6 +394,9 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const i
             if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
             float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
             if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+            // gradient w.r.t. the DROPPED input -> w.r.t. the layer below: the same mask again.  (The relu test of the layer
+            // below then reads its dropped output: zero exactly where this mask is zero, positive where it was positive.)
+            if (st->dropout > 0.f) nmf_dropout(s, st, din, n, kin, l);
         }
     }
     EL_LAUNCH("k_nmf_scatter", k_nmf_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);

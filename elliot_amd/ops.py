@@ -688,9 +688,10 @@ class NmfDeviceState:
     weights: dict with optional "Umf" [U,F], "Imf" [I,F] (MF branch), "Umlp" [U,E], "Imlp" [I,E], "W" list of
     [in,out] kernels and "b" list of biases (MLP branch), "hw" head weights [F + units[-1]] and optional "hb" [1]."""
 
-    def __init__(self, ctx, weights, max_batch):
+    def __init__(self, ctx, weights, max_batch, dropout=0.0, dropout_seed=42):
         self.ctx = ctx
         dev = ctx.device
+        self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
         f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
         self.use_mf = "Umf" in weights
         self.use_mlp = "Umlp" in weights
@@ -740,7 +741,13 @@ class NmfDeviceState:
             mb=a4(self.mb), vb=a4(self.vb),
             hw=p(self.hw), hb=p(self.hb), ghw=p(self.ghw), ghb=p(self.ghb), mhw=p(self.mhw), vhw=p(self.vhw),
             mhb=p(self.mhb), vhb=p(self.vhb), X0=p(self.X0), dX0=p(self.dX0), MF=p(self.MF), dlogit=p(self.dlogit),
-            act=a4(self.act), dact=a4(self.dact), ws=self._ws.data_ptr(), ws_bytes=self._ws.numel())
+            act=a4(self.act), dact=a4(self.dact), ws=self._ws.data_ptr(), ws_bytes=self._ws.numel(),
+            dropout=self.dropout, drop_step=0, drop_seed=self.dropout_seed & 0xFFFFFFFFFFFFFFFF)
+        self._drop_calls = 0
+
+    def _next_mask(self):
+        self._drop_calls += 1                                        # a fresh dropout mask per gradient evaluation
+        self._c.drop_step = self._drop_calls & 0x7FFFFFFF
 
     def weights(self):
         out = {}
@@ -757,6 +764,7 @@ class NmfDeviceState:
 
     def train_step(self, u, i, label, lr):
         self.step += 1
+        self._next_mask()
         n = u.numel()
         check(self.ctx.lib.el_nmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
                                              _ptr(i, torch.int32), _ptr(label, torch.float32), int(n), int(self.step),
@@ -767,6 +775,7 @@ class NmfDeviceState:
         """Forward + loss + backward only (multi-GPU: the BCE mean runs over n_global samples); gradients stay in the
         state's buffers (replicated_grads() lists the ones a data-parallel caller has to all-reduce)."""
         n = u.numel()
+        self._next_mask()
         check(self.ctx.lib.el_nmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
                                         _ptr(i, torch.int32), _ptr(label, torch.float32), int(n),
                                         int(n if n_global is None else n_global), _ptr(self.loss, torch.float64)), "el_nmf_grads")

@@ -19,10 +19,11 @@ def _glorot_uniform(rs, rows, cols):
 class _PointwiseModel:
     """Shared device plumbing: train_step on (user, item, label), pair scoring, full-catalogue top-k."""
 
-    def _setup(self, ctx, weights, max_batch, lr, num_users, num_items):
+    def _setup(self, ctx, weights, max_batch, lr, num_users, num_items, dropout=0.0, seed=42):
         self.ctx = ctx or ops.get_context(0)
         self.num_users, self.num_items, self._lr = num_users, num_items, lr
-        self.state = ops.NmfDeviceState(self.ctx, weights, max_batch)
+        self._dropout, self._seed = float(dropout or 0.0), seed
+        self.state = ops.NmfDeviceState(self.ctx, weights, max_batch, dropout=self._dropout, dropout_seed=seed)
         self._items = torch.arange(num_items, dtype=torch.int32, device=self.ctx.device)
 
     def _idx(self, x):
@@ -79,15 +80,13 @@ class _PointwiseModel:
 
     def load_weights(self, path):
         with open(path, "rb") as f:
-            self.state = ops.NmfDeviceState(self.ctx, pickle.load(f), self.state.Bmax)
+            self.state = ops.NmfDeviceState(self.ctx, pickle.load(f), self.state.Bmax, dropout=self._dropout, dropout_seed=self._seed)
 
 
 class NeuralMatrixFactorizationModel(_PointwiseModel):
     def __init__(self, num_users, num_items, embed_mf_size, embed_mlp_size, mlp_hidden_size, dropout, is_mf_train,
                  is_mlp_train, learning_rate=0.01, random_seed=42, name="NeuralMatrixFactorizationModel", ctx=None,
                  max_batch=1 << 20, init_weights=None, **kwargs):
-        if dropout:
-            raise NotImplementedError("NeuMF dropout > 0 is not available on the MI355X backend yet (reference default: 0)")
         if not (is_mf_train or is_mlp_train):
             raise RuntimeError('mf_train and mlp_train can not be False at the same time')
         if init_weights is None:
@@ -108,7 +107,7 @@ class NeuralMatrixFactorizationModel(_PointwiseModel):
             w["hw"] = _glorot_uniform(rs, (embed_mf_size if is_mf_train else 0) + last, 1)[:, 0].copy()
             w["hb"] = np.zeros(1, np.float32)
             init_weights = w
-        self._setup(ctx, init_weights, max_batch, learning_rate, num_users, num_items)
+        self._setup(ctx, init_weights, max_batch, learning_rate, num_users, num_items, dropout=dropout, seed=random_seed)
 
 
 class GeneralizedMatrixFactorizationModel(_PointwiseModel):

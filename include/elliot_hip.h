@@ -369,6 +369,11 @@ typedef struct el_nmf_state {
     float* act[4];  /* [Bmax, units[l]]                           */
     float* dact[4];
     void* ws; size_t ws_bytes;   /* GEMM split-K workspace */
+    /* keras Dropout(dropout) in front of every Dense of the MLP tower (neural_matrix_factorization_model.py:58-61),
+     * active in train_step only: x <- x * keep / (1 - dropout), keep ~ Bernoulli(1 - dropout) from Philox4x32-10 with
+     * counter (sample row, column / 4, drop_step, layer) and key drop_seed; the caller advances drop_step per step.
+     * TensorFlow's own random stream cannot be reproduced; the distribution is.  0 = off (the reference's default). */
+    float dropout; int32_t drop_step; uint64_t drop_seed;
 } el_nmf_state;
 
 /* Replaces: pointwise_pos_neg_sampler.Sampler.step (dataset/samplers/pointwise_pos_neg_sampler.py:26-50):

@@ -43,7 +43,9 @@ def init_gmf(U, I, F, seed):
     return {"Umf": glorot_uniform(rs, U, F), "Imf": glorot_uniform(rs, I, F), "hw": glorot_uniform(rs, F, 1)[:, 0].copy()}
 
 
-def forward(w, u, i, dtype=np.float32):
+def forward(w, u, i, dtype=np.float32, masks=None):
+    """masks: per Dense layer l the Dropout scale matrix ({0, 1/(1-rate)}, shape of the layer INPUT) applied in front of it
+    (neural_matrix_factorization_model.py:58-61, training only) or None."""
     f = lambda a: np.asarray(a, dtype=dtype)
     c = {}
     parts = []
@@ -53,10 +55,13 @@ def forward(w, u, i, dtype=np.float32):
         parts.append(c["mf"])
     if "Umlp" in w:
         x = np.concatenate([f(w["Umlp"])[u], f(w["Imlp"])[i]], axis=1)
-        c["acts"] = [x]
-        for W, b in zip(w["W"], w["b"]):
+        c["ins"], c["outs"], c["masks"] = [], [], masks
+        for l, (W, b) in enumerate(zip(w["W"], w["b"])):
+            if masks is not None:
+                x = x * f(masks[l])
+            c["ins"].append(x)
             x = np.maximum(x @ f(W) + f(b), 0)
-            c["acts"].append(x)
+            c["outs"].append(x)
         parts.append(x)
     c["cat"] = np.concatenate(parts, axis=1)
     logit = c["cat"] @ f(w["hw"]) + (f(w["hb"])[0] if "hb" in w else 0)
@@ -87,10 +92,12 @@ def gradients(w, c, u, i, y):
         d = dlogit[:, None] * hw[None, F:]
         g["W"], g["b"] = [None] * len(w["W"]), [None] * len(w["W"])
         for l in range(len(w["W"]) - 1, -1, -1):
-            d = d * (c["acts"][l + 1] > 0)
-            g["W"][l] = c["acts"][l].T @ d
+            d = d * (c["outs"][l] > 0)
+            g["W"][l] = c["ins"][l].T @ d
             g["b"][l] = d.sum(0)
             d = d @ np.asarray(w["W"][l], p.dtype).T
+            if c["masks"] is not None:
+                d = d * np.asarray(c["masks"][l], p.dtype)
         E = w["Umlp"].shape[1]
         g["Umlp"], g["Imlp"] = np.zeros(w["Umlp"].shape, p.dtype), np.zeros(w["Imlp"].shape, p.dtype)
         np.add.at(g["Umlp"], u, d[:, :E])
@@ -115,10 +122,10 @@ class NeuMFOracle:
         v += (g * g - v) * f(1 - BETA2)
         th -= (m * a) / (np.sqrt(v) + f(EPS))
 
-    def train_step(self, u, i, y):
+    def train_step(self, u, i, y, masks=None):
         u, i = np.asarray(u, np.int64), np.asarray(i, np.int64)
         y = np.asarray(y, np.float32)
-        c = forward(self.w, u, i)
+        c = forward(self.w, u, i, masks=masks)
         loss = bce(c["p"], y)
         g = gradients(self.w, c, u, i, y)
         self.t += 1
@@ -136,3 +143,26 @@ class NeuMFOracle:
 
     def predict(self, u, i):
         return forward(self.w, np.asarray(u, np.int64), np.asarray(i, np.int64))["p"]
+
+
+def dropout_masks(n, widths, rate, seed, step):
+    """The device's Dropout masks (el_neural.hip, k_nmf_dropout): Philox4x32-10 with counter (row, column // 4, step, layer),
+    key = seed; the four outputs serve four consecutive columns; keep where uniform >= rate, scale 1 / (1 - rate)."""
+    out = []
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    mask32 = np.uint64(0xFFFFFFFF)
+    for layer, width in enumerate(widths):
+        w4 = (width + 3) // 4
+        b, c4 = np.meshgrid(np.arange(n, dtype=np.uint64), np.arange(w4, dtype=np.uint64), indexing="ij")
+        c0, c1 = b & mask32, c4
+        c2, c3 = np.full_like(b, step), np.full_like(b, layer)
+        k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        for _ in range(10):
+            p0, p1 = M0 * c0, M1 * c2
+            hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask32, p1 >> np.uint64(32), p1 & mask32
+            c0, c1, c2, c3 = (hi1 ^ c1 ^ np.uint64(k0)) & mask32, lo1, (hi0 ^ c3 ^ np.uint64(k1)) & mask32, lo0
+            k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+        r = np.stack([c0, c1, c2, c3], axis=-1).reshape(n, w4 * 4)[:, :width]
+        uni = (r >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        out.append(np.where(uni < np.float32(rate), np.float32(0), np.float32(1) / (np.float32(1) - np.float32(rate))).astype(np.float32))
+    return out

@@ -121,3 +121,34 @@ def test_neumf_item_sharded_hip_path_equals_concatenated_batch(ctx):
             for k in ("Imf", "Imlp"):
                 err = np.abs(wr[k] - orc.w[k][lo:hi])
                 assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (step, k, float(err.max()))
+
+
+@pytest.mark.parametrize("rate", [0.25, 0.6])
+def test_neumf_dropout_matches_oracle_with_the_same_masks(ctx, rate):
+    """Dropout(rate) in front of every Dense, training only: the device's Philox masks are restated in oracle.dropout_masks."""
+    rs = np.random.RandomState(6)
+    U, I, F, B, lr = 150, 120, 8, 500, 0.002
+    w0 = on.init_neumf(U, I, F, 3)
+    st = ops.NmfDeviceState(ctx, w0, max_batch=B, dropout=rate, dropout_seed=1234)
+    orc = on.NeuMFOracle(w0, lr)
+    d = ctx.device
+    for s in range(4):
+        n = B if s != 2 else 77
+        u = rs.randint(0, U, n).astype(np.int32)
+        i = rs.randint(0, I, n).astype(np.int32)
+        y = rs.randint(0, 2, n).astype(np.float32)
+        st.train_step(torch.from_numpy(u).to(d), torch.from_numpy(i).to(d), torch.from_numpy(y).to(d), lr)
+        masks = on.dropout_masks(n, [2 * F, 4 * F, 2 * F], rate, 1234, s + 1)
+        got, exp = st.pop_loss(), orc.train_step(u, i, y, masks=masks)
+        assert abs(got - exp) <= 1e-4 * max(abs(exp), 1e-3), (s, got, exp)
+        gw = st.weights()
+        for k, v in orc.w.items():
+            pairs = zip(gw[k], v) if isinstance(v, list) else [(gw[k], v)]
+            for a, b in pairs:
+                err = np.abs(a - b)
+                assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()))
+    # scoring never drops
+    u, i = rs.randint(0, U, 300).astype(np.int32), rs.randint(0, I, 300).astype(np.int32)
+    p = cpu(st.forward(torch.from_numpy(u).to(d), torch.from_numpy(i).to(d)))
+    ref = on.forward(st.weights(), u.astype(np.int64), i.astype(np.int64), dtype=np.float64)["p"]
+    assert np.abs(p - ref).max() < 1e-5
