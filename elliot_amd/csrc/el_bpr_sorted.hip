@@ -420,6 +420,7 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
 // the item side (every user key is below every item key)
 static int sort_batch(hipStream_t s, const SortedWs& w, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                       int64_t U, int64_t I) {
+    EL_REQUIRE(U + I < (1LL << 32) && 3 * B < (1LL << 32), "sorted gradient path: U + I and 3B must fit 32-bit sort keys");
     EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
               w.keyI_in, w.valI_in, (u32)U);
     ElKernelTimer t("rocprim_radix_sort_pairs", s);

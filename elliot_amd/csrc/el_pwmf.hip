@@ -448,6 +448,7 @@ extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state
     EL_REQUIRE(u && i && label && loss_out, "el_pwmf_train_step: null argument");
     EL_REQUIRE(step >= 1, "el_pwmf_train_step: step must be >= 1");
     EL_REQUIRE(n < (1LL << 31), "el_pwmf_train_step: batch too large");
+    EL_REQUIRE(stp->U + stp->I < (1LL << 32), "el_pwmf_train_step: U + I must fit a 32-bit sort key");
     const el_pwmf_state st = *stp;
     PwWs w;
     EL_REQUIRE(carve(n, st.U, st.I, (char*)ws, &w) == 0, "el_pwmf_train_step: rocprim size query failed");
