@@ -450,3 +450,47 @@ def test_pointwise_plugins_learn(ctx, tmp_path):
         per_epoch = [l * (n + 1) for n, l in enumerate(m._losses)]
         assert per_epoch[-1] < per_epoch[0], (cls.__name__, per_epoch)
         assert m.get_results()[10]["test_results"]["Recall"] > 2 * 10 / data.num_items, cls.__name__
+
+
+def test_mini_runner_runs_every_model_and_the_proxy_reads_its_recs(ctx, tmp_path):
+    """One YAML with every plugin of the package; then ProxyRecommender re-evaluates the recs file BPRMF_batch wrote and gets
+    BPRMF_batch's own metrics (write -> read -> evaluate round trip through the real models)."""
+    import glob
+    import yaml
+    from elliot_amd.run import run_experiment
+    indptr, indices, _ = small_dataset(250, 200, seed=11)
+    rs = np.random.RandomState(0)
+    users = np.repeat(np.arange(250), np.diff(indptr))
+    with open(tmp_path / "dataset.tsv", "w") as f:
+        for u, i in zip(users, indices):
+            f.write(f"{u + 1}\t{i + 1}\t{rs.randint(1, 6)}\t{rs.randint(0, 10 ** 6)}\n")
+    base = {"dataset": "toy", "data_config": {"strategy": "dataset", "dataset_path": "dataset.tsv"},
+            "splitting": {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2}},
+            "top_k": 10, "evaluation": {"simple_metrics": ["nDCG", "Recall"]},
+            "path_output_rec_result": "out/recs/", "path_output_rec_weight": "out/weights/", "path_output_rec_performance": "out/perf/"}
+    common = {"epochs": 2, "batch_size": 256}
+    models = {
+        "BPRMF_batch": {"meta": {"save_recs": True}, "epochs": 1, "batch_size": 256, "factors": 16, "lr": 0.01, "l_w": 0.01, "l_b": 0.001},
+        "BPRMF": {"epochs": 1, "factors": 16},
+        "MF": {**common, "factors": 16, "lr": 0.01}, "PMF": {**common, "factors": 16, "lr": 0.01},
+        "FunkSVD": {**common, "factors": 16, "lr": 0.01},
+        "LogisticMatrixFactorization": {**common, "factors": 16, "lr": 0.05, "reg": 0.01, "alpha": 0.5},
+        "CML": {**common, "factors": 16, "lr": 0.01}, "GMF": {**common, "mf_factors": 8, "lr": 0.01},
+        "NeuMF": {**common, "mf_factors": 8, "lr": 0.01, "m": 1, "dropout": 0.1},
+        "MultiVAE": {**common, "intermediate_dim": 32, "latent_dim": 8}, "MultiDAE": {**common, "intermediate_dim": 32, "latent_dim": 8},
+    }
+    with open(tmp_path / "exp.yml", "w") as f:
+        yaml.safe_dump({"experiment": {**base, "models": models}}, f)
+    res = run_experiment(str(tmp_path / "exp.yml"))
+    assert len(res) == len(models)
+    for name, r in res.items():
+        assert 0.0 <= r[10]["test_results"]["nDCG"] <= 1.0, name
+    recs = sorted(glob.glob(str(tmp_path / "out" / "recs" / "BPRNN_*.tsv")))
+    assert recs, os.listdir(tmp_path / "out" / "recs")
+    with open(tmp_path / "proxy.yml", "w") as f:
+        yaml.safe_dump({"experiment": {**base, "models": {"ProxyRecommender": {"path": recs[-1]}}}}, f)
+    again = run_experiment(str(tmp_path / "proxy.yml"))
+    (proxy_res,) = again.values()
+    trained = next(r for n, r in res.items() if n.startswith("BPRNN_"))          # one epoch -> one file = the reported result
+    for metric, value in trained[10]["test_results"].items():
+        assert abs(proxy_res[10]["test_results"][metric] - value) < 1e-12, metric
