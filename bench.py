@@ -296,18 +296,21 @@ def main():
         def topk_step():
             s = (blk[0] % n_blocks) * Ub
             blk[0] += 1
-            ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s, s + Ub, k, excl=pos_train, algo=args.topk_algo)
+            ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s, s + Ub, k, excl=pos_train, algo=args.topk_algo,
+                           items_unchanged=s > 0)                  # block 0 of every pass over the users derives the item image
     elif topk_by_user:
         # users are independent units: each rank scores ITS blocks of users against the whole catalogue
         def topk_step():
             s = ((blk[0] * world + rank) % n_blocks) * Ub
             blk[0] += 1
-            ops.score_topk(ctx, st.Gu, full_items["Gi"], full_items["Bi"], s, s + Ub, k, excl=pos, algo=args.topk_algo)
+            ops.score_topk(ctx, st.Gu, full_items["Gi"], full_items["Bi"], s, s + Ub, k, excl=pos, algo=args.topk_algo,
+                           items_unchanged=blk[0] > 1 and (blk[0] - 1) % n_blocks != 0)
     else:
         def topk_step():
             s = (blk[0] % n_blocks) * Ub
             blk[0] += 1
-            parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo=args.topk_algo)
+            parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo=args.topk_algo,
+                                  items_unchanged=s > 0)           # block 0 of every pass over the users derives the item image
 
     def timed(fn, warmup, steps, finish=None):
         for _ in range(warmup):

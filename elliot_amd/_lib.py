@@ -84,6 +84,7 @@ class PwmfState(C.Structure):
     ]
 
 
+EL_TOPK_ITEMS_UNCHANGED = 0x100
 EL_PW_MSE, EL_PW_MSE_SIGMOID, EL_PW_LOGISTIC = 0, 1, 2
 EL_PW_ADAM, EL_PW_ADAGRAD = 0, 1
 EL_PW_BOTH, EL_PW_ITEMS, EL_PW_USERS = 0, 1, 2

@@ -23,6 +23,12 @@ struct el_ctx {
     bool timing;
     std::vector<el_timing_rec> pending;
     std::vector<hipEvent_t> pool;
+    // screened top-k: what the item-side image in the last workspace was derived from (EL_TOPK_ITEMS_UNCHANGED)
+    const void* prep_ws = nullptr;
+    const float* prep_Gi = nullptr;
+    const float* prep_Bi = nullptr;
+    int64_t prep_I = 0;
+    int prep_F = 0;
     // el_bprmf_train_loop: the captured small-batch step sequence (hipGraphExec_t) and the launch parameters it was built for
     void* loop_graph_exec = nullptr;
     std::vector<unsigned char> loop_graph_key;

@@ -569,9 +569,10 @@ static bool mfma_eligible(int F, int k, const void* cand) { return cand == nullp
 // el_topk_screen.hip
 bool el_topk_screen_eligible(int F, int k, const void* cand);
 size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, int64_t excl_nnz);
-int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream_t st);
+int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream_t st, bool items_unchanged);
 
 extern "C" size_t el_score_topk_ws_bytes(int64_t n_users, int64_t I_local, int32_t F, int32_t k, int64_t excl_nnz, int algo) {
+    algo &= 0xff;
     if ((algo == EL_TOPK_AUTO || algo == EL_TOPK_SCREEN) && el_topk_screen_eligible(F, k, nullptr) && n_users > 0)
         return el_topk_screen_ws_bytes(n_users, I_local, F, k, excl_nnz);
     return 0;
@@ -809,6 +810,8 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
                              void* ws, size_t ws_bytes) {
     if (int rc = el_bind(ctx)) return rc;
     if (int rc = check_topk_args("el_score_topk", u_start, u_stop, I_local, F, k, out_idx, out_val)) return rc;
+    const bool items_unchanged = (algo & EL_TOPK_ITEMS_UNCHANGED) != 0;
+    algo &= 0xff;
     EL_REQUIRE(Gu && Gi, "el_score_topk: null factor table");
     EL_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr) || excl_indptr != nullptr,
                "el_score_topk: excl_indices without excl_indptr");
@@ -840,7 +843,7 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
     if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=256, k<=128 and no candidate list");
     if (algo == EL_TOPK_SCREEN ||
         (algo == EL_TOPK_AUTO && selig && ws != nullptr && ws_bytes >= el_topk_screen_ws_bytes(u_stop - u_start, I_local, F, k, 0)))
-        return el_topk_screen_run(p, ws, ws_bytes, st);
+        return el_topk_screen_run(p, ws, ws_bytes, st, items_unchanged);
     bool elig = mfma_eligible(F, k, cand_indptr);
     if (algo == EL_TOPK_MFMA) EL_REQUIRE(elig, "el_score_topk: MFMA kernel needs F<=256, k<=40 and no candidate list");
     bool use_mfma = (algo == EL_TOPK_MFMA) || (algo == EL_TOPK_AUTO && elig);

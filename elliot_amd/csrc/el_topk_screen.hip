@@ -787,7 +787,7 @@ static int run_passes(ScreenParams& sp, hipStream_t st) {
     return 0;
 }
 
-int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
+int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream_t st, bool items_unchanged) {
     const int64_t n_users = p.u_stop - p.u_start;
     if (n_users <= 0) return 0;
     const int FP = screen_fp(p.F);
@@ -828,8 +828,19 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     sp.Gib = gib;
     sp.stats = stats;
     sp.prof = nullptr;
-    EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
-    if (p.I_local > 0) {
+    // The item side (bf16 image, max norm, max |bias|) depends on Gi / Bi only.  A caller that scores block after block of
+    // users against an unchanged table says so (EL_TOPK_ITEMS_UNCHANGED); the claim is honoured only if this context's
+    // previous screened call used the same workspace, tables and shape.
+    el_ctx* ctx = g_el_cur_ctx;
+    const bool reuse = items_unchanged && ctx->prep_ws == ws && ctx->prep_Gi == p.Gi && ctx->prep_Bi == p.Bi &&
+                       ctx->prep_I == p.I_local && ctx->prep_F == p.F;
+    ctx->prep_ws = ws, ctx->prep_Gi = p.Gi, ctx->prep_Bi = p.Bi, ctx->prep_I = p.I_local, ctx->prep_F = p.F;
+    if (reuse) {
+        EL_CHECK_HIP(hipMemsetAsync(stats + 2, 0, 8, st));          // only the flagged-user counter
+    } else {
+        EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
+    }
+    if (p.I_local > 0 && !reuse) {
         const unsigned pg = (unsigned)((p.I_local * (FP / 8) + 255) / 256);
         if (FP == 32)
             EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);

@@ -137,9 +137,11 @@ def _csr_ptrs(csr):
 # scoring + top-k
 # ------------------------------------------------------------------------------------------
 def score_topk(ctx, Gu, Gi, Bi, u_start, u_stop, k, excl=None, cand=None, item_offset=0, algo="auto",
-               out_idx=None, out_val=None):
+               out_idx=None, out_val=None, items_unchanged=False):
     """BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) for users
-    [u_start, u_stop): returns (idx int32 [n,k], val float32 [n,k]) on the device."""
+    [u_start, u_stop): returns (idx int32 [n,k], val float32 [n,k]) on the device.
+    items_unchanged: Gi / Bi are exactly what the previous call on this context scored against (block after block of one
+    evaluation): the screened kernels keep that call's item-side image."""
     n = int(u_stop) - int(u_start)
     I_local, F = Gi.shape
     if Gu.shape[1] != F:
@@ -164,7 +166,7 @@ def score_topk(ctx, Gu, Gi, Bi, u_start, u_stop, k, excl=None, cand=None, item_o
                                 _ptr(Gi, torch.float32, "Gi"), _ptr(Bi, torch.float32, "Bi"),
                                 int(u_start), int(u_stop), int(item_offset), int(I_local), int(F),
                                 ep, ei, cp, ci, int(k), _ptr(out_idx, torch.int32), _ptr(out_val, torch.float32),
-                                algo_id, ws, need),
+                                algo_id | (_lib.EL_TOPK_ITEMS_UNCHANGED if items_unchanged else 0), ws, need),
           "el_score_topk")
     return out_idx, out_val
 

@@ -100,9 +100,10 @@ class _Collectives:
 # ------------------------------------------------------------------------------------------------------
 # top-k
 # ------------------------------------------------------------------------------------------------------
-def sharded_topk(ctx, coll, Gu, Gi_shard, Bi_shard, item_lo, u_start, u_stop, k, excl=None, algo="auto"):
+def sharded_topk(ctx, coll, Gu, Gi_shard, Bi_shard, item_lo, u_start, u_stop, k, excl=None, algo="auto", items_unchanged=False):
     """Full-catalogue top-k of users [u_start, u_stop) with the item table sharded over `coll.world` ranks."""
-    pi, pv = ops.score_topk(ctx, Gu, Gi_shard, Bi_shard, u_start, u_stop, k, excl=excl, item_offset=item_lo, algo=algo)
+    pi, pv = ops.score_topk(ctx, Gu, Gi_shard, Bi_shard, u_start, u_stop, k, excl=excl, item_offset=item_lo, algo=algo,
+                            items_unchanged=items_unchanged)
     if coll.world == 1 and not coll.always:
         return pi, pv
     n = u_stop - u_start

@@ -49,6 +49,7 @@ class BPRMF_batch_model:
             Gi = rs.uniform(-li, li, size=(num_items, factors)).astype(np.float32)
             Bi = np.zeros(num_items, np.float32)
         self.state = ops.BprmfDeviceState(self.ctx, Gu, Gi, Bi, optimizer=optimizer)
+        self._weights_version, self._scored_version = 0, -1          # recommend() re-derives the item image after any update
 
     # -- training ---------------------------------------------------------------------------------------
     def _as_index(self, x):
@@ -59,6 +60,7 @@ class BPRMF_batch_model:
     def train_step(self, batch):
         """BPRMF_batch_model.train_step (:58-80).  batch = (user, pos, neg), shapes [B] or [B, 1]."""
         u, i, j = (self._as_index(x) for x in batch)
+        self._weights_version += 1
         self.state.train_step(u, i, j, self._learning_rate, self._l_w, self._l_b)
         return DeferredLoss(self.state)
 
@@ -66,6 +68,7 @@ class BPRMF_batch_model:
         """The whole `for batch in sampler.step(events, batch_size): train_step(batch)` loop of BPRMF_batch.train
         (:100-109) in one library call (el_bprmf_train_loop); same triplets, same updates."""
         first = sampler.advance(events)
+        self._weights_version += 1
         self.state.train_loop(sampler.pos, events, batch_size, sampler.seed, first, self._learning_rate, self._l_w, self._l_b)
         return DeferredLoss(self.state)
 
@@ -75,9 +78,11 @@ class BPRMF_batch_model:
         (("excl", csr) | ("cand", csr) | None) -> (idx int32 [n, k], val fp32 [n, k]) device tensors."""
         kind, csr = mask if mask is not None else (None, None)
         st = self.state
+        same_items = self._scored_version == self._weights_version   # block after block of one evaluation
+        self._scored_version = self._weights_version
         return ops.score_topk(self.ctx, st.Gu, st.Gi, st.Bi, start, stop, k,
                               excl=csr if kind == "excl" else None, cand=csr if kind == "cand" else None,
-                              item_offset=item_offset)
+                              item_offset=item_offset, items_unchanged=same_items)
 
     def get_top_k(self, predictions, train_mask, k=100):
         """get_top_k (:87-88) on a materialised [n, I] block (compatibility path)."""
@@ -100,6 +105,7 @@ class BPRMF_batch_model:
 
     def set_model_state(self, d):
         st = self.state
+        self._weights_version += 1
         st.Gu.copy_(torch.from_numpy(d["_user_factors"]))
         st.Gi.copy_(torch.from_numpy(d["_item_factors"]))
         st.Bi.copy_(torch.from_numpy(d["_item_bias"]))

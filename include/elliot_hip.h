@@ -229,7 +229,11 @@ enum {
     EL_TOPK_AUTO = 0,   /* SCREEN when eligible and a workspace is given, else MFMA, else the wave kernel */
     EL_TOPK_MFMA = 1,   /* force the fp32 kernel, v_mfma_f32_32x32x2_f32 (F<=256, k<=40)                */
     EL_TOPK_SIMPLE = 2, /* force the wave-per-user VALU kernel (any F, k<=4032, candidate protocol)     */
-    EL_TOPK_SCREEN = 3  /* force the bf16-screened / fp32-exact kernels (F<=256, k<=128); same results  */
+    EL_TOPK_SCREEN = 3, /* force the bf16-screened / fp32-exact kernels (F<=256, k<=128); same results  */
+    /* flag, OR-ed into algo: the caller asserts that Gi / Bi have not been written since its previous el_score_topk call
+     * with this workspace (scoring block after block of users against one table): the screened kernels then keep the
+     * item-side bf16 image of that call instead of deriving it again.  Ignored unless workspace, tables and shape match. */
+    EL_TOPK_ITEMS_UNCHANGED = 0x100
 };
 
 /* Replaces: BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) and

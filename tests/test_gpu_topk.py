@@ -296,3 +296,24 @@ def test_topk_fuzz_all_algorithms_against_oracle(ctx):
         for algo in algos:
             gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo=algo)
             assert_topk_equal(f"fuzz_{n}_{algo}_U{U}_I{I}_F{F}_k{k}", gi, gv, ei, ev)
+
+
+def test_items_unchanged_flag_reuses_only_a_matching_image(ctx):
+    """EL_TOPK_ITEMS_UNCHANGED keeps the item-side bf16 image of the previous call; results are identical, and a claim that
+    does not match the previous call (other table, other shape) is ignored."""
+    rs = np.random.RandomState(3)
+    U, I, F, k = 700, 2500, 64, 10
+    Gu = torch.from_numpy(rs.normal(size=(U, F)).astype(np.float32)).to(ctx.device)
+    Gi = torch.from_numpy(rs.normal(size=(I, F)).astype(np.float32)).to(ctx.device)
+    Bi = torch.from_numpy(rs.normal(size=I).astype(np.float32)).to(ctx.device)
+    a = ops.score_topk(ctx, Gu, Gi, Bi, 0, 350, k, algo="screen")
+    b = ops.score_topk(ctx, Gu, Gi, Bi, 350, 700, k, algo="screen", items_unchanged=True)
+    full = ops.score_topk(ctx, Gu, Gi, Bi, 0, 700, k, algo="mfma")
+    assert torch.equal(torch.cat([a[0], b[0]]), full[0]) and torch.equal(torch.cat([a[1], b[1]]), full[1])
+    Gi2 = Gi * 1.5 + 0.1                                             # another table: the (false) claim must not be believed
+    c = ops.score_topk(ctx, Gu, Gi2, Bi, 0, 350, k, algo="screen", items_unchanged=True)
+    d = ops.score_topk(ctx, Gu, Gi2, Bi, 0, 350, k, algo="mfma")
+    assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
+    e = ops.score_topk(ctx, Gu, Gi2[:2000].contiguous(), Bi[:2000].contiguous(), 0, 350, k, algo="screen", items_unchanged=True)
+    f = ops.score_topk(ctx, Gu, Gi2[:2000].contiguous(), Bi[:2000].contiguous(), 0, 350, k, algo="mfma")
+    assert torch.equal(e[0], f[0]) and torch.equal(e[1], f[1])
