@@ -382,11 +382,28 @@ class NumpyUserShardBackend:
     def item_grads(self):
         return [self.gGi, self.gBi]
 
+    def _apply(self, which, lr):
+        for n, (th, g, m, v) in enumerate(zip((self.Bi, self.Gu, self.Gi), (self.gBi.numpy(), self.gGu, self.gGi.numpy()), self.m, self.v)):
+            if n in which:
+                ob.adam_tf_sparse_apply(th, m, v, g, lr, self.t)
+                g[:] = 0
+
     def apply(self, lr):
         self.t += 1
-        for th, g, m, v in zip((self.Bi, self.Gu, self.Gi), (self.gBi.numpy(), self.gGu, self.gGi.numpy()), self.m, self.v):
-            ob.adam_tf_sparse_apply(th, m, v, g, lr, self.t)
-            g[:] = 0
+        self._apply((0, 1, 2), lr)
+
+    # the split form ShardedBprmfByUser overlaps with the asynchronous all-reduce of the item gradients
+    def begin_step(self):
+        self.t += 1
+        self.order = []
+
+    def apply_users(self, lr):
+        self.order.append("users")
+        self._apply((1,), lr)
+
+    def apply_items(self, lr):
+        self.order.append("items")
+        self._apply((0, 2), lr)
 
     def local_loss_tensor(self):
         return self.loss
@@ -416,6 +433,7 @@ def _user_shard_worker(rank, world, port, out):
             tr.train_step(torch.from_numpy((u - ulo).astype(np.int32)), torch.from_numpy(i.astype(np.int32)),
                           torch.from_numpy(j.astype(np.int32)), 0.01, 0.1, 0.001)
             loss = tr.pop_loss()
+            assert be.order == ["users", "items"]            # own rows under the collective, the replica after it
             cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
             ref_loss = ref.train_step((cu, ci, cj))
             assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss), (loss, ref_loss)
