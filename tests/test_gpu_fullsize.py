@@ -143,3 +143,64 @@ def test_fullsize_metrics_checksum(ctx, world):
     torch.cuda.synchronize()
     assert np.allclose(whole, cpu(acc), rtol=1e-12, atol=0)
     assert whole[7] > 0.5 * UB and np.all(whole[:7] >= 0) and np.all(whole[:7] <= whole[7])
+
+
+def test_fullsize_cml_pair_counts_and_clean_state(ctx, world):
+    """CML at the full size (B = 2^20: 1.1e12 (distance, bias) pairs -- only the sorted evaluation can do that).  The two
+    coefficient vectors count the SAME set of active pairs from both sides, so their sums agree exactly; the sorted copies are
+    sorted; the gradient accumulators are handed back clean; an independent fp64 evaluation of the separable sum agrees."""
+    pos = world["pos"]
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    Gu = ((torch.rand((U, F), generator=g, device=dev) * 2 - 1) * 0.05).cpu().numpy()
+    Gi = ((torch.rand((I, F), generator=g, device=dev) * 2 - 1) * 0.05).cpu().numpy()
+    Bi = ((torch.rand(I, generator=g, device=dev) * 2 - 1) * 0.05).cpu().numpy()
+    st = ops.CmlDeviceState(ctx, Gu, Gi, Bi)
+    u, i, j = ops.bpr_sample(ctx, pos, B, seed=9, first_sample=0)
+    D = ((st.Gu[u.long()] - st.Gi[j.long()]) ** 2).sum(1).double() - ((st.Gu[u.long()] - st.Gi[i.long()]) ** 2).sum(1).double()
+    E = (st.Bi[i.long()] - st.Bi[j.long()]).double()
+    margin = 0.5
+    st.train_step(u, i, j, 0.001, 0.0, 0.0, margin)
+    loss = st.pop_loss()
+    al = lambda n: (n + 255) // 256 * 256
+    ws = st._cml_ws
+    arr = [ws[k * al(B * 4):k * al(B * 4) + B * 4].view(torch.float32) for k in range(6)]      # D, E, Ds, Es, cD, cE
+    assert bool((arr[2][1:] >= arr[2][:-1]).all()) and bool((arr[3][1:] >= arr[3][:-1]).all())
+    assert float(arr[4].double().sum()) == float(arr[5].double().sum()) < 0
+    assert float((arr[0].double() - D).abs().max()) < 1e-5 and float((arr[1].double() - E).abs().max()) < 1e-7
+    # the separable sum in fp64: sum_a [n_a (margin - D_a)] - sum_b [m_b E_b]   (no pair is near the -80 clip at this scale)
+    Es, Ds = torch.sort(E).values, torch.sort(D).values
+    n_a = torch.searchsorted(Es, margin - D, right=True)
+    m_b = torch.searchsorted(Ds, margin - E, right=True)
+    exp = float((n_a.double() * (margin - D)).sum() - (m_b.double() * E).sum())
+    assert abs(loss - exp) <= 1e-6 * exp, (loss, exp)
+    assert not bool(st.gGu.any()) and not bool(st.gGi.any()) and not bool(st.gBi.any())
+
+
+def test_fullsize_pointwise_step_properties(ctx, world):
+    """FunkSVD at the full size: the batch loss equals an independent fp64 evaluation on the same samples; accumulators are
+    clean on exit; at Adam step 1 no entry moves by more than lr and an untouched row not at all."""
+    pos = world["pos"]
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    Gu = ((torch.rand((U, F), generator=g, device=dev) * 2 - 1) * 0.05).cpu().numpy()
+    Gi = ((torch.rand((I, F), generator=g, device=dev) * 2 - 1) * 0.05).cpu().numpy()
+    st = ops.PwmfDeviceState(ctx, Gu, Gi, np.zeros(U, np.float32), np.zeros(I, np.float32), kind="mse", optimizer="adam")
+    u, i, y = ops.pointwise_sample(ctx, pos, B, seed=5, first_sample=0)
+    before = st.Gu.clone()
+    x = (st.Gu[u.long()].double() * st.Gi[i.long()].double()).sum(1)
+    exp = float(((y.double() - x) ** 2).mean())
+    lr = 0.001
+    st.train_step(u, i, y, lr)
+    loss = st.pop_loss()
+    assert abs(loss - exp) <= 1e-5 * exp, (loss, exp)
+    for name in ("gGu", "gGi", "gBu", "gBi"):
+        assert not bool(getattr(st, name).any()), name
+    moved = (st.Gu - before).abs()
+    touched = torch.zeros(U, dtype=torch.bool, device=dev)
+    touched[u.long()] = True
+    assert float(moved.max()) <= lr * 1.0001
+    assert not bool(moved[~touched].any())
+    assert float(moved[touched].max()) > 0            # (a batch-MEAN loss: |g| ~ 1e-7 sits below Adam's epsilon, moves are small)
