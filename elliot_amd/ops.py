@@ -817,7 +817,10 @@ class NmfDeviceState:
 PW_KINDS = {"mse": _lib.EL_PW_MSE, "mse_sigmoid": _lib.EL_PW_MSE_SIGMOID, "logistic": _lib.EL_PW_LOGISTIC}
 PW_OPTS = {"adam": _lib.EL_PW_ADAM, "adagrad": _lib.EL_PW_ADAGRAD}
 PW_SIDES = {"both": _lib.EL_PW_BOTH, "items": _lib.EL_PW_ITEMS, "users": _lib.EL_PW_USERS}
-_PW_MARGIN, _PW_MAX_LIST, _PW_DENSE_ROWS = 16, 4032, 4096
+# entries beyond k taken before the link: two keep k' = k + 2 <= 12 on the fastest screening policy for the usual k = 10; a row
+# whose ranks k .. k' all collapse to one linked float (probability ~1e-8 per row) is redone with a 4x longer list
+_PW_MARGIN, _PW_MAX_LIST, _PW_DENSE_ROWS = 2, 4032, 4096
+_CML_MARGIN = 16             # CML re-scores with another formula: its fp32 rounding may reorder near-ties a few ranks deep
 
 
 class PwmfDeviceState:
@@ -869,6 +872,7 @@ class PwmfDeviceState:
 
     def train_step(self, u, i, label, lr, side="both"):
         self.step += 1
+        self._margin = _PW_MARGIN
         n = u.numel()
         ws, need = self._workspace(n)
         lr_t = adam_lr_t(lr, self.step) if self.optimizer == "adam" else float(lr)
@@ -924,7 +928,7 @@ class PwmfDeviceState:
         plain = self.kind != "mse_sigmoid" and self.Bu is None
         if plain:
             return score_topk(self.ctx, self.Gu, self.Gi, None, u_start, u_stop, k, excl=excl, cand=cand)
-        kk = min(self.I, k + _PW_MARGIN)
+        kk = min(self.I, k + getattr(self, "_margin", _PW_MARGIN))
         while True:
             idx, val = score_topk(self.ctx, self.Gu, self.Gi, self.Bi, u_start, u_stop, kk, excl=excl, cand=cand)
             self._link(val, kk, u_start)
@@ -935,7 +939,9 @@ class PwmfDeviceState:
                 break
             if kk >= _PW_MAX_LIST:
                 return self._recommend_dense(u_start, u_stop, k, excl, cand)
-            kk = min(self.I, _PW_MAX_LIST, kk * 4)
+            kk = min(self.I, _PW_MAX_LIST, k + 16 if kk < k + 16 else kk * 4)
+        self._margin = kk - k          # small-score models (untrained: everything near link(0)) collapse often: the next blocks
+        #                                of this evaluation start with the list length that resolved this one (reset by train_step)
         order = torch.sort(idx, dim=1, stable=True).indices                       # index asc ...
         val = torch.gather(val, 1, order)
         by_val = torch.sort(val, dim=1, descending=True, stable=True)             # ... then value desc, stable
@@ -1001,7 +1007,7 @@ class CmlDeviceState(BprmfDeviceState):
         -sum (u - i)^2 + b_i and re-ranked by (value desc, index asc), so values and order are those of the direct
         evaluation (the two formulas differ by fp32 rounding only; a difference that straddles rank k + 16 is not seen)."""
         Gi2, Bi2 = self._item_side()
-        kk = min(self.I, k + _PW_MARGIN)
+        kk = min(self.I, k + _CML_MARGIN)
         idx, raw = score_topk(self.ctx, self.Gu, Gi2, Bi2, u_start, u_stop, kk, excl=excl, cand=cand)
         val = self.rescore(idx, u_start)
         val = torch.where(raw == float("-inf"), raw, val)           # -inf padding (masked items) stays padding
