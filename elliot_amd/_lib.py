@@ -148,6 +148,7 @@ PROTOTYPES = {
     "el_bprmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i64p, _i32p, C.c_uint64, C.c_uint64,
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,
                                       _f64p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "el_topk_rerank": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int64, C.c_int32]),
     "el_cml_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "el_cml_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float,
                                     C.c_float, C.c_float, C.c_int32, C.c_float, _f64p, C.c_void_p, C.c_size_t]),

@@ -13,6 +13,7 @@
 // measured for the BPR step (el_bpr_sorted.hip); the BPR kernels fuse the forward into the user segments, which a
 // point-wise sample cannot do (its c_b is needed by two different segment owners).
 #include "el_common.h"
+#include "el_topk_common.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -300,6 +301,25 @@ __global__ __launch_bounds__(256) void k_pw_link(float* __restrict__ vals, int64
     vals[r * ld + c] = v;
 }
 
+// rows of (idx, vals) re-ordered in place by (value desc, index asc) -- the order tf.nn.top_k gives -- over their first kk <= 64
+// entries: one wave per row, the pair packed into the order-preserving key of the top-k kernels, bitonic sort in LDS
+__global__ __launch_bounds__(256) void k_rerank_rows(int32_t* __restrict__ idx, float* __restrict__ vals, int64_t n_rows, int64_t ld,
+                                                     int kk) {
+    __shared__ u64 keys[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= n_rows) return;
+    u64* kb = keys[wv];
+    kb[lane] = lane < kk ? el_make_key(vals[r * ld + lane], idx[r * ld + lane]) : 0ull;
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(kb, 64, lane);
+    if (lane < kk) {
+        const u64 k = kb[lane];
+        idx[r * ld + lane] = el_key_item(k);
+        vals[r * ld + lane] = el_key_score(k);
+    }
+}
+
 int bits_for(int64_t n) {
     int b = 1;
     while ((1LL << b) < n && b < 32) ++b;
@@ -507,6 +527,16 @@ extern "C" int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64
     if (Bu == nullptr && kind != EL_PW_MSE_SIGMOID) return 0;
     EL_LAUNCH("k_pw_link", k_pw_link, dim3((unsigned)((n_rows * k + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vals,
               n_rows, ld, (int)k, kind, Bu, u_start);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_topk_rerank(el_ctx* ctx, void* stream, int32_t* idx, float* vals, int64_t n_rows, int64_t ld, int32_t kk) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (n_rows <= 0 || kk <= 1) return 0;
+    EL_REQUIRE(idx && vals && ld >= kk && kk <= 64, "el_topk_rerank: needs kk <= 64 <= ... and ld >= kk (kk=%d, ld=%lld)", kk, (long long)ld);
+    EL_LAUNCH("k_rerank_rows", k_rerank_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, vals, n_rows, ld,
+              (int)kk);
     EL_CHECK_LAUNCH();
     return 0;
 }

@@ -823,6 +823,20 @@ _PW_MARGIN, _PW_MAX_LIST, _PW_DENSE_ROWS = 2, 4032, 4096
 _CML_MARGIN = 16             # CML re-scores with another formula: its fp32 rounding may reorder near-ties a few ranks deep
 
 
+def topk_rerank(ctx, idx, val):
+    """Rows of (idx, val) re-ordered in place by (value desc, index asc) -- tf.nn.top_k's order -- after the values were
+    transformed (link, CML re-score).  Lists of up to 64 entries go through el_topk_rerank, longer ones through two stable
+    torch sorts.  Returns (idx, val)."""
+    kk = idx.shape[1]
+    if kk <= 64:
+        check(ctx.lib.el_topk_rerank(ctx.handle, ctx.stream(), _ptr(idx, torch.int32), _ptr(val, torch.float32), int(idx.shape[0]),
+                                     int(idx.stride(0)), int(kk)), "el_topk_rerank")
+        return idx, val
+    order = torch.sort(idx, dim=1, stable=True).indices                           # index asc ...
+    by_val = torch.sort(torch.gather(val, 1, order), dim=1, descending=True, stable=True)   # ... then value desc, stable
+    return torch.gather(torch.gather(idx, 1, order), 1, by_val.indices), by_val.values
+
+
 class PwmfDeviceState:
     """Variables + optimiser slots of one point-wise factor model in HBM (include/elliot_hip.h, el_pwmf_state).
 
@@ -942,11 +956,8 @@ class PwmfDeviceState:
             kk = min(self.I, _PW_MAX_LIST, k + 16 if kk < k + 16 else kk * 4)
         self._margin = kk - k          # small-score models (untrained: everything near link(0)) collapse often: the next blocks
         #                                of this evaluation start with the list length that resolved this one (reset by train_step)
-        order = torch.sort(idx, dim=1, stable=True).indices                       # index asc ...
-        val = torch.gather(val, 1, order)
-        by_val = torch.sort(val, dim=1, descending=True, stable=True)             # ... then value desc, stable
-        idx = torch.gather(torch.gather(idx, 1, order), 1, by_val.indices)
-        return idx[:, :k].contiguous(), by_val.values[:, :k].contiguous()
+        idx, val = topk_rerank(self.ctx, idx, val)
+        return idx[:, :k].contiguous(), val[:, :k].contiguous()
 
     def _recommend_dense(self, u_start, u_stop, k, excl, cand):
         out_i, out_v = [], []
@@ -1011,8 +1022,5 @@ class CmlDeviceState(BprmfDeviceState):
         idx, raw = score_topk(self.ctx, self.Gu, Gi2, Bi2, u_start, u_stop, kk, excl=excl, cand=cand)
         val = self.rescore(idx, u_start)
         val = torch.where(raw == float("-inf"), raw, val)           # -inf padding (masked items) stays padding
-        order = torch.sort(idx, dim=1, stable=True).indices
-        val_o = torch.gather(val, 1, order)
-        by_val = torch.sort(val_o, dim=1, descending=True, stable=True)
-        idx_o = torch.gather(torch.gather(idx, 1, order), 1, by_val.indices)
-        return idx_o[:, :k].contiguous(), by_val.values[:, :k].contiguous()
+        idx, val = topk_rerank(self.ctx, idx, val)
+        return idx[:, :k].contiguous(), val[:, :k].contiguous()
