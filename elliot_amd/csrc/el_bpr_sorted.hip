@@ -477,7 +477,7 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     return 0;
 }
 
-extern "C" int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
                                           const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w,
                                           float l_b, int opt, int32_t step, float lr_t, double* loss_out, void* ws,
                                           size_t ws_bytes) {
