@@ -65,3 +65,29 @@ def test_product_code_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(root, f))
     assert not bad, f"product files import the oracle: {bad}"
+
+
+def test_library_exports_nothing_but_the_declared_entry_points():
+    """The boundary is exactly include/*.h: no el_* symbol is exported that the header does not declare."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(nm):
+        pytest.skip("no nm on this box")
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if " T el_" in line})
+    assert exported == declared_functions(), (set(exported) ^ set(declared_functions()))
+
+
+def test_header_is_plain_c():
+    """`extern "C"`, plain pointers and sizes: the header has to compile as C99 on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    inc = os.path.join(REPO, "include")
+    for f in sorted(os.listdir(inc)):
+        if f.endswith(".h"):
+            subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, f)],
+                           check=True)
