@@ -133,3 +133,22 @@ def test_sorted_gradient_path_matches_oracle(ctx):
             err = np.abs(cpu(getattr(st, name)) - ref)
             assert (err > 5e-5).mean() < 5e-3 and err.max() < 5 * lr, (s, name, float(err.max()), float((err > 5e-5).mean()))
         assert not cpu(st.gGu).any() and not cpu(st.gGi).any() and not cpu(st.gBi).any()
+
+
+def test_tiny_shapes_fuzz(ctx):
+    rs = np.random.RandomState(98)
+    for trial in range(25):
+        U, I, F, n = rs.randint(1, 5), rs.randint(2, 6), rs.randint(1, 7), rs.randint(1, 9)
+        Gu, Gi, Bi = tables(rs, U, I, F, 0.5)
+        st = ops.CmlDeviceState(ctx, Gu, Gi, Bi)
+        orc = oc.CMLOracle(Gu, Gi, Bi, 0.01, 0.01, 0.02, 0.5)
+        u, i, j = rs.randint(0, U, n), rs.randint(0, I, n), rs.randint(0, I, n)
+        st.train_step(dev(ctx, u), dev(ctx, i), dev(ctx, j), 0.01, 0.01, 0.02, 0.5)
+        got, exp = st.pop_loss(), orc.train_step((u, i, j))
+        assert abs(got - exp) <= 1e-4 * max(abs(exp), 1e-3), (trial, U, I, F, n, got, exp)
+        for name, ref in (("Gu", orc.Gu), ("Gi", orc.Gi), ("Bi", orc.Bi)):
+            assert np.abs(cpu(getattr(st, name)) - ref).max() < 0.05 + 1e-6, (trial, name)     # <= 5 lr: a hinge sitting on the boundary
+        k = min(I, 3)
+        idx, val = (cpu(t) for t in st.recommend(0, U, k))
+        best = -np.sort(-oc.CMLOracle(cpu(st.Gu), cpu(st.Gi), cpu(st.Bi), 0, 0, 0, 0).predict(0, U).astype(np.float64), axis=1)[:, :k]
+        assert np.abs(val - best).max() < 1e-5, (trial, U, I, F)

@@ -204,3 +204,26 @@ def test_rejects_bad_arguments(ctx):
                                              4, 0, 0, 1, 0.01, st.loss.data_ptr(), None, 0), "el_pwmf_train_step")
     with pytest.raises(ValueError):
         ops.PwmfDeviceState(ctx, w["Gu"], w["Gi"], Bu=np.zeros(10, np.float32))
+
+
+def test_tiny_shapes_fuzz(ctx):
+    """Degenerate sizes (one user, two items, one factor, one sample, F not a multiple of 4): every kernel path still agrees with
+    the oracle."""
+    rs = np.random.RandomState(99)
+    for trial in range(40):
+        U, I, F, n = rs.randint(1, 5), rs.randint(2, 6), rs.randint(1, 7), rs.randint(1, 9)
+        model = list(MODELS)[trial % 4]
+        w = weights(rs, U, I, F, MODELS[model][1])
+        st, orc = make(ctx, w, model, lr=0.01)
+        for s in range(2):
+            u, i = rs.randint(0, U, n), rs.randint(0, I, n)
+            y = rs.randint(0, 2, n).astype(np.float32)
+            side = ("items", "users")[s] if model == "LogisticMF" else "both"
+            got, exp = step_both(ctx, st, orc, u, i, y, 0.01, side=side)
+            assert abs(got - exp) <= 1e-4 * max(abs(exp), 1e-3), (trial, model, U, I, F, n, got, exp)
+        assert_state(st, orc, 0.01, (trial, model, U, I, F, n))
+        k = min(I, 3)
+        idx, val = (cpu(t) for t in st.recommend(0, U, k))
+        scores = orc.predict_all(0, U).astype(np.float64)
+        best = -np.sort(-scores, axis=1)[:, :k]
+        assert np.abs(val - best).max() < 1e-5, (trial, model, U, I, F)
