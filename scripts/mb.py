@@ -48,13 +48,15 @@ def main():
         return
     if a.what == "vae":
         import numpy as np
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from oracle import multi_vae as ov
         U, I, H, L, B = 138493, 26744, 600, 200, 512
         ip, ix = zipf_csr_device(U, I, dev, mean_log=4.5, sigma_log=1.0, dmin=20, dmax=3000, seed=5)
         csr = ops.DeviceCSR.from_tensors(ip, ix, I)
         print("interactions", csr.nnz)
-        st = ops.VaeDeviceState(ctx, ov.init_weights(I, H, L, 1), max_batch=B)
+        rs = np.random.RandomState(1)
+        gl = lambda a, b: (rs.standard_normal((a, b)) * np.sqrt(2.0 / (a + b))).astype(np.float32)
+        z = lambda n: np.zeros(n, np.float32)
+        st = ops.VaeDeviceState(ctx, {"W1": gl(I, H), "b1": z(H), "Wm": gl(H, L), "bm": z(L), "Wv": gl(H, L), "bv": z(L),
+                                      "W3": gl(L, H), "b3": z(H), "W4": gl(H, I), "b4": z(I)}, max_batch=B)
         rows_all = torch.randperm(U, device=dev, generator=g).to(torch.int32)
         ctx.timing(True)
         steps = a.iters
@@ -82,9 +84,21 @@ def main():
     ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, seed=5)
     pos = ops.DeviceCSR.from_tensors(ip, ix, I)
     if a.what == "nmf":
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from oracle import neumf as on
-        w = on.init_neumf(U, I, F, 3) if a.model != "GMF" else on.init_gmf(U, I, F, 3)
+        import numpy as np
+        rs = np.random.RandomState(3)
+        gu = lambda a, b: rs.uniform(-np.sqrt(6.0 / (a + b)), np.sqrt(6.0 / (a + b)), size=(a, b)).astype(np.float32)
+        w = {"Umf": gu(U, F), "Imf": gu(I, F)}
+        if a.model != "GMF":
+            units = [4 * F, 2 * F, F]
+            w.update({"Umlp": gu(U, F), "Imlp": gu(I, F), "W": [], "b": []})
+            kin = 2 * F
+            for n_out in units:
+                w["W"].append(gu(kin, n_out))
+                w["b"].append(np.zeros(n_out, np.float32))
+                kin = n_out
+            w["hw"], w["hb"] = gu(F + units[-1], 1)[:, 0].copy(), np.zeros(1, np.float32)
+        else:
+            w["hw"] = gu(F, 1)[:, 0].copy()
         st = ops.NmfDeviceState(ctx, w, max_batch=a.batch)
         ctx.timing(True)
         for it in range(a.iters + 2):
