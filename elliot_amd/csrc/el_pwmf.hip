@@ -457,23 +457,17 @@ extern "C" int el_pwmf_forward(el_ctx* ctx, void* stream, const el_pwmf_state* s
     return rows_vec4(*st) ? launch_fwd<4, false>(p, (hipStream_t)stream) : launch_fwd<1, false>(p, (hipStream_t)stream);
 }
 
-extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state* stp, const int32_t* u, const int32_t* i,
-                                  const float* label, int64_t n, int opt, int side, int32_t step, float lr_t,
-                                  double* loss_out, void* ws, size_t ws_bytes) {
-    if (int rc = el_bind(ctx)) return rc;
-    EL_REQUIRE(opt == EL_PW_ADAM || opt == EL_PW_ADAGRAD, "el_pwmf_train_step: unknown optimiser %d", opt);
-    EL_REQUIRE(side >= EL_PW_BOTH && side <= EL_PW_USERS, "el_pwmf_train_step: unknown side %d", side);
-    if (int rc = check_state(stp, "el_pwmf_train_step", true, opt)) return rc;
-    if (n <= 0) return 0;
-    EL_REQUIRE(u && i && label && loss_out, "el_pwmf_train_step: null argument");
-    EL_REQUIRE(step >= 1, "el_pwmf_train_step: step must be >= 1");
-    EL_REQUIRE(n < (1LL << 31), "el_pwmf_train_step: batch too large");
-    EL_REQUIRE(stp->U + stp->I < (1LL << 32), "el_pwmf_train_step: U + I must fit a 32-bit sort key");
+// forward + loss + c_b + sorted-segment gradient sums into the accumulators of `side` (mean losses divide by n_div)
+static int pw_grads(el_ctx* ctx, hipStream_t s, const el_pwmf_state* stp, const int32_t* u, const int32_t* i, const float* label,
+                    int64_t n, int64_t n_div, int side, double* loss_out, void* ws, size_t ws_bytes, const char* who) {
+    EL_REQUIRE(side >= EL_PW_BOTH && side <= EL_PW_USERS, "%s: unknown side %d", who, side);
+    EL_REQUIRE(u && i && label && loss_out, "%s: null argument", who);
+    EL_REQUIRE(n < (1LL << 31) && n_div >= n, "%s: bad batch sizes", who);
+    EL_REQUIRE(stp->U + stp->I < (1LL << 32), "%s: U + I must fit a 32-bit sort key", who);
     const el_pwmf_state st = *stp;
     PwWs w;
-    EL_REQUIRE(carve(n, st.U, st.I, (char*)ws, &w) == 0, "el_pwmf_train_step: rocprim size query failed");
-    EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_pwmf_train_step: workspace too small (%zu < %zu)", ws_bytes, w.total);
-    hipStream_t s = (hipStream_t)stream;
+    EL_REQUIRE(carve(n, st.U, st.I, (char*)ws, &w) == 0, "%s: rocprim size query failed", who);
+    EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total);
     const bool vec = rows_vec4(st);
 
     PwFwd f;
@@ -481,7 +475,7 @@ extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state
     f.st = st, f.bu = u, f.bi = i, f.label = label, f.coef = w.coef, f.n = n;
     f.keyU = w.keyU_in, f.valU = w.valU_in, f.keyI = w.keyI_in, f.valI = w.valI_in;
     f.item_key_off = (u32)st.U;
-    f.inv_n = 1.0f / (float)n;
+    f.inv_n = 1.0f / (float)n_div;
     f.loss_out = loss_out;
     if (int rc = vec ? launch_fwd<4, true>(f, s) : launch_fwd<1, true>(f, s)) return rc;
 
@@ -505,17 +499,52 @@ extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state
         PwSeg p = {w.keyI, (u32)st.U, w.valI, w.coef, u, st.Gu, st.Gi, st.gGi, st.gBi, n, st.F, item_chunk(n), 0, l_w};
         if (int rc = vec ? launch_seg<4>(p, "k_pw_seg_items", s) : launch_seg<1>(p, "k_pw_seg_items", s)) return rc;
     }
-    if (do_users) {
+    (void)ctx;
+    return 0;
+}
+
+static int pw_apply(el_ctx* ctx, hipStream_t s, const el_pwmf_state& st, int opt, int side, float lr_t) {
+    const bool do_users = side != EL_PW_ITEMS, do_items = side != EL_PW_USERS;
+    if (do_users && st.U > 0) {
         if (int rc = apply(ctx, s, opt, "k_pw_opt_Gu", st.Gu, st.gGu, st.mGu, st.vGu, st.U * st.F, lr_t)) return rc;
         if (st.Bu)
             if (int rc = apply(ctx, s, opt, "k_pw_opt_Bu", st.Bu, st.gBu, st.mBu, st.vBu, st.U, lr_t)) return rc;
     }
-    if (do_items) {
+    if (do_items && st.I > 0) {
         if (int rc = apply(ctx, s, opt, "k_pw_opt_Gi", st.Gi, st.gGi, st.mGi, st.vGi, st.I * st.F, lr_t)) return rc;
         if (st.Bi)
             if (int rc = apply(ctx, s, opt, "k_pw_opt_Bi", st.Bi, st.gBi, st.mBi, st.vBi, st.I, lr_t)) return rc;
     }
     return 0;
+}
+
+extern "C" int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state* stp, const int32_t* u, const int32_t* i,
+                                  const float* label, int64_t n, int opt, int side, int32_t step, float lr_t,
+                                  double* loss_out, void* ws, size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(opt == EL_PW_ADAM || opt == EL_PW_ADAGRAD, "el_pwmf_train_step: unknown optimiser %d", opt);
+    if (int rc = check_state(stp, "el_pwmf_train_step", true, opt)) return rc;
+    if (n <= 0) return 0;
+    EL_REQUIRE(step >= 1, "el_pwmf_train_step: step must be >= 1");
+    if (int rc = pw_grads(ctx, (hipStream_t)stream, stp, u, i, label, n, n, side, loss_out, ws, ws_bytes, "el_pwmf_train_step")) return rc;
+    return pw_apply(ctx, (hipStream_t)stream, *stp, opt, side, lr_t);
+}
+
+extern "C" int el_pwmf_grads(el_ctx* ctx, void* stream, const el_pwmf_state* stp, const int32_t* u, const int32_t* i,
+                             const float* label, int64_t n, int64_t n_global, int side, double* loss_out, void* ws,
+                             size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = check_state(stp, "el_pwmf_grads", true, EL_PW_ADAGRAD)) return rc;       // (slot layout is checked by el_pwmf_apply)
+    if (n <= 0) return 0;
+    return pw_grads(ctx, (hipStream_t)stream, stp, u, i, label, n, n_global, side, loss_out, ws, ws_bytes, "el_pwmf_grads");
+}
+
+extern "C" int el_pwmf_apply(el_ctx* ctx, void* stream, const el_pwmf_state* stp, int opt, int side, int32_t step, float lr_t) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(opt == EL_PW_ADAM || opt == EL_PW_ADAGRAD, "el_pwmf_apply: unknown optimiser %d", opt);
+    EL_REQUIRE(side >= EL_PW_BOTH && side <= EL_PW_USERS && step >= 1, "el_pwmf_apply: bad side / step");
+    if (int rc = check_state(stp, "el_pwmf_apply", true, opt)) return rc;
+    return pw_apply(ctx, (hipStream_t)stream, *stp, opt, side, lr_t);
 }
 
 extern "C" int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64_t n_rows, int64_t ld, int32_t k, int kind,

@@ -895,6 +895,27 @@ class PwmfDeviceState:
                                               PW_OPTS[self.optimizer], PW_SIDES[side], int(self.step), float(lr_t),
                                               _ptr(self.loss, torch.float64), ws, need), "el_pwmf_train_step")
 
+    def grads(self, u, i, label, n_global=None, side="both"):
+        """Forward + loss + gradient sums only (multi-GPU: a batch-mean loss runs over n_global samples); the accumulators of
+        `side` are complete on return -- item_grads() lists the replicated ones a data-parallel caller all-reduces."""
+        n = u.numel()
+        ws, need = self._workspace(n)
+        check(self.ctx.lib.el_pwmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                         _ptr(i, torch.int32), _ptr(label, torch.float32), int(n),
+                                         int(n if n_global is None else n_global), PW_SIDES[side], _ptr(self.loss, torch.float64),
+                                         ws, need), "el_pwmf_grads")
+
+    def apply(self, lr, side="both", advance=True):
+        if advance:
+            self.step += 1
+            self._margin = _PW_MARGIN
+        lr_t = adam_lr_t(lr, self.step) if self.optimizer == "adam" else float(lr)
+        check(self.ctx.lib.el_pwmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), PW_OPTS[self.optimizer],
+                                         PW_SIDES[side], int(self.step), float(lr_t)), "el_pwmf_apply")
+
+    def item_grads(self):
+        return [t for t in (self.gGi, self.gBi) if t is not None]
+
     def forward(self, u, i, out=None):
         n = u.numel()
         if out is None:

@@ -455,3 +455,41 @@ class ShardedNmf:
         tot = self.coll.all_reduce_sum(t.clone())
         t.zero_()
         return float(tot.item())
+
+
+# ------------------------------------------------------------------------------------------------------
+# point-wise factor models (MF, PMF, FunkSVD, LogisticMF): user rows sharded, item side replicated
+# ------------------------------------------------------------------------------------------------------
+class ShardedPwmf:
+    """One step of a point-wise factor model over G ranks, the same scheme as ShardedBprmfByUser: rank r owns the user rows
+    [ulo_r, uhi_r) of Gu (and Bu) with their optimiser slots and draws its (u, i, label) samples for ITS users (any item: the
+    reference's sampling distribution over the ranks, pointwise_pos_neg_sampler.py:32-46); Gi / Bi are replicated.
+    Per step: el_pwmf_grads with the batch MEAN over the GLOBAL batch -> ONE asynchronous all-reduce (sum) per item-side
+    accumulator, under which the rank's own user rows take their optimiser step -> the same item-side step on every rank.
+    G ranks x n samples are one reference-semantics step on the concatenated batch.  LogisticMF's alternating sides: a
+    `side="users"` step needs no collective at all.  `backend` = ops.PwmfDeviceState on (local user rows, full item tables;
+    user ids passed in are shard-local) or a stand-in with grads / apply / item_grads / loss."""
+
+    def __init__(self, backend, coll=None):
+        self.backend = backend
+        self.coll = coll or _Collectives()
+
+    def train_step(self, u_local, i, label, lr, n_global=None, side="both"):
+        be, coll = self.backend, self.coll
+        if n_global is None:
+            n_global = coll.world * int(u_local.shape[0])
+        be.grads(u_local, i, label, n_global=n_global, side=side)
+        works = [coll.all_reduce_sum(g, async_op=True) for g in be.item_grads()] if side != "users" else []
+        if side != "items":
+            be.apply(lr, side="users", advance=True)             # own rows: runs under the all-reduce
+        for w in works:
+            if w is not None:
+                w.wait()
+        if side != "users":
+            be.apply(lr, side="items", advance=(side == "items"))
+
+    def pop_loss(self):
+        t = self.backend.loss
+        tot = self.coll.all_reduce_sum(t.clone())
+        t.zero_()
+        return float(tot.item())

@@ -455,6 +455,15 @@ int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state* st, const
                        const float* label, int64_t n, int opt, int side, int32_t step, float lr_t,
                        double* loss_out, void* ws, size_t ws_bytes);
 
+/* Multi-GPU form of the step (data parallel over samples, user rows sharded, item table replicated):
+ * el_pwmf_grads = forward + loss + gradient sums with the batch MEAN taken over n_global samples (the sum of all ranks' n;
+ * EL_PW_LOGISTIC sums, n_global is ignored), the accumulators of `side` complete on exit; the caller all-reduces gGi / gBi
+ * over RCCL; el_pwmf_apply = the optimiser on the variables of `side`.  grads + apply with n_global = n is
+ * el_pwmf_train_step.                                                                                                */
+int el_pwmf_grads(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int32_t* u, const int32_t* i,
+                  const float* label, int64_t n, int64_t n_global, int side, double* loss_out, void* ws, size_t ws_bytes);
+int el_pwmf_apply(el_ctx* ctx, void* stream, const el_pwmf_state* st, int opt, int side, int32_t step, float lr_t);
+
 /* Turn the top-k values of el_score_topk (Bi[i] + <Gu[u],Gi[i]>) into the model's scores, in place:
  * vals[r, c] <- link(vals[r, c] + Bu[u_start + r]) (Bu may be NULL; -inf padding stays -inf).  The link is monotone,
  * so the ranking can only change where distinct inputs collapse to one float -- the host re-ranks those (ops.py). */

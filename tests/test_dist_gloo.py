@@ -456,3 +456,97 @@ def test_user_sharded_training_world2_gloo():
     mp.spawn(_user_shard_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
     assert [parallel.user_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+
+
+# ------------------------------------------------------------------------------------------ point-wise models, user shards
+class NumpyPwmfBackend:
+    """Stand-in for ops.PwmfDeviceState on (local user rows, full item tables): oracle/pointwise_mf.py arithmetic."""
+
+    def __init__(self, weights, kind, lr, optimizer, alpha=0.0, l_w=0.0):
+        from oracle import pointwise_mf as pw
+        self.pw = pw
+        self.o = pw.PointwiseOracle(weights, kind, lr, optimizer=optimizer, alpha=alpha, l_w=l_w)
+        self.g = {}
+        self.gt = {k: torch.zeros(v.shape, dtype=torch.float32) for k, v in self.o.w.items() if k in ("Gi", "Bi")}
+        self.loss = torch.zeros(1, dtype=torch.float64)
+        self.log = []
+
+    def grads(self, u, i, y, n_global=None, side="both"):
+        u, i, y = u.numpy().astype(np.int64), i.numpy().astype(np.int64), y.numpy()
+        n = len(y)
+        loss, g = self.pw.loss_and_grads(self.o.w, self.o.kind, u, i, y, self.o.alpha, self.o.l_w)
+        scale = 1.0 if self.o.kind == "logistic" else n / float(n_global)       # batch MEAN over the global batch
+        self.loss += loss * scale
+        self.g = {k: (v * np.float32(scale)).astype(np.float32) for k, v in g.items()}
+        for k in self.gt:
+            self.gt[k].copy_(torch.from_numpy(self.g[k]))
+
+    def item_grads(self):
+        return [self.gt[k] for k in ("Gi", "Bi") if k in self.gt]
+
+    def apply(self, lr, side="both", advance=True):
+        o = self.o
+        if advance:
+            o.t += 1
+        self.log.append(side)
+        for k in {"users": ("Gu", "Bu"), "items": ("Gi", "Bi")}[side]:
+            if k not in o.w:
+                continue
+            g = self.gt[k].numpy() if k in self.gt else self.g[k]
+            if o.optimizer == "adam":
+                ob.adam_tf_sparse_apply(o.w[k], o.m[k], o.v[k], g.astype(np.float32), o.lr, o.t)
+            else:
+                self.pw.adagrad_apply(o.w[k], o.m[k], g.astype(np.float32), o.lr)
+
+
+def _pwmf_worker(rank, world, port, out, model):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pointwise_mf as pw
+        kind, bias, opt = {"FunkSVD": ("mse", True, "adam"), "PMF": ("mse_sigmoid", False, "adam"),
+                           "LogisticMF": ("logistic", True, "adagrad")}[model]
+        rs = np.random.RandomState(3)
+        U, I, F, n, lr = 41, 30, 6, 64, 0.01
+        w = {"Gu": rs.normal(scale=0.3, size=(U, F)).astype(np.float32), "Gi": rs.normal(scale=0.3, size=(I, F)).astype(np.float32)}
+        if bias:
+            w["Bu"], w["Bi"] = rs.normal(scale=0.1, size=U).astype(np.float32), rs.normal(scale=0.1, size=I).astype(np.float32)
+        ulo, uhi = parallel.user_range(U, rank, world)
+        local = {k: (v[ulo:uhi] if k in ("Gu", "Bu") else v) for k, v in w.items()}
+        be = NumpyPwmfBackend(local, kind, lr, opt, alpha=0.5, l_w=0.02)
+        tr = parallel.ShardedPwmf(be, parallel._Collectives())
+        ref = pw.PointwiseOracle(w, kind, lr, optimizer=opt, alpha=0.5, l_w=0.02)
+        sides = ("items", "users") if kind == "logistic" else ("both",)
+        for step in range(4):
+            batches = []
+            for r in range(world):
+                brs = np.random.RandomState(900 + 10 * step + r)
+                l, h = parallel.user_range(U, r, world)
+                batches.append((brs.randint(l, h, n), brs.randint(0, I, n), brs.randint(0, 2, n).astype(np.float32)))
+            u, i, y = batches[rank]
+            side = sides[step % len(sides)]
+            tr.train_step(torch.from_numpy((u - ulo).astype(np.int32)), torch.from_numpy(i.astype(np.int32)), torch.from_numpy(y), lr,
+                          side=side)
+            loss = tr.pop_loss()
+            cu, ci, cy = (np.concatenate([b[x] for b in batches]) for x in range(3))
+            ref_loss = ref.train_step((cu, ci, cy), side=side)
+            assert abs(loss - ref_loss) <= 1e-5 * max(abs(ref_loss), 1e-6), (step, loss, ref_loss)
+            assert np.abs(be.o.w["Gu"] - ref.w["Gu"][ulo:uhi]).max() < 2e-6
+            assert np.abs(be.o.w["Gi"] - ref.w["Gi"]).max() < 2e-6
+            if bias:
+                assert np.abs(be.o.w["Bu"] - ref.w["Bu"][ulo:uhi]).max() < 2e-6 and np.abs(be.o.w["Bi"] - ref.w["Bi"]).max() < 2e-6
+        assert be.log == (["items", "users"] * 2 if kind == "logistic" else ["users", "items"] * 4)     # own rows first, under the collective
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["FunkSVD", "PMF", "LogisticMF"])
+def test_pointwise_models_user_sharded_world2_gloo(model):
+    """SURVEY 8e for the N3 siblings: G ranks x n samples = one reference-semantics step on the concatenated batch."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pwmf_worker, args=(2, port, out, model), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}

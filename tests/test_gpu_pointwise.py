@@ -227,3 +227,58 @@ def test_tiny_shapes_fuzz(ctx):
         scores = orc.predict_all(0, U).astype(np.float64)
         best = -np.sort(-scores, axis=1)[:, :k]
         assert np.abs(val - best).max() < 1e-5, (trial, model, U, I, F)
+
+
+class _PairSum:
+    """Two virtual ranks on one GPU: `all_reduce_sum` adds the partner's tensor (the k-th call of rank 0 pairs with the k-th of rank 1)."""
+
+    def __init__(self):
+        self.world, self.always, self.pending = 2, False, []
+
+    def all_reduce_sum(self, t, async_op=False):
+        self.pending.append(t)
+        return None if async_op else t
+
+
+@pytest.mark.parametrize("model", ["FunkSVD", "PMF", "LogisticMF"])
+def test_user_sharded_hip_path_equals_concatenated_batch(ctx, model):
+    """parallel.ShardedPwmf with two virtual ranks: local user rows + item replicas on el_pwmf_grads / el_pwmf_apply, the
+    all-reduce emulated by adding the two ranks' accumulators between grads and the item-side apply."""
+    from elliot_amd import parallel
+    rs = np.random.RandomState(21)
+    U, I, F, n, lr, G = 501, 260, 32, 3000, 0.01, 2
+    w = weights(rs, U, I, F, MODELS[model][1])
+    kind, _, opt = MODELS[model]
+    rng = [parallel.user_range(U, r, G) for r in range(G)]
+    sts = [ops.PwmfDeviceState(ctx, w["Gu"][lo:hi], w["Gi"], None if "Bu" not in w else w["Bu"][lo:hi], w.get("Bi"), kind=kind,
+                               optimizer=opt, alpha=0.5, l_w=0.02) for lo, hi in rng]
+    orc = pw.PointwiseOracle(w, kind, lr, optimizer=opt, alpha=0.5, l_w=0.02)
+    sides = ("items", "users") if kind == "logistic" else ("both",)
+    for step in range(4):
+        side = sides[step % len(sides)]
+        batches = [(rs.randint(lo, hi, n), np.minimum(rs.zipf(1.4, n) - 1, I - 1), rs.randint(0, 2, n).astype(np.float32)) for lo, hi in rng]
+        for st, (lo, hi), (u, i, y) in zip(sts, rng, batches):
+            st.grads(dev(ctx, u - lo, np.int32), dev(ctx, i, np.int32), dev(ctx, y, np.float32), n_global=G * n, side=side)
+        if side != "users":
+            for a, b in zip(sts[0].item_grads(), sts[1].item_grads()):            # the all-reduce
+                tot = a + b
+                a.copy_(tot)
+                b.copy_(tot)
+        loss = 0.0
+        for st in sts:
+            if side != "items":
+                st.apply(lr, side="users", advance=True)
+            if side != "users":
+                st.apply(lr, side="items", advance=(side == "items"))
+            loss += st.pop_loss()
+        cu, ci, cy = (np.concatenate([b[x] for b in batches]) for x in range(3))
+        exp = orc.train_step((cu, ci, cy), side=side)
+        assert abs(loss - exp) <= 1e-4 * max(abs(exp), 1e-3), (model, step, loss, exp)
+        assert torch.equal(sts[0].Gi, sts[1].Gi) and (sts[0].Bi is None or torch.equal(sts[0].Bi, sts[1].Bi))   # replicas stay identical
+        assert (np.abs(cpu(sts[0].Gi) - orc.w["Gi"]) > 2e-5).mean() < 2e-3
+        for st, (lo, hi) in zip(sts, rng):
+            assert (np.abs(cpu(st.Gu) - orc.w["Gu"][lo:hi]) > 2e-5).mean() < 2e-3
+            for g in ("gGu", "gGi", "gBu", "gBi"):
+                t = getattr(st, g)
+                assert t is None or not bool(t.any()), (model, step, g)
+        assert sts[0].step == sts[1].step == step + 1
