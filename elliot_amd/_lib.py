@@ -149,7 +149,11 @@ PROTOTYPES = {
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,
                                       _f64p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "el_topk_rerank": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int64, C.c_int32]),
-    "el_cml_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "el_cml_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "el_cml_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float,
+                                 _f32p, _f32p, _f64p]),
+    "el_cml_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float,
+                               C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_int64, _f64p, C.c_void_p, C.c_size_t]),
     "el_cml_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float,
                                     C.c_float, C.c_float, C.c_int32, C.c_float, _f64p, C.c_void_p, C.c_size_t]),
     "el_cml_prepare_items": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p]),

@@ -50,8 +50,9 @@ struct CmlArgs {
     int lpt;
     float* D;       // [B]
     float* E;       // [B]
-    float* Ds;      // sorted copies
+    float* Ds;      // sorted copies of the GLOBAL batch's D / E (n_all values; = the local batch on one GPU)
     float* Es;
+    int64_t n_all;
     float* cD;      // [B] dloss/dD
     float* cE;      // [B] dloss/dE
     double* loss_out;
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256) void k_cml_coef(CmlArgs p) {
     double l = 0.0;
     for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < p.B; a += stride) {
         const float Da = p.D[a], Ea = p.E[a];
-        const int64_t lowE = cml_bound(p.Es, p.B, -80.0f - Da, false);
-        const int64_t nA = cml_bound(p.Es, p.B, p.margin - Da, true) - lowE;
-        const int64_t lowD = cml_bound(p.Ds, p.B, -80.0f - Ea, false);
-        const int64_t mA = cml_bound(p.Ds, p.B, p.margin - Ea, true) - lowD;
+        const int64_t lowE = cml_bound(p.Es, p.n_all, -80.0f - Da, false);
+        const int64_t nA = cml_bound(p.Es, p.n_all, p.margin - Da, true) - lowE;
+        const int64_t lowD = cml_bound(p.Ds, p.n_all, -80.0f - Ea, false);
+        const int64_t mA = cml_bound(p.Ds, p.n_all, p.margin - Ea, true) - lowD;
         p.cD[a] = -(float)(nA > 0 ? nA : 0);
         p.cE[a] = -(float)(mA > 0 ? mA : 0);
         l += (double)(nA > 0 ? nA : 0) * (double)(p.margin - Da) - (double)(mA > 0 ? mA : 0) * (double)Ea +
@@ -221,18 +222,20 @@ struct CmlWs {
     size_t tmp_bytes, total;
 };
 
-int carve(int64_t B, char* base, CmlWs* w) {
+int carve(int64_t B, int64_t B_all, char* base, CmlWs* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char* p = base ? base + off : nullptr;
         off += al256(bytes);
         return p;
     };
-    float** slots[6] = {&w->D, &w->E, &w->Ds, &w->Es, &w->cD, &w->cE};
+    float** slots[4] = {&w->D, &w->E, &w->cD, &w->cE};
     for (auto s : slots) *s = (float*)take((size_t)B * 4);
+    w->Ds = (float*)take((size_t)B_all * 4);
+    w->Es = (float*)take((size_t)B_all * 4);
     size_t t = 0;
     float* np = nullptr;
-    if (rocprim::radix_sort_keys(nullptr, t, np, np, (unsigned)B, 0, 32, (hipStream_t)0) != hipSuccess) return 1;
+    if (rocprim::radix_sort_keys(nullptr, t, np, np, (unsigned)B_all, 0, 32, (hipStream_t)0) != hipSuccess) return 1;
     w->tmp_bytes = t;
     w->tmp = take(t);
     w->total = off;
@@ -261,42 +264,55 @@ int launch_rows(CmlArgs p, el_ctx* ctx, hipStream_t s) {
 
 }  // namespace
 
-extern "C" size_t el_cml_ws_bytes(int64_t B, int64_t U, int64_t I) {
-    if (B <= 0) return 0;
-    CmlWs w;
-    if (carve(B, nullptr, &w)) return 0;
-    return w.total + el_bprmf_ws_bytes(B, U, I);             // + the sort / segment scratch of the gradient pass
+static int cml_check(const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, const char* who) {
+    EL_REQUIRE(stp && stp->Gu && stp->Gi && stp->Bi && stp->gGu && stp->gGi && stp->gBi, "%s: null state", who);
+    EL_REQUIRE(stp->U > 0 && stp->I > 0 && stp->F > 0, "%s: bad shape", who);
+    EL_REQUIRE(u && i && j, "%s: null triplet arrays", who);
+    EL_REQUIRE(B < (1LL << 31), "%s: batch too large", who);
+    return 0;
 }
 
-extern "C" int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
-                                 const int32_t* j, int64_t B, float l_w, float l_b, float margin, int32_t step, float lr_t,
-                                 double* loss_out, void* ws, size_t ws_bytes) {
-    if (int rc = el_bind(ctx)) return rc;
-    EL_REQUIRE(stp && stp->Gu && stp->Gi && stp->Bi && stp->gGu && stp->gGi && stp->gBi, "el_cml_train_step: null state");
-    EL_REQUIRE(stp->mGu && stp->vGu && stp->mGi && stp->vGi && stp->mBi && stp->vBi, "el_cml_train_step: Adam slots missing");
-    EL_REQUIRE(stp->U > 0 && stp->I > 0 && stp->F > 0, "el_cml_train_step: bad shape");
-    if (B <= 0) return 0;
-    EL_REQUIRE(u && i && j && loss_out, "el_cml_train_step: null argument");
-    EL_REQUIRE(step >= 1 && B < (1LL << 31), "el_cml_train_step: bad step / batch");
-    CmlWs w;
-    EL_REQUIRE(carve(B, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
-    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I) : 0);
-    EL_REQUIRE(ws != nullptr && ws_bytes >= need, "el_cml_train_step: workspace too small (%zu < %zu)", ws_bytes, need);
-    hipStream_t s = (hipStream_t)stream;
+static CmlArgs cml_args(const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, float l_w, float l_b,
+                        float margin, double* loss_out) {
     CmlArgs p;
     memset(&p, 0, sizeof(p));
     p.st = *stp;
     p.st.tGu = p.st.tGi = p.st.tBi = nullptr;
-    p.bu = u, p.bi = i, p.bj = j, p.B = B, p.l_w = l_w, p.l_b = l_b, p.margin = margin;
-    p.D = w.D, p.E = w.E, p.Ds = w.Ds, p.Es = w.Es, p.cD = w.cD, p.cE = w.cE, p.loss_out = loss_out;
-    const bool vec = vec_ok(p.st);
-    if (int rc = vec ? launch_rows<4, 0>(p, ctx, s) : launch_rows<1, 0>(p, ctx, s)) return rc;
+    p.bu = u, p.bi = i, p.bj = j, p.B = B, p.l_w = l_w, p.l_b = l_b, p.margin = margin, p.loss_out = loss_out;
+    return p;
+}
+
+extern "C" size_t el_cml_ws_bytes(int64_t B, int64_t B_all, int64_t U, int64_t I) {
+    if (B <= 0) return 0;
+    CmlWs w;
+    if (carve(B, B_all < B ? B : B_all, nullptr, &w)) return 0;
+    return w.total + el_bprmf_ws_bytes(B, U, I);             // + the sort / segment scratch of the gradient pass
+}
+
+// phase 1: D_a, E_a of the rank's triplets (+ the regulariser into loss_out)
+extern "C" int el_cml_forward(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
+                              const int32_t* j, int64_t B, float l_w, float l_b, float* D, float* E, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (B <= 0) return 0;
+    if (int rc = cml_check(stp, u, i, j, B, "el_cml_forward")) return rc;
+    EL_REQUIRE(D && E && loss_out, "el_cml_forward: null output");
+    CmlArgs p = cml_args(stp, u, i, j, B, l_w, l_b, 0.f, loss_out);
+    p.D = D, p.E = E;
+    return vec_ok(p.st) ? launch_rows<4, 0>(p, ctx, (hipStream_t)stream) : launch_rows<1, 0>(p, ctx, (hipStream_t)stream);
+}
+
+// phase 2: coefficients of the rank's triplets against the GLOBAL batch's D / E, hinge part of the loss, row gradients
+static int cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j,
+                     int64_t B, float l_w, float l_b, float margin, const float* D, const float* E, const float* D_all,
+                     const float* E_all, int64_t B_all, double* loss_out, char* ws, size_t ws_bytes, const CmlWs& w) {
+    CmlArgs p = cml_args(stp, u, i, j, B, l_w, l_b, margin, loss_out);
+    p.D = const_cast<float*>(D), p.E = const_cast<float*>(E), p.Ds = w.Ds, p.Es = w.Es, p.cD = w.cD, p.cE = w.cE, p.n_all = B_all;
     {
         ElKernelTimer t("rocprim_radix_sort_keys", s);
         size_t tb = w.tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_keys(w.tmp, tb, w.D, w.Ds, (unsigned)B, 0, 32, s));
+        EL_CHECK_HIP(rocprim::radix_sort_keys(w.tmp, tb, D_all, w.Ds, (unsigned)B_all, 0, 32, s));
         tb = w.tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_keys(w.tmp, tb, w.E, w.Es, (unsigned)B, 0, 32, s));
+        EL_CHECK_HIP(rocprim::radix_sort_keys(w.tmp, tb, E_all, w.Es, (unsigned)B_all, 0, 32, s));
     }
     {
         const int64_t want = (B + 255) / 256, cap = (int64_t)ctx->cus * 16;
@@ -305,11 +321,41 @@ extern "C" int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state
     }
     // row gradients: batches worth sorting take the segment kernels of the BPR path (no float atomics on hot item rows:
     // 7.3 -> ~0.7 ms at B = 1M under Zipf popularity), small ones the atomic kernel
-    if (B >= 2048) {
-        if (int rc = el_bpr_sorted_cml_grads(ctx, s, p.st, u, i, j, B, l_w, l_b, w.cD, w.cE, (char*)ws + w.total, ws_bytes - w.total)) return rc;
-    } else {
-        if (int rc = vec ? launch_rows<4, 1>(p, ctx, s) : launch_rows<1, 1>(p, ctx, s)) return rc;
-    }
+    if (B >= 2048) return el_bpr_sorted_cml_grads(ctx, s, p.st, u, i, j, B, l_w, l_b, w.cD, w.cE, ws + w.total, ws_bytes - w.total);
+    return vec_ok(p.st) ? launch_rows<4, 1>(p, ctx, s) : launch_rows<1, 1>(p, ctx, s);
+}
+
+extern "C" int el_cml_grads(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
+                            const int32_t* j, int64_t B, float l_w, float l_b, float margin, const float* D, const float* E,
+                            const float* D_all, const float* E_all, int64_t B_all, double* loss_out, void* ws, size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (B <= 0) return 0;
+    if (int rc = cml_check(stp, u, i, j, B, "el_cml_grads")) return rc;
+    EL_REQUIRE(D && E && D_all && E_all && B_all >= B && B_all < (1LL << 31) && loss_out, "el_cml_grads: bad arguments");
+    CmlWs w;
+    EL_REQUIRE(carve(B, B_all, (char*)ws, &w) == 0, "el_cml_grads: rocprim size query failed");
+    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I) : 0);
+    EL_REQUIRE(ws != nullptr && ws_bytes >= need, "el_cml_grads: workspace too small (%zu < %zu)", ws_bytes, need);
+    return cml_grads(ctx, (hipStream_t)stream, stp, u, i, j, B, l_w, l_b, margin, D, E, D_all, E_all, B_all, loss_out, (char*)ws, ws_bytes, w);
+}
+
+extern "C" int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
+                                 const int32_t* j, int64_t B, float l_w, float l_b, float margin, int32_t step, float lr_t,
+                                 double* loss_out, void* ws, size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (B <= 0) return 0;
+    if (int rc = cml_check(stp, u, i, j, B, "el_cml_train_step")) return rc;
+    EL_REQUIRE(stp->mGu && stp->vGu && stp->mGi && stp->vGi && stp->mBi && stp->vBi, "el_cml_train_step: Adam slots missing");
+    EL_REQUIRE(loss_out && step >= 1, "el_cml_train_step: bad loss pointer / step");
+    CmlWs w;
+    EL_REQUIRE(carve(B, B, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
+    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I) : 0);
+    EL_REQUIRE(ws != nullptr && ws_bytes >= need, "el_cml_train_step: workspace too small (%zu < %zu)", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    CmlArgs p = cml_args(stp, u, i, j, B, l_w, l_b, margin, loss_out);
+    p.D = w.D, p.E = w.E;
+    if (int rc = vec_ok(p.st) ? launch_rows<4, 0>(p, ctx, s) : launch_rows<1, 0>(p, ctx, s)) return rc;
+    if (int rc = cml_grads(ctx, s, stp, u, i, j, B, l_w, l_b, margin, w.D, w.E, w.D, w.E, B, loss_out, (char*)ws, ws_bytes, w)) return rc;
     return el_bprmf_apply_optimizer(ctx, s, p.st, nullptr, nullptr, nullptr, 0, 0.f, EL_OPT_ADAM_TF_DENSE, step, lr_t);
 }
 

@@ -1006,15 +1006,63 @@ class CmlDeviceState(BprmfDeviceState):
     def train_step(self, u, i, j, lr, l_w, l_b, margin):
         self.step += 1
         B = u.numel()
-        need = int(self.ctx.lib.el_cml_ws_bytes(int(B), int(self.U), int(self.I)))
-        if self._cml_ws is None or self._cml_ws.numel() < need:
-            self._cml_ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+        need = self._cml_workspace(B, B)
         check(self.ctx.lib.el_cml_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
                                              _ptr(i, torch.int32), _ptr(j, torch.int32), int(B), float(l_w), float(l_b),
                                              float(margin), int(self.step), float(adam_lr_t(lr, self.step)),
                                              _ptr(self.loss, torch.float64), C.c_void_p(self._cml_ws.data_ptr()), need),
               "el_cml_train_step")
         self._items2 = None
+
+    def _cml_workspace(self, B, B_all):
+        need = int(self.ctx.lib.el_cml_ws_bytes(int(B), int(B_all), int(self.U), int(self.I)))
+        if self._cml_ws is None or self._cml_ws.numel() < need:
+            self._cml_ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+        return need
+
+    def forward_de(self, u, i, j, l_w, l_b):
+        """Phase 1 of the multi-GPU step: the rank's D_a, E_a (device float [B] each) + its share of the regulariser."""
+        B = u.numel()
+        D = torch.empty(B, dtype=torch.float32, device=self.ctx.device)
+        E = torch.empty(B, dtype=torch.float32, device=self.ctx.device)
+        check(self.ctx.lib.el_cml_forward(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                          _ptr(i, torch.int32), _ptr(j, torch.int32), int(B), float(l_w), float(l_b), _ptr(D), _ptr(E),
+                                          _ptr(self.loss, torch.float64)), "el_cml_forward")
+        return D, E
+
+    def grads_de(self, u, i, j, l_w, l_b, margin, D, E, D_all, E_all):
+        """Phase 2: the rank's triplets against the gathered D / E of the global batch; gradients stay in the accumulators."""
+        B, B_all = u.numel(), D_all.numel()
+        need = self._cml_workspace(B, B_all)
+        check(self.ctx.lib.el_cml_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
+                                        _ptr(i, torch.int32), _ptr(j, torch.int32), int(B), float(l_w), float(l_b), float(margin),
+                                        _ptr(D, torch.float32), _ptr(E, torch.float32), _ptr(D_all, torch.float32),
+                                        _ptr(E_all, torch.float32), int(B_all), _ptr(self.loss, torch.float64),
+                                        C.c_void_p(self._cml_ws.data_ptr()), need), "el_cml_grads")
+        self._items2 = None
+
+    # -- optimiser alone (multi-GPU step): the split form overlaps the item-gradient all-reduce with the user rows' update
+    def item_grads(self):
+        return [self.item_grad_flat]
+
+    def begin_step(self):
+        self.step += 1
+
+    def _apply(self, c_state, lr):
+        check(self.ctx.lib.el_bprmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(c_state), float(lr), int(self.opt), int(self.step),
+                                          float(adam_lr_t(lr, self.step))), "el_bprmf_apply")
+        self._items2 = None
+
+    def apply_users(self, lr):
+        if not hasattr(self, "_c_users"):
+            clone = lambda c: type(c).from_buffer_copy(c)
+            self._c_users, self._c_items = clone(self._c), clone(self._c)
+            self._c_users.I = 0
+            self._c_items.U = 0
+        self._apply(self._c_users, lr)
+
+    def apply_items(self, lr):
+        self._apply(self._c_items, lr)
 
     def _item_side(self):
         if self._items2 is None:

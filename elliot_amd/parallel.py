@@ -493,3 +493,38 @@ class ShardedPwmf:
         tot = self.coll.all_reduce_sum(t.clone())
         t.zero_()
         return float(tot.item())
+
+
+# ------------------------------------------------------------------------------------------------------
+# CML: user rows sharded, item side replicated -- and a real exchange step
+# ------------------------------------------------------------------------------------------------------
+class ShardedCml:
+    """One CML step over G ranks.  The reference's [B,B] hinge (CML_model.py:60-66,78) couples every triplet's distance
+    difference D_a with every triplet's bias difference E_b of the batch, so a data-parallel step has something to exchange:
+    el_cml_forward -> ALL-GATHER of the ranks' D and E vectors (2 x B floats per rank over RCCL) -> el_cml_grads of the rank's
+    triplets against the gathered vectors -> all-reduce of the item-side gradients, the rank's own user rows stepping under it
+    -> the item-side step.  G ranks x B triplets are one reference-semantics step on the concatenated batch of G B triplets
+    (its hinge has (G B)^2 terms).  `backend` = ops.CmlDeviceState on (local user rows, full item tables) or a stand-in."""
+
+    def __init__(self, backend, coll=None):
+        self.backend = backend
+        self.coll = coll or _Collectives()
+
+    def train_step(self, u_local, i, j, lr, l_w, l_b, margin):
+        be, coll = self.backend, self.coll
+        D, E = be.forward_de(u_local, i, j, l_w, l_b)
+        D_all, E_all = coll.all_gather(D), coll.all_gather(E)
+        be.grads_de(u_local, i, j, l_w, l_b, margin, D, E, D_all, E_all)
+        works = [coll.all_reduce_sum(g, async_op=True) for g in be.item_grads()]
+        be.begin_step()
+        be.apply_users(lr)
+        for w in works:
+            if w is not None:
+                w.wait()
+        be.apply_items(lr)
+
+    def pop_loss(self):
+        t = self.backend.loss
+        tot = self.coll.all_reduce_sum(t.clone())
+        t.zero_()
+        return float(tot.item())

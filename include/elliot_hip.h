@@ -483,10 +483,22 @@ int el_topk_rerank(el_ctx* ctx, void* stream, int32_t* idx, float* vals, int64_t
  * D_a = |u_a - j_a|^2 - |u_a - i_a|^2, E_b = b(i_b) - b(j_b).  Evaluated in O(B log B) (two float sorts + binary searches;
  * el_cml.hip).  Variables, gradient accumulators and Adam slots are an el_bprmf_state (Gu, Gi, Bi); optimiser = Keras
  * Adam with TF 2.3 sparse-apply semantics (EL_OPT_ADAM_TF_DENSE).  loss_out: device double[1], ADDED to.            */
-size_t el_cml_ws_bytes(int64_t B, int64_t U, int64_t I);
+size_t el_cml_ws_bytes(int64_t B, int64_t B_all, int64_t U, int64_t I);   /* B_all = B on one GPU */
 int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i,
                       const int32_t* j, int64_t B, float l_w, float l_b, float margin, int32_t step, float lr_t,
                       double* loss_out, void* ws, size_t ws_bytes);
+
+/* Multi-GPU form (data parallel over triplets).  The [B,B] hinge couples EVERY distance of the global batch with
+ * EVERY bias difference, so the ranks have a real exchange step: el_cml_forward writes the rank's D_a / E_a (device float[B]) and
+ * adds its share of the regulariser; the caller ALL-GATHERS D and E (2 x B floats per rank); el_cml_grads evaluates the rank's
+ * triplets against the gathered vectors (D_all / E_all, B_all values: sorted copies + binary searches), adds its share of the
+ * hinge sum and leaves the row gradients in the accumulators; item-side gradients are all-reduced, el_bprmf_apply is the
+ * optimiser.  forward + grads(D_all = D) + apply on one rank is el_cml_train_step.                                          */
+int el_cml_forward(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i, const int32_t* j,
+                   int64_t B, float l_w, float l_b, float* D, float* E, double* loss_out);
+int el_cml_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i, const int32_t* j,
+                 int64_t B, float l_w, float l_b, float margin, const float* D, const float* E, const float* D_all,
+                 const float* E_all, int64_t B_all, double* loss_out, void* ws, size_t ws_bytes);
 
 /* Replaces: CML_model.predict (:97-102), score(u,i) = -|Gu[u] - Gi[i]|^2 + Bi[i], through the fused scoring kernel:
  * el_cml_prepare_items writes Gi2 = 2 Gi and Bi2 = Bi - |Gi|^2, so that el_score_topk(Gu, Gi2, Bi2) ranks by

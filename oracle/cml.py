@@ -63,3 +63,40 @@ class CMLOracle:
     def predict(self, start, stop):
         d = self.Gu[start:stop, None, :] - self.Gi[None, :, :]
         return -np.sum(d * d, axis=-1) + self.Bi[None, :]
+
+
+# ---- the separable form the device evaluates (el_cml.hip): used by the multi-rank tests, pinned against loss_and_grads -------
+def distances(Gu, Gi, Bi, u, i, j, dtype=np.float32):
+    f = lambda a: np.asarray(a, dtype=dtype)
+    Gu, Gi, Bi = f(Gu), f(Gi), f(Bi)
+    D = np.sum((Gu[u] - Gi[j]) ** 2, -1) - np.sum((Gu[u] - Gi[i]) ** 2, -1)
+    return D, Bi[i] - Bi[j]
+
+
+def coefficients(D, E, D_all, E_all, margin):
+    """cD_a = -#{b : -80 - D_a <= E_b <= margin - D_a}, cE_a = -#{b : -80 - E_a <= D_b <= margin - E_a} over the GLOBAL batch,
+    and the local triplets' share of the hinge sum."""
+    Es, Ds = np.sort(np.asarray(E_all, np.float64)), np.sort(np.asarray(D_all, np.float64))
+    D64, E64 = np.asarray(D, np.float64), np.asarray(E, np.float64)
+    low = np.searchsorted(Es, -80.0 - D64, side="left")
+    n_a = np.searchsorted(Es, margin - D64, side="right") - low
+    m_a = np.searchsorted(Ds, margin - E64, side="right") - np.searchsorted(Ds, -80.0 - E64, side="left")
+    hinge = float(np.sum(n_a * (margin - D64)) - np.sum(m_a * E64) + np.sum(low) * (margin + 80.0))
+    return -n_a.astype(np.float64), -m_a.astype(np.float64), hinge
+
+
+def row_gradients(Gu, Gi, Bi, u, i, j, cD, cE, l_w, l_b, dtype=np.float32):
+    f = lambda a: np.asarray(a, dtype=dtype)
+    Gu, Gi, Bi, cD, cE = f(Gu), f(Gi), f(Bi), f(cD), f(cE)
+    dGu, dGi, dBi = np.zeros_like(Gu), np.zeros_like(Gi), np.zeros_like(Bi)
+    np.add.at(dGu, u, (2 * cD)[:, None] * (Gi[i] - Gi[j]) + dtype(l_w) * Gu[u])
+    np.add.at(dGi, i, (2 * cD)[:, None] * (Gu[u] - Gi[i]) + dtype(l_w) * Gi[i])
+    np.add.at(dGi, j, -(2 * cD)[:, None] * (Gu[u] - Gi[j]) + dtype(l_w) * Gi[j])
+    np.add.at(dBi, i, cE + dtype(l_b) * Bi[i])
+    np.add.at(dBi, j, -cE + dtype(l_b) / 10 * Bi[j])
+    return dGu, dGi, dBi
+
+
+def regulariser(Gu, Gi, Bi, u, i, j, l_w, l_b):
+    return float(l_w * 0.5 * (np.sum(Gu[u] ** 2) + np.sum(Gi[i] ** 2) + np.sum(Gi[j] ** 2)) + l_b * 0.5 * np.sum(Bi[i] ** 2)
+                 + l_b * 0.5 * np.sum(Bi[j] ** 2) / 10)

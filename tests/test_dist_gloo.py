@@ -550,3 +550,90 @@ def test_pointwise_models_user_sharded_world2_gloo(model):
     out = mgr.dict()
     mp.spawn(_pwmf_worker, args=(2, port, out, model), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+# ------------------------------------------------------------------------------------------ CML: the all-gather of D, E
+class NumpyCmlBackend:
+    """Stand-in for ops.CmlDeviceState on (local user rows, full item tables), oracle/cml.py's separable form."""
+
+    def __init__(self, Gu_local, Gi, Bi, lr):
+        from oracle import cml as oc
+        self.oc, self.lr = oc, lr
+        self.w = {"Gu": Gu_local.copy(), "Gi": Gi.copy(), "Bi": Bi.copy()}
+        self.m = {k: np.zeros_like(v) for k, v in self.w.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.w.items()}
+        self.flat = torch.zeros(Gi.size + Bi.size, dtype=torch.float32)
+        self.loss = torch.zeros(1, dtype=torch.float64)
+        self.t = 0
+
+    def forward_de(self, u, i, j, l_w, l_b):
+        u, i, j = (x.numpy().astype(np.int64) for x in (u, i, j))
+        D, E = self.oc.distances(self.w["Gu"], self.w["Gi"], self.w["Bi"], u, i, j)
+        self.loss += self.oc.regulariser(self.w["Gu"], self.w["Gi"], self.w["Bi"], u, i, j, l_w, l_b)
+        return torch.from_numpy(D.astype(np.float32)), torch.from_numpy(E.astype(np.float32))
+
+    def grads_de(self, u, i, j, l_w, l_b, margin, D, E, D_all, E_all):
+        u, i, j = (x.numpy().astype(np.int64) for x in (u, i, j))
+        cD, cE, hinge = self.oc.coefficients(D.numpy(), E.numpy(), D_all.numpy(), E_all.numpy(), margin)
+        self.loss += hinge
+        self.gGu, dGi, dBi = self.oc.row_gradients(self.w["Gu"], self.w["Gi"], self.w["Bi"], u, i, j, cD, cE, l_w, l_b)
+        self.flat.copy_(torch.from_numpy(np.concatenate([dGi.reshape(-1), dBi]).astype(np.float32)))
+
+    def item_grads(self):
+        return [self.flat]
+
+    def begin_step(self):
+        self.t += 1
+
+    def apply_users(self, lr):
+        ob.adam_tf_sparse_apply(self.w["Gu"], self.m["Gu"], self.v["Gu"], self.gGu.astype(np.float32), lr, self.t)
+
+    def apply_items(self, lr):
+        g = self.flat.numpy()
+        nI = self.w["Gi"].size
+        ob.adam_tf_sparse_apply(self.w["Gi"], self.m["Gi"], self.v["Gi"], g[:nI].reshape(self.w["Gi"].shape), lr, self.t)
+        ob.adam_tf_sparse_apply(self.w["Bi"], self.m["Bi"], self.v["Bi"], g[nI:].copy(), lr, self.t)
+
+
+def _cml_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cml as oc
+        rs = np.random.RandomState(8)
+        U, I, F, B, lr, l_w, l_b, margin = 37, 28, 5, 48, 0.01, 0.01, 0.02, 0.5
+        Gu, Gi = rs.normal(scale=0.4, size=(U, F)).astype(np.float32), rs.normal(scale=0.4, size=(I, F)).astype(np.float32)
+        Bi = rs.normal(scale=0.2, size=I).astype(np.float32)
+        ulo, uhi = parallel.user_range(U, rank, world)
+        be = NumpyCmlBackend(Gu[ulo:uhi], Gi, Bi, lr)
+        tr = parallel.ShardedCml(be, parallel._Collectives())
+        ref = oc.CMLOracle(Gu, Gi, Bi, lr, l_w, l_b, margin)
+        for step in range(3):
+            batches = []
+            for r in range(world):
+                brs = np.random.RandomState(700 + 10 * step + r)
+                l, h = parallel.user_range(U, r, world)
+                batches.append((brs.randint(l, h, B), brs.randint(0, I, B), brs.randint(0, I, B)))
+            u, i, j = batches[rank]
+            tr.train_step(torch.from_numpy((u - ulo).astype(np.int32)), torch.from_numpy(i.astype(np.int32)),
+                          torch.from_numpy(j.astype(np.int32)), lr, l_w, l_b, margin)
+            loss = tr.pop_loss()
+            cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+            ref_loss = ref.train_step((cu, ci, cj))                   # the [2B, 2B] hinge of the concatenated batch
+            assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss), (step, loss, ref_loss)
+            assert np.abs(be.w["Gu"] - ref.Gu[ulo:uhi]).max() < 1e-5 and np.abs(be.w["Gi"] - ref.Gi).max() < 1e-5
+            assert np.abs(be.w["Bi"] - ref.Bi).max() < 1e-5
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cml_user_sharded_world2_gloo_with_the_all_gather_of_distances():
+    """CML's hinge couples the whole batch: the ranks all-gather D and E (a real exchange step), then G ranks x B triplets are
+    one reference-semantics step on the concatenated batch."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cml_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}

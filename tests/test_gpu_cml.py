@@ -152,3 +152,39 @@ def test_tiny_shapes_fuzz(ctx):
         idx, val = (cpu(t) for t in st.recommend(0, U, k))
         best = -np.sort(-oc.CMLOracle(cpu(st.Gu), cpu(st.Gi), cpu(st.Bi), 0, 0, 0, 0).predict(0, U).astype(np.float64), axis=1)[:, :k]
         assert np.abs(val - best).max() < 1e-5, (trial, U, I, F)
+
+
+def test_user_sharded_hip_path_equals_concatenated_batch(ctx):
+    """parallel.ShardedCml's kernel sequence with two virtual ranks on one GPU: forward -> gather of D, E -> grads against the
+    gathered vectors -> sum of the item-side accumulators -> split apply.  Equals the oracle's step on the concatenated batch
+    (whose hinge has (2B)^2 terms); item replicas stay bit-identical."""
+    from elliot_amd import parallel
+    rs = np.random.RandomState(31)
+    U, I, F, B, lr, l_w, l_b, margin, G = 400, 300, 32, 2500, 0.01, 0.01, 0.02, 0.5, 2
+    Gu, Gi, Bi = tables(rs, U, I, F, 0.3)
+    rng = [parallel.user_range(U, r, G) for r in range(G)]
+    sts = [ops.CmlDeviceState(ctx, Gu[lo:hi], Gi, Bi) for lo, hi in rng]
+    orc = oc.CMLOracle(Gu, Gi, Bi, lr, l_w, l_b, margin)
+    for step in range(3):
+        batches = [(rs.randint(lo, hi, B), rs.randint(0, 40, B), rs.randint(0, I, B)) for lo, hi in rng]
+        dv = [[dev(ctx, u - lo), dev(ctx, i), dev(ctx, j)] for (lo, hi), (u, i, j) in zip(rng, batches)]
+        de = [st.forward_de(*t, l_w, l_b) for st, t in zip(sts, dv)]
+        D_all, E_all = torch.cat([d for d, _ in de]), torch.cat([e for _, e in de])          # the all-gather
+        for st, t, (D, E) in zip(sts, dv, de):
+            st.grads_de(*t, l_w, l_b, margin, D, E, D_all, E_all)
+        tot = sts[0].item_grad_flat + sts[1].item_grad_flat                                  # the all-reduce
+        loss = 0.0
+        for st in sts:
+            st.item_grad_flat.copy_(tot)
+            st.begin_step()
+            st.apply_users(lr)
+            st.apply_items(lr)
+            loss += st.pop_loss()
+        cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
+        exp = orc.train_step((cu, ci, cj))
+        assert abs(loss - exp) <= 1e-4 * abs(exp), (step, loss, exp)
+        assert torch.equal(sts[0].Gi, sts[1].Gi) and torch.equal(sts[0].Bi, sts[1].Bi)
+        assert (np.abs(cpu(sts[0].Gi) - orc.Gi) > 5e-5).mean() < 5e-3 and (np.abs(cpu(sts[0].Bi) - orc.Bi) > 5e-5).mean() < 5e-3
+        for st, (lo, hi) in zip(sts, rng):
+            assert (np.abs(cpu(st.Gu) - orc.Gu[lo:hi]) > 5e-5).mean() < 5e-3
+            assert not bool(st.gGu.any()) and not bool(st.item_grad_flat.any())

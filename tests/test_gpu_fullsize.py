@@ -165,7 +165,8 @@ def test_fullsize_cml_pair_counts_and_clean_state(ctx, world):
     loss = st.pop_loss()
     al = lambda n: (n + 255) // 256 * 256
     ws = st._cml_ws
-    arr = [ws[k * al(B * 4):k * al(B * 4) + B * 4].view(torch.float32) for k in range(6)]      # D, E, Ds, Es, cD, cE
+    D_, E_, cD_, cE_, Ds_, Es_ = (ws[k * al(B * 4):k * al(B * 4) + B * 4].view(torch.float32) for k in range(6))   # el_cml.hip carve()
+    arr = [D_, E_, Ds_, Es_, cD_, cE_]
     assert bool((arr[2][1:] >= arr[2][:-1]).all()) and bool((arr[3][1:] >= arr[3][:-1]).all())
     assert float(arr[4].double().sum()) == float(arr[5].double().sum()) < 0
     assert float((arr[0].double() - D).abs().max()) < 1e-5 and float((arr[1].double() - E).abs().max()) < 1e-7

@@ -40,3 +40,19 @@ def test_clip_region_contributes_constant_terms():
     assert loss == 0.0 and not dGu.any()                                              # diff = 100 > margin: inactive
     loss, dGu, *_ = cml.loss_and_grads(Gu, Gi, Bi, np.array([0]), np.array([1]), np.array([0]), 0.0, 0.0, 0.5, dtype=np.float64)
     assert loss == 80.5 and not dGu.any()                                             # diff = -100 < -80: clipped, constant
+
+
+def test_separable_form_equals_the_matrix_form():
+    """What the device evaluates (sorted counts) against the [B,B] matrix restatement, incl. pairs beyond the -80 clip."""
+    rs = np.random.RandomState(5)
+    U, I, F, B = 15, 12, 4, 60
+    for scale in (0.5, 5.0):
+        Gu, Gi, Bi = rs.normal(scale=scale, size=(U, F)), rs.normal(scale=scale, size=(I, F)), rs.normal(scale=0.4, size=I)
+        u, i, j = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, I, B)
+        loss, dGu, dGi, dBi = cml.loss_and_grads(Gu, Gi, Bi, u, i, j, 0.01, 0.02, 0.5, dtype=np.float64)
+        D, E = cml.distances(Gu, Gi, Bi, u, i, j, dtype=np.float64)
+        cD, cE, hinge = cml.coefficients(D, E, D, E, 0.5)
+        g = cml.row_gradients(Gu, Gi, Bi, u, i, j, cD, cE, 0.01, 0.02, dtype=np.float64)
+        assert abs(hinge + cml.regulariser(Gu, Gi, Bi, u, i, j, 0.01, 0.02) - loss) < 1e-8 * abs(loss)
+        for a, b in zip(g, (dGu, dGi, dBi)):
+            assert np.abs(a - b).max() < 1e-9
