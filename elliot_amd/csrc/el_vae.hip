@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_vae_densify(const int32_t* __restrict__
 // loss += anneal * (-1/2) * mean_{b,j}(logvar - mu^2 - exp(logvar) + 1)   (:119-121, :137)
 __global__ __launch_bounds__(256) void k_vae_sample(const float* __restrict__ mv, const float* __restrict__ eps,
                                                     int64_t B, int L, float anneal, float* __restrict__ z,
-                                                    double* loss_out) {
+                                                    double* loss_out, int64_t Bd) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float term = 0.f;
     if (t < B * L) {
@@ -138,14 +138,14 @@ __global__ __launch_bounds__(256) void k_vae_sample(const float* __restrict__ mv
     __syncthreads();
     if (threadIdx.x == 0 && loss_out) {
         const double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
-        if (tot != 0.0 && anneal != 0.f) atomicAdd(loss_out, (double)anneal * (-0.5) * tot / ((double)B * (double)L));
+        if (tot != 0.0 && anneal != 0.f) atomicAdd(loss_out, (double)anneal * (-0.5) * tot / ((double)Bd * (double)L));
     }
 }
 
 // d[mu | logvar] from dz and the KL term
 __global__ __launch_bounds__(256) void k_vae_dmv(const float* __restrict__ dz, const float* __restrict__ mv,
                                                  const float* __restrict__ eps, int64_t B, int L, float anneal,
-                                                 float* __restrict__ dmv) {
+                                                 float* __restrict__ dmv, int64_t Bd) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * L) return;
     const int64_t b = t / L;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_vae_dmv(const float* __restrict__ dz, c
     const float mu = mv[b * 2 * L + j], lv = mv[b * 2 * L + L + j];
     const float e = eps ? eps[t] : 0.f;
     const float g = dz[t];
-    const float kscale = anneal / ((float)B * (float)L);
+    const float kscale = anneal / ((float)Bd * (float)L);
     dmv[b * 2 * L + j] = g + kscale * mu;
     dmv[b * 2 * L + L + j] = g * e * 0.5f * expf(0.5f * lv) + kscale * 0.5f * (expf(lv) - 1.0f);
 }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int
 __global__ __launch_bounds__(256) void k_vae_softmax(float* __restrict__ logits, const int32_t* __restrict__ rows,
                                                      const int64_t* __restrict__ indptr,
                                                      const int32_t* __restrict__ indices, int64_t B, int64_t I,
-                                                     int mode, double* loss_out) {
+                                                     int mode, double* loss_out, int64_t Bd) {
     __shared__ float red[4];
     __shared__ float bc;
     const int64_t b = blockIdx.x;
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void k_vae_softmax(float* __restrict__ logits,
     __syncthreads();
     if (tid == 0) {
         const double tot = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
-        atomicAdd(loss_out, -tot / (double)B);
+        atomicAdd(loss_out, -tot / (double)Bd);
     }
-    const float invB = 1.0f / (float)B;
+    const float invB = 1.0f / (float)Bd;
     for (int64_t i = tid; i < I; i += 256) row[i] = expf(row[i] - lse) * cnt * invB;
     __syncthreads();
     for (int64_t e = r0 + tid; e < r1; e += 256) row[indices[e]] -= invB;
@@ -289,7 +289,7 @@ static int colsum(hipStream_t s, const float* X, int64_t B, int64_t N, float* ou
 
 static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
                        const int32_t* rows, int64_t B, const float* eps, float anneal, float rate, u64 seed, u32 step,
-                       double* loss_out) {
+                       double* loss_out, int64_t Bd) {
     const int H = st->H, L = st->L;
     const int64_t I = st->I;
     EL_VAE_ENC1(k_vae_enc1, rows, indptr, indices, st->w[0], st->w[1], B, H, rate, seed, step, st->h, st->rnorm);
@@ -298,7 +298,7 @@ static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const
         if (int rc = el_gemm_f32(ctx, s, 0, 0, B, L, H, st->h, H, st->w[2], L, st->z, L, st->w[3], 1 /*tanh*/, st->ws, st->ws_bytes)) return rc;
     } else {
         if (int rc = el_gemm_f32(ctx, s, 0, 0, B, 2 * L, H, st->h, H, st->w[2], 2 * L, st->mv, 2 * L, st->w[3], 0, st->ws, st->ws_bytes)) return rc;
-        EL_LAUNCH("k_vae_sample", k_vae_sample, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->mv, eps, B, L, anneal, st->z, loss_out);
+        EL_LAUNCH("k_vae_sample", k_vae_sample, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->mv, eps, B, L, anneal, st->z, loss_out, Bd);
     }
     if (int rc = el_gemm_f32(ctx, s, 0, 0, B, H, L, st->z, L, st->w[4], H, st->h2, H, st->w[5], 1 /*tanh*/, st->ws, st->ws_bytes)) return rc;
     if (int rc = el_gemm_f32(ctx, s, 0, 0, B, I, H, st->h2, H, st->w[6], I, st->logits, I, st->w[7], 0, st->ws, st->ws_bytes)) return rc;
@@ -306,20 +306,20 @@ static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const
     return 0;
 }
 
-extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr,
-                                 const int32_t* indices, const int32_t* rows, int64_t B, const float* eps, float anneal,
-                                 float dropout_rate, uint64_t dropout_seed, int32_t step, float lr_t, double* loss_out) {
-    if (int rc = el_bind(ctx)) return rc;
+// forward, loss (batch means over Bd rows: Bd = B, or the global batch when several ranks share a step) and backward: the eight
+// gradient buffers st->g[] are complete on exit
+static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
+                     const int32_t* rows, int64_t B, int64_t Bd, const float* eps, float anneal, float dropout_rate,
+                     uint64_t dropout_seed, int32_t step, double* loss_out) {
     if (int rc = vae_check(st, B)) return rc;
-    EL_REQUIRE(indptr && indices && rows && loss_out && step >= 1, "el_vae_train_step: bad arguments");
-    for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t] && st->m[t] && st->v[t], "el_vae_train_step: optimiser buffers missing");
+    EL_REQUIRE(indptr && indices && rows && loss_out && step >= 1 && Bd >= B, "el_vae: bad arguments");
+    for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t], "el_vae: gradient buffers missing");
     EL_REQUIRE(st->dh2 && (st->dae || st->dmv) && st->dh && st->dz, "el_vae_train_step: backward buffers missing");
-    hipStream_t s = (hipStream_t)stream;
     const int H = st->H, L = st->L;
     const int64_t I = st->I;
-    if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, anneal, dropout_rate, dropout_seed, (u32)step, loss_out)) return rc;
+    if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, anneal, dropout_rate, dropout_seed, (u32)step, loss_out, Bd)) return rc;
     // loss + dlogits (in place)
-    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out);
+    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out, Bd);
     float* dl = st->logits;
     // decoder output layer
     if (int rc = el_gemm_f32(ctx, s, 1, 0, H, I, B, st->h2, H, dl, I, st->g[6], I, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dW4 = h2^T dl
@@ -336,7 +336,7 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
         if (int rc = colsum(s, st->dz, B, L, st->g[3])) return rc;
         if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, L, st->dz, L, st->w[2], L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dh
     } else {
-        EL_LAUNCH("k_vae_dmv", k_vae_dmv, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->dz, st->mv, eps, B, L, anneal, st->dmv);
+        EL_LAUNCH("k_vae_dmv", k_vae_dmv, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->dz, st->mv, eps, B, L, anneal, st->dmv, Bd);
         if (int rc = el_gemm_f32(ctx, s, 1, 0, H, 2 * L, B, st->h, H, st->dmv, 2 * L, st->g[2], 2 * L, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dWmv
         if (int rc = colsum(s, st->dmv, B, 2 * L, st->g[3])) return rc;
         if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, 2 * L, st->dmv, 2 * L, st->w[2], 2 * L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dh = dmv Wmv^T
@@ -348,7 +348,15 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
     EL_LAUNCH("k_vae_densify", k_vae_densify, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, st->rnorm, B, I,
               dropout_rate, (u64)dropout_seed, (u32)step, st->logits);
     if (int rc = el_gemm_f32(ctx, s, 1, 0, I, H, B, st->logits, I, st->dh, H, st->g[0], H, nullptr, 0, st->ws, st->ws_bytes)) return rc;
-    // Adam on the ten variables (W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4)
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// Adam on the ten variables (W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4)
+static int vae_apply(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t) {
+    for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t] && st->m[t] && st->v[t], "el_vae: optimiser buffers missing");
+    const int H = st->H, L = st->L;
+    const int64_t I = st->I;
     const int64_t LL = st->dae ? L : 2 * L;
     const int64_t sizes[8] = {I * H, H, (int64_t)H * LL, LL, (int64_t)L * H, H, (int64_t)H * I, I};
     for (int t = 0; t < 8; ++t) {
@@ -359,6 +367,27 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
     return 0;
 }
 
+extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr,
+                                 const int32_t* indices, const int32_t* rows, int64_t B, const float* eps, float anneal,
+                                 float dropout_rate, uint64_t dropout_seed, int32_t step, float lr_t, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = vae_grads(ctx, (hipStream_t)stream, st, indptr, indices, rows, B, B, eps, anneal, dropout_rate, dropout_seed, step, loss_out)) return rc;
+    return vae_apply(ctx, (hipStream_t)stream, st, lr_t);
+}
+
+extern "C" int el_vae_grads(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
+                            const int32_t* rows, int64_t B, int64_t B_global, const float* eps, float anneal, float dropout_rate,
+                            uint64_t dropout_seed, int32_t step, double* loss_out) {
+    if (int rc = el_bind(ctx)) return rc;
+    return vae_grads(ctx, (hipStream_t)stream, st, indptr, indices, rows, B, B_global, eps, anneal, dropout_rate, dropout_seed, step, loss_out);
+}
+
+extern "C" int el_vae_apply(el_ctx* ctx, void* stream, const el_vae_state* st, float lr_t) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(st != nullptr, "el_vae_apply: null state");
+    return vae_apply(ctx, (hipStream_t)stream, st, lr_t);
+}
+
 // log_softmax(logits) of the batch rows into st->logits [B, I] (multi_vae_model.py:145-155; dropout off)
 extern "C" int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr,
                               const int32_t* indices, const int32_t* rows, int64_t B, const float* eps) {
@@ -366,8 +395,8 @@ extern "C" int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st,
     if (int rc = vae_check(st, B)) return rc;
     EL_REQUIRE(indptr && indices && rows, "el_vae_predict: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, 0.f, 0.f, 0, 0, nullptr)) return rc;
-    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, st->I, 0, nullptr);
+    if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, 0.f, 0.f, 0, 0, nullptr, B)) return rc;
+    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, st->I, 0, nullptr, B);
     EL_CHECK_LAUNCH();
     return 0;
 }

@@ -656,6 +656,23 @@ class VaeDeviceState:
                                              float(adam_lr_t(lr, self.step)), _ptr(self.loss, torch.float64)),
               "el_vae_train_step")
 
+    def grads(self, train_csr, rows, anneal, eps=None, dropout_rate=0.0, dropout_seed=42, n_global=None):
+        """Forward + loss + backward only; the batch means run over n_global rows (multi-GPU).  dense_grads() lists the buffers a
+        data-parallel caller all-reduces before apply()."""
+        B = rows.numel()
+        check(self.ctx.lib.el_vae_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), *_csr_ptrs(train_csr),
+                                        _ptr(rows, torch.int32, "rows"), int(B), int(B if n_global is None else n_global),
+                                        _ptr(eps, torch.float32, "eps"), float(anneal), float(dropout_rate), int(dropout_seed),
+                                        int(self.step + 1), _ptr(self.loss, torch.float64)), "el_vae_grads")
+
+    def apply(self, lr):
+        self.step += 1
+        check(self.ctx.lib.el_vae_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), float(adam_lr_t(lr, self.step))),
+              "el_vae_apply")
+
+    def dense_grads(self):
+        return list(self.g)
+
     def predict(self, train_csr, rows, eps=None):
         """log_softmax(logits) [B, I] view of the activation buffer (multi_vae_model.py:144-155)."""
         B = rows.numel()

@@ -528,3 +528,33 @@ class ShardedCml:
         tot = self.coll.all_reduce_sum(t.clone())
         t.zero_()
         return float(tot.item())
+
+
+# ------------------------------------------------------------------------------------------------------
+# Mult-VAE / Mult-DAE: data parallel over the user rows of a batch, weights replicated
+# ------------------------------------------------------------------------------------------------------
+class ShardedVae:
+    """One Mult-VAE / Mult-DAE step over G ranks: the users of a batch are independent samples, so the batch is
+    split; every rank runs el_vae_grads on its rows with both batch means taken over the GLOBAL batch, the gradients of the
+    ten (replicated) dense variables are all-reduced (sum) -- 4 (2 I H + ...) bytes, 130 MB at the ML-20M shape: the bandwidth-
+    heavy form the survey names; it is here for completeness, the named configuration is single-GPU -- and every rank applies
+    the same Adam step.  `backend` = ops.VaeDeviceState or a stand-in with grads / apply / dense_grads / loss."""
+
+    def __init__(self, backend, coll=None):
+        self.backend = backend
+        self.coll = coll or _Collectives()
+
+    def train_step(self, train_csr, rows, lr, anneal, eps=None, dropout_rate=0.0, dropout_seed=42, n_global=None):
+        be, coll = self.backend, self.coll
+        if n_global is None:
+            n_global = coll.world * int(rows.shape[0])
+        be.grads(train_csr, rows, anneal, eps=eps, dropout_rate=dropout_rate, dropout_seed=dropout_seed, n_global=n_global)
+        for g in be.dense_grads():
+            coll.all_reduce_sum(g)
+        be.apply(lr)
+
+    def pop_loss(self):
+        t = self.backend.loss
+        tot = self.coll.all_reduce_sum(t.clone())
+        t.zero_()
+        return float(tot.item())

@@ -342,6 +342,15 @@ int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* st,
                       const float* eps, float anneal, float dropout_rate, uint64_t dropout_seed,
                       int32_t step, float lr_t, double* loss_out);
 
+/* Multi-GPU form (data parallel over the user rows of a batch, weights replicated): el_vae_grads = forward + loss +
+ * backward with both batch means (multinomial NLL over rows, KL over rows x latent units) taken over B_global rows (the sum of
+ * all ranks' B), the eight gradient buffers st->g[] complete on exit; the caller all-reduces them over RCCL; el_vae_apply =
+ * Adam on the ten variables.  grads + apply with B_global = B is el_vae_train_step.                                      */
+int el_vae_grads(el_ctx* ctx, void* stream, const el_vae_state* st,
+                 const int64_t* indptr, const int32_t* indices, const int32_t* rows, int64_t B, int64_t B_global,
+                 const float* eps, float anneal, float dropout_rate, uint64_t dropout_seed, int32_t step, double* loss_out);
+int el_vae_apply(el_ctx* ctx, void* stream, const el_vae_state* st, float lr_t);
+
 /* Replaces: VariationalAutoEncoder.predict (multi_vae_model.py:144-155): st->logits[0..B) receives
  * log_softmax(logits) of users rows[0..B) (dropout off; eps as above).                        */
 int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st,

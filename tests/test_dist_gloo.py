@@ -637,3 +637,77 @@ def test_cml_user_sharded_world2_gloo_with_the_all_gather_of_distances():
     out = mgr.dict()
     mp.spawn(_cml_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+# ------------------------------------------------------------------------------------------ Mult-VAE, data parallel
+class NumpyVaeBackend:
+    """Stand-in for ops.VaeDeviceState: oracle/multi_vae.py forward / gradients on the rank's rows of a dense batch."""
+
+    def __init__(self, weights, lr):
+        from oracle import multi_vae as ov
+        self.ov = ov
+        self.o = ov.MultiVAEOracle(weights, lr)
+        self.gt = {k: torch.zeros(v.shape, dtype=torch.float32) for k, v in self.o.w.items()}
+        self.loss = torch.zeros(1, dtype=torch.float64)
+
+    def grads(self, X, rows, anneal, eps=None, dropout_rate=0.0, dropout_seed=42, n_global=None):
+        x = X[rows.numpy()]
+        c = self.ov.forward(self.o.w, x, eps.numpy())
+        scale = len(x) / float(n_global)                       # both losses are batch MEANS: local mean x n / n_global
+        self.loss += self.ov.loss_from(c, anneal) * scale
+        g = self.ov.gradients(self.o.w, c, np.float32(anneal))
+        for k in self.gt:
+            self.gt[k].copy_(torch.from_numpy((g[k] * np.float32(scale)).astype(np.float32)))
+
+    def dense_grads(self):
+        return [self.gt[k] for k in self.ov.NAMES]
+
+    def apply(self, lr):
+        o, f = self.o, np.float32
+        o.t += 1
+        a = self.ov.adam_lr_t(o.lr, o.t)
+        for k in self.ov.NAMES:
+            gg = self.gt[k].numpy()
+            o.m[k] += (gg - o.m[k]) * f(1 - self.ov.BETA1)
+            o.v[k] += (gg * gg - o.v[k]) * f(1 - self.ov.BETA2)
+            o.w[k] -= (o.m[k] * a) / (np.sqrt(o.v[k]) + f(self.ov.EPS))
+
+
+def _vae_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import multi_vae as ov
+        rs = np.random.RandomState(4)
+        U, I, H, L, n, lr = 40, 50, 12, 5, 8, 0.005
+        X = (rs.rand(U, I) < 0.15).astype(np.float32)
+        X[X.sum(1) == 0, 0] = 1
+        w0 = ov.init_weights(I, H, L, 2)
+        be = NumpyVaeBackend(w0, lr)
+        tr = parallel.ShardedVae(be, parallel._Collectives())
+        ref = ov.MultiVAEOracle(w0, lr)
+        for step in range(3):
+            brs = np.random.RandomState(50 + step)
+            rows_all = brs.permutation(U)[:world * n]
+            eps_all = brs.normal(size=(world * n, L)).astype(np.float32)
+            rows, eps = rows_all[rank * n:(rank + 1) * n], eps_all[rank * n:(rank + 1) * n]
+            tr.train_step(X, torch.from_numpy(rows), lr, 0.1, eps=torch.from_numpy(eps))
+            loss = tr.pop_loss()
+            ref_loss = ref.train_step(X[rows_all], eps_all, 0.1)
+            assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss), (step, loss, ref_loss)
+            for k in ov.NAMES:
+                assert np.abs(be.o.w[k] - ref.w[k]).max() < 2e-6, (step, k)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multivae_data_parallel_world2_gloo():
+    """the rows of a batch split over the ranks, gradients of the replicated weights all-reduced: G ranks x n
+    rows = one reference-semantics step on the batch of G n rows."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_vae_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}

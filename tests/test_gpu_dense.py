@@ -124,3 +124,44 @@ def test_dae_train_steps_and_predict_match_oracle(ctx, rate):
     pred = cpu(st.predict(csr, torch.from_numpy(rows).to(d)))
     ref = od.log_softmax(od.forward(st.weights(), X[rows], dtype=np.float64)["logits"])
     assert np.abs(pred - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("dae", [False, True])
+def test_data_parallel_hip_path_equals_one_batch(ctx, dae):
+    """parallel.ShardedVae's kernel sequence with two virtual ranks: el_vae_grads on half of the rows each (batch means over the
+    WHOLE batch), the gradient buffers added (the all-reduce), el_vae_apply on both: equals the oracle's step on the whole
+    batch, replicas stay bit-identical."""
+    from oracle import multi_dae as od
+    rs = np.random.RandomState(17)
+    U, I, H, L, n, lr, G = 260, 500, 32, 8, 48, 0.001, 2
+    X = (rs.rand(U, I) < 0.05).astype(np.float32)
+    X[np.arange(U), rs.randint(0, I, U)] = 1.0
+    m = sp.csr_matrix(X)
+    m.sort_indices()
+    csr = ops.DeviceCSR(m.indptr, m.indices, I, ctx.device)
+    w0 = od.init_weights(I, H, L, 5) if dae else ov.init_weights(I, H, L, 5)
+    sts = [ops.VaeDeviceState(ctx, w0, max_batch=n) for _ in range(G)]
+    orc = od.MultiDAEOracle(w0, lr) if dae else ov.MultiVAEOracle(w0, lr)
+    d = ctx.device
+    for s in range(3):
+        rows_all = rs.permutation(U)[:G * n].astype(np.int32)
+        eps_all = rs.normal(size=(G * n, L)).astype(np.float32)
+        for r, st in enumerate(sts):
+            st.grads(csr, torch.from_numpy(rows_all[r * n:(r + 1) * n]).to(d), 0.1,
+                     eps=None if dae else torch.from_numpy(eps_all[r * n:(r + 1) * n]).to(d), n_global=G * n)
+        for a, b in zip(sts[0].dense_grads(), sts[1].dense_grads()):
+            tot = a + b
+            a.copy_(tot)
+            b.copy_(tot)
+        loss = 0.0
+        for st in sts:
+            st.apply(lr)
+            loss += st.pop_loss()
+        exp = orc.train_step(X[rows_all]) if dae else orc.train_step(X[rows_all], eps_all, 0.1)
+        assert abs(loss - exp) <= 1e-4 * abs(exp), (s, loss, exp)
+        for a, b in zip(sts[0].w, sts[1].w):
+            assert torch.equal(a, b)
+        gw = sts[0].weights()
+        for k in (od.NAMES if dae else ov.NAMES):
+            err = np.abs(gw[k] - orc.w[k])
+            assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()))
