@@ -100,6 +100,10 @@ PROTOTYPES = {
     "el_timing_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "el_bpr_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
+    "el_bpr_sampler_meta_bytes": (C.c_size_t, [C.c_int64]),
+    "el_bpr_sampler_meta_build": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_void_p]),
+    "el_bpr_sample_meta": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                     C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "el_bpr_sample_mt19937_ws_bytes": (C.c_size_t, [C.c_int64]),
     "el_bpr_sample_mt19937": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64p, _i32p, _i64p, _i32p, C.c_int64, C.c_int64,
                                         C.c_int64, _i32p, _i32p, _i32p, C.c_void_p, C.c_size_t]),
@@ -150,7 +154,7 @@ PROTOTYPES = {
     "el_bprmf_train_loop_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "el_bprmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i64p, _i32p, C.c_uint64, C.c_uint64,
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,
-                                      _f64p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+                                      _f64p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "el_topk_rerank": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int64, C.c_int32]),
     "el_cml_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "el_cml_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float,

@@ -57,10 +57,43 @@ struct PhiloxStream {
     }
 };
 
+// Optional per-user record of the sampler (el_bpr_sampler_meta_build): everything a draw needs about its user in ONE 64-byte
+// line -- row start, row length and a 384-bit membership signature of the row.  A negative candidate whose signature bit is
+// clear is certainly not a positive (the usual case: rows fill ~18 % of the bits), so the binary search over the row -- three
+// more cache lines per triplet -- only runs on a signature hit.  Accept / reject decisions are those of the plain path.
+struct __attribute__((aligned(64))) SamplerRec {
+    int64_t r0;
+    int32_t len;
+    u32 pad;
+    u32 sig[12];
+};
+#define EL_SIG_BITS 384u
+__device__ __forceinline__ u32 el_sig_bit(int32_t item) { return ((u32)item * 0x9E3779B1u) % EL_SIG_BITS; }
+
+__global__ __launch_bounds__(256) void k_bpr_sampler_meta(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                          int64_t U, SamplerRec* __restrict__ meta) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    SamplerRec r;
+    r.r0 = indptr[u];
+    const int64_t r1 = indptr[u + 1];
+    r.len = (int32_t)(r1 - r.r0);
+    r.pad = 0u;
+#pragma unroll
+    for (int w = 0; w < 12; ++w) r.sig[w] = 0u;
+    for (int64_t e = r.r0; e < r1; ++e) {
+        const u32 b = el_sig_bit(indices[e]);
+        r.sig[b >> 5] |= 1u << (b & 31u);
+    }
+    meta[u] = r;
+}
+
+template <bool META>
 __global__ __launch_bounds__(256) void k_bpr_sample(const int64_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices, int64_t U, int64_t I,
                                                     int64_t item_lo, int64_t item_hi, u64 seed, u64 first, int64_t n,
-                                                    int32_t* out_u, int32_t* out_i, int32_t* out_j) {
+                                                    int32_t* out_u, int32_t* out_i, int32_t* out_j,
+                                                    const SamplerRec* __restrict__ meta) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     PhiloxStream ps;
@@ -68,7 +101,18 @@ __global__ __launch_bounds__(256) void k_bpr_sample(const int64_t* __restrict__ 
     const u32 range = (u32)(item_hi - item_lo);
     for (;;) {
         u32 u = ps.bounded((u32)U);
-        int64_t r0 = indptr[u], r1 = indptr[u + 1];
+        int64_t r0, r1;
+        uint4 sg[3];
+        if (META) {
+            const uint4* rec = reinterpret_cast<const uint4*>(meta + u);
+            const uint4 h = rec[0];
+            sg[0] = rec[1], sg[1] = rec[2], sg[2] = rec[3];
+            r0 = (int64_t)(((u64)h.y << 32) | (u64)h.x);
+            r1 = r0 + (int64_t)(int32_t)h.z;
+        } else {
+            r0 = indptr[u];
+            r1 = indptr[u + 1];
+        }
         int64_t lui = r1 - r0;
         if (lui <= 0 || lui >= I) continue;  // no positive / no negative available: re-draw the user
         u32 ipos = ps.bounded((u32)lui);
@@ -76,7 +120,14 @@ __global__ __launch_bounds__(256) void k_bpr_sample(const int64_t* __restrict__ 
         int32_t jt = -1;
         for (int attempt = 0; attempt < 4096; ++attempt) {
             int32_t cand = (int32_t)(item_lo + (int64_t)ps.bounded(range));
-            if (!el_row_contains(indices, r0, r1, cand)) {
+            bool maybe = true;
+            if (META) {
+                const u32 b = el_sig_bit(cand), w = b >> 5;
+                const uint4 q = w < 4 ? sg[0] : (w < 8 ? sg[1] : sg[2]);
+                const u32 word = (w & 3u) == 0 ? q.x : ((w & 3u) == 1 ? q.y : ((w & 3u) == 2 ? q.z : q.w));
+                maybe = ((word >> (b & 31u)) & 1u) != 0u;
+            }
+            if (!maybe || !el_row_contains(indices, r0, r1, cand)) {
                 jt = cand;
                 break;
             }
@@ -98,8 +149,37 @@ extern "C" int el_bpr_sample(el_ctx* ctx, void* stream, const int64_t* pos_indpt
     EL_REQUIRE(item_lo >= 0 && item_hi <= I && item_hi > item_lo, "el_bpr_sample: bad negative range");
     if (n <= 0) return 0;
     unsigned grid = (unsigned)((n + 255) / 256);
-    EL_LAUNCH("k_bpr_sample", k_bpr_sample, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos_indptr, pos_indices, U, I,
-                       item_lo, item_hi, (u64)seed, (u64)first_sample, n, out_u, out_i, out_j);
+    EL_LAUNCH("k_bpr_sample", k_bpr_sample<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos_indptr, pos_indices, U, I,
+                       item_lo, item_hi, (u64)seed, (u64)first_sample, n, out_u, out_i, out_j, (const SamplerRec*)nullptr);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t el_bpr_sampler_meta_bytes(int64_t U) { return U > 0 ? (size_t)U * sizeof(SamplerRec) : 0; }
+
+extern "C" int el_bpr_sampler_meta_build(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices,
+                                         int64_t U, void* meta) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(pos_indptr && pos_indices && meta && U >= 1, "el_bpr_sampler_meta_build: bad arguments");
+    EL_REQUIRE(((uintptr_t)meta & 63) == 0, "el_bpr_sampler_meta_build: meta must be 64-byte aligned");
+    EL_LAUNCH("k_bpr_sampler_meta", k_bpr_sampler_meta, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+              pos_indptr, pos_indices, U, (SamplerRec*)meta);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_bpr_sample_meta(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices, const void* meta,
+                                  int64_t U, int64_t I, int64_t item_lo, int64_t item_hi, uint64_t seed, uint64_t first_sample,
+                                  int64_t n, int32_t* out_u, int32_t* out_i, int32_t* out_j) {
+    if (meta == nullptr) return el_bpr_sample(ctx, stream, pos_indptr, pos_indices, U, I, item_lo, item_hi, seed, first_sample, n, out_u, out_i, out_j);
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(pos_indptr && pos_indices && out_u && out_i && out_j, "el_bpr_sample_meta: null pointer");
+    EL_REQUIRE(U >= 1 && U < 0xffffffffLL && I >= 2 && I < 0x7fffffffLL, "el_bpr_sample_meta: U/I out of range");
+    EL_REQUIRE(item_lo >= 0 && item_hi <= I && item_hi > item_lo, "el_bpr_sample_meta: bad negative range");
+    EL_REQUIRE(((uintptr_t)meta & 63) == 0, "el_bpr_sample_meta: meta must be 64-byte aligned");
+    if (n <= 0) return 0;
+    EL_LAUNCH("k_bpr_sample", k_bpr_sample<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_indptr,
+              pos_indices, U, I, item_lo, item_hi, (u64)seed, (u64)first_sample, n, out_u, out_i, out_j, (const SamplerRec*)meta);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -893,7 +973,7 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
                                    const int32_t* pos_indices, uint64_t seed, uint64_t first_sample, int64_t events,
                                    int64_t B, float lr, float l_w, float l_b, int opt, int32_t first_step,
                                    const float* lr_t_host, double* loss_out, int algo, void* ws, size_t ws_bytes,
-                                   void* loop_ws, size_t loop_ws_bytes) {
+                                   void* loop_ws, size_t loop_ws_bytes, const void* sampler_meta) {
     if (int rc = el_bind(ctx)) return rc;
     EL_REQUIRE(stp != nullptr && B >= 1 && events >= 0, "el_bprmf_train_loop: bad arguments");
     if (events == 0) return 0;
@@ -942,8 +1022,8 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
     int64_t k = 0;
     for (int64_t c0 = 0; c0 < events; c0 += cap) {
         const int64_t cn = (events - c0 < cap) ? events - c0 : cap;
-        if (int rc = el_bpr_sample(ctx, stream, pos_indptr, pos_indices, st.U, st.I, 0, st.I, seed, first_sample + (uint64_t)c0,
-                                   cn, bu, bi, bj))
+        if (int rc = el_bpr_sample_meta(ctx, stream, pos_indptr, pos_indices, sampler_meta, st.U, st.I, 0, st.I, seed,
+                                        first_sample + (uint64_t)c0, cn, bu, bi, bj))
             return rc;
         const int64_t csteps = (cn + B - 1) / B;
         if (use_graph) {

@@ -272,17 +272,37 @@ def rec_metrics(ctx, rec_idx, test, threshold, cutoff, u_start=0, sums=None, per
 # ------------------------------------------------------------------------------------------
 # sampler
 # ------------------------------------------------------------------------------------------
-def bpr_sample(ctx, pos, n, seed, first_sample=0, item_lo=0, item_hi=None, out=None):
-    """custom_sampler.Sampler.step (custom_sampler.py:31-46) on the device: n triplets."""
+def sampler_meta(ctx, pos):
+    """The sampler's per-user records of a positives CSR (el_bpr_sampler_meta_build), built once and cached on the CSR object:
+    row start, row length and a 384-bit membership signature in one 64-byte line per user."""
+    meta = getattr(pos, "_sampler_meta", None)
+    if meta is None:
+        nbytes = int(ctx.lib.el_bpr_sampler_meta_bytes(int(pos.n_rows)))
+        meta = torch.empty(nbytes + 64, dtype=torch.uint8, device=ctx.device)
+        off = (-meta.data_ptr()) % 64
+        meta = meta[off:off + nbytes]                                 # 64-byte aligned view
+        check(ctx.lib.el_bpr_sampler_meta_build(ctx.handle, ctx.stream(), *_csr_ptrs(pos), int(pos.n_rows),
+                                                C.c_void_p(meta.data_ptr())), "el_bpr_sampler_meta_build")
+        try:
+            pos._sampler_meta = meta
+        except Exception:
+            pass
+    return meta
+
+
+def bpr_sample(ctx, pos, n, seed, first_sample=0, item_lo=0, item_hi=None, out=None, use_meta=True):
+    """custom_sampler.Sampler.step (custom_sampler.py:31-46) on the device: n triplets.  use_meta: draw through the per-user
+    records (same triplets, fewer cache lines per draw); False = the plain CSR path."""
     U, I = pos.n_rows, pos.n_cols
     if item_hi is None:
         item_hi = I
     if out is None:
         out = tuple(torch.empty((n,), dtype=torch.int32, device=ctx.device) for _ in range(3))
-    check(ctx.lib.el_bpr_sample(ctx.handle, ctx.stream(), *_csr_ptrs(pos), int(U), int(I), int(item_lo), int(item_hi),
-                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample), int(n),
-                                _ptr(out[0], torch.int32), _ptr(out[1], torch.int32), _ptr(out[2], torch.int32)),
-          "el_bpr_sample")
+    meta = sampler_meta(ctx, pos) if use_meta else None
+    check(ctx.lib.el_bpr_sample_meta(ctx.handle, ctx.stream(), *_csr_ptrs(pos), C.c_void_p(meta.data_ptr()) if meta is not None else None,
+                                     int(U), int(I), int(item_lo), int(item_hi), int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample),
+                                     int(n), _ptr(out[0], torch.int32), _ptr(out[1], torch.int32), _ptr(out[2], torch.int32)),
+          "el_bpr_sample_meta")
     return out
 
 
@@ -494,7 +514,7 @@ class BprmfDeviceState:
             int(first_sample), int(events), int(B), float(lr), float(l_w), float(l_b), self.opt, int(self.step + 1),
             lr_t.ctypes.data_as(C.c_void_p), _ptr(self.loss, torch.float64), algo,
             C.c_void_p(self._ws.data_ptr()) if need else None, self._ws.numel() if need else 0,
-            C.c_void_p(buf.data_ptr()), lneed), "el_bprmf_train_loop")
+            C.c_void_p(buf.data_ptr()), lneed, C.c_void_p(sampler_meta(self.ctx, pos).data_ptr())), "el_bprmf_train_loop")
         self.step += steps
         return steps
 

@@ -360,3 +360,24 @@ def test_train_loop_equals_per_batch_calls(ctx, B, algo, exact, timed):
                 assert np.abs(x - y).max() < 1e-5, name
     with pytest.raises(ValueError):
         b.train_loop(ops.DeviceCSR(indptr[:11], indices[:indptr[10]], I, ctx.device), events, B, 7, 0, lr, l_w, l_b)
+
+
+def test_sampler_records_give_the_same_triplets(ctx):
+    """el_bpr_sample_meta (one 64-byte record per user: row start, length, 384-bit membership signature) == el_bpr_sample, bit
+    for bit, incl. heavy rows whose signature is full, rows of one item, the sharded negative range and the epoch loop."""
+    from elliot_amd.synthetic import zipf_csr
+    indptr, indices = zipf_csr(5000, 1200, mean_log=2.2, sigma_log=1.3, dmin=1, dmax=1100, seed=6)
+    pos = ops.DeviceCSR(indptr, indices, 1200, ctx.device)
+    for kw in (dict(), dict(item_lo=300, item_hi=900)):
+        a = ops.bpr_sample(ctx, pos, 200000, seed=11, first_sample=12345, use_meta=False, **kw)
+        b = ops.bpr_sample(ctx, pos, 200000, seed=11, first_sample=12345, use_meta=True, **kw)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    meta = ops.sampler_meta(ctx, pos)
+    assert meta.data_ptr() % 64 == 0 and meta.numel() == 64 * 5000
+    rec = meta.view(torch.int32).view(5000, 16).cpu().numpy()
+    assert np.array_equal(rec[:, 2], np.diff(indptr))                      # row lengths
+    lo = rec[:, 0].astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(lo | (rec[:, 1].astype(np.int64) << 32), indptr[:-1])
+    bits = np.unpackbits(rec[:, 4:].copy().view(np.uint8), axis=1, bitorder="little").sum(1)
+    assert (bits <= np.minimum(np.diff(indptr), 384)).all() and bits[np.diff(indptr) > 0].min() >= 1
