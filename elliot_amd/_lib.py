@@ -144,6 +144,8 @@ PROTOTYPES = {
                                C.c_float, C.c_float, C.c_uint64, C.c_int32, _f64p]),
     "el_vae_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(VaeState), C.c_float]),
     "el_vae_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(VaeState), _i64p, _i32p, _i32p, C.c_int64, _f32p]),
+    "el_pointwise_sample_meta": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
+                                           C.c_uint64, C.c_int64, _i32p, _i32p, _f32p]),
     "el_pointwise_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
                                       C.c_int64, _i32p, _i32p, _f32p]),
     "el_nmf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, C.c_int64, _f32p]),

@@ -61,15 +61,6 @@ struct PhiloxStream {
 // line -- row start, row length and a 384-bit membership signature of the row.  A negative candidate whose signature bit is
 // clear is certainly not a positive (the usual case: rows fill ~18 % of the bits), so the binary search over the row -- three
 // more cache lines per triplet -- only runs on a signature hit.  Accept / reject decisions are those of the plain path.
-struct __attribute__((aligned(64))) SamplerRec {
-    int64_t r0;
-    int32_t len;
-    u32 pad;
-    u32 sig[12];
-};
-#define EL_SIG_BITS 384u
-__device__ __forceinline__ u32 el_sig_bit(int32_t item) { return ((u32)item * 0x9E3779B1u) % EL_SIG_BITS; }
-
 __global__ __launch_bounds__(256) void k_bpr_sampler_meta(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                           int64_t U, SamplerRec* __restrict__ meta) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,13 +93,10 @@ __global__ __launch_bounds__(256) void k_bpr_sample(const int64_t* __restrict__ 
     for (;;) {
         u32 u = ps.bounded((u32)U);
         int64_t r0, r1;
-        uint4 sg[3];
+        SamplerUser su;
         if (META) {
-            const uint4* rec = reinterpret_cast<const uint4*>(meta + u);
-            const uint4 h = rec[0];
-            sg[0] = rec[1], sg[1] = rec[2], sg[2] = rec[3];
-            r0 = (int64_t)(((u64)h.y << 32) | (u64)h.x);
-            r1 = r0 + (int64_t)(int32_t)h.z;
+            su.load(meta, u);
+            r0 = su.r0, r1 = su.r1;
         } else {
             r0 = indptr[u];
             r1 = indptr[u + 1];
@@ -120,13 +108,7 @@ __global__ __launch_bounds__(256) void k_bpr_sample(const int64_t* __restrict__ 
         int32_t jt = -1;
         for (int attempt = 0; attempt < 4096; ++attempt) {
             int32_t cand = (int32_t)(item_lo + (int64_t)ps.bounded(range));
-            bool maybe = true;
-            if (META) {
-                const u32 b = el_sig_bit(cand), w = b >> 5;
-                const uint4 q = w < 4 ? sg[0] : (w < 8 ? sg[1] : sg[2]);
-                const u32 word = (w & 3u) == 0 ? q.x : ((w & 3u) == 1 ? q.y : ((w & 3u) == 2 ? q.z : q.w));
-                maybe = ((word >> (b & 31u)) & 1u) != 0u;
-            }
+            const bool maybe = META ? su.maybe(cand) : true;
             if (!maybe || !el_row_contains(indices, r0, r1, cand)) {
                 jt = cand;
                 break;

@@ -221,3 +221,32 @@ __host__ __device__ inline el_philox4 el_philox4x32_10(u32 c0, u32 c1, u32 c2, u
     el_philox4 o = {c0, c1, c2, c3};
     return o;
 }
+
+// ---- per-user record of the samplers (el_bpr_sampler_meta_build) -------------------------------------------------------
+struct __attribute__((aligned(64))) SamplerRec {
+    int64_t r0;      // row start in the positives CSR
+    int32_t len;     // row length
+    u32 pad;
+    u32 sig[12];     // 384-bit membership signature of the row
+};
+#define EL_SIG_BITS 384u
+__device__ __forceinline__ u32 el_sig_bit(int32_t item) { return ((u32)item * 0x9E3779B1u) % EL_SIG_BITS; }
+
+// the user's record in one 64-byte read; -> row bounds; sig_maybe(cand): false = certainly not in the row
+struct SamplerUser {
+    int64_t r0, r1;
+    uint4 sg[3];
+    __device__ __forceinline__ void load(const SamplerRec* __restrict__ meta, u32 u) {
+        const uint4* rec = reinterpret_cast<const uint4*>(meta + u);
+        const uint4 h = rec[0];
+        sg[0] = rec[1], sg[1] = rec[2], sg[2] = rec[3];
+        r0 = (int64_t)(((u64)h.y << 32) | (u64)h.x);
+        r1 = r0 + (int64_t)(int32_t)h.z;
+    }
+    __device__ __forceinline__ bool maybe(int32_t cand) const {
+        const u32 b = el_sig_bit(cand), w = b >> 5;
+        const uint4 q = w < 4 ? sg[0] : (w < 8 ? sg[1] : sg[2]);
+        const u32 word = (w & 3u) == 0 ? q.x : ((w & 3u) == 1 ? q.y : ((w & 3u) == 2 ? q.z : q.w));
+        return ((word >> (b & 31u)) & 1u) != 0u;
+    }
+};

@@ -67,16 +67,25 @@ struct PwPhilox {
 
 // u ~ U[0,U); coin; positive: i ~ U(pos(u)), label 1; negative: i ~ U[0,I) \ pos(u), label 0
 // (pointwise_pos_neg_sampler.py:33-46)
+template <bool META>
 __global__ __launch_bounds__(256) void k_pw_sample(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                    int64_t U, int64_t I, u64 seed, u64 first, int64_t n, int32_t* out_u,
-                                                   int32_t* out_i, float* out_y) {
+                                                   int32_t* out_i, float* out_y, const SamplerRec* __restrict__ meta) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     PwPhilox ps;
     ps.init(first + (u64)t, seed);
     for (;;) {
         u32 u = ps.bounded((u32)U);
-        int64_t r0 = indptr[u], r1 = indptr[u + 1];
+        int64_t r0, r1;
+        SamplerUser su;
+        if (META) {
+            su.load(meta, u);                                 // one 64-byte record: row bounds + membership signature
+            r0 = su.r0, r1 = su.r1;
+        } else {
+            r0 = indptr[u];
+            r1 = indptr[u + 1];
+        }
         int64_t lui = r1 - r0;
         if (lui <= 0 || lui >= I) continue;
         u32 coin = ps.next() >> 31;                       // random.getrandbits(1)
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pw_sample(const int64_t* __restrict__ i
         } else {
             for (int attempt = 0; attempt < 4096 && it < 0; ++attempt) {
                 int32_t cand = (int32_t)ps.bounded((u32)I);
-                if (!el_row_contains(indices, r0, r1, cand)) it = cand;
+                if ((META && !su.maybe(cand)) || !el_row_contains(indices, r0, r1, cand)) it = cand;
             }
             if (it < 0) continue;
         }
@@ -104,8 +113,23 @@ extern "C" int el_pointwise_sample(el_ctx* ctx, void* stream, const int64_t* pos
     EL_REQUIRE(pos_indptr && pos_indices && out_u && out_i && out_label, "el_pointwise_sample: null pointer");
     EL_REQUIRE(U >= 1 && U < 0xffffffffLL && I >= 2 && I < 0x7fffffffLL, "el_pointwise_sample: U/I out of range");
     if (n <= 0) return 0;
-    EL_LAUNCH("k_pw_sample", k_pw_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_indptr,
-              pos_indices, U, I, (u64)seed, (u64)first_sample, n, out_u, out_i, out_label);
+    EL_LAUNCH("k_pw_sample", k_pw_sample<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_indptr,
+              pos_indices, U, I, (u64)seed, (u64)first_sample, n, out_u, out_i, out_label, (const SamplerRec*)nullptr);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_pointwise_sample_meta(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices,
+                                        const void* meta, int64_t U, int64_t I, uint64_t seed, uint64_t first_sample, int64_t n,
+                                        int32_t* out_u, int32_t* out_i, float* out_label) {
+    if (meta == nullptr) return el_pointwise_sample(ctx, stream, pos_indptr, pos_indices, U, I, seed, first_sample, n, out_u, out_i, out_label);
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(pos_indptr && pos_indices && out_u && out_i && out_label, "el_pointwise_sample_meta: null pointer");
+    EL_REQUIRE(U >= 1 && U < 0xffffffffLL && I >= 2 && I < 0x7fffffffLL, "el_pointwise_sample_meta: U/I out of range");
+    EL_REQUIRE(((uintptr_t)meta & 63) == 0, "el_pointwise_sample_meta: meta must be 64-byte aligned");
+    if (n <= 0) return 0;
+    EL_LAUNCH("k_pw_sample", k_pw_sample<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_indptr,
+              pos_indices, U, I, (u64)seed, (u64)first_sample, n, out_u, out_i, out_label, (const SamplerRec*)meta);
     EL_CHECK_LAUNCH();
     return 0;
 }

@@ -710,14 +710,17 @@ class VaeDeviceState:
 # ------------------------------------------------------------------------------------------
 # NeuMF / GMF
 # ------------------------------------------------------------------------------------------
-def pointwise_sample(ctx, pos, n, seed, first_sample=0):
-    """pointwise_pos_neg_sampler.Sampler.step (pointwise_pos_neg_sampler.py:26-50) on the device."""
+def pointwise_sample(ctx, pos, n, seed, first_sample=0, use_meta=True):
+    """pointwise_pos_neg_sampler.Sampler.step (pointwise_pos_neg_sampler.py:26-50) on the device (use_meta: through the per-user
+    sampler records -- same draws, fewer cache lines)."""
     u = torch.empty(n, dtype=torch.int32, device=ctx.device)
     i = torch.empty(n, dtype=torch.int32, device=ctx.device)
     y = torch.empty(n, dtype=torch.float32, device=ctx.device)
-    check(ctx.lib.el_pointwise_sample(ctx.handle, ctx.stream(), *_csr_ptrs(pos), int(pos.n_rows), int(pos.n_cols),
-                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample), int(n), _ptr(u), _ptr(i), _ptr(y)),
-          "el_pointwise_sample")
+    meta = sampler_meta(ctx, pos) if use_meta else None
+    check(ctx.lib.el_pointwise_sample_meta(ctx.handle, ctx.stream(), *_csr_ptrs(pos),
+                                           C.c_void_p(meta.data_ptr()) if meta is not None else None, int(pos.n_rows),
+                                           int(pos.n_cols), int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample), int(n), _ptr(u),
+                                           _ptr(i), _ptr(y)), "el_pointwise_sample_meta")
     return u, i, y
 
 

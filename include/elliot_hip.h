@@ -406,6 +406,11 @@ int el_pointwise_sample(el_ctx* ctx, void* stream, const int64_t* pos_indptr, co
                         int64_t U, int64_t I, uint64_t seed, uint64_t first_sample, int64_t n,
                         int32_t* out_u, int32_t* out_i, float* out_label);
 
+/* The same draws through the per-user sampler records (el_bpr_sampler_meta_build); meta == NULL is el_pointwise_sample. */
+int el_pointwise_sample_meta(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices, const void* meta,
+                             int64_t U, int64_t I, uint64_t seed, uint64_t first_sample, int64_t n,
+                             int32_t* out_u, int32_t* out_i, float* out_label);
+
 /* Replaces: NeuralMatrixFactorizationModel.get_recs / GeneralizedMatrixFactorizationModel.get_recs on an
  * explicit pair list (neural_matrix_factorization_model.py:120-144): out_prob[b] = sigmoid(...) of (u[b], i[b]). */
 int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,

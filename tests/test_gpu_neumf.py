@@ -152,3 +152,12 @@ def test_neumf_dropout_matches_oracle_with_the_same_masks(ctx, rate):
     p = cpu(st.forward(torch.from_numpy(u).to(d), torch.from_numpy(i).to(d)))
     ref = on.forward(st.weights(), u.astype(np.int64), i.astype(np.int64), dtype=np.float64)["p"]
     assert np.abs(p - ref).max() < 1e-5
+
+
+def test_pointwise_sampler_records_give_the_same_samples(ctx):
+    indptr, indices = zipf_csr(4000, 900, mean_log=2.2, sigma_log=1.2, dmin=1, dmax=850, seed=3)
+    pos = ops.DeviceCSR(indptr, indices, 900, ctx.device)
+    a = ops.pointwise_sample(ctx, pos, 150000, seed=5, first_sample=777, use_meta=False)
+    b = ops.pointwise_sample(ctx, pos, 150000, seed=5, first_sample=777, use_meta=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
