@@ -363,17 +363,23 @@ class ShardedBprmfByUser:
         self.backend = backend
         self.coll = coll or _Collectives()
 
-    def train_step(self, u_local, i, j, lr, l_w, l_b):
+    def train_step(self, u_local, i, j, lr, l_w, l_b, overlap=None):
+        """overlap: optional callable enqueuing model-independent work (drawing the NEXT batch) while the collective is in
+        flight -- it is called after the all-reduce was issued and before its result is waited for."""
         be, coll = self.backend, self.coll
         be.grads(u_local, i, j, l_w, l_b)
         if not hasattr(be, "apply_users"):                      # test backends: plain order
             for g in be.item_grads():
                 coll.all_reduce_sum(g)
             be.apply(lr)
+            if overlap is not None:
+                overlap()
             return
         works = [coll.all_reduce_sum(g, async_op=True) for g in be.item_grads()]
         be.begin_step()
         be.apply_users(lr)                                      # the rank's own rows: runs under the all-reduce
+        if overlap is not None:
+            overlap()                                           # ... and so does whatever does not read the model
         for w in works:
             if w is not None:
                 w.wait()
