@@ -235,20 +235,21 @@ def main():
         trainer = parallel.ShardedBprmfByUser(be, coll)
         st = be.state
         exchange_used[0] = "user"
-        # the triplets of step t+1 are drawn while step t's all-reduce is in flight (the sampler does not read the model):
+        # the triplets of step t+1 are drawn AND sorted while step t's all-reduce is in flight (neither reads the model):
         # queued after the collective was issued, before its result is waited for
         drawn = [0]
 
         def draw():
             t = ops.bpr_sample(ctx, pos_train, B, seed=42 + rank, first_sample=drawn[0])
             drawn[0] += B
+            be.presort(*t)                                           # ... and ordered (prep + radix sort read only the triplets)
             return t
 
         nxt = [draw()]
 
         def train_step():
             t = nxt[0]
-            trainer.train_step(t[0], t[1], t[2], lr, l_w, l_b, overlap=lambda: nxt.__setitem__(0, draw()))
+            trainer.train_step(t[0], t[1], t[2], lr, l_w, l_b, overlap=lambda: nxt.__setitem__(0, draw()), presorted=True)
 
         pop_loss = trainer.pop_loss
     else:

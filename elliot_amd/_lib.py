@@ -113,6 +113,9 @@ PROTOTYPES = {
     "el_bprmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "el_bprmf_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
                                  C.c_float, C.c_float, C.c_int32, _f64p, C.c_void_p, C.c_size_t]),
+    "el_bprmf_grads_presorted": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
+                                 C.c_float, C.c_float, C.c_int32, _f64p, C.c_void_p, C.c_size_t]),
+    "el_bprmf_presort": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t]),
     "el_bprmf_shard_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
                                        C.c_float, C.c_float, C.c_int32, _f32p, _f64p, C.c_void_p, C.c_size_t]),
     "el_rows_segment_sum_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),

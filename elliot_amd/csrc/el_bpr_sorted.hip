@@ -493,7 +493,8 @@ extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_train_step_sorted: workspace too small (%zu < %zu)",
                ws_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
+    if (opt != -2)                                   // -2: el_bprmf_presort already ordered this batch in `ws`
+        if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
     SegParams base;
     memset(&base, 0, sizeof(base));
     base.st = st;
@@ -538,6 +539,24 @@ extern "C" int el_bprmf_grads(el_ctx* ctx, void* stream, const el_bprmf_state* s
                               const int32_t* j, int64_t B, float l_w, float l_b, int32_t step, double* loss_out, void* ws,
                               size_t ws_bytes) {
     return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -1, step, 0.f, loss_out, ws, ws_bytes);
+}
+
+// The sort of a batch reads nothing but the triplets, so a multi-GPU step can order the NEXT batch while its collective is in
+// flight: el_bprmf_presort fills `ws` (prep + the one radix sort), el_bprmf_grads_presorted runs the segment kernels on it.
+extern "C" int el_bprmf_presort(el_ctx* ctx, void* stream, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                                int64_t U, int64_t I, void* ws, size_t ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(u && i && j && B >= 1 && B < (1LL << 30) && U >= 1 && I >= 1, "el_bprmf_presort: bad arguments");
+    SortedWs w;
+    EL_REQUIRE(carve_ws(B, U, I, (char*)ws, &w) == 0, "el_bprmf_presort: rocprim size query failed");
+    EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_presort: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    return sort_batch((hipStream_t)stream, w, u, i, j, B, U, I);
+}
+
+extern "C" int el_bprmf_grads_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
+                                        const int32_t* j, int64_t B, float l_w, float l_b, int32_t step, double* loss_out,
+                                        void* ws, size_t ws_bytes) {
+    return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -2, step, 0.f, loss_out, ws, ws_bytes);
 }
 
 // =====================================================================================================

@@ -304,17 +304,31 @@ class HipUserShardBackend:
         self.state = ops.BprmfDeviceState(ctx, Gu_shard, Gi, Bi, optimizer="sgd_dense" if optimizer == "sgd" else optimizer)
         self._ws = None
 
-    def grads(self, u_local, i, j, l_w, l_b):
-        import ctypes as C
+    def _workspace(self, B):
         st, ctx = self.state, self.ctx
-        B = u_local.numel()
         need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
-        ops.check(ctx.lib.el_bprmf_grads(ctx.handle, ctx.stream(), C.byref(st._c), ops._ptr(u_local, torch.int32),
-                                         ops._ptr(i, torch.int32), ops._ptr(j, torch.int32), int(B), float(l_w), float(l_b),
-                                         int(st.step + 1), ops._ptr(st.loss, torch.float64), C.c_void_p(self._ws.data_ptr()),
-                                         self._ws.numel()), "el_bprmf_grads")
+
+    def presort(self, u_local, i, j):
+        """Order a batch for grads(..., presorted=True): reads only the triplets, so it can run under the previous step's
+        collective.  One workspace: the previous batch's segment kernels are done (stream order) before this overwrites it."""
+        import ctypes as C
+        st, ctx = self.state, self.ctx
+        self._workspace(u_local.numel())
+        ops.check(ctx.lib.el_bprmf_presort(ctx.handle, ctx.stream(), ops._ptr(u_local, torch.int32), ops._ptr(i, torch.int32),
+                                           ops._ptr(j, torch.int32), int(u_local.numel()), int(st.U), int(st.I),
+                                           C.c_void_p(self._ws.data_ptr()), self._ws.numel()), "el_bprmf_presort")
+
+    def grads(self, u_local, i, j, l_w, l_b, presorted=False):
+        import ctypes as C
+        st, ctx = self.state, self.ctx
+        B = u_local.numel()
+        self._workspace(B)
+        fn = ctx.lib.el_bprmf_grads_presorted if presorted else ctx.lib.el_bprmf_grads
+        ops.check(fn(ctx.handle, ctx.stream(), C.byref(st._c), ops._ptr(u_local, torch.int32), ops._ptr(i, torch.int32),
+                     ops._ptr(j, torch.int32), int(B), float(l_w), float(l_b), int(st.step + 1), ops._ptr(st.loss, torch.float64),
+                     C.c_void_p(self._ws.data_ptr()), self._ws.numel()), "el_bprmf_grads")
 
     def item_grads(self):
         return [self.state.item_grad_flat]                    # gGi rows + gBi in one buffer: one collective per step
@@ -363,11 +377,15 @@ class ShardedBprmfByUser:
         self.backend = backend
         self.coll = coll or _Collectives()
 
-    def train_step(self, u_local, i, j, lr, l_w, l_b, overlap=None):
-        """overlap: optional callable enqueuing model-independent work (drawing the NEXT batch) while the collective is in
-        flight -- it is called after the all-reduce was issued and before its result is waited for."""
+    def train_step(self, u_local, i, j, lr, l_w, l_b, overlap=None, presorted=False):
+        """overlap: optional callable enqueuing model-independent work (drawing AND ordering the NEXT batch: backend.presort)
+        while the collective is in flight -- it is called after the all-reduce was issued and before its result is waited for.
+        presorted: this batch was ordered by backend.presort already."""
         be, coll = self.backend, self.coll
-        be.grads(u_local, i, j, l_w, l_b)
+        if presorted:
+            be.grads(u_local, i, j, l_w, l_b, presorted=True)
+        else:
+            be.grads(u_local, i, j, l_w, l_b)
         if not hasattr(be, "apply_users"):                      # test backends: plain order
             for g in be.item_grads():
                 coll.all_reduce_sum(g)

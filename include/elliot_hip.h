@@ -193,6 +193,15 @@ int el_bprmf_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                    const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                    float l_w, float l_b, int32_t step, double* loss_out, void* ws, size_t ws_bytes);
 
+/* el_bprmf_grads in two halves: ordering a batch reads only its triplets, so a multi-GPU step can do it for the NEXT batch
+ * while the item-gradient all-reduce is in flight.  el_bprmf_presort fills ws (el_bprmf_ws_bytes(B, U, I)) with the sorted
+ * (row, triplet) pairs of (u, i, j); el_bprmf_grads_presorted is el_bprmf_grads on the same triplets and the same ws.     */
+int el_bprmf_presort(el_ctx* ctx, void* stream, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                     int64_t U, int64_t I, void* ws, size_t ws_bytes);
+int el_bprmf_grads_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* st,
+                             const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                             float l_w, float l_b, int32_t step, double* loss_out, void* ws, size_t ws_bytes);
+
 /* Step 4: optimiser alone on (Gu, local Gi, local Bi); opt = EL_OPT_ADAM_TF_DENSE or EL_OPT_SGD.  */
 int el_bprmf_apply(el_ctx* ctx, void* stream, const el_bprmf_state* st, float lr, int opt, int32_t step, float lr_t);
 

@@ -381,3 +381,27 @@ def test_sampler_records_give_the_same_triplets(ctx):
     assert np.array_equal(lo | (rec[:, 1].astype(np.int64) << 32), indptr[:-1])
     bits = np.unpackbits(rec[:, 4:].copy().view(np.uint8), axis=1, bitorder="little").sum(1)
     assert (bits <= np.minimum(np.diff(indptr), 384)).all() and bits[np.diff(indptr) > 0].min() >= 1
+
+
+def test_presorted_gradients_equal_the_one_call_form(ctx):
+    """el_bprmf_presort + el_bprmf_grads_presorted == el_bprmf_grads (the split lets a multi-GPU step order the next batch under
+    its collective); the workspace is reused batch after batch."""
+    from elliot_amd import parallel
+    rs = np.random.RandomState(44)
+    U, I, F, B = 900, 500, 32, 5000
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    a = parallel.HipUserShardBackend(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    b = parallel.HipUserShardBackend(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    d = ctx.device
+    for step in range(3):
+        u, i, j = (torch.from_numpy(x.astype(np.int32)).to(d) for x in (rs.randint(0, U, B), rs.randint(0, 30, B), rs.randint(0, I, B)))
+        a.grads(u, i, j, 0.1, 0.001)
+        b.presort(u, i, j)
+        b.grads(u, i, j, 0.1, 0.001, presorted=True)
+        for name in ("gGu", "gGi", "gBi"):
+            x, y = cpu(getattr(a.state, name)), cpu(getattr(b.state, name))
+            assert np.abs(x - y).max() <= 1e-6 * max(1.0, np.abs(x).max()), (step, name)       # hot rows: atomics order only
+        assert abs(a.state.pop_loss() - b.state.pop_loss()) < 1e-6
+        a.apply(0.01)
+        b.apply(0.01)
+    assert np.abs(cpu(a.state.Gi) - cpu(b.state.Gi)).max() < 1e-6
