@@ -178,6 +178,10 @@ PROTOTYPES = {
     "el_pwmf_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, _f32p, C.c_int64, C.c_int64, C.c_int,
                                 _f64p, C.c_void_p, C.c_size_t]),
     "el_pwmf_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), C.c_int, C.c_int, C.c_int32, C.c_float]),
+    "el_pwmf_train_loop_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "el_pwmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i64p, _i32p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                     C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int32, C.c_void_p, _f64p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_size_t]),
     "el_pwmf_link_values": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int32, C.c_int, _f32p,
                                       C.c_int64]),
     "el_dense_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

@@ -569,3 +569,55 @@ extern "C" int el_topk_rerank(el_ctx* ctx, void* stream, int32_t* idx, float* va
     EL_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The epoch loop of the point-wise plugins (matrix_factorization.py:85-97 and siblings) from one call, as el_bprmf_train_loop does
+// for BPRMF_batch: the samples of up to PW_LOOP_CHUNK draws come from ONE sampler launch (the sampler does not read the model),
+// the batches are consecutive slices of it.  Same Philox stream and kernels as the per-batch calls.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int el_pointwise_sample_meta(el_ctx* ctx, void* stream, const int64_t* pos_indptr, const int32_t* pos_indices,
+                                        const void* meta, int64_t U, int64_t I, uint64_t seed, uint64_t first_sample, int64_t n,
+                                        int32_t* out_u, int32_t* out_i, float* out_label);
+
+static const int64_t PW_LOOP_CHUNK = 4 << 20;
+
+static int64_t pw_loop_cap(int64_t events, int64_t B) {
+    int64_t most = (PW_LOOP_CHUNK / B) * B;
+    if (most < B) most = B;
+    const int64_t want = ((events + B - 1) / B) * B;
+    return want < most ? (want < B ? B : want) : most;
+}
+
+extern "C" size_t el_pwmf_train_loop_ws_bytes(int64_t events, int64_t B) {
+    if (events <= 0 || B <= 0) return 0;
+    return align256((size_t)pw_loop_cap(events, B) * 12);
+}
+
+extern "C" int el_pwmf_train_loop(el_ctx* ctx, void* stream, const el_pwmf_state* stp, const int64_t* pos_indptr,
+                                  const int32_t* pos_indices, const void* sampler_meta, uint64_t seed, uint64_t first_sample,
+                                  int64_t events, int64_t B, int opt, int side, int32_t first_step, const float* lr_t_host,
+                                  double* loss_out, void* ws, size_t ws_bytes, void* loop_ws, size_t loop_ws_bytes) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(stp != nullptr && B >= 1 && events >= 0 && lr_t_host != nullptr, "el_pwmf_train_loop: bad arguments");
+    if (events == 0) return 0;
+    const size_t need = el_pwmf_train_loop_ws_bytes(events, B);
+    EL_REQUIRE(loop_ws != nullptr && loop_ws_bytes >= need, "el_pwmf_train_loop: loop workspace too small (%zu < %zu)", loop_ws_bytes, need);
+    const int64_t cap = pw_loop_cap(events, B);
+    int32_t* bu = (int32_t*)loop_ws;
+    int32_t* bi = bu + cap;
+    float* by = (float*)(bu + 2 * cap);
+    int64_t k = 0;
+    for (int64_t c0 = 0; c0 < events; c0 += cap) {
+        const int64_t cn = (events - c0 < cap) ? events - c0 : cap;
+        if (int rc = el_pointwise_sample_meta(ctx, stream, pos_indptr, pos_indices, sampler_meta, stp->U, stp->I, seed,
+                                              first_sample + (uint64_t)c0, cn, bu, bi, by))
+            return rc;
+        for (int64_t off = 0; off < cn; off += B, ++k) {
+            const int64_t n = (cn - off < B) ? cn - off : B;
+            if (int rc = el_pwmf_train_step(ctx, stream, stp, bu + off, bi + off, by + off, n, opt, side, first_step + (int32_t)k,
+                                            lr_t_host[k], loss_out, ws, ws_bytes))
+                return rc;
+        }
+    }
+    return 0;
+}

@@ -935,6 +935,30 @@ class PwmfDeviceState:
                                               PW_OPTS[self.optimizer], PW_SIDES[side], int(self.step), float(lr_t),
                                               _ptr(self.loss, torch.float64), ws, need), "el_pwmf_train_step")
 
+    def train_loop(self, pos, events, B, seed, first_sample, lr, side="both"):
+        """One sampler pass of an epoch -- `for batch in sampler.step(events, B): train_step(batch)` -- from a single library
+        call (el_pwmf_train_loop): the same Philox stream and kernels as the per-batch calls, no host work in between."""
+        steps = (int(events) + int(B) - 1) // int(B)
+        if steps == 0:
+            return 0
+        if pos.n_rows != self.U or pos.n_cols != self.I:
+            raise ValueError("train_loop: the positives' CSR must describe this state's users x items")
+        adam = self.optimizer == "adam"
+        lr_t = np.array([adam_lr_t(lr, self.step + 1 + k) if adam else lr for k in range(steps)], dtype=np.float32)
+        ws, need = self._workspace(min(int(B), int(events)) if events < B else int(B))
+        lneed = int(self.ctx.lib.el_pwmf_train_loop_ws_bytes(int(events), int(B)))
+        buf = getattr(self, "_loop_ws", None)
+        if buf is None or buf.numel() < lneed:
+            buf = self._loop_ws = torch.empty(lneed, dtype=torch.uint8, device=self.ctx.device)
+        self._margin = _PW_MARGIN
+        check(self.ctx.lib.el_pwmf_train_loop(
+            self.ctx.handle, self.ctx.stream(), C.byref(self._c), *_csr_ptrs(pos), C.c_void_p(sampler_meta(self.ctx, pos).data_ptr()),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_sample), int(events), int(B), PW_OPTS[self.optimizer], PW_SIDES[side],
+            int(self.step + 1), lr_t.ctypes.data_as(C.c_void_p), _ptr(self.loss, torch.float64), ws, need,
+            C.c_void_p(buf.data_ptr()), lneed), "el_pwmf_train_loop")
+        self.step += steps
+        return steps
+
     def grads(self, u, i, label, n_global=None, side="both"):
         """Forward + loss + gradient sums only (multi-GPU: a batch-mean loss runs over n_global samples); the accumulators of
         `side` are complete on return -- item_grads() lists the replicated ones a data-parallel caller all-reduces."""

@@ -36,11 +36,15 @@ class LogisticMatrixFactorization(PointwisePluginMixin, RecMixin, BaseRecommende
         if self._restore:
             return self.restore_weights()
         events, bs = self._data.transactions, self._batch_size
+        fused = getattr(self._sampler, "philox", False) and getattr(self._config, "fused_epoch", True) and not self._verbose
         for it in self.iterate(self._epochs):
             epoch_loss = 0
             with tqdm(total=int(events * 2 // bs), disable=not self._verbose) as bar:
                 for update_users in (False, True):
                     self._model.set_update_user(update_users)
+                    if fused:                                         # the same pass inside the library
+                        epoch_loss = self._model.train_epoch(self._sampler, events, bs)
+                        continue
                     for batch in self._sampler.step(events, bs):
                         epoch_loss += self._model.train_step(batch)
                         bar.update()

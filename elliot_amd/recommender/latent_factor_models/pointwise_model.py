@@ -49,6 +49,12 @@ class PointwiseFactorModel:
         self.state.train_step(self._idx(user), self._idx(item), y, self._lr, side=self._side)
         return DeferredLoss(self.state)
 
+    def train_epoch(self, sampler, events, batch_size):
+        """One sampler pass `for batch in sampler.step(events, batch_size): train_step(batch)` in one library call."""
+        first = sampler.advance(events)
+        self.state.train_loop(sampler.pos, events, batch_size, sampler.seed, first, self._lr, side=self._side)
+        return DeferredLoss(self.state)
+
     def predict(self, inputs, training=False, **kwargs):
         user, item = inputs
         shape = tuple(user.shape) if isinstance(user, torch.Tensor) else tuple(np.shape(user))

@@ -498,6 +498,17 @@ int el_pwmf_grads(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int3
                   const float* label, int64_t n, int64_t n_global, int side, double* loss_out, void* ws, size_t ws_bytes);
 int el_pwmf_apply(el_ctx* ctx, void* stream, const el_pwmf_state* st, int opt, int side, int32_t step, float lr_t);
 
+/* Replaces: one sampler pass of a point-wise plugin's epoch (matrix_factorization.py:85-97: `for batch in sampler.step(events,
+ * B): loss += model.train_step(batch)`) from ONE call, as el_bprmf_train_loop does for BPRMF_batch: el_pointwise_sample_meta
+ * (first_sample + start; up to 4 M draws per launch, sampler_meta may be NULL) + el_pwmf_train_step per batch.
+ *   lr_t_host[k]: step size of batch k (Adam: bias-corrected; Adagrad: lr); first_step: optimiser iteration of batch 0
+ *   ws: el_pwmf_ws_bytes(B, U, I); loop_ws: el_pwmf_train_loop_ws_bytes(events, B).                                        */
+size_t el_pwmf_train_loop_ws_bytes(int64_t events, int64_t B);
+int el_pwmf_train_loop(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int64_t* pos_indptr, const int32_t* pos_indices,
+                       const void* sampler_meta, uint64_t seed, uint64_t first_sample, int64_t events, int64_t B, int opt, int side,
+                       int32_t first_step, const float* lr_t_host, double* loss_out, void* ws, size_t ws_bytes,
+                       void* loop_ws, size_t loop_ws_bytes);
+
 /* Turn the top-k values of el_score_topk (Bi[i] + <Gu[u],Gi[i]>) into the model's scores, in place:
  * vals[r, c] <- link(vals[r, c] + Bu[u_start + r]) (Bu may be NULL; -inf padding stays -inf).  The link is monotone,
  * so the ranking can only change where distinct inputs collapse to one float -- the host re-ranks those (ops.py). */

@@ -282,3 +282,32 @@ def test_user_sharded_hip_path_equals_concatenated_batch(ctx, model):
                 t = getattr(st, g)
                 assert t is None or not bool(t.any()), (model, step, g)
         assert sts[0].step == sts[1].step == step + 1
+
+
+@pytest.mark.parametrize("model,B", [("FunkSVD", 512), ("PMF", 4096), ("LogisticMF", 700)])
+def test_train_loop_equals_per_batch_calls(ctx, model, B):
+    """el_pwmf_train_loop = pointwise sampler + train_step per batch (same Philox offsets, same kernels, short last batch)."""
+    from elliot_amd.synthetic import zipf_csr
+    rs = np.random.RandomState(12)
+    U, I, F = 2500, 700, 16
+    indptr, indices = zipf_csr(U, I, mean_log=2.0, sigma_log=0.6, dmin=1, dmax=60, seed=3)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    w = weights(rs, U, I, F, MODELS[model][1])
+    a, _ = make(ctx, w, model)
+    b, _ = make(ctx, w, model)
+    events, lr = 4 * B + B // 3, 0.01
+    sides = ("items", "users") if model == "LogisticMF" else ("both",)
+    first = 500
+    for side in sides:
+        for start in range(0, events, B):
+            n = min(B, events - start)
+            u, i, y = ops.pointwise_sample(ctx, pos, n, seed=9, first_sample=first + start)
+            a.train_step(u, i, y, lr, side=side)
+        assert b.train_loop(pos, events, B, 9, first, lr, side=side) == 5
+        first += events
+    assert a.step == b.step
+    la, lb = a.pop_loss(), b.pop_loss()
+    assert abs(la - lb) <= 1e-8 * abs(la), (la, lb)
+    wa, wb = a.weights(), b.weights()
+    for k in ("Gu", "Gi") + (("Bu", "Bi") if MODELS[model][1] else ()):
+        assert np.abs(wa[k] - wb[k]).max() < 1e-6, k
