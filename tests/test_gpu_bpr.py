@@ -400,8 +400,9 @@ def test_presorted_gradients_equal_the_one_call_form(ctx):
         b.grads(u, i, j, 0.1, 0.001, presorted=True)
         for name in ("gGu", "gGi", "gBi"):
             x, y = cpu(getattr(a.state, name)), cpu(getattr(b.state, name))
-            assert np.abs(x - y).max() <= 1e-6 * max(1.0, np.abs(x).max()), (step, name)       # hot rows: atomics order only
-        assert abs(a.state.pop_loss() - b.state.pop_loss()) < 1e-6
+            assert np.abs(x - y).max() <= 1e-5 * max(1.0, np.abs(x).max()), (step, name)       # hot rows: atomics order only
+        la, lb = a.state.pop_loss(), b.state.pop_loss()
+        assert abs(la - lb) <= 1e-8 * abs(la), (la, lb)
         a.apply(0.01)
         b.apply(0.01)
-    assert np.abs(cpu(a.state.Gi) - cpu(b.state.Gi)).max() < 1e-6
+    assert np.abs(cpu(a.state.Gi) - cpu(b.state.Gi)).max() < 1e-5
