@@ -1,21 +1,34 @@
 #!/usr/bin/env python
-"""bench.py -- BASELINE.json metric: BPR-MF positive-pairs/sec + full-catalog top-k users/sec.
+"""bench.py -- BASELINE.json metric: BPR-MF positive-pairs/sec + full-catalog top-k users/sec @1/2/4/8 GPU.
 
-One JSON line on rank 0.  N=1 workload = BASELINE.json configs[1]: BPRMF d=128 on synthetic
-1M users x 100K items (SURVEY.md 8d "S-1M"), inputs resident in HBM before the timed region.
+One JSON line on rank 0.
 
-  step (train) : sample B triplets on the device -> gather -> BPR loss -> Adam (TF-dense semantics, the
-                 reference's BPRMF_batch_model.train_step) for one batch of B = --batch triplets
-  step (top-k) : fused score + masked top-k for one block of --topk-block users against the full catalogue
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-`value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Both legs carry a
-roofline object for their dominant kernel (duration from hipEvents recorded inside the library on the
-launch stream).  `cpu_baseline` times the CPU oracle (a port of the reference path; /root/reference is
-absent on the GPU box) on a bounded sample, rank 0 / N=1 only.
+N = 1  workload = BASELINE.json configs[1]: BPRMF d=128 on synthetic 1M users x 100K items (SURVEY.md 8d "S-1M"),
+       inputs resident in HBM before the timed region.
+         step (train) : sample B triplets on the device -> gather -> BPR loss -> Adam (TF-dense semantics, the reference's
+                        BPRMF_batch_model.train_step) for one batch of B = --batch triplets
+         step (top-k) : fused score + masked top-k for one block of --topk-block users against the full catalogue
+       `value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Two secondary legs follow
+       (parity-test configurations of BASELINE.json, here with their own rooflines): "vae" = Mult-VAE at the ML-20M shape
+       (configs[2]), "neumf" = NeuMF d=128 at the per-GPU shape of configs[3] under user sharding.
+N > 1  one process per GPU.  `python bench.py --gpus N` launches itself under torch.distributed.run when WORLD_SIZE is not
+       set (the driver's own torchrun launch is honoured as is).  Primary leg: USER shards (the rank's user rows + a replica
+       of the item table, all-reduce of the item gradients, collective-free top-k).  Second leg "item_shard": north_star's
+       partitioning (item rows sharded, user-gradient exchange, all-gather + merge of partial top-k).  Each leg reports the
+       bytes and the time of its collectives.
+
+Both BPR legs carry a roofline object for their dominant kernel (duration from hipEvents recorded inside the library on the
+launch stream).  `cpu_baseline` times the CPU restatements (oracle/: ports of the reference path; /root/reference is absent on
+the GPU box) on a bounded sample, rank 0 / N=1 only.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,9 +37,6 @@ import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-
-from elliot_amd import ops, parallel  # noqa: E402
-from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
@@ -48,24 +58,55 @@ def parse():
     ap.add_argument("--train-algo", default="auto", choices=["auto", "atomic", "sorted"])
     ap.add_argument("--topk-algo", default="auto", choices=["auto", "screen", "mfma", "simple"])
     ap.add_argument("--shard", default="user", choices=["user", "item"],
-                    help="N > 1: shard the USER table (item table replicated, all-reduce of item gradients) or the ITEM table "
-                         "(north_star's formulation: user table replicated, user-gradient exchange per --exchange)")
+                    help="N > 1, primary leg: shard the USER table (item table replicated, all-reduce of item gradients) or the "
+                         "ITEM table (north_star's formulation: user table replicated, user-gradient exchange per --exchange)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "dense"],
-                    help="N > 1: how user-row gradients travel (parallel.pick_exchange)")
-    ap.add_argument("--topk-shard", default="user", choices=["user", "item"],
-                    help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial top-k")
+                    help="N > 1, item shards: how user-row gradients travel (parallel.pick_exchange)")
+    ap.add_argument("--topk-shard", default=None, choices=["user", "item"],
+                    help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial "
+                         "top-k (default: user for --shard user, item for the item-shard leg)")
+    ap.add_argument("--legs", default="auto",
+                    help="comma list of bpr,item_shard,vae,neumf,metrics (auto: N=1 -> bpr,metrics,vae,neumf; N>1 -> bpr,item_shard)")
     ap.add_argument("--prefetch", action="store_true",
                     help="draw the triplets of step t+1 on a side stream during step t (measured: no gain, the step is HBM-bound)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-topk-users", type=int, default=640)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget of each cpu_baseline measurement")
+    ap.add_argument("--vae-shape", default="138493,26744,600,200,512", help="users,items,hidden,latent,batch of the vae leg")
+    ap.add_argument("--neumf-shape", default="1250000,1000000,128,262144", help="users,items,factors,batch of the neumf leg")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 outside a torchrun environment: start N ranks (one per GPU, RCCL) and relay
+    rank 0's JSON line.  Refuses -- loudly, non-zero -- when the node has fewer than N GPUs instead of silently measuring one."""
+    shared = os.environ.get("EL_BENCH_SHARED_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not shared:
+        print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU "
+              f"number from fewer devices (EL_BENCH_SHARED_GPU=1 runs the control flow on one GPU over gloo for development)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC for RCCL (see the environment notes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -78,6 +119,8 @@ def dist_setup(args):
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = dist.get_backend()
+        world = dist.get_world_size()                       # what the process group observed, not what the flag claims
     elif args.force_sharded:
         # one rank, but through RCCL and the N > 1 code path: an API check of the collectives on a 1-GPU box
         import torch.distributed as dist
@@ -86,7 +129,8 @@ def dist_setup(args):
         os.environ["EL_FORCE_COLLECTIVES"] = "1"
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
-    return world, rank, local
+        backend = dist.get_backend()
+    return world, rank, local, backend
 
 
 class PrefetchSampler:
@@ -94,8 +138,9 @@ class PrefetchSampler:
     depend on the model, so a training loop can always run it one batch ahead.  Two triplet buffers, events both ways."""
 
     def __init__(self, ctx, pos, B, seed, enabled=True):
+        from elliot_amd import ops
         dev = ctx.device
-        self.ctx, self.pos, self.B, self.seed, self.enabled = ctx, pos, B, seed, enabled
+        self.ops, self.ctx, self.pos, self.B, self.seed, self.enabled = ops, ctx, pos, B, seed, enabled
         self.bufs = [tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3)) for _ in range(2)]
         self.side = torch.cuda.Stream(device=dev)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -105,7 +150,7 @@ class PrefetchSampler:
             self._issue(0)
 
     def _draw(self, b):
-        ops.bpr_sample(self.ctx, self.pos, self.B, seed=self.seed, first_sample=self.ctr, out=self.bufs[b])
+        self.ops.bpr_sample(self.ctx, self.pos, self.B, seed=self.seed, first_sample=self.ctr, out=self.bufs[b])
         self.ctr += self.B
 
     def _issue(self, b):
@@ -150,54 +195,150 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
+def timed(ctx, world, fn, warmup, steps, finish=None):
+    """W untimed calls, then exactly K calls between barrier + synchronize on both sides; max over ranks."""
+    for _ in range(warmup):
+        fn()
+    if finish:
+        finish()
+    barrier(world)
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if finish:
+        finish()                                                 # a collective still in flight belongs to the timed work
+    barrier(world)
+    dt = time.perf_counter() - t0
+    ctx.timing(False)
+    rep = ctx.timing_report()
+    return max_over_ranks(dt, world, ctx.device), rep
+
+
+def time_collective(world, dev, fn, reps=5):
+    """Wall time of one collective call (barrier-bracketed mean of `reps`, max over ranks), outside every timed region."""
+    fn()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    barrier(world)
+    return max_over_ranks((time.perf_counter() - t0) / reps, world, dev) * 1e3
+
+
+def dominant(rep):
+    name = max(rep, key=lambda n: rep[n][1])
+    return name, rep[name][1] / rep[name][0] * 1e-3   # seconds per launch
+
+
+def source_hash():
+    """Hash of the kernel sources: PMC traffic figures are only quoted for the code they were collected on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "elliot_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(U, I, F, B, Ub, world):
+    """HBM bytes per launch from the rocprofv3 PMC passes (scripts/collect_traffic.sh -> profiles/traffic.json).  Not measured
+    in this run: quoted only when the file was collected on THIS workload and THESE kernel sources, otherwise dropped (null)."""
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        c = tj["config"]
+        if (c["users"], c["items"], c["factors"], c["batch"], c["topk_block"]) != (U, I, F, B, Ub) or world != 1:
+            return {}, "profiles/traffic.json was collected on another workload"
+        if tj.get("source_hash") != source_hash():
+            return {}, f"profiles/traffic.json is stale (collected on kernel sources {tj.get('source_hash')}, commit {tj.get('commit')})"
+        return tj["bytes_per_launch"], f"rocprofv3 PMC passes at commit {tj.get('commit')} (scripts/collect_traffic.sh), same kernel sources"
+    except Exception as ex:  # noqa: BLE001
+        return {}, f"no traffic file ({type(ex).__name__})"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args, host):
-    """CPU oracle ("port") timed on this host: a bounded sample of the same workload."""
+    """The reference path on this host's cores, bounded samples of the same workload.
+    (1) "value": N-thread torch-CPU restatement of BPRMF_batch_model.train_step / predict + get_top_k (the reference's TF eager
+        path is BLAS + Eigen thread pools; TF 2.3.2 cannot be installed here) -- oracle/torch_cpu.py;
+    (2) "port_1core": the NumPy / plain-C oracles the parity tests check against, one core."""
     from oracle import bprmf_batch as ob
     from oracle import cref
-    out = {"kind": "port", "cores": 1}
-    # --- train: one TF-semantics step (NumPy fp32) at the GPU workload's shapes, smaller batch
-    Bc = min(args.batch, 1 << 16)
+    from oracle import torch_cpu as tc
+    cores = tc.use_all_cores()
+    budget = args.cpu_seconds
+    out = {"kind": "port", "cores": cores, "unit": "pairs/s"}
     rs = np.random.RandomState(0)
-    u = rs.randint(0, args.users, Bc)
-    i = rs.randint(0, args.items, Bc)
-    j = rs.randint(0, args.items, Bc)
+    B = args.batch
+    u = torch.from_numpy(rs.randint(0, args.users, B))
+    i = torch.from_numpy(rs.randint(0, args.items, B))
+    j = torch.from_numpy(rs.randint(0, args.items, B))
+    m = tc.BprmfBatchTorchCpu(host["Gu"], host["Gi"], host["Bi"], 0.001, 0.1, 0.001)
+    m.train_step(u, i, j)                                   # warm-up (page faults of the optimiser slots)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or time.perf_counter() - t0 < budget:
+        m.train_step(u, i, j)
+        n += 1
+    dt = time.perf_counter() - t0
+    out["value"] = B * n / dt
+    out["sample"] = (f"oracle/torch_cpu.py BprmfBatchTorchCpu.train_step (restatement of BPRMF_batch_model.py:58-80 with Keras dense "
+                     f"Adam; TF 2.3.2 not installable), {n} steps of B={B} on U={args.users}, I={args.items}, F={args.factors}, fp32, "
+                     f"{cores} torch threads; {dt:.2f}s")
+    del m
+    # top-k: matmul + where + top_k on blocks of 4096 users
+    Ub = 4096
+    Gu, Gi, Bi = (torch.from_numpy(host[k]) for k in ("Gu", "Gi", "Bi"))
+    indptr, indices = torch.from_numpy(host["indptr"]), torch.from_numpy(host["indices"]).to(torch.int64)
+    t0 = time.perf_counter()
+    nb = 0
+    while nb < 1 or (time.perf_counter() - t0 < budget and (nb + 1) * Ub <= args.users):
+        s = nb * Ub
+        e = min(s + Ub, args.users)
+        ip = indptr[s:e + 1] - indptr[s]
+        tc.predict_topk(Gu[s:e], Gi, Bi, ip, indices[int(indptr[s]):int(indptr[e])], args.k)
+        nb += 1
+    dt = time.perf_counter() - t0
+    nu_done = min(nb * Ub, args.users)
+    out["topk"] = {"value": nu_done / dt, "unit": "users/s", "cores": cores, "kind": "port",
+                   "sample": f"oracle/torch_cpu.py predict_topk (addmm + masked fill + torch.topk; BPRMF_batch_model.py:83-88), "
+                             f"{nu_done} users x {args.items} items in blocks of {Ub}, F={args.factors}, k={args.k}, {cores} threads; {dt:.2f}s"}
+    # ---- the parity oracles themselves, one core
+    p1 = {"cores": 1, "kind": "port"}
+    Bc = min(args.batch, 1 << 16)
+    un, inn, jn = (x[:Bc].numpy() for x in (u, i, j))
     orc = ob.BPRMFBatchOracle(host["Gu"], host["Gi"], host["Bi"], 0.001, 0.1, 0.001, optimizer=args.opt)
     t0 = time.perf_counter()
-    nsteps = 0
-    while time.perf_counter() - t0 < 10.0:                 # ~10 s of CPU work
-        orc.train_step((u, i, j))
-        nsteps += 1
+    n = 0
+    while n < 1 or time.perf_counter() - t0 < budget * 0.6:
+        orc.train_step((un, inn, jn))
+        n += 1
     dt = time.perf_counter() - t0
-    out["value"] = Bc * nsteps / dt
-    out["unit"] = "pairs/s"
-    out["sample"] = (f"oracle/bprmf_batch.py train_step ({args.opt}), {nsteps} steps, B={Bc}, U={args.users}, "
-                     f"I={args.items}, F={args.factors}, NumPy fp32 single thread; {dt:.2f}s")
-    # --- top-k: C oracle (fmaf chain + selection) on a few users against the full catalogue
+    p1["value"], p1["unit"] = Bc * n / dt, "pairs/s"
+    p1["sample"] = f"oracle/bprmf_batch.py train_step ({args.opt}), {n} steps, B={Bc}, NumPy fp32 single thread; {dt:.2f}s"
     nu = args.cpu_topk_users
     t0 = time.perf_counter()
     cref.score_topk_f32(host["Gu"][:nu], host["Gi"], host["Bi"], 0, nu, args.k,
                         excl=(host["indptr"][:nu + 1], host["indices"][:int(host["indptr"][nu])]))
     dt = time.perf_counter() - t0
-    out["topk"] = {"value": nu / dt, "unit": "users/s", "cores": 1, "kind": "port",
-                   "sample": f"oracle/c/el_oracle.c orc_score_topk_f32, {nu} users x {args.items} items, F={args.factors}, "
-                             f"k={args.k}; {dt:.2f}s"}
+    p1["topk"] = {"value": nu / dt, "unit": "users/s",
+                  "sample": f"oracle/c/el_oracle.c orc_score_topk_f32 (fmaf chain, the bit-exact checker), {nu} users x {args.items} items; {dt:.2f}s"}
+    out["port_1core"] = p1
     return out
 
 
-def main():
-    args = parse()
-    world, rank, local = dist_setup(args)
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    ctx = ops.get_context(local)
+# ---------------------------------------------------------------------------------------------------------------------
+# BPR-MF leg (train + top-k), any sharding
+# ---------------------------------------------------------------------------------------------------------------------
+def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False, keep_host=False):
+    from elliot_amd import ops, parallel
     dev = ctx.device
-    torch.cuda.set_device(dev)
     U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
-
-    # ---------------- synthetic inputs, resident in HBM -------------------------------------------
-    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
-    pos = ops.DeviceCSR.from_tensors(indptr, indices, I)
+    K, W = args.steps, args.warmup
+    indptr, indices, pos = data["indptr"], data["indices"], data["pos"]
     g = torch.Generator(device=dev)
     g.manual_seed(42)
     lim_u, lim_i = (6.0 / (U + F)) ** 0.5, (6.0 / (I + F)) ** 0.5           # GlorotUniform (BPRMF_batch_model.py:39-42)
@@ -205,17 +346,16 @@ def main():
     Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i
     Bi = torch.zeros(I, device=dev)
 
-    # item shard of this rank (north_star: tables shard by item; N=1 -> the whole catalogue)
-    lo, hi = parallel.item_range(I, rank, world)
+    lo, hi = parallel.item_range(I, rank, world) if shard == "item" else (0, I)
     lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
-    sample_ctr = [0]
     finish_train = None
-    exchange_used = [None]
+    exchange = None
     coll = parallel._Collectives()
-    if world == 1 and not args.force_sharded:
+    sharded = world > 1 or args.force_sharded
+    collectives = []                                                          # (what, op, bytes per rank and call, callable)
+    if not sharded:
         st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
         pos_train = pos
-
         sampler = PrefetchSampler(ctx, pos, B, 42, enabled=args.prefetch)
 
         def train_step():
@@ -224,7 +364,7 @@ def main():
             sampler.release(b)
 
         pop_loss = st.pop_loss
-    elif args.shard == "user":
+    elif shard == "user":
         # USER shards: the rank owns the user rows [ulo, uhi) and a replica of the item table; B triplets per rank for its
         # own users (items: the whole catalogue, the reference's sampling distribution), all-reduce of the item gradients
         ulo, uhi = parallel.user_range(U, rank, world)
@@ -234,7 +374,7 @@ def main():
         be = parallel.HipUserShardBackend(ctx, Gu[ulo:uhi], Gi, Bi, optimizer=args.opt)
         trainer = parallel.ShardedBprmfByUser(be, coll)
         st = be.state
-        exchange_used[0] = "user"
+        exchange = "user"
         # the triplets of step t+1 are drawn AND sorted while step t's all-reduce is in flight (neither reads the model):
         # queued after the collective was issued, before its result is waited for
         drawn = [0]
@@ -252,22 +392,32 @@ def main():
             trainer.train_step(t[0], t[1], t[2], lr, l_w, l_b, overlap=lambda: nxt.__setitem__(0, draw()), presorted=True)
 
         pop_loss = trainer.pop_loss
+        scratch = torch.zeros_like(st.item_grad_flat)
+        collectives.append(("item gradients gGi [I,F] + gBi [I]", "all_reduce", scratch.numel() * 4,
+                            lambda: coll.all_reduce_sum(scratch)))
     else:
-        # item-sharded training: B triplets PER RANK with positive and negative inside the rank's shard, all-gather of
-        # the per-triplet user-gradient rows, identical user-table replicas (elliot_amd/parallel.py)
+        # item-sharded training: B triplets PER RANK with positive and negative inside the rank's shard, exchange of the
+        # user-row gradients, identical user-table replicas (elliot_amd/parallel.py)
         sip, six = parallel.shard_csr(indptr, indices, lo, hi)
         pos_train = ops.DeviceCSR.from_tensors(sip, six, hi - lo)
         exchange = args.exchange if args.exchange != "auto" else parallel.pick_exchange(U, B, world)
-        exchange_used[0] = exchange
         if exchange == "dense":
             # reduce-scatter of the dense user-gradient table, optimiser on the owned user rows, all-gather of the rows
             be = parallel.HipDenseBackend(ctx, Gu, Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), rank, world, optimizer=args.opt)
             trainer = parallel.ShardedBprmfDense(be, coll)
+            full = torch.zeros_like(be.state.gGu)
+            own = torch.zeros_like(be.g_own)
+            collectives.append(("dense user-gradient table gGu [U,F]", "reduce_scatter", full.numel() * 4,
+                                lambda: coll.reduce_scatter_rows(own, full)))
+            collectives.append(("updated user rows Gu [U/G,F] -> every replica", "all_gather", full.numel() * 4,
+                                lambda: coll.all_gather_rows_into(full, own)))
         else:
             be = parallel.HipBackend(ctx, Gu, Gi[lo:hi].contiguous(), Bi[lo:hi].contiguous(), optimizer=args.opt)
             trainer = parallel.ShardedBprmf(be, coll)
+            rows = torch.zeros((B, F), dtype=torch.float32, device=dev)
+            collectives.append(("per-triplet user-gradient rows [B,F] (+ ids)", "all_gather", world * B * (F + 1) * 4,
+                                lambda: coll.all_gather(rows)))
         st = be.state
-
         sampler = PrefetchSampler(ctx, pos_train, B, 42 + rank, enabled=args.prefetch)
 
         def train_step():
@@ -282,10 +432,8 @@ def main():
     Ub = min(args.topk_block, U)
     n_blocks = max(1, U // Ub)
     blk = [0]
-
-    sharded = world > 1 or args.force_sharded
-    user_sharded = sharded and args.shard == "user"
-    topk_by_user = sharded and args.topk_shard == "user" and not user_sharded
+    user_sharded = sharded and shard == "user"
+    topk_by_user = sharded and topk_shard == "user" and not user_sharded
     full_items = {}
 
     def prepare_topk():
@@ -320,70 +468,55 @@ def main():
             blk[0] += 1
             parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, s, s + Ub, k, excl=pos, algo=args.topk_algo,
                                   items_unchanged=s > 0)           # block 0 of every pass over the users derives the item image
+        if sharded:
+            part = torch.zeros((Ub, k), dtype=torch.float32, device=dev)
+            collectives.append(("partial top-k lists [Ub,k] (ids + scores) per block", "all_gather", 2 * world * Ub * k * 4,
+                                lambda: (coll.all_gather(part), coll.all_gather(part))))
 
-    def timed(fn, warmup, steps, finish=None):
-        for _ in range(warmup):
-            fn()
-        if finish:
-            finish()
-        barrier(world)
-        ctx.timing(True)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        if finish:
-            finish()                                                 # a collective still in flight belongs to the timed work
-        barrier(world)
-        dt = time.perf_counter() - t0
-        ctx.timing(False)
-        rep = ctx.timing_report()
-        return max_over_ranks(dt, world, dev), rep
-
-    K, W = args.steps, args.warmup
-    dt_train, rep_train = timed(train_step, W, K, finish_train)
+    dt_train, rep_train = timed(ctx, world, train_step, W, K, finish_train)
     loss = pop_loss()
     prepare_topk()
-    dt_topk, rep_topk = timed(topk_step, W, K)
+    dt_topk, rep_topk = timed(ctx, world, topk_step, W, K)
 
     # ---- accuracy metrics from the index tensor: one block of users, synthetic held-out set -------------
-    dt_met = None
-    if world == 1:
+    met = None
+    if with_metrics and world == 1:
+        from elliot_amd.synthetic import zipf_csr_device
         tip, tix = zipf_csr_device(U, I, dev, mean_log=2.0, sigma_log=0.7, dmin=1, dmax=200, seed=99)
         held = ops.DeviceTestSet.from_tensors(tip, tix, None)
         idx_blk, _ = parallel.sharded_topk(ctx, coll, st.Gu, st.Gi, st.Bi, lo, 0, Ub, k, excl=pos, algo=args.topk_algo)
         msum = torch.zeros(8, dtype=torch.float64, device=dev)
+        dt_met, rep_met = timed(ctx, world, lambda: ops.rec_metrics(ctx, idx_blk, held, 0.0, k, u_start=0, sums=msum), W, K)
+        met = {"value": Ub * K / dt_met, "unit": "users/s", "ms_per_step": dt_met / K * 1e3,
+               "what": f"nDCG/Precision/Recall/HR/MAP/MRR/F1@{k} from the [users, k] index tensor (el_rec_metrics), "
+                       f"{int(held.nnz)} held-out interactions",
+               "kernels_ms_per_step": {n: v[1] / K for n, v in rep_met.items()}}
+        del held, tip, tix
 
-        def metrics_step():
-            ops.rec_metrics(ctx, idx_blk, held, 0.0, k, u_start=0, sums=msum)
+    # ---- the leg's collectives, timed on their own (bytes per rank and call) --------------------------------------------
+    coll_rep = []
+    if sharded:
+        for what, op, nbytes, fn in collectives:
+            ms = time_collective(world, dev, fn)
+            coll_rep.append({"what": what, "op": op, "bytes": int(nbytes), "ms": ms,
+                             "algbw_GBs": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None})
 
-        dt_met, rep_met = timed(metrics_step, W, K)
+    # ---- fragile users of the last block: rank-k / k+1 gap inside the fp32 re-association bound -----------
+    fragile = None
+    if world == 1 and not args.force_sharded and hasattr(ops, "fragile_users"):
+        fragile = ops.fragile_users(ctx, st.Gu, st.Gi, st.Bi, 0, Ub, k, excl=pos)
 
-    if rank != 0:
-        return
-    # ---------------- metrics ---------------------------------------------------------------------
     pairs_per_s = world * B * K / dt_train            # B triplets per rank and step
     users_per_s = (world if (topk_by_user or user_sharded) else 1) * Ub * K / dt_topk
-
-    # HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.md), valid for the default workload only
-    traffic = {}
-    try:
-        tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        c = tj["config"]
-        if (c["users"], c["items"], c["factors"], c["batch"], c["topk_block"]) == (U, I, F, B, Ub) and world == 1:
-            traffic = tj["bytes_per_launch"]
-    except Exception:
-        pass
-
-    def dominant(rep):
-        name = max(rep, key=lambda n: rep[n][1])
-        return name, rep[name][1] / rep[name][0] * 1e-3   # seconds per launch
+    traffic, traffic_note = load_traffic(U, I, F, B, Ub, world if not args.force_sharded else 0)
 
     # train roofline: algorithmic bytes of the dominant kernel (DESIGN.md "algorithmic bytes")
     rows_u, rows_i = int(st.Gu.shape[0]), int(st.Gi.shape[0])  # what this rank's optimiser pass actually covers
-    if exchange_used[0] == "dense":
+    if exchange == "dense":
         rows_u = be.Us
     alg = {
         "k_adam_dense_Gu": 24.0 * rows_u * F,                 # theta, m, v read + write
+        "k_adam_rows_Gu": 24.0 * rows_u * F,                  # the same pass reading compact gradient rows
         "k_adam_dense_Gi": 24.0 * rows_i * F,
         "k_bprmf_fwd_bwd": B * (24.0 * F + 28.0),             # 3 rows read + 3 gradient rows written (+ idx, bias)
         "k_bpr_user_seg": B * (16.0 * F + 28.0),              # gamma_u, gamma_i, gamma_j read + dGu row written
@@ -396,58 +529,229 @@ def main():
     }
     dn, dsec = dominant(rep_train)
     achieved = alg.get(dn, 0.0) / dsec / 1e9
+    step_bytes = 24.0 * (rows_u + rows_i) * F + B * (24.0 * F + 28.0)     # dense-Adam surcharge + per-triplet bytes
     roof_train = {"kernel": dn, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dn),
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dn), "traffic_source": traffic_note,
+                  "step_GBs": step_bytes / (dt_train / K) / 1e9,
                   "kernels_ms_per_step": {n: v[1] / K for n, v in rep_train.items()}}
     # top-k roofline: the dominant kernel is one full user x item scoring GEMM (2*U*I*F flop per launch): the fp32 MFMA
     # kernel, or one of the two bf16 passes of the screened kernel (the other pass repeats the same flops; results are
     # re-scored in fp32 and bit-identical)
     tn, tsec = dominant(rep_topk)
-    flops = 2.0 * Ub * (I if (topk_by_user or user_sharded) else (hi - lo)) * F
+    flops = 2.0 * Ub * (I if (topk_by_user or user_sharded or not sharded) else (hi - lo)) * F
     ach_t = flops / tsec / 1e12
     screened = tn.startswith("k_screen")
     peak_t = MFMA_BF16_PEAK_TFLOPS if screened else MFMA_F32_PEAK_TFLOPS
     roof_topk = {"kernel": tn, "bound": "mfma", "achieved": ach_t, "peak": peak_t, "unit": "TFLOP/s",
-                 "frac": ach_t / peak_t, "traffic": traffic.get(tn),
+                 "frac": ach_t / peak_t, "traffic": traffic.get(tn), "traffic_source": traffic_note,
                  "dtype": "bf16 MFMA screen + f32 exact re-score" if screened else "f32",
                  "effective_TFLOPs": flops / (dt_topk / K) / 1e12,
                  "kernels_ms_per_step": {n: v[1] / K for n, v in rep_topk.items()}}
+    if not sharded:
+        par = "single"
+    elif exchange == "user":
+        par = (f"user-shard x{world}: train = {B} triplets/rank for the rank's own users (item table replicated) + "
+               f"all-reduce of the item gradients ({I * (F + 1) * 4 / 1e6:.0f} MB)")
+    else:
+        par = (f"item-shard x{world}: train = {B} triplets/rank + "
+               + ("reduce-scatter of the dense user-gradient table, optimiser on U/G user rows, all-gather of the rows"
+                  if exchange == "dense" else "all-gather of user-gradient rows") + " (weak)")
+    topk_sharding = ("single" if not sharded else
+                     f"by user: each rank scores {Ub}-user blocks of the users it owns against its replica of the item table, no collective"
+                     if user_sharded else
+                     f"by user: {Ub} users per rank and step vs the whole catalogue (item table all-gathered once per evaluation)"
+                     if topk_by_user else f"by item: all users vs I/{world} items per rank + all-gather/merge of partial lists")
+    res = {
+        "value": pairs_per_s, "unit": "pairs/s", "ms_per_step": dt_train / K * 1e3, "scaling": "weak",
+        "parallelism": par, "loss_per_pair_last": loss / (B * world * (K + W)), "roofline": roof_train,
+        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3,
+                 "scaling": "weak" if (topk_by_user or user_sharded or not sharded) else "strong",
+                 "sharding": topk_sharding, "roofline": roof_topk},
+        "interactions": int(pos.nnz), "topk_block": Ub,
+    }
+    if fragile is not None:
+        res["topk"]["fragile_users"] = fragile
+    if coll_rep:
+        res["collectives"] = coll_rep
+    if met is not None:
+        res["metrics"] = met
+    if keep_host:
+        res["_host"] = {"Gu": st.Gu.cpu().numpy(), "Gi": st.Gi.cpu().numpy(), "Bi": st.Bi.cpu().numpy(),
+                        "indptr": pos.indptr.cpu().numpy(), "indices": pos.indices.cpu().numpy()}
+    return res
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mult-VAE leg (BASELINE configs[2]) and NeuMF leg (configs[3], per-GPU shape)
+# ---------------------------------------------------------------------------------------------------------------------
+def vae_leg(args, ctx):
+    """multi_vae_model.py:125-142 train_step at the ML-20M shape: users/s + MFMA roofline of the fp32 GEMM kernel."""
+    from elliot_amd import ops
+    from elliot_amd.synthetic import zipf_csr_device
+    dev = ctx.device
+    U, I, H, L, B = (int(x) for x in args.vae_shape.split(","))
+    K, W = args.steps, args.warmup
+    ip, ix = zipf_csr_device(U, I, dev, mean_log=4.5, sigma_log=1.0, dmin=20, dmax=3000, seed=5)
+    csr = ops.DeviceCSR.from_tensors(ip, ix, I)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    gn = lambda a, b: torch.randn((a, b), generator=g, device=dev) * (2.0 / (a + b)) ** 0.5       # GlorotNormal scale
+    z = lambda n: torch.zeros(n, device=dev)
+    st = ops.VaeDeviceState(ctx, {"W1": gn(I, H), "b1": z(H), "Wm": gn(H, L), "bm": z(L), "Wv": gn(H, L), "bv": z(L),
+                                  "W3": gn(L, H), "b3": z(H), "W4": gn(H, I), "b4": z(I)}, max_batch=B)
+    perm = torch.randperm(U, device=dev, generator=g).to(torch.int32)
+    nb = U // B
+    eps = torch.randn((B, L), device=dev, generator=g)
+    it = [0]
+
+    def step():
+        b = it[0] % nb
+        it[0] += 1
+        st.train_step(csr, perm[b * B:(b + 1) * B], 0.001, min(0.2, it[0] / 200000.0), eps=eps)
+
+    dt, rep = timed(ctx, 1, step, W, K)
+    loss = st.pop_loss()
+    ms = dt / K * 1e3
+    nnz_row = float(csr.nnz) / U
+    # flops executed by the dense GEMM launches of one step (the first layer and its weight gradient run on the CSR rows):
+    #   fwd  h->mv (H x 2L), z->h2 (L x H), h2->logits (H x I);  bwd: two products each
+    gemm_flops = B * 2.0 * (H * 2 * L + L * H + H * I) * 3
+    alg_flops = B * (2400.0 * I + 720000.0) * 2.5                      # SURVEY 8d: dense-input formulation, fwd x 2.5
+    gname = "k_gemm_f32"
+    gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / K
+    ach = gemm_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    return {"value": B * K / dt, "unit": "users/s", "ms_per_step": ms,
+            "workload": f"MultiVAE {U} users x {I} items (ML-20M shape, BASELINE configs[2]), hidden {H}, latent {L}, batch {B}, "
+                        f"{int(csr.nnz)} interactions ({nnz_row:.0f}/user), Adam, anneal schedule of multi_vae.py:105-108",
+            "loss_mean": loss / (K + W),
+            "roofline": {"kernel": gname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
+                         "flops_per_step_gemm": gemm_flops, "gemm_ms_per_step": gms,
+                         "step_TFLOPs_dense_gemm": gemm_flops / (ms * 1e-3) / 1e12,
+                         "step_TFLOPs_survey8d": alg_flops / (ms * 1e-3) / 1e12,
+                         "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}
+
+
+def neumf_leg(args, ctx):
+    """neural_matrix_factorization_model.py:96-106 train_step, d=128, tower (4F, 2F, F): samples/s + MFMA roofline."""
+    from elliot_amd import ops
+    from elliot_amd.synthetic import zipf_csr_device
+    dev = ctx.device
+    U, I, F, B = (int(x) for x in args.neumf_shape.split(","))
+    K, W = args.steps, args.warmup
+    ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=11)
+    pos = ops.DeviceCSR.from_tensors(ip, ix, I)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    gu = lambda a, b: (torch.rand((a, b), generator=g, device=dev) * 2 - 1) * (6.0 / (a + b)) ** 0.5    # GlorotUniform
+    units = [4 * F, 2 * F, F]
+    w = {"Umf": gu(U, F), "Imf": gu(I, F), "Umlp": gu(U, F), "Imlp": gu(I, F), "W": [], "b": []}
+    kin = 2 * F
+    for n_out in units:
+        w["W"].append(gu(kin, n_out))
+        w["b"].append(torch.zeros(n_out, device=dev))
+        kin = n_out
+    w["hw"], w["hb"] = gu(F + units[-1], 1)[:, 0].contiguous(), torch.zeros(1, device=dev)
+    st = ops.NmfDeviceState(ctx, w, max_batch=B)
+    del w
+    it = [0]
+
+    def step():
+        u, i, y = ops.pointwise_sample(ctx, pos, B, seed=3, first_sample=it[0] * B)
+        it[0] += 1
+        st.train_step(u, i, y, 0.001)
+
+    dt, rep = timed(ctx, 1, step, W, K)
+    loss = st.pop_loss()
+    ms = dt / K * 1e3
+    mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # SURVEY 8d: fwd 36 F^2 + 4 F per sample, x3 fwd + bwd
+    gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / K
+    ach = mlp_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    emb_bytes = 24.0 * 2 * (U + I) * F                                 # Keras Adam moves every row of the 4 embedding tables
+    ams = sum(v[1] for n, v in rep.items() if n.startswith("k_adam_dense")) / K
+    return {"value": B * K / dt, "unit": "samples/s", "ms_per_step": ms,
+            "workload": f"NeuMF d={F} (GMF + MLP {units}), {U} users x {I} items = the per-GPU shape of BASELINE configs[3] (10M x 1M over "
+                        f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: dense over "
+                        f"the four embedding tables)",
+            "loss_mean": loss / (K + W),
+            "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
+                         "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,
+                         "step_TFLOPs_mlp": mlp_flops / (ms * 1e-3) / 1e12,
+                         "adam_tables_GBs": emb_bytes / (ams * 1e-3) / 1e9 if ams > 0 else None,
+                         "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    world, rank, local, backend = dist_setup(args)
+    if world != args.gpus:
+        # never report an N-GPU line from a different number of ranks
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
+    from elliot_amd import ops
+    from elliot_amd.synthetic import zipf_csr_device
+    ctx = ops.get_context(local)
+    dev = ctx.device
+    torch.cuda.set_device(dev)
+    U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
+    sharded = world > 1 or args.force_sharded
+    legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else ["bpr", "metrics", "vae", "neumf"])
+
+    # ---------------- synthetic inputs, resident in HBM -------------------------------------------
+    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+    data = {"indptr": indptr, "indices": indices, "pos": ops.DeviceCSR.from_tensors(indptr, indices, I)}
+
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    topk_shard = args.topk_shard or ("user" if args.shard == "user" else "item")
+    main_leg = bpr_leg(args, ctx, world, rank, data, args.shard, topk_shard, with_metrics="metrics" in legs, keep_host=want_cpu and rank == 0)
+    second = None
+    if "item_shard" in legs and sharded and args.shard == "user":
+        torch.cuda.empty_cache()
+        second = bpr_leg(args, ctx, world, rank, data, "item", args.topk_shard or "item")
+    del data, indptr, indices
+    torch.cuda.empty_cache()
+    vae = neumf = None
+    if world == 1 and not args.force_sharded:
+        if "vae" in legs:
+            vae = vae_leg(args, ctx)
+            torch.cuda.empty_cache()
+        if "neumf" in legs:
+            neumf = neumf_leg(args, ctx)
+            torch.cuda.empty_cache()
+    if rank != 0:
+        return
+
+    host = main_leg.pop("_host", None)
     line = {
         "metric": "BPR-MF positive-pairs/sec + full-catalog top-k users/sec",
-        "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt_train / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": main_leg["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
                    else f"BPRMF d={F}, synthetic {U} users x {I} items",
-                   "users": U, "items": I, "factors": F, "interactions": int(pos.nnz), "batch": B,
-                   "batch_per_gpu": B, "optimizer": args.opt, "topk_block": Ub, "k": k,
-                   "parallelism": "single" if world == 1 else
-                   (f"user-shard x{world}: train = {B} triplets/rank for the rank's own users (item table replicated) + "
-                    f"all-reduce of the item gradients ({I * (F + 1) * 4 / 1e6:.0f} MB)") if exchange_used[0] == "user" else
-                   f"item-shard x{world}: train = {B} triplets/rank + "
-                   + ("reduce-scatter of the dense user-gradient table, optimiser on U/G user rows, all-gather of the rows"
-                      if exchange_used[0] == "dense" else "all-gather of user-gradient rows")
-                   + " (weak); top-k: see topk.sharding"},
-        "loss_per_pair_last": loss / (B * world * (K + W)),
-        "roofline": roof_train,
-        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3,
-                 "scaling": "weak" if (topk_by_user or user_sharded or world == 1) else "strong",
-                 "sharding": ("single" if not sharded else
-                              f"by user: each rank scores {Ub}-user blocks of the users it owns against its replica of the item table, no collective"
-                              if user_sharded else
-                              f"by user: {Ub} users per rank and step vs the whole catalogue (item table all-gathered once per evaluation)"
-                              if topk_by_user else f"by item: all users vs I/{world} items per rank + all-gather/merge of partial lists"),
-                 "roofline": roof_topk},
+                   "users": U, "items": I, "factors": F, "interactions": main_leg["interactions"], "batch": B,
+                   "batch_per_gpu": B, "optimizer": args.opt, "topk_block": main_leg["topk_block"], "k": k,
+                   "parallelism": main_leg["parallelism"] + ("; top-k: see topk.sharding" if sharded else ""),
+                   "world_size_observed": world, "backend": backend},
+        "loss_per_pair_last": main_leg["loss_per_pair_last"],
+        "roofline": main_leg["roofline"],
+        "topk": main_leg["topk"],
     }
-    if dt_met is not None:
-        line["metrics"] = {"value": Ub * K / dt_met, "unit": "users/s", "ms_per_step": dt_met / K * 1e3,
-                           "what": f"nDCG/Precision/Recall/HR/MAP/MRR/F1@{k} from the [users, k] index tensor (el_rec_metrics), "
-                                   f"{int(held.nnz)} held-out interactions",
-                           "kernels_ms_per_step": {n: v[1] / K for n, v in rep_met.items()}}
-    if world == 1 and not args.no_cpu_baseline:
-        host = {"Gu": st.Gu.cpu().numpy(), "Gi": st.Gi.cpu().numpy(), "Bi": st.Bi.cpu().numpy(),
-                "indptr": pos.indptr.cpu().numpy(), "indices": pos.indices.cpu().numpy()}
+    for key in ("collectives", "metrics"):
+        if key in main_leg:
+            line[key] = main_leg[key]
+    if second is not None:
+        line["item_shard"] = {kk: second[kk] for kk in ("value", "unit", "ms_per_step", "scaling", "parallelism", "loss_per_pair_last",
+                                                       "roofline", "topk", "collectives") if kk in second}
+    if vae is not None:
+        line["vae"] = vae
+    if neumf is not None:
+        line["neumf"] = neumf
+    if want_cpu and host is not None:
         line["cpu_baseline"] = cpu_baseline(args, host)
     print(json.dumps(line), flush=True)
 

@@ -33,6 +33,7 @@ class BprmfState(C.Structure):
         ("mGu", _f32p), ("vGu", _f32p), ("mGi", _f32p), ("vGi", _f32p), ("mBi", _f32p), ("vBi", _f32p),
         ("tGu", _i32p), ("tGi", _i32p), ("tBi", _i32p),
         ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32),
+        ("uslot", _i64p), ("gGu_rows", _f32p), ("gGu_cap", C.c_int64),
     ]
 
 
@@ -129,6 +130,8 @@ PROTOTYPES = {
     "el_bprsgd_levels_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "el_rec_metrics_ws_bytes": (C.c_size_t, [C.c_int64]),
+    "el_topk_fragile": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int32, C.c_int64, C.c_int64, _i32p, _f32p, C.c_int64,
+                                  C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "el_rec_metrics": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _f32p,
                                  C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "el_score_topk_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int]),

@@ -420,6 +420,65 @@ __global__ __launch_bounds__(256) void k_adam_dense(float* __restrict__ th, floa
     adam_dense_body<true, 2>(th, g, m, v, n, lr_t, b1, b2, eps);
 }
 
+// The same pass reading COMPACT gradient rows (el_bprmf_state.uslot / gGu_rows): every element still decays m, v and moves
+// theta (Keras sparse apply), but a gradient is fetched only for rows stamped with this step and nothing is zeroed afterwards:
+// 12 + 12 bytes per parameter + 4 per parameter of a touched row, against 16 + 12 (+ 4 re-zeroed) of the dense form.
+// n4 = U F / 4 float4 elements; row of element e = e / F4 (a shift when F4 is a power of two).
+template <int UNR>
+__global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ th, const float* __restrict__ grows,
+                                                   const int64_t* __restrict__ uslot, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n4, int F4, int f4_shift, int32_t step,
+                                                   float lr_t, float b1, float b2, float eps) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    f4* th4 = reinterpret_cast<f4*>(th);
+    const f4* g4 = reinterpret_cast<const f4*>(grows);
+    f4* m4 = reinterpret_cast<f4*>(m);
+    f4* v4 = reinterpret_cast<f4*>(v);
+    const bool small = n4 < (1LL << 31);
+    for (int64_t e0 = t; e0 < n4; e0 += stride * UNR) {
+        f4 a[UNR], gg[UNR], mm[UNR], vv[UNR];
+        int64_t gsrc[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int64_t e = e0 + q * stride;
+            gsrc[q] = -1;
+            if (e < n4) {
+                const int64_t row = f4_shift >= 0 ? (e >> f4_shift) : (small ? (int64_t)((u32)e / (u32)F4) : e / F4);
+                const int64_t ent = uslot[row];
+                if ((int32_t)(ent >> 32) == step) gsrc[q] = (ent & 0xffffffffLL) * F4 + (e - row * F4);
+                a[q] = __builtin_nontemporal_load(th4 + e);
+                mm[q] = __builtin_nontemporal_load(m4 + e);
+                vv[q] = __builtin_nontemporal_load(v4 + e);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const f4 zero = {0.f, 0.f, 0.f, 0.f};
+            gg[q] = gsrc[q] >= 0 ? __builtin_nontemporal_load(g4 + gsrc[q]) : zero;
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int64_t e = e0 + q * stride;
+            if (e < n4) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float ax = a[q][x], mx = mm[q][x], vx = vv[q][x];
+                    el_adam_elem(ax, mx, vx, gg[q][x], lr_t, b1, b2, omb1, omb2, eps);
+                    a[q][x] = ax;
+                    mm[q][x] = mx;
+                    vv[q][x] = vx;
+                }
+                __builtin_nontemporal_store(a[q], th4 + e);
+                __builtin_nontemporal_store(mm[q], m4 + e);
+                __builtin_nontemporal_store(vv[q], v4 + e);
+            }
+        }
+    }
+}
+
 // Small models (ML-1M: 0.6 M parameters): the three dense passes are launch-bound, so they share one launch.
 struct AdamTriple {
     float* th[3];
@@ -599,7 +658,7 @@ int el_bprmf_check_state(const el_bprmf_state* stp, const int32_t* u, const int3
                          double* loss_out, int opt, int32_t step, bool* vec, bool* rows_mode) {
     EL_REQUIRE(stp != nullptr, "el_bprmf_train_step: null state");
     const el_bprmf_state& st = *stp;
-    EL_REQUIRE(st.Gu && st.Gi && st.Bi && st.gGu && st.gGi && st.gBi, "el_bprmf_train_step: null table/accumulator");
+    EL_REQUIRE(st.Gu && st.Gi && st.Bi && (st.gGu || st.uslot) && st.gGi && st.gBi, "el_bprmf_train_step: null table/accumulator");
     EL_REQUIRE(st.F >= 1 && st.U >= 1 && st.I >= 1, "el_bprmf_train_step: bad shape");
     EL_REQUIRE(u && i && j && loss_out, "el_bprmf_train_step: null batch/loss pointer");
     EL_REQUIRE(step >= 1, "el_bprmf_train_step: step is 1-based");
@@ -608,7 +667,7 @@ int el_bprmf_check_state(const el_bprmf_state* stp, const int32_t* u, const int3
     if (adam) EL_REQUIRE(st.mGu && st.vGu && st.mGi && st.vGi && st.mBi && st.vBi, "el_bprmf_train_step: Adam slots missing");
     *rows_mode = (opt == EL_OPT_ADAM_LAZY) || (opt == EL_OPT_SGD && st.tGu != nullptr);
     if (*rows_mode) EL_REQUIRE(st.tGu && st.tGi && st.tBi, "el_bprmf_train_step: stamp arrays missing");
-    *vec = rows_aligned16(st.Gu, st.F) && rows_aligned16(st.Gi, st.F) && rows_aligned16(st.gGu, st.F) &&
+    *vec = rows_aligned16(st.Gu, st.F) && rows_aligned16(st.Gi, st.F) && rows_aligned16(st.uslot ? st.gGu_rows : st.gGu, st.F) &&
            rows_aligned16(st.gGi, st.F) &&
            (!adam || (rows_aligned16(st.mGu, st.F) && rows_aligned16(st.vGu, st.F) &&
                       rows_aligned16(st.mGi, st.F) && rows_aligned16(st.vGi, st.F)));
@@ -628,6 +687,20 @@ int el_bprmf_apply_optimizer(el_ctx* ctx, hipStream_t s, const el_bprmf_state& s
     if (opt == EL_OPT_ADAM_TF_DENSE) {
         const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
         auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        if (st.uslot) {
+            // user table: compact gradient rows of this step (written by the sorted segment kernels)
+            EL_REQUIRE(st.F % 4 == 0 && al16(st.Gu) && al16(st.mGu) && al16(st.vGu) && st.gGu_rows && al16(st.gGu_rows),
+                       "el_bprmf_apply: compact user-gradient rows need F %% 4 == 0 and 16-byte aligned tables");
+            const int F4 = st.F / 4;
+            int sh = -1;
+            if ((F4 & (F4 - 1)) == 0) { sh = 0; while ((1 << sh) < F4) ++sh; }
+            EL_LAUNCH("k_adam_rows_Gu", k_adam_rows<2>, dim3(stream_grid(ctx, nu / 4 + 1)), dim3(256), 0, s, st.Gu, st.gGu_rows, st.uslot,
+                      st.mGu, st.vGu, nu / 4, F4, sh, step, lr_t, b1, b2, eps);
+            EL_LAUNCH("k_adam_dense_Gi", k_adam_dense, dim3(stream_grid(ctx, ni / 4 + 1)), dim3(256), 0, s, st.Gi, st.gGi, st.mGi, st.vGi, ni, lr_t, b1, b2, eps);
+            EL_LAUNCH("k_adam_dense_Bi", k_adam_dense, dim3(stream_grid(ctx, st.I / 4 + 1)), dim3(256), 0, s, st.Bi, st.gBi, st.mBi, st.vBi, st.I, lr_t, b1, b2, eps);
+            EL_CHECK_LAUNCH();
+            return 0;
+        }
         if (nu + ni <= (4LL << 20) && al16(st.Gu) && al16(st.gGu) && al16(st.mGu) && al16(st.vGu) && al16(st.Gi) && al16(st.gGi) &&
             al16(st.mGi) && al16(st.vGi) && al16(st.Bi) && al16(st.gBi) && al16(st.mBi) && al16(st.vBi)) {
             AdamTriple t = {{st.Gu, st.Gi, st.Bi}, {st.gGu, st.gGi, st.gBi}, {st.mGu, st.mGi, st.mBi}, {st.vGu, st.vGi, st.vBi}, {nu, ni, st.I}};
@@ -674,7 +747,8 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
     if (B <= 0) return 0;
     const el_bprmf_state st = *stp;
     bool sorted = (algo == EL_BPR_SORTED);
-    if (algo == EL_BPR_AUTO) sorted = (B >= 2048) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I);
+    if (algo == EL_BPR_AUTO) sorted = (B >= 2048 || st.uslot) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I);
+    EL_REQUIRE(sorted || !st.uslot, "el_bprmf_train_step: compact user-gradient rows (uslot) need the SORTED path and its workspace");
     if (sorted)
         return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, lr, l_w, l_b, opt, step, lr_t, loss_out, ws, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -975,7 +1049,7 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
     // enough for the fused three-tensor pass, no per-kernel timing requested
     static const bool graphs_on = [] { const char* e = getenv("EL_LOOP_GRAPH"); return !(e && atoi(e) == 0); }();
     const el_bprmf_state& st = *stp;
-    bool use_graph = graphs_on && !ctx->timing && opt == EL_OPT_ADAM_TF_DENSE && steps >= 4 &&
+    bool use_graph = graphs_on && !ctx->timing && opt == EL_OPT_ADAM_TF_DENSE && steps >= 4 && !stp->uslot &&
                      (algo == EL_BPR_ATOMIC || (algo == EL_BPR_AUTO && B < 2048));
     const int64_t nu = st.U * (int64_t)st.F, ni = st.I * (int64_t)st.F;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };

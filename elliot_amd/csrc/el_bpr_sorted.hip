@@ -87,16 +87,25 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = gid / lpt;
     const int sub = (int)(threadIdx.x & (lpt - 1));
-    const int64_t p0 = grp * p.chunk;
-    const int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
+    int64_t p0 = grp * p.chunk;
+    int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
+    // Compact user-gradient rows (el_bprmf_state.uslot): a segment belongs, whole, to the group whose chunk holds its HEAD --
+    // that group walks on past its chunk end, the next one skips the positions of a segment that began before its chunk
+    // (user segments are short: Poisson(B/U)).  Every row is then one plain store into gGu_rows[head position].
+    const bool compact = p.st.uslot != nullptr;
+    if (compact && p0 < p1) {
+        while (p0 < p1 && p0 > 0 && p.keys[p0] == p.keys[p0 - 1]) ++p0;
+        if (p0 < p1)
+            while (p1 < p.n && p.keys[p1] == p.keys[p1 - 1]) ++p1;
+    }
     float myloss = 0.f;
-    if (p0 < p.n) {
-        int64_t cur = -1;
+    if (p0 < p1) {
+        int64_t cur = -1, head = 0;
         bool started_inside = false;
         float gu[CPL][VW], acc[CPL][VW];
         int cnt = 0;
         auto flush = [&](bool ends_inside) {
-            float* g = p.st.gGu + cur * F;
+            float* g = compact ? p.st.gGu_rows + head * F : p.st.gGu + cur * F;
             const float w = (float)cnt * p.l_w;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
                     float v[VW];
 #pragma unroll
                     for (int x = 0; x < VW; ++x) v[x] = acc[q][x] + w * gu[q][x];
-                    if (started_inside && ends_inside) {
+                    if (compact || (started_inside && ends_inside)) {
                         stv<VW>(g + e, v);
                     } else {
 #pragma unroll
@@ -113,6 +122,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
                     }
                 }
             }
+            if (sub == 0 && compact) p.st.uslot[cur] = ((int64_t)p.step << 32) | head;
             if (sub == 0 && p.st.tGu) p.st.tGu[cur] = p.step;
         };
         // The index chain of a position is three dependent loads deep (sorted key / triplet -> i, j -> Bi[i], Bi[j]); a group
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
                     if (key != cur) {
                         if (cur >= 0) flush(true);
                         cur = key;
+                        head = pos;
                         started_inside = (pos > p0) || (pos == 0) || ((int64_t)p.keys[pos - 1] != key);
                         cnt = 0;
 #pragma unroll
@@ -495,6 +506,12 @@ extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(
     hipStream_t s = (hipStream_t)stream;
     if (opt != -2)                                   // -2: el_bprmf_presort already ordered this batch in `ws`
         if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
+    if (st.uslot) {
+        EL_REQUIRE(st.gGu_rows != nullptr && st.gGu_cap >= B, "el_bprmf_train_step: compact user-gradient rows need gGu_rows with >= B rows (%lld < %lld)",
+                   (long long)st.gGu_cap, (long long)B);
+        EL_REQUIRE(vec && ((uintptr_t)st.gGu_rows & 15) == 0 && !rows_mode && (opt == EL_OPT_ADAM_TF_DENSE || opt < 0),
+                   "el_bprmf_train_step: compact user-gradient rows need F %% 4 == 0, 16-byte aligned tables and the TF-dense Adam");
+    }
     SegParams base;
     memset(&base, 0, sizeof(base));
     base.st = st;
@@ -526,6 +543,7 @@ int el_bpr_sorted_cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st
     memset(&base, 0, sizeof(base));
     base.st = st;
     base.st.tGu = base.st.tGi = base.st.tBi = nullptr;
+    base.st.uslot = nullptr;                                  // CML writes the dense accumulator
     base.bi = i, base.bj = j, base.bu = u;
     base.s = cD, base.s2 = cE, base.cml = 1;
     base.l_w = l_w, base.l_b = l_b;
@@ -837,7 +855,7 @@ extern "C" int el_rows_segment_sum(el_ctx* ctx, void* stream, const int32_t* ids
 // optimiser phase alone (gradients already in gGu / gGi / gBi): TF-dense Adam or dense SGD
 extern "C" int el_bprmf_apply(el_ctx* ctx, void* stream, const el_bprmf_state* stp, float lr, int opt, int32_t step, float lr_t) {
     if (int rc = el_bind(ctx)) return rc;
-    EL_REQUIRE(stp != nullptr && stp->Gu && stp->Gi && stp->Bi && stp->gGu && stp->gGi && stp->gBi, "el_bprmf_apply: null state");
+    EL_REQUIRE(stp != nullptr && stp->Gu && stp->Gi && stp->Bi && (stp->gGu || stp->uslot) && stp->gGi && stp->gBi, "el_bprmf_apply: null state");
     EL_REQUIRE(opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_SGD, "el_bprmf_apply: only the dense optimisers (adam_tf_dense, sgd) are available here");
     if (opt == EL_OPT_ADAM_TF_DENSE) EL_REQUIRE(stp->mGu && stp->vGu && stp->mGi && stp->vGi && stp->mBi && stp->vBi, "el_bprmf_apply: Adam slots missing");
     el_bprmf_state st = *stp;

@@ -181,3 +181,61 @@ extern "C" int el_rec_metrics(el_ctx* ctx, void* stream, const int32_t* rec_idx,
     EL_CHECK_LAUNCH();
     return 0;
 }
+
+// =====================================================================================================
+// Fragile-user report.  The fused top-k pins ONE summation order for the fp32 scores (the k-ordered fma
+// chain); TensorFlow / Eigen's order in BPRMF_batch_model.py:83-84 (`tf.matmul`) cannot be known here.  Two correct fp32
+// evaluations of <u, i> differ by at most gamma = F 2^-23 |u| |i| (both sums within F 2^-24 |u||i| of the exact value), so a
+// user's top-k SET is independent of the summation order whenever score_k - score_{k+1} >= F 2^-23 |u| max(|i_k|, |i_{k+1}|).
+// This kernel counts the users for whom that does not hold, from a [n, k+1] list of el_score_topk: one wave per user.
+//   counts[0] += fragile users, counts[1] += users with fewer than k+1 finite entries (nothing beyond rank k can displace)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_topk_fragile(const float* __restrict__ Gu, const float* __restrict__ Gi, int F,
+                                                      int64_t u_start, int64_t n, const int32_t* __restrict__ idx,
+                                                      const float* __restrict__ val, int64_t ld, int k, int64_t item_offset,
+                                                      unsigned char* __restrict__ flags, unsigned long long* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int32_t ia = idx[r * ld + (k - 1)], ib = idx[r * ld + k];
+    const float va = val[r * ld + (k - 1)], vb = val[r * ld + k];
+    const bool full = ia >= 0 && ib >= 0 && va > -INFINITY && vb > -INFINITY;
+    int fragile = 0;
+    if (full) {
+        const float* pu = Gu + (u_start + r) * (int64_t)F;
+        const float* pa = Gi + ((int64_t)ia - item_offset) * F;
+        const float* pb = Gi + ((int64_t)ib - item_offset) * F;
+        double nu = 0.0, na = 0.0, nb = 0.0;
+        for (int f = lane; f < F; f += 64) {
+            const double x = pu[f], y = pa[f], z = pb[f];
+            nu += x * x;
+            na += y * y;
+            nb += z * z;
+        }
+        nu = el_group_sum(nu, 64);
+        na = el_group_sum(na, 64);
+        nb = el_group_sum(nb, 64);
+        const double bound = (double)F * 1.1920928955078125e-07 * sqrt(nu) * sqrt(na > nb ? na : nb);
+        fragile = ((double)va - (double)vb) < bound ? 1 : 0;
+    }
+    if (lane == 0) {
+        if (flags) flags[r] = (unsigned char)fragile;
+        if (fragile) atomicAdd(counts, 1ull);
+        if (!full) atomicAdd(counts + 1, 1ull);
+    }
+}
+
+extern "C" int el_topk_fragile(el_ctx* ctx, void* stream, const float* Gu, const float* Gi, int32_t F, int64_t u_start,
+                               int64_t u_stop, const int32_t* idx, const float* val, int64_t ld, int32_t k, int64_t item_offset,
+                               unsigned char* flags, uint64_t* counts) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(u_stop >= u_start, "el_topk_fragile: u_stop < u_start");
+    const int64_t n = u_stop - u_start;
+    if (n == 0) return 0;
+    EL_REQUIRE(Gu && Gi && idx && val && counts, "el_topk_fragile: null pointer");
+    EL_REQUIRE(F >= 1 && k >= 1 && ld >= (int64_t)k + 1, "el_topk_fragile: needs lists of at least k + 1 entries (ld %lld, k %d)", (long long)ld, k);
+    EL_LAUNCH("k_topk_fragile", k_topk_fragile, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Gu, Gi, (int)F, u_start, n,
+              idx, val, ld, (int)k, item_offset, flags, reinterpret_cast<unsigned long long*>(counts));
+    EL_CHECK_LAUNCH();
+    return 0;
+}

@@ -269,6 +269,25 @@ def rec_metrics(ctx, rec_idx, test, threshold, cutoff, u_start=0, sums=None, per
     return (sums, rows) if per_user else sums
 
 
+def fragile_users(ctx, Gu, Gi, Bi, u_start, u_stop, k, excl=None, cand=None, item_offset=0, algo="auto", flags=False):
+    """Fragile-user report: how many of the users [u_start, u_stop) have a rank-k / rank-(k+1) score gap
+    below the fp32 re-association bound F 2^-23 |u| max|i| -- for those (and only those) the top-k SET could differ under
+    another correct fp32 summation order (TensorFlow's `tf.matmul`, BPRMF_batch_model.py:83-84).  Scores k + 1 entries per
+    user with the fused kernels, then el_topk_fragile.  Returns a dict (and the uint8 flag tensor when flags=True)."""
+    idx, val = score_topk(ctx, Gu, Gi, Bi, u_start, u_stop, k + 1, excl=excl, cand=cand, item_offset=item_offset, algo=algo)
+    n = u_stop - u_start
+    counts = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+    fl = torch.zeros(n, dtype=torch.uint8, device=ctx.device) if flags else None
+    check(ctx.lib.el_topk_fragile(ctx.handle, ctx.stream(), _ptr(Gu, torch.float32), _ptr(Gi, torch.float32), int(Gu.shape[1]),
+                                  int(u_start), int(u_stop), _ptr(idx, torch.int32), _ptr(val, torch.float32), int(idx.shape[1]),
+                                  int(k), int(item_offset), C.c_void_p(fl.data_ptr()) if fl is not None else None,
+                                  C.c_void_p(counts.data_ptr())), "el_topk_fragile")
+    c = counts.cpu().tolist()
+    rep = {"users": int(n), "k": int(k), "fragile": int(c[0]), "short_lists": int(c[1]),
+           "bound": "score[k-1] - score[k] < F * 2^-23 * |u| * max(|i_k|, |i_k+1|)"}
+    return (rep, fl) if flags else rep
+
+
 # ------------------------------------------------------------------------------------------
 # sampler
 # ------------------------------------------------------------------------------------------
@@ -372,13 +391,14 @@ def _strided_tables(rows, F, count, gap_bytes, device):
     return [big[t * stride:t * stride + n].view(rows, F) for t in range(count)], big
 
 
-def tune_table_layout(ctx, rows, F):
-    """The TF-dense Adam pass streams theta, g, m and v of a table at once (4 reads + 3 writes per element).  How far apart
-    those arrays sit in HBM decides how their channel / bank sequences collide: measured on MI355X, 0.61 to 0.82 ms for the
-    same 1M x 128 table, periodic in the distance (about 6 MiB) -- and with one allocation per array it is the allocator's
-    luck.  So the four arrays of a large table are carved from one allocation and the distance is picked by timing the pass
-    itself on a scratch copy (a dozen candidates, ~0.1 s, once per table shape and process).  Returns the gap in bytes."""
-    key = (int(rows), int(F))
+def tune_table_layout(ctx, rows, F, compact=False):
+    """The TF-dense Adam pass streams theta, g, m and v of a table at once (4 reads + 3 writes per element; with compact
+    gradient rows: theta, m, v and the rows of the batch's users).  How far apart those arrays sit in HBM decides how their
+    channel / bank sequences collide: measured on MI355X, 0.61 to 0.82 ms for the same 1M x 128 table, periodic in the
+    distance (about 6 MiB) -- and with one allocation per array it is the allocator's luck.  So the arrays of a large table
+    are carved from one allocation and the distance is picked by timing the pass itself on a scratch copy (a dozen
+    candidates, ~0.1 s, once per table shape and process).  Returns the gap in bytes."""
+    key = (int(rows), int(F), bool(compact))
     cache = ctx.__dict__.setdefault("_layout_cache", {})
     if key in cache:
         return cache[key]
@@ -388,19 +408,43 @@ def tune_table_layout(ctx, rows, F):
     dev = ctx.device
     dummy = [torch.zeros((64, F), dtype=torch.float32, device=dev) for _ in range(4)] + \
             [torch.zeros(64, dtype=torch.float32, device=dev) for _ in range(4)]
+    uslot = grows = hit = slot = None
+    if compact:
+        # what a step looks like: ~63 % of the rows (1 - 1/e at B = U) carry a gradient row, slots ascending with the user id
+        try:
+            grows = torch.zeros((rows, F), dtype=torch.float32, device=dev)
+        except RuntimeError:
+            cache[key] = 0
+            return 0
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        hit = (torch.rand(rows, generator=g, device=dev) < 0.63).to(torch.int64)
+        slot = torch.arange(rows, dtype=torch.int64, device=dev) * hit
+        uslot = torch.zeros(rows, dtype=torch.int64, device=dev)
     best, best_ms = 0, None
     for mib in _LAYOUT_CANDIDATES_MIB:
         gap = int(mib * (1 << 20))
         try:
-            tabs, big = _strided_tables(rows, F, 4, gap, dev)
+            tabs, big = _strided_tables(rows, F, 3 if compact else 4, gap, dev)
         except RuntimeError:                                      # out of memory for the scratch copy: keep the plain layout
             break
-        c = BprmfState(Gu=tabs[0].data_ptr(), gGu=tabs[1].data_ptr(), mGu=tabs[2].data_ptr(), vGu=tabs[3].data_ptr(),
-                       Gi=dummy[0].data_ptr(), gGi=dummy[1].data_ptr(), mGi=dummy[2].data_ptr(), vGi=dummy[3].data_ptr(),
-                       Bi=dummy[4].data_ptr(), gBi=dummy[5].data_ptr(), mBi=dummy[6].data_ptr(), vBi=dummy[7].data_ptr(),
-                       tGu=None, tGi=None, tBi=None, U=rows, I=64, F=F)
-        run = lambda it: check(ctx.lib.el_bprmf_apply(ctx.handle, ctx.stream(), C.byref(c), 0.001, EL_OPT_ADAM_TF_DENSE, it, 0.001),
-                               "el_bprmf_apply")
+        if compact:
+            c = BprmfState(Gu=tabs[0].data_ptr(), gGu=None, mGu=tabs[1].data_ptr(), vGu=tabs[2].data_ptr(),
+                           uslot=uslot.data_ptr(), gGu_rows=grows.data_ptr(), gGu_cap=rows,
+                           Gi=dummy[0].data_ptr(), gGi=dummy[1].data_ptr(), mGi=dummy[2].data_ptr(), vGi=dummy[3].data_ptr(),
+                           Bi=dummy[4].data_ptr(), gBi=dummy[5].data_ptr(), mBi=dummy[6].data_ptr(), vBi=dummy[7].data_ptr(),
+                           tGu=None, tGi=None, tBi=None, U=rows, I=64, F=F)
+        else:
+            c = BprmfState(Gu=tabs[0].data_ptr(), gGu=tabs[1].data_ptr(), mGu=tabs[2].data_ptr(), vGu=tabs[3].data_ptr(),
+                           Gi=dummy[0].data_ptr(), gGi=dummy[1].data_ptr(), mGi=dummy[2].data_ptr(), vGi=dummy[3].data_ptr(),
+                           Bi=dummy[4].data_ptr(), gBi=dummy[5].data_ptr(), mBi=dummy[6].data_ptr(), vBi=dummy[7].data_ptr(),
+                           tGu=None, tGi=None, tBi=None, U=rows, I=64, F=F)
+
+        def run(it):
+            if compact:
+                torch.add(slot, hit, alpha=it << 32, out=uslot)          # stamps of step `it` on the touched rows
+            check(ctx.lib.el_bprmf_apply(ctx.handle, ctx.stream(), C.byref(c), 0.001, EL_OPT_ADAM_TF_DENSE, it, 0.001), "el_bprmf_apply")
+
         for it in range(2):
             run(it + 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -420,10 +464,19 @@ def tune_table_layout(ctx, rows, F):
 class BprmfDeviceState:
     """Gu/Gi/Bi + gradient accumulators + Adam slots in HBM (BPRMF_batch_model.py:39-44)."""
 
-    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam"):
+    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None):
+        """compact_user_grads: user-row gradients as compact rows + per-user stamps (el_bprmf_state.uslot) instead of a dense
+        [U,F] accumulator -- the dense Adam pass then reads a gradient only for the batch's users and re-zeroes nothing.
+        None = automatic (TF-dense Adam on a user table of >= 64 MB with F % 4 == 0), True / False force it."""
         self.ctx = ctx
         self.opt = OPTIMIZERS[optimizer] if isinstance(optimizer, str) else int(optimizer)
         dev = ctx.device
+        big = int(Gu.shape[0]) * int(Gu.shape[1]) * 4 >= (64 << 20)
+        env = os.environ.get("EL_COMPACT_UGRAD")
+        if compact_user_grads is None and env in ("0", "1"):
+            compact_user_grads = env == "1"
+        self.compact = bool(self.opt == EL_OPT_ADAM_TF_DENSE and int(Gu.shape[1]) % 4 == 0 and optimizer != "sgd_dense" and
+                            (big if compact_user_grads is None else compact_user_grads))
 
         def own(x, dt):
             if isinstance(x, np.ndarray):
@@ -435,18 +488,25 @@ class BprmfDeviceState:
         self.I = self.Gi.shape[0]
         z = torch.zeros_like
         adam = self.opt in (EL_OPT_ADAM_TF_DENSE, EL_OPT_ADAM_LAZY)
+        self.uslot = self.gGu_rows = None
         if self.opt == EL_OPT_ADAM_TF_DENSE and self.U * self.F * 4 >= (64 << 20):
-            # the dense Adam pass streams these four at once: one allocation, tuned distance (tune_table_layout)
-            gap = tune_table_layout(ctx, self.U, self.F)
-            (self.Gu, self.gGu, self.mGu, self.vGu), self._user_block = _strided_tables(self.U, self.F, 4, gap, dev)
+            # the dense Adam pass streams these at once: one allocation, tuned distance (tune_table_layout)
+            gap = tune_table_layout(ctx, self.U, self.F, compact=self.compact)
+            if self.compact:
+                (self.Gu, self.mGu, self.vGu), self._user_block = _strided_tables(self.U, self.F, 3, gap, dev)
+                self.gGu = None
+            else:
+                (self.Gu, self.gGu, self.mGu, self.vGu), self._user_block = _strided_tables(self.U, self.F, 4, gap, dev)
             self.Gu.copy_(Gu if isinstance(Gu, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(Gu)))
             self.layout_gap = gap
         else:
             self.Gu = own(Gu, torch.float32)
-            self.gGu = z(self.Gu)
+            self.gGu = None if self.compact else z(self.Gu)
             self.mGu = z(self.Gu) if adam else None
             self.vGu = z(self.Gu) if adam else None
             self.layout_gap = None
+        if self.compact:
+            self.uslot = torch.zeros(self.U, dtype=torch.int64, device=dev)       # (step << 32) | slot; step 0 is never used
         # item-side gradients in ONE buffer (gGi rows, then gBi): a data-parallel caller all-reduces `item_grad_flat` once
         rows_end = (self.I * self.F + 3) // 4 * 4                       # gBi starts on a 16-byte boundary
         self.item_grad_flat = torch.zeros(rows_end + self.I, dtype=torch.float32, device=dev)
@@ -461,16 +521,49 @@ class BprmfDeviceState:
         self.tGi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
         self.tBi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.step = 0
+        self._step = 0
         self._ws = None
         self._c = BprmfState(
             Gu=self.Gu.data_ptr(), Gi=self.Gi.data_ptr(), Bi=self.Bi.data_ptr(),
-            gGu=self.gGu.data_ptr(), gGi=self.gGi.data_ptr(), gBi=self.gBi.data_ptr(),
+            gGu=self.gGu.data_ptr() if self.gGu is not None else None, gGi=self.gGi.data_ptr(), gBi=self.gBi.data_ptr(),
+            uslot=self.uslot.data_ptr() if self.compact else None, gGu_rows=None, gGu_cap=0,
             mGu=self.mGu.data_ptr() if adam else None, vGu=self.vGu.data_ptr() if adam else None,
             mGi=self.mGi.data_ptr() if adam else None, vGi=self.vGi.data_ptr() if adam else None,
             mBi=self.mBi.data_ptr() if adam else None, vBi=self.vBi.data_ptr() if adam else None,
             tGu=self.tGu.data_ptr() if rows else None, tGi=self.tGi.data_ptr() if rows else None,
             tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F)
+
+    @property
+    def step(self):
+        return self._step
+
+    @step.setter
+    def step(self, value):
+        value = int(value)
+        if self.compact and value < self._step:
+            self.uslot.zero_()                 # stamps of later steps must not be mistaken for this step's gradient rows
+        self._step = value
+
+    def ensure_rows(self, B):
+        """Compact mode: gradient rows for a batch of B triplets (slot = sorted position of a user's first occurrence)."""
+        if self.compact and (self.gGu_rows is None or self.gGu_rows.shape[0] < B):
+            self.gGu_rows = torch.empty((int(B), self.F), dtype=torch.float32, device=self.ctx.device)
+            self._c.gGu_rows = self.gGu_rows.data_ptr()
+            self._c.gGu_cap = int(B)
+            for c in getattr(self, "_c_clones", ()):                      # (multi-GPU: split user / item apply states)
+                c.gGu_rows, c.gGu_cap = self._c.gGu_rows, self._c.gGu_cap
+
+    def user_grad_dense(self):
+        """Dense [U,F] view of the user-row gradients of the LAST gradient pass (tests / diagnostics): the accumulator itself, or
+        the compact rows scattered by their stamps."""
+        if not self.compact:
+            return self.gGu
+        out = torch.zeros((self.U, self.F), dtype=torch.float32, device=self.ctx.device)
+        ent = self.uslot
+        hit = (ent >> 32) == max(int(self.uslot.max().item()) >> 32, 1)
+        rows = torch.nonzero(hit).flatten()
+        out[rows] = self.gGu_rows[(ent[rows] & 0xFFFFFFFF)]
+        return out
 
     def train_step(self, u, i, j, lr, l_w, l_b, algo="auto"):
         """BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80).  u,i,j: int32 device tensors.
@@ -480,7 +573,11 @@ class BprmfDeviceState:
         lr_t = adam_lr_t(lr, self.step)
         algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
         ws, ws_bytes = None, 0
-        if algo == _lib.EL_BPR_SORTED or (algo == _lib.EL_BPR_AUTO and B >= 2048):
+        if self.compact:
+            if algo == _lib.EL_BPR_ATOMIC:
+                raise ValueError("compact user-gradient rows need the sorted gradient path")
+            self.ensure_rows(B)
+        if algo == _lib.EL_BPR_SORTED or (algo == _lib.EL_BPR_AUTO and B >= 2048) or self.compact:
             need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
@@ -492,6 +589,25 @@ class BprmfDeviceState:
                                                algo, ws, ws_bytes),
               "el_bprmf_train_step")
 
+    def grads(self, u, i, j, l_w, l_b):
+        """First half of train_step: loss + the summed row gradients of the batch (what OptimizerV2 receives after its segment
+        sum, BPRMF_batch_model.py:77) into gGu (or the compact rows) / gGi / gBi, no optimiser.  apply() consumes them."""
+        B = u.numel()
+        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+        self.ensure_rows(B)
+        check(self.ctx.lib.el_bprmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
+                                          _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(l_w), float(l_b),
+                                          int(self.step + 1), _ptr(self.loss, torch.float64), C.c_void_p(self._ws.data_ptr()),
+                                          self._ws.numel()), "el_bprmf_grads")
+
+    def apply(self, lr):
+        """Second half: the optimiser (TF-dense Adam / dense SGD) on the accumulated gradients; accumulators come back clean."""
+        self.step += 1
+        check(self.ctx.lib.el_bprmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), float(lr), int(self.opt),
+                                          int(self.step), float(adam_lr_t(lr, self.step))), "el_bprmf_apply")
+
     def train_loop(self, pos, events, B, seed, first_sample, lr, l_w, l_b, algo="auto"):
         """One epoch of `for batch in sampler.step(events, B): train_step(batch)` (BPRMF_batch.py:100-109) from a single
         library call: the same Philox stream and the same kernels as the per-batch calls, no host round trip in between."""
@@ -501,8 +617,10 @@ class BprmfDeviceState:
         if pos.n_rows != self.U or pos.n_cols != self.I:
             raise ValueError("train_loop: the positives' CSR must describe this state's users x items")
         algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
-        lr_t = np.array([adam_lr_t(lr, self.step + 1 + k) for k in range(steps)], dtype=np.float32)
-        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))) if B >= 2048 else 0
+        lr_t = self._lr_t_host = np.array([adam_lr_t(lr, self.step + 1 + k) for k in range(steps)], dtype=np.float32)
+        # (kept alive on self: the library may copy the table with an asynchronous memcpy on the stream)
+        self.ensure_rows(B)
+        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))) if (B >= 2048 or self.compact) else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         lneed = int(self.ctx.lib.el_bprmf_train_loop_ws_bytes(int(events), int(B)))
@@ -734,7 +852,8 @@ class NmfDeviceState:
         self.ctx = ctx
         dev = ctx.device
         self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
-        f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) if isinstance(x, np.ndarray) \
+            else x.to(device=dev, dtype=torch.float32).contiguous().clone()
         self.use_mf = "Umf" in weights
         self.use_mlp = "Umlp" in weights
         self.head_bias = "hb" in weights
@@ -1063,7 +1182,7 @@ class CmlDeviceState(BprmfDeviceState):
     """CML_model's variables (Gu, Gi, Bi) + Adam slots: the BPR state with the metric-learning step and scoring."""
 
     def __init__(self, ctx, Gu, Gi, Bi):
-        super().__init__(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+        super().__init__(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=False)
         self._cml_ws = None
         self._items2 = None
 

@@ -141,7 +141,8 @@ class HipBackend:
         if optimizer not in ("adam", "adam_tf_dense", "sgd"):
             raise ValueError("item-sharded training supports the dense optimisers (adam_tf_dense, sgd)")
         self.ctx = ctx
-        self.state = ops.BprmfDeviceState(ctx, Gu, Gi_shard, Bi_shard, optimizer="sgd_dense" if optimizer == "sgd" else optimizer)
+        self.state = ops.BprmfDeviceState(ctx, Gu, Gi_shard, Bi_shard, optimizer="sgd_dense" if optimizer == "sgd" else optimizer,
+                                          compact_user_grads=False)     # el_rows_segment_sum fills the dense accumulator
         self._ws = None
         self._ws2 = None
         self._dU = None
@@ -325,6 +326,7 @@ class HipUserShardBackend:
         st, ctx = self.state, self.ctx
         B = u_local.numel()
         self._workspace(B)
+        st.ensure_rows(B)                                       # (compact user-gradient rows: one slot per sorted position)
         fn = ctx.lib.el_bprmf_grads_presorted if presorted else ctx.lib.el_bprmf_grads
         ops.check(fn(ctx.handle, ctx.stream(), C.byref(st._c), ops._ptr(u_local, torch.int32), ops._ptr(i, torch.int32),
                      ops._ptr(j, torch.int32), int(B), float(l_w), float(l_b), int(st.step + 1), ops._ptr(st.loss, torch.float64),
@@ -353,6 +355,7 @@ class HipUserShardBackend:
             self._c_users, self._c_items = clone(self.state._c), clone(self.state._c)
             self._c_users.I = 0                                 # zero-length item passes
             self._c_items.U = 0
+            self.state._c_clones = (self._c_users, self._c_items)
         self._apply(self._c_users, lr)
 
     def apply_items(self, lr):

@@ -124,6 +124,17 @@ typedef struct el_bprmf_state {
     int32_t* tBi; /* [I] */
     int64_t U, I;
     int32_t F;
+    /* Optional compact user-gradient rows (NULL = the dense accumulator gGu is used; the default).  TensorFlow hands the
+     * optimiser IndexedSlices -- one summed row per DISTINCT user of the batch (BPRMF_batch_model.py:77-78) -- and this is
+     * that form: the sorted gradient path writes the row of the user whose segment starts at sorted position h to
+     * gGu_rows[h, :] and stamps uslot[user] = (step << 32) | h; the TF-dense Adam pass reads a gradient row only where the
+     * stamp carries the current step (every other row has g = 0) and nothing is re-zeroed.  HBM traffic of the pass drops
+     * from 32 to ~26.5 bytes per parameter at the BASELINE configs[1] shape.  Requires F % 4 == 0, 16-byte aligned tables,
+     * EL_OPT_ADAM_TF_DENSE and the SORTED gradient path (gGu may then be NULL); uslot is zero-initialised by the caller and
+     * must be zeroed again whenever the step counter is moved backwards.                                             */
+    int64_t* uslot;   /* [U] (step << 32) | slot */
+    float* gGu_rows;  /* [gGu_cap, F] */
+    int64_t gGu_cap;  /* rows of gGu_rows, >= the batch size of every step */
 } el_bprmf_state;
 
 /* How the duplicate-row gradient sum (OptimizerV2's segment-sum of IndexedSlices) is formed. */
@@ -572,6 +583,17 @@ int el_rec_metrics(el_ctx* ctx, void* stream, const int32_t* rec_idx, int64_t ld
                    const int64_t* test_indptr, const int32_t* test_indices, const float* test_ratings,
                    double threshold, int32_t cutoff, const double* discount, double* sums, double* per_user,
                    void* ws, size_t ws_bytes);
+
+/* Fragile-user report (BASELINE.md "fragile near-tie users reported separately").  The reference scores
+ * with tf.matmul (BPRMF_batch_model.py:83-84), whose fp32 summation order is unknowable here; the kernels pin the k-ordered
+ * fma chain.  Any two fp32 evaluations of <u,i> differ by at most F 2^-23 |u||i|, so a user's top-k SET does not depend on
+ * the order when  val[k-1] - val[k] >= F 2^-23 |u| max(|i_k|, |i_k+1|).  From [u_stop-u_start, ld] lists of el_score_topk
+ * with ld >= k + 1 (ask for k + 1 entries):
+ *   counts[0] += users for whom the bound does NOT hold ("fragile"), counts[1] += users with fewer than k + 1 candidates
+ *   flags     optional uint8 [u_stop-u_start]: 1 = fragile                                                              */
+int el_topk_fragile(el_ctx* ctx, void* stream, const float* Gu, const float* Gi, int32_t F, int64_t u_start, int64_t u_stop,
+                    const int32_t* idx, const float* val, int64_t ld, int32_t k, int64_t item_offset,
+                    unsigned char* flags, uint64_t* counts);
 
 #ifdef __cplusplus
 }

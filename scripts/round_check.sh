@@ -1,12 +1,16 @@
 #!/bin/bash
 # Full GPU check: parity tests, smoke, bench line, rocprofv3 kernel stats of the bench command.
+#   usage (through gpurun): bash scripts/round_check.sh <tag> [traffic]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-x}
 cd $R
 mkdir -p gpurun_out/$TAG
-(timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -15) > gpurun_out/$TAG/pytest.log
+(timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -x 2>&1 | tail -25) > gpurun_out/$TAG/pytest.log
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > gpurun_out/$TAG/smoke.log
-(timeout 400 python bench.py 2>&1 | tail -2) > gpurun_out/$TAG/bench.log
+(timeout 600 python bench.py 2> gpurun_out/$TAG/bench.err | tail -1) > gpurun_out/$TAG/bench_line.json
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/$TAG/bench_prof.log 2>&1
-tail -3 gpurun_out/$TAG/pytest.log; tail -1 gpurun_out/$TAG/smoke.log; tail -1 gpurun_out/$TAG/bench.log | cut -c1-1500
+python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline ($TAG)" > gpurun_out/$TAG/bench_kernel_stats.md 2>&1
+rm -rf gpurun_out/$TAG/prof
+if [ "$2" = "traffic" ]; then bash scripts/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1; fi
+tail -4 gpurun_out/$TAG/pytest.log; tail -1 gpurun_out/$TAG/smoke.log; cut -c1-1800 gpurun_out/$TAG/bench_line.json; tail -5 gpurun_out/$TAG/bench.err

@@ -11,14 +11,22 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
+def run_bench(*extra, env=None):
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--users", "60000", "--items", "8000", "--factors", "64", "--batch", "65536",
-           "--topk-block", "16384", "--steps", "3", "--warmup", "1", "--cpu-topk-users", "32", *extra]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO)
-    assert out.returncode == 0, out.stderr[-2000:]
+           "--topk-block", "16384", "--steps", "3", "--warmup", "1", "--cpu-topk-users", "32", "--cpu-seconds", "0.5", *extra]
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=e)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     return json.loads(lines[0])
+
+
+def check_roofline(r):
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["achieved"] > 0 and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and "kernel" in r
 
 
 def check_common(d, n_gpus=1):
@@ -26,26 +34,62 @@ def check_common(d, n_gpus=1):
                 "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == n_gpus and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["world_size_observed"] == n_gpus
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - d["config"]["batch"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(d["value"] - n_gpus * d["config"]["batch"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     for r in (d["roofline"], d["topk"]["roofline"]):
-        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-        assert r["achieved"] > 0 and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-        assert "traffic" in r and "kernel" in r
+        check_roofline(r)
     assert d["topk"]["value"] > 0 and d["topk"]["unit"] == "users/s"
 
 
 def test_default_line_has_every_field():
-    d = run_bench()
+    d = run_bench("--legs", "bpr,metrics")
     check_common(d)
     cb = d["cpu_baseline"]
-    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] == os.cpu_count() and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
     assert cb["topk"]["value"] > 0 and cb["topk"]["unit"] == "users/s"
-    assert d["value"] > 50 * cb["value"]                      # (sanity, not a claim: the roofline fraction is the quality number)
+    assert cb["port_1core"]["cores"] == 1 and cb["port_1core"]["value"] > 0 and cb["port_1core"]["topk"]["value"] > 0
+    assert d["metrics"]["value"] > 0
+    fr = d["topk"]["fragile_users"]
+    assert fr["users"] == d["config"]["topk_block"] and 0 <= fr["fragile"] <= fr["users"]
+
+
+def test_secondary_legs_carry_their_rooflines():
+    """vae = BASELINE configs[2], neumf = configs[3] per-GPU shape; here at toy shapes (the default shapes run in bench.py itself)."""
+    d = run_bench("--legs", "bpr,vae,neumf", "--no-cpu-baseline", "--vae-shape", "3000,1500,96,32,256", "--neumf-shape", "5000,3000,32,8192")
+    check_common(d)
+    for leg, unit in (("vae", "users/s"), ("neumf", "samples/s")):
+        assert d[leg]["value"] > 0 and d[leg]["unit"] == unit and d[leg]["workload"]
+        check_roofline(d[leg]["roofline"])
+        assert d[leg]["roofline"]["bound"] == "mfma" and d[leg]["roofline"]["kernel"] == "k_gemm_f32"
 
 
 def test_one_rank_sharded_path_prints_the_same_contract():
     d = run_bench("--force-sharded", "--no-cpu-baseline")
     check_common(d)
-    assert d["topk"]["sharding"]                              # (world 1: the line still says "single"; the N > 1 code ran through RCCL)
+    assert d["topk"]["sharding"]                              # (world 1: the N > 1 code ran through RCCL)
+    assert d["collectives"] and d["collectives"][0]["op"] == "all_reduce" and d["collectives"][0]["bytes"] > 0
+
+
+def test_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` without torchrun in front: bench.py starts the ranks itself and rank 0 prints n_gpus == 2.  The
+    dev box has ONE GPU, so both ranks share cuda:0 over gloo (EL_BENCH_SHARED_GPU=1): the control flow, not a measurement."""
+    d = run_bench("--gpus", "2", "--no-cpu-baseline", env={"EL_BENCH_SHARED_GPU": "1"})
+    check_common(d, n_gpus=2)
+    assert d["config"]["backend"] == "gloo"
+    assert d["collectives"][0]["op"] == "all_reduce" and d["collectives"][0]["ms"] > 0
+    sec = d["item_shard"]                                     # north_star's partitioning as the second leg
+    assert sec["value"] > 0 and sec["topk"]["value"] > 0 and sec["topk"]["scaling"] == "strong"
+    ops_seen = {c["op"] for c in sec["collectives"]}
+    assert "all_gather" in ops_seen and all(c["bytes"] > 0 and c["ms"] > 0 for c in sec["collectives"])
+    check_roofline(sec["roofline"])
+
+
+def test_refuses_more_gpus_than_the_node_has():
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64"]
+    e = dict(os.environ)
+    e.pop("EL_BENCH_SHARED_GPU", None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=REPO, env=e)
+    assert out.returncode != 0 and "refusing" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

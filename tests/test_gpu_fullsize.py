@@ -87,8 +87,86 @@ def test_fullsize_sampler_and_train_step_properties(ctx, world):
     assert float(di.max()) <= lr * (1 + 1e-3)
     if bool((~touched_i).any()):
         assert float(di[~touched_i].max()) == 0.0
-    assert not bool(st.gGu.any()) and not bool(st.gGi.any())                      # accumulators zero on exit
+    assert (st.gGu is None or not bool(st.gGu.any())) and not bool(st.gGi.any())   # accumulators zero on exit
     world["trained"] = True
+
+
+def _oracle_rows(Gu0, Gi0, Bi0, u, i, j, su, si, l_w, l_b):
+    """Oracle gradients (oracle/bprmf_batch.py, fp32 and fp64) of the sampled user rows `su` / item rows `si` (device int64
+    tensors): every triplet of the batch that touches a sampled row is pulled out and re-indexed into small tables that hold
+    just the rows those triplets reference -- for the sampled rows the sub-batch gradient IS the full-batch gradient."""
+    from oracle import bprmf_batch as ob
+    dev = u.device
+    mu = torch.zeros(U, dtype=torch.bool, device=dev)
+    mu[su] = True
+    mi = torch.zeros(I, dtype=torch.bool, device=dev)
+    mi[si] = True
+    sel = torch.nonzero(mu[u.long()] | mi[i.long()] | mi[j.long()]).flatten()
+    uu, ii, jj = u[sel].long(), i[sel].long(), j[sel].long()
+    users = torch.unique(torch.cat([uu, su]))
+    items = torch.unique(torch.cat([ii, jj, si]))
+    ru = torch.full((U,), -1, dtype=torch.int64, device=dev)
+    ru[users] = torch.arange(users.numel(), device=dev)
+    ri = torch.full((I,), -1, dtype=torch.int64, device=dev)
+    ri[items] = torch.arange(items.numel(), device=dev)
+    gu_s, gi_s, bi_s = cpu(Gu0[users]), cpu(Gi0[items]), cpu(Bi0[items])
+    a = (cpu(ru[uu]), cpu(ri[ii]), cpu(ri[jj]))
+    g32 = ob.gradients(gu_s, gi_s, bi_s, *a, l_w, l_b)                      # (dBi, dGu, dGi)
+    g64 = ob.gradients(gu_s, gi_s, bi_s, *a, l_w, l_b, dtype=np.float64)
+    pu, pi = cpu(ru[su]), cpu(ri[si])
+    return {"n": int(sel.numel()),
+            "gGu": (g32[1][pu], g64[1][pu]), "gGi": (g32[2][pi], g64[2][pi]), "gBi": (g32[0][pi], g64[0][pi])}
+
+
+def test_fullsize_gradients_and_weights_on_sampled_rows(ctx):
+    """configs[1] training parity beyond the loss: three steps at B = 2^20 on the 1M x 100K x 128 tables; at every step the
+    PRE-optimiser gradients gGu / gGi / gBi of 2048 random user rows, 2048 random item rows and the 8 HOTTEST item rows
+    (tens of thousands of occurrences each: chunk-crossing segments, the 32-bit U + item sort keys, hot-row combines)
+    against oracle/bprmf_batch.py evaluated on exactly the triplets that touch those rows; after the three steps the
+    weights of the same rows against the oracle's Keras-Adam recurrence fed with the oracle's gradients.
+    Tolerances: gradients 2e-5 of the tensor's largest sampled entry or 4x the oracle's own fp32-vs-fp64 distance (fp32
+    summation order is the only freedom); weights: at most 2e-4 of the entries off by more than 2e-5 (Adam's m/(sqrt(v)+eps)
+    flips where a sum cancels to ~0), none by more than 3 lr."""
+    from oracle import bprmf_batch as ob
+    dev = ctx.device
+    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+    pos = ops.DeviceCSR.from_tensors(indptr, indices, I)
+    g = torch.Generator(device=dev)
+    g.manual_seed(43)
+    Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * 0.05
+    Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * 0.05
+    Bi = (torch.rand(I, generator=g, device=dev) - 0.5) * 0.02
+    st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    assert st.compact                                        # what bench.py runs at this size
+    del Gu, Gi, Bi
+    lr, l_w, l_b = 0.001, 0.1, 0.001
+    t0 = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=0)
+    hot = torch.argsort(torch.bincount(torch.cat([t0[1], t0[2]]).long(), minlength=I), descending=True)[:8]
+    su = torch.randperm(U, generator=g, device=dev)[:2048]
+    si = torch.unique(torch.cat([torch.randperm(I, generator=g, device=dev)[:2048], hot]))
+    th = {"Gu": cpu(st.Gu[su]), "Gi": cpu(st.Gi[si]), "Bi": cpu(st.Bi[si])}
+    m = {k: np.zeros_like(x) for k, x in th.items()}
+    v = {k: np.zeros_like(x) for k, x in th.items()}
+    for step in range(3):
+        u, i, j = t0 if step == 0 else ops.bpr_sample(ctx, pos, B, seed=42, first_sample=step * B)
+        exp = _oracle_rows(st.Gu, st.Gi, st.Bi, u, i, j, su, si, l_w, l_b)
+        assert exp["n"] > 100_000                            # the hot rows really are hot
+        st.grads(u, i, j, l_w, l_b)
+        got = {"gGu": cpu(st.user_grad_dense()[su]), "gGi": cpu(st.gGi[si]), "gBi": cpu(st.gBi[si])}
+        for name in ("gGu", "gGi", "gBi"):
+            e32, e64 = exp[name]
+            scale = float(np.abs(e64).max())
+            err = float(np.abs(got[name] - e64).max())
+            ref_err = float(np.abs(e32.astype(np.float64) - e64).max())
+            assert err <= max(2e-5 * scale, 4 * ref_err), (step, name, err, ref_err, scale)
+        st.apply(lr)
+        for name, gname in (("Gu", "gGu"), ("Gi", "gGi"), ("Bi", "gBi")):
+            ob.adam_tf_sparse_apply(th[name], m[name], v[name], exp[gname][0].astype(np.float32), lr, step + 1)
+    st.pop_loss()
+    for name, rows in (("Gu", su), ("Gi", si), ("Bi", si)):
+        gotw = cpu(getattr(st, name)[rows])
+        err = np.abs(gotw - th[name])
+        assert float((err > 2e-5).mean()) <= 2e-4 and float(err.max()) < 3 * lr, (name, float(err.max()), float((err > 2e-5).mean()))
 
 
 def test_fullsize_topk_properties(ctx, world):

@@ -317,3 +317,30 @@ def test_items_unchanged_flag_reuses_only_a_matching_image(ctx):
     e = ops.score_topk(ctx, Gu, Gi2[:2000].contiguous(), Bi[:2000].contiguous(), 0, 350, k, algo="screen", items_unchanged=True)
     f = ops.score_topk(ctx, Gu, Gi2[:2000].contiguous(), Bi[:2000].contiguous(), 0, 350, k, algo="mfma")
     assert torch.equal(e[0], f[0]) and torch.equal(e[1], f[1])
+
+
+def test_fragile_user_report_matches_numpy(ctx):
+    """el_topk_fragile: users whose rank-k / k+1 gap is inside F 2^-23 |u| max|i| -- counted exactly like a NumPy
+    evaluation of the same bound on the oracle's k+1 lists; a planted exact tie is always fragile."""
+    rs = np.random.RandomState(11)
+    U, I, F, k = 700, 900, 64, 10
+    Gu = rs.normal(size=(U, F)).astype(np.float32)
+    Gi = rs.normal(size=(I, F)).astype(np.float32) * 0.01      # small item norms: many gaps inside the bound
+    Bi = np.zeros(I, np.float32)
+    Gi[5] = Gi[17]                                             # exact tie for every user
+    indptr, indices = random_excl(rs, U, I, 0, 8)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    d = ctx.device
+    rep, flags = ops.fragile_users(ctx, torch.from_numpy(Gu).to(d), torch.from_numpy(Gi).to(d), torch.from_numpy(Bi).to(d), 0, U, k,
+                                   excl=pos, flags=True)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k + 1, excl=(indptr, indices))
+    nu = np.sqrt((Gu.astype(np.float64) ** 2).sum(1))
+    ni = np.sqrt((Gi.astype(np.float64) ** 2).sum(1))
+    bound = F * 2.0 ** -23 * nu * np.maximum(ni[ei[:, k - 1]], ni[ei[:, k]])
+    exp = (ev[:, k - 1].astype(np.float64) - ev[:, k].astype(np.float64)) < bound
+    got = cpu(flags).astype(bool)
+    assert np.array_equal(got, exp)
+    assert rep["fragile"] == int(exp.sum()) and rep["users"] == U and rep["short_lists"] == 0
+    tie_rows = np.where((ei[:, k - 1] == 5) & (ei[:, k] == 17))[0]
+    assert all(got[r] for r in tie_rows)
+    assert 0 < rep["fragile"] < U
