@@ -268,9 +268,9 @@ def cpu_baseline(args, host):
     from oracle import bprmf_batch as ob
     from oracle import cref
     from oracle import torch_cpu as tc
-    cores = tc.use_all_cores()
+    cores = tc.use_all_cores()                               # affinity mask / cgroup quota, not os.cpu_count()
     budget = args.cpu_seconds
-    out = {"kind": "port", "cores": cores, "unit": "pairs/s"}
+    out = {"kind": "port", "cores": cores, "host_cpu_count": os.cpu_count(), "unit": "pairs/s"}
     rs = np.random.RandomState(0)
     B = args.batch
     u = torch.from_numpy(rs.randint(0, args.users, B))

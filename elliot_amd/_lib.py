@@ -98,6 +98,7 @@ PROTOTYPES = {
     "el_abi_version": (C.c_int, []),
     "el_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "el_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "el_tuning_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "el_timing_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "el_bpr_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),

@@ -21,6 +21,7 @@ struct el_ctx {
     char arch[64];
     // optional per-kernel timing (el_timing_enable): hipEvents recorded on the launch stream
     bool timing;
+    bool tuning = false;   // el_tuning_mode: optimiser launches use the *_tune kernel instantiations
     std::vector<el_timing_rec> pending;
     std::vector<hipEvent_t> pool;
     // screened top-k: what the item-side image in the last workspace was derived from (EL_TOPK_ITEMS_UNCHANGED)

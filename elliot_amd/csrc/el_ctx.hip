@@ -57,6 +57,12 @@ extern "C" int el_timing_enable(el_ctx* ctx, int on) {
     return 0;
 }
 
+extern "C" int el_tuning_mode(el_ctx* ctx, int on) {
+    EL_REQUIRE(ctx != nullptr, "el_tuning_mode: null ctx");
+    ctx->tuning = on != 0;
+    return 0;
+}
+
 // Synchronises the recorded events and writes "name count total_ms\n" lines (aggregated per kernel
 // name) into buf; clears the records.
 extern "C" int el_timing_report(el_ctx* ctx, char* buf, int len) {

@@ -422,6 +422,7 @@ def tune_table_layout(ctx, rows, F, compact=False):
         slot = torch.arange(rows, dtype=torch.int64, device=dev) * hit
         uslot = torch.zeros(rows, dtype=torch.int64, device=dev)
     best, best_ms = 0, None
+    check(ctx.lib.el_tuning_mode(ctx.handle, 1), "el_tuning_mode")      # probes under their own kernel symbols (profiles)
     for mib in _LAYOUT_CANDIDATES_MIB:
         gap = int(mib * (1 << 20))
         try:
@@ -457,6 +458,7 @@ def tune_table_layout(ctx, rows, F, compact=False):
         if best_ms is None or ms < best_ms:
             best, best_ms = gap, ms
         del tabs, big
+    check(ctx.lib.el_tuning_mode(ctx.handle, 0), "el_tuning_mode")
     cache[key] = best
     return best
 

@@ -53,6 +53,10 @@ int el_device_info(el_ctx* ctx, char* name, int len, int* cus, int64_t* hbm_byte
  * el_timing_report synchronises them and writes "kernel_name launches total_ms\n" lines. */
 int el_timing_enable(el_ctx* ctx, int on);
 int el_timing_report(el_ctx* ctx, char* buf, int len);
+/* Launches of the optimiser passes made while this is on (the HBM placement tuner of the host layer times the dense Adam
+ * pass on scratch tables) carry their own kernel symbols (k_adam_*<..., true>), so that a rocprofv3 kernel trace of a run
+ * lists the product launches and the tuner's probes separately. */
+int el_tuning_mode(el_ctx* ctx, int on);
 
 /* ---- BPR triplet sampler (K1) ------------------------------------------------ */
 

@@ -18,9 +18,29 @@ import torch
 BETA1, BETA2, EPS = 0.9, 0.999, 1e-7
 
 
-def use_all_cores():
+def usable_cores():
+    """Cores this process may actually run on: min(os.cpu_count(), CPU affinity mask, cgroup CPU quota).  A container on a
+    256-thread host with an 8-CPU quota reports os.cpu_count() == 256; 256 OpenMP threads on 8 CPUs run slower than one."""
     n = os.cpu_count() or 1
-    torch.set_num_threads(n)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            quota = float(txt[0]) if txt[0] not in ("max", "-1") else -1.0
+            period = float(txt[1]) if len(txt) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def use_all_cores(n=None):
+    torch.set_num_threads(n or usable_cores())
     return torch.get_num_threads()
 
 
@@ -48,17 +68,25 @@ class BprmfBatchTorchCpu:
         loss = torch.nn.functional.softplus(-dc).sum() + self.l_w * (l2(gu) + l2(gi) + l2(gj)) + self.l_b * l2(bi) + \
             self.l_b * l2(bj) / 10.0
         s = torch.where(d >= -80.0, -torch.sigmoid(-d), torch.zeros_like(d))   # d loss / d difference (clip passes inside)
-        dGu = torch.zeros_like(Gu).index_add_(0, u, s[:, None] * (gi - gj) + self.l_w * gu)
-        dGi = torch.zeros_like(Gi).index_add_(0, i, s[:, None] * gu + self.l_w * gi)
-        dGi.index_add_(0, j, -s[:, None] * gu + self.l_w * gj)
-        dBi = torch.zeros_like(Bi).index_add_(0, i, s + self.l_b * bi)
-        dBi.index_add_(0, j, -s + (self.l_b / 10.0) * bj)
+        # IndexedSlices: one gradient row per batch entry; OptimizerV2 sums duplicate indices (unsorted_segment_sum over the
+        # unique indices) before the sparse apply
+        uu, inv_u = torch.unique(u, return_inverse=True)
+        gU = torch.zeros((uu.numel(), Gu.shape[1])).index_add_(0, inv_u, s[:, None] * (gi - gj) + self.l_w * gu)
+        ij = torch.cat([i, j])
+        ii, inv_i = torch.unique(ij, return_inverse=True)
+        gI = torch.zeros((ii.numel(), Gi.shape[1])).index_add_(0, inv_i, torch.cat([s[:, None] * gu + self.l_w * gi,
+                                                                                 -s[:, None] * gu + self.l_w * gj]))
+        gB = torch.zeros(ii.numel()).index_add_(0, inv_i, torch.cat([s + self.l_b * bi, -s + (self.l_b / 10.0) * bj]))
         self.step += 1
         t = self.step
         lr_t = self.lr * (1.0 - BETA2 ** t) ** 0.5 / (1.0 - BETA1 ** t)
-        for th, g, m, v in zip((Gu, Gi, Bi), (dGu, dGi, dBi), self.m, self.v):   # dense over every row (Keras sparse apply)
-            m.mul_(BETA1).add_(g, alpha=1.0 - BETA1)
-            v.mul_(BETA2).addcmul_(g, g, value=1.0 - BETA2)
+        # Keras Adam._resource_apply_sparse: m <- m b1 (ALL rows); m[idx] += (1-b1) g; v <- v b2 (ALL rows); v[idx] += (1-b2) g^2;
+        # theta <- theta - lr_t m / (sqrt(v) + eps) (ALL rows)
+        for th, idx, g, m, v in ((Gu, uu, gU, self.m[0], self.v[0]), (Gi, ii, gI, self.m[1], self.v[1]), (Bi, ii, gB, self.m[2], self.v[2])):
+            m.mul_(BETA1)
+            m.index_add_(0, idx, g, alpha=1.0 - BETA1)
+            v.mul_(BETA2)
+            v.index_add_(0, idx, g * g, alpha=1.0 - BETA2)
             th.addcdiv_(m, v.sqrt().add_(EPS), value=-lr_t)
         return float(loss)
 

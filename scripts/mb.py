@@ -35,7 +35,11 @@ def main():
     g.manual_seed(1)
     if a.what == "gemm":
         ctx.timing(True)
-        for (M, N, K, tA, tB) in [(512, 26744, 600, 0, 0), (600, 26744, 512, 1, 0), (512, 600, 26744, 0, 1),
+        B2 = 262144
+        for (M, N, K, tA, tB) in [(512, 26744, 600, 0, 0), (600, 26744, 512, 1, 0), (512, 600, 26744, 0, 1),      # Mult-VAE, ML-20M shape
+                                  (512, 400, 600, 0, 0), (512, 600, 200, 0, 0), (600, 400, 512, 1, 0), (512, 600, 400, 0, 1),
+                                  (B2, 512, 256, 0, 0), (B2, 256, 512, 0, 0), (B2, 128, 256, 0, 0),                # NeuMF tower fwd
+                                  (B2, 256, 512, 0, 1), (B2, 512, 256, 0, 1), (256, 512, B2, 1, 0), (512, 256, B2, 1, 0),
                                   (4096, 4096, 4096, 0, 0), (8192, 8192, 1024, 0, 1)]:
             A = torch.randn((K, M) if tA else (M, K), device=dev)
             Bm = torch.randn((N, K) if tB else (K, N), device=dev)

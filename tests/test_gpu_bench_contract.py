@@ -47,7 +47,7 @@ def test_default_line_has_every_field():
     d = run_bench("--legs", "bpr,metrics")
     check_common(d)
     cb = d["cpu_baseline"]
-    assert cb["kind"] in ("port", "reference") and cb["cores"] == os.cpu_count() and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
+    assert cb["kind"] in ("port", "reference") and 1 <= cb["cores"] <= os.cpu_count() and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
     assert cb["topk"]["value"] > 0 and cb["topk"]["unit"] == "users/s"
     assert cb["port_1core"]["cores"] == 1 and cb["port_1core"]["value"] > 0 and cb["port_1core"]["topk"]["value"] > 0
     assert d["metrics"]["value"] > 0
