@@ -22,6 +22,7 @@ struct el_ctx {
     // optional per-kernel timing (el_timing_enable): hipEvents recorded on the launch stream
     bool timing;
     bool tuning = false;   // el_tuning_mode: optimiser launches use the *_tune kernel instantiations
+    float* zeros = nullptr; // 256 bytes of zeros in device memory (source of out-of-range LDS-DMA lanes, el_gemm.hip)
     std::vector<el_timing_rec> pending;
     std::vector<hipEvent_t> pool;
     // screened top-k: what the item-side image in the last workspace was derived from (EL_TOPK_ITEMS_UNCHANGED)

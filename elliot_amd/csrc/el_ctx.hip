@@ -34,6 +34,12 @@ extern "C" int el_ctx_create(int device, el_ctx** out) {
     strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
     c->arch[sizeof(c->arch) - 1] = 0;
     c->timing = false;
+    EL_CHECK_HIP(hipSetDevice(device));
+    if (hipMalloc((void**)&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) {
+        el_set_error("el_ctx_create: cannot allocate the context's scratch on device %d", device);
+        delete c;
+        return 1;
+    }
     *out = c;
     return 0;
 }
@@ -47,6 +53,7 @@ extern "C" int el_ctx_destroy(el_ctx* ctx) {
     }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->loop_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->loop_graph_exec);
+    if (ctx->zeros) (void)hipFree(ctx->zeros);
     delete ctx;
     return 0;
 }

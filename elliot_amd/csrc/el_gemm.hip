@@ -2,21 +2,39 @@
 //
 // The dense layers of the reference's neural latent-factor models are Keras `Dense` calls
 // (multi_vae_model.py:44-53,72-78; neural_matrix_factorization_model.py:59-64): y = act(x W + b) forward and
-// the two transposed products backward.  One tiled kernel serves all of them:
+// the two transposed products backward.  One tiled kernel family serves all of them:
 //   C[M,N] = act( op(A)[M,K] * op(B)[K,N] + bias[N] )
 // op() selects the storage order of each operand (K-contiguous or X-contiguous), so x W, dY W^T and X^T dY
 // run without materialising a transpose.
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of
-// 32x32), BK = 32, both operands staged through LDS with a register prefetch of the next K tile, one
-// __syncthreads per K tile (two LDS buffers).  LDS images are chosen per storage order so that every
-// ds_read_b32 of an MFMA operand is bank-conflict free:
-//   K-contiguous operand  -> tile[X][BK+1]   (read (x, k) at x*33 + k)
-//   X-contiguous operand  -> tile[BK][BX+4]  (read (x, k) at k*132 + x, float4 stores stay 16-B aligned)
+// k_gemm_f32_v<TA, TB, TM, TN> (the aligned fast path: every leading dimension and contiguous extent a multiple of 4
+// floats, 16-byte aligned bases -- all Dense shapes of the models):
+//   * 256 threads = 2 x 2 waves, wave tile (32 TM) x (32 TN), block tile (64 TM) x (64 TN), BK = 32; the host picks
+//     TM, TN in {1, 2} per shape so that the tile count fills the 256 CUs evenly (M = 512 x N = 26 744 is 836 tiles of
+//     128 x 128 = 3.27 per CU, i.e. a 4th round at 27 % occupancy; 1672 tiles of 128 x 64 waste 7 %).
+//   * global -> registers -> LDS staging with one 16-byte load / ds_write_b128 per 4 floats and NO divergent code in
+//     the k loop: a float4 is whole inside or whole outside the matrix (alignment contract), so the bounds test is a
+//     select on the address and on the loaded value.  (The first version tested every float; hipcc turned the tile
+//     fetch into ~9 000 instructions of branches per k tile.)
+//   * LDS images and fragment reads, chosen so that reads are wide AND conflict-free:
+//       K-contiguous operand  -> tile[X][36]: lane (col, hi) reads ONE ds_read_b128 = k 8t+4hi .. 8t+4hi+3 of its row and
+//                                feeds four MFMA k-steps from it (row stride 36 = 4 * 9: the 16 lanes of every b128 lane
+//                                group fall on 16 distinct bank quads);
+//       X-contiguous operand  -> tile[32][BX+4]: lane (col, hi) reads one ds_read_b64 at k = 8t+4hi+j, x = 2 col, 2 col+1
+//                                -- the two values go to the wave's two MFMA tiles, i.e. tile t holds the rows / columns
+//                                x = 2 c + t (a permutation the epilogue undoes; adjacent columns of one lane are then
+//                                stored as one float2).
+//     Both operands use the same k <-> (step, hi) assignment, so every product a_mk b_kn is formed exactly once; inside a
+//     block of 8 k values the accumulation order is (0,4,1,5,2,6,3,7) instead of ascending -- fp32 round-off level, the
+//     parity tests compare against fp64 with a sqrt(K) bound.
+//   * one __syncthreads per k tile (two LDS buffers), next tile's global loads in flight under the MFMAs.
+// k_gemm_f32 (generic path, any alignment): 128 x 128 x 32 tiles, scalar-capable loads, ds_read_b32 fragments.
 // Small-MN / huge-K products (dH = dLogits * W4^T: 512 x 600 x 26744) are split along K over gridDim.z; the
 // partial tiles go to a workspace and k_gemm_reduce sums them in a fixed order (deterministic) and applies the
-// epilogue.  Numerics: fp32 fma chains in k order (MFMA f32 is exact fp32, MI355X_MICROARCH.md).
+// epilogue.  Numerics: MFMA f32 is exact fp32 fma arithmetic (MI355X_MICROARCH.md).
 #include "el_common.h"
+#include <cmath>
+#include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -30,8 +48,12 @@ struct GemmParams {
     int64_t M, N, K, lda, ldb, ldc;
     int act;
     int64_t kchunk;  // K range per blockIdx.z
-    float* ws;       // split-K partials [gridDim.z][M][N] or NULL
+    float* ws;       // split-K partials [gridDim.z][M][N] or NULL; stream-K: partial-tile slots [2 * P][BM * BN]
     int vecA, vecB;
+    // stream-K fast path: the (tile, k tile) units of the whole problem are dealt to P persistent workgroups in contiguous ranges
+    int64_t units, nkt, tiles_n;
+    int P, whole_tiles;
+    const float* zeros;   // >= 16 bytes of zeros in device memory
 };
 
 __device__ __forceinline__ float el_act(float v, int act) {
@@ -194,6 +216,332 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmParams p) {
     }
 }
 
+// ---- aligned fast path --------------------------------------------------------------------------------------------
+// LDS images of one k tile (KB = 32 k values), both UNPADDED so that LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base +
+// lane * 16 bytes, no VGPRs, no ds_write) can fill them:
+//   K-contiguous operand  tile[BX][32]: the 16-byte chunk c4 of row x sits at chunk position c4 ^ ((x >> 1) & 7) -- the
+//                         swizzle is applied to the SOURCE address of each lane (lane -> row = lane/8, position = lane%8), the
+//                         LDS side stays lane-linear.  Lane (col, hi) reads ONE ds_read_b128 = k 8t+4hi .. +3 of its row: the
+//                         16 lanes of every b128 lane group hold 16 distinct (x&1, (x>>1)&7) pairs = 16 distinct bank quads.
+//   X-contiguous operand  tile[32][BX]: lane (col, hi) reads one ds_read_b64 at k = 8t+4hi+j, x = 2 col, 2 col+1 (32 lanes =
+//                         64 consecutive banks); the two values feed the wave's two MFMA tiles, i.e. tile t holds the rows /
+//                         columns x = 2 c + t (a permutation the epilogue undoes; adjacent columns are stored as float2).
+// Both operands use the same k <-> (MFMA step, hi) assignment; inside a block of 8 k values the accumulation order is
+// (0,4,1,5,2,6,3,7) instead of ascending -- fp32 round-off level.
+// Lanes whose float4 lies outside the matrix (M / N edge, K tail) read 16 bytes of zeros instead (el_ctx.zeros): the bounds
+// test is a select on the source address, the k loop has no divergent code.
+constexpr int KB = GBK;
+
+template <bool XC, int BX>
+struct VTile {
+    static constexpr int FLOATS = BX * KB;
+    static constexpr int NDMA = BX * KB / 256 / 4;      // LDS-DMA instructions per wave and k tile (1 KiB each, 4 waves)
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// one operand tile (x0 .. x0+BX-1, k0 .. k0+31) -> LDS, NDMA instructions per wave
+template <bool XC, int BX>
+__device__ __forceinline__ void v_dma(const float* __restrict__ base, int64_t ld, int X, int x0, int K, int k0,
+                                      const float* __restrict__ zeros, float* tile, int wave, int lane, bool live = true) {
+#pragma unroll
+    for (int q = 0; q < VTile<XC, BX>::NDMA; ++q) {
+        const int i = q * 4 + wave;                      // 1 KiB piece of the image
+        int gx, gk;
+        if (!XC) {
+            const int x = 8 * i + (lane >> 3);
+            gx = x0 + x;
+            gk = k0 + 4 * ((lane & 7) ^ ((x >> 1) & 7));
+        } else {
+            const int flat = 64 * i + lane;
+            gk = k0 + flat / (BX / 4);
+            gx = x0 + 4 * (flat % (BX / 4));
+        }
+        const bool ok = live && gx < X && gk < K;
+        const float* src = XC ? base + (int64_t)gk * ld + gx : base + (int64_t)gx * ld + gk;
+        src = ok ? src : zeros;
+        float* dst = tile + 256 * i;                     // wave-uniform; the hardware adds lane * 16 bytes
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    }
+}
+
+// fragments of one operand for the 8 k values of block t8: f[j][t] = value of MFMA k-step j (0..3) for the wave's tile t.
+//   xw = first x of the wave inside the block tile; lane = (col, hi)
+template <bool XC, int BX, int T>
+__device__ __forceinline__ void v_frags(const float* tile, int xw, int col, int hi, int t8, float (&f)[4][T]) {
+    if (!XC) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int x = xw + 32 * t + col;
+            const float4 v = *reinterpret_cast<const float4*>(tile + x * KB + (((2 * t8 + hi) ^ ((x >> 1) & 7)) << 2));
+            f[0][t] = v.x;
+            f[1][t] = v.y;
+            f[2][t] = v.z;
+            f[3][t] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* src = tile + (8 * t8 + 4 * hi + j) * BX + xw + T * col;
+            if (T == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(src);
+                f[j][0] = v.x;
+                f[j][T - 1] = v.y;
+            } else {
+                f[j][0] = src[0];
+            }
+        }
+    }
+}
+
+// TA: A stored [K][M] (M contiguous).  TB: B stored [N][K] (K contiguous).  Block tile (64 TM) x (64 TN), 2 x 2 waves.
+//
+// Persistent schedule.  The work is the list of units (tile t, k tile kt), t-major; workgroup w of P (P = two per CU, all
+// resident at once) owns the contiguous range [w U / P, (w+1) U / P) -- rounded to whole tiles when there are many tiles
+// (p.whole_tiles), to single k tiles ("stream-K") when there are few -- and runs ONE pipeline through it: the LDS-DMA of
+// unit u+1 is issued before the MFMAs of unit u whichever tile u+1 belongs to, so a tile boundary costs an epilogue, not a
+// pipeline restart.  A tile whose k range lies inside one workgroup's range is finished there (bias + activation, stored
+// to C); a tile cut by a range boundary leaves one partial accumulator tile per contributing workgroup in `ws` (slot 2w: the
+// segment that starts w's range, 2w+1: the one that ends it) and k_gemm_sk_fix adds them in workgroup order --
+// deterministic, no spinning on other workgroups.
+template <bool TA, bool TB, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32_v(GemmParams p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr bool AXC = TA, BXC = !TB;
+    typedef VTile<AXC, BM> TlA;
+    typedef VTile<BXC, BN> TlB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);        // [2][TlA::FLOATS]
+    float* Bs = As + 2 * TlA::FLOATS;                  // [2][TlB::FLOATS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, col = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int w = blockIdx.x, nkt = (int)p.nkt, tiles_n = (int)p.tiles_n;
+    int u0, u1;
+    if (p.whole_tiles) {
+        const int T = (int)(p.units / p.nkt);
+        u0 = (int)(((int64_t)w * T) / p.P) * nkt;
+        u1 = (int)(((int64_t)(w + 1) * T) / p.P) * nkt;
+    } else {
+        u0 = (int)(((int64_t)w * p.units) / p.P);
+        u1 = (int)(((int64_t)(w + 1) * p.units) / p.P);
+    }
+    if (u0 >= u1) return;
+    const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    int tile = u0 / nkt;
+    int kt = u0 - tile * nkt;
+    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    v_dma<AXC, BM>(p.A, p.lda, M, m0, K, kt * KB, p.zeros, As, wave, lane);
+    v_dma<BXC, BN>(p.B, p.ldb, N, n0, K, kt * KB, p.zeros, Bs, wave, lane);
+    int buf = 0;
+    for (int u = u0; u < u1; ++u) {
+        __syncthreads();                                // unit u has landed (vmcnt(0) + barrier); buffer buf^1 is free again
+        // next unit (possibly the first k tile of the next output tile)
+        int ntile = tile, nk = kt + 1;
+        if (nk == nkt) {
+            nk = 0;
+            ntile = tile + 1;
+        }
+        const int nm0 = (ntile / tiles_n) * BM, nn0 = (ntile % tiles_n) * BN;
+        const bool more = u + 1 < u1;                   // (the last unit "prefetches" zeros: no branch in the loop body)
+        const float* At = As + buf * TlA::FLOATS;
+        const float* Bt = Bs + buf * TlB::FLOATS;
+#pragma unroll
+        for (int t8 = 0; t8 < KB / 8; ++t8) {
+            float fa[4][TM], fb[4][TN];
+            v_frags<AXC, BM, TM>(At, wr * 32 * TM, col, hi, t8, fa);
+            v_frags<BXC, BN, TN>(Bt, wc * 32 * TN, col, hi, t8, fb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][ta], fb[j][tb], acc[ta][tb], 0, 0, 0);
+            if (t8 == 0) {                              // the next unit's LDS-DMA goes out behind the first MFMAs of this one
+                v_dma<AXC, BM>(p.A, p.lda, M, nm0, K, nk * KB, p.zeros, As + (buf ^ 1) * TlA::FLOATS, wave, lane, more);
+                v_dma<BXC, BN>(p.B, p.ldb, N, nn0, K, nk * KB, p.zeros, Bs + (buf ^ 1) * TlB::FLOATS, wave, lane, more);
+            }
+        }
+        buf ^= 1;
+        if (kt == nkt - 1 || u == u1 - 1) {
+            // the segment of `tile` inside this range ends here.  MFMA D: lane holds column c = col of its tile, rows
+            // rr = (r&3) + 8*(r>>2) + 4*hi.  Tile t of an X-contiguous operand holds x = T c + t (v_frags), of a K-contiguous
+            // one x = 32 t + c.
+            const int seg0 = tile * nkt > u0 ? tile * nkt : u0;
+            const bool whole = seg0 == tile * nkt && kt == nkt - 1;
+            if (!whole) {
+                // partial accumulators in REGISTER order (k_gemm_sk_fix knows the layout): 16 fully coalesced 16-byte stores
+                float* slot = p.ws + (int64_t)(2 * w + (seg0 == u0 ? 0 : 1)) * (BM * BN);
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int q = (ta * TN + tb) * 4 + g;
+                            *reinterpret_cast<float4*>(slot + ((int64_t)q * 256 + tid) * 4) =
+                                make_float4(acc[ta][tb][4 * g], acc[ta][tb][4 * g + 1], acc[ta][tb][4 * g + 2], acc[ta][tb][4 * g + 3]);
+                        }
+            } else {
+                float* out = p.C + (int64_t)m0 * p.ldc + n0;
+                const int64_t ldo = p.ldc;
+                const int mlim = M - m0, nlim = N - n0;
+                if (BXC && TN == 2 && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0)) {
+                    // a lane holds columns 2c, 2c+1 of rows 8g+4hi+{0..3}: lanes c, c^1 swap half of their rows (DPP quad_perm) so
+                    // that each ends up with FOUR adjacent columns of two rows -> 16-byte stores, half the store instructions
+                    // (the store tail of a 64-value-per-lane epilogue is issue-bound: cdna_hip_programming.md T21)
+                    const bool odd = (col & 1) != 0;
+                    const int n = wc * 64 + 2 * (col & ~1);
+                    float b0 = 0.f, b1 = 0.f;
+                    if (p.bias) {
+                        const int nn = wc * 64 + 2 * col;
+                        b0 = nn < nlim ? p.bias[n0 + nn] : 0.f;
+                        b1 = nn + 1 < nlim ? p.bias[n0 + nn + 1] : 0.f;
+                    }
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float o0[4], o1[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                o0[q] = el_act(acc[ta][0][4 * g + q] + b0, p.act);
+                                o1[q] = el_act(acc[ta][TN - 1][4 * g + q] + b1, p.act);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const float k0v = odd ? o0[2 + j] : o0[j], k1v = odd ? o1[2 + j] : o1[j];
+                                const float s0v = odd ? o0[j] : o0[2 + j], s1v = odd ? o1[j] : o1[2 + j];
+                                const float r0v = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0v), 0xB1, 0xF, 0xF, true));
+                                const float r1v = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1v), 0xB1, 0xF, 0xF, true));
+                                const int rr = 8 * g + 4 * hi + (odd ? 2 : 0) + j;
+                                const int m = wr * 32 * TM + (AXC ? TM * rr + ta : 32 * ta + rr);
+                                const float4 v = odd ? make_float4(r0v, r1v, k0v, k1v) : make_float4(k0v, k1v, r0v, r1v);
+                                if (m < mlim) {
+                                    float* dst = out + m * ldo + n;
+                                    if (n + 3 < nlim) {
+                                        *reinterpret_cast<float4*>(dst) = v;
+                                    } else {
+                                        if (n < nlim) dst[0] = v.x;
+                                        if (n + 1 < nlim) dst[1] = v.y;
+                                        if (n + 2 < nlim) dst[2] = v.z;
+                                    }
+                                }
+                            }
+                        }
+                } else {
+                    const bool pair = BXC && TN == 2 && (ldo % 2 == 0) && (((uintptr_t)out & 7) == 0);
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const int m = wr * 32 * TM + (AXC ? TM * rr + ta : 32 * ta + rr);
+                            if (m < mlim) {
+                                float* orow = out + m * ldo;
+                                if (BXC && TN == 2) {
+                                    const int n = wc * 64 + 2 * col;
+                                    const float v0 = el_act(acc[ta][0][r] + ((p.bias && n < nlim) ? p.bias[n0 + n] : 0.f), p.act);
+                                    const float v1 = el_act(acc[ta][TN - 1][r] + ((p.bias && n + 1 < nlim) ? p.bias[n0 + n + 1] : 0.f), p.act);
+                                    if (pair && n + 1 < nlim) {
+                                        *reinterpret_cast<float2*>(orow + n) = make_float2(v0, v1);
+                                    } else {
+                                        if (n < nlim) orow[n] = v0;
+                                        if (n + 1 < nlim) orow[n + 1] = v1;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int tb = 0; tb < TN; ++tb) {
+                                        const int n = wc * 32 * TN + (BXC ? TN * col + tb : 32 * tb + col);
+                                        if (n < nlim) orow[n] = el_act(acc[ta][tb][r] + (p.bias ? p.bias[n0 + n] : 0.f), p.act);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
+        }
+        tile = ntile;
+        kt = nk;
+        m0 = nm0;
+        n0 = nn0;
+    }
+}
+
+// Tiles cut by a range boundary: sum the partial accumulator tiles of the contributing workgroups (ascending), epilogue, store.
+// Partials are in register order: float4 number q * 256 + tid of a slot = accumulator registers 4g .. 4g+3 of MFMA tile
+// (ta, tb) (q = (ta TN + tb) 4 + g) of thread tid.  grid = (tiles, TM 4); tiles finished inside one range return at once.
+template <bool AXC, bool BXC, int TM, int TN>
+__global__ __launch_bounds__(256) void k_gemm_sk_fix(GemmParams p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const int64_t tile = blockIdx.x;
+    const int64_t ua = tile * p.nkt, ub = ua + p.nkt - 1;
+    const int64_t wa = ((ua + 1) * p.P - 1) / p.units, wb = ((ub + 1) * p.P - 1) / p.units;   // owner of a unit x: floor(((x+1) P - 1) / U)
+    if (wa == wb) return;
+    const int64_t m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int64_t sa = (wa * p.units) / p.P;                      // first unit of wa's range
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31, wr = wave >> 1, wc = wave & 1;
+    const int g = blockIdx.y & 3, ta = blockIdx.y >> 2;           // grid.y = TM * 4: one (ta, g) register group, every tb
+    const float* first = p.ws + (2 * wa + (sa == ua ? 0 : 1)) * (int64_t)(BM * BN);
+    float4 acc[TN];
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int64_t e = ((int64_t)((ta * TN + tb) * 4 + g) * 256 + tid) * 4;
+        float4 a = *reinterpret_cast<const float4*>(first + e);
+        for (int64_t w = wa + 1; w <= wb; ++w) {
+            const float4 b = *reinterpret_cast<const float4*>(p.ws + (2 * w) * (int64_t)(BM * BN) + e);
+            a.x += b.x;
+            a.y += b.y;
+            a.z += b.z;
+            a.w += b.w;
+        }
+        acc[tb] = a;
+    }
+    const bool pair = BXC && TN == 2 && (p.ldc % 2 == 0) && (((uintptr_t)p.C & 7) == 0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int rr = 8 * g + 4 * hi + x;
+        const int64_t m = m0 + wr * 32 * TM + (AXC ? TM * rr + ta : 32 * ta + rr);
+        if (m >= p.M) continue;
+        float* orow = p.C + m * p.ldc;
+        float v[TN];
+        int64_t n[TN];
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb) {
+            n[tb] = n0 + wc * 32 * TN + (BXC ? TN * col + tb : 32 * tb + col);
+            const float raw = x == 0 ? acc[tb].x : (x == 1 ? acc[tb].y : (x == 2 ? acc[tb].z : acc[tb].w));
+            v[tb] = el_act(raw + ((p.bias && n[tb] < p.N) ? p.bias[n[tb]] : 0.f), p.act);
+        }
+        if (pair && n[TN - 1] < p.N) {
+            *reinterpret_cast<float2*>(orow + n[0]) = make_float2(v[0], v[TN - 1]);
+        } else {
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb)
+                if (n[tb] < p.N) orow[n[tb]] = v[tb];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_reduce(const float* __restrict__ ws, int splits, int64_t M, int64_t N,
                                                      float* C, int64_t ldc, const float* __restrict__ bias, int act) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,10 +564,73 @@ static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
     return s < 1 ? 1 : (int)s;
 }
 
+// Tile shape of the stream-K fast path: 128 x 128 unless the padding of a narrow M or N to multiples of 128 wastes more than
+// the smaller tile's lower efficiency costs; P = persistent workgroups (two per CU; fewer when there is less work than that).
+struct GemmPlan {
+    int tm, tn, P, whole_tiles;
+    int64_t nkt, tiles_n, units;
+};
+
+static GemmPlan gemm_plan(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
+    GemmPlan pl;
+    auto waste = [](int64_t X, int64_t b) { return (double)((X + b - 1) / b * b) / (double)X; };
+    pl.tm = (waste(M, 128) > 1.12 * waste(M, 64)) ? 1 : 2;
+    pl.tn = (waste(N, 128) > 1.12 * waste(N, 64)) ? 1 : 2;
+    int mode = -1;
+    if (const char* e = getenv("EL_GEMM_TILE")) {                 // experiments: "tm,tn[,whole_tiles]"
+        int tm = 2, tn = 2, wt = -1;
+        if (sscanf(e, "%d,%d,%d", &tm, &tn, &wt) >= 2 && (tm == 1 || tm == 2) && (tn == 1 || tn == 2)) pl.tm = tm, pl.tn = tn, mode = wt;
+    }
+    const int64_t bm = 64 * pl.tm, bn = 64 * pl.tn;
+    pl.nkt = (K + KB - 1) / KB;
+    if (pl.nkt < 1) pl.nkt = 1;
+    pl.tiles_n = (N + bn - 1) / bn;
+    const int64_t tiles = ((M + bm - 1) / bm) * pl.tiles_n;
+    pl.units = tiles * pl.nkt;
+    static const int per_cu = [] { const char* e = getenv("EL_GEMM_WG_PER_CU"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 2; }();
+    static const int min_units = [] { const char* e = getenv("EL_GEMM_MIN_UNITS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+    int64_t P = (int64_t)ctx->cus * per_cu;
+    // whole tiles per workgroup (no partial tiles to combine) when the rounding costs little: >= 8 tiles per workgroup
+    pl.whole_tiles = mode >= 0 ? mode : (tiles >= 8 * P ? 1 : 0);
+    if (pl.whole_tiles) {
+        if (P > tiles) P = tiles;
+    } else {
+        const int64_t cap = (pl.units + min_units - 1) / min_units;        // at least min_units k tiles per workgroup
+        if (P > cap) P = cap;
+    }
+    if (P < 1) P = 1;
+    pl.P = (int)P;
+    return pl;
+}
+
 extern "C" size_t el_gemm_ws_bytes(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
     if (!ctx) return 0;
-    const int s = gemm_splits(ctx, M, N, K);
-    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
+    const int s1 = gemm_splits(ctx, M, N, K);
+    const size_t generic = s1 > 1 ? (size_t)s1 * (size_t)M * (size_t)N * 4 : 0;
+    const size_t sk = (size_t)2 * (size_t)ctx->cus * 2 * 128 * 128 * 4;            // two partial-tile slots per persistent workgroup
+    return generic > sk ? generic : sk;
+}
+
+template <bool TA, bool TB, int TM, int TN>
+static int gemm_launch_v(el_ctx* ctx, const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const size_t lds = (size_t)2 * (VTile<TA, BM>::FLOATS + VTile<!TB, BN>::FLOATS) * 4;
+    auto kern = k_gemm_f32_v<TA, TB, TM, TN>;
+    EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EL_LAUNCH("k_gemm_f32", kern, dim3((unsigned)p.P), dim3(256), lds, s, p);
+    const int64_t tiles = p.units / p.nkt;
+    if (!p.whole_tiles && (p.units % p.P != 0 || (p.units / p.P) % p.nkt != 0))       // some tile is cut by a range boundary
+        EL_LAUNCH("k_gemm_reduce", (k_gemm_sk_fix<TA, !TB, TM, TN>), dim3((unsigned)tiles, (unsigned)(TM * 4)), dim3(256), 0, s, p);
+    (void)ctx;
+    return 0;
+}
+
+template <bool TA, bool TB>
+static int gemm_launch_tile(el_ctx* ctx, const GemmParams& p, const GemmPlan& pl, hipStream_t s) {
+    if (pl.tm == 2 && pl.tn == 2) return gemm_launch_v<TA, TB, 2, 2>(ctx, p, s);
+    if (pl.tm == 2 && pl.tn == 1) return gemm_launch_v<TA, TB, 2, 1>(ctx, p, s);
+    if (pl.tm == 1 && pl.tn == 2) return gemm_launch_v<TA, TB, 1, 2>(ctx, p, s);
+    return gemm_launch_v<TA, TB, 1, 1>(ctx, p, s);
 }
 
 // C[M,N] = act(op(A) op(B) + bias).  transA = 0: A is [M,K] (lda >= K); 1: A is stored [K,M] (lda >= M).
@@ -248,27 +659,50 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
     p.act = act;
     p.vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
-    int splits = gemm_splits(ctx, M, N, K);
-    if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * 4)) splits = 1;
-    p.kchunk = ((K + splits - 1) / splits + GBK - 1) / GBK * GBK;
-    if (p.kchunk < GBK) p.kchunk = GBK;
-    splits = (int)((K + p.kchunk - 1) / p.kchunk);
-    if (splits < 1) splits = 1;
-    p.ws = splits > 1 ? (float*)ws : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((N + GBN - 1) / GBN), (unsigned)((M + GBM - 1) / GBM), (unsigned)splits);
-    const size_t lds = (size_t)4 * G_TILE * 4;
+    // aligned fast path: a float4 of either operand never straddles the matrix edge
+    static const bool fast_on = [] { const char* e = getenv("EL_GEMM_FAST"); return !(e && atoi(e) == 0); }();
+    const bool fast0 = fast_on && p.vecA && p.vecB && K >= 1 && (transA ? M : K) % 4 == 0 && (transB ? K : N) % 4 == 0 &&
+                       M < (1LL << 30) && N < (1LL << 30) && K < (1LL << 30) && ctx->zeros != nullptr;
+    int splits = 1;
+    GemmPlan pl = gemm_plan(ctx, M, N, K);
+    const bool fast = fast0 && ws != nullptr && ws_bytes >= (size_t)2 * pl.P * (64 * pl.tm) * (64 * pl.tn) * 4;
+    if (fast) {
+        p.ws = (float*)ws;
+        p.units = pl.units;
+        p.nkt = pl.nkt;
+        p.tiles_n = pl.tiles_n;
+        p.P = pl.P;
+        p.whole_tiles = pl.whole_tiles;
+        p.zeros = ctx->zeros;
+        int rc;
+        if (!transA && !transB) rc = gemm_launch_tile<false, false>(ctx, p, pl, s);
+        else if (!transA && transB) rc = gemm_launch_tile<false, true>(ctx, p, pl, s);
+        else if (transA && !transB) rc = gemm_launch_tile<true, false>(ctx, p, pl, s);
+        else rc = gemm_launch_tile<true, true>(ctx, p, pl, s);
+        if (rc) return rc;
+    } else {
+        splits = gemm_splits(ctx, M, N, K);
+        if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * 4)) splits = 1;
+        p.kchunk = ((K + splits - 1) / splits + GBK - 1) / GBK * GBK;
+        if (p.kchunk < GBK) p.kchunk = GBK;
+        splits = (int)((K + p.kchunk - 1) / p.kchunk);
+        if (splits < 1) splits = 1;
+        p.ws = splits > 1 ? (float*)ws : nullptr;
+        dim3 grid((unsigned)((N + GBN - 1) / GBN), (unsigned)((M + GBM - 1) / GBM), (unsigned)splits);
+        const size_t lds = (size_t)4 * G_TILE * 4;
 #define EL_GEMM_GO(TA_, TB_)                                                                                          \
     do {                                                                                                              \
         auto kern = k_gemm_f32<TA_, TB_>;                                                                             \
         EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         EL_LAUNCH("k_gemm_f32", kern, grid, dim3(256), lds, s, p);                                                    \
     } while (0)
-    if (!transA && !transB) EL_GEMM_GO(false, false);
-    else if (!transA && transB) EL_GEMM_GO(false, true);
-    else if (transA && !transB) EL_GEMM_GO(true, false);
-    else EL_GEMM_GO(true, true);
+        if (!transA && !transB) EL_GEMM_GO(false, false);
+        else if (!transA && transB) EL_GEMM_GO(false, true);
+        else if (transA && !transB) EL_GEMM_GO(true, false);
+        else EL_GEMM_GO(true, true);
 #undef EL_GEMM_GO
+    }
     EL_CHECK_LAUNCH();
     if (splits > 1) {
         const int64_t n = M * N;

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-excl", action="store_true")
     ap.add_argument("--model", default="FunkSVD", choices=["MF", "PMF", "FunkSVD", "LogisticMF", "NeuMF", "GMF"])
+    ap.add_argument("--shape", action="append", default=None, help="gemm: M,N,K,tA,tB (repeatable; default: the model shapes)")
     a = ap.parse_args()
     os.environ["EL_TOPK_VARIANT"] = str(a.variant)
     ctx = ops.get_context(0)
@@ -36,19 +37,27 @@ def main():
     if a.what == "gemm":
         ctx.timing(True)
         B2 = 262144
-        for (M, N, K, tA, tB) in [(512, 26744, 600, 0, 0), (600, 26744, 512, 1, 0), (512, 600, 26744, 0, 1),      # Mult-VAE, ML-20M shape
+        shapes = [tuple(int(x) for x in sh.split(",")) for sh in a.shape] if a.shape else None
+        for (M, N, K, tA, tB) in shapes or [(512, 26744, 600, 0, 0), (600, 26744, 512, 1, 0), (512, 600, 26744, 0, 1),      # Mult-VAE, ML-20M shape
                                   (512, 400, 600, 0, 0), (512, 600, 200, 0, 0), (600, 400, 512, 1, 0), (512, 600, 400, 0, 1),
                                   (B2, 512, 256, 0, 0), (B2, 256, 512, 0, 0), (B2, 128, 256, 0, 0),                # NeuMF tower fwd
                                   (B2, 256, 512, 0, 1), (B2, 512, 256, 0, 1), (256, 512, B2, 1, 0), (512, 256, B2, 1, 0),
                                   (4096, 4096, 4096, 0, 0), (8192, 8192, 1024, 0, 1)]:
             A = torch.randn((K, M) if tA else (M, K), device=dev)
             Bm = torch.randn((N, K) if tB else (K, N), device=dev)
-            for _ in range(5):
-                ops.gemm(ctx, A, Bm, bool(tA), bool(tB))
+            out = torch.empty((M, N), device=dev)
+            for _ in range(3):                                   # warm-up: code load, clocks
+                ops.gemm(ctx, A, Bm, bool(tA), bool(tB), out=out)
+            torch.cuda.synchronize()
+            ctx.timing_report()
+            for _ in range(a.iters if a.iters > 3 else 10):
+                ops.gemm(ctx, A, Bm, bool(tA), bool(tB), out=out)
             torch.cuda.synchronize()
             rep = ctx.timing_report()
-            ms = sum(v[1] for v in rep.values()) / 5
-            print(f"gemm M={M} N={N} K={K} tA={tA} tB={tB}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s  {rep}")
+            ms = sum(v[1] for v in rep.values()) / (a.iters if a.iters > 3 else 10)
+            n_it = a.iters if a.iters > 3 else 10
+            parts = " ".join(f"{k.replace('k_gemm_', '')}={v[1] / n_it:.3f}" for k, v in rep.items())
+            print(f"gemm M={M} N={N} K={K} tA={tA} tB={tB}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s  [{parts}]")
         return
     if a.what == "vae":
         import numpy as np
