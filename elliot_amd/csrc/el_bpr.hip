@@ -1093,7 +1093,20 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
         key.grid_a = stream_grid(ctx, big / 4 + 1);
         AdamTriple t = {{st.Gu, st.Gi, st.Bi}, {st.gGu, st.gGi, st.gBi}, {st.mGu, st.mGi, st.mBi}, {st.vGu, st.vGi, st.vBi}, {nu, ni, st.I}};
         if (loop_graph_get(ctx, s, key, t, bi, bj)) use_graph = false;     // capture unavailable: eager path, same results
-        else EL_CHECK_HIP(hipMemcpyAsync(lr_tab, lr_t_host, (size_t)steps * 4, hipMemcpyHostToDevice, s));
+        else {
+            // the table travels through a pinned buffer of the context: the caller's array need not outlive this call
+            if (ctx->lr_copied) EL_CHECK_HIP(hipEventSynchronize(ctx->lr_copied));      // previous copy has left the buffer
+            else EL_CHECK_HIP(hipEventCreateWithFlags(&ctx->lr_copied, hipEventDisableTiming));
+            if (ctx->lr_pinned_cap < (size_t)steps) {
+                if (ctx->lr_pinned) (void)hipHostFree(ctx->lr_pinned);
+                ctx->lr_pinned = nullptr, ctx->lr_pinned_cap = 0;
+                EL_CHECK_HIP(hipHostMalloc((void**)&ctx->lr_pinned, (size_t)steps * 4, hipHostMallocDefault));
+                ctx->lr_pinned_cap = (size_t)steps;
+            }
+            memcpy(ctx->lr_pinned, lr_t_host, (size_t)steps * 4);
+            EL_CHECK_HIP(hipMemcpyAsync(lr_tab, ctx->lr_pinned, (size_t)steps * 4, hipMemcpyHostToDevice, s));
+            EL_CHECK_HIP(hipEventRecord(ctx->lr_copied, s));
+        }
     }
 
     int64_t k = 0;

@@ -23,6 +23,10 @@ struct el_ctx {
     bool timing;
     bool tuning = false;   // el_tuning_mode: optimiser launches use the *_tune kernel instantiations
     float* zeros = nullptr; // 256 bytes of zeros in device memory (source of out-of-range LDS-DMA lanes, el_gemm.hip)
+    // el_bprmf_train_loop: pinned staging copy of the caller's step-size table (the caller's array may be freed on return)
+    float* lr_pinned = nullptr;
+    size_t lr_pinned_cap = 0;
+    hipEvent_t lr_copied = nullptr;
     std::vector<el_timing_rec> pending;
     std::vector<hipEvent_t> pool;
     // screened top-k: what the item-side image in the last workspace was derived from (EL_TOPK_ITEMS_UNCHANGED)

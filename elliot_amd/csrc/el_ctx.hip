@@ -54,6 +54,11 @@ extern "C" int el_ctx_destroy(el_ctx* ctx) {
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->loop_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->loop_graph_exec);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
+    if (ctx->lr_copied) {
+        (void)hipEventSynchronize(ctx->lr_copied);
+        (void)hipEventDestroy(ctx->lr_copied);
+    }
+    if (ctx->lr_pinned) (void)hipHostFree(ctx->lr_pinned);
     delete ctx;
     return 0;
 }

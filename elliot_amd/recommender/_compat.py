@@ -4,7 +4,7 @@ Inside an Elliot installation the genuine Evaluator / folders / recommendation w
 models behave exactly like in-tree Elliot models; stand-alone the API-compatible mirrors of this
 package are used.  (This is host plumbing only: no numeric path depends on it.)
 """
-try:  # pragma: no cover - needs the reference's full dependency set (tensorflow not required here)
+try:  # inside an Elliot process (exercised by tests/test_host_reference_boundary.py with PYTHONPATH=/root/reference)
     from elliot.evaluation.evaluator import Evaluator
     from elliot.utils.folder import build_model_folder
     from elliot.utils.write import store_recommendation

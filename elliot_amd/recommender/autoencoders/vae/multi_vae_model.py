@@ -63,12 +63,15 @@ class VariationalAutoEncoder:
         """:144-155 for users [start, stop): log_softmax(logits) as a [n, I] device tensor (z is sampled at
         inference too, as in the reference, unless eps_mode == 'zero')."""
         rows = torch.arange(start, stop, dtype=torch.int32, device=self.ctx.device)
+        self._row0 = int(start)                 # the block get_top_k(preds, ...) refers to (the reference slices its mask by it)
         return self.state.predict(self.train_csr, rows, eps=self._eps(stop - start))
 
-    def get_top_k(self, preds, train_mask, k=100):
-        """:157-159"""
+    def get_top_k(self, preds, train_mask, k=100, offset=None):
+        """:157-159.  `preds` = the block predict(start, stop) returned; the tagged CSR mask covers ALL users, so the rows of
+        the block are addressed by `offset` (default: the start of the last predict call)."""
         kind, csr = train_mask
-        idx, val = ops.dense_topk(self.ctx, preds, self._row0, self._row0 + preds.shape[0], k,
+        row0 = int(getattr(self, "_row0", 0) if offset is None else offset)
+        idx, val = ops.dense_topk(self.ctx, preds, row0, row0 + preds.shape[0], k,
                                   excl=csr if kind == "excl" else None, cand=csr if kind == "cand" else None)
         return val, idx
 

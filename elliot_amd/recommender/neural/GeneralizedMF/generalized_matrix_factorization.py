@@ -24,11 +24,13 @@ class GMF(RecMixin, BaseRecommenderModel):
         if self._batch_size < 1:
             self._batch_size = self._data.transactions
         self._ctx = ops.get_context(max(int(getattr(self._config, "gpu", 0) or 0), 0))
-        self._sampler = pointwise_pos_neg_sampler.Sampler(self._data.sp_i_train, ctx=self._ctx)
+        replay = getattr(self._params, "sampler", "philox") == "replay"      # the reference's exact sample stream
+        self._sampler = pointwise_pos_neg_sampler.Sampler(self._data.i_train_dict if replay else self._data.sp_i_train,
+                                                          ctx=self._ctx, replay=replay)
         self._model = GeneralizedMatrixFactorizationModel(self._num_users, self._num_items, int(self._mf_factors),
                                                           self._is_edge_weight_train, self._learning_rate, self._seed,
                                                           ctx=self._ctx,
-                                                          max_batch=max(min(self._batch_size, 1 << 20), self._num_items),
+                                                          max_batch=max(min(self._batch_size, 1 << 23), self._num_items),
                                                           init_weights=kwargs.get("init_weights"))
 
     @property

@@ -20,7 +20,7 @@ class Sampler:
     def __init__(self, indexed_ratings, m, ctx=None, sp_i_train=None):
         np.random.seed(42)                                  # :16
         random.seed(42)                                     # :17
-        self.ctx = ctx or ops.get_context(0)
+        self.ctx = ctx                                      # (resolved in step(): the epoch bookkeeping itself is host work)
         self._m = int(m)
         self._indexed_ratings = indexed_ratings
         self._csr = sp_i_train.tocsr() if sp_i_train is not None else None
@@ -70,6 +70,8 @@ class Sampler:
     def step(self, batch_size: int):
         use_py = self._indexed_ratings is not None and self._n_pos * (1 + self._m) <= self.PY_LIMIT
         s = self._epoch_python() if use_py else self._epoch_vectorised()
+        if self.ctx is None:
+            self.ctx = ops.get_context(0)
         d = self.ctx.device
         u = torch.from_numpy(np.ascontiguousarray(s[:, 0], dtype=np.int32)).to(d)
         i = torch.from_numpy(np.ascontiguousarray(s[:, 1], dtype=np.int32)).to(d)

@@ -38,7 +38,7 @@ class NeuMF(RecMixin, BaseRecommenderModel):
         self._model = NeuralMatrixFactorizationModel(self._num_users, self._num_items, F, self._mlp_factors,
                                                      self._mlp_hidden_size, self._dropout, self._is_mf_train,
                                                      self._is_mlp_train, self._learning_rate, self._seed, ctx=self._ctx,
-                                                     max_batch=max(min(self._batch_size, 1 << 20), self._num_items),
+                                                     max_batch=max(min(self._batch_size, 1 << 23), self._num_items),
                                                      init_weights=kwargs.get("init_weights"))
 
     @property

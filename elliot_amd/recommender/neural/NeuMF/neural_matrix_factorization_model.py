@@ -36,9 +36,16 @@ class _PointwiseModel:
         y = label if isinstance(label, torch.Tensor) else torch.from_numpy(np.asarray(label, dtype=np.float32))
         y = y.reshape(-1).to(device=self.ctx.device, dtype=torch.float32).contiguous()
         u, i = self._idx(user), self._idx(pos)
-        B = self.state.Bmax
-        for s in range(0, u.numel(), B):       # a batch larger than the activation buffers is split (same gradients
-            self.state.train_step(u[s:s + B], i[s:s + B], y[s:s + B], self._lr)   # only if it fits: see DESIGN)
+        B, n = self.state.Bmax, u.numel()
+        if n > B and not getattr(self, "_warned_split", False):
+            # the reference takes ONE optimiser step per batch (neural_matrix_factorization_model.py:96-106); a batch beyond the
+            # activation buffers (the plugins size them for up to 8M samples) is processed as several consecutive steps
+            import logging
+            logging.getLogger(__name__).warning("NeuMF/GMF: batch of %d samples exceeds the %d-sample activation buffers; it is "
+                                                "split into %d optimiser steps (the reference would take one)", n, B, -(-n // B))
+            self._warned_split = True
+        for s in range(0, n, B):
+            self.state.train_step(u[s:s + B], i[s:s + B], y[s:s + B], self._lr)
         return DeferredLoss(self.state)
 
     def get_recs(self, inputs, training=False, **kwargs):

@@ -107,7 +107,9 @@ class RecMixin(object):
         block = self._recommendation_block()
         for offset in range(0, self._num_users, block):
             offset_stop = min(offset + block, self._num_users)
-            recs_val, recs_test = self.process_protocol(k, offset, offset_stop)
+            # (the reference computes `predictions = self._model.predict(...)` here and hands the dense [Ub, I] block on;
+            #  the fused kernels never materialise it -- the slot stays in the signatures, filled with None)
+            recs_val, recs_test = self.process_protocol(k, None, offset, offset_stop)
             predictions_top_k_val.update(recs_val)
             predictions_top_k_test.update(recs_test)
         return predictions_top_k_val, predictions_top_k_test
@@ -124,18 +126,28 @@ class RecMixin(object):
             if hasattr(self._data, "val_dict") else {}
         return val, self.get_single_recommendation(self.get_candidate_mask(), k, *args)
 
-    def get_single_recommendation(self, mask, k, offset, offset_stop):
-        """`mask` is what get_candidate_mask() returned (a device CSR descriptor, see below)."""
+    def get_single_recommendation(self, mask, k, predictions, offset, offset_stop):
+        """Same signature as the reference's (recommender_utils_mixin.py:84).  `mask` is what get_candidate_mask() returned
+        (a tagged device CSR, see below); `predictions` -- the reference's dense score block -- is accepted and ignored: the
+        model scores and selects in one fused pass."""
         idx, val = self._model.recommend(mask, k, offset, offset_stop)       # [Ub, k] device tensors
         return self._arrays_to_recs(idx.cpu().numpy(), val.cpu().numpy(), offset, offset_stop)
 
     def _arrays_to_recs(self, idx, val, offset, offset_stop):
-        """recommender_utils_mixin.py:86-88: private -> public ids, `{user: [(item, score), ...]}`."""
+        """recommender_utils_mixin.py:86-88: private -> public ids, `{user: [(item, score), ...]}`.  Rows with fewer than k
+        candidates are padded by the kernels with (-1, -inf): those entries are dropped here (index -1 would otherwise wrap to
+        the last public item and count as a recommendation of it)."""
         pub_items = self._public_item_array()
-        items = pub_items[idx]
         pu = self._data.private_users
-        il, vl = items.tolist(), val.tolist()
-        return {pu[u]: list(zip(il[r], vl[r])) for r, u in enumerate(range(offset, offset_stop))}
+        short = idx < 0
+        if not short.any():
+            il, vl = pub_items[idx].tolist(), val.tolist()
+            return {pu[u]: list(zip(il[r], vl[r])) for r, u in enumerate(range(offset, offset_stop))}
+        out = {}
+        for r, u in enumerate(range(offset, offset_stop)):
+            keep = ~short[r]
+            out[pu[u]] = list(zip(pub_items[idx[r][keep]].tolist(), val[r][keep].tolist()))
+        return out
 
     def _public_item_array(self):
         if getattr(self, "_pub_items_cache", None) is None:
@@ -154,7 +166,12 @@ class RecMixin(object):
         from .masks import device_masks
         m = device_masks(self._data, self._model.ctx)
         if self._negative_sampling:
-            return ("cand", m.val if validation else m.test)
+            cand = m.val if validation else m.test
+            if cand is None:
+                # an unmasked top-k would silently recommend train items and score against the wrong candidate set
+                raise Exception(f"negative_sampling is configured but the data set carries no {'validation' if validation else 'test'} "
+                                f"candidate mask ({'val' if validation else 'test'}_mask / _cand_csr)")
+            return ("cand", cand)
         return ("excl", m.train)
 
     def restore_weights(self):

@@ -43,7 +43,11 @@ def build_config(exp, base_dir):
         path_output_rec_performance=_resolve(base_dir, exp.get("path_output_rec_performance",
                                                                "../results/{0}/performance/"), ds))
     if "negative_sampling" in exp:
-        cfg.negative_sampling = _ns(exp["negative_sampling"])
+        # elliot/negative_sampling/negative_sampling.py builds the per-user candidate sets inside Elliot's DataSet
+        # (dataset.py:219-243); this stand-alone mini runner has no such component, and scoring without the candidate masks
+        # would silently rank the whole catalogue.  Inside Elliot (external.* models) the protocol is served from its masks.
+        raise NotImplementedError("negative_sampling: not available in the stand-alone runner -- run the models inside Elliot "
+                                  "(external_models_path) or hand the DataSet val_cand_csr / test_cand_csr")
     for p in (cfg.path_output_rec_result, cfg.path_output_rec_weight, cfg.path_output_rec_performance):
         os.makedirs(p, exist_ok=True)
     return cfg

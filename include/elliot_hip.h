@@ -180,6 +180,7 @@ int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
  * loss += model.train_step(batch)` for the batches [0,B), [B,2B), ... of `events` samples (the last one may be short),
  * launched back to back from this one call -- el_bpr_sample(first_sample + start) + el_bprmf_train_step per batch.
  *   first_step : optimiser iteration of the first batch (1-based); lr_t_host[k] = bias-corrected step size of batch k
+ *                (HOST array of ceil(events / B) floats; read or copied before the call returns -- it may be freed then)
  *   ws         : as for el_bprmf_train_step(B);  loop_ws: el_bprmf_train_loop_ws_bytes(events, B) bytes of device
  *                scratch (triplets of up to 4M samples per sampler launch -- the sampler does not read the model --, the
  *                step-size table, a control block)

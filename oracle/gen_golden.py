@@ -119,6 +119,7 @@ def main():
     gen_splitter()
     gen_early_stopping()
     gen_bprmf_end_to_end(cs, mfm)
+    gen_pointwise_and_neumf_samplers()
 
 
 def gen_bprmf_end_to_end(cs, mfm):
@@ -157,6 +158,35 @@ def gen_bprmf_end_to_end(cs, mfm):
     print("bprmf_e2e_ref.npz: reference epoch of", T, "triplets,", U, "users")
     # the reference's own checkpoint of that model (MFModel.save_weights, BPRMF_model.py:133-139): on-disk format fixture
     model.save_weights(os.path.join(OUT, "bprmf_ref_weights.pkl"))
+
+
+def gen_pointwise_and_neumf_samplers():
+    """The reference's own point-wise sampler (dataset/samplers/pointwise_pos_neg_sampler.py:26-50) and NeuMF epoch sampler
+    (recommender/neural/NeuMF/custom_sampler.py:27-48) on the small data set: their (u, i, label) streams."""
+    pw = load_by_path("ref_pointwise_sampler", "elliot/dataset/samplers/pointwise_pos_neg_sampler.py")
+    nm = load_by_path("ref_neumf_sampler", "elliot/recommender/neural/NeuMF/custom_sampler.py")
+    U = 200
+    indptr, indices, itd = small_dataset(U, 150, seed=0)
+    I = int(indices.max()) + 1
+    lists = ref_ui_lists(itd)
+    N = 6000
+    ref = pw.Sampler(itd)                                   # seeds np.random AND random with 42
+    parts = [b for b in ref.step(N, 512)]
+    ru, ri, rb = (np.concatenate([p[k] for p in parts]).astype(np.int64) for k in range(3))
+    ora = osampler.RefPointwiseSampler(lists, I)
+    op = [b for b in ora.step(N, 512)]
+    for k, r in enumerate((ru, ri, rb)):
+        assert np.array_equal(r, np.concatenate([p[k] for p in op])), "oracle restatement != reference point-wise sampler"
+    np.savez_compressed(os.path.join(OUT, "pointwise_sampler_ref.npz"), u=ru.astype(np.int32), i=ri.astype(np.int32), b=rb.astype(np.int8))
+    print("pointwise_sampler_ref.npz: oracle == reference for", N, "samples; positives", int(rb.sum()))
+    out = {}
+    for m in (0, 2):
+        ref = nm.Sampler(itd, m)
+        ep = [b for b in ref.step(700)]
+        out[f"u_m{m}"], out[f"i_m{m}"], out[f"b_m{m}"] = (np.concatenate([p[k] for p in ep]).astype(np.int32) for k in range(3))
+        assert [len(p[0]) for p in ep[:-1]] == [700] * (len(ep) - 1)
+        print(f"neumf_sampler_ref.npz: m={m}: epoch of", out[f"u_m{m}"].shape[0], "samples")
+    np.savez_compressed(os.path.join(OUT, "neumf_sampler_ref.npz"), **out)
 
 
 def gen_splitter():

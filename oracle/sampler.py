@@ -100,6 +100,42 @@ class RefSampler:
             yield t[:, 0:1], t[:, 1:2], t[:, 2:3]
 
 
+class RefPointwiseSampler:
+    """pointwise_pos_neg_sampler.Sampler (pointwise_pos_neg_sampler.py:14-50): NumPy's legacy MT19937 (`np.random.seed(42)`,
+    restated by MT19937 above) interleaved with Python's own generator (`random.seed(42)`, `random.getrandbits(1)`: the
+    standard library's -- it is CPython, not the reference, so it is used as is).  ui_lists as for RefSampler."""
+
+    def __init__(self, ui_lists, n_items):
+        import random
+        self.rng = MT19937(42)                 # :16
+        self.py = random.Random(42)            # :17
+        self.ui = [list(map(int, l)) for l in ui_lists]
+        self.n_users = len(self.ui)
+        self.n_items = int(n_items)
+
+    def sample(self):
+        r = self.rng.randint
+        u = r(self.n_users)                    # :34
+        ui = self.ui[u]
+        lui = len(ui)
+        if lui == self.n_items:                # :37-38
+            self.sample()
+        b = self.py.getrandbits(1)             # :39
+        if b:
+            i = ui[r(lui)]                     # :41
+        else:
+            i = r(self.n_items)                # :43
+            while i in ui:                     # :44-45
+                i = r(self.n_items)
+        return u, i, b
+
+    def step(self, events, batch_size):        # :48-50
+        for start in range(0, events, batch_size):
+            n = min(start + batch_size, events) - start
+            t = np.array([self.sample() for _ in range(n)], dtype=np.int64)
+            yield t[:, 0], t[:, 1], t[:, 2]
+
+
 # ------------------------------------------------------------------------------------------
 # Philox4x32-10 (Salmon et al. 2011) -- the device sampler's bit stream
 # ------------------------------------------------------------------------------------------

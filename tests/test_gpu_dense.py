@@ -165,3 +165,53 @@ def test_data_parallel_hip_path_equals_one_batch(ctx, dae):
         for k in (od.NAMES if dae else ov.NAMES):
             err = np.abs(gw[k] - orc.w[k])
             assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()))
+
+
+def test_vae_step_at_the_ml20m_shape_matches_oracle(ctx):
+    """BASELINE configs[2] shape: I = 26 744 items, hidden 600, latent 200, batch 512 (multi_vae.py:57-61,68-69) -- the shapes
+    whose GEMMs run the stream-K schedule (512 x 26744 x 600 logits, its two transposed products, the K = 26744 split).
+    One el_vae_grads + el_vae_apply per step, two steps, against oracle/multi_vae.py on the densified batch:
+      loss        1e-4 relative (north_star)
+      gradients   every one of the ten tensors within 2e-5 of its own largest entry (fp32 summation order is the freedom; the
+                  products sum up to 26 744 terms)
+      weights     after Adam: at most 2e-3 of the entries off by more than 2e-5 (m / (sqrt(v) + eps) flips sign where a
+                  gradient cancels to ~0), none by more than 5 lr."""
+    rs = np.random.RandomState(21)
+    U, I, H, L, B = 1536, 26744, 600, 200, 512
+    from elliot_amd.synthetic import zipf_csr
+    indptr, indices = zipf_csr(U, I, mean_log=4.5, sigma_log=1.0, dmin=20, dmax=3000, seed=5)
+    csr = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    w0 = ov.init_weights(I, H, L, 42)
+    for k in ("b1", "bm", "bv", "b3", "b4"):
+        w0[k] = rs.normal(scale=0.01, size=w0[k].shape).astype(np.float32)
+    lr = 0.001
+    st = ops.VaeDeviceState(ctx, w0, max_batch=B)
+    orc = ov.MultiVAEOracle(w0, lr)
+    d = ctx.device
+    L2 = st.L
+    for s in range(2):
+        rows = rs.permutation(U)[:B].astype(np.int32)
+        X = np.zeros((B, I), np.float32)
+        for r, u in enumerate(rows):
+            X[r, indices[indptr[u]:indptr[u + 1]]] = 1.0
+        eps = rs.normal(size=(B, L)).astype(np.float32)
+        anneal = 0.1
+        st.grads(csr, torch.from_numpy(rows).to(d), anneal, eps=torch.from_numpy(eps).to(d))
+        got_loss = st.pop_loss()
+        c = ov.forward(orc.w, X, eps)
+        exp_loss = float(ov.loss_from(c, anneal))
+        assert abs(got_loss - exp_loss) <= 1e-4 * abs(exp_loss), (s, got_loss, exp_loss)
+        g = ov.gradients(orc.w, c, np.float32(anneal))
+        dev_g = {n: cpu(t) for n, t in zip(st.ORDER, st.g)}
+        got_g = {"W1": dev_g["W1"], "b1": dev_g["b1"], "Wm": dev_g["Wmv"][:, :L2], "Wv": dev_g["Wmv"][:, L2:], "bm": dev_g["bmv"][:L2],
+                 "bv": dev_g["bmv"][L2:], "W3": dev_g["W3"], "b3": dev_g["b3"], "W4": dev_g["W4"], "b4": dev_g["b4"]}
+        for k in ov.NAMES:
+            scale = float(np.abs(g[k]).max())
+            err = float(np.abs(got_g[k] - g[k]).max())
+            assert err <= 2e-5 * scale, (s, k, err, scale)
+        st.apply(lr)
+        assert abs(orc.train_step(X, eps, anneal) - exp_loss) < 1e-9 * abs(exp_loss)
+        gw = st.weights()
+        for k in ov.NAMES:
+            err = np.abs(gw[k] - orc.w[k])
+            assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()), float((err > 2e-5).mean()))

@@ -104,3 +104,40 @@ def test_c_topk_shards_merge_to_global():
     for u in range(U):
         order = np.lexsort((ci[u], -cv[u]))[:k]
         assert np.array_equal(ci[u][order], full_i[u]) and np.array_equal(cv[u][order], full_v[u])
+
+
+def _small_itd():
+    from elliot_amd.synthetic import small_dataset
+    return small_dataset(200, 150, seed=0)           # the data set oracle/gen_golden.py ran the reference on
+
+
+def test_pointwise_sampler_stream_equals_the_reference(golden):
+    """oracle restatement AND the product's host replay (`sampler: replay` of the point-wise plugins) against the stream the
+    reference's own pointwise_pos_neg_sampler.Sampler.step produced (interleaved np.random / random draws, both seeded 42)."""
+    from elliot_amd.dataset.samplers.pointwise_pos_neg_sampler import replay_stream
+    g = golden("pointwise_sampler_ref.npz")
+    indptr, indices, itd = _small_itd()
+    n = g["u"].shape[0]
+    lists = [list(set(itd[u])) for u in itd]
+    ora = osampler.RefPointwiseSampler(lists, int(indices.max()) + 1)
+    parts = list(ora.step(n, 512))
+    for k, name in enumerate(("u", "i", "b")):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), g[name].astype(np.int64)), name
+    # the product: two calls continue one stream (epoch after epoch), like consecutive Sampler.step batches
+    u1, i1, b1, st = replay_stream(itd, 2500)
+    u2, i2, b2, _ = replay_stream(itd, n - 2500, st)
+    assert np.array_equal(np.concatenate([u1, u2]), g["u"]) and np.array_equal(np.concatenate([i1, i2]), g["i"])
+    assert np.array_equal(np.concatenate([b1, b2]), g["b"])
+    rows = [set(indices[indptr[u]:indptr[u + 1]].tolist()) for u in range(len(itd))]
+    assert all((int(i) in rows[int(u)]) == bool(b) for u, i, b in zip(g["u"], g["i"], g["b"]))
+
+
+def test_neumf_epoch_sampler_equals_the_reference(golden):
+    """elliot_amd's NeuMF epoch sampler (host bookkeeping of neural/NeuMF/custom_sampler.py:27-48: positives + m negatives per
+    positive, set-deduplicated, random.sample shuffle) reproduces the reference's epoch sample for sample, m = 0 and m = 2."""
+    from elliot_amd.recommender.neural.NeuMF.custom_sampler import Sampler
+    g = golden("neumf_sampler_ref.npz")
+    _, _, itd = _small_itd()
+    for m in (0, 2):
+        s = Sampler(itd, m)._epoch_python()                     # (constructor seeds np.random / random with 42, like the reference)
+        assert np.array_equal(s[:, 0], g[f"u_m{m}"]) and np.array_equal(s[:, 1], g[f"i_m{m}"]) and np.array_equal(s[:, 2], g[f"b_m{m}"]), m
