@@ -65,8 +65,10 @@ __device__ __forceinline__ int el_screen_slot(int row) {
 // One thread per (item, 8-column chunk): 32 B in, 16 B out, the row norm is reduced over the SL = FP/8 lanes of the item.
 template <int FP>
 __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ Gi, const float* __restrict__ Bi, int64_t I,
-                                                     int F, unsigned short* __restrict__ Gib, float* stats) {
+                                                     int F, unsigned short* __restrict__ Gib, float* stats,
+                                                     const unsigned long long* __restrict__ rebuild) {
     constexpr int SL = FP / 8;
+    if (*rebuild == 0ull) return;                         // the image in this workspace was built from these very tables
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t item = t / SL;
     const int sl = (int)(t % SL);
@@ -112,6 +114,57 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
         if (nmax > __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st, nmax);
         if (bmax > __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + 1, bmax);
     }
+}
+
+// ---- EL_TOPK_ITEMS_UNCHANGED is a claim the library checks -------------------------------------------------------
+// A caller (any C host, not only the Python model classes with their weight-version counter) may update Gi / Bi IN PLACE
+// between two blocks and still pass the flag: same pointers, same shape, stale bf16 image.  So the claim is verified on the
+// device: k_items_hash folds every element of Gi and Bi (with its index) into an order-independent 64-bit sum -- a read-only
+// pass over the table, about as long as building the image -- k_items_decide compares it with the hash the image in this
+// workspace was built from, and k_screen_prep returns at once only when they agree.  No host synchronisation.
+//   ctl[0] = hash the image was built from, ctl[1] = hash of the tables now, ctl[2] = 1: rebuild
+__device__ __forceinline__ u64 el_mix_elem(u64 idx, u32 w) {
+    u32 a = w + 0x9E3779B9u * (u32)(idx + 1), b = w ^ (0x85EBCA77u * (u32)((idx >> 7) + 3));
+    a ^= a >> 16, a *= 0x85EBCA6Bu, a ^= a >> 13, a *= 0xC2B2AE35u, a ^= a >> 16;
+    b ^= b >> 15, b *= 0x2C1B3C6Du, b ^= b >> 12, b *= 0x297A2D39u, b ^= b >> 15;
+    return ((u64)a << 32) | (u64)b;
+}
+
+__global__ __launch_bounds__(256) void k_items_hash(const float* __restrict__ Gi, const float* __restrict__ Bi, int64_t n_g,
+                                                    int64_t n_b, u64* ctl) {
+    const u32* g = reinterpret_cast<const u32*>(Gi);
+    const u32* b = reinterpret_cast<const u32*>(Bi);
+    const int64_t stride = (int64_t)gridDim.x * 256, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    u64 h = 0;
+    if ((reinterpret_cast<uintptr_t>(Gi) & 15) == 0) {
+        const uint4* g4 = reinterpret_cast<const uint4*>(Gi);
+        const int64_t n4 = n_g >> 2;
+        for (int64_t e = t; e < n4; e += stride) {
+            const uint4 v = g4[e];
+            h += el_mix_elem(4 * e, v.x) + el_mix_elem(4 * e + 1, v.y) + el_mix_elem(4 * e + 2, v.z) + el_mix_elem(4 * e + 3, v.w);
+        }
+        for (int64_t e = (n4 << 2) + t; e < n_g; e += stride) h += el_mix_elem(e, g[e]);
+    } else {
+        for (int64_t e = t; e < n_g; e += stride) h += el_mix_elem(e, g[e]);
+    }
+    if (Bi)
+        for (int64_t e = t; e < n_b; e += stride) h += el_mix_elem(n_g + e, b[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += (u64)__shfl_xor((long long)h, o, 64);
+    __shared__ u64 part[4];                                // one atomic per workgroup: same-address atomics serialise in L2
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 tot = part[0] + part[1] + part[2] + part[3];
+        if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(ctl + 1), (unsigned long long)tot);
+    }
+}
+
+__global__ void k_items_decide(u64* ctl, float* stats, int force) {
+    const bool stale = force || ctl[0] != ctl[1];
+    ctl[0] = ctl[1];
+    ctl[2] = stale ? 1ull : 0ull;
+    if (stale) stats[0] = stats[1] = 0.f;                 // max ||i||, max |bias|: re-derived by k_screen_prep
 }
 
 struct ScreenParams {
@@ -832,24 +885,34 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     // users against an unchanged table says so (EL_TOPK_ITEMS_UNCHANGED); the claim is honoured only if this context's
     // previous screened call used the same workspace, tables and shape.
     el_ctx* ctx = g_el_cur_ctx;
-    const bool reuse = items_unchanged && ctx->prep_ws == ws && ctx->prep_Gi == p.Gi && ctx->prep_Bi == p.Bi &&
+    const bool claim = items_unchanged && ctx->prep_ws == ws && ctx->prep_Gi == p.Gi && ctx->prep_Bi == p.Bi &&
                        ctx->prep_I == p.I_local && ctx->prep_F == p.F;
     ctx->prep_ws = ws, ctx->prep_Gi = p.Gi, ctx->prep_Bi = p.Bi, ctx->prep_I = p.I_local, ctx->prep_F = p.F;
-    if (reuse) {
-        EL_CHECK_HIP(hipMemsetAsync(stats + 2, 0, 8, st));          // only the flagged-user counter
-    } else {
-        EL_CHECK_HIP(hipMemsetAsync(stats, 0, 16, st));
-    }
-    if (p.I_local > 0 && !reuse) {
+    u64* ctl = reinterpret_cast<u64*>(reinterpret_cast<char*>(stats) + 32);     // inside the 256-byte control block
+    EL_CHECK_HIP(hipMemsetAsync(stats + 2, 0, 8, st));                          // the flagged-user counter
+    EL_CHECK_HIP(hipMemsetAsync(ctl + 1, 0, 8, st));                            // hash accumulator
+    if (p.I_local > 0) {
+        // the claim "items unchanged" is VERIFIED (in-place updates keep pointers and shapes): hash of the tables now against
+        // the hash the image was built from; without the claim the image is rebuilt and its hash recorded
+        const int64_t n_g = p.I_local * (int64_t)p.F;
+        int64_t hb = (n_g / 4 + 255) / 256;
+        const int64_t hcap = (int64_t)ctx->cus * 2;
+        if (hb > hcap) hb = hcap;
+        if (hb < 1) hb = 1;
+        EL_LAUNCH("k_items_hash", k_items_hash, dim3((unsigned)hb), dim3(256), 0, st, p.Gi, p.Bi, n_g, p.I_local, ctl);
+        EL_LAUNCH("k_items_decide", k_items_decide, dim3(1), dim3(1), 0, st, ctl, stats, claim ? 0 : 1);
+        const unsigned long long* rebuild = reinterpret_cast<const unsigned long long*>(ctl + 2);
         const unsigned pg = (unsigned)((p.I_local * (FP / 8) + 255) / 256);
         if (FP == 32)
-            EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
         else if (FP == 64)
-            EL_LAUNCH("k_screen_prep", k_screen_prep<64>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<64>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
         else if (FP == 128)
-            EL_LAUNCH("k_screen_prep", k_screen_prep<128>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<128>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
         else
-            EL_LAUNCH("k_screen_prep", k_screen_prep<256>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<256>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
+    } else {
+        EL_CHECK_HIP(hipMemsetAsync(stats, 0, 8, st));
     }
     const char* pe = getenv("EL_SCREEN_PROF");
     const bool prof = pe && pe[0] == '1';

@@ -268,7 +268,9 @@ enum {
     EL_TOPK_SCREEN = 3, /* force the bf16-screened / fp32-exact kernels (F<=256, k<=128); same results  */
     /* flag, OR-ed into algo: the caller asserts that Gi / Bi have not been written since its previous el_score_topk call
      * with this workspace (scoring block after block of users against one table): the screened kernels then keep the
-     * item-side bf16 image of that call instead of deriving it again.  Ignored unless workspace, tables and shape match. */
+     * item-side bf16 image of that call instead of deriving it again.  Ignored unless workspace, tables and shape match --
+     * and VERIFIED: a 64-bit hash of every element of Gi / Bi (read-only pass on the device, no host synchronisation) is
+     * compared with the hash the image was built from; tables updated in place at the same address rebuild the image. */
     EL_TOPK_ITEMS_UNCHANGED = 0x100
 };
 

@@ -319,6 +319,38 @@ def test_items_unchanged_flag_reuses_only_a_matching_image(ctx):
     assert torch.equal(e[0], f[0]) and torch.equal(e[1], f[1])
 
 
+def test_items_unchanged_claim_is_verified_after_in_place_updates(ctx):
+    """The C-ABI hazard: Gi / Bi are updated IN PLACE (same pointers, same shapes -- what an optimiser does) and the caller still
+    passes EL_TOPK_ITEMS_UNCHANGED.  The library hashes the tables on the device and rebuilds the image: lists and score bits
+    equal a fresh exact evaluation after every mutation, whether the whole table, a single element or only a bias changed, and
+    the flag keeps working (bit-identical results) while nothing changes."""
+    rs = np.random.RandomState(4)
+    U, I, F, k = 600, 3000, 128, 10
+    Gu = torch.from_numpy(rs.normal(size=(U, F)).astype(np.float32)).to(ctx.device)
+    Gi = torch.from_numpy(rs.normal(size=(I, F)).astype(np.float32)).to(ctx.device)
+    Bi = torch.from_numpy(rs.normal(size=I).astype(np.float32)).to(ctx.device)
+    ptr = (Gi.data_ptr(), Bi.data_ptr())
+
+    def check(what):
+        got = ops.score_topk(ctx, Gu, Gi, Bi, 0, U, k, algo="screen", items_unchanged=True)        # the claim, true or not
+        exp = ops.score_topk(ctx, Gu, Gi, Bi, 0, U, k, algo="mfma")
+        assert torch.equal(got[0], exp[0]) and torch.equal(got[1].view(torch.int32), exp[1].view(torch.int32)), what
+        assert (Gi.data_ptr(), Bi.data_ptr()) == ptr
+
+    ops.score_topk(ctx, Gu, Gi, Bi, 0, U, k, algo="screen")
+    check("unchanged")
+    Gi.mul_(-0.7).add_(0.05)                                   # an optimiser step: every element moves, in place
+    check("whole table rewritten in place")
+    check("unchanged again")
+    best = int(ops.score_topk(ctx, Gu, Gi, Bi, 0, 1, 1, algo="mfma")[0][0, 0])
+    Gi[best, 5] -= 40.0                                         # ONE element: user 0's best item drops out
+    check("one element")
+    Bi[(best + 1) % I] += 300.0                                 # only a bias: that item now tops every list
+    check("one bias")
+    top = ops.score_topk(ctx, Gu, Gi, Bi, 0, U, k, algo="screen", items_unchanged=True)[0][:, 0]
+    assert bool((top == (best + 1) % I).all())
+
+
 def test_fragile_user_report_matches_numpy(ctx):
     """el_topk_fragile: users whose rank-k / k+1 gap is inside F 2^-23 |u| max|i| -- counted exactly like a NumPy
     evaluation of the same bound on the oracle's k+1 lists; a planted exact tie is always fragile."""
