@@ -67,6 +67,9 @@ def parse():
                          "top-k (default: user for --shard user, item for the item-shard leg)")
     ap.add_argument("--legs", default="auto",
                     help="comma list of bpr,item_shard,vae,neumf,metrics (auto: N=1 -> bpr,metrics,vae,neumf; N>1 -> bpr,item_shard)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
+                    help="N > 1: collectives through torch.distributed (RCCL process group) or through the library's own C ABI "
+                         "(el_comm_init / el_allreduce_rows / el_allgather_topk: RCCL called directly)")
     ap.add_argument("--prefetch", action="store_true",
                     help="draw the triplets of step t+1 on a side stream during step t (measured: no gain, the step is HBM-bound)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
@@ -350,7 +353,7 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
     finish_train = None
     exchange = None
-    coll = parallel._Collectives()
+    coll = data.get("coll") or parallel._Collectives()
     sharded = world > 1 or args.force_sharded
     collectives = []                                                          # (what, op, bytes per rank and call, callable)
     if not sharded:
@@ -704,6 +707,9 @@ def main():
     # ---------------- synthetic inputs, resident in HBM -------------------------------------------
     indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
     data = {"indptr": indptr, "indices": indices, "pos": ops.DeviceCSR.from_tensors(indptr, indices, I)}
+    if args.comm == "abi" and sharded:
+        from elliot_amd import parallel
+        data["coll"] = parallel.RcclAbiCollectives(ctx, rank, world)          # RCCL through el_comm_* (one communicator for all legs)
 
     want_cpu = world == 1 and not args.no_cpu_baseline
     topk_shard = args.topk_shard or ("user" if args.shard == "user" else "item")
@@ -736,7 +742,7 @@ def main():
                    "users": U, "items": I, "factors": F, "interactions": main_leg["interactions"], "batch": B,
                    "batch_per_gpu": B, "optimizer": args.opt, "topk_block": main_leg["topk_block"], "k": k,
                    "parallelism": main_leg["parallelism"] + ("; top-k: see topk.sharding" if sharded else ""),
-                   "world_size_observed": world, "backend": backend},
+                   "world_size_observed": world, "backend": backend, "collectives_through": args.comm if sharded else None},
         "loss_per_pair_last": main_leg["loss_per_pair_last"],
         "roofline": main_leg["roofline"],
         "topk": main_leg["topk"],

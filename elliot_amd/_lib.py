@@ -99,6 +99,14 @@ PROTOTYPES = {
     "el_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "el_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "el_tuning_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "el_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "el_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "el_comm_destroy": (C.c_int, [C.c_void_p]),
+    "el_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "el_allreduce_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_int64]),
+    "el_reduce_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64]),
+    "el_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "el_allgather_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int32, _i32p, _f32p]),
     "el_timing_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "el_bpr_sample": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),

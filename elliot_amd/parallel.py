@@ -97,6 +97,131 @@ class _Collectives:
         return work if async_op else full
 
 
+class _AbiWork:
+    """Handle of a collective issued on the communication stream: wait() makes the CURRENT stream wait for it."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class RcclAbiCollectives:
+    """The same four collectives as _Collectives, issued through the C ABI of libelliot_hip.so (el_comm_init /
+    el_allreduce_rows / el_reduce_scatter_rows / el_allgather_rows / el_allgather_topk: RCCL called directly) instead
+    of torch.distributed -- what a C host of the library runs.  torch is only the buffer holder here.  One communicator per
+    rank; the 128-byte RCCL id travels out of band (`exchange_id`: a TCPStore next to MASTER_PORT, or any callable).
+    Collectives run on a side stream ordered after the caller's stream; async_op=True returns a handle whose wait() orders
+    the caller's stream after the collective (kernels enqueued in between overlap it)."""
+
+    def __init__(self, ctx, rank, world, unique_id=None, exchange_id=None):
+        import ctypes as C
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.always = True
+        self.dist = None
+        if unique_id is None:
+            unique_id = (exchange_id or self._store_exchange)(self._make_id() if self.rank == 0 else None)
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        h = C.c_void_p()
+        torch.cuda.set_device(ctx.device)
+        ops.check(ctx.lib.el_comm_init(ctx.handle, self._id, self.rank, self.world, C.byref(h)), "el_comm_init")
+        self._h = h
+        self.stream = torch.cuda.Stream(device=ctx.device)
+
+    def _make_id(self):
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        ops.check(self.ctx.lib.el_comm_unique_id(buf), "el_comm_unique_id")
+        return buf.raw
+
+    def _store_exchange(self, mine):
+        """Rank 0 publishes the id in a TCPStore on MASTER_ADDR : MASTER_PORT + 17 (host sockets: control plane only)."""
+        import os
+        from datetime import timedelta
+        if self.world == 1:
+            return mine
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17, self.world,
+                         self.rank == 0, timeout=timedelta(seconds=120))
+        if self.rank == 0:
+            store.set("el_comm_id", mine)
+            return mine
+        return store.get("el_comm_id")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            torch.cuda.synchronize(self.ctx.device)
+            self.ctx.lib.el_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _run(self, fn, async_op):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)                              # inputs written on the caller's stream are complete
+        with torch.cuda.stream(self.stream):
+            fn(self.stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        work = _AbiWork(done)
+        if async_op:
+            return work
+        work.wait()
+        return None
+
+    def all_reduce_sum(self, t, async_op=False):
+        if t.dtype != torch.float32:
+            # the fp64 loss scalar: gather the ranks' values (el_allgather_rows moves bytes) and add them here
+            parts = self.all_gather(t.reshape(1, -1)).reshape(self.world, -1)
+            t.copy_(parts.sum(0).reshape(t.shape))
+            return None if async_op else t
+        assert t.is_contiguous()
+        w = self._run(lambda s: ops.check(self.ctx.lib.el_allreduce_rows(self.ctx.handle, self._h, s, t.data_ptr(), t.numel()),
+                                          "el_allreduce_rows"), async_op)
+        return w if async_op else t
+
+    def all_gather(self, t):
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._run(lambda s: ops.check(self.ctx.lib.el_allgather_rows(self.ctx.handle, self._h, s, t.data_ptr(), out.data_ptr(),
+                                                                     t.numel() * t.element_size()), "el_allgather_rows"), False)
+        return out
+
+    def all_gather_topk(self, idx, val):
+        """[n, k] partial lists of every rank -> ([world, n, k] ids, [world, n, k] scores) in one RCCL group."""
+        n, k = idx.shape
+        gi = torch.empty((self.world, n, k), dtype=torch.int32, device=idx.device)
+        gv = torch.empty((self.world, n, k), dtype=torch.float32, device=idx.device)
+        self._run(lambda s: ops.check(self.ctx.lib.el_allgather_topk(self.ctx.handle, self._h, s, idx.data_ptr(), val.data_ptr(), int(n),
+                                                                     int(k), gi.data_ptr(), gv.data_ptr()), "el_allgather_topk"), False)
+        return gi, gv
+
+    def reduce_scatter_rows(self, out, full):
+        assert out.is_contiguous() and full.is_contiguous() and full.numel() == self.world * out.numel()
+        self._run(lambda s: ops.check(self.ctx.lib.el_reduce_scatter_rows(self.ctx.handle, self._h, s, full.data_ptr(), out.data_ptr(),
+                                                                          out.numel()), "el_reduce_scatter_rows"), False)
+        return out
+
+    def all_gather_rows_into(self, full, part, async_op=False):
+        part = part if part.is_contiguous() else part.contiguous()
+        w = self._run(lambda s: ops.check(self.ctx.lib.el_allgather_rows(self.ctx.handle, self._h, s, part.data_ptr(), full.data_ptr(),
+                                                                         part.numel() * part.element_size()), "el_allgather_rows"), async_op)
+        return w if async_op else full
+
+
+def make_collectives(kind, ctx=None, rank=0, world=1):
+    """kind "torch": torch.distributed (RCCL through the process group); "abi": RCCL through the library's own C ABI."""
+    if kind == "abi":
+        return RcclAbiCollectives(ctx, rank, world)
+    return _Collectives()
+
+
 # ------------------------------------------------------------------------------------------------------
 # top-k
 # ------------------------------------------------------------------------------------------------------
@@ -107,8 +232,11 @@ def sharded_topk(ctx, coll, Gu, Gi_shard, Bi_shard, item_lo, u_start, u_stop, k,
     if coll.world == 1 and not coll.always:
         return pi, pv
     n = u_stop - u_start
-    gi = coll.all_gather(pi).reshape(coll.world, n, k)
-    gv = coll.all_gather(pv).reshape(coll.world, n, k)
+    if hasattr(coll, "all_gather_topk"):                          # C ABI: both lists in one RCCL group (el_allgather_topk)
+        gi, gv = coll.all_gather_topk(pi, pv)
+    else:
+        gi = coll.all_gather(pi).reshape(coll.world, n, k)
+        gv = coll.all_gather(pv).reshape(coll.world, n, k)
     return ops.topk_merge(ctx, gi, gv)
 
 

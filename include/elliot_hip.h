@@ -602,6 +602,29 @@ int el_topk_fragile(el_ctx* ctx, void* stream, const float* Gu, const float* Gi,
                     const int32_t* idx, const float* val, int64_t ld, int32_t k, int64_t item_offset,
                     unsigned char* flags, uint64_t* counts);
 
+/* ---- Collectives of the sharded paths (new design; the reference is single-device) --------------------
+ * RCCL over xGMI, one communicator per rank = per process = per GPU.  RCCL is bound at run time (the nccl* symbols already in
+ * the process, else librccl.so.1): no link-time dependency.  Rank 0 obtains the 128-byte id (el_comm_unique_id) and hands it
+ * to the other ranks out of band (file, TCP store, MPI -- the host's business), every rank calls el_comm_init with it.
+ * All calls are asynchronous on `stream`; buffers are device pointers.
+ *   el_allreduce_rows       buf[0..count) <- sum over ranks, in place (fp32): the item gradients gGi / gBi of the user-sharded
+ *                           step, the dense gradients of NeuMF / Mult-VAE -- north_star's "all-reduce of user-row gradients"
+ *                           when buf is the dense user-gradient table
+ *   el_reduce_scatter_rows  own[0..count_per_rank) <- block `rank` of the element-wise sum of full[0..world*count_per_rank)
+ *   el_allgather_rows       full <- concatenation of every rank's `part` (bytes_per_rank bytes each; part may alias its block)
+ *   el_allgather_topk       all_idx / all_val [world, n_users, k] <- every rank's partial lists of el_score_topk on its item
+ *                           shard; el_topk_merge(all_idx, all_val, G = world) follows                                    */
+typedef struct el_comm el_comm;
+int el_comm_unique_id(void* id128);
+int el_comm_init(el_ctx* ctx, const void* id128, int rank, int world, el_comm** out);
+int el_comm_destroy(el_comm* comm);
+int el_comm_rank(const el_comm* comm, int* rank, int* world);
+int el_allreduce_rows(el_ctx* ctx, el_comm* comm, void* stream, float* buf, int64_t count);
+int el_reduce_scatter_rows(el_ctx* ctx, el_comm* comm, void* stream, const float* full, float* own, int64_t count_per_rank);
+int el_allgather_rows(el_ctx* ctx, el_comm* comm, void* stream, const void* part, void* full, int64_t bytes_per_rank);
+int el_allgather_topk(el_ctx* ctx, el_comm* comm, void* stream, const int32_t* part_idx, const float* part_val,
+                      int64_t n_users, int32_t k, int32_t* all_idx, float* all_val);
+
 #ifdef __cplusplus
 }
 #endif

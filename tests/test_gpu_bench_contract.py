@@ -93,3 +93,11 @@ def test_refuses_more_gpus_than_the_node_has():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=REPO, env=e)
     assert out.returncode != 0 and "refusing" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_collectives_through_the_c_abi_one_rank():
+    """--comm abi: the sharded legs with RCCL called through el_comm_* (one rank: an API check on the 1-GPU box)."""
+    d = run_bench("--force-sharded", "--no-cpu-baseline", "--comm", "abi")
+    check_common(d)
+    assert d["config"]["collectives_through"] == "abi"
+    assert d["collectives"][0]["op"] == "all_reduce" and d["collectives"][0]["ms"] > 0
