@@ -320,6 +320,24 @@ __global__ __launch_bounds__(256) void k_rerank_rows(int32_t* __restrict__ idx, 
     }
 }
 
+// the same for lists of up to 4096 entries (the link / re-score margins of point-wise models and CML grow the lists up to
+// 4032): one wave per row and workgroup, key buffer of cap = 2^m >= kk slots in dynamic LDS
+__global__ __launch_bounds__(64) void k_rerank_rows_long(int32_t* __restrict__ idx, float* __restrict__ vals, int64_t n_rows, int64_t ld,
+                                                         int kk, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
+    u64* kb = reinterpret_cast<u64*>(rr_lds);
+    const int lane = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    for (int t = lane; t < cap; t += 64) kb[t] = t < kk ? el_make_key(vals[r * ld + t], idx[r * ld + t]) : 0ull;
+    el_wave_lds_sync();
+    el_wave_bitonic_desc(kb, cap, lane);
+    for (int t = lane; t < kk; t += 64) {
+        const u64 k = kb[t];
+        idx[r * ld + t] = el_key_item(k);
+        vals[r * ld + t] = el_key_score(k);
+    }
+}
+
 int bits_for(int64_t n) {
     int b = 1;
     while ((1LL << b) < n && b < 32) ++b;
@@ -563,9 +581,16 @@ extern "C" int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64
 extern "C" int el_topk_rerank(el_ctx* ctx, void* stream, int32_t* idx, float* vals, int64_t n_rows, int64_t ld, int32_t kk) {
     if (int rc = el_bind(ctx)) return rc;
     if (n_rows <= 0 || kk <= 1) return 0;
-    EL_REQUIRE(idx && vals && ld >= kk && kk <= 64, "el_topk_rerank: needs kk <= 64 <= ... and ld >= kk (kk=%d, ld=%lld)", kk, (long long)ld);
-    EL_LAUNCH("k_rerank_rows", k_rerank_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, vals, n_rows, ld,
-              (int)kk);
+    EL_REQUIRE(idx && vals && ld >= kk && kk <= 4096, "el_topk_rerank: needs kk <= 4096 and ld >= kk (kk=%d, ld=%lld)", kk, (long long)ld);
+    if (kk <= 64) {
+        EL_LAUNCH("k_rerank_rows", k_rerank_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, vals, n_rows, ld,
+                  (int)kk);
+    } else {
+        int cap = 128;
+        while (cap < kk) cap <<= 1;
+        EL_LAUNCH("k_rerank_rows", k_rerank_rows_long, dim3((unsigned)n_rows), dim3(64), (size_t)cap * 8, (hipStream_t)stream, idx, vals, n_rows,
+                  ld, (int)kk, cap);
+    }
     EL_CHECK_LAUNCH();
     return 0;
 }

@@ -986,16 +986,13 @@ _CML_MARGIN = 16             # CML re-scores with another formula: its fp32 roun
 
 def topk_rerank(ctx, idx, val):
     """Rows of (idx, val) re-ordered in place by (value desc, index asc) -- tf.nn.top_k's order -- after the values were
-    transformed (link, CML re-score).  Lists of up to 64 entries go through el_topk_rerank, longer ones through two stable
-    torch sorts.  Returns (idx, val)."""
+    transformed (link, CML re-score): el_topk_rerank, lists of up to 4096 entries.  Returns (idx, val)."""
     kk = idx.shape[1]
-    if kk <= 64:
-        check(ctx.lib.el_topk_rerank(ctx.handle, ctx.stream(), _ptr(idx, torch.int32), _ptr(val, torch.float32), int(idx.shape[0]),
-                                     int(idx.stride(0)), int(kk)), "el_topk_rerank")
-        return idx, val
-    order = torch.sort(idx, dim=1, stable=True).indices                           # index asc ...
-    by_val = torch.sort(torch.gather(val, 1, order), dim=1, descending=True, stable=True)   # ... then value desc, stable
-    return torch.gather(torch.gather(idx, 1, order), 1, by_val.indices), by_val.values
+    if kk > 4096:
+        raise ValueError("topk_rerank: lists of more than 4096 entries are not produced by any caller")
+    check(ctx.lib.el_topk_rerank(ctx.handle, ctx.stream(), _ptr(idx, torch.int32), _ptr(val, torch.float32), int(idx.shape[0]),
+                                 int(idx.stride(0)), int(kk)), "el_topk_rerank")
+    return idx, val
 
 
 class PwmfDeviceState:

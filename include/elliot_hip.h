@@ -533,7 +533,7 @@ int el_pwmf_train_loop(el_ctx* ctx, void* stream, const el_pwmf_state* st, const
 int el_pwmf_link_values(el_ctx* ctx, void* stream, float* vals, int64_t n_rows, int64_t ld, int32_t k, int kind,
                         const float* Bu, int64_t u_start);
 
-/* Re-order the first kk <= 64 entries of every row of (idx int32[n_rows, ld], vals float[n_rows, ld]) in place by
+/* Re-order the first kk <= 4096 entries of every row of (idx int32[n_rows, ld], vals float[n_rows, ld]) in place by
  * (value desc, index asc): the order tf.nn.top_k(sorted=True) returns (matrix_factorization_model.py:100-101) -- applied to
  * lists whose values were transformed after the selection (el_pwmf_link_values, el_cml_rescore).  NaN-free input assumed. */
 int el_topk_rerank(el_ctx* ctx, void* stream, int32_t* idx, float* vals, int64_t n_rows, int64_t ld, int32_t kk);

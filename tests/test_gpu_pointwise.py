@@ -311,3 +311,18 @@ def test_train_loop_equals_per_batch_calls(ctx, model, B):
     wa, wb = a.weights(), b.weights()
     for k in ("Gu", "Gi") + (("Bu", "Bi") if MODELS[model][1] else ()):
         assert np.abs(wa[k] - wb[k]).max() < 1e-6, k
+
+
+@pytest.mark.parametrize("kk", [2, 12, 64, 65, 200, 1000, 4032])
+def test_topk_rerank_any_length_equals_a_stable_two_key_sort(ctx, kk):
+    """el_topk_rerank: (value desc, index asc) for lists of up to 4096 entries -- ties on purpose (values drawn from a few
+    levels), rows of different content."""
+    rs = np.random.RandomState(kk)
+    n = 37
+    idx = np.stack([rs.permutation(10 * kk + 50)[:kk] for _ in range(n)]).astype(np.int32)
+    val = rs.choice(np.array([-1.5, 0.0, 0.25, 0.25000003, 3.0], np.float32), size=(n, kk)).astype(np.float32)
+    d = ctx.device
+    oi, ov = ops.topk_rerank(ctx, torch.from_numpy(idx.copy()).to(d), torch.from_numpy(val.copy()).to(d))
+    for r in range(n):
+        order = np.lexsort((idx[r], -val[r].astype(np.float64)))
+        assert np.array_equal(cpu(oi[r]), idx[r][order]) and np.array_equal(cpu(ov[r]), val[r][order]), (kk, r)
