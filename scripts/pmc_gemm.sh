@@ -33,5 +33,13 @@ for k, d in res.items():
         print("    MFMA util = %.1f %%" % (100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (d["GRBM_GUI_ACTIVE"] / 8.0)))
     if "SQ_WAVE_CYCLES" in d and "SQ_WAIT_ANY" in d:
         w = d["SQ_WAVE_CYCLES"]
-        print("    waves: parked %.0f %%, issue-stalled %.0f %%, issuing %.0f %%" % (100 * d["SQ_WAIT_ANY"] / w if False else 0, 0, 0))
+        print("    waves: parked (waitcnt/barrier) %.0f %%, issue-stalled (MFMA pipe / dependency) %.0f %%, issuing %.0f %%"
+              % (100 * d["SQ_WAIT_ANY"] / w, 100 * d["SQ_WAIT_INST_ANY"] / w, 100 * d["SQ_ACTIVE_INST_ANY"] / w))
+    if "SQ_LDS_BANK_CONFLICT" in d:
+        print("    LDS: bank-conflict cycles %.0f of %.0f active (%.2f %%)" % (d["SQ_LDS_BANK_CONFLICT"], d["SQ_LDS_IDX_ACTIVE"],
+              100.0 * d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1)))
+    if "FETCH_SIZE" in d:
+        print("    HBM-side traffic per launch: %.1f MiB fetched (x2 correction applied), %.1f MiB written" % (2 * d["FETCH_SIZE"] / 1024, d.get("WRITE_SIZE", 0) / 1024))
+    if "SQ_WAVES" in d:
+        print("    waves launched %.0f" % d["SQ_WAVES"])
 PY
