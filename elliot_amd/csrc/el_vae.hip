@@ -28,15 +28,18 @@ __device__ __forceinline__ float vae_drop_scale(float rate, u64 seed, u32 step, 
     return uni < rate ? 0.f : 1.0f / (1.0f - rate);
 }
 
-// one workgroup (4 waves) per batch row; wave w takes nonzeros w, w+4, ...; lane owns float4 chunks
-// c = lane, lane+64, ... of the H hidden units; the four partial rows are combined through LDS.
+// one workgroup (NW = 16 waves) per batch row; wave w takes nonzeros w, w+NW, ...; lane owns float4 chunks
+// c = lane, lane+64, ... of the H hidden units; the partial rows are combined through LDS in a fixed order.
+// (Four waves per row left the kernel's duration to its heaviest row: a user with 3000 interactions is a chain of 190
+//  dependent index -> W1-row round trips per wave; sixteen waves cut that chain fourfold and the 512 rows still fill the chip.)
+constexpr int ENC_NW = 16;
 template <int CPL>
-__global__ __launch_bounds__(256) void k_vae_enc1(const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
+__global__ __launch_bounds__(ENC_NW * 64) void k_vae_enc1(const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
                                                   const int32_t* __restrict__ indices, const float* __restrict__ W1,
                                                   const float* __restrict__ b1, int64_t B, int H, float rate, u64 seed,
                                                   u32 step, float* __restrict__ h, float* __restrict__ rnorm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);   // [4][H/4]
+    float4* part = reinterpret_cast<float4*>(smem);   // [ENC_NW][H/4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = blockIdx.x;
     const int32_t user = rows[b];
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void k_vae_enc1(const int32_t* __restrict__ ro
     // ENC_U nonzeros of a wave are in flight together: a heavy row (thousands of items) is a chain of dependent
     // index -> W1-row loads, and with one workgroup per batch row that chain, not bandwidth, was the kernel's duration
     constexpr int ENC_U = 4;
-    for (int64_t e0 = r0 + wave * ENC_U; e0 < r1; e0 += 4 * ENC_U) {
+    for (int64_t e0 = r0 + wave * ENC_U; e0 < r1; e0 += ENC_NW * ENC_U) {
         float wv[ENC_U];
         const float4* wr[ENC_U];
 #pragma unroll
@@ -86,14 +89,22 @@ __global__ __launch_bounds__(256) void k_vae_enc1(const int32_t* __restrict__ ro
     }
     __syncthreads();
     float* hb = h + b * (int64_t)H;
-    for (int c = threadIdx.x; c < H4; c += 256) {
-        const float4 p0 = part[c], p1 = part[H4 + c], p2 = part[2 * H4 + c], p3 = part[3 * H4 + c];
+    for (int c = threadIdx.x; c < H4; c += ENC_NW * 64) {
+        float4 t = part[c];
+#pragma unroll
+        for (int w = 1; w < ENC_NW; ++w) {                  // fixed order: run-to-run identical sums
+            const float4 q = part[w * H4 + c];
+            t.x += q.x;
+            t.y += q.y;
+            t.z += q.z;
+            t.w += q.w;
+        }
         const float4 bb = reinterpret_cast<const float4*>(b1)[c];
         float4 o;
-        o.x = tanhf(((p0.x + p1.x) + (p2.x + p3.x)) + bb.x);
-        o.y = tanhf(((p0.y + p1.y) + (p2.y + p3.y)) + bb.y);
-        o.z = tanhf(((p0.z + p1.z) + (p2.z + p3.z)) + bb.z);
-        o.w = tanhf(((p0.w + p1.w) + (p2.w + p3.w)) + bb.w);
+        o.x = tanhf(t.x + bb.x);
+        o.y = tanhf(t.y + bb.y);
+        o.z = tanhf(t.z + bb.z);
+        o.w = tanhf(t.w + bb.w);
         reinterpret_cast<float4*>(hb)[c] = o;
     }
     if (threadIdx.x == 0) rnorm[b] = nrm;
@@ -184,34 +195,71 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int
 //   mode 0 (predict): logits <- log_softmax(logits)                         (multi_vae_model.py:153-155)
 //   mode 1 (train)  : loss += -(1/B) sum_i log_softmax_i x_i ;  logits <- d loss / d logits
 //                     = (softmax * sum_i x_i - x) / B                        (:131-137)
-__global__ __launch_bounds__(256) void k_vae_softmax(float* __restrict__ logits, const int32_t* __restrict__ rows,
-                                                     const int64_t* __restrict__ indptr,
-                                                     const int32_t* __restrict__ indices, int64_t B, int64_t I,
-                                                     int mode, double* loss_out, int64_t Bd) {
-    __shared__ float red[4];
+constexpr int SMX_NT = 1024;
+// one workgroup of 1024 threads per batch row (26 744 logits = 107 KB, L2-resident after the first sweep); 16-byte accesses
+// when the rows are 16-byte aligned (I % 4 == 0)
+template <bool V4>
+__global__ __launch_bounds__(SMX_NT) void k_vae_softmax(float* __restrict__ logits, const int32_t* __restrict__ rows,
+                                                        const int64_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, int64_t B, int64_t I,
+                                                        int mode, double* loss_out, int64_t Bd) {
+    constexpr int NWV = SMX_NT / 64;
+    __shared__ float red[NWV];
     __shared__ float bc;
     const int64_t b = blockIdx.x;
     float* row = logits + b * I;
+    float4* row4 = reinterpret_cast<float4*>(row);
+    const int64_t I4 = V4 ? (I >> 2) : 0;
     const int tid = threadIdx.x;
     float m = -INFINITY;
-    for (int64_t i = tid; i < I; i += 256) m = fmaxf(m, row[i]);
+    if (V4) {
+        for (int64_t i = tid; i < I4; i += SMX_NT) {
+            const float4 v = row4[i];
+            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+    } else {
+        for (int64_t i = tid; i < I; i += SMX_NT) m = fmaxf(m, row[i]);
+    }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) {
+        float t = red[0];
+        for (int w = 1; w < NWV; ++w) t = fmaxf(t, red[w]);
+        bc = t;
+    }
     __syncthreads();
     m = bc;
     float s = 0.f;
-    for (int64_t i = tid; i < I; i += 256) s += expf(row[i] - m);
+    if (V4) {
+        for (int64_t i = tid; i < I4; i += SMX_NT) {
+            const float4 v = row4[i];
+            s += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+        }
+    } else {
+        for (int64_t i = tid; i < I; i += SMX_NT) s += expf(row[i] - m);
+    }
     s = el_group_sum(s, 64);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) bc = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NWV; ++w) t += red[w];
+        bc = t;
+    }
     __syncthreads();
     const float lse = m + logf(bc);
     if (mode == 0) {
-        for (int64_t i = tid; i < I; i += 256) row[i] = row[i] - lse;
+        if (V4) {
+            for (int64_t i = tid; i < I4; i += SMX_NT) {
+                float4 v = row4[i];
+                v.x -= lse, v.y -= lse, v.z -= lse, v.w -= lse;
+                row4[i] = v;
+            }
+        } else {
+            for (int64_t i = tid; i < I; i += SMX_NT) row[i] = row[i] - lse;
+        }
         return;
     }
     const int32_t user = rows[b];
@@ -219,19 +267,29 @@ __global__ __launch_bounds__(256) void k_vae_softmax(float* __restrict__ logits,
     const float cnt = (float)(r1 - r0);          // sum_i x_i for the binary train row
     // NLL over the row's positives (reads the ORIGINAL logits: do this before overwriting)
     float nll = 0.f;
-    for (int64_t e = r0 + tid; e < r1; e += 256) nll += row[indices[e]] - lse;
+    for (int64_t e = r0 + tid; e < r1; e += SMX_NT) nll += row[indices[e]] - lse;
     nll = el_group_sum(nll, 64);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = nll;
     __syncthreads();
     if (tid == 0) {
-        const double tot = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+        double tot = 0.0;
+        for (int w = 0; w < NWV; ++w) tot += (double)red[w];
         atomicAdd(loss_out, -tot / (double)Bd);
     }
     const float invB = 1.0f / (float)Bd;
-    for (int64_t i = tid; i < I; i += 256) row[i] = expf(row[i] - lse) * cnt * invB;
+    const float sc = cnt * invB;
+    if (V4) {
+        for (int64_t i = tid; i < I4; i += SMX_NT) {
+            float4 v = row4[i];
+            v.x = expf(v.x - lse) * sc, v.y = expf(v.y - lse) * sc, v.z = expf(v.z - lse) * sc, v.w = expf(v.w - lse) * sc;
+            row4[i] = v;
+        }
+    } else {
+        for (int64_t i = tid; i < I; i += SMX_NT) row[i] = expf(row[i] - lse) * sc;
+    }
     __syncthreads();
-    for (int64_t e = r0 + tid; e < r1; e += 256) row[indices[e]] -= invB;
+    for (int64_t e = r0 + tid; e < r1; e += SMX_NT) row[indices[e]] -= invB;
 }
 
 // TF dense ApplyAdam arithmetic; resets the gradient buffer
@@ -274,11 +332,11 @@ static int vae_check(const el_vae_state* st, int64_t B) {
     do {                                                                                                \
         const int cpl = (st->H / 4 + 63) / 64;                                                          \
         const unsigned g = (unsigned)B;                                                                 \
-        const size_t lds = (size_t)st->H * 4 * 4;                                                       \
-        if (cpl <= 1) EL_LAUNCH(#KERN, (KERN<1>), dim3(g), dim3(256), lds, s, __VA_ARGS__);             \
-        else if (cpl <= 2) EL_LAUNCH(#KERN, (KERN<2>), dim3(g), dim3(256), lds, s, __VA_ARGS__);        \
-        else if (cpl <= 3) EL_LAUNCH(#KERN, (KERN<3>), dim3(g), dim3(256), lds, s, __VA_ARGS__);        \
-        else EL_LAUNCH(#KERN, (KERN<4>), dim3(g), dim3(256), lds, s, __VA_ARGS__);                      \
+        const size_t lds = (size_t)st->H * 4 * ENC_NW;                                                  \
+        if (cpl <= 1) EL_LAUNCH(#KERN, (KERN<1>), dim3(g), dim3(ENC_NW * 64), lds, s, __VA_ARGS__);     \
+        else if (cpl <= 2) EL_LAUNCH(#KERN, (KERN<2>), dim3(g), dim3(ENC_NW * 64), lds, s, __VA_ARGS__); \
+        else if (cpl <= 3) EL_LAUNCH(#KERN, (KERN<3>), dim3(g), dim3(ENC_NW * 64), lds, s, __VA_ARGS__); \
+        else EL_LAUNCH(#KERN, (KERN<4>), dim3(g), dim3(ENC_NW * 64), lds, s, __VA_ARGS__);              \
     } while (0)
 
 static int colsum(hipStream_t s, const float* X, int64_t B, int64_t N, float* out) {
@@ -319,7 +377,10 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     const int64_t I = st->I;
     if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, anneal, dropout_rate, dropout_seed, (u32)step, loss_out, Bd)) return rc;
     // loss + dlogits (in place)
-    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out, Bd);
+    if (I % 4 == 0 && ((uintptr_t)st->logits & 15) == 0)
+        EL_LAUNCH("k_vae_softmax", k_vae_softmax<true>, dim3((unsigned)B), dim3(SMX_NT), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out, Bd);
+    else
+        EL_LAUNCH("k_vae_softmax", k_vae_softmax<false>, dim3((unsigned)B), dim3(SMX_NT), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out, Bd);
     float* dl = st->logits;
     // decoder output layer
     if (int rc = el_gemm_f32(ctx, s, 1, 0, H, I, B, st->h2, H, dl, I, st->g[6], I, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dW4 = h2^T dl
@@ -396,7 +457,10 @@ extern "C" int el_vae_predict(el_ctx* ctx, void* stream, const el_vae_state* st,
     EL_REQUIRE(indptr && indices && rows, "el_vae_predict: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = vae_forward(ctx, s, st, indptr, indices, rows, B, eps, 0.f, 0.f, 0, 0, nullptr, B)) return rc;
-    EL_LAUNCH("k_vae_softmax", k_vae_softmax, dim3((unsigned)B), dim3(256), 0, s, st->logits, rows, indptr, indices, B, st->I, 0, nullptr, B);
+    if (st->I % 4 == 0 && ((uintptr_t)st->logits & 15) == 0)
+        EL_LAUNCH("k_vae_softmax", k_vae_softmax<true>, dim3((unsigned)B), dim3(SMX_NT), 0, s, st->logits, rows, indptr, indices, B, st->I, 0, nullptr, B);
+    else
+        EL_LAUNCH("k_vae_softmax", k_vae_softmax<false>, dim3((unsigned)B), dim3(SMX_NT), 0, s, st->logits, rows, indptr, indices, B, st->I, 0, nullptr, B);
     EL_CHECK_LAUNCH();
     return 0;
 }
