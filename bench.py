@@ -198,14 +198,19 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
-def timed(ctx, world, fn, warmup, steps, finish=None):
-    """W untimed calls, then exactly K calls between barrier + synchronize on both sides; max over ranks."""
+def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=True):
+    """W untimed calls, then exactly K calls between barrier + synchronize on both sides; max over ranks.
+    The per-kernel hipEvents (two per launch) ride along in the timed region for the BPR legs (8-12 launches per step: their
+    cost is below the noise and the kernel times then belong to exactly the timed steps).  Legs of 40+ short launches per step
+    (Mult-VAE, NeuMF) are timed WITHOUT them and profiled in a second pass of K steps (events_in_timed_region=False): the
+    events would otherwise add ~2 us per launch to the reported step."""
     for _ in range(warmup):
         fn()
     if finish:
         finish()
     barrier(world)
-    ctx.timing(True)
+    if events_in_timed_region:
+        ctx.timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
@@ -213,6 +218,13 @@ def timed(ctx, world, fn, warmup, steps, finish=None):
         finish()                                                 # a collective still in flight belongs to the timed work
     barrier(world)
     dt = time.perf_counter() - t0
+    if not events_in_timed_region:
+        ctx.timing(True)
+        for _ in range(steps):
+            fn()
+        if finish:
+            finish()
+        barrier(world)
     ctx.timing(False)
     rep = ctx.timing_report()
     return max_over_ranks(dt, world, ctx.device), rep
@@ -612,7 +624,7 @@ def vae_leg(args, ctx):
         it[0] += 1
         st.train_step(csr, perm[b * B:(b + 1) * B], 0.001, min(0.2, it[0] / 200000.0), eps=eps)
 
-    dt, rep = timed(ctx, 1, step, W, K)
+    dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False)
     loss = st.pop_loss()
     ms = dt / K * 1e3
     nnz_row = float(csr.nnz) / U
@@ -626,7 +638,7 @@ def vae_leg(args, ctx):
     return {"value": B * K / dt, "unit": "users/s", "ms_per_step": ms,
             "workload": f"MultiVAE {U} users x {I} items (ML-20M shape, BASELINE configs[2]), hidden {H}, latent {L}, batch {B}, "
                         f"{int(csr.nnz)} interactions ({nnz_row:.0f}/user), Adam, anneal schedule of multi_vae.py:105-108",
-            "loss_mean": loss / (K + W),
+            "loss_mean": loss / (2 * K + W),
             "roofline": {"kernel": gname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
                          "flops_per_step_gemm": gemm_flops, "gemm_ms_per_step": gms,
@@ -664,7 +676,7 @@ def neumf_leg(args, ctx):
         it[0] += 1
         st.train_step(u, i, y, 0.001)
 
-    dt, rep = timed(ctx, 1, step, W, K)
+    dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False)
     loss = st.pop_loss()
     ms = dt / K * 1e3
     mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # fwd 36 F^2 + 4 F per sample, x3 fwd + bwd
@@ -676,7 +688,7 @@ def neumf_leg(args, ctx):
             "workload": f"NeuMF d={F} (GMF + MLP {units}), {U} users x {I} items = the per-GPU shape of BASELINE configs[3] (10M x 1M over "
                         f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: dense over "
                         f"the four embedding tables)",
-            "loss_mean": loss / (K + W),
+            "loss_mean": loss / (2 * K + W),
             "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
                          "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,

@@ -110,6 +110,214 @@ __global__ __launch_bounds__(ENC_NW * 64) void k_vae_enc1(const int32_t* __restr
     if (threadIdx.x == 0) rnorm[b] = nrm;
 }
 
+// ---- dW1 = x~^T dh on the batch's nonzeros ---------------------------------------------------------------------------
+// x~ (the l2-normalised, dropped-out batch rows) has ~130 nonzeros per row of 26 744: as a dense GEMM (round 1: densify +
+// 26744 x 600 x 512 on the MFMA pipe, 0.21 ms) 99.5 % of the products are zeros.  Here the batch is transposed on the fly --
+// count per item (atomics on int counters), exclusive scan, fill (atomic cursors), and one wave per item that SORTS its list of
+// batch rows before it adds coef(b, item) * dh[b, :] in ascending b -- so the sums do not depend on the order the atomics
+// landed in (deterministic, like the GEMM it replaces) and every row of gW1 is written exactly once (zeros for items the
+// batch does not touch: gW1 is a dense variable's gradient, Keras' dense Adam reads all of it).
+__global__ __launch_bounds__(256) void k_vae_w1_count(const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices, int32_t* __restrict__ cnt) {
+    const int32_t user = rows[blockIdx.x];
+    const int64_t r0 = indptr[user], r1 = indptr[user + 1];
+    for (int64_t e = r0 + threadIdx.x; e < r1; e += 256) atomicAdd(cnt + indices[e], 1);
+}
+
+// off[0..I] = exclusive scan of cnt[0..I), cursor = off; one workgroup of 16 waves, coalesced: wave w owns a contiguous chunk,
+// pass 1 adds it up, pass 2 (after the 16 chunk sums are prefixed) writes 64 offsets per iteration from a wave-level scan
+// ... and lists the HEAVY items (more than W1_LIGHT batch rows) in heavy[1..], their number in heavy[0]
+constexpr int W1_LIGHT = 16;
+__global__ __launch_bounds__(1024) void k_vae_w1_scan(const int32_t* __restrict__ cnt, int64_t I, int32_t* __restrict__ off,
+                                                      int32_t* __restrict__ cursor, int32_t* __restrict__ heavy) {
+    __shared__ int32_t tot[16];
+    __shared__ int32_t nheavy;
+    if (threadIdx.x == 0) nheavy = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = ((I + 15) / 16 + 63) / 64 * 64, i0 = wave * chunk, i1 = (i0 + chunk < I) ? i0 + chunk : I;
+    int32_t s = 0;
+    for (int64_t i = i0 + lane; i < i1; i += 64) s += cnt[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) tot[wave] = s;
+    __syncthreads();
+    int32_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry += tot[w];
+    for (int64_t base = i0; base < i1; base += 64) {
+        const int64_t i = base + lane;
+        const int32_t v = i < i1 ? cnt[i] : 0;
+        int32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (i < i1) {
+            off[i] = carry + inc - v;
+            cursor[i] = carry + inc - v;
+            if (v > W1_LIGHT) heavy[1 + atomicAdd(&nheavy, 1)] = (int32_t)i;     // (few items: LDS atomics; any order)
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+    if (threadIdx.x == 1023) off[I] = carry;                 // the last wave's final carry = the grand total (its chunk may be empty)
+    __syncthreads();
+    if (threadIdx.x == 0) heavy[0] = nheavy;
+}
+
+__global__ __launch_bounds__(256) void k_vae_w1_fill(const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ indices, int32_t* __restrict__ cursor,
+                                                     int32_t* __restrict__ pairs) {
+    const int32_t b = blockIdx.x, user = rows[b];
+    const int64_t r0 = indptr[user], r1 = indptr[user + 1];
+    for (int64_t e = r0 + threadIdx.x; e < r1; e += 256) pairs[atomicAdd(cursor + indices[e], 1)] = b;
+}
+
+// one workgroup (W1_NW = 16 waves) per item.  The item's list of batch rows is turned into presence flags in LDS (batch rows
+// are distinct), wave w then walks ITS contiguous range of b ascending -- so the order of the sum is fixed whatever order the
+// atomics of k_vae_w1_fill landed in, without sorting -- four rows in flight at a time; the 16 partial rows are combined in wave
+// order.  A popular item sits in most rows of the batch: with one wave per item its 500 dependent row reads were the
+// kernel's whole duration.
+// LIGHT items (at most W1_LIGHT = 16 batch rows; most of the catalogue): one wave per item, four items per workgroup, no LDS --
+// lane t < n holds list entry t, its rank among the entries gives the ascending order, four rows in flight at a time.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_vae_w1_light(const int32_t* __restrict__ rows, const float* __restrict__ rnorm,
+                                                      const int32_t* __restrict__ off, const int32_t* __restrict__ pairs,
+                                                      const float* __restrict__ dh, int64_t I, int H, float rate, u64 seed, u32 step,
+                                                      float* __restrict__ gW1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= I) return;
+    const int o0 = off[item], n = off[item + 1] - o0;
+    if (n > W1_LIGHT) return;                                // k_vae_w1_rows writes this row
+    const int H4 = H >> 2;
+    float4 acc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n > 0) {
+        const int myb = lane < n ? pairs[o0 + lane] : 0x7fffffff;
+        float mycf = 0.f;
+        if (lane < n) mycf = rnorm[myb] * vae_drop_scale(rate, seed, step, (u32)rows[myb], (u32)item);
+        int rank = 0;
+        for (int t = 0; t < n; ++t) rank += (__shfl(myb, t, 64) < myb) ? 1 : 0;      // batch rows are distinct
+        for (int r0 = 0; r0 < n; r0 += 4) {
+            int bb[4];
+            float cf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u64 who = __ballot(lane < n && rank == r0 + t);
+                const int src = who ? __ffsll((long long)who) - 1 : 0;
+                bb[t] = who ? __shfl(myb, src, 64) : -1;
+                cf[t] = who ? __shfl(mycf, src, 64) : 0.f;
+            }
+            float4 v[4][CPL];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int c = lane + q * 64;
+                    v[t][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bb[t] >= 0 && c < H4) v[t][q] = reinterpret_cast<const float4*>(dh + (int64_t)bb[t] * H)[c];
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    acc[q].x += cf[t] * v[t][q].x;
+                    acc[q].y += cf[t] * v[t][q].y;
+                    acc[q].z += cf[t] * v[t][q].z;
+                    acc[q].w += cf[t] * v[t][q].w;
+                }
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(gW1 + item * (int64_t)H);
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lane + q * 64;
+        if (c < H4) dst[c] = acc[q];
+    }
+}
+
+// HEAVY items (listed by k_vae_w1_scan): a fixed grid walks the list.
+constexpr int W1_NW = 16;
+template <int CPL>
+__global__ __launch_bounds__(W1_NW * 64) void k_vae_w1_rows(const int32_t* __restrict__ rows, const float* __restrict__ rnorm,
+                                                          const int32_t* __restrict__ off, const int32_t* __restrict__ pairs,
+                                                          const float* __restrict__ dh, int64_t I, int H, int cap, float rate, u64 seed,
+                                                          u32 step, float* __restrict__ gW1, const int32_t* __restrict__ heavy) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H4 = H >> 2;
+    float4* part = reinterpret_cast<float4*>(smem);                          // [W1_NW][H4]
+    unsigned char* present = reinterpret_cast<unsigned char*>(part + (size_t)W1_NW * H4);   // [cap]
+    const int nh = heavy[0];
+  for (int hi = blockIdx.x; hi < nh; hi += gridDim.x) {
+    const int64_t item = heavy[1 + hi];
+    float4* dst = reinterpret_cast<float4*>(gW1 + item * (int64_t)H);
+    const int o0 = off[item], n = off[item + 1] - o0;
+    __syncthreads();                                         // (previous item's partials have been read)
+    for (int t = tid; t < cap; t += W1_NW * 64) present[t] = 0;
+    __syncthreads();
+    for (int t = tid; t < n; t += W1_NW * 64) present[pairs[o0 + t]] = 1;
+    __syncthreads();
+    float4 acc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int R = cap / W1_NW;                               // rows of the batch per wave (cap >= 1024: R >= 64)
+    for (int b0 = wave * R; b0 < (wave + 1) * R; b0 += 64) {
+        u64 m = __ballot(present[b0 + lane] != 0);
+        while (m) {
+            int bb[4];
+            float cf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                    // up to four present rows, their coefficients and row reads in flight
+                bb[t] = -1;
+                cf[t] = 0.f;
+                if (m) {
+                    bb[t] = b0 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    cf[t] = rnorm[bb[t]] * vae_drop_scale(rate, seed, step, (u32)rows[bb[t]], (u32)item);
+                }
+            }
+            float4 v[4][CPL];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int c = lane + q * 64;
+                    v[t][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bb[t] >= 0 && c < H4) v[t][q] = reinterpret_cast<const float4*>(dh + (int64_t)bb[t] * H)[c];
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    acc[q].x += cf[t] * v[t][q].x;
+                    acc[q].y += cf[t] * v[t][q].y;
+                    acc[q].z += cf[t] * v[t][q].z;
+                    acc[q].w += cf[t] * v[t][q].w;
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lane + q * 64;
+        if (c < H4) part[wave * H4 + c] = acc[q];
+    }
+    __syncthreads();
+    for (int c = tid; c < H4; c += W1_NW * 64) {
+        float4 t = part[c];
+#pragma unroll
+        for (int w = 1; w < W1_NW; ++w) {
+            const float4 q = part[w * H4 + c];
+            t.x += q.x;
+            t.y += q.y;
+            t.z += q.z;
+            t.w += q.w;
+        }
+        dst[c] = t;
+    }
+  }
+}
+
 // dense image of the normalised (and dropped-out) batch rows: xd[b, item] = x~(b, item), zero elsewhere.
 // dW1 = xd^T dh is then one dense MFMA GEMM (the reference multiplies the dense block too) -- deterministic,
 // and 4x faster here than scattering 600-float rows with atomics onto popular items.
@@ -404,7 +612,40 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     }
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh, st->h, B * H);
     if (int rc = colsum(s, st->dh, B, H, st->g[1])) return rc;
-    // dW1 = xd^T dhpre with xd the dense image of the batch (the logits buffer is free again: dl was consumed)
+    // dW1 = x~^T dhpre.  Sparse transposition of the batch (k_vae_w1_*) when its scratch fits: counters in the GEMM workspace,
+    // the (item-ordered) list of batch rows in the logits buffer (free again: dl was consumed)
+    static const bool sparse_on = [] { const char* e = getenv("EL_VAE_SPARSE_W1"); return !(e && atoi(e) == 0); }();
+    const int cpl1 = (H / 4 + 63) / 64;
+    if (sparse_on && B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && st->ws_bytes >= (size_t)(4 * (I + 1) + 4) * 4 &&
+        (((uintptr_t)st->dh | (uintptr_t)st->g[0]) & 15) == 0) {
+        int32_t* cnt = (int32_t*)st->ws;
+        int32_t* off = cnt + (I + 1);
+        int32_t* cursor = off + (I + 1);
+        int32_t* pairs = (int32_t*)st->logits;                      // <= B * I entries: every batch row has <= I nonzeros
+        EL_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(I + 1) * 4, s));
+        EL_LAUNCH("k_vae_w1_count", k_vae_w1_count, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, cnt);
+        int32_t* heavy = cursor + (I + 1);                          // [1 + I]
+        EL_LAUNCH("k_vae_w1_scan", k_vae_w1_scan, dim3(1), dim3(1024), 0, s, cnt, I, off, cursor, heavy);
+        EL_LAUNCH("k_vae_w1_fill", k_vae_w1_fill, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, cursor, pairs);
+        int cap = 1024;                                             // presence flags: >= 64 batch rows per wave
+        while (cap < B) cap <<= 1;
+        const size_t lds = (size_t)W1_NW * (H / 4) * 16 + (size_t)cap;
+        const unsigned gl = (unsigned)((I + 3) / 4), gh = (unsigned)(ctx->cus * 2);
+#define EL_W1R(CPL_)                                                                                                                   \
+    do {                                                                                                                               \
+        EL_LAUNCH("k_vae_w1_light", (k_vae_w1_light<CPL_>), dim3(gl), dim3(256), 0, s, rows, st->rnorm, off, pairs, st->dh, I, H,      \
+                  dropout_rate, (u64)dropout_seed, (u32)step, st->g[0]);                                                               \
+        EL_LAUNCH("k_vae_w1_rows", (k_vae_w1_rows<CPL_>), dim3(gh), dim3(W1_NW * 64), lds, s, rows, st->rnorm, off, pairs, st->dh, I, H, \
+                  cap, dropout_rate, (u64)dropout_seed, (u32)step, st->g[0], heavy);                                                   \
+    } while (0)
+        if (cpl1 <= 1) EL_W1R(1);
+        else if (cpl1 <= 2) EL_W1R(2);
+        else if (cpl1 <= 3) EL_W1R(3);
+        else EL_W1R(4);
+#undef EL_W1R
+        EL_CHECK_LAUNCH();
+        return 0;
+    }
     EL_CHECK_HIP(hipMemsetAsync(st->logits, 0, (size_t)B * I * 4, s));
     EL_LAUNCH("k_vae_densify", k_vae_densify, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, st->rnorm, B, I,
               dropout_rate, (u64)dropout_seed, (u32)step, st->logits);
@@ -414,16 +655,68 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
 }
 
 // Adam on the ten variables (W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4)
+// Keras dense Adam on all eight variables of the model from ONE launch (eight launches of 3-100 us kernels were mostly
+// launch gaps), 16 bytes per lane: m += (g - m)(1 - b1); v += (g g - v)(1 - b2); theta -= (m alpha) / (sqrt(v) + eps)
+struct AdamOct {
+    float* th[8];
+    float* g[8];
+    float* m[8];
+    float* v[8];
+    int64_t n[8];
+};
+__global__ __launch_bounds__(256) void k_adam_apply_oct(AdamOct t, float alpha, float b1, float b2, float eps) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        float *th = t.th[k], *g = t.g[k], *m = t.m[k], *v = t.v[k];
+        const int64_t n = t.n[k];
+        int64_t done = 0;
+        if ((((uintptr_t)th | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+            f4 *th4 = reinterpret_cast<f4*>(th), *m4 = reinterpret_cast<f4*>(m), *v4 = reinterpret_cast<f4*>(v);
+            const f4* g4 = reinterpret_cast<const f4*>(g);
+            const int64_t n4 = n >> 2;
+            for (int64_t e = tid; e < n4; e += stride) {
+                f4 a = __builtin_nontemporal_load(th4 + e), mm = __builtin_nontemporal_load(m4 + e), vv = __builtin_nontemporal_load(v4 + e);
+                const f4 gg = __builtin_nontemporal_load(g4 + e);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    mm[x] = mm[x] + (gg[x] - mm[x]) * omb1;
+                    vv[x] = vv[x] + (gg[x] * gg[x] - vv[x]) * omb2;
+                    a[x] = a[x] - (mm[x] * alpha) / (sqrtf(vv[x]) + eps);
+                }
+                __builtin_nontemporal_store(a, th4 + e);
+                __builtin_nontemporal_store(mm, m4 + e);
+                __builtin_nontemporal_store(vv, v4 + e);
+            }
+            done = n4 << 2;
+        }
+        for (int64_t e = done + tid; e < n; e += stride) {
+            const float gg = g[e];
+            float mm = m[e], vv = v[e];
+            mm = mm + (gg - mm) * omb1;
+            vv = vv + (gg * gg - vv) * omb2;
+            th[e] = th[e] - (mm * alpha) / (sqrtf(vv) + eps);
+            m[e] = mm;
+            v[e] = vv;
+        }
+    }
+}
+
 static int vae_apply(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t) {
     for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t] && st->m[t] && st->v[t], "el_vae: optimiser buffers missing");
     const int H = st->H, L = st->L;
     const int64_t I = st->I;
     const int64_t LL = st->dae ? L : 2 * L;
     const int64_t sizes[8] = {I * H, H, (int64_t)H * LL, LL, (int64_t)L * H, H, (int64_t)H * I, I};
-    for (int t = 0; t < 8; ++t) {
-        EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(grid1d(sizes[t], ctx)), dim3(256), 0, s, st->w[t], st->g[t],
-                  st->m[t], st->v[t], sizes[t], lr_t, 0.9f, 0.999f, 1e-7f, 0);
+    AdamOct t;
+    int64_t big = 0;
+    for (int k = 0; k < 8; ++k) {
+        t.th[k] = (float*)st->w[k], t.g[k] = (float*)st->g[k], t.m[k] = (float*)st->m[k], t.v[k] = (float*)st->v[k], t.n[k] = sizes[k];
+        if (sizes[k] > big) big = sizes[k];
     }
+    EL_LAUNCH("k_adam_apply_dense", k_adam_apply_oct, dim3(grid1d(big / 4 + 1, ctx)), dim3(256), 0, s, t, lr_t, 0.9f, 0.999f, 1e-7f);
     EL_CHECK_LAUNCH();
     return 0;
 }
