@@ -755,10 +755,13 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
     q.kA = k;
     q.surv = 128;
     if (k <= 12) {
-        const int sd = I_local >= 300000 ? 8 : (ntiles >= 192 ? 4 : 1);
+        // every 8th tile from 60 K items (round 2: at I = 100 K pass 1 drops 0.66 -> 0.36 ms and the sample of 12.5 K items still
+        // gives a usable guess: 4.52 -> 4.24 ms per 131 072-user block, nobody falls back; scripts/screen_sweep.sh), every 4th
+        // for smaller catalogues of at least 192 tiles
+        const int sd = I_local >= 60000 ? 8 : (ntiles >= 192 ? 4 : 1);
         if (sd > 1) {
             q.stride = sd;
-            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd == 8 ? 4 : 5);
+            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd == 8 ? (I_local >= 300000 ? 4 : 3) : 5);
         }
     } else {
         int sd = (int)(1.15 * k / 24.0 + 0.5);                  // kA ~ 20-30 of the 64 slots: a 1/sd sample has rank sd(kA + 1/2)
