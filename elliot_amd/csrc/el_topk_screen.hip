@@ -180,6 +180,7 @@ struct ScreenParams {
     int64_t list_cap;            // entries in `lists` / `lsc`
     int32_t* ulist;              // [n_users] flagged users (relative ids), filled by k_screen_flags
     int32_t* ulist_n;            // [1]
+    const void* zeros;           // >= 16 bytes of zeros in device memory (LDS-DMA source of rows past the catalogue's end)
     float* Tg;                   // [n_users] the threshold guess T (thr = T - 2E); k_screen_final verifies it
     float* Eu;                   // [n_users] E_u
     int kA;                      // T = kA-th largest clean slot maximum (== k with stride 1: T is then rigorous)
@@ -294,20 +295,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     const int step = (MODE == 1) ? sp.stride : 1;
     const int nv = (ntiles + step - 1) / step;              // tiles this pass visits: 0, step, 2 step, ...
     const int ng = (nv + NSUB - 1) / NSUB;                  // staged groups of NSUB visited tiles
-    uint4 pre[NSUB][NPC];
+    // The bf16 item tiles go from the image to LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write;
+    // round 1 staged them through 32 VGPRs).  The LDS side of a DMA is lane-linear (wave-uniform base + lane * 16 bytes), so the
+    // XOR swizzle is applied to the SOURCE slot: the lane that lands at position `pos` of row r fetches slot pos ^ key(r).
+    // Rows past the end of the catalogue read 16 bytes of zeros.  gload(x) is issued right after the barrier that retires
+    // group x - 2 (its buffer is free), the barrier at the end of group x - 1 (vmcnt(0) + s_barrier) sees it landed.
     float pre_bias[NSUB];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto gload = [&](int g) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const int64_t tile = (int64_t)(g * NSUB + sub) * step;
+            char* tbase = tiles + ((g & 1) * NSUB + sub) * TILEB;
 #pragma unroll
             for (int q = 0; q < NPC; ++q) {
-                const int piece = q * NT + tid;
-                const int r = piece / SL, sl = piece % SL;
-                const int64_t item = tile * TI + r;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (piece < TI * SL && item < I) v = *reinterpret_cast<const uint4*>(sp.Gib + item * FP + sl * 8);
-                pre[sub][q] = v;
+                const int i = q * NW + wave_u;                       // 1 KiB piece of the tile (wave-uniform)
+                if (i * 64 < TI * SL) {
+                    const int piece = i * 64 + lane;
+                    const int r = piece / SL, pos = piece % SL;
+                    const int64_t item = tile * TI + r;
+                    const unsigned short* src = sp.Gib + item * FP + ((pos ^ ((r / RPB) & SWZ)) * 8);
+                    if (!(item < I)) src = reinterpret_cast<const unsigned short*>(sp.zeros);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(tbase + i * 1024), 16, 0, 0);
+                }
             }
             pre_bias[sub] = 0.f;
             if (tid < TI) {
@@ -319,14 +330,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
     auto lstore = [&](int g) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
-#pragma unroll
-            for (int q = 0; q < NPC; ++q) {
-                const int piece = q * NT + tid;
-                const int r = piece / SL, sl = piece % SL;
-                if (piece < TI * SL)
-                    *reinterpret_cast<uint4*>(tiles + ((g & 1) * NSUB + sub) * TILEB + r * ROWB + ((sl ^ ((r / RPB) & SWZ)) << 4)) =
-                        pre[sub][q];
-            }
             if (tid < TI) Bs[((g & 3) * NSUB + sub) * TI + tid] = pre_bias[sub];
         }
     };
@@ -873,6 +876,7 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     const ScreenPolicy pol = screen_policy(p.k, p.I_local);
     sp.surv = pol.surv;
     sp.stride = pol.stride;
+    sp.zeros = g_el_cur_ctx->zeros;
     sp.kA = pol.kA;
     sp.ulist_n = (int32_t*)(stats + 2);
     void* fb_scratch = base;
