@@ -10,8 +10,9 @@ N = 1  workload = BASELINE.json configs[1]: BPRMF d=128 on synthetic 1M users x 
          step (train) : sample B triplets on the device -> gather -> BPR loss -> Adam (TF-dense semantics, the reference's
                         BPRMF_batch_model.train_step) for one batch of B = --batch triplets
          step (top-k) : fused score + masked top-k for one block of --topk-block users against the full catalogue
-       `value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Two secondary legs follow
-       (parity-test configurations of BASELINE.json, here with their own rooflines): "vae" = Mult-VAE at the ML-20M shape
+       `value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Secondary legs follow
+       (parity-test configurations of BASELINE.json, here with their own rooflines): "c4_one_gpu" = the same two steps at
+       north_star's target shape, 10 M users x 1 M items, resident on one GPU; "vae" = Mult-VAE at the ML-20M shape
        (configs[2]), "neumf" = NeuMF d=128 at the per-GPU shape of configs[3] under user sharding.
 N > 1  one process per GPU.  `python bench.py --gpus N` launches itself under torch.distributed.run when WORLD_SIZE is not
        set (the driver's own torchrun launch is honoured as is).  Primary leg: USER shards (the rank's user rows + a replica
@@ -66,7 +67,8 @@ def parse():
                     help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial "
                          "top-k (default: user for --shard user, item for the item-shard leg)")
     ap.add_argument("--legs", default="auto",
-                    help="comma list of bpr,item_shard,vae,neumf,metrics (auto: N=1 -> bpr,metrics,vae,neumf; N>1 -> bpr,item_shard)")
+                    help="comma list of bpr,item_shard,c4,vae,neumf,metrics (auto: N=1 -> bpr,metrics,c4,vae,neumf; N>1 -> bpr,item_shard)")
+    ap.add_argument("--c4-shape", default="10000000,1000000", help="users,items of the c4 leg (north_star's target shape on ONE GPU)")
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
                     help="N > 1: collectives through torch.distributed (RCCL process group) or through the library's own C ABI "
                          "(el_comm_init / el_allreduce_rows / el_allgather_topk: RCCL called directly)")
@@ -715,7 +717,7 @@ def main():
     torch.cuda.set_device(dev)
     U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
     sharded = world > 1 or args.force_sharded
-    legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else ["bpr", "metrics", "vae", "neumf"])
+    legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else ["bpr", "metrics", "c4", "vae", "neumf"])
 
     # ---------------- synthetic inputs, resident in HBM -------------------------------------------
     indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
@@ -733,8 +735,19 @@ def main():
         second = bpr_leg(args, ctx, world, rank, data, "item", args.topk_shard or "item")
     del data, indptr, indices
     torch.cuda.empty_cache()
-    vae = neumf = None
+    vae = neumf = c4 = None
     if world == 1 and not args.force_sharded:
+        if "c4" in legs:
+            # north_star's target shape (BASELINE configs[3] sizes: 10 M users x 1 M items, d = 128) resident on ONE GPU: the same
+            # two steps as the headline leg, 10x the rows (tables + Adam moments 16.9 GB, exclusion CSR 3.3 GB)
+            a4 = argparse.Namespace(**vars(args))
+            a4.users, a4.items = (int(x) for x in args.c4_shape.split(","))
+            ip4, ix4 = zipf_csr_device(a4.users, a4.items, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=4321)
+            d4 = {"indptr": ip4, "indices": ix4, "pos": ops.DeviceCSR.from_tensors(ip4, ix4, a4.items)}
+            c4 = bpr_leg(a4, ctx, world, rank, d4, "user", "user")
+            c4["workload"] = f"BPRMF d={F}, synthetic {a4.users} users x {a4.items} items on one GPU (north_star target shape)"
+            del d4, ip4, ix4
+            torch.cuda.empty_cache()
         if "vae" in legs:
             vae = vae_leg(args, ctx)
             torch.cuda.empty_cache()
@@ -766,6 +779,9 @@ def main():
     if second is not None:
         line["item_shard"] = {kk: second[kk] for kk in ("value", "unit", "ms_per_step", "scaling", "parallelism", "loss_per_pair_last",
                                                        "roofline", "topk", "collectives") if kk in second}
+    if c4 is not None:
+        line["c4_one_gpu"] = {kk: c4[kk] for kk in ("workload", "value", "unit", "ms_per_step", "interactions", "loss_per_pair_last",
+                                                    "roofline", "topk") if kk in c4}
     if vae is not None:
         line["vae"] = vae
     if neumf is not None:

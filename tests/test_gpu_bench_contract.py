@@ -57,8 +57,13 @@ def test_default_line_has_every_field():
 
 def test_secondary_legs_carry_their_rooflines():
     """vae = BASELINE configs[2], neumf = configs[3] per-GPU shape; here at toy shapes (the default shapes run in bench.py itself)."""
-    d = run_bench("--legs", "bpr,vae,neumf", "--no-cpu-baseline", "--vae-shape", "3000,1500,96,32,256", "--neumf-shape", "5000,3000,32,8192")
+    d = run_bench("--legs", "bpr,c4,vae,neumf", "--no-cpu-baseline", "--vae-shape", "3000,1500,96,32,256", "--neumf-shape", "5000,3000,32,8192",
+                  "--c4-shape", "300000,40000")
     check_common(d)
+    c4 = d["c4_one_gpu"]                                   # north_star's target shape on one GPU (here small)
+    assert c4["value"] > 0 and c4["unit"] == "pairs/s" and c4["topk"]["value"] > 0 and "300000 users x 40000 items" in c4["workload"]
+    for r in (c4["roofline"], c4["topk"]["roofline"]):
+        check_roofline(r)
     for leg, unit in (("vae", "users/s"), ("neumf", "samples/s")):
         assert d[leg]["value"] > 0 and d[leg]["unit"] == unit and d[leg]["workload"]
         check_roofline(d[leg]["roofline"])

@@ -207,6 +207,32 @@ def test_fullsize_topk_properties(ctx, world):
     world["s0"] = s0
 
 
+def test_c4_catalogue_topk_screened_vs_fp32_and_oracle(ctx):
+    """north_star's target catalogue (BASELINE configs[3]/C4: 1 M items, d = 128): a 16 384-user block, screened kernel == fp32
+    MFMA kernel on indices and score bits, == the C oracle on a sample of users; k = 10 and k = 100."""
+    dev = ctx.device
+    U4, I4, UB4 = 65536, 1_000_000, 16384
+    indptr, indices = zipf_csr_device(U4, I4, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=99)
+    pos = ops.DeviceCSR.from_tensors(indptr, indices, I4)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    Gu = (torch.rand((U4, F), generator=g, device=dev) * 2 - 1) * (6.0 / (U4 + F)) ** 0.5
+    Gi = (torch.rand((I4, F), generator=g, device=dev) * 2 - 1) * (6.0 / (I4 + F)) ** 0.5
+    Bi = (torch.rand(I4, generator=g, device=dev) - 0.5) * 0.01
+    s0 = 2 * UB4
+    for k, other, UB4 in ((10, "mfma", UB4), (100, "simple", 2048)):          # (the fp32 MFMA kernel keeps k <= 40 candidates per lane)
+        i_scr, v_scr = ops.score_topk(ctx, Gu, Gi, Bi, s0, s0 + UB4, k, excl=pos, algo="screen")
+        i_mf, v_mf = ops.score_topk(ctx, Gu, Gi, Bi, s0, s0 + UB4, k, excl=pos, algo=other)
+        assert torch.equal(i_scr, i_mf) and torch.equal(v_scr.view(torch.int32), v_mf.view(torch.int32)), k
+        users = torch.arange(s0, s0 + UB4, device=dev, dtype=torch.int32)
+        assert not bool(_row_members(pos, users, i_scr).any())
+        n = 6
+        ip = cpu(pos.indptr[s0:s0 + n + 1])
+        ix = cpu(pos.indices[int(ip[0]):int(ip[-1])])
+        ei, ev = cref.score_topk_f32(cpu(Gu[s0:s0 + n]), cpu(Gi), cpu(Bi), 0, n, k, excl=(ip - ip[0], ix))
+        assert np.array_equal(cpu(i_scr[:n]), ei) and np.array_equal(cpu(v_scr[:n]), ev), k
+
+
 def test_fullsize_metrics_checksum(ctx, world):
     if "idx" not in world:
         pytest.skip("needs the top-k block of the previous test")
