@@ -1,0 +1,181 @@
+// Host-side data plane: the two sequential integer loops between a ratings file and the CSR the kernels
+// consume, in C instead of per-user / per-row Python.  No HIP call in this file; the functions work without a GPU.
+//
+//   el_host_split_flags    per-user train / test flags exactly as elliot/splitter/base_splitter.py:256-274 draws them
+//                          (np.random.seed(seed) once -- process_splitting :73 --, then per user, in groupby order, a list
+//                          [0]*train + [1]*test shuffled by the legacy np.random.shuffle: Fisher-Yates from the top,
+//                          j = masked-rejection draw from the MT19937 32-bit stream)
+//   el_host_pyset_order    iteration order of a CPython set after inserting the given non-negative ints in order: the
+//                          private item ids of the reference are the positions in `list({k for a in train_dict.values() for k
+//                          in a.keys()})` (elliot/dataset/dataset.py:202, :211-214)
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "el_common.h"
+
+namespace {
+
+// MT19937, the generator behind the legacy numpy.random module (init_genrand seeding = np.random.seed(int))
+struct Mt {
+    uint32_t key[624];
+    int pos;
+    explicit Mt(uint32_t seed) {
+        for (int i = 0; i < 624; ++i) {
+            key[i] = seed;
+            seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u;
+        }
+        pos = 624;
+    }
+    void gen() {
+        const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+        int i = 0;
+        for (; i < 624 - 397; ++i) {
+            const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+            key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+        }
+        for (; i < 623; ++i) {
+            const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+            key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+        }
+        const uint32_t y = (key[623] & UP) | (key[0] & LO);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+        pos = 0;
+    }
+    uint32_t next() {
+        if (pos == 624) gen();
+        uint32_t y = key[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    // numpy random_interval / legacy rk_interval: uniform on [0, max], max <= 0xffffffff
+    uint32_t interval(uint32_t max) {
+        if (max == 0) return 0;
+        uint32_t mask = max;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        uint32_t v;
+        while ((v = (next() & mask)) > max) {
+        }
+        return v;
+    }
+};
+
+}  // namespace
+
+extern "C" int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int8_t* flags) {
+    EL_REQUIRE(seg_len != nullptr && flags != nullptr && n_seg >= 0, "el_host_split_flags: null argument");
+    EL_REQUIRE(mode == 0 || mode == 1, "el_host_split_flags: mode 0 = random_subsampling(test_ratio), 1 = leave_n_out(n)");
+    Mt mt(seed);
+    int64_t off = 0;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        const int64_t n = seg_len[s];
+        EL_REQUIRE(n >= 0 && n <= 0xffffffffll, "el_host_split_flags: a segment longer than 2^32 - 1 rows");
+        int64_t train;
+        if (mode == 0)
+            train = (int64_t)floor((double)n * (1.0 - param));         // base_splitter.py:257
+        else
+            train = n - (int64_t)param;                                // :277-279 (leave-n-out)
+        if (train < 0) train = 0;
+        if (train > n) train = n;
+        int8_t* x = flags + off;
+        memset(x, 0, (size_t)train);
+        memset(x + train, 1, (size_t)(n - train));
+        for (int64_t i = n - 1; i >= 1; --i) {                         // legacy shuffle of a sequence
+            const uint32_t j = mt.interval((uint32_t)i);
+            const int8_t t = x[i];
+            x[i] = x[j];
+            x[j] = t;
+        }
+        off += n;
+    }
+    return 0;
+}
+
+// CPython set (Objects/setobject.c, 3.7 - 3.12): open addressing, LINEAR_PROBES = 9 slots after the home slot when they fit
+// below the end of the table, then i = 5 i + 1 + perturb with perturb >>= 5; growth when fill * 5 >= mask * 3 to the first
+// power of two above used * 4 (used * 2 beyond 50 000); a resize re-inserts in table order; iteration is table order.
+// hash(int) = the int for 0 <= x < 2^61 - 1.  `out` receives the distinct keys in iteration order; *n_out their number.
+extern "C" int el_host_pyset_order(const int64_t* keys, int64_t n, int64_t* out, int64_t* n_out) {
+    EL_REQUIRE(n_out != nullptr && (n == 0 || (keys != nullptr && out != nullptr)), "el_host_pyset_order: null argument");
+    const int LINEAR_PROBES = 9;
+    size_t mask = 7, fill = 0;
+    int64_t* tab = (int64_t*)malloc((mask + 1) * sizeof(int64_t));   // key + 1, 0 = empty
+    EL_REQUIRE(tab != nullptr, "el_host_pyset_order: out of memory");
+    memset(tab, 0, (mask + 1) * sizeof(int64_t));
+    auto insert_clean = [](int64_t* t, size_t m, int64_t key) {
+        size_t perturb = (size_t)key, i = (size_t)key & m;
+        for (;;) {
+            if (t[i] == 0) {
+                t[i] = key + 1;
+                return;
+            }
+            if (i + LINEAR_PROBES <= m) {
+                for (int j = 1; j <= LINEAR_PROBES; ++j)
+                    if (t[i + j] == 0) {
+                        t[i + j] = key + 1;
+                        return;
+                    }
+            }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & m;
+        }
+    };
+    for (int64_t e = 0; e < n; ++e) {
+        const int64_t key = keys[e];
+        if (key < 0 || key >= 2305843009213693951ll) {
+            free(tab);
+            EL_REQUIRE(false, "el_host_pyset_order: keys must be ints in [0, 2^61 - 1)");
+        }
+        size_t perturb = (size_t)key, i = (size_t)key & mask;
+        bool placed = false, present = false;
+        while (!placed && !present) {
+            const int probes = (i + LINEAR_PROBES <= mask) ? LINEAR_PROBES : 0;
+            for (int j = 0; j <= probes; ++j) {
+                const int64_t v = tab[i + j];
+                if (v == 0) {
+                    tab[i + j] = key + 1;
+                    placed = true;
+                    break;
+                }
+                if (v == key + 1) {
+                    present = true;
+                    break;
+                }
+            }
+            if (!placed && !present) {
+                perturb >>= 5;
+                i = (i * 5 + 1 + perturb) & mask;
+            }
+        }
+        if (!placed) continue;
+        ++fill;
+        if (fill * 5 < mask * 3) continue;
+        const size_t minused = fill > 50000 ? fill * 2 : fill * 4;
+        size_t newsize = 8;
+        while (newsize <= minused) newsize <<= 1;
+        int64_t* nt = (int64_t*)malloc(newsize * sizeof(int64_t));
+        if (nt == nullptr) {
+            free(tab);
+            EL_REQUIRE(false, "el_host_pyset_order: out of memory");
+        }
+        memset(nt, 0, newsize * sizeof(int64_t));
+        for (size_t s = 0; s <= mask; ++s)
+            if (tab[s] != 0) insert_clean(nt, newsize - 1, tab[s] - 1);
+        free(tab);
+        tab = nt;
+        mask = newsize - 1;
+    }
+    int64_t m = 0;
+    for (size_t s = 0; s <= mask; ++s)
+        if (tab[s] != 0) out[m++] = tab[s] - 1;
+    *n_out = m;
+    free(tab);
+    return 0;
+}

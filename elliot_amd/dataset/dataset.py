@@ -4,7 +4,13 @@
 num_users/num_items/transactions, private_/public_ id maps, sp_i_train (CSR fp32), test_dict/val_dict, config,
 get_test()/get_validation() -- built from index arrays in vectorised NumPy instead of per-user pandas filters
 (`dataframe_to_dict`, dataset.py:247-255, is O(U*T)).  The dict-of-dict views (`train_dict`, `i_train_dict`) and
-the dense `allunrated_mask` are materialised lazily and only on request: the kernels never need them.
+the dense `allunrated_mask` are materialised lazily and only on request: the kernels never need them, and the
+stand-alone evaluator's device path takes the held-out splits as CSR arrays (`split_csr`) without the dicts.
+
+The two loops NumPy cannot vectorise run in C (include/elliot_hip.h, "host-side data plane"; no GPU involved):
+the per-user shuffles of the splitter (`el_host_split_flags`) and the CPython-set iteration order that defines the
+reference's private item ids (`el_host_pyset_order`) -- both bit-identical to the reference at any size
+(tests/test_host_dataplane.py).
 
 `load_tsv_dataset` covers the slice of the reference loader the hello-world experiment uses
 (config_files/sample_hello_world.yml:3-9): a `user<TAB>item<TAB>rating[<TAB>timestamp]` file plus per-user
@@ -27,14 +33,10 @@ class DataSet:
         self.config = config
         tu, ti, tr = (np.asarray(x) for x in train)
         if public_users is None:
-            _, first = np.unique(tu, return_index=True)
-            public_users = tu[np.sort(first)]
+            public_users = self._first_appearance(tu)
         if public_items is None:
-            if ti.shape[0] <= 5_000_000:
-                # user-major order of appearance, as `{k for a in train_dict.values() for k in a}` inserts them
-                public_items = np.array(list({int(k) for k in self._items_in_dict_order(tu, ti, public_users)}))
-            else:
-                public_items = np.unique(ti)
+            # user-major order of appearance, as `{k for a in train_dict.values() for k in a}` inserts them (dataset.py:202)
+            public_items = pyset_order(self._items_in_dict_order(tu, ti, public_users))
         self.users = list(np.asarray(public_users).tolist())
         self.items = list(np.asarray(public_items).tolist())
         self.num_users, self.num_items = len(self.users), len(self.items)
@@ -60,15 +62,61 @@ class DataSet:
 
     @staticmethod
     def _items_in_dict_order(tu, ti, public_users):
-        pos = {u: n for n, u in enumerate(np.asarray(public_users).tolist())}
-        rank = np.fromiter((pos[u] for u in tu.tolist()), dtype=np.int64, count=tu.shape[0])
-        return ti[np.argsort(rank, kind="stable")].tolist()
+        public_users = np.asarray(public_users)
+        rank = DataSet._to_private(tu, public_users)
+        return ti[DataSet._group_stable(rank, public_users.shape[0])]
 
     @staticmethod
-    def _to_private(pub, table):
+    def _to_private(pub, table, missing=None):
+        """Position of every element of `pub` in `table` (distinct values); `missing` = what an absent value maps to (None:
+        the caller guarantees membership).  Integer ids inside a modest range go through a lookup table (one gather);
+        otherwise a binary search in the sorted table (searchsorted with a `sorter=` argument dereferences it at every
+        comparison: 10 s per 2e7 queries, measured)."""
+        pub, table = np.asarray(pub), np.asarray(table)
+        if table.shape[0] == 0:
+            return np.full(pub.shape[0], -1 if missing is None else missing, dtype=np.int64)
+        if table.dtype.kind in "iu" and pub.dtype.kind in "iu":
+            lo, hi = int(table.min()), int(table.max())
+            if hi - lo < 8 * table.shape[0] + (1 << 24):
+                lut = np.full(hi - lo + 1, -1 if missing is None else missing, dtype=np.int64)
+                lut[table - lo] = np.arange(table.shape[0], dtype=np.int64)
+                if missing is None:
+                    return lut[pub - lo]
+                inside = (pub >= lo) & (pub <= hi)
+                out = np.full(pub.shape[0], missing, dtype=np.int64)
+                out[inside] = lut[pub[inside] - lo]
+                return out
         sorter = np.argsort(table, kind="stable")
-        loc = np.searchsorted(table, pub, sorter=sorter)
-        return sorter[loc]
+        st = table[sorter]
+        loc = np.searchsorted(st, pub)
+        if missing is None:
+            return sorter[loc]
+        loc = np.minimum(loc, st.shape[0] - 1)
+        return np.where(st[loc] == pub, sorter[loc], missing)
+
+    @staticmethod
+    def _first_appearance(values):
+        """Distinct values in order of first appearance (`list(data['userId'].unique())`, dataset.py:248)."""
+        values = np.asarray(values)
+        if values.dtype.kind in "iu" and values.shape[0]:
+            lo, hi = int(values.min()), int(values.max())
+            if hi - lo < 8 * values.shape[0] + (1 << 24):
+                first = np.full(hi - lo + 1, -1, dtype=np.int64)
+                first[values[::-1] - lo] = np.arange(values.shape[0] - 1, -1, -1, dtype=np.int64)   # repeated index: the last write wins
+                present = np.flatnonzero(first >= 0)
+                return values[np.sort(first[present])]
+        _, first = np.unique(values, return_index=True)
+        return values[np.sort(first)]
+
+    @staticmethod
+    def _group_stable(rank, n_groups):
+        """Permutation that brings equal ranks together, groups ascending, file order inside a group: a counting sort
+        (scipy's coo -> csr conversion), O(T) instead of a comparison sort of the whole interaction list."""
+        n = rank.shape[0]
+        if n == 0:
+            return np.zeros(0, dtype=np.int64)
+        m = sp.coo_matrix((np.ones(n, dtype=np.int8), (rank, np.arange(n, dtype=np.int64))), shape=(n_groups, n))
+        return sp.csr_matrix(m).indices.astype(np.int64, copy=False)
 
     # -- lazily materialised dict views ----------------------------------------------------------------
     def _dict_of(self, triples, restrict_users=True):
@@ -113,6 +161,34 @@ class DataSet:
             raise MemoryError("dense allunrated_mask refused at this size; use sp_i_train")
         return self.sp_i_train.toarray() == 0
 
+    def split_csr(self, validation=False):
+        """The held-out split as CSR arrays in PRIVATE ids (indptr int64 [U+1], cols int32 sorted per row, ratings fp32):
+        what `Evaluator._split_to_csr` derives from the dicts, built from the triples in vectorised NumPy.  Users the model
+        has no row for are dropped, items it has no row for get ids >= num_items (never recommended, still relevant); a
+        (user, item) pair listed twice keeps its LAST rating, as dict(zip(items, ratings)) does (dataset.py:252)."""
+        triples = self._val_triples if validation else self._test_triples
+        if triples is None:
+            return None
+        u, i, r = (np.asarray(x) for x in triples)
+        pu = self._to_private(u, self._pub_u, missing=-1)
+        ok = pu >= 0
+        pu, i, r = pu[ok], i[ok], np.asarray(r, dtype=np.float32)[ok]
+        pi = self._to_private(i, self._pub_i, missing=-1)
+        known = pi >= 0
+        if not known.all():
+            # items the model has no row for: ids num_items, num_items + 1, ... (any numbering does: they are never
+            # recommended and only count as relevant items of their user)
+            vals, inv = np.unique(i[~known], return_inverse=True)
+            pi[~known] = self.num_items + inv
+        key = pu * (int(pi.max(initial=0)) + 1) + pi
+        order = np.argsort(key, kind="stable")
+        key, pu, pi, r = key[order], pu[order], pi[order], r[order]
+        last = np.concatenate([key[1:] != key[:-1], [True]]) if key.shape[0] else np.zeros(0, dtype=bool)
+        pu, pi, r = pu[last], pi[last], r[last]
+        indptr = np.zeros(self.num_users + 1, dtype=np.int64)
+        np.cumsum(np.bincount(pu, minlength=self.num_users), out=indptr[1:])
+        return indptr, pi.astype(np.int32), r
+
     def get_test(self):
         return self.test_dict
 
@@ -121,23 +197,57 @@ class DataSet:
 
 
 # ---------------------------------------------------------------------------------------------------
+def _split_flags(users, mode, param, seed):
+    from .. import _lib
+    users = np.asarray(users)
+    lo = int(users.min()) if users.shape[0] and users.dtype.kind in "iu" else 0
+    if users.shape[0] and users.dtype.kind in "iu" and int(users.max()) - lo < 8 * users.shape[0] + (1 << 24):
+        # groupby order = ascending id: counting sort instead of a comparison sort of the whole file
+        cnt = np.bincount(users - lo)
+        seg = np.ascontiguousarray(cnt[cnt > 0], dtype=np.int64)
+        rank = (np.cumsum(cnt > 0) - 1)[users - lo]
+        order = DataSet._group_stable(rank, seg.shape[0])
+    else:
+        order = np.argsort(users, kind="stable")
+        su = users[order]
+        bounds = np.flatnonzero(np.concatenate([[True], su[1:] != su[:-1], [True]])) if su.shape[0] else np.zeros(1, dtype=np.int64)
+        seg = np.ascontiguousarray(np.diff(bounds), dtype=np.int64)
+    sorted_flags = np.empty(users.shape[0], dtype=np.int8)
+    _lib.check(_lib.load().el_host_split_flags(seg.ctypes.data, seg.shape[0], mode, float(param), int(seed) & 0xffffffff,
+                                               sorted_flags.ctypes.data), "el_host_split_flags")
+    flags = np.empty(users.shape[0], dtype=np.int8)
+    flags[order] = sorted_flags
+    return flags
+
+
 def random_subsampling(users, ratio, seed=42):
     """Per-user train/test flags as splitter/base_splitter.py:256-274 draws them: np.random.seed(seed) once
     (process_splitting :73), then for every user in groupby (= sorted id) order a list of floor(n(1-r)) zeros and
-    the rest ones is shuffled with the legacy np.random.shuffle and laid over the user's rows in file order."""
-    users = np.asarray(users)
-    rs = np.random.RandomState(seed)
-    flags = np.zeros(users.shape[0], dtype=np.int8)
-    order = np.argsort(users, kind="stable")
-    su = users[order]
-    bounds = np.flatnonzero(np.concatenate([[True], su[1:] != su[:-1], [True]]))
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        n = b - a
-        ntrain = int(math.floor(n * (1 - ratio)))
-        lst = [0] * ntrain + [1] * (n - ntrain)
-        rs.shuffle(lst)
-        flags[order[a:b]] = lst
-    return flags
+    the rest ones is shuffled with the legacy np.random.shuffle and laid over the user's rows in file order.  The shuffles
+    (a sequential MT19937 stream) run in C: `el_host_split_flags`."""
+    return _split_flags(users, 0, ratio, seed)
+
+
+def leave_n_out(users, n=1, seed=42):
+    """base_splitter.py:276-290 (random leave-n-out, one fold): n held-out rows per user, same stream discipline."""
+    return _split_flags(users, 1, n, seed)
+
+
+def pyset_order(keys):
+    """`list(set_built_by_inserting(keys))` -- the reference's private item order (dataset.py:202, :211-214).  Non-negative
+    integer ids take the C emulation of the CPython set (`el_host_pyset_order`, any size); anything else (string ids, negative
+    ids) goes through the interpreter's own set."""
+    keys = np.asarray(keys)
+    if keys.dtype.kind in "iu" and (keys.shape[0] == 0 or (int(keys.min()) >= 0 and int(keys.max()) < (1 << 61) - 1)):
+        from .. import _lib
+        k64 = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty(k64.shape[0], dtype=np.int64)
+        import ctypes
+        n_out = ctypes.c_int64(0)
+        _lib.check(_lib.load().el_host_pyset_order(k64.ctypes.data, k64.shape[0], out.ctypes.data, ctypes.byref(n_out)),
+                   "el_host_pyset_order")
+        return out[:n_out.value].astype(keys.dtype, copy=False)
+    return np.array(list({k for k in keys.tolist()}))
 
 
 def load_tsv_dataset(config, path, test_ratio=0.2, seed=42):

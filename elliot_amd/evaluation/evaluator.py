@@ -47,10 +47,23 @@ class Evaluator:
             raise Exception("Cutoff values must be smaller than recommendation list length (top_k)")
         self._rel_threshold = getattr(cfg.evaluation, "relevance_threshold", 0)
         self._metrics = [_canon(m) for m in cfg.evaluation.simple_metrics]
-        self._test = _Split(data.get_test(), self._rel_threshold)
-        val = data.get_validation() if hasattr(data, "get_validation") else None
-        self._val = _Split(val, self._rel_threshold) if val else None
+        self._dict_splits = None          # the dict-based form is only built when eval() is handed recommendation dicts
         self._needed_recommendations = cfg.top_k
+
+    def _splits(self):
+        if self._dict_splits is None:
+            data = self._data
+            val = data.get_validation() if hasattr(data, "get_validation") else None
+            self._dict_splits = (_Split(data.get_test(), self._rel_threshold), _Split(val, self._rel_threshold) if val else None)
+        return self._dict_splits
+
+    @property
+    def _test(self):
+        return self._splits()[0]
+
+    @property
+    def _val(self):
+        return self._splits()[1]
 
     def get_needed_recommendations(self):
         return self._needed_recommendations
@@ -63,6 +76,12 @@ class Evaluator:
         row for get ids >= num_items: never recommended, but they count as relevant items like in the reference."""
         if getattr(self, "_dev_sets", None) is None:
             from .. import ops
+            if hasattr(data, "split_csr"):                 # array data plane (SURVEY 8f N2): no dicts on the way to the device
+                test = data.split_csr(False)
+                val = data.split_csr(True)
+                self._dev_sets = {"test": ops.DeviceTestSet(*test, device),
+                                  "val": ops.DeviceTestSet(*val, device) if val is not None and val[1].shape[0] else None}
+                return self._dev_sets
             self._dev_sets = {"test": self._split_to_csr(ops, data, self._test_dict_raw(data, False), device)}
             raw_val = self._test_dict_raw(data, True)
             self._dev_sets["val"] = self._split_to_csr(ops, data, raw_val, device) if raw_val else None

@@ -106,6 +106,27 @@ def main():
         exp[data.private_users[u]] = [(data.private_items[int(i)], float(sc[i])) for i in top]
     same = all(test_recs[u] == exp[u] for u in exp) and set(test_recs) == set(exp)
     ref_eval = RefEvaluator(data, params).eval((exp, exp))
+    # our array data plane (el_host_split_flags / el_host_pyset_order / vectorised CSR) on the same TSV vs the reference's
+    # DataSetLoader + Splitter + DataSet: same split, same private ids, same matrices
+    from elliot_amd.dataset.dataset import load_tsv_dataset, default_config
+    ours = load_tsv_dataset(default_config(), config.data_config.dataset_path, 0.2, 42)
+    ref_test = data.get_test()
+    plane = {
+        "users": list(ours.users) == list(data.users), "items": list(ours.items) == list(data.items),
+        "transactions": int(ours.transactions) == int(data.transactions),
+        "sp_i_train": bool((ours.sp_i_train != data.sp_i_train).nnz == 0),
+        "test_dict": {u: dict(v) for u, v in ours.test_dict.items() if v} == {u: dict(v) for u, v in ref_test.items() if v},
+        "train_dict": {u: dict(v) for u, v in ours.train_dict.items()} == {u: dict(v) for u, v in data.train_dict.items()},
+    }
+    ip, cols, vals = ours.split_csr(False)
+    pu, pi = data.public_users, data.public_items
+    csr_ok = True
+    for u, its in ref_test.items():
+        if u not in pu:
+            continue
+        row = {int(c): float(v) for c, v in zip(cols[ip[pu[u]]:ip[pu[u] + 1]], vals[ip[pu[u]]:ip[pu[u] + 1]]) if c < data.num_items}
+        csr_ok &= row == {pi[i]: float(r) for i, r in its.items() if i in pi}
+    plane["split_csr"] = bool(csr_ok)
     files = sorted(os.listdir(config.path_output_rec_result))
     first = open(os.path.join(config.path_output_rec_result, files[0])).readline().rstrip("\n").split("\t")
     out = {
@@ -116,6 +137,7 @@ def main():
         "rec_files": files, "first_rec_row_fields": len(first), "first_rec_user": first[0],
         "weights_saved_to": os.path.basename(model._model.saved or ""), "weight_dir_exists": os.path.isdir(os.path.join(config.path_output_rec_weight, model.name)),
         "loss": float(model.get_loss()), "best_iteration": int(getattr(params, "best_iteration", -1)), "name": params.name,
+        "data_plane": plane,
         "signature": list(__import__("inspect").signature(RecMixin.get_single_recommendation).parameters),
     }
     print("RESULT " + json.dumps(out))

@@ -1,0 +1,122 @@
+"""SURVEY 8f N2 -- the array data plane: split flags and private item order from C (el_host_*), held-out CSR without dicts.
+Everything here runs without a GPU (the el_host_* entry points are plain CPU code inside libelliot_hip.so)."""
+import math
+
+import numpy as np
+import pytest
+
+from elliot_amd.dataset import dataset as D
+from elliot_amd.evaluation.evaluator import Evaluator
+
+
+def _py_split(users, mode, param, seed):
+    """The reference's loop (base_splitter.py:256-281) with the interpreter's own legacy shuffle."""
+    users = np.asarray(users)
+    rs = np.random.RandomState(seed)
+    flags = np.zeros(users.shape[0], dtype=np.int8)
+    order = np.argsort(users, kind="stable")
+    su = users[order]
+    bounds = np.flatnonzero(np.concatenate([[True], su[1:] != su[:-1], [True]]))
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        n = b - a
+        ntrain = int(math.floor(n * (1 - param))) if mode == 0 else n - int(param)
+        lst = [0] * ntrain + [1] * (n - ntrain)
+        rs.shuffle(lst)
+        flags[order[a:b]] = lst
+    return flags
+
+
+@pytest.mark.parametrize("n_users,n_rows,ratio,seed", [(1, 1, 0.2, 42), (7, 40, 0.2, 42), (300, 20000, 0.2, 42), (2500, 150000, 0.35, 7),
+                                                       (50, 3000, 0.0, 1), (50, 3000, 1.0, 1)])
+def test_split_flags_equal_the_legacy_numpy_stream(n_users, n_rows, ratio, seed):
+    rs = np.random.RandomState(n_rows)
+    users = rs.randint(0, n_users, size=n_rows) * 3 + 11
+    assert np.array_equal(D.random_subsampling(users, ratio, seed), _py_split(users, 0, ratio, seed))
+
+
+def test_leave_n_out_flags():
+    rs = np.random.RandomState(5)
+    users = rs.randint(0, 400, size=30000)
+    got = D.leave_n_out(users, 2, seed=42)
+    assert np.array_equal(got, _py_split(users, 1, 2, 42))
+    assert (np.bincount(users, weights=got) == 2).all()
+
+
+def test_split_flags_empty_and_single_rows():
+    assert D.random_subsampling(np.zeros(0, dtype=np.int64), 0.2).shape == (0,)
+    assert D.random_subsampling(np.array([5, 6, 7]), 0.2).tolist() == [1, 1, 1]      # floor(1 * 0.8) = 0 train rows (reference behaviour)
+
+
+@pytest.mark.parametrize("n,hi", [(0, 10), (1, 1), (9, 8), (100, 50), (1000, 5000), (6000, 1 << 20), (70000, 100000), (260000, 10 ** 7),
+                                  (50000, 1 << 45)])
+def test_private_item_order_is_the_cpython_set_order(n, hi):
+    rs = np.random.RandomState(n + 1)
+    keys = rs.randint(0, hi, size=n).astype(np.int64)
+    assert D.pyset_order(keys).tolist() == list({int(k) for k in keys.tolist()})
+
+
+def test_pyset_order_sequential_and_clustered_ids():
+    for keys in (np.arange(200000), np.arange(0, 3_000_000, 17), np.repeat(np.arange(5000), 3)[::-1].copy(),
+                 (np.arange(40000) * 1024) % 1_000_003):
+        assert D.pyset_order(keys).tolist() == list({int(k) for k in keys.tolist()})
+
+
+def test_pyset_order_other_key_types_use_the_interpreter():
+    assert D.pyset_order(np.array([-3, 5, -3, 7])).tolist() == list({k for k in [-3, 5, -3, 7]})
+    assert sorted(D.pyset_order(np.array(["b", "a", "b"])).tolist()) == ["a", "b"]
+
+
+def _triples(rs, n_users, n_items, n):
+    return rs.randint(0, n_users, size=n) * 2 + 1, rs.randint(0, n_items, size=n) * 5, rs.randint(1, 6, size=n).astype(np.float64)
+
+
+def test_dataset_private_ids_follow_the_reference_construction():
+    """users: first appearance in train (dataset.py:248); items: set order of the user-major item stream (:202)."""
+    rs = np.random.RandomState(3)
+    tu, ti, tr = _triples(rs, 300, 800, 20000)
+    ds = D.DataSet(D.default_config(), (tu, ti, tr), _triples(rs, 300, 800, 500))
+    users = list(dict.fromkeys(tu.tolist()))
+    train_dict = {u: {} for u in users}
+    for u, i, r in zip(tu.tolist(), ti.tolist(), tr.tolist()):
+        train_dict[u][i] = r
+    items = list({k for a in train_dict.values() for k in a.keys()})
+    assert ds.users == users and ds.items == items
+    assert ds.transactions == sum(len(a) for a in train_dict.values())
+
+
+def test_split_csr_equals_the_dict_route():
+    rs = np.random.RandomState(8)
+    tu, ti, tr = _triples(rs, 200, 300, 9000)
+    # held-out rows: known and unknown users / items, duplicated pairs (the last rating wins in a dict)
+    eu, ei, er = _triples(rs, 230, 340, 2500)
+    eu = np.concatenate([eu, eu[:40]])
+    ei = np.concatenate([ei, ei[:40]])
+    er = np.concatenate([er, er[:40] + 1.0])
+    ds = D.DataSet(D.default_config(), (tu, ti, tr), (eu, ei, er), (eu[::3], ei[::3], er[::3]))
+    for validation in (False, True):
+        indptr, cols, vals = ds.split_csr(validation)
+        split = ds.val_dict if validation else ds.test_dict
+
+        class _Ops:                                   # the dict route of the evaluator, captured instead of uploaded
+            @staticmethod
+            def DeviceTestSet(ip, c, v, device):
+                return ip, c, v
+        ip2, c2, v2 = Evaluator._split_to_csr(_Ops, ds, split, None)
+        assert np.array_equal(indptr, ip2)
+        for u in range(ds.num_users):
+            a, b = slice(indptr[u], indptr[u + 1]), slice(ip2[u], ip2[u + 1])
+            known = cols[a] < ds.num_items
+            assert np.array_equal(cols[a][known], c2[b][c2[b] < ds.num_items])
+            assert np.array_equal(vals[a][known], v2[b][c2[b] < ds.num_items])
+            assert sorted(vals[a][~known].tolist()) == sorted(v2[b][c2[b] >= ds.num_items].tolist())
+            assert len(set(cols[a].tolist())) == cols[a].shape[0]
+
+
+def test_evaluator_builds_no_dicts_until_asked():
+    rs = np.random.RandomState(2)
+    ds = D.DataSet(D.default_config(), _triples(rs, 50, 80, 2000), _triples(rs, 50, 80, 300))
+    ev = Evaluator(ds, None)
+    assert ev._dict_splits is None and "test" not in ds._cache
+    recs = {u: [(i, 1.0) for i in list(ds.items)[:10]] for u in ds.users}
+    out = ev.eval(({}, recs))
+    assert ev._dict_splits is not None and out[10]["test_results"]["nDCG"] >= 0.0

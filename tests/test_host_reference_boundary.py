@@ -29,6 +29,8 @@ def test_plugin_surface_inside_the_reference_host():
     assert r["weight_dir_exists"] and r["weights_saved_to"].startswith("best-weights-StubModel_")
     assert r["best_iteration"] == 1 and r["name"].startswith("StubModel_seed=42_e=1_bs=64")
     assert r["signature"] == ["self", "mask", "k", "predictions", "offset", "offset_stop"]
+    # our TSV -> split -> id maps -> CSR equals the reference's DataSetLoader / Splitter / DataSet on the same file
+    assert all(r["data_plane"].values()), r["data_plane"]
 
 
 def test_get_single_recommendation_has_the_reference_signature():
