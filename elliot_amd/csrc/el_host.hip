@@ -5,6 +5,10 @@
 //                          (np.random.seed(seed) once -- process_splitting :73 --, then per user, in groupby order, a list
 //                          [0]*train + [1]*test shuffled by the legacy np.random.shuffle: Fisher-Yates from the top,
 //                          j = masked-rejection draw from the MT19937 32-bit stream)
+//   el_host_negative_sample  per-user uniform negatives of the evaluation protocol exactly as NegativeSampler.
+//                          sample_by_random_uniform draws them (elliot/negative_sampling/negative_sampling.py:95-105):
+//                          random.sample(range(n_candidates), num) on the `random` module's MT19937 stream, candidates = the
+//                          items in neither train nor test, ascending
 //   el_host_pyset_order    iteration order of a CPython set after inserting the given non-negative ints in order: the
 //                          private item ids of the reference are the positions in `list({k for a in train_dict.values() for k
 //                          in a.keys()})` (elliot/dataset/dataset.py:202, :211-214)
@@ -177,5 +181,126 @@ extern "C" int el_host_pyset_order(const int64_t* keys, int64_t n, int64_t* out,
         if (tab[s] != 0) out[m++] = tab[s] - 1;
     *n_out = m;
     free(tab);
+    return 0;
+}
+
+// Python's random.Random on a caller-held state (random.getstate()[1]: 624 key words + position).  getrandbits(k), k <= 32 =
+// genrand_uint32() >> (32 - k); _randbelow_with_getrandbits(n): k = n.bit_length(), redraw while r >= n.
+namespace {
+struct PyRandom {
+    uint32_t* key;
+    uint32_t* posp;
+    uint32_t next() {
+        if (*posp >= 624) {
+            const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+            int i = 0;
+            for (; i < 624 - 397; ++i) {
+                const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+                key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+            }
+            for (; i < 623; ++i) {
+                const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+                key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+            }
+            const uint32_t y = (key[623] & UP) | (key[0] & LO);
+            key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+            *posp = 0;
+        }
+        uint32_t y = key[(*posp)++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t below(uint32_t n) {                 // n >= 1
+        int k = 32 - __builtin_clz(n);
+        uint32_t r;
+        do {
+            r = next() >> (32 - k);
+        } while (r >= n);
+        return r;
+    }
+};
+}  // namespace
+
+// excl = per user the sorted, duplicate-free private ids of the items in train or test.  out[u * num + s] = the s-th sampled
+// negative of user u (sample order).  setsize = random.sample's switch between its pool and its selection-set algorithm
+// (21, + 4 ** ceil(log(3 num, 4)) when num > 5: computed by the caller with Python's own math.log).
+extern "C" int el_host_negative_sample(const int64_t* excl_indptr, const int32_t* excl_indices, int64_t n_users, int64_t n_items,
+                                       int32_t num, int64_t setsize, uint32_t* py_state625, int32_t* out) {
+    EL_REQUIRE(excl_indptr != nullptr && py_state625 != nullptr && (out != nullptr || n_users * num == 0), "el_host_negative_sample: null argument");
+    EL_REQUIRE(n_items >= 1 && n_items < 0x7fffffffll && num >= 0, "el_host_negative_sample: bad sizes");
+    PyRandom rng{py_state625, py_state625 + 624};
+    int32_t* pool = nullptr;
+    int64_t pool_cap = 0;
+    for (int64_t u = 0; u < n_users; ++u) {
+        const int32_t* e = excl_indices + excl_indptr[u];
+        const int64_t m = excl_indptr[u + 1] - excl_indptr[u];
+        const int64_t n = n_items - m;                                 // candidates
+        if (num > n) {
+            free(pool);
+            EL_REQUIRE(false, "el_host_negative_sample: a user has fewer candidate negatives than num_items (random.sample raises ValueError)");
+        }
+        // j-th candidate (ascending) = j + #{s : e[s] - s <= j}
+        auto cand = [&](int64_t j) -> int32_t {
+            int64_t lo = 0, hi = m;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)e[mid] - mid <= j)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            return (int32_t)(j + lo);
+        };
+        int32_t* o = out + u * (int64_t)num;
+        if (n <= setsize) {
+            if (n > pool_cap) {
+                free(pool);
+                pool_cap = n > 4096 ? n : 4096;
+                pool = (int32_t*)malloc((size_t)pool_cap * sizeof(int32_t));
+                EL_REQUIRE(pool != nullptr, "el_host_negative_sample: out of memory");
+            }
+            for (int64_t j = 0, s = 0, c = 0; c < n_items && j < n; ++c) {   // candidates, ascending
+                if (s < m && e[s] == c) {
+                    ++s;
+                    continue;
+                }
+                pool[j++] = (int32_t)c;
+            }
+            for (int32_t i = 0; i < num; ++i) {
+                const uint32_t j = rng.below((uint32_t)(n - i));
+                o[i] = pool[j];
+                pool[j] = pool[n - i - 1];
+            }
+        } else {
+            // selection set: positions drawn so far (num is small -- 99 in the protocol -- a scan of the sorted-by-time list)
+            static thread_local int64_t* sel = nullptr;
+            static thread_local int32_t sel_cap = 0;
+            if (num > sel_cap) {
+                free(sel);
+                sel_cap = num;
+                sel = (int64_t*)malloc((size_t)sel_cap * sizeof(int64_t));
+                EL_REQUIRE(sel != nullptr, "el_host_negative_sample: out of memory");
+            }
+            for (int32_t i = 0; i < num; ++i) {
+                uint32_t j;
+                bool again;
+                do {
+                    j = rng.below((uint32_t)n);
+                    again = false;
+                    for (int32_t q = 0; q < i; ++q)
+                        if (sel[q] == (int64_t)j) {
+                            again = true;
+                            break;
+                        }
+                } while (again);
+                sel[i] = j;
+                o[i] = cand(j);
+            }
+        }
+    }
+    free(pool);
     return 0;
 }

@@ -2,7 +2,7 @@
 
 Honours the slice of Elliot's YAML schema (elliot/namespace/namespace_model.py:28-61) that the hello-world style
 experiments use: dataset, data_config {strategy: dataset|fixed, dataset_path | train_path/test_path},
-splitting.test_splitting {strategy: random_subsampling, test_ratio}, top_k, evaluation {cutoffs, simple_metrics,
+splitting.test_splitting {strategy: random_subsampling, test_ratio}, negative_sampling {strategy: random|fixed, num_items | files}, top_k, evaluation {cutoffs, simple_metrics,
 relevance_threshold}, gpu, path_output_rec_*, models {<Model>: {meta: {...}, <hyper-params>}}.
 The full driver (HPO, result handlers, statistical tests: elliot/run.py:39-148) stays Elliot's: plug the models in
 there through elliot_amd/external/__init__.py.
@@ -42,18 +42,29 @@ def build_config(exp, base_dir):
         path_output_rec_weight=_resolve(base_dir, exp.get("path_output_rec_weight", "../results/{0}/weights/"), ds),
         path_output_rec_performance=_resolve(base_dir, exp.get("path_output_rec_performance",
                                                                "../results/{0}/performance/"), ds))
-    if "negative_sampling" in exp:
-        # elliot/negative_sampling/negative_sampling.py builds the per-user candidate sets inside Elliot's DataSet
-        # (dataset.py:219-243); this stand-alone mini runner has no such component, and scoring without the candidate masks
-        # would silently rank the whole catalogue.  Inside Elliot (external.* models) the protocol is served from its masks.
-        raise NotImplementedError("negative_sampling: not available in the stand-alone runner -- run the models inside Elliot "
-                                  "(external_models_path) or hand the DataSet val_cand_csr / test_cand_csr")
+    if exp.get("negative_sampling"):
+        # namespace_model.py:190-198: paths resolved against the config folder; strategy "random" writes its draws to
+        # ../data/<dataset>/negative.tsv.  The candidate sets themselves are built in load_data (dataset/negative_sampling.py).
+        nsd = {k: (_resolve(base_dir, v, ds) if isinstance(v, str) and k in ("files", "file_path") else
+                   [_resolve(base_dir, x, ds) for x in v] if isinstance(v, list) else v) for k, v in exp["negative_sampling"].items()}
+        if nsd.get("strategy") == "random":
+            nsd["file_path"] = os.path.abspath(os.sep.join([base_dir, "..", "data", ds, "negative.tsv"]))
+            os.makedirs(os.path.dirname(nsd["file_path"]), exist_ok=True)
+        cfg.negative_sampling = _ns(nsd)
     for p in (cfg.path_output_rec_result, cfg.path_output_rec_weight, cfg.path_output_rec_performance):
         os.makedirs(p, exist_ok=True)
     return cfg
 
 
 def load_data(exp, cfg, base_dir):
+    data = _load_splits(exp, cfg, base_dir)
+    if hasattr(cfg, "negative_sampling"):                       # dataset.py:221-243
+        from .dataset import negative_sampling
+        negative_sampling.attach(data, cfg.negative_sampling)
+    return data
+
+
+def _load_splits(exp, cfg, base_dir):
     dc = exp["data_config"]
     seed = exp.get("random_seed", 42)
     if dc["strategy"] == "dataset":

@@ -637,7 +637,16 @@ int el_allgather_topk(el_ctx* ctx, el_comm* comm, void* stream, const int32_t* p
  *   el_host_pyset_order   replaces `list({k for a in train_dict.values() for k in a.keys()})` (elliot/dataset/dataset.py:202):
  *                         keys[n] = the train items in user-major file order (non-negative ints < 2^61 - 1); out[*n_out] <- the
  *                         distinct keys in the iteration order of the CPython set they were inserted into = the reference's
- *                         private item ids (dataset.py:211-214).  out needs room for n entries.                                 */
+ *                         private item ids (dataset.py:211-214).  out needs room for n entries.
+ *   el_host_negative_sample  replaces NegativeSampler.sample_by_random_uniform (elliot/negative_sampling/negative_sampling.py:
+ *                         95-105; strategy "random", num_items): per user random.sample(range(n_candidates), num) on Python's
+ *                         `random` MT19937 stream, candidates = the items in neither train nor test, ascending.  excl = CSR of the
+ *                         sorted private ids in train or test; py_state625 = random.getstate()[1] (624 key words + position),
+ *                         updated in place (hand it back with random.setstate); setsize = the pool / selection-set switch of
+ *                         random.sample (21, + 4 ** ceil(log(3 num, 4)) for num > 5); out[n_users * num] <- private ids in sample
+ *                         order.  Fails like random.sample (ValueError) when a user has fewer than num candidates.             */
+int el_host_negative_sample(const int64_t* excl_indptr, const int32_t* excl_indices, int64_t n_users, int64_t n_items, int32_t num,
+                            int64_t setsize, uint32_t* py_state625, int32_t* out);
 int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int8_t* flags);
 int el_host_pyset_order(const int64_t* keys, int64_t n, int64_t* out, int64_t* n_out);
 

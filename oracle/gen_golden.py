@@ -120,6 +120,7 @@ def main():
     gen_early_stopping()
     gen_bprmf_end_to_end(cs, mfm)
     gen_pointwise_and_neumf_samplers()
+    gen_negative_sampling()
 
 
 def gen_bprmf_end_to_end(cs, mfm):
@@ -187,6 +188,54 @@ def gen_pointwise_and_neumf_samplers():
         assert [len(p[0]) for p in ep[:-1]] == [700] * (len(ep) - 1)
         print(f"neumf_sampler_ref.npz: m={m}: epoch of", out[f"u_m{m}"].shape[0], "samples")
     np.savez_compressed(os.path.join(OUT, "neumf_sampler_ref.npz"), **out)
+
+
+def gen_negative_sampling():
+    """negative_sampling/negative_sampling.py:39-105 -- strategy "random", num_items 99 and 5 (random.sample's selection-set and
+    pool algorithms), `random` seeded with 42 as at the module's import; the validation-then-test order of
+    NegativeSampler.sample (:28-33; its own return statement, :36, cannot evaluate a sparse matrix as a bool, so the two
+    process_sampling calls are made directly).  Private ids = positions in the given id lists."""
+    sys.path.insert(0, REF)
+    import random
+    import warnings
+    import scipy.sparse as sp
+    from elliot.negative_sampling.negative_sampling import NegativeSampler
+    rs = np.random.RandomState(4)
+    out = {}
+    # A: 400 items -- random.sample's POOL algorithm for 99 and 300 draws (n <= setsize = 1045), its SELECTION SET for 5 (n > 21)
+    # B: 1500 items -- the selection set with re-draws for 99 (n ~ 1450 > 1045)
+    for tag, U, I, nums in (("A", 60, 400, (99, 5, 300)), ("B", 25, 1500, (99,))):
+        rows = rs.randint(0, U, 50 * U)
+        cols = rs.randint(0, I, 50 * U)
+        train = sp.csr_matrix((np.ones(50 * U, dtype=np.float32), (rows, cols)), shape=(U, I))
+        train.sum_duplicates()
+        train.data[:] = 1.0
+        test = {}
+        for u, i in zip(rs.randint(0, U + 3, 8 * U).tolist(), rs.randint(0, I + 20, 8 * U).tolist()):
+            test.setdefault(u, {})[i] = 1.0
+        pub_u = {u: u for u in range(U)}
+        pub_i = {i: i for i in range(I)}
+        out[f"{tag}_shape"] = np.array([U, I])
+        out[f"{tag}_train_indptr"], out[f"{tag}_train_indices"] = train.indptr.astype(np.int64), train.indices.astype(np.int32)
+        tu, ti = zip(*[(u, i) for u, its in test.items() for i in its])
+        out[f"{tag}_test_users"], out[f"{tag}_test_items"] = np.array(tu), np.array(ti)
+        for num in nums:
+            path = os.path.join(OUT, "_neg_tmp.tsv")
+            ns = SimpleNamespace(negative_sampling=SimpleNamespace(strategy="random", num_items=num, file_path=path))
+            random.seed(42)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                first = NegativeSampler.process_sampling(ns, pub_u, pub_i, pub_u, pub_i, train, test, validation=True)
+                second = NegativeSampler.process_sampling(ns, pub_u, pub_i, pub_u, pub_i, train, test)
+            for name, m in (("first", first), ("second", second)):
+                m = m.tocsr()
+                m.sort_indices()
+                assert (np.diff(m.indptr) == num).all()
+                out[f"{tag}_n{num}_{name}_indices"] = m.indices.astype(np.int32)
+            out[f"{tag}_n{num}_file"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+            os.remove(path)
+            print(f"negative_sampling_ref.npz: {tag}: num_items={num}: 2 x {U} users")
+    np.savez_compressed(os.path.join(OUT, "negative_sampling_ref.npz"), **out)
 
 
 def gen_splitter():

@@ -158,6 +158,56 @@ def test_mini_runner_yaml(ctx, tmp_path):
     assert os.listdir(tmp_path / "out" / "perf")
 
 
+def test_mini_runner_with_sampled_negatives(ctx, tmp_path):
+    """`negative_sampling: {strategy: random, num_items: 40}` (dataset.py:221-243, recommender_utils_mixin.py:102-109): every
+    recommended item is one of the user's candidates (its negatives of ../data/<dataset>/negative.tsv + its own test items);
+    the dict route and the device-metric route give the same nDCG."""
+    import yaml
+    from elliot_amd import run as runner
+    indptr, indices, _ = small_dataset(180, 260, seed=5)
+    rs = np.random.RandomState(1)
+    users = np.repeat(np.arange(180), np.diff(indptr))
+    os.makedirs(tmp_path / "cfg")
+    with open(tmp_path / "cfg" / "dataset.tsv", "w") as f:
+        for u, i in zip(users, indices):
+            f.write(f"{u + 1}\t{i + 1}\t{rs.randint(1, 6)}\t{rs.randint(0, 10 ** 6)}\n")
+    exp = {"dataset": "toy", "data_config": {"strategy": "dataset", "dataset_path": "dataset.tsv"},
+           "splitting": {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2}},
+           "negative_sampling": {"strategy": "random", "num_items": 40},
+           "top_k": 10, "evaluation": {"simple_metrics": ["nDCG", "HR"]},
+           "path_output_rec_result": "out/recs/", "path_output_rec_weight": "out/weights/", "path_output_rec_performance": "out/perf/",
+           "models": {"BPRMF_batch": {"meta": {"save_recs": False}, "epochs": 2, "batch_size": 512, "factors": 16, "lr": 0.01}}}
+    with open(tmp_path / "cfg" / "exp.yml", "w") as f:
+        yaml.safe_dump({"experiment": exp}, f)
+    res = runner.run_experiment(str(tmp_path / "cfg" / "exp.yml"))
+    (name, r), = res.items()
+    neg_file = tmp_path / "data" / "toy" / "negative.tsv"
+    assert neg_file.exists()
+    # rebuild the model's data to look at the lists
+    cfg = runner.build_config(exp, str(tmp_path / "cfg"))
+    data = runner.load_data(exp, cfg, str(tmp_path / "cfg"))
+    negs = {}
+    for line in neg_file.read_text().splitlines():
+        parts = line.split("\t")
+        negs[int(parts[0].strip("(),"))] = {int(x) for x in parts[1:]}
+    assert len(negs) == data.num_users and all(len(v) == 40 for v in negs.values())
+    from elliot_amd.recommender import BPRMF_batch
+    params = SimpleNamespace(meta=SimpleNamespace(verbose=False, save_recs=False), epochs=1, batch_size=512, factors=16, lr=0.01, seed=42)
+    model = BPRMF_batch(data=data, config=cfg, params=params)
+    model.train()
+    _, recs = model.get_recommendations(10)
+    test = data.test_dict
+    train = data.train_dict
+    for u, lst in recs.items():
+        allowed = negs[u] | {i for i in test.get(u, {}) if i in data.public_items}
+        got = {i for i, _ in lst}
+        assert got <= allowed and not (got & set(train[u])), u
+        assert len(lst) == min(10, len(allowed))
+    dict_route = model.evaluator.eval(model.get_recommendations(10))
+    assert abs(dict_route[10]["test_results"]["nDCG"] - model.get_results()[10]["test_results"]["nDCG"]) < 1e-9
+    assert 0.0 < r[10]["test_results"]["HR"] <= 1.0
+
+
 def test_multivae_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
     import random
     from elliot_amd.recommender import MultiVAE

@@ -120,3 +120,82 @@ def test_evaluator_builds_no_dicts_until_asked():
     recs = {u: [(i, 1.0) for i in list(ds.items)[:10]] for u in ds.users}
     out = ev.eval(({}, recs))
     assert ev._dict_splits is not None and out[10]["test_results"]["nDCG"] >= 0.0
+
+
+# ---- evaluation with sampled negatives (negative_sampling/negative_sampling.py) ---------------------------------------
+import os                                     # noqa: E402
+import random                                 # noqa: E402
+
+import scipy.sparse as sp                     # noqa: E402
+
+from elliot_amd.dataset import negative_sampling as NS     # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "negative_sampling_ref.npz")
+
+
+@pytest.mark.parametrize("tag,num", [("A", 99), ("A", 5), ("A", 300), ("B", 99)])
+def test_negative_sampling_equals_the_reference_sampler(tag, num, tmp_path):
+    """Fixture = the reference's own NegativeSampler.process_sampling run twice in a row (validation, then test: the order of
+    NegativeSampler.sample) from random.seed(42), oracle/gen_golden.py::gen_negative_sampling; pool and selection-set branches
+    of random.sample."""
+    g = np.load(GOLD)
+    U, I = g[f"{tag}_shape"].tolist()
+    train = sp.csr_matrix((np.ones(g[f"{tag}_train_indices"].shape[0], dtype=np.int8), g[f"{tag}_train_indices"], g[f"{tag}_train_indptr"]),
+                          shape=(U, I))
+    tu, ti = g[f"{tag}_test_users"], g[f"{tag}_test_items"]
+    known = (tu < U) & (ti < I)
+    test = sp.csr_matrix((np.ones(int(known.sum()), dtype=np.int8), (tu[known], ti[known])), shape=(U, I))
+    excl = (train + test).astype(bool)
+    rng = random.Random(42)
+    for name in ("first", "second"):                       # one stream across both calls
+        neg = NS.sample_by_random_uniform(excl, num, rng)
+        assert neg.shape == (U, num)
+        assert np.array_equal(np.sort(neg, axis=1).reshape(-1), g[f"{tag}_n{num}_{name}_indices"])
+        assert not excl[np.repeat(np.arange(U), num), neg.reshape(-1)].any()
+    # the negatives file as the reference leaves it (written by the second call), byte for byte
+    from types import SimpleNamespace
+    NS._write_negatives(str(tmp_path / "n.tsv"), SimpleNamespace(private_users={u: u for u in range(U)}, items=list(range(I))), neg)
+    assert (tmp_path / "n.tsv").read_bytes() == g[f"{tag}_n{num}_file"].tobytes()
+    # the Python module's state moved exactly as far as the reference's two calls moved it
+    ref = random.Random(42)
+    for _ in range(2):
+        for u in range(U):
+            ref.sample(range(I - excl[u].nnz), num)
+    assert rng.getstate() == ref.getstate()
+
+
+def test_negative_sampling_attach_builds_candidate_csrs_and_the_file(tmp_path):
+    g = np.load(GOLD)
+    U, I = g["A_shape"].tolist()
+    ip, ix = g["A_train_indptr"], g["A_train_indices"]
+    tr_u = np.repeat(np.arange(U), np.diff(ip))
+    # public ids == private ids: fix both orders
+    ds = D.DataSet(D.default_config(), (tr_u, ix.astype(np.int64), np.ones(ix.shape[0])),
+                   (g["A_test_users"], g["A_test_items"], np.ones(g["A_test_users"].shape[0])),
+                   public_users=np.arange(U), public_items=np.arange(I))
+    path = tmp_path / "neg.tsv"
+    NS.attach(ds, {"strategy": "random", "num_items": 99, "file_path": str(path)})
+    # no validation split: ONE sampling call, = the fixture's first call; candidates = negatives + the known test items
+    cip, cix = ds.test_cand_csr
+    tip, tcols, _ = ds.split_csr(False)
+    neg = g["A_n99_first_indices"].reshape(U, 99)
+    for u in range(U):
+        own = tcols[tip[u]:tip[u + 1]]
+        assert sorted(set(neg[u].tolist()) | set(own[own < I].tolist())) == cix[cip[u]:cip[u + 1]].tolist()
+    assert not hasattr(ds, "val_cand_csr")
+    lines = path.read_text().splitlines()
+    assert len(lines) == U and lines[3].split("\t")[0] == "(3,)" and [int(x) for x in lines[3].split("\t")[1:]] == neg[3].tolist()
+    # strategy "fixed" reads the same file back
+    ds2 = D.DataSet(D.default_config(), (tr_u, ix.astype(np.int64), np.ones(ix.shape[0])),
+                    (g["A_test_users"], g["A_test_items"], np.ones(g["A_test_users"].shape[0])),
+                    public_users=np.arange(U), public_items=np.arange(I))
+    NS.attach(ds2, {"strategy": "fixed", "files": [str(path)]})
+    assert np.array_equal(ds2.test_cand_csr[0], cip) and np.array_equal(ds2.test_cand_csr[1], cix)
+
+
+def test_negative_sampling_more_negatives_than_candidates_raises_like_random_sample():
+    excl = sp.csr_matrix(np.ones((2, 10), dtype=bool))
+    excl[1, 3] = False
+    excl.eliminate_zeros()
+    with pytest.raises(ValueError):
+        NS.sample_by_random_uniform(excl, 2, random.Random(42))
