@@ -107,7 +107,7 @@ PROTOTYPES = {
     "el_reduce_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64]),
     "el_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "el_allgather_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int32, _i32p, _f32p]),
-    "el_host_split_flags": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_uint32, C.c_void_p]),
+    "el_host_split_flags": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_uint32, C.c_int32, C.c_void_p]),
     "el_host_negative_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "el_host_pyset_order": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "el_timing_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

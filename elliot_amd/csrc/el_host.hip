@@ -73,11 +73,13 @@ struct Mt {
 
 }  // namespace
 
-extern "C" int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int8_t* flags) {
+extern "C" int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int32_t n_folds, int8_t* flags) {
     EL_REQUIRE(seg_len != nullptr && flags != nullptr && n_seg >= 0, "el_host_split_flags: null argument");
     EL_REQUIRE(mode == 0 || mode == 1, "el_host_split_flags: mode 0 = random_subsampling(test_ratio), 1 = leave_n_out(n)");
+    EL_REQUIRE(n_folds >= 1, "el_host_split_flags: n_folds >= 1");
     Mt mt(seed);
     int64_t off = 0;
+    for (int32_t fold = 0; fold < n_folds; ++fold)          // base_splitter.py:266-267: folds outside, users inside, one stream
     for (int64_t s = 0; s < n_seg; ++s) {
         const int64_t n = seg_len[s];
         EL_REQUIRE(n >= 0 && n <= 0xffffffffll, "el_host_split_flags: a segment longer than 2^32 - 1 rows");

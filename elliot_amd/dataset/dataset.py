@@ -197,7 +197,7 @@ class DataSet:
 
 
 # ---------------------------------------------------------------------------------------------------
-def _split_flags(users, mode, param, seed):
+def _split_flags(users, mode, param, seed, folds=1):
     from .. import _lib
     users = np.asarray(users)
     lo = int(users.min()) if users.shape[0] and users.dtype.kind in "iu" else 0
@@ -212,25 +212,27 @@ def _split_flags(users, mode, param, seed):
         su = users[order]
         bounds = np.flatnonzero(np.concatenate([[True], su[1:] != su[:-1], [True]])) if su.shape[0] else np.zeros(1, dtype=np.int64)
         seg = np.ascontiguousarray(np.diff(bounds), dtype=np.int64)
-    sorted_flags = np.empty(users.shape[0], dtype=np.int8)
-    _lib.check(_lib.load().el_host_split_flags(seg.ctypes.data, seg.shape[0], mode, float(param), int(seed) & 0xffffffff,
+    sorted_flags = np.empty((folds, users.shape[0]), dtype=np.int8)
+    _lib.check(_lib.load().el_host_split_flags(seg.ctypes.data, seg.shape[0], mode, float(param), int(seed) & 0xffffffff, int(folds),
                                                sorted_flags.ctypes.data), "el_host_split_flags")
-    flags = np.empty(users.shape[0], dtype=np.int8)
-    flags[order] = sorted_flags
+    flags = np.empty((folds, users.shape[0]), dtype=np.int8)
+    flags[:, order] = sorted_flags
     return flags
 
 
-def random_subsampling(users, ratio, seed=42):
+def random_subsampling(users, ratio, seed=42, folds=1):
     """Per-user train/test flags as splitter/base_splitter.py:256-274 draws them: np.random.seed(seed) once
     (process_splitting :73), then for every user in groupby (= sorted id) order a list of floor(n(1-r)) zeros and
     the rest ones is shuffled with the legacy np.random.shuffle and laid over the user's rows in file order.  The shuffles
-    (a sequential MT19937 stream) run in C: `el_host_split_flags`."""
-    return _split_flags(users, 0, ratio, seed)
+    (a sequential MT19937 stream) run in C: `el_host_split_flags`.  folds > 1: [folds, rows] flags, fold after fold on one stream."""
+    f = _split_flags(users, 0, ratio, seed, folds)
+    return f[0] if folds == 1 else f
 
 
-def leave_n_out(users, n=1, seed=42):
-    """base_splitter.py:276-290 (random leave-n-out, one fold): n held-out rows per user, same stream discipline."""
-    return _split_flags(users, 1, n, seed)
+def leave_n_out(users, n=1, seed=42, folds=1):
+    """base_splitter.py:276-294 (random leave-n-out): n held-out rows per user, same stream discipline."""
+    f = _split_flags(users, 1, n, seed, folds)
+    return f[0] if folds == 1 else f
 
 
 def pyset_order(keys):

@@ -1,8 +1,8 @@
 """Minimal experiment runner for the latent-factor plugins (single configuration, no hyperopt).
 
 Honours the slice of Elliot's YAML schema (elliot/namespace/namespace_model.py:28-61) that the hello-world style
-experiments use: dataset, data_config {strategy: dataset|fixed, dataset_path | train_path/test_path},
-splitting.test_splitting {strategy: random_subsampling, test_ratio}, negative_sampling {strategy: random|fixed, num_items | files}, top_k, evaluation {cutoffs, simple_metrics,
+experiments use: dataset, data_config {strategy: dataset|fixed, dataset_path | train_path/test_path/validation_path}, prefiltering, binarize,
+splitting {test_splitting, validation_splitting: every strategy of base_splitter.py}, negative_sampling {strategy: random|fixed}, top_k, evaluation {cutoffs, simple_metrics,
 relevance_threshold}, gpu, path_output_rec_*, models {<Model>: {meta: {...}, <hyper-params>}}.
 The full driver (HPO, result handlers, statistical tests: elliot/run.py:39-148) stays Elliot's: plug the models in
 there through elliot_amd/external/__init__.py.
@@ -15,7 +15,6 @@ from types import SimpleNamespace
 import numpy as np
 import yaml
 
-from .dataset.dataset import DataSet, load_tsv_dataset
 from . import recommender as rec
 
 
@@ -56,31 +55,35 @@ def build_config(exp, base_dir):
     return cfg
 
 
-def load_data(exp, cfg, base_dir):
-    data = _load_splits(exp, cfg, base_dir)
+def _to_ns(x):
+    if isinstance(x, dict):
+        return SimpleNamespace(**{k: _to_ns(v) for k, v in x.items()})
+    return x
+
+
+def load_data_objects(exp, cfg, base_dir):
+    """DataSetLoader(config).generate_dataobjects() (elliot/run.py:59-60): one list per test fold, one DataSet per validation fold;
+    prefiltering, binarize and every splitting strategy of the reference (dataset/dataloader.py)."""
+    from .dataset import dataloader, negative_sampling
+    dc = dict(exp["data_config"])
+    cfg.data_config = SimpleNamespace(**dc)
+    cfg.random_seed = exp.get("random_seed", 42)
+    cfg.binarize = bool(exp.get("binarize", False))
+    if exp.get("prefiltering"):
+        pf = exp["prefiltering"]
+        cfg.prefiltering = [_to_ns(x) for x in (pf if isinstance(pf, list) else [pf])]      # namespace_model.py:177-182
+    cfg.splitting = _to_ns(exp.get("splitting", {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2}}))
+    objs = dataloader.DataSetLoader(cfg, resolve=lambda p: _resolve(base_dir, p, cfg.dataset)).generate_dataobjects()
     if hasattr(cfg, "negative_sampling"):                       # dataset.py:221-243
-        from .dataset import negative_sampling
-        negative_sampling.attach(data, cfg.negative_sampling)
-    return data
+        for fold in objs:
+            for data in fold:
+                negative_sampling.attach(data, cfg.negative_sampling)
+    return objs
 
 
-def _load_splits(exp, cfg, base_dir):
-    dc = exp["data_config"]
-    seed = exp.get("random_seed", 42)
-    if dc["strategy"] == "dataset":
-        sp = exp.get("splitting", {}).get("test_splitting", {"strategy": "random_subsampling", "test_ratio": 0.2})
-        if sp.get("strategy") != "random_subsampling":
-            raise Exception(f"splitting strategy {sp.get('strategy')} is not available in the mini runner")
-        return load_tsv_dataset(cfg, _resolve(base_dir, dc["dataset_path"], cfg.dataset), sp.get("test_ratio", 0.2), seed)
-    if dc["strategy"] == "fixed":
-        import pandas as pd
-
-        def rd(key):
-            df = pd.read_csv(_resolve(base_dir, dc[key], cfg.dataset), sep="\t", header=None)
-            return df[0].values, df[1].values, df[2].values
-        val = rd("validation_path") if "validation_path" in dc else None
-        return DataSet(cfg, rd("train_path"), rd("test_path"), val)
-    raise Exception(f"data_config strategy {dc['strategy']} is not available in the mini runner")
+def load_data(exp, cfg, base_dir):
+    """The first (test fold, validation fold) data set -- what a configuration without folds produces."""
+    return load_data_objects(exp, cfg, base_dir)[0][0]
 
 
 def model_params(model_cfg):
@@ -100,24 +103,24 @@ def run_experiment(config_path=""):
         exp = yaml.safe_load(f)["experiment"]
     base_dir = os.path.dirname(os.path.abspath(config_path))
     cfg = build_config(exp, base_dir)
-    data = load_data(exp, cfg, base_dir)
+    folds = load_data_objects(exp, cfg, base_dir)
     results = {}
     for key, model_cfg in exp["models"].items():
-        cls_name = key.split(".")[-1]
-        cls = getattr(rec, cls_name, None)
+        cls = getattr(rec, key.split(".")[-1], None)
         if cls is None:
             raise Exception(f"Model {key} is not provided by elliot_amd (available: {rec.__all__})")
-        params = model_params(model_cfg or {})
-        model = cls(data=data, config=cfg, params=params)
-        model.train()
-        best = model.get_results()
-        results[model.name] = best
-        perf = os.path.join(cfg.path_output_rec_performance, f"rec_{model.name}.tsv")
-        with open(perf, "w") as out:
-            for cutoff, d in best.items():
-                for metric, value in d["test_results"].items():
-                    out.write(f"{model.name}\t{cutoff}\t{metric}\t{value}\n")
-        print(f"{model.name}: " + ", ".join(f"{m}@{c}={v:.5f}" for c, d in best.items() for m, v in d["test_results"].items()))
+        for t_fold, val_folds in enumerate(folds):               # elliot/run.py:59-75: every model on every data object
+            for v_fold, data in enumerate(val_folds):
+                model = cls(data=data, config=cfg, params=model_params(model_cfg or {}))
+                model.train()
+                best = model.get_results()
+                tag = model.name if (t_fold, v_fold) == (0, 0) else f"{model.name}#test{t_fold}val{v_fold}"
+                results[tag] = best
+                with open(os.path.join(cfg.path_output_rec_performance, f"rec_{tag}.tsv"), "w") as out:
+                    for cutoff, d in best.items():
+                        for metric, value in d["test_results"].items():
+                            out.write(f"{model.name}\t{cutoff}\t{metric}\t{value}\n")
+                print(f"{tag}: " + ", ".join(f"{m}@{c}={v:.5f}" for c, d in best.items() for m, v in d["test_results"].items()))
     return results
 
 

@@ -629,9 +629,9 @@ int el_allgather_topk(el_ctx* ctx, el_comm* comm, void* stream, const int32_t* p
  * Plain CPU functions (no context, no stream, no GPU needed): the two sequential integer loops of the reference's loader that
  * NumPy cannot vectorise, bit-identical to the reference's own output.
  *   el_host_split_flags   replaces Splitter.splitting_randomsubsampling_kfolds / subsampling_list_generator
- *                         (elliot/splitter/base_splitter.py:256-274) and the leave-n-out generator (:276-281) for ONE fold:
- *                         seg_len[n_seg] = rows per user in groupby (= ascending user id) order; flags[sum seg_len] <- 0 train /
- *                         1 test, laid over each user's rows in file order.  mode 0: param = test_ratio, train = floor(n (1 - r));
+ *                         (elliot/splitter/base_splitter.py:256-274) and the leave-n-out variant (:276-294):
+ *                         seg_len[n_seg] = rows per user in groupby (= ascending user id) order; flags[n_folds][sum seg_len] <- 0
+ *                         train / 1 test, laid over each user's rows in file order (fold after fold on one stream).  mode 0: param = test_ratio, train = floor(n (1 - r));
  *                         mode 1: param = n held out.  seed = Splitter.random_seed (np.random.seed(seed), legacy MT19937 stream:
  *                         one shuffle per user, Fisher-Yates from the top with masked-rejection draws).
  *   el_host_pyset_order   replaces `list({k for a in train_dict.values() for k in a.keys()})` (elliot/dataset/dataset.py:202):
@@ -647,7 +647,7 @@ int el_allgather_topk(el_ctx* ctx, el_comm* comm, void* stream, const int32_t* p
  *                         order.  Fails like random.sample (ValueError) when a user has fewer than num candidates.             */
 int el_host_negative_sample(const int64_t* excl_indptr, const int32_t* excl_indices, int64_t n_users, int64_t n_items, int32_t num,
                             int64_t setsize, uint32_t* py_state625, int32_t* out);
-int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int8_t* flags);
+int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int32_t n_folds, int8_t* flags);
 int el_host_pyset_order(const int64_t* keys, int64_t n, int64_t* out, int64_t* n_out);
 
 #ifdef __cplusplus

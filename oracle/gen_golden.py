@@ -121,6 +121,7 @@ def main():
     gen_bprmf_end_to_end(cs, mfm)
     gen_pointwise_and_neumf_samplers()
     gen_negative_sampling()
+    gen_loader()
 
 
 def gen_bprmf_end_to_end(cs, mfm):
@@ -188,6 +189,55 @@ def gen_pointwise_and_neumf_samplers():
         assert [len(p[0]) for p in ep[:-1]] == [700] * (len(ep) - 1)
         print(f"neumf_sampler_ref.npz: m={m}: epoch of", out[f"u_m{m}"].shape[0], "samples")
     np.savez_compressed(os.path.join(OUT, "neumf_sampler_ref.npz"), **out)
+
+
+def gen_loader():
+    """prefiltering/standard_prefilters.py + splitter/base_splitter.py on one small frame (timestamps with ties): the rows each
+    prefilter keeps, and the train / validation / test membership of every splitting strategy (seed 42)."""
+    sys.path.insert(0, REF)
+    import io
+    import contextlib
+    import pandas as pd
+    from elliot.splitter.base_splitter import Splitter
+    from elliot.prefiltering.standard_prefilters import PreFilter
+    rs = np.random.RandomState(11)
+    n = 2500
+    df = pd.DataFrame({"userId": rs.randint(100, 170, n) * 3, "itemId": rs.randint(0, 300, n), "rating": rs.randint(1, 6, n),
+                       "timestamp": rs.randint(0, 400, n)})
+    df = df.drop_duplicates(["userId", "itemId"]).reset_index(drop=True)
+    df["row"] = np.arange(len(df))
+    out = {c: df[c].values for c in ("userId", "itemId", "rating", "timestamp")}
+    # pandas >= 2 rejects the `axis=1` the reference passes to SeriesGroupBy.rank (:228, :240; the pandas 1.x it was written
+    # for ignored the argument for a Series): drop it for the duration of this generator
+    from pandas.core.groupby.generic import SeriesGroupBy
+    orig_rank = SeriesGroupBy.rank
+    SeriesGroupBy.rank = lambda self, *a, axis=None, **k: orig_rank(self, *a, **k)
+    sink = io.StringIO()
+    filters = {"global_threshold_3": dict(strategy="global_threshold", threshold=3), "global_average": dict(strategy="global_threshold", threshold="average"),
+               "user_average": dict(strategy="user_average"), "user_k_core": dict(strategy="user_k_core", core=30),
+               "item_k_core": dict(strategy="item_k_core", core=8), "iterative_k_core": dict(strategy="iterative_k_core", core=9),
+               "n_rounds_k_core": dict(strategy="n_rounds_k_core", core=9, rounds=2), "cold_users": dict(strategy="cold_users", threshold=33)}
+    with contextlib.redirect_stdout(sink):
+        for name, f in filters.items():
+            kept = PreFilter.single_filter(df.copy(), SimpleNamespace(**f))
+            out["filter_" + name] = kept["row"].values.astype(np.int64)
+        splits = {"temporal_ratio": dict(strategy="temporal_hold_out", test_ratio=0.25), "temporal_lno": dict(strategy="temporal_hold_out", leave_n_out=3),
+                  "fixed_ts": dict(strategy="fixed_timestamp", timestamp="300"), "best_ts": dict(strategy="fixed_timestamp", timestamp="best", min_below=5, min_over=2),
+                  "random_ratio_3folds": dict(strategy="random_subsampling", test_ratio=0.2, folds=3),
+                  "random_lno_2folds": dict(strategy="random_subsampling", leave_n_out=2, folds=2), "cross_validation_4": dict(strategy="random_cross_validation", folds=4)}
+        for name, sp_ in splits.items():
+            tl = Splitter(df.copy(), SimpleNamespace(test_splitting=SimpleNamespace(**sp_)), 42).process_splitting()
+            out["split_" + name] = np.stack([np.isin(df["row"].values, te["row"].values).astype(np.int8) for _, te in tl])
+            assert all(len(tr) + len(te) == len(df) for tr, te in tl)
+        # hierarchy: test by random subsampling, validation by temporal leave-2-out on each train part
+        ns = SimpleNamespace(test_splitting=SimpleNamespace(strategy="random_subsampling", test_ratio=0.2),
+                             validation_splitting=SimpleNamespace(strategy="temporal_hold_out", leave_n_out=2))
+        (train_val, test), = Splitter(df.copy(), ns, 42).process_splitting()
+        (train, val), = train_val
+        out["hier_test"], out["hier_val"], out["hier_train"] = (x["row"].values.astype(np.int64) for x in (test, val, train))
+    SeriesGroupBy.rank = orig_rank
+    np.savez_compressed(os.path.join(OUT, "loader_ref.npz"), **out)
+    print("loader_ref.npz:", len(df), "rows,", len(filters), "prefilters,", len(splits) + 1, "splitting configurations")
 
 
 def gen_negative_sampling():

@@ -158,6 +158,34 @@ def test_mini_runner_yaml(ctx, tmp_path):
     assert os.listdir(tmp_path / "out" / "perf")
 
 
+def test_mini_runner_folds_prefilter_and_validation_split(ctx, tmp_path):
+    """prefiltering + 2-fold cross validation + a temporal leave-one-out validation split: one run per data object
+    (elliot/run.py:59-75), the validation metric comes from the validation split (val_results != test_results)."""
+    import yaml
+    from elliot_amd.run import run_experiment
+    indptr, indices, _ = small_dataset(150, 120, seed=3)
+    rs = np.random.RandomState(2)
+    users = np.repeat(np.arange(150), np.diff(indptr))
+    with open(tmp_path / "dataset.tsv", "w") as f:
+        for u, i in zip(users, indices):
+            f.write(f"{u + 1}\t{i + 1}\t{rs.randint(1, 6)}\t{rs.randint(0, 10 ** 6)}\n")
+    cfg = {"experiment": {
+        "dataset": "toy", "data_config": {"strategy": "dataset", "dataset_path": "dataset.tsv"},
+        "prefiltering": {"strategy": "user_k_core", "core": 6}, "binarize": True,
+        "splitting": {"test_splitting": {"strategy": "random_cross_validation", "folds": 2},
+                      "validation_splitting": {"strategy": "temporal_hold_out", "leave_n_out": 1}},
+        "top_k": 10, "evaluation": {"simple_metrics": ["nDCG", "Recall"]},
+        "path_output_rec_result": "out/recs/", "path_output_rec_weight": "out/weights/", "path_output_rec_performance": "out/perf/",
+        "models": {"BPRMF_batch": {"meta": {}, "epochs": 2, "batch_size": 256, "factors": 16, "lr": 0.01}}}}
+    with open(tmp_path / "exp.yml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    res = run_experiment(str(tmp_path / "exp.yml"))
+    assert len(res) == 2 and sum("#test1val0" in k for k in res) == 1
+    for r in res.values():
+        assert 0.0 <= r[10]["test_results"]["Recall"] <= 1.0 and r[10]["val_results"] != r[10]["test_results"]
+    assert len(os.listdir(tmp_path / "out" / "perf")) == 2
+
+
 def test_mini_runner_with_sampled_negatives(ctx, tmp_path):
     """`negative_sampling: {strategy: random, num_items: 40}` (dataset.py:221-243, recommender_utils_mixin.py:102-109): every
     recommended item is one of the user's candidates (its negatives of ../data/<dataset>/negative.tsv + its own test items);

@@ -1,0 +1,84 @@
+"""elliot_amd/dataset/dataloader.py against the reference's own PreFilter and Splitter (fixture tests/golden/loader_ref.npz,
+oracle/gen_golden.py::gen_loader): which rows every prefilter keeps, which rows every splitting strategy holds out."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from elliot_amd.dataset import dataloader as L
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loader_ref.npz"))
+
+
+def frame():
+    fr = {c: GOLD[c] for c in ("userId", "itemId", "rating", "timestamp")}
+    fr["row"] = np.arange(fr["userId"].shape[0])
+    return fr
+
+
+FILTERS = {"global_threshold_3": dict(strategy="global_threshold", threshold=3), "global_average": dict(strategy="global_threshold", threshold="average"),
+           "user_average": dict(strategy="user_average"), "user_k_core": dict(strategy="user_k_core", core=30),
+           "item_k_core": dict(strategy="item_k_core", core=8), "iterative_k_core": dict(strategy="iterative_k_core", core=9),
+           "n_rounds_k_core": dict(strategy="n_rounds_k_core", core=9, rounds=2), "cold_users": dict(strategy="cold_users", threshold=33)}
+
+SPLITS = {"temporal_ratio": dict(strategy="temporal_hold_out", test_ratio=0.25), "temporal_lno": dict(strategy="temporal_hold_out", leave_n_out=3),
+          "fixed_ts": dict(strategy="fixed_timestamp", timestamp="300"), "best_ts": dict(strategy="fixed_timestamp", timestamp="best", min_below=5, min_over=2),
+          "random_ratio_3folds": dict(strategy="random_subsampling", test_ratio=0.2, folds=3),
+          "random_lno_2folds": dict(strategy="random_subsampling", leave_n_out=2, folds=2), "cross_validation_4": dict(strategy="random_cross_validation", folds=4)}
+
+
+@pytest.mark.parametrize("name", sorted(FILTERS))
+def test_prefilter_keeps_the_reference_rows(name):
+    kept = L.prefilter(frame(), [SimpleNamespace(**FILTERS[name])])
+    assert np.array_equal(kept["row"], GOLD["filter_" + name]) and 0 < kept["row"].shape[0] < GOLD["userId"].shape[0]
+
+
+@pytest.mark.parametrize("name", sorted(SPLITS))
+def test_splitting_strategy_holds_out_the_reference_rows(name):
+    folds = L.split(frame(), SimpleNamespace(test_splitting=SimpleNamespace(**SPLITS[name])), 42)
+    ref = GOLD["split_" + name]
+    assert len(folds) == ref.shape[0]
+    for (train, test), flags in zip(folds, ref):
+        assert np.array_equal(test["row"], np.flatnonzero(flags == 1)) and np.array_equal(train["row"], np.flatnonzero(flags == 0))
+
+
+def test_train_validation_test_hierarchy():
+    ns = {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2},
+          "validation_splitting": {"strategy": "temporal_hold_out", "leave_n_out": 2}}
+    (train_val, test), = L.split(frame(), ns, 42)
+    (train, val), = train_val
+    assert np.array_equal(test["row"], GOLD["hier_test"]) and np.array_equal(val["row"], GOLD["hier_val"]) and np.array_equal(train["row"], GOLD["hier_train"])
+
+
+def test_loader_builds_one_dataset_per_fold(tmp_path):
+    fr = frame()
+    with open(tmp_path / "d.tsv", "w") as f:
+        for u, i, r, t in zip(fr["userId"], fr["itemId"], fr["rating"], fr["timestamp"]):
+            f.write(f"{u}\t{i}\t{r}\t{t}\n")
+    from elliot_amd.dataset.dataset import default_config
+    cfg = default_config()
+    cfg.data_config = SimpleNamespace(strategy="dataset", dataset_path=str(tmp_path / "d.tsv"))
+    cfg.prefiltering = [SimpleNamespace(strategy="user_k_core", core=30)]
+    cfg.splitting = SimpleNamespace(test_splitting=SimpleNamespace(strategy="random_cross_validation", folds=3),
+                                    validation_splitting=SimpleNamespace(strategy="temporal_hold_out", leave_n_out=1))
+    cfg.binarize = True
+    objs = L.DataSetLoader(cfg).generate_dataobjects()
+    assert len(objs) == 3 and all(len(o) == 1 for o in objs)
+    kept = GOLD["filter_user_k_core"].shape[0]
+    for (ds,) in objs:
+        n_val = sum(len(v) for v in ds.val_dict.values())
+        n_test = sum(len(v) for v in ds.test_dict.values())
+        assert ds.transactions + n_val + n_test == kept and n_val == ds.num_users
+        assert set(np.unique(ds.sp_i_train_ratings.data).tolist()) == {1.0}
+
+
+def test_option_errors_read_like_the_reference():
+    with pytest.raises(Exception, match="Threshold option is missing"):
+        L.prefilter(frame(), [{"strategy": "global_threshold"}])
+    with pytest.raises(Exception, match="Core option is not a digit"):
+        L.prefilter(frame(), [{"strategy": "user_k_core", "core": "x"}])
+    with pytest.raises(Exception, match="Unrecognized Test Strategy"):
+        L.split(frame(), {"test_splitting": {"strategy": "nope"}})
+    with pytest.raises(Exception, match="Test splitting strategy is not defined"):
+        L.split(frame(), {})
