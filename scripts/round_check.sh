@@ -12,5 +12,9 @@ mkdir -p gpurun_out/$TAG
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/$TAG/bench_prof.log 2>&1
 python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline ($TAG)" > gpurun_out/$TAG/bench_kernel_stats.md 2>&1
 rm -rf gpurun_out/$TAG/prof
+# the headline leg alone: the c4 leg launches the same kernels on 10x the rows, which would blur the per-kernel averages above
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics > gpurun_out/$TAG/bench_prof_bpr.log 2>&1
+python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics ($TAG; headline leg only: BASELINE configs[1] training step + top-k block + metrics)" > gpurun_out/$TAG/bench_kernel_stats_bpr.md 2>&1
+rm -rf gpurun_out/$TAG/prof
 if [ "$2" = "traffic" ]; then bash scripts/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1; fi
 tail -4 gpurun_out/$TAG/pytest.log; tail -1 gpurun_out/$TAG/smoke.log; cut -c1-1800 gpurun_out/$TAG/bench_line.json; tail -5 gpurun_out/$TAG/bench.err
