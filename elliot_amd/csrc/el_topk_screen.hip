@@ -5,8 +5,12 @@
 // are re-scored with the exact fp32 chain.  Exactness comes from a rigorous error bound, not from luck:
 //
 //   s   = exact fp32-chain score of (u, i)            s' = bf16 MFMA score  sum_f bf16(u_f) bf16(i_f)  (+ bias, fp32)
-//   |s - s'| <= E_u := ||u|| * max_i ||i|| * (2^-7 * 1.02 + F * 2^-21) + 2^-21 (||u|| max||i|| + max|bias|)
-//        (bf16 rounding: relative 2^-8 per factor -> (2^-7 + 2^-16) sum|u_f i_f| <= ... ||u|| ||i|| by Cauchy-Schwarz;
+//   with u = u~ + du, i = i~ + di (u~, i~ the bf16 roundings; the residuals du, di are exact fp32 numbers):
+//        u_f i_f - u~_f i~_f = du_f i~_f + u_f di_f      (identity)
+//   |s - s'| <= E_u := ||du|| * max_i ||i~|| + ||u|| * max_i ||di|| + F * 2^-21 ||u|| max||i|| + 2^-21 (||u|| max||i|| + max|bias|)
+//        (Cauchy-Schwarz on the two sums with the MEASURED residual norms -- ||du|| per user in k_screen_thr, max ||i~|| and
+//         max ||di|| over the item shard in k_screen_prep, each with a 2^-10 margin for its own fp32 evaluation; round 1 used
+//         the worst case 2^-8 per factor instead, ||u|| max||i|| 2^-7: 3x wider on real data, hence 3x more candidates;
 //         fp32 accumulation of either chain: <= F 2^-24 sum|u_f i_f| each, taken with a 4x margin; bias add 2^-24 rel.)
 //   If T is ANY value such that k unmasked items have s' >= T, every member of the exact top-k has s' >= T - 2 E_u.
 //        (k items have s >= T - E_u, so the k-th exact score s_(k) >= T - E_u, and a member has s' >= s - E_u.)
@@ -50,10 +54,14 @@ __device__ __forceinline__ u32 el_f2bf(float x) {
 __device__ __forceinline__ float el_bf2f(u32 h) { return __uint_as_float(h << 16); }
 
 // E (screening error bound) and tol (bound on the difference of two fp32 evaluations of the same bf16 dot product)
-__device__ __forceinline__ void el_screen_bounds(float nu, float imax, float babs, int F, float& E, float& tol) {
+// nu = ||u||, du = ||u - bf16(u)||, imax = max ||i||, imax_b = max ||bf16(i)||, dmax = max ||i - bf16(i)|| (all with their margins)
+__device__ __forceinline__ void el_screen_bounds(float nu, float du, float imax, float imax_b, float dmax, float babs, int F, float& E,
+                                                 float& tol) {
     tol = (float)F * 4.8e-7f * nu * imax + 4.8e-7f * (nu * imax + babs) + 1e-30f;
-    E = nu * imax * (0.0078125f * 1.02f) + tol;
+    E = du * imax_b + nu * dmax + tol;
 }
+#define SCR_STAT_IB 16   // stats[16] = max ||bf16(i)||, stats[17] = max ||i - bf16(i)||  (stats[0] = max ||i||, [1] = max |bias|)
+#define SCR_STAT_ID 17
 
 // accumulator position (tile row 0..63) -> slot id, the order pass 1 stores the maxima in
 __device__ __forceinline__ int el_screen_slot(int row) {
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
     const int64_t item = t / SL;
     const int sl = (int)(t % SL);
     float v[8];
-    float ss = 0.f;
+    float ss = 0.f, sb = 0.f, sd = 0.f;
     const bool live = item < I;
     if (live) {
         const float* src = Gi + item * (int64_t)F + sl * 8;
@@ -92,12 +100,22 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
         o.w = el_f2bf(v[6]) | (el_f2bf(v[7]) << 16);
         *reinterpret_cast<uint4*>(Gib + item * FP + sl * 8) = o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+        for (int j = 0; j < 8; ++j) {
+            const float r = el_bf2f(el_f2bf(v[j])), d = v[j] - r;      // the residual of a bf16 rounding is an exact fp32 number
+            ss += v[j] * v[j];
+            sb += r * r;
+            sd += d * d;
+        }
     }
     ss = el_group_sum(ss, SL);                           // all SL lanes of an item hold its sum of squares
-    float nrm = sqrtf(ss) * 1.001f;
+    sb = el_group_sum(sb, SL);
+    sd = el_group_sum(sd, SL);
+    float nrm = sqrtf(ss) * 1.001f, nrb = sqrtf(sb) * 1.001f, nrd = sqrtf(sd) * 1.001f;
     if (!(nrm < INFINITY)) nrm = INFINITY;               // NaN / inf rows poison the bound -> every user falls back
+    if (!(nrb < INFINITY)) nrb = INFINITY;
+    if (!(nrd < INFINITY)) nrd = INFINITY;
     u32 nmax = live ? __float_as_uint(nrm) : 0u;         // non-negative floats order as their bit patterns
+    u32 nbmax = live ? __float_as_uint(nrb) : 0u, ndmax = live ? __float_as_uint(nrd) : 0u;
     u32 bmax = 0u;
     if (live && Bi && sl == 0) {
         float b = fabsf(Bi[item]);
@@ -107,12 +125,16 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
+        nbmax = max(nbmax, (u32)__shfl_xor((int)nbmax, o, 64));
+        ndmax = max(ndmax, (u32)__shfl_xor((int)ndmax, o, 64));
         bmax = max(bmax, (u32)__shfl_xor((int)bmax, o, 64));
     }
     if ((threadIdx.x & 63) == 0) {                       // same-address atomics serialise in L2: only raise, never re-assert
         unsigned int* st = reinterpret_cast<unsigned int*>(stats);
         if (nmax > __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st, nmax);
         if (bmax > __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + 1, bmax);
+        if (nbmax > __hip_atomic_load(st + SCR_STAT_IB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + SCR_STAT_IB, nbmax);
+        if (ndmax > __hip_atomic_load(st + SCR_STAT_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + SCR_STAT_ID, ndmax);
     }
 }
 
@@ -164,13 +186,13 @@ __global__ void k_items_decide(u64* ctl, float* stats, int force) {
     const bool stale = force || ctl[0] != ctl[1];
     ctl[0] = ctl[1];
     ctl[2] = stale ? 1ull : 0ull;
-    if (stale) stats[0] = stats[1] = 0.f;                 // max ||i||, max |bias|: re-derived by k_screen_prep
+    if (stale) stats[0] = stats[1] = stats[SCR_STAT_IB] = stats[SCR_STAT_ID] = 0.f;   // the item-side maxima: re-derived by k_screen_prep
 }
 
 struct ScreenParams {
     TopkParams t;
     const unsigned short* Gib;   // [I_local][FP] bf16
-    const float* stats;          // [0] max item norm, [1] max |bias|
+    const float* stats;          // [0] max item norm, [1] max |bias|, [16] max norm of the bf16 image rows, [17] max residual norm
     float* smax;                 // [n_users][64] slot maxima (pass 1)
     float* thr;                  // [n_users] final threshold (+inf: user is flagged)
     int32_t* cnt;                // [n_users] hits appended in pass 2
@@ -486,16 +508,21 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
     sm[lane] = M;
     inv[lane] = 0;
     const float* gu = p.Gu + user * (int64_t)p.F;
-    float ss = 0.f;
+    float ss = 0.f, sd = 0.f;
     for (int f = lane; f < FP; f += 64) {
         const float v = (f < p.F) ? gu[f] : 0.f;
-        ubf[f] = el_bf2f(el_f2bf(v));
+        const float r = el_bf2f(el_f2bf(v)), d = v - r;
+        ubf[f] = r;
         ss += v * v;
+        sd += d * d;
     }
     ss = el_group_sum(ss, 64);
+    sd = el_group_sum(sd, 64);
     const float nu = sqrtf(ss) * 1.001f;
+    float du = sqrtf(sd) * 1.001f;
+    if (!(du < INFINITY)) du = INFINITY;                  // inf / NaN user row: the bound is infinite, the user falls back
     float E, tol;
-    el_screen_bounds(nu, sp.stats[0], sp.stats[1], p.F, E, tol);
+    el_screen_bounds(nu, du, sp.stats[0], sp.stats[SCR_STAT_IB], sp.stats[SCR_STAT_ID], sp.stats[1], p.F, E, tol);
     // slots by descending maximum; only the slots near the top can decide T, so the masked items of the best k + 8 slots
     // are scored first and the rest only if those did not yield k clean slots (the rows are the kernel's HBM traffic)
     const bool fin = (M > -INFINITY) && (M < INFINITY);
@@ -764,7 +791,8 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
         const int sd = I_local >= 60000 ? 8 : (ntiles >= 192 ? 4 : 1);
         if (sd > 1) {
             q.stride = sd;
-            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd == 8 ? (I_local >= 300000 ? 4 : 3) : 5);
+            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd == 8 ? 4 : 5);   // (+3 under the round-1 bound; the measured-residual bound verifies
+            // the guess against a 3x narrower margin, so it is aimed one slot lower: 209 -> 19 fallback users per block on untrained weights)
         }
     } else {
         int sd = (int)(1.15 * k / 24.0 + 0.5);                  // kA ~ 20-30 of the 64 slots: a 1/sd sample has rank sd(kA + 1/2)
@@ -920,6 +948,7 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
             EL_LAUNCH("k_screen_prep", k_screen_prep<256>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
     } else {
         EL_CHECK_HIP(hipMemsetAsync(stats, 0, 8, st));
+        EL_CHECK_HIP(hipMemsetAsync(stats + SCR_STAT_IB, 0, 8, st));
     }
     const char* pe = getenv("EL_SCREEN_PROF");
     const bool prof = pe && pe[0] == '1';
