@@ -220,6 +220,46 @@ def test_screened_topk_large_random_block(ctx):
     assert_topk_equal("topk_screen_large", gi, gv, ei, ev)
 
 
+@pytest.mark.parametrize("case", ["bf16_exact", "near_power_of_two", "one_huge_item", "mixed_scales", "sparse_rows", "tiny"])
+def test_screened_topk_residual_bound_adversarial_inputs(ctx, case):
+    """The screening bound is ||du|| max||i~|| + ||u|| max||di|| (+ fp32 accumulation), du / di the MEASURED bf16 residuals.  Inputs
+    that push on it: operands that ARE bf16 numbers (residuals 0: the window collapses to the accumulation term, and thousands of
+    exact ties appear), values just above a power of two (the largest relative bf16 error), one item with a norm 1000x the
+    others, per-row scales over 6 orders of magnitude, rows with a handful of non-zeros, values near the fp32 denormal range.
+    Indices and score bits must still be the oracle's."""
+    rs = np.random.RandomState(sum(map(ord, case)))
+    U, I, F, k = 700, 9000, 128, 10
+    Gu = rs.normal(scale=0.1, size=(U, F)).astype(np.float32)
+    Gi = rs.normal(scale=0.1, size=(I, F)).astype(np.float32)
+    Bi = rs.normal(scale=0.01, size=I).astype(np.float32)
+
+    def to_bf16(x):
+        b = x.view(np.uint32).astype(np.uint64)
+        return (((b + 0x7fff + ((b >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+    if case == "bf16_exact":
+        Gu, Gi = to_bf16(Gu), to_bf16(np.round(Gi * 8) / 8)            # coarse item grid: many exactly equal scores
+    elif case == "near_power_of_two":
+        Gu = (np.sign(Gu) * (1.0 + 2.0 ** -9 + rs.uniform(0, 2.0 ** -12, size=Gu.shape))).astype(np.float32) * 0.125
+        Gi = (np.sign(Gi) * (1.0 + 2.0 ** -9 + rs.uniform(0, 2.0 ** -12, size=Gi.shape))).astype(np.float32) * 0.25
+    elif case == "one_huge_item":
+        Gi[1234] *= 1000.0
+        Gi[77] *= 300.0
+    elif case == "mixed_scales":
+        Gu *= (10.0 ** rs.uniform(-3, 3, size=(U, 1))).astype(np.float32)
+        Gi *= (10.0 ** rs.uniform(-2, 1, size=(I, 1))).astype(np.float32)
+    elif case == "sparse_rows":
+        Gu *= (rs.uniform(size=Gu.shape) < 0.05)
+        Gi *= (rs.uniform(size=Gi.shape) < 0.1)
+    elif case == "tiny":
+        Gu *= np.float32(1e-18)
+        Gi *= np.float32(1e-18)
+        Bi *= np.float32(1e-30)
+    excl = random_excl(rs, U, I, 0, 50)
+    ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
+    gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")
+    assert_topk_equal("topk_screen_" + case, gi, gv, ei, ev)
+
+
 @pytest.mark.parametrize("k", [10, 50])
 def test_screened_topk_all_users_fall_back(ctx, k):
     """Every item identical -> every score of a user ties -> every user is flagged: exercises all fallback tiers (dense
