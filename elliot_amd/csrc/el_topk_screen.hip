@@ -787,11 +787,12 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
     if (k <= 12) {
         // every 8th tile from 60 K items (round 2: at I = 100 K pass 1 drops 0.66 -> 0.36 ms and the sample of 12.5 K items still
         // gives a usable guess: 4.52 -> 4.24 ms per 131 072-user block, nobody falls back; scripts/screen_sweep.sh), every 4th
-        // for smaller catalogues of at least 192 tiles
-        const int sd = I_local >= 60000 ? 8 : (ntiles >= 192 ? 4 : 1);
+        // for smaller catalogues of at least 192 tiles, every 16th from 500 K items (I = 1 M: pass 1 3.04 -> 1.54 ms of a 28.9 ms
+        // block, the 62 K-item sample guesses as well as 12.5 K of 100 K do: 4.54 -> 4.77 M users/s, nobody falls back)
+        const int sd = I_local >= 500000 ? 16 : (I_local >= 60000 ? 8 : (ntiles >= 192 ? 4 : 1));
         if (sd > 1) {
             q.stride = sd;
-            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd == 8 ? 4 : 5);   // (+3 under the round-1 bound; the measured-residual bound verifies
+            q.kA = (int)((1.15 * k) / sd + 0.999) + (sd >= 8 ? 4 : 5);   // (+3 under the round-1 bound; the measured-residual bound verifies
             // the guess against a 3x narrower margin, so it is aimed one slot lower: 209 -> 19 fallback users per block on untrained weights)
         }
     } else {
