@@ -98,6 +98,7 @@ PROTOTYPES = {
     "el_abi_version": (C.c_int, []),
     "el_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "el_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "el_timing_filter": (C.c_int, [C.c_void_p, C.c_char_p]),
     "el_tuning_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "el_comm_unique_id": (C.c_int, [C.c_void_p]),
     "el_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -21,6 +21,7 @@ struct el_ctx {
     char arch[64];
     // optional per-kernel timing (el_timing_enable): hipEvents recorded on the launch stream
     bool timing;
+    std::string timing_only;   // el_timing_filter: when non-empty only launches of this name are bracketed
     bool tuning = false;   // el_tuning_mode: optimiser launches use the *_tune kernel instantiations
     float* zeros = nullptr; // 256 bytes of zeros in device memory (source of out-of-range LDS-DMA lanes, el_gemm.hip)
     // el_bprmf_train_loop: pinned staging copy of the caller's step-size table (the caller's array may be freed on return)
@@ -50,7 +51,7 @@ struct ElKernelTimer {
     hipEvent_t a, b;
     bool on;
     ElKernelTimer(const char* name_, hipStream_t s_) : c(g_el_cur_ctx), name(name_), s(s_), on(false) {
-        if (c && c->timing) {
+        if (c && c->timing && (c->timing_only.empty() || c->timing_only == name_)) {
             a = grab();
             b = grab();
             on = (a != nullptr && b != nullptr);

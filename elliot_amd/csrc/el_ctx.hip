@@ -69,6 +69,12 @@ extern "C" int el_timing_enable(el_ctx* ctx, int on) {
     return 0;
 }
 
+extern "C" int el_timing_filter(el_ctx* ctx, const char* kernel_name) {
+    EL_REQUIRE(ctx != nullptr, "el_timing_filter: null ctx");
+    ctx->timing_only = kernel_name ? kernel_name : "";
+    return 0;
+}
+
 extern "C" int el_tuning_mode(el_ctx* ctx, int on) {
     EL_REQUIRE(ctx != nullptr, "el_tuning_mode: null ctx");
     ctx->tuning = on != 0;

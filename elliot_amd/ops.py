@@ -55,7 +55,10 @@ class Context:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def timing(self, on):
+    def timing(self, on, only=None):
+        """Bracket kernel launches with hipEvents; `only` = a kernel name: just those launches (an event between two kernels
+        costs their overlap, so timed regions keep them on the kernel of interest)."""
+        check(self.lib.el_timing_filter(self.handle, only.encode() if only else None), "el_timing_filter")
         check(self.lib.el_timing_enable(self.handle, 1 if on else 0), "el_timing_enable")
 
     def timing_report(self):

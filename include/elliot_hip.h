@@ -53,6 +53,10 @@ int el_device_info(el_ctx* ctx, char* name, int len, int* cus, int64_t* hbm_byte
  * el_timing_report synchronises them and writes "kernel_name launches total_ms\n" lines. */
 int el_timing_enable(el_ctx* ctx, int on);
 int el_timing_report(el_ctx* ctx, char* buf, int len);
+/* Restricts the bracketing to the launches reported under `kernel_name` (NULL or "": every launch again).  An event between
+ * two kernels costs their back-to-back overlap (measured: 16 events per 1.5 ms training step = +4 % wall), so bench.py times
+ * its steps with events on the dominant kernel only and takes the per-kernel breakdown from a separate pass. */
+int el_timing_filter(el_ctx* ctx, const char* kernel_name);
 /* Launches of the optimiser passes made while this is on (the HBM placement tuner of the host layer times the dense Adam
  * pass on scratch tables) carry their own kernel symbols (k_adam_*<..., true>), so that a rocprofv3 kernel trace of a run
  * lists the product launches and the tuner's probes separately. */
