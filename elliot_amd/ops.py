@@ -462,6 +462,9 @@ def tune_table_layout(ctx, rows, F, compact=False):
             best, best_ms = gap, ms
         del tabs, big
     check(ctx.lib.el_tuning_mode(ctx.handle, 0), "el_tuning_mode")
+    if os.environ.get("EL_TUNE_DEBUG"):
+        import sys
+        print(f"[tune_table_layout] {key}: gap {best / (1 << 20):.1f} MiB at {best_ms:.4f} ms per pass", file=sys.stderr)
     cache[key] = best
     return best
 
