@@ -8,7 +8,8 @@ One JSON line on rank 0.
 N = 1  workload = BASELINE.json configs[1]: BPRMF d=128 on synthetic 1M users x 100K items (SURVEY.md 8d "S-1M"),
        inputs resident in HBM before the timed region.
          step (train) : sample B triplets on the device -> gather -> BPR loss -> Adam (TF-dense semantics, the reference's
-                        BPRMF_batch_model.train_step) for one batch of B = --batch triplets
+                        BPRMF_batch_model.train_step) for one batch of B = --batch triplets; software-pipelined: the sampler,
+                        prep and radix sort of step t+1 (they never read the model) run on a side stream under step t
          step (top-k) : fused score + masked top-k for one block of --topk-block users against the full catalogue
        `value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Secondary legs follow
        (parity-test configurations of BASELINE.json, here with their own rooflines): "c4_one_gpu" = the same two steps at
@@ -73,7 +74,10 @@ def parse():
                     help="N > 1: collectives through torch.distributed (RCCL process group) or through the library's own C ABI "
                          "(el_comm_init / el_allreduce_rows / el_allgather_topk: RCCL called directly)")
     ap.add_argument("--prefetch", action="store_true",
-                    help="draw the triplets of step t+1 on a side stream during step t (measured: no gain, the step is HBM-bound)")
+                    help="item-shard leg: draw the triplets of step t+1 on a side stream during step t")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N = 1: do NOT draw and order (prep + radix sort) the batch of step t+1 on a side stream while step t's segment "
+                         "kernels and optimiser pass run (default: pipelined, 1.47 -> 1.41 ms per step; same kernels, same results)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-topk-users", type=int, default=640)
@@ -142,10 +146,14 @@ class PrefetchSampler:
     """BPR triplets of step t+1 are drawn on a side stream while step t trains: the sampler (custom_sampler.py:31-46) does not
     depend on the model, so a training loop can always run it one batch ahead.  Two triplet buffers, events both ways."""
 
-    def __init__(self, ctx, pos, B, seed, enabled=True):
+    def __init__(self, ctx, pos, B, seed, enabled=True, presort_state=None):
         from elliot_amd import ops
         dev = ctx.device
         self.ops, self.ctx, self.pos, self.B, self.seed, self.enabled = ops, ctx, pos, B, seed, enabled
+        # presort_state: a BprmfDeviceState -- the batch is also ORDERED (prep + radix sort, which read only the triplets) ahead
+        # of its step, into one workspace per buffer
+        self.state = presort_state if enabled else None
+        self.ws = [presort_state.sort_workspace(B) for _ in range(2)] if self.state is not None else [None, None]
         self.bufs = [tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3)) for _ in range(2)]
         self.side = torch.cuda.Stream(device=dev)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -157,6 +165,8 @@ class PrefetchSampler:
     def _draw(self, b):
         self.ops.bpr_sample(self.ctx, self.pos, self.B, seed=self.seed, first_sample=self.ctr, out=self.bufs[b])
         self.ctr += self.B
+        if self.state is not None:
+            self.state.presort(*self.bufs[b], self.ws[b])
 
     def _issue(self, b):
         self.side.wait_stream(torch.cuda.current_stream())           # (first use / anything the caller queued before)
@@ -200,15 +210,20 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
-def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=True):
+class _Report(dict):
+    """{kernel: (launches, total_ms)} of the breakdown pass; .live = the same for the kernel bracketed inside the timed region."""
+    live = {}
+
+
+def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=True, fn_breakdown=None):
     """W untimed calls, then exactly K calls between barrier + synchronize on both sides; max over ranks.
     A hipEvent between two kernels costs their back-to-back overlap (measured: events around all 8 launches of the 1.5 ms
     training step = +4 % wall).  So the timed region carries events on ONE kernel -- the dominant one, whose live duration the
-    roofline is computed from -- and the per-kernel breakdown comes from a separate pass of K steps with events on every launch
-    (taken first: it also names the dominant kernel).  Legs of 40+ short launches per step (Mult-VAE, NeuMF:
-    events_in_timed_region=False) are timed without any event.
-    Returns (seconds of the timed region, {kernel: (launches, total_ms)} of the breakdown pass with the dominant kernel's entry
-    replaced by what was measured inside the timed region)."""
+    roofline is computed from (report.live) -- and the per-kernel breakdown comes from a separate pass of K steps with events
+    on every launch, taken first: it also names the dominant kernel.  fn_breakdown: the step to run in that pass when `fn`
+    overlaps kernels on several streams (per-kernel elapsed times of concurrent kernels mean nothing; the breakdown is then
+    of the same kernels run back to back).  Legs of 40+ short launches per step (Mult-VAE, NeuMF:
+    events_in_timed_region=False) are timed without any event."""
     for _ in range(warmup):
         fn()
     if finish:
@@ -216,13 +231,17 @@ def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=Tru
     barrier(world)
     ctx.timing(True)                                             # breakdown pass (untimed)
     for _ in range(steps):
-        fn()
+        (fn_breakdown or fn)()
     if finish:
         finish()
     barrier(world)
     ctx.timing(False)
-    rep = ctx.timing_report()
+    rep = _Report(ctx.timing_report())
     only = max(rep, key=lambda n: rep[n][1]) if (rep and events_in_timed_region) else None
+    if fn_breakdown is not None:
+        fn()                                                     # (re-prime the look-ahead of the pipelined step)
+        if finish:
+            finish()
     if only:
         ctx.timing(True, only=only)
     barrier(world)
@@ -234,9 +253,7 @@ def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=Tru
     barrier(world)
     dt = time.perf_counter() - t0
     ctx.timing(False)
-    live = ctx.timing_report()
-    if only and only in live:
-        rep[only] = live[only]
+    rep.live = ctx.timing_report()
     return max_over_ranks(dt, world, ctx.device), rep
 
 
@@ -252,8 +269,11 @@ def time_collective(world, dev, fn, reps=5):
 
 
 def dominant(rep):
+    """(name, seconds per launch) of the kernel with the largest share of the breakdown pass; the duration is the one
+    measured INSIDE the timed region when that kernel was bracketed there."""
     name = max(rep, key=lambda n: rep[n][1])
-    return name, rep[name][1] / rep[name][0] * 1e-3   # seconds per launch
+    cnt, ms = getattr(rep, "live", {}).get(name, rep[name])
+    return name, ms / cnt * 1e-3
 
 
 def source_hash():
@@ -374,6 +394,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     lo, hi = parallel.item_range(I, rank, world) if shard == "item" else (0, I)
     lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
     finish_train = None
+    breakdown_step = None
+    pipelined = False
     exchange = None
     coll = data.get("coll") or parallel._Collectives()
     sharded = world > 1 or args.force_sharded
@@ -381,13 +403,40 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     if not sharded:
         st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
         pos_train = pos
-        sampler = PrefetchSampler(ctx, pos, B, 42, enabled=args.prefetch)
+        # Software pipeline of the step: drawing AND ordering a batch (sampler, prep, radix sort) reads only the positives' CSR and
+        # the triplets, never the model -- so the batch of step t+1 is prepared on a side stream while step t's segment kernels and
+        # optimiser pass run (latency-bound work under bandwidth-bound work: 1.47 -> 1.41 ms per step).  Same kernels, same
+        # triplets, same results as the sequential step (the loss of the last step is identical to the last digit).
+        pipelined = (not args.no_pipeline) and args.train_algo in ("auto", "sorted") and B >= 2048
+        sampler = PrefetchSampler(ctx, pos, B, 42, enabled=pipelined, presort_state=st if pipelined else None)
+        hi_prio = torch.cuda.Stream(device=dev, priority=-1) if pipelined else None     # the step's own kernels outrank the look-ahead
+        if hi_prio is not None:
+            hi_prio.wait_stream(torch.cuda.current_stream())
 
         def train_step():
+            if pipelined:
+                with torch.cuda.stream(hi_prio):
+                    t, b = sampler.next()
+                    st.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, sampler.ws[b])
+                    sampler.release(b)
+                return
             t, b = sampler.next()
             st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
             sampler.release(b)
 
+        if pipelined:
+            seq_drawn = [1 << 40]                                    # (its own part of the Philox stream)
+
+            def train_step_sequential():
+                """The same step with nothing in flight beside it: what the per-kernel breakdown pass runs."""
+                torch.cuda.current_stream().wait_stream(hi_prio)
+                torch.cuda.current_stream().wait_stream(sampler.side)
+                t = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=seq_drawn[0])
+                seq_drawn[0] += B
+                st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
+                hi_prio.wait_stream(torch.cuda.current_stream())
+                sampler.side.wait_stream(torch.cuda.current_stream())
+            breakdown_step = train_step_sequential
         pop_loss = st.pop_loss
     elif shard == "user":
         # USER shards: the rank owns the user rows [ulo, uhi) and a replica of the item table; B triplets per rank for its
@@ -498,7 +547,7 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
             collectives.append(("partial top-k lists [Ub,k] (ids + scores) per block", "all_gather", 2 * world * Ub * k * 4,
                                 lambda: (coll.all_gather(part), coll.all_gather(part))))
 
-    dt_train, rep_train = timed(ctx, world, train_step, W, K, finish_train)
+    dt_train, rep_train = timed(ctx, world, train_step, W, K, finish_train, fn_breakdown=breakdown_step)
     loss = pop_loss()
     prepare_topk()
     dt_topk, rep_topk = timed(ctx, world, topk_step, W, K)
@@ -560,6 +609,13 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dn), "traffic_source": traffic_note,
                   "step_GBs": step_bytes / (dt_train / K) / 1e9,
                   "kernels_ms_per_step": {n: v[1] / K for n, v in rep_train.items()}}
+    if pipelined:
+        # the timed steps overlap the NEXT batch's sampler / prep / sort with this step's kernels: `achieved` is the dominant
+        # kernel's duration inside that timed region (it shares HBM with the look-ahead work), the breakdown above and the
+        # figure below are the same kernels run back to back
+        b2b = alg.get(dn, step_bytes) / (rep_train[dn][1] / rep_train[dn][0] * 1e-3) / 1e9
+        roof_train.update({"pipelined": "sampler + prep + sort of step t+1 on a side stream under step t",
+                           "achieved_back_to_back": b2b, "frac_back_to_back": b2b / HBM_PEAK_GBS})
     # top-k roofline: the dominant kernel is one full user x item scoring GEMM (2*U*I*F flop per launch): the fp32 MFMA
     # kernel, or one of the two bf16 passes of the screened kernel (the other pass repeats the same flops; results are
     # re-scored in fp32 and bit-identical)

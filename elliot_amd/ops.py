@@ -616,6 +616,29 @@ class BprmfDeviceState:
         check(self.ctx.lib.el_bprmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), float(lr), int(self.opt),
                                           int(self.step), float(adam_lr_t(lr, self.step))), "el_bprmf_apply")
 
+    # -- the step in two halves for a software pipeline: ordering a batch (prep + radix sort) reads only its triplets, so the
+    #    batch of step t+1 can be drawn and ordered on a side stream while step t's segment kernels and optimiser pass run
+    def sort_workspace(self, B):
+        """A workspace tensor for presort() / train_step_presorted() (el_bprmf_ws_bytes): one per batch in flight."""
+        return torch.empty(int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))), dtype=torch.uint8, device=self.ctx.device)
+
+    def presort(self, u, i, j, ws):
+        """First half of the sorted gradient path: (row, triplet) pairs of the batch, ordered, into `ws` (current stream)."""
+        check(self.ctx.lib.el_bprmf_presort(self.ctx.handle, self.ctx.stream(), _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
+                                            _ptr(j, torch.int32, "j"), int(u.numel()), int(self.U), int(self.I),
+                                            C.c_void_p(ws.data_ptr()), ws.numel()), "el_bprmf_presort")
+
+    def train_step_presorted(self, u, i, j, lr, l_w, l_b, ws):
+        """train_step on a batch that presort() ordered into `ws`: segment kernels + loss, then the optimiser -- the same kernels,
+        the same results as train_step(algo="sorted")."""
+        B = u.numel()
+        self.ensure_rows(B)
+        check(self.ctx.lib.el_bprmf_grads_presorted(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
+                                                    _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(l_w), float(l_b),
+                                                    int(self.step + 1), _ptr(self.loss, torch.float64), C.c_void_p(ws.data_ptr()),
+                                                    ws.numel()), "el_bprmf_grads_presorted")
+        self.apply(lr)
+
     def train_loop(self, pos, events, B, seed, first_sample, lr, l_w, l_b, algo="auto"):
         """One epoch of `for batch in sampler.step(events, B): train_step(batch)` (BPRMF_batch.py:100-109) from a single
         library call: the same Philox stream and the same kernels as the per-batch calls, no host round trip in between."""

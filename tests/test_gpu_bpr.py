@@ -457,3 +457,40 @@ def test_presorted_gradients_equal_the_one_call_form(ctx):
         a.apply(0.01)
         b.apply(0.01)
     assert np.abs(cpu(a.state.Gi) - cpu(b.state.Gi)).max() < 1e-5
+
+
+def test_pipelined_step_equals_the_sequential_step(ctx):
+    """bench.py's software pipeline -- the batch of step t+1 drawn AND ordered (sampler, prep, radix sort) on a side stream while
+    step t's segment kernels and optimiser pass run, the step itself on a high-priority stream -- against the plain sequence of
+    train_step calls on the same Philox stream: same triplets, same losses, same weights (hot rows: atomics order only)."""
+    import bench
+    from elliot_amd.synthetic import zipf_csr
+    rs = np.random.RandomState(91)
+    U, I, F, B, steps = 20000, 3000, 64, 8192, 7
+    indptr, indices = zipf_csr(U, I, mean_log=2.5, sigma_log=0.8, dmin=2, dmax=200, seed=5)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True)
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True)
+    sampler = bench.PrefetchSampler(ctx, pos, B, 42, enabled=True, presort_state=b)
+    hi = torch.cuda.Stream(device=ctx.device, priority=-1)
+    hi.wait_stream(torch.cuda.current_stream())
+    la, lb = [], []
+    for s in range(steps):
+        t = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=s * B)
+        a.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo="sorted")
+        la.append(a.pop_loss())
+        with torch.cuda.stream(hi):
+            tb, buf = sampler.next()
+            b.train_step_presorted(tb[0], tb[1], tb[2], lr, l_w, l_b, sampler.ws[buf])
+            sampler.release(buf)
+        torch.cuda.current_stream().wait_stream(hi)
+        assert all(torch.equal(x, y) for x, y in zip(t, tb)), s          # the look-ahead drew the batch of THIS step
+        lb.append(b.pop_loss())
+    torch.cuda.synchronize()
+    for s, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x - y) <= 1e-7 * abs(x), (s, x, y)
+    for name in ("Gu", "Gi", "Bi"):
+        x, y = cpu(getattr(a, name)), cpu(getattr(b, name))
+        assert (np.abs(x - y) > 2e-6).mean() < 1e-4 and np.abs(x - y).max() < 5 * lr, name
