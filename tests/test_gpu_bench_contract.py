@@ -55,6 +55,19 @@ def test_default_line_has_every_field():
     assert fr["users"] == d["config"]["topk_block"] and 0 <= fr["fragile"] <= fr["users"]
 
 
+def test_pipelined_and_plain_training_step_lines():
+    """Default: the next batch is drawn and sorted under the current step (roofline carries both the live and the back-to-back
+    figure of the dominant kernel); --no-pipeline: the plain sequence."""
+    d = run_bench("--legs", "bpr", "--no-cpu-baseline")
+    check_common(d)
+    r = d["roofline"]
+    assert "pipelined" in r and r["frac_back_to_back"] > 0 and abs(r["frac_back_to_back"] - r["achieved_back_to_back"] / r["peak"]) < 1e-9
+    p = run_bench("--legs", "bpr", "--no-cpu-baseline", "--no-pipeline")
+    check_common(p)
+    assert "pipelined" not in p["roofline"]
+    assert set(p["roofline"]["kernels_ms_per_step"]) == set(r["kernels_ms_per_step"])     # the same kernels either way
+
+
 def test_secondary_legs_carry_their_rooflines():
     """vae = BASELINE configs[2], neumf = configs[3] per-GPU shape; here at toy shapes (the default shapes run in bench.py itself)."""
     d = run_bench("--legs", "bpr,c4,vae,neumf", "--no-cpu-baseline", "--vae-shape", "3000,1500,96,32,256", "--neumf-shape", "5000,3000,32,8192",
