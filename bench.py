@@ -407,7 +407,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         # the triplets, never the model -- so the batch of step t+1 is prepared on a side stream while step t's segment kernels and
         # optimiser pass run (latency-bound work under bandwidth-bound work: 1.47 -> 1.41 ms per step).  Same kernels, same
         # triplets, same results as the sequential step (the loss of the last step is identical to the last digit).
-        pipelined = (not args.no_pipeline) and args.train_algo in ("auto", "sorted") and B >= 2048
+        pipelined = (not args.no_pipeline) and args.train_algo in ("auto", "sorted") and B >= 2048 and args.opt == "adam_tf_dense"
+        # (el_bprmf_apply is the dense optimiser pass; the lazy / row-wise optimisers keep the one-call step)
         sampler = PrefetchSampler(ctx, pos, B, 42, enabled=pipelined, presort_state=st if pipelined else None)
         hi_prio = torch.cuda.Stream(device=dev, priority=-1) if pipelined else None     # the step's own kernels outrank the look-ahead
         if hi_prio is not None:
