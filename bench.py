@@ -43,6 +43,8 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
+MFMA_BF16_RANDOM_TFLOPS = 1800.0  # what a bare stream of that instruction sustains on random operands (power-limited; measured:
+#                                   scripts/exp/mfma_rate.hip, profiles/r02_mfma_ceiling.md: 1.77-1.85 PFLOP/s, 2.48 on zeros)
 
 
 def parse():
@@ -628,6 +630,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     roof_topk = {"kernel": tn, "bound": "mfma", "achieved": ach_t, "peak": peak_t, "unit": "TFLOP/s",
                  "frac": ach_t / peak_t, "traffic": traffic.get(tn), "traffic_source": traffic_note,
                  "dtype": "bf16 MFMA screen + f32 exact re-score" if screened else "f32",
+                 **({"measured_ceiling_random_operands": MFMA_BF16_RANDOM_TFLOPS, "frac_of_measured_ceiling": ach_t / MFMA_BF16_RANDOM_TFLOPS}
+                    if screened else {}),
                  "effective_TFLOPs": flops / (dt_topk / K) / 1e12,
                  "kernels_ms_per_step": {n: v[1] / K for n, v in rep_topk.items()}}
     if not sharded:
