@@ -199,3 +199,64 @@ def test_negative_sampling_more_negatives_than_candidates_raises_like_random_sam
     excl.eliminate_zeros()
     with pytest.raises(ValueError):
         NS.sample_by_random_uniform(excl, 2, random.Random(42))
+
+
+# ---- property tests (hypothesis): the C loops against the interpreter's own set / shuffle / sample on arbitrary inputs ---------
+from hypothesis import given, settings, strategies as hst       # noqa: E402
+
+
+@settings(max_examples=120, deadline=None)
+@given(hst.lists(hst.integers(min_value=0, max_value=(1 << 61) - 2), max_size=400))
+def test_pyset_order_property(keys):
+    assert D.pyset_order(np.array(keys, dtype=np.int64)).tolist() == list({k for k in keys})
+
+
+@settings(max_examples=60, deadline=None)
+@given(hst.lists(hst.integers(min_value=0, max_value=2000), max_size=3000))
+def test_pyset_order_property_dense_small_ids(keys):
+    """many duplicates and collisions of the low bits: resizes at 5 / 19 / 76 / ... entries, linear probes, perturbed probes"""
+    assert D.pyset_order(np.array(keys, dtype=np.int64)).tolist() == list({k for k in keys})
+
+
+@settings(max_examples=60, deadline=None)
+@given(hst.lists(hst.integers(min_value=0, max_value=40), min_size=1, max_size=600), hst.floats(min_value=0.0, max_value=1.0),
+       hst.integers(min_value=0, max_value=2 ** 32 - 1), hst.integers(min_value=1, max_value=3))
+def test_split_flags_property(users, ratio, seed, folds):
+    users = np.array(users)
+    got = D.random_subsampling(users, ratio, seed, folds=folds)
+    got = got[None] if folds == 1 else got
+    rs = np.random.RandomState(seed)
+    order = np.argsort(users, kind="stable")
+    su = users[order]
+    bounds = np.flatnonzero(np.concatenate([[True], su[1:] != su[:-1], [True]]))
+    for f in range(folds):
+        exp = np.zeros(users.shape[0], dtype=np.int8)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            n = b - a
+            ntrain = int(math.floor(n * (1 - ratio)))
+            lst = [0] * ntrain + [1] * (n - ntrain)
+            rs.shuffle(lst)
+            exp[order[a:b]] = lst
+        assert np.array_equal(got[f], exp)
+
+
+@settings(max_examples=40, deadline=None)
+@given(hst.integers(min_value=1, max_value=12), hst.integers(min_value=30, max_value=1500), hst.integers(min_value=0, max_value=25),
+       hst.integers(min_value=0, max_value=2 ** 31 - 1))
+def test_negative_sampling_property(n_users, n_items, num, seed):
+    """el_host_negative_sample == random.sample(range(n_candidates), num) mapped onto the ascending candidates, user after user on
+    one stream -- both branches of random.sample (pool: n <= setsize; selection set otherwise)."""
+    rs = np.random.RandomState(seed % (2 ** 31))
+    dense = rs.uniform(size=(n_users, n_items)) < 0.3
+    excl = sp.csr_matrix(dense)
+    rng = random.Random(seed)
+    ref = random.Random(seed)
+    if any(n_items - int(dense[u].sum()) < num for u in range(n_users)):
+        with pytest.raises(ValueError):
+            NS.sample_by_random_uniform(excl, num, rng)
+        return
+    got = NS.sample_by_random_uniform(excl, num, rng)
+    for u in range(n_users):
+        cand = np.flatnonzero(~dense[u])
+        assert got[u].tolist() == cand[ref.sample(range(cand.shape[0]), num)].tolist()
+    assert rng.getstate() == ref.getstate()
