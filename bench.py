@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3, help="timed repeats of K steps per leg; the median repeat is the leg's time")
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=100_000)
     ap.add_argument("--factors", type=int, default=128)
@@ -70,8 +71,10 @@ def parse():
                     help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial "
                          "top-k (default: user for --shard user, item for the item-shard leg)")
     ap.add_argument("--legs", default="auto",
-                    help="comma list of bpr,item_shard,c4,vae,neumf,metrics (auto: N=1 -> bpr,metrics,c4,vae,neumf; N>1 -> bpr,item_shard)")
+                    help="comma list of bpr,item_shard,sweep,plugin,c4,c5,vae,neumf,metrics (auto: N=1 -> all but item_shard; N>1 -> bpr,item_shard)")
     ap.add_argument("--c4-shape", default="10000000,1000000", help="users,items of the c4 leg (north_star's target shape on ONE GPU)")
+    ap.add_argument("--c5-shape", default="6250000,5000000,256",
+                    help="users,items,factors of the c5 leg (BASELINE configs[4] = 50M x 5M x 256 on 8 GPUs: the per-GPU shape under user sharding)")
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
                     help="N > 1: collectives through torch.distributed (RCCL process group) or through the library's own C ABI "
                          "(el_comm_init / el_allreduce_rows / el_allgather_topk: RCCL called directly)")
@@ -212,13 +215,21 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
+REPEATS = 3                     # timed repeats of K steps per leg; the median is reported
+
+
 class _Report(dict):
-    """{kernel: (launches, total_ms)} of the breakdown pass; .live = the same for the kernel bracketed inside the timed region."""
+    """{kernel: (launches, total_ms)} of the breakdown pass; .live = the same for the kernel bracketed inside the timed region;
+    .repeats_ms = ms per step of every timed repeat (the leg reports their median)."""
     live = {}
+    repeats_ms = []
+    calls = 0
 
 
-def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=True, fn_breakdown=None):
-    """W untimed calls, then exactly K calls between barrier + synchronize on both sides; max over ranks.
+def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=True, fn_breakdown=None, repeats=None):
+    """W untimed calls, then R repeats of EXACTLY K calls, each repeat between barrier + synchronize on both sides and taken as
+    the max over ranks; the leg's time is the MEDIAN repeat (box-to-box and run-to-run spread of a 30 ms region is +-3 %; all
+    repeats are reported next to it: rep.repeats_ms).
     A hipEvent between two kernels costs their back-to-back overlap (measured: events around all 8 launches of the 1.5 ms
     training step = +4 % wall).  So the timed region carries events on ONE kernel -- the dominant one, whose live duration the
     roofline is computed from (report.live) -- and the per-kernel breakdown comes from a separate pass of K steps with events
@@ -226,6 +237,7 @@ def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=Tru
     overlaps kernels on several streams (per-kernel elapsed times of concurrent kernels mean nothing; the breakdown is then
     of the same kernels run back to back).  Legs of 40+ short launches per step (Mult-VAE, NeuMF:
     events_in_timed_region=False) are timed without any event."""
+    repeats = REPEATS if repeats is None else repeats
     for _ in range(warmup):
         fn()
     if finish:
@@ -246,17 +258,21 @@ def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=Tru
             finish()
     if only:
         ctx.timing(True, only=only)
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    if finish:
-        finish()                                                 # a collective still in flight belongs to the timed work
-    barrier(world)
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(1, repeats)):
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        if finish:
+            finish()                                             # a collective still in flight belongs to the timed work
+        barrier(world)
+        dts.append(max_over_ranks(time.perf_counter() - t0, world, ctx.device))
     ctx.timing(False)
-    rep.live = ctx.timing_report()
-    return max_over_ranks(dt, world, ctx.device), rep
+    rep.live = ctx.timing_report()                               # (launch counts and times over all repeats: the mean is unaffected)
+    rep.repeats_ms = [d / steps * 1e3 for d in dts]
+    rep.calls = warmup + steps + (1 if fn_breakdown is not None else 0) + len(dts) * steps      # calls of a step function in all
+    return sorted(dts)[len(dts) // 2], rep
 
 
 def time_collective(world, dev, fn, reps=5):
@@ -649,9 +665,10 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                      f"by user: {Ub} users per rank and step vs the whole catalogue (item table all-gathered once per evaluation)"
                      if topk_by_user else f"by item: all users vs I/{world} items per rank + all-gather/merge of partial lists")
     res = {
-        "value": pairs_per_s, "unit": "pairs/s", "ms_per_step": dt_train / K * 1e3, "scaling": "weak",
-        "parallelism": par, "loss_per_pair_last": loss / (B * world * (K + W)), "roofline": roof_train,
-        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3,
+        "value": pairs_per_s, "unit": "pairs/s", "ms_per_step": dt_train / K * 1e3, "repeats_ms_per_step": rep_train.repeats_ms,
+        "scaling": "weak",
+        "parallelism": par, "loss_per_pair_last": loss / (B * world * max(rep_train.calls, 1)), "roofline": roof_train,
+        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "repeats_ms_per_step": rep_topk.repeats_ms,
                  "scaling": "weak" if (topk_by_user or user_sharded or not sharded) else "strong",
                  "sharding": topk_sharding, "roofline": roof_topk},
         "interactions": int(pos.nnz), "topk_block": Ub,
@@ -666,6 +683,54 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         res["_host"] = {"Gu": st.Gu.cpu().numpy(), "Gi": st.Gi.cpu().numpy(), "Bi": st.Bi.cpu().numpy(),
                         "indptr": pos.indptr.cpu().numpy(), "indices": pos.indices.cpu().numpy()}
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batch-size sweep of the headline (B in {4 096, 65 536, 1 048 576}; the reference's default batch_size is 512)
+# ---------------------------------------------------------------------------------------------------------------------
+def sweep_leg(args, ctx, data):
+    """pairs/s of the training step at B in {4096, 65536, 2^20} for the reference's optimiser semantics (adam_tf_dense: Keras'
+    sparse apply moves EVERY row each step, 24 (U + I) F bytes whatever B is) and for the touched-rows-only Adam (adam_lazy: a
+    documented deviation, what a user who does not need TF's semantics would run).  Each point is one el_bprmf_train_loop call
+    (sampler + step per batch launched back to back inside the library, the plugin's fused-epoch path) of `steps` batches,
+    median of --repeats, on fresh tables."""
+    from elliot_amd import ops
+    dev = ctx.device
+    U, I, F = args.users, args.items, args.factors
+    pos = data["pos"]
+    lr, l_w, l_b = 0.001, 0.1, 0.001
+    out = []
+    for opt in ("adam_tf_dense", "adam_lazy"):
+        g = torch.Generator(device=dev)
+        g.manual_seed(42)
+        lim_u, lim_i = (6.0 / (U + F)) ** 0.5, (6.0 / (I + F)) ** 0.5
+        st = ops.BprmfDeviceState(ctx, (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * lim_u,
+                                  (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i, torch.zeros(I, device=dev), optimizer=opt)
+        drawn = 0
+        for B in (4096, 65536, 1 << 20):
+            steps = args.steps * (1 if B >= (1 << 20) else 4)
+            st.train_loop(pos, args.warmup * B, B, 42, drawn, lr, l_w, l_b)
+            drawn += args.warmup * B
+            dts = []
+            for _ in range(REPEATS):
+                barrier(1)
+                t0 = time.perf_counter()
+                st.train_loop(pos, steps * B, B, 42, drawn, lr, l_w, l_b)
+                barrier(1)
+                dts.append(time.perf_counter() - t0)
+                drawn += steps * B
+            dt = sorted(dts)[len(dts) // 2]
+            dense_bytes = 24.0 * (U + I) * F if opt == "adam_tf_dense" else 0.0
+            step_bytes = dense_bytes + B * ((24.0 if opt == "adam_tf_dense" else 72.0) * F + 28.0)
+            out.append({"optimizer": opt, "batch": B, "steps": steps, "value": B * steps / dt, "unit": "pairs/s",
+                        "ms_per_step": dt / steps * 1e3, "repeats_ms_per_step": [d / steps * 1e3 for d in dts],
+                        "step_GBs_algorithmic": step_bytes / (dt / steps) / 1e9})
+        st.pop_loss()
+        del st
+        torch.cuda.empty_cache()
+    return {"what": "el_bprmf_train_loop (sampler + step per batch, launched inside the library), U x I x F of the headline leg; "
+                    "adam_tf_dense = the reference's Keras semantics (every row of the tables moves each step), adam_lazy = touched rows only",
+            "points": out}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -710,7 +775,7 @@ def vae_leg(args, ctx):
     return {"value": B * K / dt, "unit": "users/s", "ms_per_step": ms,
             "workload": f"MultiVAE {U} users x {I} items (ML-20M shape, BASELINE configs[2]), hidden {H}, latent {L}, batch {B}, "
                         f"{int(csr.nnz)} interactions ({nnz_row:.0f}/user), Adam, anneal schedule of multi_vae.py:105-108",
-            "loss_mean": loss / (2 * K + W),
+            "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             "roofline": {"kernel": gname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
                          "flops_per_step_gemm": gemm_flops, "gemm_ms_per_step": gms,
@@ -760,7 +825,7 @@ def neumf_leg(args, ctx):
             "workload": f"NeuMF d={F} (GMF + MLP {units}), {U} users x {I} items = the per-GPU shape of BASELINE configs[3] (10M x 1M over "
                         f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: dense over "
                         f"the four embedding tables)",
-            "loss_mean": loss / (2 * K + W),
+            "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
                          "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,
@@ -769,8 +834,81 @@ def neumf_leg(args, ctx):
                          "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# plugin level: external.BPRMF_batch through RecMixin.train() + evaluate() at the headline shape
+# ---------------------------------------------------------------------------------------------------------------------
+def plugin_e2e_leg(args, ctx, data):
+    """One epoch of `external.BPRMF_batch` driven exactly as ModelCoordinator.single drives a model (model_coordinator.py:62-65:
+    cls(data=, config=, params=) -> train()), loaded the way elliot/run.py:67-75 loads an external model: RecMixin.train() =
+    the sampler's `transactions` triplets in batches of `batch_size` through the model's train_step / train_epoch, then
+    RecMixin.evaluate() = top-k of EVERY user under the train mask + nDCG / Recall on the device (recommender_utils_mixin.py:
+    29-61).  The data set is the headline leg's interactions split 80/20 per interaction (every user keeps a train item).
+    Timed: the constructor (tables drawn on the device, masks and sampler records shipped), train() -- of which evaluate() is
+    timed inside."""
+    import importlib.util
+    import tempfile
+    from types import SimpleNamespace
+    from elliot_amd.dataset.dataset import DataSet, default_config
+    path = os.path.join(REPO, "elliot_amd", "external", "__init__.py")
+    spec = importlib.util.spec_from_file_location("external", path, submodule_search_locations=[os.path.dirname(path)])
+    external = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = external
+    spec.loader.exec_module(external)
+    cls = getattr(sys.modules["external"], "BPRMF_batch")
+    U, I, F = args.users, args.items, args.factors
+    t_data = time.perf_counter()
+    indptr, indices = data["indptr"].cpu().numpy(), data["indices"].cpu().numpy()
+    users = np.repeat(np.arange(U, dtype=np.int64), np.diff(indptr))
+    rs = np.random.RandomState(7)
+    held = rs.random_sample(indices.shape[0]) < 0.2
+    held[indptr[:-1]] = False                                         # every user keeps at least one train interaction
+    ones = np.ones(indices.shape[0], dtype=np.float32)
+    out = tempfile.mkdtemp(prefix="el_bench_")
+    cfg = default_config(top_k=args.k, cutoffs=[args.k], simple_metrics=["nDCG", "Recall"], out_dir=out)
+    for pth in (cfg.path_output_rec_result, cfg.path_output_rec_weight):
+        os.makedirs(pth, exist_ok=True)
+    tr = ~held
+    ds = DataSet(cfg, (users[tr], indices[tr].astype(np.int64), ones[tr]), (users[held], indices[held].astype(np.int64), ones[held]),
+                 public_users=np.arange(U, dtype=np.int64), public_items=np.arange(I, dtype=np.int64))
+    t_data = time.perf_counter() - t_data
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False, save_weights=False), epochs=1, seed=42,
+                             factors=F, lr=0.001, l_w=0.1, l_b=0.001, batch_size=args.batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = cls(data=ds, config=cfg, params=params)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+    spent = {"eval": 0.0}
+    ev = m.evaluate
+
+    def timed_eval(*a, **k):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ev(*a, **k)
+        torch.cuda.synchronize()
+        spent["eval"] += time.perf_counter() - t
+    m.evaluate = timed_eval
+    t0 = time.perf_counter()
+    m.train()
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0 - spent["eval"]
+    res = m.get_results()[args.k]["test_results"]
+    del sys.modules["external"]
+    steps = -(-ds.transactions // args.batch)
+    return {"what": f"external.BPRMF_batch (elliot/run.py:67-75 loading) -> RecMixin.train(): 1 epoch = {ds.transactions} triplets in "
+                    f"{steps} steps of batch_size {args.batch} + evaluate(): top-{args.k} of all {U} users under the train mask, "
+                    f"nDCG / Recall on the device against {int(held.sum())} held-out interactions",
+            "train_epoch_s": t_train, "train_pairs_per_s": ds.transactions / t_train, "evaluate_s": spent["eval"],
+            "evaluate_users_per_s": U / spent["eval"] if spent["eval"] > 0 else None,
+            "constructor_s": t_init, "dataset_build_host_s": t_data,
+            "constructor_note": "tables drawn in HBM (GlorotUniform distribution), train CSR / sampler records shipped once",
+            "nDCG": res.get("nDCG"), "Recall": res.get("Recall")}
+
+
 def main():
+    global REPEATS
     args = parse()
+    REPEATS = max(1, args.repeats)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args))
     world, rank, local, backend = dist_setup(args)
@@ -786,7 +924,8 @@ def main():
     torch.cuda.set_device(dev)
     U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
     sharded = world > 1 or args.force_sharded
-    legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else ["bpr", "metrics", "c4", "vae", "neumf"])
+    legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else
+                                                            ["bpr", "metrics", "sweep", "plugin", "c4", "c5", "vae", "neumf"])
 
     # ---------------- synthetic inputs, resident in HBM -------------------------------------------
     indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
@@ -802,9 +941,16 @@ def main():
     if "item_shard" in legs and sharded and args.shard == "user":
         torch.cuda.empty_cache()
         second = bpr_leg(args, ctx, world, rank, data, "item", args.topk_shard or "item")
+    sweep = plugin = None
+    if world == 1 and not args.force_sharded:
+        if "sweep" in legs:
+            sweep = sweep_leg(args, ctx, data)
+        if "plugin" in legs:
+            plugin = plugin_e2e_leg(args, ctx, data)
+            torch.cuda.empty_cache()
     del data, indptr, indices
     torch.cuda.empty_cache()
-    vae = neumf = c4 = None
+    vae = neumf = c4 = c5 = None
     if world == 1 and not args.force_sharded:
         if "c4" in legs:
             # north_star's target shape (BASELINE configs[3] sizes: 10 M users x 1 M items, d = 128) resident on ONE GPU: the same
@@ -816,6 +962,20 @@ def main():
             c4 = bpr_leg(a4, ctx, world, rank, d4, "user", "user")
             c4["workload"] = f"BPRMF d={F}, synthetic {a4.users} users x {a4.items} items on one GPU (north_star target shape)"
             del d4, ip4, ix4
+            torch.cuda.empty_cache()
+        if "c5" in legs:
+            # BASELINE configs[4] (BPRMF d=256, 50 M users x 5 M items on 8 GPUs) at its PER-GPU shape under user sharding: the rank's
+            # 6.25 M user rows + a replica of the 5 M-item table (~ 50 GB of tables and optimiser state); fewer steps per repeat --
+            # a top-k block against 5 M items takes ~0.35 s
+            a5 = argparse.Namespace(**vars(args))
+            a5.users, a5.items, a5.factors = (int(x) for x in args.c5_shape.split(","))
+            a5.steps, a5.warmup = max(2, min(args.steps, 5)), min(args.warmup, 2)
+            ip5, ix5 = zipf_csr_device(a5.users, a5.items, dev, mean_log=3.0, sigma_log=1.0, dmin=5, dmax=2000, seed=5432)
+            d5 = {"indptr": ip5, "indices": ix5, "pos": ops.DeviceCSR.from_tensors(ip5, ix5, a5.items)}
+            c5 = bpr_leg(a5, ctx, world, rank, d5, "user", "user")
+            c5["workload"] = (f"BPRMF d={a5.factors}, synthetic {a5.users} users x {a5.items} items = the per-GPU shape of BASELINE configs[4] "
+                              f"(50M x 5M x 256 over 8 GPUs) under user sharding; {a5.steps} steps per repeat")
+            del d5, ip5, ix5
             torch.cuda.empty_cache()
         if "vae" in legs:
             vae = vae_leg(args, ctx)
@@ -830,7 +990,8 @@ def main():
     line = {
         "metric": "BPR-MF positive-pairs/sec + full-catalog top-k users/sec",
         "value": main_leg["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": main_leg["ms_per_step"], "repeats_ms_per_step": main_leg["repeats_ms_per_step"], "repeats": REPEATS,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
                    else f"BPRMF d={F}, synthetic {U} users x {I} items",
@@ -849,8 +1010,15 @@ def main():
         line["item_shard"] = {kk: second[kk] for kk in ("value", "unit", "ms_per_step", "scaling", "parallelism", "loss_per_pair_last",
                                                        "roofline", "topk", "collectives") if kk in second}
     if c4 is not None:
-        line["c4_one_gpu"] = {kk: c4[kk] for kk in ("workload", "value", "unit", "ms_per_step", "interactions", "loss_per_pair_last",
+        line["c4_one_gpu"] = {kk: c4[kk] for kk in ("workload", "value", "unit", "ms_per_step", "repeats_ms_per_step", "interactions", "loss_per_pair_last",
                                                     "roofline", "topk") if kk in c4}
+    if c5 is not None:
+        line["c5_per_gpu"] = {kk: c5[kk] for kk in ("workload", "value", "unit", "ms_per_step", "repeats_ms_per_step", "interactions",
+                                                    "loss_per_pair_last", "roofline", "topk") if kk in c5}
+    if sweep is not None:
+        line["batch_sweep"] = sweep
+    if plugin is not None:
+        line["plugin_e2e"] = plugin
     if vae is not None:
         line["vae"] = vae
     if neumf is not None:

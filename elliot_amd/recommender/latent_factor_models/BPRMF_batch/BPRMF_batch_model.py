@@ -40,6 +40,15 @@ class BPRMF_batch_model:
         self._num_users, self._num_items = num_users, num_items
         if init_weights is not None:
             Gu, Gi, Bi = init_weights
+        elif (num_users + num_items) * factors * 4 >= (64 << 20) and kwargs.get("init", "auto") != "host":
+            # large tables (a 1 M x 128 user table is 512 MB): the same distribution drawn in HBM -- a host draw + H2D copy of
+            # 10^8 floats costs seconds per model instance (one per HPO trial and fold, model_coordinator.py:58-65)
+            g = torch.Generator(device=self.ctx.device)
+            g.manual_seed(int(random_seed))
+            lu, li = (6.0 / (num_users + factors)) ** 0.5, (6.0 / (num_items + factors)) ** 0.5
+            Gu = (torch.rand((num_users, factors), generator=g, device=self.ctx.device) * 2 - 1) * lu
+            Gi = (torch.rand((num_items, factors), generator=g, device=self.ctx.device) * 2 - 1) * li
+            Bi = torch.zeros(num_items, device=self.ctx.device)
         else:
             # tf.initializers.GlorotUniform (:39-42): U(-L, L), L = sqrt(6 / (rows + factors)); Bi = 0.
             # TF's seeded bit stream cannot be reproduced without TF -- the distribution is.

@@ -83,6 +83,23 @@ def test_secondary_legs_carry_their_rooflines():
         assert d[leg]["roofline"]["bound"] == "mfma" and d[leg]["roofline"]["kernel"] == "k_gemm_f32"
 
 
+def test_sweep_plugin_and_c5_legs():
+    """batch_sweep (B x optimiser grid through el_bprmf_train_loop), plugin_e2e (external.BPRMF_batch through RecMixin.train() +
+    evaluate()), c5_per_gpu (BASELINE configs[4] per-GPU shape; here small, d = 256) -- every leg reports its repeats."""
+    d = run_bench("--legs", "bpr,sweep,plugin,c5", "--no-cpu-baseline", "--c5-shape", "200000,30000,256", "--repeats", "2")
+    check_common(d)
+    assert d["repeats"] == 2 and len(d["repeats_ms_per_step"]) == 2 and min(d["repeats_ms_per_step"]) <= d["ms_per_step"] <= max(d["repeats_ms_per_step"])
+    pts = d["batch_sweep"]["points"]
+    assert {(p["optimizer"], p["batch"]) for p in pts} == {(o, b) for o in ("adam_tf_dense", "adam_lazy") for b in (4096, 65536, 1 << 20)}
+    assert all(p["value"] > 0 and p["unit"] == "pairs/s" and len(p["repeats_ms_per_step"]) == 2 for p in pts)
+    pl = d["plugin_e2e"]
+    assert pl["train_epoch_s"] > 0 and pl["evaluate_s"] > 0 and pl["train_pairs_per_s"] > 0 and 0 <= pl["nDCG"] <= 1 and 0 <= pl["Recall"] <= 1
+    c5 = d["c5_per_gpu"]
+    assert c5["value"] > 0 and c5["topk"]["value"] > 0 and "200000 users x 30000 items" in c5["workload"] and "d=256" in c5["workload"]
+    for r in (c5["roofline"], c5["topk"]["roofline"]):
+        check_roofline(r)
+
+
 def test_one_rank_sharded_path_prints_the_same_contract():
     d = run_bench("--force-sharded", "--no-cpu-baseline")
     check_common(d)
