@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget of each cpu_baseline measurement")
     ap.add_argument("--vae-shape", default="138493,26744,600,200,512", help="users,items,hidden,latent,batch of the vae leg")
     ap.add_argument("--neumf-shape", default="1250000,1000000,128,262144", help="users,items,factors,batch of the neumf leg")
+    ap.add_argument("--neumf-topk-users", type=int, default=128, help="users per full-catalogue scoring step of the neumf leg (0: skip)")
     return ap.parse_args()
 
 
@@ -816,6 +817,34 @@ def neumf_leg(args, ctx):
     dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False)
     loss = st.pop_loss()
     ms = dt / K * 1e3
+    # ---- full-catalogue scoring + top-k: el_nmf_score_topk on a block of users against the leg's whole catalogue.
+    # 20 F^2 flop per (user, item) pair after the separable first layer (2 (H1 H2 + H2 H3)): inherently ~10^4 x the work of a dot
+    # product, so the block is small and the step count its own
+    nu = int(args.neumf_topk_users)
+    tk = None
+    if nu > 0 and st.fused_supported(args.k + 2):
+        ks, ws_ = max(1, min(K, 2)), 1
+        blk = [0]
+
+        def topk_step():
+            s0 = (blk[0] * nu) % max(U - nu, 1)
+            blk[0] += 1
+            st.recommend(s0, s0 + nu, args.k, excl=pos, items_unchanged=blk[0] > 1)
+
+        dt_k, rep_k = timed(ctx, 1, topk_step, ws_, ks)
+        pair_flops = 2.0 * (units[0] * units[1] + units[1] * units[2])
+        ksec = rep_k.live.get("k_nmf_score", rep_k.get("k_nmf_score", (1, 0.0)))
+        ksec = ksec[1] / max(ksec[0], 1) * 1e-3
+        ach_k = pair_flops * nu * I / ksec / 1e12 if ksec > 0 else 0.0
+        tk = {"value": nu * ks / dt_k, "unit": "users/s", "ms_per_step": dt_k / ks * 1e3, "repeats_ms_per_step": rep_k.repeats_ms,
+              "steps": ks, "users_per_step": nu,
+              "what": f"NeuMF get_recs + get_top_k (neural_matrix_factorization_model.py:119-148) of {nu} users x {I} items, k={args.k}: "
+                      f"el_nmf_score_topk (layer 1 separable, layers 2-3 + head per pair on fp32 MFMA, selection fused) + sigmoid link "
+                      f"+ re-rank; the reference's route materialises {nu} x {I} x {4 * F} activations",
+              "roofline": {"kernel": "k_nmf_score", "bound": "mfma", "achieved": ach_k, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach_k / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
+                           "flops_per_pair": pair_flops, "flops_per_pair_reference_form": 2.0 * (2 * F * units[0] + units[0] * units[1] + units[1] * units[2]),
+                           "kernels_ms_per_step": {n: v[1] / ks for n, v in rep_k.items()}}}
     mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # fwd 36 F^2 + 4 F per sample, x3 fwd + bwd
     gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / K
     ach = mlp_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
@@ -826,6 +855,7 @@ def neumf_leg(args, ctx):
                         f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: dense over "
                         f"the four embedding tables)",
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
+            **({"topk": tk} if tk is not None else {}),
             "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
                          "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,

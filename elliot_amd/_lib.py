@@ -172,6 +172,11 @@ PROTOTYPES = {
     "el_nmf_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_int32, C.c_float]),
     "el_nmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), _i32p, _i32p, _f32p, C.c_int64,
                                     C.c_int32, C.c_float, _f64p]),
+    "el_nmf_score_supported": (C.c_int, [C.POINTER(NmfState), C.c_int32]),
+    "el_nmf_score_ws_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(NmfState), C.c_int64, C.c_int64, C.c_int32, C.c_int]),
+    "el_nmf_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                    _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, C.c_size_t]),
+    "el_gmf_item_image": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int32, _f32p]),
     "el_bprmf_train_loop_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "el_bprmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i64p, _i32p, C.c_uint64, C.c_uint64,
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,

@@ -36,6 +36,12 @@ struct el_ctx {
     const float* prep_Bi = nullptr;
     int64_t prep_I = 0;
     int prep_F = 0;
+    // el_nmf_score_topk: what the PI image (item-side layer-1 projection) in the last workspace was derived from
+    const void* nmf_ws = nullptr;
+    const float* nmf_Imlp = nullptr;
+    const float* nmf_W1 = nullptr;
+    int64_t nmf_I = 0;
+    int nmf_E = 0, nmf_H1 = 0;
     // el_bprmf_train_loop: the captured small-batch step sequence (hipGraphExec_t) and the launch parameters it was built for
     void* loop_graph_exec = nullptr;
     std::vector<unsigned char> loop_graph_key;

@@ -906,20 +906,8 @@ class NmfDeviceState:
         self.hb = f(weights["hb"]) if self.head_bias else None
         self.ghw, self.mhw, self.vhw = z(self.hw), z(self.hw), z(self.hw)
         self.ghb, self.mhb, self.vhb = z(self.hb), z(self.hb), z(self.hb)
-        B = self.Bmax = int(max_batch)
-        zz = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        self.X0 = zz(B, 2 * self.E) if self.use_mlp else None
-        self.dX0 = zz(B, 2 * self.E) if self.use_mlp else None
-        self.MF = zz(B, self.F) if self.use_mf else None
-        self.dlogit = zz(B)
-        self.act = [zz(B, n) for n in self.units]
-        self.dact = [zz(B, n) for n in self.units]
-        dims = [2 * self.E] + self.units
-        need = 16
-        for l in range(len(self.units)):
-            for mnk in ((B, dims[l + 1], dims[l]), (dims[l], dims[l + 1], B), (B, dims[l], dims[l + 1])):
-                need = max(need, int(ctx.lib.el_gemm_ws_bytes(ctx.handle, *mnk)))
-        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        B = int(max_batch)
+        self._alloc_activations(B)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.step = 0
         p = lambda t: None if t is None else t.data_ptr()
@@ -936,6 +924,40 @@ class NmfDeviceState:
             act=a4(self.act), dact=a4(self.dact), ws=self._ws.data_ptr(), ws_bytes=self._ws.numel(),
             dropout=self.dropout, drop_step=0, drop_seed=self.dropout_seed & 0xFFFFFFFFFFFFFFFF)
         self._drop_calls = 0
+
+    def _alloc_activations(self, B):
+        """Activation / backward buffers for batches of up to B samples (+ the GEMM workspace sized for them)."""
+        ctx, dev = self.ctx, self.ctx.device
+        self.Bmax = B = int(B)
+        zz = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.X0 = zz(B, 2 * self.E) if self.use_mlp else None
+        self.dX0 = zz(B, 2 * self.E) if self.use_mlp else None
+        self.MF = zz(B, self.F) if self.use_mf else None
+        self.dlogit = zz(B)
+        self.act = [zz(B, n) for n in self.units]
+        self.dact = [zz(B, n) for n in self.units]
+        dims = [2 * self.E] + self.units
+        need = 16
+        for l in range(len(self.units)):
+            for mnk in ((B, dims[l + 1], dims[l]), (dims[l], dims[l + 1], B), (B, dims[l], dims[l + 1])):
+                need = max(need, int(ctx.lib.el_gemm_ws_bytes(ctx.handle, *mnk)))
+        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def ensure_batch(self, n):
+        """Grow the activation buffers to hold a batch of n samples: the reference takes ONE optimiser step per batch
+        (neural_matrix_factorization_model.py:96-106), whatever its size.  Raises (torch's out-of-memory error) when HBM cannot
+        hold the activations -- never splits the batch into several steps behind the caller's back."""
+        if n <= self.Bmax:
+            return
+        self.X0 = self.dX0 = self.MF = self.dlogit = self._ws = None
+        self.act, self.dact = [], []
+        torch.cuda.empty_cache()
+        self._alloc_activations(n)
+        p = lambda t: None if t is None else t.data_ptr()
+        a4 = lambda ts: _lib._P4(*([p(t) for t in ts] + [None] * (4 - len(ts))))
+        c = self._c
+        c.Bmax, c.X0, c.dX0, c.MF, c.dlogit = self.Bmax, p(self.X0), p(self.dX0), p(self.MF), p(self.dlogit)
+        c.act, c.dact, c.ws, c.ws_bytes = a4(self.act), a4(self.dact), self._ws.data_ptr(), self._ws.numel()
 
     def _next_mask(self):
         self._drop_calls += 1                                        # a fresh dropout mask per gradient evaluation
@@ -956,6 +978,7 @@ class NmfDeviceState:
 
     def train_step(self, u, i, label, lr):
         self.step += 1
+        self._margin = _PW_MARGIN
         self._next_mask()
         n = u.numel()
         check(self.ctx.lib.el_nmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
@@ -974,6 +997,7 @@ class NmfDeviceState:
 
     def apply(self, lr):
         self.step += 1
+        self._margin = _PW_MARGIN
         check(self.ctx.lib.el_nmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self.step),
                                         float(adam_lr_t(lr, self.step))), "el_nmf_apply")
 
@@ -1000,6 +1024,95 @@ class NmfDeviceState:
         self.loss.zero_()
         return v
 
+    # -- full-catalogue scoring -> masked top-k --------------------------------------------------------------------
+    def fused_supported(self, k):
+        """True when el_nmf_score_topk takes this network and list length (three Dense layers, units <= (1024, 256, 128), ...)."""
+        return bool(self.use_mlp and self.ctx.lib.el_nmf_score_supported(C.byref(self._c), int(k)))
+
+    def score_topk_logits(self, u_start, u_stop, k, excl=None, cand=None, item_offset=0, I_local=None, items_unchanged=False):
+        """el_nmf_score_topk: the k best unmasked items of users [u_start, u_stop) by (logit desc, item asc) and their logits --
+        layer 1 in its separable form, layers 2-3 and the head per (user, item) pair on fp32 MFMA tiles, selection fused."""
+        n = int(u_stop) - int(u_start)
+        I_local = self.I - int(item_offset) if I_local is None else int(I_local)
+        need = int(self.ctx.lib.el_nmf_score_ws_bytes(self.ctx.handle, C.byref(self._c), n, I_local, int(k), 1 if cand is not None else 0))
+        if need == 0:
+            raise _lib.ElliotHipError("el_nmf_score_topk does not take this network shape / k (NmfDeviceState.fused_supported)")
+        ws = getattr(self, "_score_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._score_ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+            items_unchanged = False
+        out_idx = torch.empty((n, k), dtype=torch.int32, device=self.ctx.device)
+        out_val = torch.empty((n, k), dtype=torch.float32, device=self.ctx.device)
+        ep, ei = _csr_ptrs(excl)
+        cp, ci = _csr_ptrs(cand)
+        check(self.ctx.lib.el_nmf_score_topk(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(u_start), int(u_stop),
+                                             int(item_offset), I_local, ep, ei, cp, ci, int(k), _ptr(out_idx), _ptr(out_val),
+                                             _lib.EL_TOPK_ITEMS_UNCHANGED if items_unchanged else 0, C.c_void_p(ws.data_ptr()),
+                                             ws.numel()), "el_nmf_score_topk")
+        return out_idx, out_val
+
+    def _dot_tables(self, items_unchanged):
+        """The MF-only network (GMF; NeuMF with is_mlp_train False) is sigmoid(<Umf[u], Imf[i] * h> (+ b)): tables for the fused
+        dot-product top-k kernels -- the item image Imf * h (el_gmf_item_image) and a constant bias row for the Dense(1) bias."""
+        img = getattr(self, "_gmf_image", None)
+        if img is None or not items_unchanged:
+            if img is None:
+                img = self._gmf_image = (torch.empty_like(self.tab[1]),
+                                         torch.empty(self.I, dtype=torch.float32, device=self.ctx.device) if self.head_bias else None)
+            check(self.ctx.lib.el_gmf_item_image(self.ctx.handle, self.ctx.stream(), _ptr(self.tab[1], torch.float32),
+                                                 _ptr(self.hw, torch.float32), int(self.I), int(self.F), _ptr(img[0], torch.float32)),
+                  "el_gmf_item_image")
+            if self.head_bias:
+                img[1].copy_(self.hb.expand(self.I))
+        return img
+
+    def _pairs_topk(self, u_start, u_stop, k, excl, cand):
+        """The reference's own route (index grids -> get_recs -> get_top_k, neural_matrix_factorization.py:111-119) for networks
+        the fused kernel does not take: probabilities of every (user, item) pair in blocks of Bmax pairs, dense top-k."""
+        nu, dev = int(u_stop) - int(u_start), self.ctx.device
+        items = torch.arange(self.I, dtype=torch.int32, device=dev)
+        preds = torch.empty((nu, self.I), dtype=torch.float32, device=dev)
+        per = max(1, self.Bmax // self.I)
+        for s in range(0, nu, per):
+            e = min(s + per, nu)
+            ug = torch.arange(u_start + s, u_start + e, dtype=torch.int32, device=dev).repeat_interleave(self.I)
+            self.forward(ug, items.repeat(e - s), out=preds[s:e].reshape(-1))
+        return dense_topk(self.ctx, preds, u_start, u_stop, k, excl=excl, cand=cand)
+
+    def recommend(self, u_start, u_stop, k, excl=None, cand=None, items_unchanged=False):
+        """get_recs + get_top_k of NeuMF / GMF for users [u_start, u_stop): (idx int32 [n, k], probabilities fp32 [n, k]).
+        The fused kernels rank by the logit; sigmoid is monotone, so the ranking by probability can differ only where distinct
+        logits round to one probability (tf.nn.top_k orders those by item index): the list is taken a few entries longer, linked
+        (el_pwmf_link_values), re-ranked by (value desc, index asc) and cut -- the rule of PwmfDeviceState.recommend."""
+        if self.use_mlp and not self.fused_supported(min(self.I, k + _PW_MARGIN)):
+            return self._pairs_topk(u_start, u_stop, k, excl, cand)
+        max_list = _NMF_MAX_LIST if self.use_mlp else _PW_MAX_LIST
+
+        def score(kk):
+            if self.use_mlp:
+                return self.score_topk_logits(u_start, u_stop, kk, excl=excl, cand=cand, items_unchanged=items_unchanged)
+            img, brow = self._dot_tables(items_unchanged)
+            return score_topk(self.ctx, self.tab[0], img, brow, u_start, u_stop, kk, excl=excl, cand=cand, items_unchanged=items_unchanged)
+
+        kk = min(self.I, k + getattr(self, "_margin", _PW_MARGIN))
+        while True:
+            idx, val = score(kk)
+            items_unchanged = True
+            check(self.ctx.lib.el_pwmf_link_values(self.ctx.handle, self.ctx.stream(), _ptr(val, torch.float32), int(val.shape[0]),
+                                                   int(val.stride(0)), int(kk), _lib.EL_PW_MSE_SIGMOID, None, int(u_start)),
+                  "el_pwmf_link_values")
+            if kk >= self.I:
+                break
+            open_rows = (val[:, k - 1] == val[:, kk - 1]) & (val[:, k - 1] > float("-inf"))
+            if not bool(open_rows.any()):
+                break
+            if kk >= max_list:
+                return self._pairs_topk(u_start, u_stop, k, excl, cand)
+            kk = min(self.I, max_list, k + 16 if kk < k + 16 else kk * 4)
+        self._margin = kk - k
+        idx, val = topk_rerank(self.ctx, idx, val)
+        return idx[:, :k].contiguous(), val[:, :k].contiguous()
+
 
 # ------------------------------------------------------------------------------------------
 # point-wise factor models: MF, PMF, FunkSVD, LogisticMF (SURVEY 8f, N3)
@@ -1010,6 +1123,7 @@ PW_SIDES = {"both": _lib.EL_PW_BOTH, "items": _lib.EL_PW_ITEMS, "users": _lib.EL
 # entries beyond k taken before the link: two keep k' = k + 2 <= 12 on the fastest screening policy for the usual k = 10; a row
 # whose ranks k .. k' all collapse to one linked float (probability ~1e-8 per row) is redone with a 4x longer list
 _PW_MARGIN, _PW_MAX_LIST, _PW_DENSE_ROWS = 2, 4032, 4096
+_NMF_MAX_LIST = 448          # el_nmf_score_topk keeps k <= 448 candidates per wave in LDS
 _CML_MARGIN = 16             # CML re-scores with another formula: its fp32 rounding may reorder near-ties a few ranks deep
 
 

@@ -24,7 +24,7 @@ class _PointwiseModel:
         self.num_users, self.num_items, self._lr = num_users, num_items, lr
         self._dropout, self._seed = float(dropout or 0.0), seed
         self.state = ops.NmfDeviceState(self.ctx, weights, max_batch, dropout=self._dropout, dropout_seed=seed)
-        self._items = torch.arange(num_items, dtype=torch.int32, device=self.ctx.device)
+        self._weights_version, self._scored_version = 0, -1          # recommend() keeps the item-side image between blocks
 
     def _idx(self, x):
         if isinstance(x, torch.Tensor):
@@ -36,16 +36,11 @@ class _PointwiseModel:
         y = label if isinstance(label, torch.Tensor) else torch.from_numpy(np.asarray(label, dtype=np.float32))
         y = y.reshape(-1).to(device=self.ctx.device, dtype=torch.float32).contiguous()
         u, i = self._idx(user), self._idx(pos)
-        B, n = self.state.Bmax, u.numel()
-        if n > B and not getattr(self, "_warned_split", False):
-            # the reference takes ONE optimiser step per batch (neural_matrix_factorization_model.py:96-106); a batch beyond the
-            # activation buffers (the plugins size them for up to 8M samples) is processed as several consecutive steps
-            import logging
-            logging.getLogger(__name__).warning("NeuMF/GMF: batch of %d samples exceeds the %d-sample activation buffers; it is "
-                                                "split into %d optimiser steps (the reference would take one)", n, B, -(-n // B))
-            self._warned_split = True
-        for s in range(0, n, B):
-            self.state.train_step(u[s:s + B], i[s:s + B], y[s:s + B], self._lr)
+        self._weights_version += 1
+        # the reference takes ONE optimiser step per batch (neural_matrix_factorization_model.py:96-106): a batch beyond the
+        # activation buffers grows them (or fails loudly when HBM cannot hold them) -- it is never split into several steps
+        self.state.ensure_batch(u.numel())
+        self.state.train_step(u, i, y, self._lr)
         return DeferredLoss(self.state)
 
     def get_recs(self, inputs, training=False, **kwargs):
@@ -60,20 +55,16 @@ class _PointwiseModel:
         return out.reshape(shape)
 
     def recommend(self, mask, k, start, stop, item_offset=0):
-        """Score users [start, stop) against the whole catalogue (the reference builds [Ub, I] index grids,
-        neural_matrix_factorization.py:114-119) and take the masked top-k."""
-        nu, I = stop - start, self.num_items
-        users = torch.arange(start, stop, dtype=torch.int32, device=self.ctx.device)
-        preds = torch.empty((nu, I), dtype=torch.float32, device=self.ctx.device)
-        per = max(1, self.state.Bmax // I)
-        for s in range(0, nu, per):
-            e = min(s + per, nu)
-            ug = users[s:e].repeat_interleave(I)
-            ig = self._items.repeat(e - s)
-            self.state.forward(ug, ig, out=preds[s:e].reshape(-1))
+        """Users [start, stop) against the whole catalogue + masked top-k: (idx int32 [n, k], probabilities fp32 [n, k]).
+        The reference builds [Ub, I] index grids and runs the network on every pair (neural_matrix_factorization.py:111-119,
+        neural_matrix_factorization_model.py:119-144); here NeuMF goes through el_nmf_score_topk (layer 1 separable, layers 2-3
+        and the head on fp32 MFMA tiles per pair, selection fused -- no [Ub, I] block) and GMF through the fused dot-product
+        top-k kernels on the item image Imf * h (ops.NmfDeviceState.recommend)."""
         kind, csr = mask if mask is not None else (None, None)
-        return ops.dense_topk(self.ctx, preds, start, stop, k, excl=csr if kind == "excl" else None,
-                              cand=csr if kind == "cand" else None)
+        same = self._scored_version == self._weights_version          # block after block of one evaluation
+        self._scored_version = self._weights_version
+        return self.state.recommend(start, stop, k, excl=csr if kind == "excl" else None, cand=csr if kind == "cand" else None,
+                                    items_unchanged=same)
 
     def get_top_k(self, preds, train_mask, k=100):
         kind, csr = train_mask
@@ -88,6 +79,7 @@ class _PointwiseModel:
     def load_weights(self, path):
         with open(path, "rb") as f:
             self.state = ops.NmfDeviceState(self.ctx, pickle.load(f), self.state.Bmax, dropout=self._dropout, dropout_seed=self._seed)
+        self._weights_version += 1
 
 
 class NeuralMatrixFactorizationModel(_PointwiseModel):

@@ -34,8 +34,11 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 3   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
-                            * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*                     */
+#define EL_ABI_VERSION 4   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
+                            * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*
+                            * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
+                            *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
+                            *    el_nmf_score_topk, el_gmf_item_image                                                    */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -117,6 +120,8 @@ enum {
     EL_OPT_SGD = 3            /* theta -= lr * grad            (NOT the reference)     */
 };
 
+/* Every el_*_state struct must be ZERO-INITIALISED by the host (memset / = {0}) before its fields are set: optional fields
+ * (NULL = feature off) switch code paths, and fields added by a later ABI version sit at the END of a struct.            */
 typedef struct el_bprmf_state {
     float* Gu;  /* [U,F] user factors      (BPRMF_batch_model.py:41) */
     float* Gi;  /* [I,F] item factors      (BPRMF_batch_model.py:42) */
@@ -461,6 +466,36 @@ int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const i
 int el_nmf_grads(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
                  const float* label, int64_t n, int64_t n_global, double* loss_out);
 int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step, float lr_t);
+
+/* Full-catalogue scoring fused with the masked top-k for NeuMF.
+ * Replaces: NeuMF.get_recommendations' [Ub, I] index grids (neural/NeuMF/neural_matrix_factorization.py:111-119) +
+ * NeuralMatrixFactorizationModel.get_recs (neural_matrix_factorization_model.py:119-144) + get_top_k (:146-148) for users
+ * [u_start, u_stop) against the item shard [item_offset, item_offset + I_local) of the state's tables (rows of tab[1] / tab[3]):
+ *   logit(u,i) = w . [Umf[u]*Imf[i] ; MLP([Umlp[u] ; Imlp[i]])] + b       (the network of el_nmf_forward, no Dropout)
+ *   out_idx / out_val [n_users, k]: the k best unmasked items by (LOGIT desc, item asc) and their logits; mask / padding
+ *   semantics of el_score_topk.  The model's output is sigmoid(logit): apply el_pwmf_link_values(EL_PW_MSE_SIGMOID) to the
+ *   list and re-rank with el_topk_rerank where distinct logits collapse to one float (take the list a few entries longer).
+ * Layer 1 is evaluated in its separable form (W1[:E]^T u + W1[E:]^T i, two projections), layers 2-3 and the head per pair on
+ * fp32 MFMA tiles with the selection fused; nothing of size [users, I] is written.  Numerics: every dot product is the k-ordered
+ * fp32 fma chain from +0, `+ bias`, relu; layer 1 = (chain_u + chain_i) + b1; head = two interleaved chains (even / odd
+ * positions of [mf ; mlp]) summed, + b, + 0.0f (pinned by oracle/c/el_oracle.c: orc_nmf_logits).
+ * Supported: use_mlp with n_layers == 3, units <= (1024, 256, 128), units[2] <= half of units[1] rounded up to {32,64,128,256},
+ * E <= 256, F <= 256, k <= 448 (el_nmf_score_supported; anything else: el_nmf_forward on pair lists + el_dense_topk).
+ *   flags: EL_TOPK_ITEMS_UNCHANGED = the caller asserts that Imlp and W1 are what the previous call with this workspace
+ *          projected (block after block of one evaluation): the [I_local, units[0]] item projection is kept -- verified by a
+ *          device-side hash of both arrays, no host synchronisation
+ *   ws   : el_nmf_score_ws_bytes(...) bytes, 16-byte aligned (item projection I_local x units[0] x 4 bytes + per-block scratch)  */
+int el_nmf_score_supported(const el_nmf_state* st, int32_t k);
+size_t el_nmf_score_ws_bytes(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int32_t k, int with_cand);
+int el_nmf_score_topk(el_ctx* ctx, void* stream, const el_nmf_state* st, int64_t u_start, int64_t u_stop,
+                      int64_t item_offset, int64_t I_local, const int64_t* excl_indptr, const int32_t* excl_indices,
+                      const int64_t* cand_indptr, const int32_t* cand_indices, int32_t k, int32_t* out_idx, float* out_val,
+                      int flags, void* ws, size_t ws_bytes);
+
+/* GMF (generalized_matrix_factorization_model.py:59-66,81-93): score = sigmoid(sum_f h_f u_f i_f) = sigmoid(<u, i * h>).
+ * out[i, f] = Imf[i, f] * hw[f]: the item image that turns GMF's full-catalogue scoring into el_score_topk(Umf, out, NULL)
+ * (screened bf16 / exact fp32 kernels), followed by el_pwmf_link_values(EL_PW_MSE_SIGMOID) + el_topk_rerank.            */
+int el_gmf_item_image(el_ctx* ctx, void* stream, const float* Imf, const float* hw, int64_t I, int32_t F, float* out);
 
 /* ---- point-wise factor models: MF, PMF, FunkSVD, LogisticMF -----------------------------
  * One kernel family for the reference's TF models that score a (user, item) sample with a dot product of two

@@ -183,3 +183,73 @@ void orc_score_topk_f64(const double* P, const double* Q, const double* b, int64
     }
     free(blk);
 }
+
+/*
+ * NeuMF full-catalogue logits (neural/NeuMF/neural_matrix_factorization_model.py:75-93 `call`, :119-144 `get_recs`):
+ *   mf   = Umf[u] * Imf[i];  mlp = relu-Dense chain on concat(Umlp[u], Imlp[i]) (3 layers);  logit = w . [mf ; mlp] + b
+ * (the model's output is sigmoid(logit); the ranking is taken on the logit, the link is applied to the survivors).
+ * Pinned summation order (= what elliot_amd/csrc/el_nmf_score.hip computes; TF's own order inside tf.matmul is unknowable
+ * without TF -- "parity unpinned" for the order, checked against fp64 maths in tests/test_oracle_neumf.py):
+ *   layer 1   pu[k] = fmaf chain over e of Umlp[u][e] W1[e][k],  pi[k] = chain over e of Imlp[i][e] W1[E+e][k]  (both from +0),
+ *             a1[k] = max((pu[k] + pi[k]) + b1[k], 0)                              (Dense on a concat, evaluated separably)
+ *   layer l   a[m]  = max(chain over k of W[k][m] a_prev[k] (from +0) + b[m], 0)
+ *   head      two interleaved chains over the positions p of x = [mf ; a3]: acc_(p & 1) = fmaf(w[p], x[p], acc_(p & 1)),
+ *             p ascending, mf[f] = Umf[u][f] * Imf[i][f] rounded to fp32 first; note the parity is that of f inside mf and of
+ *             the feature index inside a3 (F even in every configuration of the reference; the kernel pairs the same way)
+ *             logit = ((acc_0 + acc_1) + b) + 0.0f
+ * out[(r * n_items) + (i - i0)] for users[r], items [i0, i1).
+ */
+static void dense_chain(const float* W, const float* a, int K, int N, float* acc) {
+    for (int n = 0; n < N; ++n) acc[n] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float ak = a[k];
+        const float* w = W + (int64_t)k * N;
+        for (int n = 0; n < N; ++n) acc[n] = fmaf(w[n], ak, acc[n]);
+    }
+}
+
+void orc_nmf_logits(const float* Umf, const float* Imf, const float* Umlp, const float* Imlp, int32_t F, int32_t E,
+                    const float* W1, const float* b1, int32_t H1, const float* W2, const float* b2, int32_t H2,
+                    const float* W3, const float* b3, int32_t H3, const float* hw, const float* hb,
+                    const int64_t* users, int64_t n_users, int64_t i0, int64_t i1, float* out) {
+    const int64_t nI = i1 - i0;
+    for (int64_t r = 0; r < n_users; ++r) {
+        const int64_t u = users[r];
+        float* pu = (float*)malloc(sizeof(float) * (size_t)H1);
+        dense_chain(W1, Umlp + u * E, E, H1, pu);
+#pragma omp parallel
+        {
+            float* pi = (float*)malloc(sizeof(float) * (size_t)H1);
+            float* a1 = (float*)malloc(sizeof(float) * (size_t)H1);
+            float* a2 = (float*)malloc(sizeof(float) * (size_t)H2);
+            float* a3 = (float*)malloc(sizeof(float) * (size_t)H3);
+#pragma omp for schedule(static)
+            for (int64_t i = i0; i < i1; ++i) {
+                dense_chain(W1 + (int64_t)E * H1, Imlp + i * E, E, H1, pi);
+                for (int k = 0; k < H1; ++k) {
+                    const float t = (pu[k] + pi[k]) + b1[k];
+                    a1[k] = t > 0.0f ? t : 0.0f;
+                }
+                dense_chain(W2, a1, H1, H2, a2);
+                for (int m = 0; m < H2; ++m) {
+                    const float t = a2[m] + b2[m];
+                    a2[m] = t > 0.0f ? t : 0.0f;
+                }
+                dense_chain(W3, a2, H2, H3, a3);
+                for (int m = 0; m < H3; ++m) {
+                    const float t = a3[m] + b3[m];
+                    a3[m] = t > 0.0f ? t : 0.0f;
+                }
+                float acc[2] = {0.0f, 0.0f};
+                for (int f = 0; f < F; ++f) {
+                    const float term = Umf[u * F + f] * Imf[i * F + f];
+                    acc[f & 1] = fmaf(hw[f], term, acc[f & 1]);
+                }
+                for (int m = 0; m < H3; ++m) acc[m & 1] = fmaf(hw[F + m], a3[m], acc[m & 1]);
+                out[r * nI + (i - i0)] = ((acc[0] + acc[1]) + (hb ? hb[0] : 0.0f)) + 0.0f;
+            }
+            free(pi); free(a1); free(a2); free(a3);
+        }
+        free(pu);
+    }
+}

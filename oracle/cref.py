@@ -99,3 +99,28 @@ def topk_rows_f32(scores, u_start, k, excl=None, cand=None, item_offset=0):
     lib.orc_topk_rows_f32(_p(scores), C.c_int64(I), C.c_int64(u_start), C.c_int64(n), C.c_int64(item_offset),
                           C.c_int64(I), e[2], e[3], c[2], c[3], C.c_int32(k), _p(oi), _p(ov))
     return oi, ov
+
+
+def nmf_logits(w, users, i0=0, i1=None):
+    """NeuMF logits of `users` x items [i0, i1) with the pinned summation order (orc_nmf_logits); w: the weight dict of
+    oracle/neumf.py (Umf, Imf, Umlp, Imlp, W[3], b[3], hw, optional hb).  Returns float32 [len(users), i1 - i0]."""
+    lib = load()
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    Umlp, Imlp = f(w["Umlp"]), f(w["Imlp"])
+    has_mf = "Umf" in w
+    Umf, Imf = (f(w["Umf"]), f(w["Imf"])) if has_mf else (np.zeros((1, 1), np.float32), np.zeros((1, 1), np.float32))
+    F = Umf.shape[1] if has_mf else 0
+    E = Umlp.shape[1]
+    W = [f(x) for x in w["W"]]
+    b = [f(x) for x in w["b"]]
+    assert len(W) == 3
+    hw = f(w["hw"])
+    hb = f(w["hb"]) if "hb" in w else None
+    users = np.ascontiguousarray(users, np.int64)
+    if i1 is None:
+        i1 = Imlp.shape[0]
+    out = np.empty((users.shape[0], i1 - i0), np.float32)
+    lib.orc_nmf_logits(_p(Umf), _p(Imf), _p(Umlp), _p(Imlp), C.c_int32(F), C.c_int32(E), _p(W[0]), _p(b[0]), C.c_int32(W[0].shape[1]),
+                       _p(W[1]), _p(b[1]), C.c_int32(W[1].shape[1]), _p(W[2]), _p(b[2]), C.c_int32(W[2].shape[1]), _p(hw), _p(hb),
+                       _p(users), C.c_int64(users.shape[0]), C.c_int64(i0), C.c_int64(i1), _p(out))
+    return out

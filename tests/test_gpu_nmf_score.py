@@ -1,0 +1,220 @@
+"""GPU parity of the fused NeuMF / GMF full-catalogue scoring (el_nmf_score_topk, el_gmf_item_image) against the
+C oracle's pinned-order logits (oracle/c/el_oracle.c: orc_nmf_logits) + its masked top-k: index lists AND logit bits, at toy
+shapes (every padding / mask / candidate-list edge) and at d = 128 against a 100 000-item catalogue."""
+import numpy as np
+import pytest
+import torch
+
+from elliot_amd import ops
+from oracle import cref
+from oracle import neumf as on
+from tests.gpu_util import assert_topk_equal, cpu, random_excl
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(U, I, F, seed, units=None, scale=4.0):
+    """GlorotUniform draws are tiny at these sizes (logits ~ 1e-3, everything ties after the sigmoid): scaled up, with biases."""
+    w = on.init_neumf(U, I, F, seed, units=units)
+    rs = np.random.RandomState(seed + 100)
+    for k in ("Umf", "Imf", "Umlp", "Imlp"):
+        w[k] = (w[k] * scale).astype(np.float32)
+    w["W"] = [(x * 1.5).astype(np.float32) for x in w["W"]]
+    w["b"] = [rs.normal(scale=0.05, size=b.shape).astype(np.float32) for b in w["b"]]
+    w["hb"] = np.array([0.07], np.float32)
+    return w
+
+
+def _oracle_topk(w, u0, u1, k, excl=None, cand=None, i0=0, i1=None):
+    L = cref.nmf_logits(w, np.arange(u0, u1), i0, i1)
+    ex = None if excl is None else (excl[0], excl[1])
+    ca = None if cand is None else (cand[0], cand[1])
+    # orc_topk_rows_f32 indexes CSR rows by ABSOLUTE user id
+    return cref.topk_rows_f32(L, u0, k, excl=ex, cand=ca, item_offset=i0)
+
+
+@pytest.mark.parametrize("F,units,k", [(32, None, 10), (16, None, 7), (8, [40, 24, 12], 5), (64, None, 20), (12, [48, 20, 10], 12),
+                                       (9, [36, 18, 9], 10)])
+def test_nmf_score_topk_matches_oracle_bit_for_bit(ctx, F, units, k):
+    U, I = 70, 2500
+    w = _weights(U, I, F, seed=F, units=units)
+    st = ops.NmfDeviceState(ctx, w, max_batch=1024)
+    assert st.fused_supported(k)
+    rs = np.random.RandomState(1)
+    ip, ix = random_excl(rs, U, I, 0, 40)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    for u0, u1 in ((0, U), (13, 41)):
+        idx, val = st.score_topk_logits(u0, u1, k, excl=excl)
+        ei, ev = _oracle_topk(w, u0, u1, k, excl=(ip, ix))
+        assert_topk_equal(f"nmf_score_F{F}_k{k}", cpu(idx), cpu(val), ei, ev)
+    # no mask at all
+    idx, val = st.score_topk_logits(0, 9, k)
+    ei, ev = _oracle_topk(w, 0, 9, k)
+    assert_topk_equal(f"nmf_score_nomask_F{F}", cpu(idx), cpu(val), ei, ev)
+
+
+def test_nmf_score_branches_mlp_only_and_no_head_bias(ctx):
+    U, I, F, k = 40, 1800, 16, 10
+    w = _weights(U, I, F, seed=5)
+    mlp_only = {kk: v for kk, v in w.items() if kk not in ("Umf", "Imf")}
+    mlp_only["hw"] = w["hw"][F:].copy()
+    st = ops.NmfDeviceState(ctx, mlp_only, max_batch=512)
+    idx, val = st.score_topk_logits(0, U, k)
+    ei, ev = _oracle_topk(mlp_only, 0, U, k)
+    assert_topk_equal("nmf_score_mlp_only", cpu(idx), cpu(val), ei, ev)
+    nob = {kk: v for kk, v in w.items() if kk != "hb"}
+    st = ops.NmfDeviceState(ctx, nob, max_batch=512)
+    idx, val = st.score_topk_logits(0, U, k)
+    ei, ev = _oracle_topk(nob, 0, U, k)
+    assert_topk_equal("nmf_score_no_hb", cpu(idx), cpu(val), ei, ev)
+
+
+def test_nmf_score_short_lists_candidates_and_item_shards(ctx):
+    U, I, F, k = 30, 700, 16, 10
+    w = _weights(U, I, F, seed=11)
+    st = ops.NmfDeviceState(ctx, w, max_batch=512)
+    rs = np.random.RandomState(2)
+    # users whose train rows cover almost the whole catalogue: fewer than k unmasked items -> -inf padding with the lowest masked ids
+    rows = [np.sort(rs.choice(I, I - rs.randint(0, 2 * k), replace=False)) if u % 3 == 0 else np.sort(rs.choice(I, 5, replace=False))
+            for u in range(U)]
+    ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    ix = np.concatenate(rows).astype(np.int32)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    idx, val = st.score_topk_logits(0, U, k, excl=excl)
+    ei, ev = _oracle_topk(w, 0, U, k, excl=(ip, ix))
+    assert_topk_equal("nmf_score_short", cpu(idx), cpu(val), ei, ev)
+    # candidate protocol (negative sampling: mask = in the candidate row), incl. rows with fewer than k candidates and an empty one
+    crow = [np.sort(rs.choice(I, rs.randint(0, 4) if u % 5 == 0 else rs.randint(20, 120), replace=False)) for u in range(U)]
+    crow[3] = np.zeros(0, np.int64)
+    cp = np.concatenate([[0], np.cumsum([len(r) for r in crow])]).astype(np.int64)
+    cx = np.concatenate(crow).astype(np.int32)
+    cand = ops.DeviceCSR(cp, cx, I, ctx.device)
+    idx, val = st.score_topk_logits(0, U, k, cand=cand)
+    ei, ev = _oracle_topk(w, 0, U, k, cand=(cp, cx))
+    assert_topk_equal("nmf_score_cand", cpu(idx), cpu(val), ei, ev)
+    # item shards (global ids through item_offset) + merge == one shard
+    parts_i, parts_v = [], []
+    for lo, hi in ((0, 260), (260, I)):
+        pi, pv = st.score_topk_logits(0, U, k, excl=excl, item_offset=lo, I_local=hi - lo)
+        e2i, e2v = _oracle_topk(w, 0, U, k, excl=(ip, ix), i0=lo, i1=hi)
+        assert_topk_equal(f"nmf_score_shard_{lo}", cpu(pi), cpu(pv), e2i, e2v)
+        parts_i.append(pi)
+        parts_v.append(pv)
+    mi, mv = ops.topk_merge(ctx, torch.stack(parts_i), torch.stack(parts_v))
+    fi, fv = _oracle_topk(w, 0, U, k, excl=(ip, ix))
+    assert_topk_equal("nmf_score_merged", cpu(mi), cpu(mv), fi, fv)
+
+
+def test_nmf_score_large_k_and_item_image_reuse(ctx):
+    U, I, F = 24, 5000, 32
+    w = _weights(U, I, F, seed=21)
+    st = ops.NmfDeviceState(ctx, w, max_batch=512)
+    for k in (100, 300):
+        idx, val = st.score_topk_logits(0, U, k)
+        ei, ev = _oracle_topk(w, 0, U, k)
+        assert_topk_equal(f"nmf_score_k{k}", cpu(idx), cpu(val), ei, ev)
+    # EL_TOPK_ITEMS_UNCHANGED is verified on the device: the same call with the flag gives the same lists; after an in-place
+    # update of the item MLP table (same address) the kept projection would be stale -- the hash notices and it is rebuilt
+    i1, v1 = st.score_topk_logits(0, U, 10)
+    i2, v2 = st.score_topk_logits(0, U, 10, items_unchanged=True)
+    assert torch.equal(i1, i2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32))
+    st.tab[3].mul_(-1.0)
+    w2 = dict(w)
+    w2["Imlp"] = -w["Imlp"]
+    i3, v3 = st.score_topk_logits(0, U, 10, items_unchanged=True)
+    ei, ev = _oracle_topk(w2, 0, U, 10)
+    assert_topk_equal("nmf_score_after_inplace_update", cpu(i3), cpu(v3), ei, ev)
+
+
+def test_nmf_score_d128_against_100k_items(ctx):
+    """BASELINE configs[3] model (d = 128, tower 512-256-128) against a 100 000-item catalogue: a handful of users bit-exact against
+    the oracle's pinned chain (1.6e10 fma per user on the host), 64 more against the device's own pair scoring (el_nmf_forward:
+    another summation order, so values to 2e-6 and the sets compared where the k / k+1 gap exceeds that)."""
+    U, I, F, k = 80, 100_000, 128, 10
+    w = _weights(U, I, F, seed=7, scale=12.0)
+    st = ops.NmfDeviceState(ctx, w, max_batch=1 << 20)
+    rs = np.random.RandomState(3)
+    ip, ix = random_excl(rs, U, I, 5, 60)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    idx, val = st.score_topk_logits(0, U, k + 1, excl=excl)
+    n = 3
+    ei, ev = _oracle_topk(w, 0, n, k + 1, excl=(ip, ix))
+    assert_topk_equal("nmf_score_d128", cpu(idx[:n]), cpu(val[:n]), ei, ev)
+    # pair scoring of the listed items: probabilities of el_nmf_forward == sigmoid(fused logits) to fp32 round-off
+    users = torch.arange(U, dtype=torch.int32, device=ctx.device).repeat_interleave(k + 1)
+    p_pairs = st.forward(users, idx.reshape(-1).contiguous()).reshape(U, k + 1)
+    p_fused = torch.sigmoid(val.double()).float()
+    assert float((p_pairs - p_fused).abs().max()) < 2e-6
+    # ordering, range, exclusions
+    v = cpu(val)
+    assert (v[:, :-1] >= v[:, 1:]).all()
+    got = cpu(idx)
+    assert got.min() >= 0 and got.max() < I
+    for u in range(U):
+        assert not set(got[u].tolist()) & set(ix[ip[u]:ip[u + 1]].tolist())
+
+
+def test_recommend_links_and_reranks_like_topk_on_probabilities(ctx):
+    """NmfDeviceState.recommend = get_recs + get_top_k of the reference: sigmoid of the logits, ties of the PROBABILITY broken by
+    item index.  Checked against the device's own probabilities of every pair (el_nmf_forward + el_dense_topk, the reference's
+    route) on weights whose logits are large enough to collapse after the sigmoid (saturation: p == 1.0f for many items)."""
+    U, I, F, k = 50, 1500, 16, 10
+    for scale, wscale in ((4.0, 1.0), (30.0, 6.0)):           # ordinary; saturated (many probabilities round to exactly 1)
+        w = _weights(U, I, F, seed=31, scale=scale)
+        w["hw"] = (w["hw"] * wscale).astype(np.float32)
+        st = ops.NmfDeviceState(ctx, w, max_batch=1 << 17)
+        rs = np.random.RandomState(4)
+        ip, ix = random_excl(rs, U, I, 0, 30)
+        excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+        idx, val = st.recommend(0, U, k, excl=excl)
+        ri, rv = st._pairs_topk(0, U, k + 1, excl, None)
+        # the two routes evaluate the logit in different summation orders: values agree to fp32 round-off everywhere; a row whose
+        # LIST differs must contain a near-tie (a probability gap inside that noise) among the pair route's first k + 1 entries
+        assert float((val - rv[:, :k]).abs().max()) < 2e-6
+        diff_rows = np.nonzero(~cpu((idx == ri[:, :k]).all(1)))[0]
+        full = cpu(rv)
+        for u in diff_rows:
+            assert (np.abs(np.diff(full[u])) < 4e-6).any(), (scale, int(u), full[u].tolist())
+        if scale < 10:
+            assert len(diff_rows) <= U // 4
+        # internal consistency of the fused list: ordered by (probability desc, index asc)
+        v, ii = cpu(val), cpu(idx)
+        assert (v[:, :-1] >= v[:, 1:]).all()
+        tie = v[:, :-1] == v[:, 1:]
+        assert (ii[:, :-1][tie] < ii[:, 1:][tie]).all()
+
+
+def test_gmf_recommend_through_the_dot_product_kernels(ctx):
+    """GMF: sigmoid(sum_f h_f u_f i_f) ranked by the fused dot-product top-k kernels on the item image Imf * h: lists equal the C
+    oracle's fma chain on (Umf, Imf * h) (bit-exact raw scores), values = sigmoid of those."""
+    U, I, F, k = 300, 4000, 64, 10
+    w = on.init_gmf(U, I, F, 5)
+    w = {kk: (v * 6).astype(np.float32) for kk, v in w.items()}
+    st = ops.NmfDeviceState(ctx, w, max_batch=4096)
+    rs = np.random.RandomState(6)
+    ip, ix = random_excl(rs, U, I, 0, 25)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    idx, val = st.recommend(0, U, k, excl=excl)
+    img = (w["Imf"] * w["hw"][None, :]).astype(np.float32)
+    ei, ev = cref.score_topk_f32(w["Umf"], img, None, 0, U, k, excl=(ip, ix))
+    p = 1.0 / (1.0 + np.exp(-ev.astype(np.float64)))
+    distinct = (np.diff(p.astype(np.float32), axis=1) != 0).all(1)           # rows without probability ties: the lists must agree
+    assert distinct.mean() > 0.9
+    assert np.array_equal(cpu(idx)[distinct], ei[distinct])
+    assert np.abs(cpu(val).astype(np.float64) - p).max() < 1e-6
+    # and the pair route agrees on the values
+    users = torch.arange(U, dtype=torch.int32, device=ctx.device).repeat_interleave(k)
+    pp = st.forward(users, idx.reshape(-1).contiguous()).reshape(U, k)
+    assert float((pp - val).abs().max()) < 2e-6
+
+
+def test_unsupported_tower_takes_the_pair_route(ctx):
+    U, I, F = 20, 300, 8
+    w = on.init_neumf(U, I, F, 3, units=[16, 8])                    # two Dense layers: not the fused kernel's shape
+    st = ops.NmfDeviceState(ctx, w, max_batch=8192)
+    assert not st.fused_supported(10)
+    idx, val = st.recommend(0, U, 5)
+    ri, rv = st._pairs_topk(0, U, 5, None, None)
+    assert torch.equal(idx, ri) and torch.equal(val, rv)
+    with pytest.raises(Exception):
+        st.score_topk_logits(0, U, 5)

@@ -89,3 +89,30 @@ def test_dropout_masks_enter_forward_and_backward_like_autograd():
         pairs = zip(v, tw[k]) if isinstance(v, list) else [(v, tw[k])]
         for a, b in pairs:
             assert np.abs(a - b.grad.numpy()).max() < 1e-12, k
+
+
+def test_c_oracle_logits_equal_the_network_in_fp64():
+    """oracle/c/el_oracle.c::orc_nmf_logits (the pinned-order checker of el_nmf_score_topk: separable layer 1, k-ordered fma
+    chains, two interleaved head chains) is the same function as oracle/neumf.py::forward -- in fp64 maths, to fp32 round-off."""
+    from oracle import cref
+    for F, units in ((16, None), (9, [36, 18, 9]), (32, [100, 40, 20])):
+        U, I = 12, 400
+        w = on.init_neumf(U, I, F, 3, units=units)
+        rs = np.random.RandomState(F)
+        for k in ("Umf", "Imf", "Umlp", "Imlp"):
+            w[k] = (w[k] * 5).astype(np.float32)
+        w["b"] = [rs.normal(scale=0.1, size=b.shape).astype(np.float32) for b in w["b"]]
+        w["hb"] = np.array([-0.2], np.float32)
+        L = cref.nmf_logits(w, np.arange(U))
+        u, i = np.repeat(np.arange(U), I), np.tile(np.arange(I), U)
+        p = on.forward(w, u, i, dtype=np.float64)["p"].reshape(U, I)
+        ref = np.log(p) - np.log1p(-p)
+        assert np.abs(L - ref).max() < 5e-6 * max(1.0, np.abs(ref).max())
+        # a shard of the items and a subset of the users: the same numbers
+        L2 = cref.nmf_logits(w, np.array([7, 2]), 100, 250)
+        assert np.array_equal(L2, L[[7, 2], 100:250])
+        # without the MF branch / without the head bias
+        w2 = {k: v for k, v in w.items() if k not in ("Umf", "Imf", "hb")}
+        w2["hw"] = w["hw"][F:].copy()
+        p2 = on.forward(w2, u, i, dtype=np.float64)["p"].reshape(U, I)
+        assert np.abs(cref.nmf_logits(w2, np.arange(U)) - (np.log(p2) - np.log1p(-p2))).max() < 5e-6
