@@ -16,6 +16,8 @@ Follows elliot/recommender/latent_factor_models/BPRMF_batch/BPRMF_batch_model.py
 """
 import numpy as np
 
+from . import tf_clauses
+
 BETA1, BETA2, EPS = 0.9, 0.999, 1e-7
 
 
@@ -43,7 +45,8 @@ def gradients(Gu, Gi, Bi, u, i, j, l_w, l_b, dtype=np.float32):
     xui = bi + np.sum(gu * gi, axis=1, dtype=dtype)
     xuj = bj + np.sum(gu * gj, axis=1, dtype=dtype)
     d = xui - xuj
-    s = np.where(d >= -80.0, -1.0 / (1.0 + np.exp(d.astype(np.float64))), 0.0).astype(dtype)
+    inside = (d >= -80.0) if tf_clauses.get("clip_gradient_inclusive_at_bound") else (d > -80.0)      # [TF] clause, oracle/tf_clauses.py
+    s = np.where(inside, -1.0 / (1.0 + np.exp(d.astype(np.float64))), 0.0).astype(dtype)
     dGu = np.zeros(Gu.shape, dtype)
     dGi = np.zeros(Gi.shape, dtype)
     dBi = np.zeros(Bi.shape, dtype)
@@ -66,11 +69,18 @@ def adam_tf_sparse_apply(theta, m, v, g, lr, t):
     the batch still decay and move).  fp32, in place."""
     f = np.float32
     lr_t = adam_lr_t(lr, t)
+    if not tf_clauses.get("adam_sparse_apply_moves_all_rows"):          # [TF] clause switched off: only the touched rows move
+        rows = np.flatnonzero(np.any(np.reshape(g, (g.shape[0], -1)) != 0, axis=1))
+        return adam_lazy_apply(theta, m, v, g, rows, lr, t)
     m *= f(BETA1)
     m += g * f(1.0 - BETA1)
     v *= f(BETA2)
     v += (g * g) * f(1.0 - BETA2)
-    theta -= (lr_t * m) / (np.sqrt(v) + f(EPS))
+    if tf_clauses.get("adam_epsilon_outside_sqrt_with_folded_bias_correction"):
+        theta -= (lr_t * m) / (np.sqrt(v) + f(EPS))
+    else:                                                                # "epsilon hat" form
+        b1p, b2p = np.power(f(BETA1), f(t)), np.power(f(BETA2), f(t))
+        theta -= f(lr) * (m / (f(1) - b1p)) / (np.sqrt(v / (f(1) - b2p)) + f(EPS))
 
 
 def adam_lazy_apply(theta, m, v, g, rows, lr, t):

@@ -14,6 +14,8 @@ the declared kernel_regularizers are never added to the loss (train_step uses ne
 """
 import numpy as np
 
+from . import tf_clauses
+
 BETA1, BETA2, EPS = 0.9, 0.999, 1e-7
 NAMES = ("W1", "b1", "Wm", "bm", "Wv", "bv", "W3", "b3", "W4", "b4")
 
@@ -47,7 +49,9 @@ def forward(w, x, eps, drop_scale=None, dtype=np.float32):
     """x: dense [B, I] batch; eps: [B, L]; drop_scale: [B, I] of {0, 1/(1-rate)} or None."""
     f = lambda a: np.asarray(a, dtype=dtype)
     x = f(x)
-    xn = x / np.sqrt(np.maximum((x * x).sum(axis=1, keepdims=True), dtype(1e-12)))
+    ss = (x * x).sum(axis=1, keepdims=True)
+    # [TF] clause (oracle/tf_clauses.py): K.l2_normalize = x * rsqrt(max(sum x^2, 1e-12)); switched off: x / (sqrt(sum x^2) + 1e-12)
+    xn = x / np.sqrt(np.maximum(ss, dtype(1e-12))) if tf_clauses.get("l2_normalize_epsilon_1e12_inside_max") else x / (np.sqrt(ss) + dtype(1e-12))
     if drop_scale is not None:
         xn = xn * f(drop_scale)
     h = np.tanh(xn @ f(w["W1"]) + f(w["b1"]))

@@ -12,6 +12,7 @@ Follows
 """
 import numpy as np
 
+from . import tf_clauses
 from .bprmf_batch import adam_lr_t, adam_tf_sparse_apply
 
 BETA1, BETA2, EPS = 0.9, 0.999, 1e-7
@@ -70,14 +71,15 @@ def forward(w, u, i, dtype=np.float32, masks=None):
 
 
 def bce(p, y):
-    pc = np.clip(p, 1e-7, 1 - 1e-7)
+    pc = np.clip(p, 1e-7, 1 - 1e-7) if tf_clauses.get("bce_clips_probabilities_at_1e7") else p        # [TF] clause, oracle/tf_clauses.py
     return float(-np.mean(y * np.log(pc) + (1 - y) * np.log(1 - pc)))
 
 
 def gradients(w, c, u, i, y):
     n = len(y)
     p = c["p"]
-    dlogit = np.where((p > 1e-7) & (p < 1 - 1e-7), (p - y) / n, 0.0).astype(p.dtype)
+    live = ((p > 1e-7) & (p < 1 - 1e-7)) if tf_clauses.get("bce_clips_probabilities_at_1e7") else np.ones(p.shape, bool)
+    dlogit = np.where(live, (p - y) / n, 0.0).astype(p.dtype)
     g = {"hw": c["cat"].T @ dlogit}
     if "hb" in w:
         g["hb"] = np.array([dlogit.sum()])

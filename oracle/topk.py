@@ -7,6 +7,8 @@ Follows (reference checkout paths):
 """
 import numpy as np
 
+from . import tf_clauses
+
 
 def dense_mask_from_excl(indptr, indices, u_start, u_stop, n_items, item_offset=0):
     """allunrated_mask[u_start:u_stop] (dataset.py:245) from the train CSR: True = candidate."""
@@ -36,7 +38,8 @@ def get_top_k(preds, mask, k, item_offset=0):
     val = np.empty((n, k), masked.dtype)
     cols = np.arange(I)
     for r in range(n):
-        order = np.lexsort((cols, -masked[r]))  # primary: -score asc (= score desc), secondary: index asc
+        tie = cols if tf_clauses.get("top_k_ties_lower_index_first") else -cols      # [TF] clause, oracle/tf_clauses.py
+        order = np.lexsort((tie, -masked[r]))  # primary: -score asc (= score desc), secondary: index asc
         idx[r] = order[:k] + item_offset
         val[r] = masked[r, order[:k]]
     return val, idx
