@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libelliot_hip.so")
+LIB_PATH = os.environ.get("EL_LIB_PATH") or os.path.join(_HERE, "csrc", "libelliot_hip.so")   # (EL_LIB_PATH: another BUILD of the
+#                                                       same library for kernel A/B runs, scripts/exp/build_variants.sh -- never a fallback)
 
 EL_OPT_ADAM_TF_DENSE = 0
 EL_OPT_ADAM_LAZY = 2
@@ -109,6 +110,7 @@ PROTOTYPES = {
     "el_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "el_allgather_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int32, _i32p, _f32p]),
     "el_host_split_flags": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_uint32, C.c_int32, C.c_void_p]),
+    "el_host_split_flags_state": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]),
     "el_host_negative_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "el_host_pyset_order": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "el_timing_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

@@ -73,11 +73,7 @@ struct Mt {
 
 }  // namespace
 
-extern "C" int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int32_t n_folds, int8_t* flags) {
-    EL_REQUIRE(seg_len != nullptr && flags != nullptr && n_seg >= 0, "el_host_split_flags: null argument");
-    EL_REQUIRE(mode == 0 || mode == 1, "el_host_split_flags: mode 0 = random_subsampling(test_ratio), 1 = leave_n_out(n)");
-    EL_REQUIRE(n_folds >= 1, "el_host_split_flags: n_folds >= 1");
-    Mt mt(seed);
+static int split_flags_on(Mt& mt, const int64_t* seg_len, int64_t n_seg, int mode, double param, int32_t n_folds, int8_t* flags) {
     int64_t off = 0;
     for (int32_t fold = 0; fold < n_folds; ++fold)          // base_splitter.py:266-267: folds outside, users inside, one stream
     for (int64_t s = 0; s < n_seg; ++s) {
@@ -102,6 +98,32 @@ extern "C" int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mo
         off += n;
     }
     return 0;
+}
+
+extern "C" int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int32_t n_folds, int8_t* flags) {
+    EL_REQUIRE(seg_len != nullptr && flags != nullptr && n_seg >= 0, "el_host_split_flags: null argument");
+    EL_REQUIRE(mode == 0 || mode == 1, "el_host_split_flags: mode 0 = random_subsampling(test_ratio), 1 = leave_n_out(n)");
+    EL_REQUIRE(n_folds >= 1, "el_host_split_flags: n_folds >= 1");
+    Mt mt(seed);
+    return split_flags_on(mt, seg_len, n_seg, mode, param, n_folds, flags);
+}
+
+// The same draws on a generator state the CALLER carries (624 key words + position, as np.random.get_state()[1:3]): the reference
+// seeds np.random ONCE per Splitter.process_splitting (base_splitter.py:73) and every level of the train / validation / test
+// hierarchy -- the test split, then the validation split of each test fold's train part (:86-98) -- continues that one stream.
+extern "C" int el_host_split_flags_state(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t* np_state625,
+                                         int32_t n_folds, int8_t* flags) {
+    EL_REQUIRE(seg_len != nullptr && flags != nullptr && n_seg >= 0 && np_state625 != nullptr, "el_host_split_flags_state: null argument");
+    EL_REQUIRE(mode == 0 || mode == 1, "el_host_split_flags_state: mode 0 = random_subsampling(test_ratio), 1 = leave_n_out(n)");
+    EL_REQUIRE(n_folds >= 1, "el_host_split_flags_state: n_folds >= 1");
+    EL_REQUIRE(np_state625[624] <= 624u, "el_host_split_flags_state: position word out of range");
+    Mt mt(0u);
+    memcpy(mt.key, np_state625, sizeof(mt.key));
+    mt.pos = (int)np_state625[624];
+    const int rc = split_flags_on(mt, seg_len, n_seg, mode, param, n_folds, flags);
+    memcpy(np_state625, mt.key, sizeof(mt.key));
+    np_state625[624] = (uint32_t)mt.pos;
+    return rc;
 }
 
 // CPython set (Objects/setobject.c, 3.7 - 3.12): open addressing, LINEAR_PROBES = 9 slots after the home slot when they fit

@@ -640,8 +640,10 @@ int el_topk_launch_mfma(const TopkParams& p, hipStream_t st) {
 static const int LIST_SPLIT = 64;
 static const int LIST_DENSE = 64;
 
-// exact scores of the first min(*ulist_n, LIST_DENSE) listed users against the whole shard: one thread per item keeps its
-// row in registers and walks the users (rows staged in LDS), so the item table is read once.  F <= 128 (screened path).
+// exact scores of the first min(*ulist_n, LIST_DENSE) listed users against the whole shard: one thread per item keeps (half of)
+// its row in registers and walks the users (rows staged in LDS), so the item table is read once.  F <= 256: factors 128..255 are
+// a second sweep that CONTINUES each chain from the partial sum the first sweep left in `preds` -- the same k-ordered fma chain
+// (the one-thread-per-(item, user) kernel below re-read the 5 M x 256 table 64 times: 108 ms per call at BASELINE configs[4]).
 __global__ __launch_bounds__(256) void k_list_scores(TopkParams p, float* __restrict__ preds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* us = reinterpret_cast<float*>(smem);            // [n][F]
@@ -656,18 +658,21 @@ __global__ __launch_bounds__(256) void k_list_scores(TopkParams p, float* __rest
     __syncthreads();
     const int64_t il = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (il >= p.I_local) return;
-    float gi[128];
     const float* row = p.Gi + il * (int64_t)F;
-#pragma unroll
-    for (int f = 0; f < 128; ++f) gi[f] = f < F ? row[f] : 0.f;
     const float bias = p.Bi ? p.Bi[il] : 0.f;
-    for (int slot = 0; slot < n; ++slot) {
-        const float* gu = us + slot * F;
-        float a = 0.f;
+    for (int f0 = 0; f0 < F; f0 += 128) {
+        float gi[128];
 #pragma unroll
-        for (int f = 0; f < 128; ++f)
-            if (f < F) a = __builtin_fmaf(gi[f], gu[f], a);
-        preds[(int64_t)slot * p.I_local + il] = (p.Bi ? a + bias : a) + 0.0f;
+        for (int f = 0; f < 128; ++f) gi[f] = f0 + f < F ? row[f0 + f] : 0.f;
+        const bool last = f0 + 128 >= F;
+        for (int slot = 0; slot < n; ++slot) {
+            const float* gu = us + slot * F + f0;
+            float a = f0 ? preds[(int64_t)slot * p.I_local + il] : 0.f;
+#pragma unroll
+            for (int f = 0; f < 128; ++f)
+                if (f0 + f < F) a = __builtin_fmaf(gi[f], gu[f], a);
+            preds[(int64_t)slot * p.I_local + il] = last ? (p.Bi ? a + bias : a) + 0.0f : a;
+        }
     }
 }
 
@@ -711,7 +716,7 @@ int el_topk_run_list(const TopkParams& p0, void* scratch, size_t scratch_bytes, 
         d.ulist_skip = 0;
         d.ulist_max = LIST_DENSE;
         d.nsplit = 0;
-        if (p0.F <= 128)
+        if (p0.F <= 256)
             EL_LAUNCH("k_list_scores", k_list_scores, dim3((unsigned)((p0.I_local + 255) / 256)), dim3(256), (size_t)LIST_DENSE * p0.F * 4, st,
                       d, preds);
         else

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
     const int64_t item = t / SL;
     const int sl = (int)(t % SL);
     float v[8];
-    float ss = 0.f, sb = 0.f, sd = 0.f;
+    float ss = 0.f, sb = 0.f, sd = 0.f, amax = 0.f;
     const bool live = item < I;
     if (live) {
         const float* src = Gi + item * (int64_t)F + sl * 8;
@@ -100,17 +100,27 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
         o.w = el_f2bf(v[6]) | (el_f2bf(v[7]) << 16);
         *reinterpret_cast<uint4*>(Gib + item * FP + sl * 8) = o;
 #pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    }
+    // The norms are taken SCALE-SAFELY: the squares of a row whose entries sit below ~1e-19 underflow to zero in fp32, the measured
+    // residual norm would read 0 and the bound collapse below the true bf16 error (advisor, round 2).  Every entry is divided by the
+    // row's largest magnitude first (a row maximum so small that its reciprocal overflows gives inf norms: every user falls back).
+    for (int o = SL >> 1; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float rs = amax > 0.f ? 1.0f / amax : 0.f;
+    if (live) {
+#pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float r = el_bf2f(el_f2bf(v[j])), d = v[j] - r;      // the residual of a bf16 rounding is an exact fp32 number
-            ss += v[j] * v[j];
-            sb += r * r;
-            sd += d * d;
+            const float vs = v[j] * rs, rr = r * rs, ds = d * rs;
+            ss += vs * vs;
+            sb += rr * rr;
+            sd += ds * ds;
         }
     }
     ss = el_group_sum(ss, SL);                           // all SL lanes of an item hold its sum of squares
     sb = el_group_sum(sb, SL);
     sd = el_group_sum(sd, SL);
-    float nrm = sqrtf(ss) * 1.001f, nrb = sqrtf(sb) * 1.001f, nrd = sqrtf(sd) * 1.001f;
+    float nrm = amax * sqrtf(ss) * 1.001f, nrb = amax * sqrtf(sb) * 1.001f, nrd = amax * sqrtf(sd) * 1.001f;
     if (!(nrm < INFINITY)) nrm = INFINITY;               // NaN / inf rows poison the bound -> every user falls back
     if (!(nrb < INFINITY)) nrb = INFINITY;
     if (!(nrd < INFINITY)) nrd = INFINITY;
@@ -488,8 +498,24 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
 // One wave per user.  A masked item j contaminates its slot when it may be the slot's arg-max: its s' is recomputed
 // here (same bf16 operands, fp32 fma chain) and compared with the slot maximum with the fp32 re-association tolerance.
 // (If it is NOT flagged, the arg-max is another item, and that item is unmasked or it would have flagged the slot.)
+// (occupancy knobs of the two latency-bound per-user kernels; -D overrides are for A/B builds, scripts/exp/build_variants.sh)
+#ifndef EL_SCR_WPE
+#define EL_SCR_WPE 6                 // 6 waves per SIMD (<= 80 VGPRs, 24 KB of LDS per workgroup): thr 0.357 -> 0.306 ms, final 1.25 -> 1.15 ms
+#endif                               // per 131 072-user block on trained tables (gpurun_out r03c; 7 and 8 spill and lose it again)
+#if EL_SCR_WPE > 0
+#define SCR_LB __launch_bounds__(256, EL_SCR_WPE)
+#else
+#define SCR_LB __launch_bounds__(256)
+#endif
+#ifndef EL_SCR_XC
+#define EL_SCR_XC 256
+#endif
+#ifndef EL_SCR_GUS
+#define EL_SCR_GUS 256
+#endif
+
 template <int FP>
-__global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
+__global__ SCR_LB void k_screen_thr(ScreenParams sp) {
     const TopkParams& p = sp.t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ur = (int64_t)blockIdx.x * 4 + wv, user = p.u_start + ur;     // one wave per user, 4 users per workgroup
@@ -508,18 +534,23 @@ __global__ __launch_bounds__(256) void k_screen_thr(ScreenParams sp) {
     sm[lane] = M;
     inv[lane] = 0;
     const float* gu = p.Gu + user * (int64_t)p.F;
-    float ss = 0.f, sd = 0.f;
+    float ss = 0.f, sd = 0.f, amax = 0.f;
+    for (int f = lane; f < FP; f += 64) amax = fmaxf(amax, (f < p.F) ? fabsf(gu[f]) : 0.f);
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float rs = amax > 0.f ? 1.0f / amax : 0.f;      // scale-safe norms: see k_screen_prep
     for (int f = lane; f < FP; f += 64) {
         const float v = (f < p.F) ? gu[f] : 0.f;
         const float r = el_bf2f(el_f2bf(v)), d = v - r;
         ubf[f] = r;
-        ss += v * v;
-        sd += d * d;
+        const float vs = v * rs, ds = d * rs;
+        ss += vs * vs;
+        sd += ds * ds;
     }
     ss = el_group_sum(ss, 64);
     sd = el_group_sum(sd, 64);
-    const float nu = sqrtf(ss) * 1.001f;
-    float du = sqrtf(sd) * 1.001f;
+    float nu = amax * sqrtf(ss) * 1.001f;
+    if (!(nu < INFINITY)) nu = INFINITY;
+    float du = amax * sqrtf(sd) * 1.001f;
     if (!(du < INFINITY)) du = INFINITY;                  // inf / NaN user row: the bound is infinite, the user falls back
     float E, tol;
     el_screen_bounds(nu, du, sp.stats[0], sp.stats[SCR_STAT_IB], sp.stats[SCR_STAT_ID], sp.stats[1], p.F, E, tol);
@@ -632,15 +663,15 @@ __device__ __forceinline__ float el_exact_score(const TopkParams& p, const float
 }
 
 template <int SCR_SURV>
-__global__ __launch_bounds__(256) void k_screen_final(ScreenParams sp) {
+__global__ SCR_LB void k_screen_final(ScreenParams sp) {
     const TopkParams& p = sp.t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ur = (int64_t)blockIdx.x * 4 + wv, user = p.u_start + ur;     // one wave per user, 4 users per workgroup
     if (user >= p.u_stop || sp.ovf[ur]) return;
-    constexpr int XC = 512;                          // exclusion rows up to this length are searched in LDS
+    constexpr int XC = EL_SCR_XC;                    // exclusion rows up to this length are searched in LDS
     __shared__ u64 surv_[4][SCR_SURV];
     __shared__ int32_t xrow_[4][XC];
-    __shared__ __attribute__((aligned(16))) float gus_[4][256];   // F <= 256 (eligibility)
+    __shared__ __attribute__((aligned(16))) float gus_[4][EL_SCR_GUS];   // F <= 256 (eligibility)
     u64* surv = surv_[wv];
     int32_t* xrow = xrow_[wv];
     float* gu_s = gus_[wv];

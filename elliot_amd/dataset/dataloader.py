@@ -13,7 +13,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from .dataset import DataSet, _split_flags
+from .dataset import DataSet, _split_flags, np_seed_state
 
 COLUMNS = ("userId", "itemId", "rating", "timestamp")
 
@@ -136,8 +136,9 @@ def _rank_first(frame, ascending):
     return rank, r, cnt
 
 
-def _test_flags(frame, ns, seed):
-    """[folds, rows] int8 test flags of ONE level of the hierarchy (handle_hierarchy, :134-196)."""
+def _test_flags(frame, ns, seed, state=None):
+    """[folds, rows] int8 test flags of ONE level of the hierarchy (handle_hierarchy, :134-196).  state: the np.random stream of
+    the whole process_splitting call (the random strategies draw from it and leave it advanced)."""
     strategy = _get(ns, "strategy")
     if strategy is None:
         raise Exception("Strategy option not found")
@@ -166,9 +167,9 @@ def _test_flags(frame, ns, seed):
         if not str(folds).isdigit():
             raise Exception("Folds option value is not valid")
         if _has(ns, "test_ratio"):
-            return _split_flags(users, 0, float(_get(ns, "test_ratio")), seed, int(folds))
+            return _split_flags(users, 0, float(_get(ns, "test_ratio")), seed, int(folds), state=state)
         if _has(ns, "leave_n_out"):
-            return _split_flags(users, 1, int(_get(ns, "leave_n_out")), seed, int(folds))
+            return _split_flags(users, 1, int(_get(ns, "leave_n_out")), seed, int(folds), state=state)
         raise Exception(f"Option missing for {strategy} strategy")
     if strategy == "random_cross_validation":
         if not _has(ns, "folds"):
@@ -219,8 +220,10 @@ def split(frame, splitting, seed=42):
     if not _has(splitting, "test_splitting"):
         raise Exception("Test splitting strategy is not defined")
 
+    state = np_seed_state(seed)              # np.random.seed(seed) ONCE (:73): every level and fold below continues this stream
+
     def level(fr, ns):
-        flags = _test_flags(fr, ns, seed)
+        flags = _test_flags(fr, ns, seed, state)
         return [(take(fr, f == 0), take(fr, f == 1)) for f in flags]
 
     out = level(frame, _get(splitting, "test_splitting"))

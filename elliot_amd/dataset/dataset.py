@@ -197,7 +197,20 @@ class DataSet:
 
 
 # ---------------------------------------------------------------------------------------------------
-def _split_flags(users, mode, param, seed, folds=1):
+def np_seed_state(seed):
+    """The legacy np.random state right after np.random.seed(seed): MT19937 init_genrand, 624 key words + position 624."""
+    st = np.empty(625, dtype=np.uint32)
+    x = int(seed) & 0xFFFFFFFF
+    for i in range(624):
+        st[i] = x
+        x = (1812433253 * (x ^ (x >> 30)) + i + 1) & 0xFFFFFFFF
+    st[624] = 624
+    return st
+
+
+def _split_flags(users, mode, param, seed, folds=1, state=None):
+    """state: a np_seed_state() array carried by the caller -- the draws continue that stream and leave it advanced (the levels of
+    a train / validation / test hierarchy share ONE stream, base_splitter.py:73,86-98); None = a fresh stream seeded with `seed`."""
     from .. import _lib
     users = np.asarray(users)
     lo = int(users.min()) if users.shape[0] and users.dtype.kind in "iu" else 0
@@ -213,8 +226,11 @@ def _split_flags(users, mode, param, seed, folds=1):
         bounds = np.flatnonzero(np.concatenate([[True], su[1:] != su[:-1], [True]])) if su.shape[0] else np.zeros(1, dtype=np.int64)
         seg = np.ascontiguousarray(np.diff(bounds), dtype=np.int64)
     sorted_flags = np.empty((folds, users.shape[0]), dtype=np.int8)
-    _lib.check(_lib.load().el_host_split_flags(seg.ctypes.data, seg.shape[0], mode, float(param), int(seed) & 0xffffffff, int(folds),
-                                               sorted_flags.ctypes.data), "el_host_split_flags")
+    if state is None:
+        state = np_seed_state(seed)
+    assert state.dtype == np.uint32 and state.shape == (625,) and state.flags.c_contiguous
+    _lib.check(_lib.load().el_host_split_flags_state(seg.ctypes.data, seg.shape[0], mode, float(param), state.ctypes.data, int(folds),
+                                                     sorted_flags.ctypes.data), "el_host_split_flags_state")
     flags = np.empty((folds, users.shape[0]), dtype=np.int8)
     flags[:, order] = sorted_flags
     return flags

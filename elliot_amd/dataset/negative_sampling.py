@@ -80,14 +80,17 @@ def read_from_files(data, path):
     return m
 
 
-def attach(data, ns, seed=42):
+def attach(data, ns, seed=42, rng=None):
     """Equivalent of dataset.py:221-243: sets `data.test_cand_csr` (and `val_cand_csr` when the data set has a validation
-    split) = (indptr int64, indices int32) of negatives + held-out items.  `ns` = the `negative_sampling` namespace / dict."""
+    split) = (indptr int64, indices int32) of negatives + held-out items.  `ns` = the `negative_sampling` namespace / dict.
+    rng: the run's `random.Random` -- the reference seeds the `random` MODULE once, at the import of negative_sampling.py (:16),
+    and every data object of a run (test folds x validation folds) continues that one stream; a caller with several data objects
+    creates ONE random.Random(42) and hands it to every attach() (run.load_data_objects does).  None = a fresh stream (one object)."""
     get = (lambda k, d=None: ns.get(k, d)) if isinstance(ns, dict) else (lambda k, d=None: getattr(ns, k, d))
     strategy = get("strategy")
     test_pos = _known_split_csr(data, False)
     has_val = data.split_csr(True) is not None
-    rng = random.Random(seed)
+    rng = rng if rng is not None else random.Random(seed)
     train = data.sp_i_train.astype(np.int8)
 
     def negatives(validation):

@@ -161,15 +161,21 @@ class RcclAbiCollectives:
         except Exception:
             pass
 
-    def _run(self, fn, async_op):
+    def _run(self, fn, async_op, tensors=()):
+        """tensors: every buffer the collective reads or writes on the SIDE stream.  They are (a) recorded on that stream, so that the
+        caching allocator does not hand a block freed on the caller's stream (a `.contiguous()` temporary, an output the caller
+        drops early) to the next allocation while the collective still uses it, and (b) kept alive by the returned handle."""
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self.stream.wait_event(ready)                              # inputs written on the caller's stream are complete
+        for t in tensors:
+            t.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             fn(self.stream.cuda_stream)
             done = torch.cuda.Event()
             done.record(self.stream)
         work = _AbiWork(done)
+        work.keep = tuple(tensors)
         if async_op:
             return work
         work.wait()
@@ -183,14 +189,14 @@ class RcclAbiCollectives:
             return None if async_op else t
         assert t.is_contiguous()
         w = self._run(lambda s: ops.check(self.ctx.lib.el_allreduce_rows(self.ctx.handle, self._h, s, t.data_ptr(), t.numel()),
-                                          "el_allreduce_rows"), async_op)
+                                          "el_allreduce_rows"), async_op, (t,))
         return w if async_op else t
 
     def all_gather(self, t):
         t = t.contiguous()
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         self._run(lambda s: ops.check(self.ctx.lib.el_allgather_rows(self.ctx.handle, self._h, s, t.data_ptr(), out.data_ptr(),
-                                                                     t.numel() * t.element_size()), "el_allgather_rows"), False)
+                                                                     t.numel() * t.element_size()), "el_allgather_rows"), False, (t, out))
         return out
 
     def all_gather_topk(self, idx, val):
@@ -199,19 +205,21 @@ class RcclAbiCollectives:
         gi = torch.empty((self.world, n, k), dtype=torch.int32, device=idx.device)
         gv = torch.empty((self.world, n, k), dtype=torch.float32, device=idx.device)
         self._run(lambda s: ops.check(self.ctx.lib.el_allgather_topk(self.ctx.handle, self._h, s, idx.data_ptr(), val.data_ptr(), int(n),
-                                                                     int(k), gi.data_ptr(), gv.data_ptr()), "el_allgather_topk"), False)
+                                                                     int(k), gi.data_ptr(), gv.data_ptr()), "el_allgather_topk"), False,
+                  (idx, val, gi, gv))
         return gi, gv
 
     def reduce_scatter_rows(self, out, full):
         assert out.is_contiguous() and full.is_contiguous() and full.numel() == self.world * out.numel()
         self._run(lambda s: ops.check(self.ctx.lib.el_reduce_scatter_rows(self.ctx.handle, self._h, s, full.data_ptr(), out.data_ptr(),
-                                                                          out.numel()), "el_reduce_scatter_rows"), False)
+                                                                          out.numel()), "el_reduce_scatter_rows"), False, (out, full))
         return out
 
     def all_gather_rows_into(self, full, part, async_op=False):
         part = part if part.is_contiguous() else part.contiguous()
         w = self._run(lambda s: ops.check(self.ctx.lib.el_allgather_rows(self.ctx.handle, self._h, s, part.data_ptr(), full.data_ptr(),
-                                                                         part.numel() * part.element_size()), "el_allgather_rows"), async_op)
+                                                                         part.numel() * part.element_size()), "el_allgather_rows"), async_op,
+                      (part, full))
         return w if async_op else full
 
 

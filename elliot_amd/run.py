@@ -75,9 +75,11 @@ def load_data_objects(exp, cfg, base_dir):
     cfg.splitting = _to_ns(exp.get("splitting", {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2}}))
     objs = dataloader.DataSetLoader(cfg, resolve=lambda p: _resolve(base_dir, p, cfg.dataset)).generate_dataobjects()
     if hasattr(cfg, "negative_sampling"):                       # dataset.py:221-243
+        import random
+        rng = random.Random(42)         # negative_sampling.py:16 seeds `random` once per process: ONE stream over all data objects
         for fold in objs:
             for data in fold:
-                negative_sampling.attach(data, cfg.negative_sampling)
+                negative_sampling.attach(data, cfg.negative_sampling, rng=rng)
     return objs
 
 

@@ -687,6 +687,12 @@ int el_allgather_topk(el_ctx* ctx, el_comm* comm, void* stream, const int32_t* p
 int el_host_negative_sample(const int64_t* excl_indptr, const int32_t* excl_indices, int64_t n_users, int64_t n_items, int32_t num,
                             int64_t setsize, uint32_t* py_state625, int32_t* out);
 int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t seed, int32_t n_folds, int8_t* flags);
+/* el_host_split_flags on a generator state the caller carries: np_state625 = the legacy MT19937 state (624 key words + position,
+ * np.random.get_state()[1:3]; after np.random.seed(s): init_genrand(s), position 624), updated in place.  The reference seeds
+ * np.random ONCE per Splitter.process_splitting (base_splitter.py:73); the test split and then the validation split of every test
+ * fold's train part (:86-98) continue that one stream -- a host that splits a hierarchy passes the same state to every call.   */
+int el_host_split_flags_state(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t* np_state625, int32_t n_folds,
+                              int8_t* flags);
 int el_host_pyset_order(const int64_t* keys, int64_t n, int64_t* out, int64_t* n_out);
 
 #ifdef __cplusplus

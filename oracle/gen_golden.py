@@ -235,6 +235,21 @@ def gen_loader():
         (train_val, test), = Splitter(df.copy(), ns, 42).process_splitting()
         (train, val), = train_val
         out["hier_test"], out["hier_val"], out["hier_train"] = (x["row"].values.astype(np.int64) for x in (test, val, train))
+        # hierarchies whose levels BOTH draw from np.random: the stream seeded once in process_splitting (:73) runs on through the
+        # validation split of every test fold (:86-98) -- random test + random validation; two test folds, two validation folds each
+        ns = SimpleNamespace(test_splitting=SimpleNamespace(strategy="random_subsampling", test_ratio=0.2),
+                             validation_splitting=SimpleNamespace(strategy="random_subsampling", test_ratio=0.1))
+        (train_val, test), = Splitter(df.copy(), ns, 42).process_splitting()
+        (train, val), = train_val
+        out["hier_rr_test"], out["hier_rr_val"], out["hier_rr_train"] = (x["row"].values.astype(np.int64) for x in (test, val, train))
+        ns = SimpleNamespace(test_splitting=SimpleNamespace(strategy="random_subsampling", test_ratio=0.2, folds=2),
+                             validation_splitting=SimpleNamespace(strategy="random_subsampling", leave_n_out=2, folds=2))
+        tl = Splitter(df.copy(), ns, 42).process_splitting()
+        assert len(tl) == 2 and all(len(tv) == 2 for tv, _ in tl)
+        for a, (train_val, test) in enumerate(tl):
+            out[f"hier_ff_test{a}"] = test["row"].values.astype(np.int64)
+            for b, (train, val) in enumerate(train_val):
+                out[f"hier_ff_val{a}{b}"], out[f"hier_ff_train{a}{b}"] = val["row"].values.astype(np.int64), train["row"].values.astype(np.int64)
     SeriesGroupBy.rank = orig_rank
     np.savez_compressed(os.path.join(OUT, "loader_ref.npz"), **out)
     print("loader_ref.npz:", len(df), "rows,", len(filters), "prefilters,", len(splits) + 1, "splitting configurations")

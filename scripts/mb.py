@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--opt", default="adam_tf_dense")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-excl", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=0, help="topk: BPR steps (B = --batch, TF-dense Adam) on the tables before scoring -- "
+                    "the candidate windows of the screened kernels depend on the norms a trained model has")
+    ap.add_argument("--sweep", default="", help="topk: comma list of stride:kA settings (EL_SCREEN_STRIDE / EL_SCREEN_KA) to time after the default")
     ap.add_argument("--model", default="FunkSVD", choices=["MF", "PMF", "FunkSVD", "LogisticMF", "NeuMF", "GMF"])
     ap.add_argument("--shape", action="append", default=None, help="gemm: M,N,K,tA,tB (repeatable; default: the model shapes)")
     a = ap.parse_args()
@@ -158,17 +161,42 @@ def main():
         print(f"{a.model}: recommend {min(U, 131072)} users in {dt * 1e3:.3f} ms -> {min(U, 131072) / dt / 1e6:.2f} M users/s")
         return
     if a.what == "topk":
-        ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)   # warm-up: code load, workspace
-        torch.cuda.synchronize()
+        if a.train_steps > 0:
+            lim_u, lim_i = (6.0 / (1_000_000 + F)) ** 0.5, (6.0 / (I + F)) ** 0.5       # GlorotUniform of the bench's 1M x I tables
+            Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * lim_u
+            Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i
+            stt = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+            for it in range(a.train_steps):
+                u, i, j = ops.bpr_sample(ctx, pos, a.batch, seed=42, first_sample=it * a.batch)
+                stt.train_step(u, i, j, 0.001, 0.1, 0.001)
+            Gu, Gi, Bi = stt.Gu, stt.Gi, stt.Bi
+        settings = [("default", None, None)] + [(x, x.split(":")[0], x.split(":")[1]) for x in a.sweep.split(",") if x]
+        for name, sd, ka in settings:
+            for var, val in (("EL_SCREEN_STRIDE", sd), ("EL_SCREEN_KA", ka)):
+                if val is None:
+                    os.environ.pop(var, None)
+                else:
+                    os.environ[var] = val
+            ctx.timing(False)
+            ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)   # warm-up: code load, workspace
+            torch.cuda.synchronize()
+            ctx.timing(True)
+            t0 = time.perf_counter()
+            for _ in range(a.iters):
+                ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo, items_unchanged=True)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / a.iters * 1e3
+            rep = ctx.timing_report()
+            tot = sum(ms / a.iters for _, (c, ms) in rep.items())
+            print(f"[{name}] kernels {tot:.3f} ms/call, wall (with events) {wall:.3f} ms -> {U / tot * 1e3 / 1e6:.2f} M users/s")
+            for n, (c, ms) in rep.items():
+                per = ms / a.iters
+                if per > 0.02:
+                    print(f"    {n}: {per:.3f} ms/call  {2.0 * U * I * F / per / 1e9:.1f} TFLOP/s")
+        return
     ctx.timing(True)
-    if a.what == "topk":
-        for _ in range(a.iters):
-            ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)
-        torch.cuda.synchronize()
-        rep = ctx.timing_report()
-        for n, (c, ms) in rep.items():
-            per = ms / c
-            print(f"{n}: {per:.3f} ms/launch  {2.0 * U * I * F / per / 1e9:.1f} TFLOP/s  {U / per * 1e3:.0f} users/s")
+    if False:
+        pass
     else:
         st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=a.opt)
         for it in range(a.iters):

@@ -1,6 +1,8 @@
 import os
 import sys
 
+sys.dont_write_bytecode = True      # tests import the read-only reference checkout (tests/helpers/ref_host_boundary.py): no __pycache__ there
+
 import numpy as np
 import pytest
 

@@ -220,7 +220,8 @@ def test_screened_topk_large_random_block(ctx):
     assert_topk_equal("topk_screen_large", gi, gv, ei, ev)
 
 
-@pytest.mark.parametrize("case", ["bf16_exact", "near_power_of_two", "one_huge_item", "mixed_scales", "sparse_rows", "tiny"])
+@pytest.mark.parametrize("case", ["bf16_exact", "near_power_of_two", "one_huge_item", "mixed_scales", "sparse_rows", "tiny", "tiny_users",
+                                  "tiny_rows_among_normal"])
 def test_screened_topk_residual_bound_adversarial_inputs(ctx, case):
     """The screening bound is ||du|| max||i~|| + ||u|| max||di|| (+ fp32 accumulation), du / di the MEASURED bf16 residuals.  Inputs
     that push on it: operands that ARE bf16 numbers (residuals 0: the window collapses to the accumulation term, and thousands of
@@ -254,6 +255,15 @@ def test_screened_topk_residual_bound_adversarial_inputs(ctx, case):
         Gu *= np.float32(1e-18)
         Gi *= np.float32(1e-18)
         Bi *= np.float32(1e-30)
+    elif case == "tiny_users":
+        # |u_f| ~ 1e-22: v * v underflows to zero in fp32 -- a residual norm summed from plain squares reads 0 and the bound collapses
+        # below the true bf16 error (advisor, round 2); the norms are taken relative to the row maximum instead
+        Gu *= np.float32(1e-21)
+        Bi[:] = 0
+    elif case == "tiny_rows_among_normal":
+        Gu[::3] *= np.float32(1e-21)
+        Gi[::5] *= np.float32(1e-21)
+        Bi[:] = 0
     excl = random_excl(rs, U, I, 0, 50)
     ei, ev = cref.score_topk_f32(Gu, Gi, Bi, 0, U, k, excl=excl)
     gi, gv = run_gpu(ctx, Gu, Gi, Bi, 0, U, k, excl=excl, algo="screen")

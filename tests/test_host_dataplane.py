@@ -260,3 +260,39 @@ def test_negative_sampling_property(n_users, n_items, num, seed):
         cand = np.flatnonzero(~dense[u])
         assert got[u].tolist() == cand[ref.sample(range(cand.shape[0]), num)].tolist()
     assert rng.getstate() == ref.getstate()
+
+
+def test_negative_sampling_stream_runs_on_over_the_data_objects_of_a_run():
+    """The reference seeds the `random` MODULE once (negative_sampling.py:16); the data objects of a run (test folds x validation
+    folds, run.py loops over all of them) draw their negatives one after the other from that stream.  Two data objects with one
+    shared random.Random(42): the second one's negatives are the continuation of the stream -- what a single generator drawing
+    for both exclusion matrices in turn produces --, not a replay of the first object's draws."""
+    g = np.load(GOLD)
+    U, I = g["A_shape"].tolist()
+    ip, ix = g["A_train_indptr"], g["A_train_indices"]
+    tr_u = np.repeat(np.arange(U), np.diff(ip))
+    objs = []
+    for drop in (0, 1):                                    # two "folds": the second loses every 7th train row
+        keep = np.ones(ix.shape[0], bool)
+        if drop:
+            keep[::7] = False
+            keep[ip[:-1]] = True                           # (every user keeps a train item)
+        objs.append(D.DataSet(D.default_config(), (tr_u[keep], ix[keep].astype(np.int64), np.ones(int(keep.sum()))),
+                              (g["A_test_users"], g["A_test_items"], np.ones(g["A_test_users"].shape[0])),
+                              public_users=np.arange(U), public_items=np.arange(I)))
+    rng = random.Random(42)
+    for ds in objs:
+        NS.attach(ds, {"strategy": "random", "num_items": 20}, rng=rng)
+    ref = random.Random(42)
+    for ds in objs:
+        excl = (ds.sp_i_train.astype(np.int8) + NS._known_split_csr(ds, False)).astype(bool)
+        neg = NS.sample_by_random_uniform(excl, 20, ref)
+        cip, cix = ds.test_cand_csr
+        for u in range(0, U, 17):
+            held = NS._known_split_csr(ds, False)[u].indices
+            assert set(cix[cip[u]:cip[u + 1]].tolist()) == set(neg[u].tolist()) | set(held.tolist())
+    assert rng.getstate() == ref.getstate()
+    # a fresh generator per object (the round-2 behaviour) gives the second object other negatives
+    again = D.DataSet(D.default_config(), objs[1]._train_triples, objs[1]._test_triples, public_users=np.arange(U), public_items=np.arange(I))
+    NS.attach(again, {"strategy": "random", "num_items": 20})
+    assert not np.array_equal(again.test_cand_csr[1], objs[1].test_cand_csr[1])

@@ -51,6 +51,26 @@ def test_train_validation_test_hierarchy():
     assert np.array_equal(test["row"], GOLD["hier_test"]) and np.array_equal(val["row"], GOLD["hier_val"]) and np.array_equal(train["row"], GOLD["hier_train"])
 
 
+def test_random_levels_share_one_generator_stream():
+    """Both levels draw from np.random: the reference seeds it ONCE per process_splitting (base_splitter.py:73) and the validation
+    split of every test fold's train part continues that stream (:86-98) -- a restart per level would reuse the test level's
+    draws.  One test fold + one validation fold; two test folds x two validation folds."""
+    ns = {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2},
+          "validation_splitting": {"strategy": "random_subsampling", "test_ratio": 0.1}}
+    (train_val, test), = L.split(frame(), ns, 42)
+    (train, val), = train_val
+    assert np.array_equal(test["row"], GOLD["hier_rr_test"]) and np.array_equal(val["row"], GOLD["hier_rr_val"]) and np.array_equal(train["row"], GOLD["hier_rr_train"])
+    ns = {"test_splitting": {"strategy": "random_subsampling", "test_ratio": 0.2, "folds": 2},
+          "validation_splitting": {"strategy": "random_subsampling", "leave_n_out": 2, "folds": 2}}
+    out = L.split(frame(), ns, 42)
+    assert len(out) == 2
+    for a, (train_val, test) in enumerate(out):
+        assert np.array_equal(test["row"], GOLD[f"hier_ff_test{a}"])
+        assert len(train_val) == 2
+        for b, (train, val) in enumerate(train_val):
+            assert np.array_equal(val["row"], GOLD[f"hier_ff_val{a}{b}"]) and np.array_equal(train["row"], GOLD[f"hier_ff_train{a}{b}"])
+
+
 def test_loader_builds_one_dataset_per_fold(tmp_path):
     fr = frame()
     with open(tmp_path / "d.tsv", "w") as f:
