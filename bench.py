@@ -276,6 +276,24 @@ def timed(ctx, world, fn, warmup, steps, finish=None, events_in_timed_region=Tru
     return sorted(dts)[len(dts) // 2], rep
 
 
+XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (7 links per GPU on an 8-GPU MI355X node: point to point, no switch)
+
+
+def expected_collective(op, nbytes, world):
+    """Wire model of one collective on the node's xGMI mesh, printed beside the measured time so that the first real N-GPU run
+    checks itself.  nbytes = the full buffer (all_reduce: the buffer; reduce_scatter: its input; all_gather: its output).  A rank
+    puts frac * nbytes on the wire (2 (G-1)/G for all_reduce, (G-1)/G otherwise).  Two bounds: "direct" = every peer reached over
+    its own link at once (reduce-scatter / all-gather by direct exchange: min(G-1, 7) links busy), "ring" = one link per direction
+    (what a ring schedule is bound by on point-to-point links).  Link rate 153 GB/s at 100 %; RCCL typically delivers 60-75 % of it."""
+    if world < 2:
+        return None
+    frac = {"all_reduce": 2.0 * (world - 1) / world, "reduce_scatter": (world - 1.0) / world, "all_gather": (world - 1.0) / world}[op]
+    wire = frac * nbytes
+    links = min(world - 1, 7)
+    return {"bytes_on_wire_per_rank": wire, "direct_all_links_ms": wire / (links * XGMI_LINK_GBS * 1e9) * 1e3,
+            "ring_one_link_ms": wire / (XGMI_LINK_GBS * 1e9) * 1e3, "link_GBs": XGMI_LINK_GBS, "links_used_direct": links}
+
+
 def time_collective(world, dev, fn, reps=5):
     """Wall time of one collective call (barrier-bracketed mean of `reps`, max over ranks), outside every timed region."""
     fn()
@@ -306,17 +324,23 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def load_traffic(U, I, F, B, Ub, world):
-    """HBM bytes per launch from the rocprofv3 PMC passes (scripts/collect_traffic.sh -> profiles/traffic.json).  Not measured
-    in this run: quoted only when the file was collected on THIS workload and THESE kernel sources, otherwise dropped (null)."""
+def load_traffic(U, I, F, B, Ub, world, leg=None):
+    """HBM bytes per launch from the rocprofv3 PMC passes (scripts/collect_traffic.sh -> profiles/traffic.json, one entry per bench
+    leg).  Not measured in this run: quoted only when the file was collected on THIS workload and THESE kernel sources, otherwise
+    dropped (null).  leg: the entry to look in (default: whichever BPR workload has this shape)."""
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        c = tj["config"]
-        if (c["users"], c["items"], c["factors"], c["batch"], c["topk_block"]) != (U, I, F, B, Ub) or world != 1:
-            return {}, "profiles/traffic.json was collected on another workload"
         if tj.get("source_hash") != source_hash():
             return {}, f"profiles/traffic.json is stale (collected on kernel sources {tj.get('source_hash')}, commit {tj.get('commit')})"
-        return tj["bytes_per_launch"], f"rocprofv3 PMC passes at commit {tj.get('commit')} (scripts/collect_traffic.sh), same kernel sources"
+        if world != 1:
+            return {}, "profiles/traffic.json holds single-GPU workloads"
+        for name, w in tj.get("workloads", {}).items():
+            c = w.get("config", {})
+            if (leg is not None and name == leg) or (leg is None and "users" in c and
+                                                     (c["users"], c["items"], c["factors"], c["batch"], c["topk_block"]) == (U, I, F, B, Ub)):
+                return w["bytes_per_launch"], (f"rocprofv3 PMC passes at commit {tj.get('commit')} (scripts/collect_traffic.sh, workload "
+                                               f"'{name}'), same kernel sources")
+        return {}, "profiles/traffic.json has no entry for this workload"
     except Exception as ex:  # noqa: BLE001
         return {}, f"no traffic file ({type(ex).__name__})"
 
@@ -593,7 +617,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         for what, op, nbytes, fn in collectives:
             ms = time_collective(world, dev, fn)
             coll_rep.append({"what": what, "op": op, "bytes": int(nbytes), "ms": ms,
-                             "algbw_GBs": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None})
+                             "algbw_GBs": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                             "expected_ms": expected_collective(op, nbytes, world)})
 
     # ---- fragile users of the last block: rank-k / k+1 gap inside the fp32 re-association bound -----------
     fragile = None
@@ -771,6 +796,7 @@ def vae_leg(args, ctx):
     gemm_flops = B * 2.0 * (H * 2 * L + L * H + H * I) * 3
     alg_flops = B * (2400.0 * I + 720000.0) * 2.5                      # dense-input formulation, fwd x 2.5
     gname = "k_gemm_f32"
+    vtraffic, vnote = (load_traffic(0, 0, 0, 0, 0, 1, leg="vae") if args.vae_shape == "138493,26744,600,200,512" else ({}, "non-default shape"))
     gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / K
     ach = gemm_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
     return {"value": B * K / dt, "unit": "users/s", "ms_per_step": ms,
@@ -778,7 +804,8 @@ def vae_leg(args, ctx):
                         f"{int(csr.nnz)} interactions ({nnz_row:.0f}/user), Adam, anneal schedule of multi_vae.py:105-108",
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             "roofline": {"kernel": gname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": vtraffic.get("k_gemm_f32_per_step"), "traffic_unit": "HBM bytes of the kernel's launches of ONE step",
+                         "traffic_source": vnote, "dtype": "f32",
                          "flops_per_step_gemm": gemm_flops, "gemm_ms_per_step": gms,
                          "step_TFLOPs_dense_gemm": gemm_flops / (ms * 1e-3) / 1e12,
                          "step_TFLOPs_survey8d": alg_flops / (ms * 1e-3) / 1e12,
@@ -821,6 +848,7 @@ def neumf_leg(args, ctx):
     # 20 F^2 flop per (user, item) pair after the separable first layer (2 (H1 H2 + H2 H3)): inherently ~10^4 x the work of a dot
     # product, so the block is small and the step count its own
     nu = int(args.neumf_topk_users)
+    ntraffic, nnote = (load_traffic(0, 0, 0, 0, 0, 1, leg="neumf") if args.neumf_shape == "1250000,1000000,128,262144" else ({}, "non-default shape"))
     tk = None
     if nu > 0 and st.fused_supported(args.k + 2):
         ks, ws_ = max(1, min(K, 2)), 1
@@ -842,7 +870,8 @@ def neumf_leg(args, ctx):
                       f"el_nmf_score_topk (layer 1 separable, layers 2-3 + head per pair on fp32 MFMA, selection fused) + sigmoid link "
                       f"+ re-rank; the reference's route materialises {nu} x {I} x {4 * F} activations",
               "roofline": {"kernel": "k_nmf_score", "bound": "mfma", "achieved": ach_k, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach_k / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
+                           "frac": ach_k / MFMA_F32_PEAK_TFLOPS, "traffic": ntraffic.get("k_nmf_score") if nu == 128 else None,
+                           "traffic_source": nnote, "dtype": "f32",
                            "flops_per_pair": pair_flops, "flops_per_pair_reference_form": 2.0 * (2 * F * units[0] + units[0] * units[1] + units[1] * units[2]),
                            "kernels_ms_per_step": {n: v[1] / ks for n, v in rep_k.items()}}}
     mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # fwd 36 F^2 + 4 F per sample, x3 fwd + bwd
@@ -857,7 +886,8 @@ def neumf_leg(args, ctx):
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             **({"topk": tk} if tk is not None else {}),
             "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "dtype": "f32",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": ntraffic.get("k_gemm_f32_per_step"),
+                         "traffic_unit": "HBM bytes of the kernel's launches of ONE step", "traffic_source": nnote, "dtype": "f32",
                          "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,
                          "step_TFLOPs_mlp": mlp_flops / (ms * 1e-3) / 1e12,
                          "adam_tables_GBs": emb_bytes / (ams * 1e-3) / 1e9 if ams > 0 else None,

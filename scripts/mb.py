@@ -15,7 +15,8 @@ from elliot_amd.synthetic import zipf_csr_device  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["topk", "train", "vae", "gemm", "pwmf", "nmf"])
+    ap.add_argument("what", choices=["topk", "train", "vae", "gemm", "pwmf", "nmf", "nmfscore"])
+    ap.add_argument("--score-users", type=int, default=128, help="nmfscore: users per el_nmf_score_topk call")
     ap.add_argument("--users", type=int, default=131072)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--factors", type=int, default=128)
@@ -99,7 +100,7 @@ def main():
     Bi = torch.zeros(I, device=dev)
     ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, seed=5)
     pos = ops.DeviceCSR.from_tensors(ip, ix, I)
-    if a.what == "nmf":
+    if a.what in ("nmf", "nmfscore"):
         import numpy as np
         rs = np.random.RandomState(3)
         gu = lambda a, b: rs.uniform(-np.sqrt(6.0 / (a + b)), np.sqrt(6.0 / (a + b)), size=(a, b)).astype(np.float32)
@@ -115,7 +116,18 @@ def main():
             w["hw"], w["hb"] = gu(F + units[-1], 1)[:, 0].copy(), np.zeros(1, np.float32)
         else:
             w["hw"] = gu(F, 1)[:, 0].copy()
-        st = ops.NmfDeviceState(ctx, w, max_batch=a.batch)
+        st = ops.NmfDeviceState(ctx, w, max_batch=a.batch if a.what == "nmf" else 4096)
+        if a.what == "nmfscore":
+            nu = a.score_users
+            st.recommend(0, nu, a.k, excl=pos)
+            torch.cuda.synchronize()
+            ctx.timing(True)
+            for it in range(a.iters):
+                st.recommend((it + 1) * nu, (it + 2) * nu, a.k, excl=pos, items_unchanged=True)
+            torch.cuda.synchronize()
+            for n, (c, ms) in sorted(ctx.timing_report().items(), key=lambda kv: -kv[1][1]):
+                print(f"{n}: {ms / a.iters:.4f} ms/call ({c // a.iters} launches/call)")
+            return
         ctx.timing(True)
         for it in range(a.iters + 2):
             if it == 2:

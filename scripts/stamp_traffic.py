@@ -3,7 +3,8 @@
 commit and the kernel-source hash it was collected on.  bench.py quotes `roofline.traffic` from this file only while the hash of
 elliot_amd/csrc still matches, and says so in `roofline.traffic_source`.
 HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): FETCH_SIZE counts 64 B per 128-B request of wide coalesced
-reads on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as is."""
+reads on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as is.  One entry per bench leg (c2 = headline, c4, c5, vae,
+neumf); for the GEMM kernel of the vae / neumf legs (launches of many shapes) the figure is per STEP (all its launches of a step)."""
 import json
 import os
 import subprocess
@@ -14,24 +15,20 @@ sys.path.insert(0, REPO)
 import bench  # noqa: E402
 
 
-def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "traffic", "summary.json")
-    d = json.load(open(src))
-    if d["source_hash"] != bench.source_hash():
-        print(f"warning: collected on kernel sources {d['source_hash']}, the tree is at {bench.source_hash()}", file=sys.stderr)
-    commit = subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], text=True).strip()
-    cfg = d["config"]
+def per_launch(kernels, cfg, leg):
     out = {}
-    for k, c in d["kernels"].items():
-        f = c.get("FETCH_SIZE", {}).get("KiB_per_dispatch")
-        w = c.get("WRITE_SIZE", {}).get("KiB_per_dispatch")
-        if f is None or w is None:
+    for k, c in kernels.items():
+        f, w = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
+        if not f or not w:
             continue
-        out[k] = (2.0 * f + w) * 1024.0
-    if "k_adam_dense" in out:
+        if leg in ("vae", "neumf") and k in ("k_gemm_f32", "k_gemm_reduce", "k_adam_dense", "k_adam_apply_dense"):
+            steps = float(cfg.get("steps_profiled", 1))
+            out[k + "_per_step"] = (2.0 * f["KiB_total"] + w["KiB_total"]) * 1024.0 / steps
+        else:
+            out[k] = (2.0 * f["KiB_per_dispatch"] + w["KiB_per_dispatch"]) * 1024.0
+    if "k_adam_dense" in out and leg in ("c2", "c4", "c5"):
         # one kernel name, launches of different sizes per step (item table, item bias; the user table too in the dense form):
         # split the per-step total by element counts
-        n = d["kernels"]["k_adam_dense"]["FETCH_SIZE"]["dispatches"]
         U, I, F = cfg["users"], cfg["items"], cfg["factors"]
         parts = {"k_adam_dense_Gi": I * F, "k_adam_dense_Bi": I}
         per_step = 2
@@ -42,13 +39,25 @@ def main():
         s = float(sum(parts.values()))
         for name, cnt in parts.items():
             out[name] = tot * cnt / s
-        del n
-    res = {"note": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->bytes) from rocprofv3 --pmc passes on the bench workload "
-                   "(scripts/collect_traffic.sh); quoted by bench.py only while source_hash matches elliot_amd/csrc",
-           "commit": commit, "source_hash": d["source_hash"], "config": cfg, "bytes_per_launch": out}
+    return out
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "traffic", "summary.json")
+    d = json.load(open(src))
+    if d["source_hash"] != bench.source_hash():
+        print(f"warning: collected on kernel sources {d['source_hash']}, the tree is at {bench.source_hash()}", file=sys.stderr)
+    commit = subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], text=True).strip()
+    wl = {}
+    for leg, w in d["workloads"].items():
+        wl[leg] = {"config": w["config"], "bytes_per_launch": per_launch(w["kernels"], w["config"], leg)}
+    res = {"note": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->bytes) from rocprofv3 --pmc passes on the workload of every "
+                   "bench leg (scripts/collect_traffic.sh); quoted by bench.py only while source_hash matches elliot_amd/csrc",
+           "commit": commit, "source_hash": d["source_hash"], "workloads": wl}
     json.dump(res, open(os.path.join(REPO, "profiles", "traffic.json"), "w"), indent=1)
-    for k, v in sorted(out.items()):
-        print(f"{k:28s} {v / 1e6:10.1f} MB")
+    for leg, w in wl.items():
+        for k, v in sorted(w["bytes_per_launch"].items()):
+            print(f"{leg:6s} {k:32s} {v / 1e6:10.1f} MB")
 
 
 if __name__ == "__main__":

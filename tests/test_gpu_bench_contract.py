@@ -114,6 +114,8 @@ def test_gpus_2_launches_two_ranks_by_itself():
     check_common(d, n_gpus=2)
     assert d["config"]["backend"] == "gloo"
     assert d["collectives"][0]["op"] == "all_reduce" and d["collectives"][0]["ms"] > 0
+    ex = d["collectives"][0]["expected_ms"]                   # wire model beside the measurement: 2 (G-1)/G S bytes per rank
+    assert abs(ex["bytes_on_wire_per_rank"] - d["collectives"][0]["bytes"]) < 1 and ex["ring_one_link_ms"] >= ex["direct_all_links_ms"] > 0
     sec = d["item_shard"]                                     # north_star's partitioning as the second leg
     assert sec["value"] > 0 and sec["topk"]["value"] > 0 and sec["topk"]["scaling"] == "strong"
     ops_seen = {c["op"] for c in sec["collectives"]}
