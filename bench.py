@@ -931,14 +931,14 @@ def plugin_e2e_leg(args, ctx, data):
     ds = DataSet(cfg, (users[tr], indices[tr].astype(np.int64), ones[tr]), (users[held], indices[held].astype(np.int64), ones[held]),
                  public_users=np.arange(U, dtype=np.int64), public_items=np.arange(I, dtype=np.int64))
     t_data = time.perf_counter() - t_data
-    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False, save_weights=False), epochs=1, seed=42,
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False, save_weights=False), epochs=2, seed=42,
                              factors=F, lr=0.001, l_w=0.1, l_b=0.001, batch_size=args.batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     m = cls(data=ds, config=cfg, params=params)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
-    spent = {"eval": 0.0}
+    evals = []
     ev = m.evaluate
 
     def timed_eval(*a, **k):
@@ -946,19 +946,22 @@ def plugin_e2e_leg(args, ctx, data):
         t = time.perf_counter()
         ev(*a, **k)
         torch.cuda.synchronize()
-        spent["eval"] += time.perf_counter() - t
+        evals.append(time.perf_counter() - t)
     m.evaluate = timed_eval
     t0 = time.perf_counter()
     m.train()
     torch.cuda.synchronize()
-    t_train = time.perf_counter() - t0 - spent["eval"]
+    t_train = (time.perf_counter() - t0 - sum(evals)) / 2
+    spent = {"eval": evals[-1]}                                       # the second evaluate(): steady state (the first one also ships the
+    #                                                                  held-out CSR / masks and loads the kernels)
     res = m.get_results()[args.k]["test_results"]
     del sys.modules["external"]
     steps = -(-ds.transactions // args.batch)
-    return {"what": f"external.BPRMF_batch (elliot/run.py:67-75 loading) -> RecMixin.train(): 1 epoch = {ds.transactions} triplets in "
+    return {"what": f"external.BPRMF_batch (elliot/run.py:67-75 loading) -> RecMixin.train(), 2 epochs: an epoch = {ds.transactions} triplets in "
                     f"{steps} steps of batch_size {args.batch} + evaluate(): top-{args.k} of all {U} users under the train mask, "
                     f"nDCG / Recall on the device against {int(held.sum())} held-out interactions",
             "train_epoch_s": t_train, "train_pairs_per_s": ds.transactions / t_train, "evaluate_s": spent["eval"],
+            "evaluate_first_call_s": evals[0],
             "evaluate_users_per_s": U / spent["eval"] if spent["eval"] > 0 else None,
             "constructor_s": t_init, "dataset_build_host_s": t_data,
             "constructor_note": "tables drawn in HBM (GlorotUniform distribution), train CSR / sampler records shipped once",

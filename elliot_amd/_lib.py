@@ -34,7 +34,7 @@ class BprmfState(C.Structure):
         ("mGu", _f32p), ("vGu", _f32p), ("mGi", _f32p), ("vGi", _f32p), ("mBi", _f32p), ("vBi", _f32p),
         ("tGu", _i32p), ("tGi", _i32p), ("tBi", _i32p),
         ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32),
-        ("uslot", _i64p), ("gGu_rows", _f32p), ("gGu_cap", C.c_int64),
+        ("uslot", _i64p), ("gGu_rows", _f32p), ("gGu_cap", C.c_int64), ("Gu_next", _f32p),
     ]
 
 
@@ -131,6 +131,8 @@ PROTOTYPES = {
                                  C.c_float, C.c_float, C.c_int32, _f64p, C.c_void_p, C.c_size_t]),
     "el_bprmf_grads_presorted": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
                                  C.c_float, C.c_float, C.c_int32, _f64p, C.c_void_p, C.c_size_t]),
+    "el_bprmf_train_step_presorted": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
+                                                C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_float, _f64p, C.c_void_p, C.c_size_t]),
     "el_bprmf_presort": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t]),
     "el_bprmf_shard_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
                                        C.c_float, C.c_float, C.c_int32, _f32p, _f64p, C.c_void_p, C.c_size_t]),

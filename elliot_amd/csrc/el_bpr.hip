@@ -330,14 +330,7 @@ __global__ void k_loop_ctl_set(LoopCtl* ctl, int64_t cn, int32_t k) {
     ctl[1] = ctl[0];
 }
 
-// Keras-2.3 Adam, sparse-apply arithmetic, one element:
-//   m <- m*b1 ; m += g*(1-b1) ; v <- v*b2 ; v += (g*g)*(1-b2) ; theta -= (lr_t*m)/(sqrt(v)+eps)
-__device__ __forceinline__ void el_adam_elem(float& th, float& m, float& v, float g, float lr_t, float b1, float b2,
-                                             float omb1, float omb2, float eps) {
-    m = m * b1 + g * omb1;
-    v = v * b2 + (g * g) * omb2;
-    th = th - (lr_t * m) / (sqrtf(v) + eps);
-}
+// (el_adam_elem -- Keras-2.3 Adam, sparse-apply arithmetic, one element -- lives in el_common.h)
 
 // dense pass: EVERY element of the variable decays and moves (TF sparse-apply semantics);
 // the gradient accumulator is reset on the way.  Pure streaming: 4 read + 3(4) write streams.
@@ -659,6 +652,16 @@ static unsigned stream_grid(el_ctx* ctx, int64_t n_threads) {
     return (unsigned)blocks;
 }
 
+// TF-dense Adam on the item side alone (Gi, Bi): what is left of the optimiser phase after the fused user-side kernel
+int el_bprmf_apply_items_adam(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, float lr_t) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    const int64_t ni = st.I * (int64_t)st.F;
+    EL_LAUNCH("k_adam_dense_Gi", k_adam_dense, dim3(stream_grid(ctx, ni / 4 + 1)), dim3(256), 0, s, st.Gi, st.gGi, st.mGi, st.vGi, ni, lr_t, b1, b2, eps);
+    EL_LAUNCH("k_adam_dense_Bi", k_adam_dense, dim3(stream_grid(ctx, st.I / 4 + 1)), dim3(256), 0, s, st.Bi, st.gBi, st.mBi, st.vBi, st.I, lr_t, b1, b2, eps);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
 // shared argument validation of both train-step paths
 int el_bprmf_check_state(const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j,
                          double* loss_out, int opt, int32_t step, bool* vec, bool* rows_mode) {
@@ -769,7 +772,9 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
     const el_bprmf_state st = *stp;
     bool sorted = (algo == EL_BPR_SORTED);
     if (algo == EL_BPR_AUTO) sorted = (B >= 2048 || st.uslot) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I);
+    if (st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE && algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I)) sorted = true;
     EL_REQUIRE(sorted || !st.uslot, "el_bprmf_train_step: compact user-gradient rows (uslot) need the SORTED path and its workspace");
+    EL_REQUIRE(sorted || !(st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE), "el_bprmf_train_step: a second user table (Gu_next) needs the SORTED path and its workspace");
     if (sorted)
         return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, lr, l_w, l_b, opt, step, lr_t, loss_out, ws, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -1110,6 +1115,7 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
     }
 
     int64_t k = 0;
+    el_bprmf_state cur = *stp;
     for (int64_t c0 = 0; c0 < events; c0 += cap) {
         const int64_t cn = (events - c0 < cap) ? events - c0 : cap;
         if (int rc = el_bpr_sample_meta(ctx, stream, pos_indptr, pos_indices, sampler_meta, st.U, st.I, 0, st.I, seed,
@@ -1124,9 +1130,14 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
         }
         for (int64_t off = 0; off < cn; off += B, ++k) {
             const int64_t n = (cn - off < B) ? cn - off : B;
-            if (int rc = el_bprmf_train_step(ctx, stream, stp, bu + off, bi + off, bj + off, n, lr, l_w, l_b, opt,
+            if (int rc = el_bprmf_train_step(ctx, stream, &cur, bu + off, bi + off, bj + off, n, lr, l_w, l_b, opt,
                                              first_step + (int32_t)k, adam ? lr_t_host[k] : 0.f, loss_out, algo, ws, ws_bytes))
                 return rc;
+            if (cur.Gu_next && opt == EL_OPT_ADAM_TF_DENSE) {      // fused user side: the step left the current table in Gu_next
+                float* t = cur.Gu;
+                cur.Gu = cur.Gu_next;
+                cur.Gu_next = t;
+            }
         }
     }
     EL_CHECK_LAUNCH();

@@ -241,6 +241,189 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
     }
 }
 
+// ---- user segments fused with the optimiser pass (el_bprmf_state.Gu_next) -------------------------------------------------------
+// rowptr[r] = first sorted position whose user key is >= r (rowptr[U] = B): one thread per position fills the rows of the gap
+// in front of it.
+__global__ __launch_bounds__(256) void k_bpr_rowptr(const u32* __restrict__ keys, int64_t B, int64_t U, int32_t* __restrict__ rowptr) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t > B) return;
+    const int64_t key = t < B ? (int64_t)keys[t] : U;
+    const int64_t prev = t > 0 ? (int64_t)keys[t - 1] : -1;
+    for (int64_t r = prev + 1; r <= key; ++r) rowptr[r] = (int32_t)t;
+}
+
+struct FusedParams {
+    const int32_t* rowptr;    // [U + 1]
+    float* Gu_new;            // [U, F]: the updated user rows (Gu keeps the pre-update values for the item segments)
+    float lr_t, b1, b2, eps;
+};
+
+// One lane group (lpt lanes x 16 B = a row) owns RPG consecutive user rows: it prefetches their theta / m / v, walks the sorted
+// positions of those rows (a contiguous range, rowptr) exactly as k_bpr_user_seg does -- index chains staged in LDS, SUB
+// triplets' row gathers in flight -- keeping the RPG gradient rows in registers (the row a triplet belongs to is picked by
+// selects, not branches: two groups share a wave), then takes Keras' Adam step on every one of its rows (g = 0 for a row without
+// triplets: m, v decay, theta moves -- the all-rows semantics of k_adam_rows) and stores theta to Gu_new, m and v in place.
+// Same operations in the same order as k_bpr_user_seg + k_adam_rows: the tables come out bit-identical.
+template <int CPL, int RPG>
+__global__ __launch_bounds__(256) void k_bpr_user_adam(SegParams p, FusedParams f) {
+    constexpr int VW = 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int F = p.st.F, lpt = p.lpt;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = gid / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const int64_t rowbase = grp * RPG;
+    float myloss = 0.f;
+    if (rowbase < p.st.U) {
+        const int nrows = (int)((p.st.U - rowbase < RPG) ? p.st.U - rowbase : RPG);
+        const int64_t p0 = f.rowptr[rowbase], p1 = f.rowptr[rowbase + nrows];
+        float th[RPG][CPL][VW], mm[RPG][CPL][VW], vv[RPG][CPL][VW], acc[RPG][CPL][VW];
+        int cnt[RPG];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+            cnt[r] = 0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                for (int x = 0; x < VW; ++x) th[r][q][x] = mm[r][q][x] = vv[r][q][x] = acc[r][q][x] = 0.f;
+                if (r < nrows && e < F) {
+                    const int64_t o = (rowbase + r) * F + e;
+                    ldv<VW>(p.st.Gu + o, th[r][q]);
+                    const f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.st.mGu + o));
+                    const f4 b = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.st.vGu + o));
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) mm[r][q][x] = a[x], vv[r][q][x] = b[x];
+                }
+            }
+        }
+        extern __shared__ unsigned char seg_lds[];
+        const int gl = (int)(threadIdx.x / lpt), ngl = 256 / lpt;
+        u32* s_key = reinterpret_cast<u32*>(seg_lds) + (0 * ngl + gl) * BPR_USTG;
+        u32* s_b = reinterpret_cast<u32*>(seg_lds) + (1 * ngl + gl) * BPR_USTG;
+        u32* s_i = reinterpret_cast<u32*>(seg_lds) + (2 * ngl + gl) * BPR_USTG;
+        u32* s_j = reinterpret_cast<u32*>(seg_lds) + (3 * ngl + gl) * BPR_USTG;
+        float* s_bi = reinterpret_cast<float*>(seg_lds) + (4 * ngl + gl) * BPR_USTG;
+        float* s_bj = reinterpret_cast<float*>(seg_lds) + (5 * ngl + gl) * BPR_USTG;
+        constexpr int SUB = (CPL == 1) ? 2 : 1;
+        for (int64_t sbase = p0; sbase < p1; sbase += BPR_USTG) {
+            const int cs = (int)((p1 - sbase < BPR_USTG) ? p1 - sbase : BPR_USTG);
+            for (int t = sub; t < cs; t += lpt) {
+                const u32 b = p.vals[sbase + t];
+                const int32_t ii = p.bi[b], jj = p.bj[b];
+                s_key[t] = p.keys[sbase + t];
+                s_b[t] = b;
+                s_i[t] = (u32)ii;
+                s_j[t] = (u32)jj;
+                s_bi[t] = p.st.Bi[ii];
+                s_bj[t] = p.st.Bi[jj];
+            }
+            el_wave_lds_sync();
+            for (int base = 0; base < cs; base += SUB) {
+                bool okv[SUB];
+                float rgi[SUB][CPL][VW], rgj[SUB][CPL][VW];
+#pragma unroll
+                for (int t = 0; t < SUB; ++t) {
+                    okv[t] = base + t < cs;
+                    const int tt = okv[t] ? base + t : base;
+                    const float* pi = p.st.Gi + (int64_t)s_i[tt] * F;
+                    const float* pj = p.st.Gi + (int64_t)s_j[tt] * F;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) rgi[t][q][x] = rgj[t][q][x] = 0.f;
+                        if (okv[t] && e < F) {
+                            ldv<VW>(pi + e, rgi[t][q]);
+                            ldv<VW>(pj + e, rgj[t][q]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < SUB; ++t) {
+                    if (!okv[t]) continue;                       // group-uniform
+                    const int ridx = (int)((int64_t)s_key[base + t] - rowbase);
+                    const int64_t b = (int64_t)s_b[base + t];
+                    float gu[CPL][VW];                              // gamma_u = the pre-update row of this triplet's user
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            float g = th[0][q][x];
+#pragma unroll
+                            for (int r = 1; r < RPG; ++r) g = (ridx == r) ? th[r][q][x] : g;
+                            gu[q][x] = g;
+                        }
+                    float dpi = 0.f, dpj = 0.f, nsq = 0.f;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            dpi += gu[q][x] * rgi[t][q][x];
+                            dpj += gu[q][x] * rgj[t][q][x];
+                            nsq += gu[q][x] * gu[q][x] + rgi[t][q][x] * rgi[t][q][x] + rgj[t][q][x] * rgj[t][q][x];
+                        }
+                    dpi = el_group_sum(dpi, lpt);
+                    dpj = el_group_sum(dpj, lpt);
+                    const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
+                    const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
+                    const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
+                    float sb = 0.f;
+                    if (d >= -80.0f) sb = -1.0f / (1.0f + expf(d));
+                    myloss += p.l_w * 0.5f * nsq;
+                    if (sub == 0) {
+                        p.s[b] = sb;
+                        myloss += el_softplus_s(-dc) + p.l_b * 0.5f * beta_i * beta_i + (p.l_b * 0.5f * beta_j * beta_j) / 10.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            const float c = sb * (rgi[t][q][x] - rgj[t][q][x]);
+#pragma unroll
+                            for (int r = 0; r < RPG; ++r) acc[r][q][x] += (ridx == r) ? c : 0.f;
+                        }
+#pragma unroll
+                    for (int r = 0; r < RPG; ++r) cnt[r] += (ridx == r) ? 1 : 0;
+                }
+            }
+            el_wave_lds_sync();
+        }
+        const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+            if (r >= nrows) continue;
+            const float w = (float)cnt[r] * p.l_w;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+                if (e < F) {
+                    f4 a, m4, v4;
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) {
+                        const float g = cnt[r] ? acc[r][q][x] + w * th[r][q][x] : 0.f;
+                        float tx = th[r][q][x], mx = mm[r][q][x], vx = vv[r][q][x];
+                        el_adam_elem(tx, mx, vx, g, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                        a[x] = tx, m4[x] = mx, v4[x] = vx;
+                    }
+                    const int64_t o = (rowbase + r) * F + e;
+                    __builtin_nontemporal_store(a, reinterpret_cast<f4*>(f.Gu_new + o));
+                    __builtin_nontemporal_store(m4, reinterpret_cast<f4*>(p.st.mGu + o));
+                    __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(p.st.vGu + o));
+                }
+            }
+        }
+    }
+    __shared__ float wsum[4];
+    float wl = el_group_sum(myloss, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+        if (tot != 0.0) atomicAdd(p.loss_out, tot);
+    }
+}
+
 // ---- item segments -----------------------------------------------------------------------
 template <int VW, int CPL>
 __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
@@ -398,6 +581,7 @@ struct SortedWs {
     float* s;
     void* tmp;
     size_t tmp_bytes;
+    int32_t* rowptr;       // [U + 1] first sorted position of every user row (fused user-side kernel)
     size_t total;
 };
 
@@ -423,6 +607,7 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
     if (rocprim::radix_sort_pairs(nullptr, t2, np, np, np, np, (unsigned)(2 * B), 0, bits_for(I), (hipStream_t)0) != hipSuccess) return 1;
     w->tmp_bytes = t1 > t2 ? t1 : t2;
     w->tmp = take(w->tmp_bytes);
+    w->rowptr = (int32_t*)take((size_t)(U + 1) * 4);
     w->total = off;
     return 0;
 }
@@ -454,8 +639,31 @@ int el_bprmf_check_state(const el_bprmf_state* stp, const int32_t* u, const int3
                          double* loss_out, int opt, int32_t step, bool* vec, bool* rows_mode);
 int el_pick_lpt(int F, int vw, int* cpl);
 
+int el_bprmf_apply_items_adam(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, float lr_t);      // el_bpr.hip
+
+// user side of the step as ONE kernel (el_bprmf_state.Gu_next): rowptr, then segments + Adam over every user row
+static int launch_user_adam(const SegParams& pu, hipStream_t s, int64_t B, const SortedWs& w, int lpt, int cpl, float lr_t) {
+    FusedParams f;
+    f.rowptr = w.rowptr;
+    f.Gu_new = pu.st.Gu_next;
+    f.lr_t = lr_t, f.b1 = 0.9f, f.b2 = 0.999f, f.eps = 1e-7f;
+    EL_LAUNCH("k_bpr_rowptr", k_bpr_rowptr, dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, s, w.keyU, B, pu.st.U, w.rowptr);
+    static const int rpg = [] { const char* e = getenv("EL_FUSED_RPG"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 8) ? v : 4; }();
+    const int64_t groups = (pu.st.U + rpg - 1) / rpg;
+    const unsigned grid = (unsigned)((groups * lpt + 255) / 256);
+    const size_t lds = (size_t)(256 / lpt) * BPR_USTG * 6 * 4;
+#define EL_UA(CPL_, RPG_) EL_LAUNCH("k_bpr_user_adam", (k_bpr_user_adam<CPL_, RPG_>), dim3(grid), dim3(256), lds, s, pu, f)
+    if (cpl == 1) {
+        if (rpg == 2) EL_UA(1, 2); else if (rpg == 8) EL_UA(1, 8); else EL_UA(1, 4);
+    } else {
+        if (rpg == 2) EL_UA(2, 2); else EL_UA(2, 4);
+    }
+#undef EL_UA
+    return 0;
+}
+
 template <int VW>
-static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w) {
+static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w, bool fused = false, float lr_t = 0.f) {
     int cpl = 1;
     const int lpt = el_pick_lpt(base.st.F, VW, &cpl);
     EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build", base.st.F);
@@ -477,7 +685,11 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
 #define EL_SEG(CPL_)                                                                                      \
     do {                                                                                                  \
-        EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), ldsU, s, pu);      \
+        if (fused) {                                                                                      \
+            if (int rc = launch_user_adam(pu, s, B, w, lpt, cpl, lr_t)) return rc;                        \
+        } else {                                                                                          \
+            EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), ldsU, s, pu);  \
+        }                                                                                                 \
         EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi);      \
     } while (0)
     if (cpl == 1) EL_SEG(1);
@@ -488,10 +700,10 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     return 0;
 }
 
-extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
-                                          const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w,
-                                          float l_b, int opt, int32_t step, float lr_t, double* loss_out, void* ws,
-                                          size_t ws_bytes) {
+// opt: the optimiser, or -1 = gradients only (el_bprmf_grads); presorted: el_bprmf_presort already ordered this batch in `ws`
+static int sorted_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i, const int32_t* j,
+                       int64_t B, float lr, float l_w, float l_b, int opt, bool presorted, int32_t step, float lr_t, double* loss_out,
+                       void* ws, size_t ws_bytes) {
     if (int rc = el_bind(ctx)) return rc;
     bool vec = false, rows_mode = false;
     if (int rc = el_bprmf_check_state(stp, u, i, j, loss_out, opt < 0 ? EL_OPT_SGD : opt, step, &vec, &rows_mode)) return rc;
@@ -504,11 +716,9 @@ extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_train_step_sorted: workspace too small (%zu < %zu)",
                ws_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    if (opt != -2)                                   // -2: el_bprmf_presort already ordered this batch in `ws`
+    if (!presorted)
         if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
     if (st.uslot) {
-        EL_REQUIRE(st.gGu_rows != nullptr && st.gGu_cap >= B, "el_bprmf_train_step: compact user-gradient rows need gGu_rows with >= B rows (%lld < %lld)",
-                   (long long)st.gGu_cap, (long long)B);
         EL_REQUIRE(vec && ((uintptr_t)st.gGu_rows & 15) == 0 && !rows_mode && (opt == EL_OPT_ADAM_TF_DENSE || opt < 0),
                    "el_bprmf_train_step: compact user-gradient rows need F %% 4 == 0, 16-byte aligned tables and the TF-dense Adam");
     }
@@ -524,10 +734,29 @@ extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(
     base.l_b = l_b;
     base.step = step;
     base.loss_out = loss_out;
-    int rc = vec ? launch_segs<4>(base, s, B, w) : launch_segs<1>(base, s, B, w);
+    // fused user side (el_bprmf_state.Gu_next): segments + Keras Adam over every user row in one kernel, new rows to Gu_next
+    int cplq = 1;
+    el_pick_lpt(st.F, 4, &cplq);
+    const bool fused = st.Gu_next != nullptr && opt == EL_OPT_ADAM_TF_DENSE && vec && !rows_mode && cplq <= 2 &&
+                       (((uintptr_t)st.Gu_next | (uintptr_t)st.mGu | (uintptr_t)st.vGu) & 15) == 0;
+    if (st.Gu_next != nullptr && opt == EL_OPT_ADAM_TF_DENSE)
+        EL_REQUIRE(fused, "el_bprmf_train_step: Gu_next needs F %% 4 == 0, F <= 512 and 16-byte aligned tables");
+    if (st.uslot && !fused) {
+        EL_REQUIRE(st.gGu_rows != nullptr && st.gGu_cap >= B, "el_bprmf_train_step: compact user-gradient rows need gGu_rows with >= B rows (%lld < %lld)",
+                   (long long)st.gGu_cap, (long long)B);
+    }
+    int rc = vec ? launch_segs<4>(base, s, B, w, fused, lr_t) : launch_segs<1>(base, s, B, w);
     if (rc) return rc;
     if (opt < 0) return 0;                           // gradients only (el_bprmf_grads)
+    if (fused) return el_bprmf_apply_items_adam(ctx, s, st, lr_t);
     return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
+}
+
+extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
+                                          const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w,
+                                          float l_b, int opt, int32_t step, float lr_t, double* loss_out, void* ws,
+                                          size_t ws_bytes) {
+    return sorted_step(ctx, stream, stp, u, i, j, B, lr, l_w, l_b, opt, false, step, lr_t, loss_out, ws, ws_bytes);
 }
 
 // CML (el_cml.hip): the same sort + segment walk with the per-triplet coefficients given (cD = dloss/dD, cE = dloss/dE)
@@ -556,7 +785,7 @@ int el_bpr_sorted_cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st
 extern "C" int el_bprmf_grads(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
                               const int32_t* j, int64_t B, float l_w, float l_b, int32_t step, double* loss_out, void* ws,
                               size_t ws_bytes) {
-    return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -1, step, 0.f, loss_out, ws, ws_bytes);
+    return sorted_step(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -1, false, step, 0.f, loss_out, ws, ws_bytes);
 }
 
 // The sort of a batch reads nothing but the triplets, so a multi-GPU step can order the NEXT batch while its collective is in
@@ -574,7 +803,16 @@ extern "C" int el_bprmf_presort(el_ctx* ctx, void* stream, const int32_t* u, con
 extern "C" int el_bprmf_grads_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
                                         const int32_t* j, int64_t B, float l_w, float l_b, int32_t step, double* loss_out,
                                         void* ws, size_t ws_bytes) {
-    return el_bprmf_train_step_sorted(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -2, step, 0.f, loss_out, ws, ws_bytes);
+    return sorted_step(ctx, stream, stp, u, i, j, B, 0.f, l_w, l_b, -1, true, step, 0.f, loss_out, ws, ws_bytes);
+}
+
+// The whole step on a batch el_bprmf_presort ordered into `ws` (software pipeline of a single GPU: the NEXT batch is drawn and
+// ordered on a side stream meanwhile): segment kernels + loss + optimiser; the fused user-side kernel when st->Gu_next is set.
+extern "C" int el_bprmf_train_step_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
+                                             const int32_t* j, int64_t B, float lr, float l_w, float l_b, int opt, int32_t step,
+                                             float lr_t, double* loss_out, void* ws, size_t ws_bytes) {
+    EL_REQUIRE(opt == EL_OPT_ADAM_TF_DENSE || opt == EL_OPT_SGD, "el_bprmf_train_step_presorted: the dense optimisers only (adam_tf_dense, sgd)");
+    return sorted_step(ctx, stream, stp, u, i, j, B, lr, l_w, l_b, opt, true, step, lr_t, loss_out, ws, ws_bytes);
 }
 
 // =====================================================================================================

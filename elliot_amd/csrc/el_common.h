@@ -235,6 +235,15 @@ __host__ __device__ inline el_philox4 el_philox4x32_10(u32 c0, u32 c1, u32 c2, u
     return o;
 }
 
+// Keras-2.3 Adam, sparse-apply arithmetic, one element:
+//   m <- m*b1 ; m += g*(1-b1) ; v <- v*b2 ; v += (g*g)*(1-b2) ; theta -= (lr_t*m)/(sqrt(v)+eps)
+__device__ __forceinline__ void el_adam_elem(float& th, float& m, float& v, float g, float lr_t, float b1, float b2,
+                                             float omb1, float omb2, float eps) {
+    m = m * b1 + g * omb1;
+    v = v * b2 + (g * g) * omb2;
+    th = th - (lr_t * m) / (sqrtf(v) + eps);
+}
+
 // ---- per-user record of the samplers (el_bpr_sampler_meta_build) -------------------------------------------------------
 struct __attribute__((aligned(64))) SamplerRec {
     int64_t r0;      // row start in the positives CSR

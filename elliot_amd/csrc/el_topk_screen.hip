@@ -74,7 +74,7 @@ __device__ __forceinline__ int el_screen_slot(int row) {
 template <int FP>
 __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ Gi, const float* __restrict__ Bi, int64_t I,
                                                      int F, unsigned short* __restrict__ Gib, float* stats,
-                                                     const unsigned long long* __restrict__ rebuild) {
+                                                     const unsigned long long* __restrict__ rebuild, float2* __restrict__ inorm) {
     constexpr int SL = FP / 8;
     if (*rebuild == 0ull) return;                         // the image in this workspace was built from these very tables
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void k_screen_prep(const float* __restrict__ G
     if (!(nrm < INFINITY)) nrm = INFINITY;               // NaN / inf rows poison the bound -> every user falls back
     if (!(nrb < INFINITY)) nrb = INFINITY;
     if (!(nrd < INFINITY)) nrd = INFINITY;
+    if (live && sl == 0) inorm[item] = make_float2(nrb, nrd);      // per-item norms: the second-level screen of k_screen_final
     u32 nmax = live ? __float_as_uint(nrm) : 0u;         // non-negative floats order as their bit patterns
     u32 nbmax = live ? __float_as_uint(nrb) : 0u, ndmax = live ? __float_as_uint(nrd) : 0u;
     u32 bmax = 0u;
@@ -215,10 +216,14 @@ struct ScreenParams {
     const void* zeros;           // >= 16 bytes of zeros in device memory (LDS-DMA source of rows past the catalogue's end)
     float* Tg;                   // [n_users] the threshold guess T (thr = T - 2E); k_screen_final verifies it
     float* Eu;                   // [n_users] E_u
+    float* nuv;                  // [n_users] ||u|| (with margin), k_screen_thr
+    float* duv;                  // [n_users] ||u - bf16(u)||
+    float2* inorm;               // [I_local] (||bf16(i)||, ||i - bf16(i)||) per item (with margins), k_screen_prep
     int kA;                      // T = kA-th largest clean slot maximum (== k with stride 1: T is then rigorous)
     int surv;                    // unmasked hits a user may have before it is sent to the exact fallback (128 or 512)
     int stride;                  // pass 1 visits tiles t with t % stride == 0
     unsigned long long* prof;    // EL_SCREEN_PROF=1: [n_waves][8] cycle / event counters (developer tool)
+    unsigned long long* prof2;   // EL_SCREEN_PROF=1: [16] sums over the users of k_screen_final: phase cycles and candidate counts
 };
 
 #define PROF_T() (PROF ? __builtin_amdgcn_s_memtime() : 0ull)
@@ -622,6 +627,8 @@ __global__ SCR_LB void k_screen_thr(ScreenParams sp) {
         sp.thr[ur] = good ? (T - 2.0f * E) : INFINITY;
         sp.Tg[ur] = T;
         sp.Eu[ur] = E;
+        sp.nuv[ur] = nu;
+        sp.duv[ur] = du;
         sp.ovf[ur] = good ? 0 : 1;
         sp.cnt[ur] = 0;
     }
@@ -675,6 +682,9 @@ __global__ SCR_LB void k_screen_final(ScreenParams sp) {
     u64* surv = surv_[wv];
     int32_t* xrow = xrow_[wv];
     float* gu_s = gus_[wv];
+    const bool prf = sp.prof2 != nullptr;
+    unsigned long long tp0 = prf ? __builtin_amdgcn_s_memtime() : 0ull, tp1 = 0, tp2 = 0, tp3 = 0;
+    int pf_ns0 = 0, pf_ns1 = 0;
     for (int f = lane; f < p.F; f += 64) gu_s[f] = p.Gu[user * (int64_t)p.F + f];
     const int n = sp.cnt[ur];
     int64_t e0 = 0, e1 = 0, zoff = 0;
@@ -728,24 +738,74 @@ __global__ SCR_LB void k_screen_final(ScreenParams sp) {
         }
     }
     el_wave_lds_sync();
+    if (prf) tp1 = __builtin_amdgcn_s_memtime();
+    pf_ns0 = ns;
     if (ns > SCR_SURV || ns < p.k) {                 // window overflow / cannot happen unless flagged: exact fallback
         if (lane == 0) sp.ovf[ur] = 1;
         return;
     }
-    // ---- second-level screen on s': with t' = the k-th largest KNOWN s' of these unmasked candidates, every member of the
-    // exact top-k has s' >= t' - 2E (same lemma as for T); candidates of unknown s' (+inf) sort first and always stay
+    // ---- second-level screen with PER-ITEM error radii.  For a candidate j whose s' is known, the exact score lies in
+    // [s'_j - e_j, s'_j + e_j], e_j = ||du|| ||bf16(i_j)|| + ||u|| ||i_j - bf16(i_j)|| + tol (the Cauchy-Schwarz bound of the header with
+    // THIS item's measured norms, k_screen_prep, instead of the maxima over the shard -- in a trained table a few popular items carry
+    // norms several times the typical one, and E_u is sized for them).  With L = the k-th largest lower bound, k candidates have an
+    // exact score >= L, so a candidate whose upper bound is below L is not in the top-k.  Candidates of unknown s' (records with
+    // several rows) have no lower bound and always stay.  Round 2 cut at (k-th largest s') - 2 E_u: ~2x as many exact re-scorings,
+    // i.e. random 4F-byte row reads, the bulk of this kernel's time on trained tables.
     {
+        constexpr int NQ = SCR_SURV / 64;
+        u64 mk[NQ];
+        float ubd[NQ];
+        const float nu = sp.nuv[ur], du = sp.duv[ur];
+        float E_, tol;
+        el_screen_bounds(nu, du, sp.stats[0], sp.stats[SCR_STAT_IB], sp.stats[SCR_STAT_ID], sp.stats[1], p.F, E_, tol);
         int n2 = 64;
         while (n2 < ns) n2 <<= 1;
-        el_wave_bitonic_desc(surv, n2, lane);
-        if (nunk + p.k <= ns) {
-            const float cut = el_key_score(surv[nunk + p.k - 1]) - 2.0f * sp.Eu[ur];
-            int keep = 0;
-            for (int t = lane; t < ns; t += 64) keep += (el_key_score(surv[t]) >= cut) ? 1 : 0;
-            for (int o = 32; o > 0; o >>= 1) keep += __shfl_xor(keep, o, 64);
-            ns = keep;                               // sorted: the kept candidates are a prefix
+        u64 lbk[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int t = q * 64 + lane;
+            mk[q] = 0ull;
+            ubd[q] = -INFINITY;
+            lbk[q] = 0ull;
+            if (q * 64 < ns && t < ns) {
+                const u64 key = surv[t];
+                mk[q] = key;
+                const float s1 = el_key_score(key);
+                if (s1 < INFINITY) {
+                    const int32_t g = el_key_item(key);
+                    const float2 nn = sp.inorm[(int64_t)g - p.item_offset];
+                    const float e = du * nn.x + nu * nn.y + tol;
+                    ubd[q] = s1 + e;
+                    lbk[q] = el_make_key(s1 - e, g);
+                } else {
+                    ubd[q] = INFINITY;
+                }
+            }
         }
+        el_wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q * 64 < n2) surv[q * 64 + lane] = lbk[q];
+        el_wave_lds_sync();
+        el_wave_bitonic_desc(surv, n2, lane);
+        const float L = (ns - nunk >= p.k) ? el_key_score(surv[p.k - 1]) : -INFINITY;
+        el_wave_lds_sync();
+        int ns2 = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q * 64 < ns) {
+                const bool kp = (q * 64 + lane < ns) && (ubd[q] >= L);
+                const u64 b = __ballot(kp);
+                const int pos = ns2 + __popcll(b & ((1ull << lane) - 1ull));
+                if (kp) surv[pos] = mk[q];
+                ns2 += __popcll(b);
+            }
+        }
+        el_wave_lds_sync();
+        ns = ns2;
     }
+    if (prf) tp2 = __builtin_amdgcn_s_memtime();
+    pf_ns1 = ns;
     const bool vec4 = (p.F % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.Gi) & 15) == 0);
     u64 nk[SCR_SURV / 64];
 #pragma unroll
@@ -759,6 +819,7 @@ __global__ SCR_LB void k_screen_final(ScreenParams sp) {
         }
     }
     el_wave_lds_sync();
+    if (prf) tp3 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int q = 0; q < SCR_SURV / 64; ++q) surv[q * 64 + lane] = nk[q];
     el_wave_lds_sync();
@@ -783,6 +844,17 @@ __global__ SCR_LB void k_screen_final(ScreenParams sp) {
         const u64 kk = surv[t];
         p.out_idx[orow + t] = el_key_item(kk);
         p.out_val[orow + t] = el_key_score(kk);
+    }
+    if (prf && lane == 0) {
+        const unsigned long long tp4 = __builtin_amdgcn_s_memtime();
+        atomicAdd(sp.prof2 + 0, 1ull);
+        atomicAdd(sp.prof2 + 1, tp1 - tp0);          // records -> unmasked candidates
+        atomicAdd(sp.prof2 + 2, tp2 - tp1);          // second-level screen
+        atomicAdd(sp.prof2 + 3, tp3 - tp2);          // exact re-scoring
+        atomicAdd(sp.prof2 + 4, tp4 - tp3);          // sort, verify, write
+        atomicAdd(sp.prof2 + 5, (unsigned long long)n);
+        atomicAdd(sp.prof2 + 6, (unsigned long long)pf_ns0);
+        atomicAdd(sp.prof2 + 7, (unsigned long long)pf_ns1);
     }
 }
 
@@ -850,7 +922,7 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
 size_t el_topk_screen_ws_bytes(int64_t n_users, int64_t I_local, int F, int k, int64_t excl_nnz) {
     const int FP = screen_fp(F);
     if (excl_nnz < 0) excl_nnz = 0;
-    return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 6 * a256((size_t)n_users * 4) +
+    return a256((size_t)I_local * FP * 2) + a256(16) + a256((size_t)n_users * SCR_TI * 4) + 8 * a256((size_t)n_users * 4) + a256((size_t)I_local * 8) +
            a256(el_topk_list_scratch_bytes(n_users, I_local, k)) + a256(((size_t)n_users * screen_policy(k, I_local).surv + (size_t)excl_nnz) * 12);
 }
 
@@ -897,12 +969,25 @@ static int run_passes(ScreenParams& sp, hipStream_t st) {
         free(h);
         EL_CHECK_HIP(hipFree(sp.prof));
         sp.prof = nullptr;
+        EL_CHECK_HIP(hipMalloc((void**)&sp.prof2, 16 * 8));
+        EL_CHECK_HIP(hipMemsetAsync(sp.prof2, 0, 16 * 8, st));
     }
     if (sp.surv == 128)
         EL_LAUNCH("k_screen_final", k_screen_final<128>, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
     else
         EL_LAUNCH("k_screen_final", k_screen_final<512>, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, sp);
     EL_CHECK_LAUNCH();
+    if (PROF) {
+        unsigned long long a[16];
+        EL_CHECK_HIP(hipStreamSynchronize(st));
+        EL_CHECK_HIP(hipMemcpy(a, sp.prof2, sizeof(a), hipMemcpyDeviceToHost));
+        EL_CHECK_HIP(hipFree(sp.prof2));
+        sp.prof2 = nullptr;
+        const double nu_ = a[0] ? (double)a[0] : 1.0;
+        fprintf(stderr, "[screen prof] final per user (%llu users): expand %.0f | screen %.0f | rescore %.0f | sort+write %.0f cycles (100 MHz clock); "
+                        "records %.1f -> unmasked %.1f -> after the second-level screen %.1f\n", a[0], a[1] / nu_, a[2] / nu_, a[3] / nu_, a[4] / nu_,
+                a[5] / nu_, a[6] / nu_, a[7] / nu_);
+    }
     return 0;
 }
 
@@ -915,8 +1000,10 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     char* base = (char*)ws;
     ScreenParams sp;
     sp.t = p;
-    unsigned short* gib = (unsigned short*)base;
-    base += a256((size_t)p.I_local * FP * 2);
+    unsigned short* gib = (unsigned short*)base;                  // item side first: its place does not depend on n_users, so the
+    base += a256((size_t)p.I_local * FP * 2);                     // image survives from block to block (EL_TOPK_ITEMS_UNCHANGED)
+    sp.inorm = (float2*)base;
+    base += a256((size_t)p.I_local * 8);
     float* stats = (float*)base;
     base += a256(16);
     sp.smax = (float*)base;
@@ -933,6 +1020,10 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     base += a256((size_t)n_users * 4);
     sp.Eu = (float*)base;
     base += a256((size_t)n_users * 4);
+    sp.nuv = (float*)base;
+    base += a256((size_t)n_users * 4);
+    sp.duv = (float*)base;
+    base += a256((size_t)n_users * 4);
     const ScreenPolicy pol = screen_policy(p.k, p.I_local);
     sp.surv = pol.surv;
     sp.stride = pol.stride;
@@ -948,6 +1039,7 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     sp.Gib = gib;
     sp.stats = stats;
     sp.prof = nullptr;
+    sp.prof2 = nullptr;
     // The item side (bf16 image, max norm, max |bias|) depends on Gi / Bi only.  A caller that scores block after block of
     // users against an unchanged table says so (EL_TOPK_ITEMS_UNCHANGED); the claim is honoured only if this context's
     // previous screened call used the same workspace, tables and shape.
@@ -971,13 +1063,13 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
         const unsigned long long* rebuild = reinterpret_cast<const unsigned long long*>(ctl + 2);
         const unsigned pg = (unsigned)((p.I_local * (FP / 8) + 255) / 256);
         if (FP == 32)
-            EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<32>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild, sp.inorm);
         else if (FP == 64)
-            EL_LAUNCH("k_screen_prep", k_screen_prep<64>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<64>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild, sp.inorm);
         else if (FP == 128)
-            EL_LAUNCH("k_screen_prep", k_screen_prep<128>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<128>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild, sp.inorm);
         else
-            EL_LAUNCH("k_screen_prep", k_screen_prep<256>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild);
+            EL_LAUNCH("k_screen_prep", k_screen_prep<256>, dim3(pg), dim3(256), 0, st, p.Gi, p.Bi, p.I_local, p.F, gib, stats, rebuild, sp.inorm);
     } else {
         EL_CHECK_HIP(hipMemsetAsync(stats, 0, 8, st));
         EL_CHECK_HIP(hipMemsetAsync(stats + SCR_STAT_IB, 0, 8, st));

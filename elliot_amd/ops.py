@@ -472,7 +472,7 @@ def tune_table_layout(ctx, rows, F, compact=False):
 class BprmfDeviceState:
     """Gu/Gi/Bi + gradient accumulators + Adam slots in HBM (BPRMF_batch_model.py:39-44)."""
 
-    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None):
+    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None, fused_user_step=None):
         """compact_user_grads: user-row gradients as compact rows + per-user stamps (el_bprmf_state.uslot) instead of a dense
         [U,F] accumulator -- the dense Adam pass then reads a gradient only for the batch's users and re-zeroes nothing.
         None = automatic (TF-dense Adam on a user table of >= 64 MB with F % 4 == 0), True / False force it."""
@@ -485,6 +485,13 @@ class BprmfDeviceState:
             compact_user_grads = env == "1"
         self.compact = bool(self.opt == EL_OPT_ADAM_TF_DENSE and int(Gu.shape[1]) % 4 == 0 and optimizer != "sgd_dense" and
                             (big if compact_user_grads is None else compact_user_grads))
+
+        # fused user side (el_bprmf_state.Gu_next): segments + Keras Adam over every user row in ONE kernel, the new rows written to a
+        # second table that swaps roles with Gu after every step -- whenever the compact form applies (EL_FUSED_USER=0: the
+        # two-kernel form, which grads() / apply() always use)
+        self.fused = bool(self.compact and fused_user_step is not False and os.environ.get("EL_FUSED_USER", "1") != "0"
+                          and int(Gu.shape[1]) <= 512)
+        self.Gu_next = None
 
         def own(x, dt):
             if isinstance(x, np.ndarray):
@@ -500,7 +507,10 @@ class BprmfDeviceState:
         if self.opt == EL_OPT_ADAM_TF_DENSE and self.U * self.F * 4 >= (64 << 20):
             # the dense Adam pass streams these at once: one allocation, tuned distance (tune_table_layout)
             gap = tune_table_layout(ctx, self.U, self.F, compact=self.compact)
-            if self.compact:
+            if self.compact and self.fused:
+                (self.Gu, self.mGu, self.vGu, self.Gu_next), self._user_block = _strided_tables(self.U, self.F, 4, gap, dev)
+                self.gGu = None
+            elif self.compact:
                 (self.Gu, self.mGu, self.vGu), self._user_block = _strided_tables(self.U, self.F, 3, gap, dev)
                 self.gGu = None
             else:
@@ -509,6 +519,8 @@ class BprmfDeviceState:
             self.layout_gap = gap
         else:
             self.Gu = own(Gu, torch.float32)
+            if self.fused:
+                self.Gu_next = torch.empty_like(self.Gu)
             self.gGu = None if self.compact else z(self.Gu)
             self.mGu = z(self.Gu) if adam else None
             self.vGu = z(self.Gu) if adam else None
@@ -539,7 +551,16 @@ class BprmfDeviceState:
             mGi=self.mGi.data_ptr() if adam else None, vGi=self.vGi.data_ptr() if adam else None,
             mBi=self.mBi.data_ptr() if adam else None, vBi=self.vBi.data_ptr() if adam else None,
             tGu=self.tGu.data_ptr() if rows else None, tGi=self.tGi.data_ptr() if rows else None,
-            tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F)
+            tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F,
+            Gu_next=self.Gu_next.data_ptr() if self.Gu_next is not None else None)
+
+    def _swap_user_tables(self, steps=1):
+        """After `steps` fused train steps the current user table is the other one of the pair (include/elliot_hip.h, Gu_next)."""
+        if self.fused and steps % 2:
+            self.Gu, self.Gu_next = self.Gu_next, self.Gu
+            self._c.Gu, self._c.Gu_next = self.Gu.data_ptr(), self.Gu_next.data_ptr()
+            for c in getattr(self, "_c_clones", ()):
+                c.Gu, c.Gu_next = self._c.Gu, self._c.Gu_next
 
     @property
     def step(self):
@@ -584,7 +605,8 @@ class BprmfDeviceState:
         if self.compact:
             if algo == _lib.EL_BPR_ATOMIC:
                 raise ValueError("compact user-gradient rows need the sorted gradient path")
-            self.ensure_rows(B)
+            if not self.fused:
+                self.ensure_rows(B)
         if algo == _lib.EL_BPR_SORTED or (algo == _lib.EL_BPR_AUTO and B >= 2048) or self.compact:
             need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
             if self._ws is None or self._ws.numel() < need:
@@ -596,6 +618,7 @@ class BprmfDeviceState:
                                                self.opt, int(self.step), float(lr_t), _ptr(self.loss, torch.float64),
                                                algo, ws, ws_bytes),
               "el_bprmf_train_step")
+        self._swap_user_tables()
 
     def grads(self, u, i, j, l_w, l_b):
         """First half of train_step: loss + the summed row gradients of the batch (what OptimizerV2 receives after its segment
@@ -632,12 +655,17 @@ class BprmfDeviceState:
         """train_step on a batch that presort() ordered into `ws`: segment kernels + loss, then the optimiser -- the same kernels,
         the same results as train_step(algo="sorted")."""
         B = u.numel()
-        self.ensure_rows(B)
-        check(self.ctx.lib.el_bprmf_grads_presorted(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
-                                                    _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(l_w), float(l_b),
-                                                    int(self.step + 1), _ptr(self.loss, torch.float64), C.c_void_p(ws.data_ptr()),
-                                                    ws.numel()), "el_bprmf_grads_presorted")
-        self.apply(lr)
+        if self.opt not in (EL_OPT_ADAM_TF_DENSE, EL_OPT_SGD) or self.tGu is not None:
+            raise ValueError("train_step_presorted: the dense optimisers only (adam_tf_dense, sgd_dense)")
+        if not self.fused:
+            self.ensure_rows(B)
+        self.step += 1
+        check(self.ctx.lib.el_bprmf_train_step_presorted(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
+                                                         _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(lr), float(l_w),
+                                                         float(l_b), int(self.opt), int(self.step), float(adam_lr_t(lr, self.step)),
+                                                         _ptr(self.loss, torch.float64), C.c_void_p(ws.data_ptr()), ws.numel()),
+              "el_bprmf_train_step_presorted")
+        self._swap_user_tables()
 
     def train_loop(self, pos, events, B, seed, first_sample, lr, l_w, l_b, algo="auto"):
         """One epoch of `for batch in sampler.step(events, B): train_step(batch)` (BPRMF_batch.py:100-109) from a single
@@ -650,7 +678,8 @@ class BprmfDeviceState:
         algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
         lr_t = self._lr_t_host = np.array([adam_lr_t(lr, self.step + 1 + k) for k in range(steps)], dtype=np.float32)
         # (kept alive on self: the library may copy the table with an asynchronous memcpy on the stream)
-        self.ensure_rows(B)
+        if not self.fused:
+            self.ensure_rows(B)
         need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))) if (B >= 2048 or self.compact) else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
@@ -665,6 +694,7 @@ class BprmfDeviceState:
             C.c_void_p(self._ws.data_ptr()) if need else None, self._ws.numel() if need else 0,
             C.c_void_p(buf.data_ptr()), lneed, C.c_void_p(sampler_meta(self.ctx, pos).data_ptr())), "el_bprmf_train_loop")
         self.step += steps
+        self._swap_user_tables(steps)
         return steps
 
     def pop_loss(self):

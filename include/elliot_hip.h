@@ -38,7 +38,8 @@ typedef struct el_ctx el_ctx;
                             * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*
                             * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
-                            *    el_nmf_score_topk, el_gmf_item_image                                                    */
+                            *    el_nmf_score_topk, el_gmf_item_image; el_bprmf_state.Gu_next + el_bprmf_train_step_presorted;
+                            *    el_host_split_flags_state                                                             */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -148,6 +149,16 @@ typedef struct el_bprmf_state {
     int64_t* uslot;   /* [U] (step << 32) | slot */
     float* gGu_rows;  /* [gGu_cap, F] */
     int64_t gGu_cap;  /* rows of gGu_rows, >= the batch size of every step */
+    /* Optional second user table (NULL = off): with it, the SORTED gradient path and EL_OPT_ADAM_TF_DENSE, el_bprmf_train_step /
+     * el_bprmf_train_step_presorted run the user side of the step as ONE kernel -- every user row is read once (theta, m, v),
+     * the gradient of a row with triplets in the batch is formed in registers from its sorted segment (gathers of gamma_i,
+     * gamma_j), Keras' Adam moves the row, and the NEW value goes to Gu_next while Gu keeps the pre-update rows the item-side
+     * gradients still have to read.  No gradient row is written or re-read, the batch's user rows are read once instead of
+     * twice: ~1 GB of the 6.6 GB a step moves at the BASELINE configs[1] shape.  Same arithmetic in the same order as the
+     * two-kernel form (bit-identical tables).  AFTER SUCH A CALL THE CURRENT TABLE IS Gu_next: the caller swaps the two pointers
+     * before its next call (el_bprmf_train_loop does it per batch and leaves the current table in Gu when the number of batches
+     * is even, in Gu_next when it is odd).  F % 4 == 0, F <= 512, 16-byte aligned tables.                                  */
+    float* Gu_next;   /* [U,F] or NULL */
 } el_bprmf_state;
 
 /* How the duplicate-row gradient sum (OptimizerV2's segment-sum of IndexedSlices) is formed. */
@@ -226,6 +237,13 @@ int el_bprmf_presort(el_ctx* ctx, void* stream, const int32_t* u, const int32_t*
 int el_bprmf_grads_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                              const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                              float l_w, float l_b, int32_t step, double* loss_out, void* ws, size_t ws_bytes);
+
+/* el_bprmf_train_step on a batch that el_bprmf_presort already ordered into `ws` (the sampler, the key preparation and the radix
+ * sort read only the positives and the triplets, so a single GPU prepares the batch of step t + 1 on a side stream while step t
+ * runs): segment kernels + loss + optimiser, with the fused user-side kernel when st->Gu_next is given (see el_bprmf_state).  */
+int el_bprmf_train_step_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i,
+                                  const int32_t* j, int64_t B, float lr, float l_w, float l_b, int opt, int32_t step, float lr_t,
+                                  double* loss_out, void* ws, size_t ws_bytes);
 
 /* Step 4: optimiser alone on (Gu, local Gi, local Bi); opt = EL_OPT_ADAM_TF_DENSE or EL_OPT_SGD.  */
 int el_bprmf_apply(el_ctx* ctx, void* stream, const el_bprmf_state* st, float lr, int opt, int32_t step, float lr_t);

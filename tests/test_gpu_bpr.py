@@ -494,3 +494,58 @@ def test_pipelined_step_equals_the_sequential_step(ctx):
     for name in ("Gu", "Gi", "Bi"):
         x, y = cpu(getattr(a, name)), cpu(getattr(b, name))
         assert (np.abs(x - y) > 2e-6).mean() < 1e-4 and np.abs(x - y).max() < 5 * lr, name
+
+
+@pytest.mark.parametrize("F,U", [(128, 30000), (64, 5001), (256, 9000), (16, 777), (384, 2000)])
+def test_fused_user_side_equals_the_two_kernel_form_bit_for_bit(ctx, F, U):
+    """el_bprmf_state.Gu_next: user segments + Keras Adam over every user row in ONE kernel, the new rows written to the second
+    table (ping-pong).  Same operations in the same order as k_bpr_user_seg + k_adam_rows -- the user table, its Adam slots and the
+    item side come out BIT-identical over several steps (odd and even numbers of swaps; users without triplets, users with many; a
+    row count that is not a multiple of the rows a lane group owns); the loss differs by the order of its fp32 partial sums only.
+    Also through train_loop (the library swaps the pair per batch) and train_step_presorted."""
+    from elliot_amd.synthetic import zipf_csr
+    rs = np.random.RandomState(F + U)
+    I, B = 1500, 8192
+    indptr, indices = zipf_csr(U, I, mean_log=2.0, sigma_log=0.9, dmin=1, dmax=150, seed=F)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, fused_user_step=False)
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True)
+    assert b.fused and not a.fused and b.Gu_next is not None
+    for s in range(5):
+        n = B if s != 3 else 2500                                  # a short batch: most rows have no triplet
+        t = ops.bpr_sample(ctx, pos, n, seed=7, first_sample=s * B)
+        a.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        if s % 2:
+            ws = b.sort_workspace(n)
+            b.presort(t[0], t[1], t[2], ws)
+            b.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, ws)
+        else:
+            b.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        la, lb = a.pop_loss(), b.pop_loss()
+        assert abs(la - lb) <= 2e-6 * abs(la), (s, la, lb)
+        for name in ("Gu", "mGu", "vGu", "Gi", "mGi", "vGi", "Bi"):
+            x, y = getattr(a, name), getattr(b, name)
+            if s == 0 and name in ("Gu", "mGu", "vGu"):
+                # same inputs -> the same bits.  (From the second step on the INPUTS differ in the last bit: the item-side kernel, the
+                # same in both forms, combines the chunk-crossing segments of hot items with float atomics whose order varies
+                # from launch to launch.)
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (s, name)
+            else:                                                  # (Adam's m / (sqrt(v) + eps) amplifies a last-bit input difference where v ~ 0)
+                err = (x - y).abs()
+                assert float((err > 2e-6).float().mean()) < 1e-4 and float(err.max()) < 5 * lr, (s, name, float(err.max()))
+    # the epoch loop inside the library: 3 batches (an odd number of swaps), same Philox stream in both forms
+    a.train_loop(pos, 3 * B, B, 11, 0, lr, l_w, l_b)
+    b.train_loop(pos, 3 * B, B, 11, 0, lr, l_w, l_b)
+    la, lb = a.pop_loss(), b.pop_loss()
+    assert abs(la - lb) <= 1e-5 * abs(la)
+    assert float(((a.Gu - b.Gu).abs() > 4e-6).float().mean()) < 1e-4 and float((a.vGu - b.vGu).abs().max()) <= 1e-7
+    # grads() / apply() on the fused state take the two-kernel form and leave the pair alone: from equal tables, equal bits
+    b.Gu.copy_(a.Gu), b.mGu.copy_(a.mGu), b.vGu.copy_(a.vGu), b.Gi.copy_(a.Gi), b.mGi.copy_(a.mGi), b.vGi.copy_(a.vGi)
+    b.Bi.copy_(a.Bi), b.mBi.copy_(a.mBi), b.vBi.copy_(a.vBi)
+    t = ops.bpr_sample(ctx, pos, B, seed=9, first_sample=0)
+    for st in (a, b):
+        st.grads(t[0], t[1], t[2], l_w, l_b)
+        st.apply(lr)
+    assert torch.equal(a.Gu.view(torch.int32), b.Gu.view(torch.int32))
