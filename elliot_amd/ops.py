@@ -405,6 +405,9 @@ def tune_table_layout(ctx, rows, F, compact=False):
     cache = ctx.__dict__.setdefault("_layout_cache", {})
     if key in cache:
         return cache[key]
+    if os.environ.get("EL_LAYOUT_GAP_MIB"):                       # experiments: a fixed distance instead of the timed pick
+        cache[key] = int(float(os.environ["EL_LAYOUT_GAP_MIB"]) * (1 << 20))
+        return cache[key]
     if os.environ.get("EL_TUNE_LAYOUT", "1") == "0" or rows * F * 4 < (64 << 20):
         cache[key] = 0
         return 0
