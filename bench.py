@@ -636,6 +636,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     alg = {
         "k_adam_dense_Gu": 24.0 * rows_u * F,                 # theta, m, v read + write
         "k_adam_rows_Gu": 24.0 * rows_u * F,                  # the same pass reading compact gradient rows
+        "k_bpr_user_adam": 24.0 * rows_u * F + B * (8.0 * F + 28.0),   # user segments fused with the Adam pass: theta, m, v of every
+        #                                                        user row read + written once, gamma_i / gamma_j gathered per triplet
         "k_adam_dense_Gi": 24.0 * rows_i * F,
         "k_adam_dense3": 24.0 * ((rows_u + rows_i) * F + rows_i),   # small models: the three dense passes share one launch
         "k_bprmf_fwd_bwd": B * (24.0 * F + 28.0),             # 3 rows read + 3 gradient rows written (+ idx, bias)
