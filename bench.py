@@ -596,6 +596,24 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     prepare_topk()
     dt_topk, rep_topk = timed(ctx, world, topk_step, W, K)
 
+    # ---- the fp32-only MFMA kernel beside the screened one: its arithmetic IS the reference's fp32 matmul form, the screened
+    #      route returns the same bits after its exact re-score (tests/test_gpu_topk.py)
+    f32_entry = None
+    if world == 1 and not args.force_sharded and args.topk_algo == "auto" and F <= 256 and k <= 40:
+        def topk_f32_step():
+            s = (blk[0] % n_blocks) * Ub
+            blk[0] += 1
+            ops.score_topk(ctx, st.Gu, st.Gi, st.Bi, s, s + Ub, k, excl=pos, algo="mfma")
+        K32 = max(2, min(K, 4))
+        dt32, rep32 = timed(ctx, world, topk_f32_step, 1, K32)
+        n32 = dominant(rep32)[0]
+        s32 = rep32[n32][1] / K32 * 1e-3                       # all launches of the kernel in one block (it may split the items)
+        f32_entry = {"value": Ub * K32 / dt32, "unit": "users/s", "ms_per_step": dt32 / K32 * 1e3, "steps": K32,
+                     "repeats_ms_per_step": rep32.repeats_ms,
+                     "roofline": {"kernel": n32, "bound": "mfma", "achieved": 2.0 * Ub * I * F / s32 / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": 2.0 * Ub * I * F / s32 / 1e12 / MFMA_F32_PEAK_TFLOPS, "dtype": "f32",
+                                  "kernels_ms_per_step": {n: v[1] / K32 for n, v in rep32.items()}}}
+
     # ---- accuracy metrics from the index tensor: one block of users, synthetic held-out set -------------
     met = None
     if with_metrics and world == 1:
@@ -703,6 +721,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     }
     if fragile is not None:
         res["topk"]["fragile_users"] = fragile
+    if f32_entry is not None:
+        res["topk"]["fp32_mfma"] = f32_entry
     if coll_rep:
         res["collectives"] = coll_rep
     if met is not None:
@@ -843,7 +863,9 @@ def neumf_leg(args, ctx):
         it[0] += 1
         st.train_step(u, i, y, 0.001)
 
-    dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False)
+    # the timed region ends with st.sync(): under the deferred decay (el_nmf_state.row_last) the postponed every-row updates of
+    # the K steps are replayed there -- every (element, step) update of Keras' Adam is inside the timed region
+    dt, rep = timed(ctx, 1, step, W, K, finish=st.sync, events_in_timed_region=False)
     loss = st.pop_loss()
     ms = dt / K * 1e3
     # ---- full-catalogue scoring + top-k: el_nmf_score_topk on a block of users against the leg's whole catalogue.
@@ -881,10 +903,13 @@ def neumf_leg(args, ctx):
     ach = mlp_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
     emb_bytes = 24.0 * 2 * (U + I) * F                                 # Keras Adam moves every row of the 4 embedding tables
     ams = sum(v[1] for n, v in rep.items() if n.startswith("k_adam_dense")) / K
+    rows_ms = sum(v[1] for n, v in rep.items() if n in ("k_nmf_catchup", "k_nmf_apply_rows", "k_nmf_flush_rows")) / K
     return {"value": B * K / dt, "unit": "samples/s", "ms_per_step": ms,
             "workload": f"NeuMF d={F} (GMF + MLP {units}), {U} users x {I} items = the per-GPU shape of BASELINE configs[3] (10M x 1M over "
-                        f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: dense over "
-                        f"the four embedding tables)",
+                        f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: every row of "
+                        f"the four embedding tables moves at every step"
+                        + (f"; rows without a gradient are replayed bit for bit when next needed, the {K}-step region ends with the replay of "
+                           f"all of them)" if st.deferred else ", one dense pass per table and step)"),
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             **({"topk": tk} if tk is not None else {}),
             "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -893,6 +918,8 @@ def neumf_leg(args, ctx):
                          "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,
                          "step_TFLOPs_mlp": mlp_flops / (ms * 1e-3) / 1e12,
                          "adam_tables_GBs": emb_bytes / (ams * 1e-3) / 1e9 if ams > 0 else None,
+                         "embedding_rows_ms_per_step": rows_ms if st.deferred else None,
+                         "embedding_step_equivalent_GBs": emb_bytes / (rows_ms * 1e-3) / 1e9 if (st.deferred and rows_ms > 0) else None,
                          "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}
 
 

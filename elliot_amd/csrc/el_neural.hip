@@ -318,6 +318,147 @@ __global__ __launch_bounds__(256) void k_nmf_scatter(el_nmf_state st, const int3
     }
 }
 
+// ---- deferred decay of the embedding tables ---------------------------------------------------------------------------
+// Keras' Adam moves EVERY row of an embedding table at every step: m <- b1 m, v <- b2 v,
+// theta <- theta - lr_t m / (sqrt(v) + eps), gradient or not.  The eager form streams theta, g, m, v of all (U + I)(F + E)
+// parameters per step: 3.3 of the 10 ms of a step at 1.25 M x 1 M x 128, for a batch that touches a fifth of the rows.
+// For a row WITHOUT a gradient that update reads nothing but the row itself, so it can be postponed and replayed in
+// registers -- the same fp32 operations on the same operands in the same order, hence the same bits -- at the moment the row is
+// needed again: by a batch that contains it (k_nmf_catchup, before the forward pass reads it) or by anything that reads the
+// tables as a whole (k_nmf_flush_rows: scoring, weights(), a checkpoint).  row_last[side][r] = the optimiser step row r of
+// that side's tables is current at; lr_hist[s - hist_base] = lr_t of step s.  Every (element, step) update is still performed
+// exactly once; what disappears is the HBM round trip of the rows a step does not touch.
+//
+// One wave per (sample, side: 0 user / 1 item).  The first wave to stamp a row with this batch's claim number owns it: it
+// replays the row's missed steps (last, t-1] now and applies step t with the accumulated gradient row after the backward pass
+// (k_nmf_apply_rows); the other occurrences of the row do nothing.
+struct NmfRowTabs {
+    float* th[2];
+    float* g[2];
+    float* m[2];
+    float* v[2];
+    int D[2];
+    int n;
+};
+
+__device__ __forceinline__ NmfRowTabs nmf_row_tabs(const el_nmf_state& st, int side) {
+    NmfRowTabs r;
+    r.n = 0;
+    if (st.use_mf) {
+        r.th[r.n] = st.tab[side], r.g[r.n] = st.gtab[side], r.m[r.n] = st.mtab[side], r.v[r.n] = st.vtab[side], r.D[r.n] = st.F;
+        r.n++;
+    }
+    if (st.use_mlp) {
+        r.th[r.n] = st.tab[2 + side], r.g[r.n] = st.gtab[2 + side], r.m[r.n] = st.mtab[2 + side], r.v[r.n] = st.vtab[2 + side], r.D[r.n] = st.E;
+        r.n++;
+    }
+    return r;
+}
+
+// steps (s0, s1] without a gradient on the elements f = f0 + lane + 64 q (q < Q, f < D) of one row; lr_hist is indexed from s0 + 1
+template <int Q>
+__device__ __forceinline__ void nmf_replay_chunk(float* __restrict__ th, float* __restrict__ m, float* __restrict__ v, int D, int f0,
+                                                 int lane, const float* __restrict__ lr_from, int nsteps) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    float a[Q], mm[Q], vv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int f = f0 + lane + 64 * q;
+        a[q] = mm[q] = vv[q] = 0.f;
+        if (f < D) a[q] = th[f], mm[q] = m[f], vv[q] = v[f];
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const float lr = lr_from[s];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) el_adam_elem(a[q], mm[q], vv[q], 0.0f, lr, b1, b2, omb1, omb2, eps);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int f = f0 + lane + 64 * q;
+        if (f < D) th[f] = a[q], m[f] = mm[q], v[f] = vv[q];
+    }
+}
+
+__device__ __forceinline__ void nmf_replay_row(float* th, float* m, float* v, int D, int lane, const float* lr_from, int nsteps) {
+    if (D <= 64) nmf_replay_chunk<1>(th, m, v, D, 0, lane, lr_from, nsteps);
+    else if (D <= 128) nmf_replay_chunk<2>(th, m, v, D, 0, lane, lr_from, nsteps);
+    else
+        for (int f0 = 0; f0 < D; f0 += 256) nmf_replay_chunk<4>(th, m, v, D, f0, lane, lr_from, nsteps);
+}
+
+__global__ __launch_bounds__(256) void k_nmf_catchup(el_nmf_state st, const int32_t* __restrict__ bu, const int32_t* __restrict__ bi,
+                                                     int64_t n, int32_t t, int32_t claim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= 2 * n) return;
+    const int side = p >= n ? 1 : 0;
+    const int64_t b = p - (side ? n : 0);
+    const int64_t row = side ? bi[b] : bu[b];
+    int own = 0, last = 0;
+    if (lane == 0) {
+        own = atomicExch(st.row_stamp[side] + row, claim) != claim;
+        st.row_own[(int64_t)side * st.Bmax + b] = (uint8_t)own;
+        if (own) last = st.row_last[side][row];
+    }
+    own = __builtin_amdgcn_readfirstlane(own);
+    last = __builtin_amdgcn_readfirstlane(last);
+    const int nsteps = (t - 1) - last;
+    if (!own || nsteps <= 0) return;
+    const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
+    const NmfRowTabs rt = nmf_row_tabs(st, side);
+    for (int k = 0; k < rt.n; ++k) {
+        const int64_t off = row * rt.D[k];
+        nmf_replay_row(rt.th[k] + off, rt.m[k] + off, rt.v[k] + off, rt.D[k], lane, lr_from, nsteps);
+    }
+    if (lane == 0) st.row_last[side][row] = t - 1;
+}
+
+// step t on the rows this batch owns: Keras sparse apply with the accumulated gradient row (duplicates already summed); the
+// gradient row is zero again afterwards
+__global__ __launch_bounds__(256) void k_nmf_apply_rows(el_nmf_state st, const int32_t* __restrict__ bu, const int32_t* __restrict__ bi,
+                                                        int64_t n, int32_t t, float lr_t) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= 2 * n) return;
+    const int side = p >= n ? 1 : 0;
+    const int64_t b = p - (side ? n : 0);
+    if (!st.row_own[(int64_t)side * st.Bmax + b]) return;
+    const int64_t row = side ? bi[b] : bu[b];
+    const NmfRowTabs rt = nmf_row_tabs(st, side);
+    for (int k = 0; k < rt.n; ++k) {
+        const int64_t off = row * rt.D[k];
+        float *th = rt.th[k] + off, *g = rt.g[k] + off, *m = rt.m[k] + off, *v = rt.v[k] + off;
+        for (int f = lane; f < rt.D[k]; f += 64) {
+            float a = th[f], mm = m[f], vv = v[f];
+            const float gg = g[f];
+            el_adam_elem(a, mm, vv, gg, lr_t, b1, b2, omb1, omb2, eps);
+            th[f] = a, m[f] = mm, v[f] = vv;
+            if (gg != 0.f) g[f] = 0.f;
+        }
+    }
+    if (lane == 0) st.row_last[side][row] = t;
+}
+
+// every row of one side up to step t (one wave per row)
+__global__ __launch_bounds__(256) void k_nmf_flush_rows(el_nmf_state st, int side, int64_t rows, int32_t t) {
+    const int lane = threadIdx.x & 63;
+    const NmfRowTabs rt = nmf_row_tabs(st, side);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int last = st.row_last[side][row];
+        const int nsteps = t - last;
+        if (nsteps <= 0) continue;
+        const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
+        for (int k = 0; k < rt.n; ++k) {
+            const int64_t off = row * rt.D[k];
+            nmf_replay_row(rt.th[k] + off, rt.m[k] + off, rt.v[k] + off, rt.D[k], lane, lr_from, nsteps);
+        }
+        if (lane == 0) st.row_last[side][row] = t;
+    }
+}
+
+__global__ void k_nmf_hist_set(float* hist, int32_t idx, float lr_t) { hist[idx] = lr_t; }
+
 // ---- host -------------------------------------------------------------------------------------------------------
 static unsigned g1(int64_t n, el_ctx* ctx) {
     int64_t b = (n + 255) / 256;
@@ -349,6 +490,51 @@ static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
         EL_REQUIRE(st->ghw && st->mhw && st->vhw, "el_nmf: head optimiser buffers missing");
         if (st->use_mlp) EL_REQUIRE(st->dX0 != nullptr, "el_nmf: dX0 missing");
     }
+    if (st->row_last[0] || st->row_last[1]) {
+        EL_REQUIRE(st->row_last[0] && st->row_last[1] && st->row_stamp[0] && st->row_stamp[1] && st->row_own && st->lr_hist &&
+                   st->lr_hist_cap >= 2, "el_nmf: deferred decay needs row_last[2], row_stamp[2], row_own and lr_hist");
+        EL_REQUIRE(st->opt_step >= 0 && st->flushed_step >= 0 && st->flushed_step <= st->opt_step && st->hist_base >= 1,
+                   "el_nmf: deferred-decay counters corrupt (zero-initialise opt_step / flushed_step / claim_seq, hist_base = 1)");
+    }
+    return 0;
+}
+
+static inline bool nmf_deferred(const el_nmf_state* st) { return st->row_last[0] != nullptr; }
+
+// every embedding row current at st->opt_step (no-op in the eager form and when nothing is pending)
+static int nmf_sync(el_ctx* ctx, hipStream_t s, el_nmf_state* st) {
+    if (!nmf_deferred(st) || st->flushed_step >= st->opt_step) return 0;
+    const int64_t rows[2] = {st->U, st->I};
+    for (int side = 0; side < 2; ++side) {
+        int64_t g = (rows[side] + 3) / 4;
+        const int64_t cap = (int64_t)ctx->cus * 32;
+        if (g > cap) g = cap;
+        EL_LAUNCH("k_nmf_flush_rows", k_nmf_flush_rows, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, s, *st, side, rows[side], st->opt_step);
+    }
+    EL_CHECK_LAUNCH();
+    st->flushed_step = st->opt_step;
+    st->hist_base = st->opt_step + 1;                    // steps <= opt_step are never replayed again
+    return 0;
+}
+
+extern "C" int el_nmf_sync_tables(el_ctx* ctx, void* stream, el_nmf_state* st) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = nmf_check(st, 1, false)) return rc;
+    return nmf_sync(ctx, (hipStream_t)stream, st);
+}
+
+// deferred decay, start of step t = opt_step + 1: record lr_t, elect the owners of the batch's rows and bring those rows to t - 1
+static int nmf_begin_rows(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n) {
+    const int32_t t = st->opt_step + 1;
+    st->claim_seq += 1;
+    if (st->claim_seq <= 0) {                            // 2^31 gradient evaluations: start the claim numbers again
+        EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[0], 0, (size_t)st->U * 4, s));
+        EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[1], 0, (size_t)st->I * 4, s));
+        st->claim_seq = 1;
+    }
+    EL_LAUNCH("k_nmf_catchup", k_nmf_catchup, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, s, *st, u, i, n, t, st->claim_seq);
+    EL_CHECK_LAUNCH();
+    st->batch_u = u, st->batch_i = i, st->batch_n = n;
     return 0;
 }
 
@@ -378,13 +564,14 @@ static int nmf_forward(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const
 }
 
 // probabilities of the pairs (u[b], i[b]) -- get_recs (neural_matrix_factorization_model.py:120-144)
-extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,
                               int64_t n, float* out_prob) {
     if (int rc = el_bind(ctx)) return rc;
     if (n == 0) return 0;
     if (int rc = nmf_check(st, n, false)) return rc;
     EL_REQUIRE(u && i && out_prob, "el_nmf_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = nmf_sync(ctx, s, st)) return rc;
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
     EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, (const float*)nullptr, n, 0, out_prob, (double*)nullptr, n);
     EL_CHECK_LAUNCH();
@@ -393,10 +580,12 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st,
 
 // forward, BinaryCrossentropy (mean over n_div samples: n_div = n, or the global batch when several ranks share a step),
 // backward: every gradient buffer of the state is complete on exit
-static int nmf_grads(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, const float* label,
+static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, const float* label,
                      int64_t n, int64_t n_div, double* loss_out) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
+    if (nmf_deferred(st))
+        if (int rc = nmf_begin_rows(ctx, s, st, u, i, n)) return rc;
     if (int rc = nmf_forward(ctx, s, st, u, i, n, true)) return rc;
     EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
     if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
@@ -429,13 +618,25 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const i
 }
 
 // Keras Adam on every variable (dense apply; the embedding gradients are dense accumulators, zero again on exit)
-static int nmf_apply(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, float lr_t) {
+static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     const int64_t rows[4] = {st->U, st->I, st->U, st->I};
     const int64_t dims[4] = {st->F, st->F, st->E, st->E};
-    for (int t = 0; t < 4; ++t) {
+    if (nmf_deferred(st)) {
+        EL_REQUIRE(st->batch_u && st->batch_i && st->batch_n >= 1, "el_nmf_apply: deferred decay applies the rows of the preceding el_nmf_grads");
+        const int32_t t = st->opt_step + 1;
+        if (t - st->hist_base >= st->lr_hist_cap) {                 // history full: bring every row to t - 1, restart the history at t
+            // (the batch's own rows are at t - 1 already; the flush leaves them alone)
+            if (int rc = nmf_sync(ctx, s, st)) return rc;
+        }
+        EL_LAUNCH("k_nmf_hist_set", k_nmf_hist_set, dim3(1), dim3(1), 0, s, st->lr_hist, t - st->hist_base, lr_t);
+        EL_LAUNCH("k_nmf_apply_rows", k_nmf_apply_rows, dim3((unsigned)((2 * st->batch_n + 3) / 4)), dim3(256), 0, s, *st, st->batch_u,
+                  st->batch_i, st->batch_n, t, lr_t);
+        st->batch_u = st->batch_i = nullptr, st->batch_n = 0;
+    }
+    for (int t = 0; t < 4 && !nmf_deferred(st); ++t) {
         const bool on = (t < 2) ? st->use_mf : st->use_mlp;
         if (!on) continue;
         const int64_t cnt = rows[t] * dims[t];
@@ -457,30 +658,36 @@ static int nmf_apply(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, float l
         EL_LAUNCH("k_adam_apply_dense", k_adam_apply_dense, dim3(1), dim3(256), 0, s, st->hb, st->ghb, st->mhb, st->vhb, (int64_t)1,
                   lr_t, b1, b2, eps, 0);
     EL_CHECK_LAUNCH();
+    st->opt_step += 1;
+    if (!nmf_deferred(st)) st->flushed_step = st->opt_step;
     return 0;
 }
 
-extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,
                                  const float* label, int64_t n, int32_t step, float lr_t, double* loss_out) {
     if (int rc = el_bind(ctx)) return rc;
     if (n == 0) return 0;
     if (int rc = nmf_check(st, n, true)) return rc;
     EL_REQUIRE(u && i && label && loss_out && step >= 1, "el_nmf_train_step: bad arguments");
+    if (nmf_deferred(st)) EL_REQUIRE(step == st->opt_step + 1, "el_nmf_train_step: step %d does not follow the state's %d applied steps", (int)step, (int)st->opt_step);
     if (int rc = nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n, loss_out)) return rc;
     return nmf_apply(ctx, (hipStream_t)stream, st, lr_t);
 }
 
-extern "C" int el_nmf_grads(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+extern "C" int el_nmf_grads(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,
                             const float* label, int64_t n, int64_t n_global, double* loss_out) {
     if (int rc = el_bind(ctx)) return rc;
     if (int rc = nmf_check(st, n, true)) return rc;
     EL_REQUIRE(n >= 1 && n_global >= n && u && i && label && loss_out, "el_nmf_grads: bad arguments");
+    EL_REQUIRE(!nmf_deferred(st) || n_global == n, "el_nmf_grads: a batch shared with other ranks (n_global > n) cannot use the deferred "
+               "decay -- the rows other ranks' samples move are not known here; leave el_nmf_state.row_last NULL");
     return nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n_global, loss_out);
 }
 
-extern "C" int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step, float lr_t) {
+extern "C" int el_nmf_apply(el_ctx* ctx, void* stream, el_nmf_state* st, int32_t step, float lr_t) {
     if (int rc = el_bind(ctx)) return rc;
     if (int rc = nmf_check(st, 1, true)) return rc;
     EL_REQUIRE(step >= 1, "el_nmf_apply: step >= 1");
+    if (nmf_deferred(st)) EL_REQUIRE(step == st->opt_step + 1, "el_nmf_apply: step %d does not follow the state's %d applied steps", (int)step, (int)st->opt_step);
     return nmf_apply(ctx, (hipStream_t)stream, st, lr_t);
 }

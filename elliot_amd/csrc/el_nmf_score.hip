@@ -548,7 +548,9 @@ static int ns_launch(const NsParams& p, int64_t n_users, int nsplit, hipStream_t
     return 0;
 }
 
-extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, const el_nmf_state* st, int64_t u_start, int64_t u_stop,
+extern "C" int el_nmf_sync_tables(el_ctx* ctx, void* stream, el_nmf_state* st);      // el_neural.hip
+
+extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, int64_t u_start, int64_t u_stop,
                                  int64_t item_offset, int64_t I_local, const int64_t* excl_indptr, const int32_t* excl_indices,
                                  const int64_t* cand_indptr, const int32_t* cand_indices, int32_t k, int32_t* out_idx,
                                  float* out_val, int flags, void* ws, size_t ws_bytes) {
@@ -571,6 +573,7 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, const el_nmf_state* 
     EL_REQUIRE(((uintptr_t)ws & 15) == 0, "el_nmf_score_topk: workspace must be 16-byte aligned");
     EL_REQUIRE(!st->use_mf || (((uintptr_t)st->tab[1] & 15) == 0), "el_nmf_score_topk: item MF table must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = el_nmf_sync_tables(ctx, stream, st)) return rc;            // deferred decay: every row current before it is read
     char* base = (char*)ws;
     u64* ctl = (u64*)(base + L.ctl);
     // ---- item side.  The small packed images are rebuilt every call (microseconds); PI (I x H1 projection) only when the caller

@@ -912,10 +912,16 @@ class NmfDeviceState:
     weights: dict with optional "Umf" [U,F], "Imf" [I,F] (MF branch), "Umlp" [U,E], "Imlp" [I,E], "W" list of
     [in,out] kernels and "b" list of biases (MLP branch), "hw" head weights [F + units[-1]] and optional "hb" [1]."""
 
-    def __init__(self, ctx, weights, max_batch, dropout=0.0, dropout_seed=42):
+    _LR_HIST = 1 << 16          # optimiser steps of lr_t history kept on the device by the deferred decay
+
+    def __init__(self, ctx, weights, max_batch, dropout=0.0, dropout_seed=42, deferred=None):
+        """deferred: Keras' every-row Adam decay of the embedding tables is postponed per row and replayed bit for bit when the
+        row is next needed (include/elliot_hip.h, el_nmf_state.row_last).  None = on unless EL_NMF_DEFERRED=0; a data-parallel
+        owner that all-reduces gtab of replicated tables turns it off (set_deferred(False); parallel.ShardedNmf does)."""
         self.ctx = ctx
         dev = ctx.device
         self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
+        self.deferred = (os.environ.get("EL_NMF_DEFERRED", "1") != "0") if deferred is None else bool(deferred)
         f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) if isinstance(x, np.ndarray) \
             else x.to(device=dev, dtype=torch.float32).contiguous().clone()
         self.use_mf = "Umf" in weights
@@ -973,6 +979,45 @@ class NmfDeviceState:
             act=a4(self.act), dact=a4(self.dact), ws=self._ws.data_ptr(), ws_bytes=self._ws.numel(),
             dropout=self.dropout, drop_step=0, drop_seed=self.dropout_seed & 0xFFFFFFFFFFFFFFFF)
         self._drop_calls = 0
+        self._c.hist_base = 1
+        if self.deferred:
+            self._alloc_deferred()
+
+    def _alloc_deferred(self):
+        dev, c = self.ctx.device, self._c
+        zi = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        self._row_last, self._row_stamp = [zi(self.U), zi(self.I)], [zi(self.U), zi(self.I)]
+        if self.step:
+            for t in self._row_last:
+                t.fill_(self.step)                                    # switched on mid-run: every row is current
+        self._row_own = torch.zeros(2 * self.Bmax, dtype=torch.uint8, device=dev)
+        self._lr_hist = torch.zeros(self._LR_HIST, dtype=torch.float32, device=dev)
+        c.row_last = (C.c_void_p * 2)(*[t.data_ptr() for t in self._row_last])
+        c.row_stamp = (C.c_void_p * 2)(*[t.data_ptr() for t in self._row_stamp])
+        c.row_own, c.lr_hist, c.lr_hist_cap = self._row_own.data_ptr(), self._lr_hist.data_ptr(), self._LR_HIST
+        c.hist_base, c.claim_seq = self.step + 1, 0
+        c.opt_step = c.flushed_step = self.step
+
+    def sync(self):
+        """Deferred decay: replay what is pending so that tab / mtab / vtab hold every row at the current step (no-op otherwise).
+        Called by everything in this class that reads the tables; call it before reading the tensors directly."""
+        if self.deferred:
+            check(self.ctx.lib.el_nmf_sync_tables(self.ctx.handle, self.ctx.stream(), C.byref(self._c)), "el_nmf_sync_tables")
+
+    def set_deferred(self, on):
+        on = bool(on)
+        if on == self.deferred:
+            return
+        if not on:
+            self.sync()
+            self.deferred = False
+            c = self._c
+            c.row_last, c.row_stamp = (C.c_void_p * 2)(None, None), (C.c_void_p * 2)(None, None)
+            c.row_own = c.lr_hist = None
+            self._row_last = self._row_stamp = self._row_own = self._lr_hist = None
+        else:
+            self.deferred = True
+            self._alloc_deferred()
 
     def _alloc_activations(self, B):
         """Activation / backward buffers for batches of up to B samples (+ the GEMM workspace sized for them)."""
@@ -1007,12 +1052,16 @@ class NmfDeviceState:
         c = self._c
         c.Bmax, c.X0, c.dX0, c.MF, c.dlogit = self.Bmax, p(self.X0), p(self.dX0), p(self.MF), p(self.dlogit)
         c.act, c.dact, c.ws, c.ws_bytes = a4(self.act), a4(self.dact), self._ws.data_ptr(), self._ws.numel()
+        if self.deferred:
+            self._row_own = torch.zeros(2 * self.Bmax, dtype=torch.uint8, device=self.ctx.device)
+            c.row_own = self._row_own.data_ptr()
 
     def _next_mask(self):
         self._drop_calls += 1                                        # a fresh dropout mask per gradient evaluation
         self._c.drop_step = self._drop_calls & 0x7FFFFFFF
 
     def weights(self):
+        self.sync()
         out = {}
         for n, t in zip(["Umf", "Imf", "Umlp", "Imlp"], self.tab):
             if t is not None:
@@ -1040,6 +1089,11 @@ class NmfDeviceState:
         state's buffers (replicated_grads() lists the ones a data-parallel caller has to all-reduce)."""
         n = u.numel()
         self._next_mask()
+        if self.deferred and n_global is not None and int(n_global) != n:
+            # a step shared with other ranks: the replicated tables take gradient rows of samples this rank never saw (all-reduce
+            # of gtab), so which rows move is not known from the local batch -- back to the eager every-row passes
+            self.set_deferred(False)
+        self._batch_keep = (u, i)                                    # deferred decay: el_nmf_apply walks the batch's rows again
         check(self.ctx.lib.el_nmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
                                         _ptr(i, torch.int32), _ptr(label, torch.float32), int(n),
                                         int(n if n_global is None else n_global), _ptr(self.loss, torch.float64)), "el_nmf_grads")
@@ -1103,6 +1157,7 @@ class NmfDeviceState:
     def _dot_tables(self, items_unchanged):
         """The MF-only network (GMF; NeuMF with is_mlp_train False) is sigmoid(<Umf[u], Imf[i] * h> (+ b)): tables for the fused
         dot-product top-k kernels -- the item image Imf * h (el_gmf_item_image) and a constant bias row for the Dense(1) bias."""
+        self.sync()
         img = getattr(self, "_gmf_image", None)
         if img is None or not items_unchanged:
             if img is None:

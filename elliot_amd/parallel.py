@@ -603,6 +603,10 @@ class ShardedNmf:
         self.backend = backend
         self.coll = coll or _Collectives()
         self.shard = shard
+        if hasattr(backend, "set_deferred"):
+            # the replicated tables take gradients of OTHER ranks' samples through the all-reduce: which rows moved is not known
+            # from the local batch, so the per-row deferred decay of ops.NmfDeviceState is off and every step streams every row
+            backend.set_deferred(False)
 
     def train_step(self, u, i, label, lr, n_global=None):
         be, coll = self.backend, self.coll

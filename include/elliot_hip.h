@@ -39,7 +39,8 @@ typedef struct el_ctx el_ctx;
                             * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
                             *    el_nmf_score_topk, el_gmf_item_image; el_bprmf_state.Gu_next + el_bprmf_train_step_presorted;
-                            *    el_host_split_flags_state                                                             */
+                            *    el_host_split_flags_state; el_nmf_state ends in the deferred-decay fields (row_last ..
+                            *    batch_n) and the el_nmf_* calls take it non-const; el_nmf_sync_tables                */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -452,6 +453,24 @@ typedef struct el_nmf_state {
      * counter (sample row, column / 4, drop_step, layer) and key drop_seed; the caller advances drop_step per step.
      * TensorFlow's own random stream cannot be reproduced; the distribution is.  0 = off (the reference's default). */
     float dropout; int32_t drop_step; uint64_t drop_seed;
+    /* Deferred decay of the embedding tables (optional; row_last[0] == NULL = the eager form: every step streams theta, g, m, v
+     * of every row).  Keras' Adam moves EVERY row of an embedding table at every step -- m <- b1 m, v <- b2 v,
+     * theta <- theta - lr_t m / (sqrt(v) + eps) -- gradient or not.  For a row without a gradient that update
+     * reads nothing but the row itself, so the library postpones it and replays the missed steps in registers -- the same fp32
+     * operations on the same operands in the same order, hence the same bits -- when a batch contains the row again or when the
+     * tables are read as a whole (el_nmf_forward, el_nmf_score_topk and el_nmf_sync_tables bring every row up to date first).
+     * A caller that reads tab[] / mtab[] / vtab[] itself calls el_nmf_sync_tables before; one that all-reduces gtab[] of a
+     * replicated table over several ranks (el_nmf_grads / el_nmf_apply) leaves the feature off: the rows of other ranks'
+     * samples are not known here.  With it on, every el_nmf_grads is followed by its el_nmf_apply.
+     *   row_last[0] int32[U], row_last[1] int32[I]   zero-initialised: the optimiser step the row is current at
+     *   row_stamp[0] int32[U], row_stamp[1] int32[I] zero-initialised scratch
+     *   row_own      uint8[2 * Bmax]                 scratch
+     *   lr_hist      float[lr_hist_cap]              the library records lr_t per step here (cap >= 2; when it is full every
+     *                                                row is brought up to date and the history restarts)
+     *   hist_base = 1, opt_step = flushed_step = claim_seq = 0, batch_* = NULL/0 at creation; maintained by the library.      */
+    int32_t* row_last[2]; int32_t* row_stamp[2]; uint8_t* row_own; float* lr_hist;
+    int32_t lr_hist_cap, hist_base, opt_step, flushed_step, claim_seq;
+    const int32_t* batch_u; const int32_t* batch_i; int64_t batch_n;
 } el_nmf_state;
 
 /* Replaces: pointwise_pos_neg_sampler.Sampler.step (dataset/samplers/pointwise_pos_neg_sampler.py:26-50):
@@ -467,13 +486,13 @@ int el_pointwise_sample_meta(el_ctx* ctx, void* stream, const int64_t* pos_indpt
 
 /* Replaces: NeuralMatrixFactorizationModel.get_recs / GeneralizedMatrixFactorizationModel.get_recs on an
  * explicit pair list (neural_matrix_factorization_model.py:120-144): out_prob[b] = sigmoid(...) of (u[b], i[b]). */
-int el_nmf_forward(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+int el_nmf_forward(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,
                    int64_t n, float* out_prob);
 
 /* Replaces: train_step of both models (neural_matrix_factorization_model.py:96-106;
  * generalized_matrix_factorization_model.py:68-79): forward, keras BinaryCrossentropy (batch mean), backward,
  * Adam.  label: float[n] in {0,1}.  loss_out: device double[1], loss is ADDED.                          */
-int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+int el_nmf_train_step(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,
                       const float* label, int64_t n, int32_t step, float lr_t, double* loss_out);
 
 /* Multi-GPU form of the step (data parallel over samples, item tables sharded): el_nmf_grads = forward +
@@ -481,9 +500,14 @@ int el_nmf_train_step(el_ctx* ctx, void* stream, const el_nmf_state* st, const i
  * buffer of the state complete on exit; the caller all-reduces the gradients of the replicated variables (user tables,
  * Dense layers, head) over RCCL; el_nmf_apply = Keras Adam on every variable.  grads + apply with n_global = n is
  * el_nmf_train_step.                                                                                            */
-int el_nmf_grads(el_ctx* ctx, void* stream, const el_nmf_state* st, const int32_t* u, const int32_t* i,
+int el_nmf_grads(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,
                  const float* label, int64_t n, int64_t n_global, double* loss_out);
-int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step, float lr_t);
+int el_nmf_apply(el_ctx* ctx, void* stream, el_nmf_state* st, int32_t step, float lr_t);
+
+/* Deferred decay (el_nmf_state.row_last): replays the postponed gradient-free Adam steps of every embedding row so that tab[],
+ * mtab[], vtab[] hold exactly what the eager form holds after st->opt_step steps.  No-op when the feature is off or nothing is
+ * pending.  The state is not const in the el_nmf_* calls: the library keeps its step counters in it.                         */
+int el_nmf_sync_tables(el_ctx* ctx, void* stream, el_nmf_state* st);
 
 /* Full-catalogue scoring fused with the masked top-k for NeuMF.
  * Replaces: NeuMF.get_recommendations' [Ub, I] index grids (neural/NeuMF/neural_matrix_factorization.py:111-119) +
@@ -505,7 +529,7 @@ int el_nmf_apply(el_ctx* ctx, void* stream, const el_nmf_state* st, int32_t step
  *   ws   : el_nmf_score_ws_bytes(...) bytes, 16-byte aligned (item projection I_local x units[0] x 4 bytes + per-block scratch)  */
 int el_nmf_score_supported(const el_nmf_state* st, int32_t k);
 size_t el_nmf_score_ws_bytes(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int32_t k, int with_cand);
-int el_nmf_score_topk(el_ctx* ctx, void* stream, const el_nmf_state* st, int64_t u_start, int64_t u_stop,
+int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, int64_t u_start, int64_t u_stop,
                       int64_t item_offset, int64_t I_local, const int64_t* excl_indptr, const int32_t* excl_indices,
                       const int64_t* cand_indptr, const int32_t* cand_indices, int32_t k, int32_t* out_idx, float* out_val,
                       int flags, void* ws, size_t ws_bytes);

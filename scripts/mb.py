@@ -134,6 +134,7 @@ def main():
                 torch.cuda.synchronize(); ctx.timing_report(); t0 = time.perf_counter()
             u, i, y = ops.pointwise_sample(ctx, pos, a.batch, seed=3, first_sample=it * a.batch)
             st.train_step(u, i, y, 0.001)
+        st.sync()                                        # deferred decay: the postponed row updates belong to the timed steps
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.iters
         rep, tot = ctx.timing_report(), 0

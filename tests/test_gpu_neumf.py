@@ -239,3 +239,72 @@ def test_pointwise_replay_sampler_emits_the_reference_stream(ctx, golden):
     u, i, y = (np.concatenate([b[k] for b in got]) for k in range(3))
     assert u.dtype == np.int32 and y.dtype == np.float32
     assert np.array_equal(u, g["u"]) and np.array_equal(i, g["i"]) and np.array_equal(y, g["b"].astype(np.float32))
+
+
+def _adam_np(th, m, v, g, lr_t):
+    """el_adam_elem (csrc/el_common.h) in NumPy fp32: every operation rounded on its own, the order of the kernel."""
+    f = np.float32
+    b1, b2, eps = f(0.9), f(0.999), f(1e-7)
+    m[...] = m * b1 + g * (f(1) - b1)
+    v[...] = v * b2 + (g * g) * (f(1) - b2)
+    th[...] = th - (f(lr_t) * m) / (np.sqrt(v) + eps)
+
+
+@pytest.mark.parametrize("model,F,hist", [("neumf", 128, None), ("neumf", 40, 4), ("gmf", 64, 3), ("neumf", 300, 5)])
+def test_deferred_decay_replays_the_every_row_adam_bit_for_bit(ctx, model, F, hist, monkeypatch):
+    """The embedding tables under the deferred decay (el_nmf_state.row_last) against an EAGER shadow on the host that moves every
+    row at every step with the device's own gradient rows: theta, m, v of all four tables bit-identical whenever the tables are
+    read -- after long stretches without a read (rows untouched for 9 steps are replayed at once), after reads in the middle
+    (forward / weights / scoring sync), with duplicate rows in a batch, rows that are never touched, and with a 3..5-step lr
+    history that fills up and restarts.  F = 300 takes the chunked row loop, 40 the sub-wave one."""
+    if hist:
+        monkeypatch.setattr(ops.NmfDeviceState, "_LR_HIST", hist)
+    U, I, B, lr = 900, 700, 256, 0.01
+    w0 = on.init_neumf(U, I, F, 11, units=[64, 32, 16]) if model == "neumf" else on.init_gmf(U, I, F, 11)
+    st = ops.NmfDeviceState(ctx, w0, max_batch=B, deferred=True)
+    assert st.deferred
+    names = [n for n in ("Umf", "Imf", "Umlp", "Imlp") if n in w0]
+    tix = {"Umf": 0, "Imf": 1, "Umlp": 2, "Imlp": 3}
+    sh = {n: [np.array(w0[n], np.float32, copy=True), np.zeros_like(w0[n], dtype=np.float32), np.zeros_like(w0[n], dtype=np.float32)] for n in names}
+    rs = np.random.RandomState(3)
+    d = ctx.device
+
+    def check(tag):
+        st.sync()
+        for n in names:
+            t = tix[n]
+            for got, exp, what in zip((st.tab[t], st.mtab[t], st.vtab[t]), sh[n], "tmv"):
+                got = cpu(got)
+                assert np.array_equal(got, exp), (tag, n, what, int((got != exp).sum()), float(np.abs(got - exp).max()))
+
+    for step in range(1, 25):
+        n = B if step % 5 else 17
+        u = rs.randint(0, U // 3 if step % 2 else U, n).astype(np.int32)             # a third of the users: the rest wait
+        i = (rs.zipf(1.3, n) % (I - 50)).astype(np.int32)                             # hot items; the last 50 never appear
+        y = rs.randint(0, 2, n).astype(np.float32)
+        st.grads(torch.from_numpy(u).to(d), torch.from_numpy(i).to(d), torch.from_numpy(y).to(d))
+        g = {nm: cpu(st.gtab[tix[nm]]) for nm in names}                               # the gradient rows the apply will consume
+        st.apply(lr)
+        for nm in names:
+            _adam_np(*sh[nm], g[nm], np.float32(ops.adam_lr_t(lr, step)))
+            assert not cpu(st.gtab[tix[nm]]).any()                                    # accumulators zero again
+        if step in (1, 2, 11, 12, 21):
+            check(step)
+        if step == 15:                                                                # a read through the library syncs by itself
+            uu = torch.arange(0, 50, dtype=torch.int32, device=d)
+            p = cpu(st.forward(uu, uu))
+            ww = st.weights()
+            ref = on.forward({**ww, **{k: sh[k][0] for k in names}}, np.arange(50), np.arange(50), dtype=np.float64)["p"]
+            assert np.abs(p - ref).max() < 1e-5
+    check("end")
+    # switching the feature off leaves an eager state that carries on from the same numbers
+    st.set_deferred(False)
+    u = torch.from_numpy(rs.randint(0, U, B).astype(np.int32)).to(d)
+    i = torch.from_numpy(rs.randint(0, I, B).astype(np.int32)).to(d)
+    st.grads(u, i, torch.ones(B, device=d))
+    g = {nm: cpu(st.gtab[tix[nm]]) for nm in names}
+    st.apply(lr)
+    for nm in names:
+        _adam_np(*sh[nm], g[nm], np.float32(ops.adam_lr_t(lr, 25)))
+    for nm in names:
+        assert np.array_equal(cpu(st.tab[tix[nm]]), sh[nm][0]), nm
