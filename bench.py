@@ -482,6 +482,15 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                 sampler.side.wait_stream(torch.cuda.current_stream())
             breakdown_step = train_step_sequential
         pop_loss = st.pop_loss
+        # deferred decay of the user table (the state turns it on at its first batch when 4 B <= U): the timed region ends with
+        # the replay of every postponed row update -- each (element, step) update of Keras' every-row Adam is inside the timed
+        # region.  A no-op in the every-row form.
+        def finish_train():
+            if hi_prio is not None:
+                with torch.cuda.stream(hi_prio):
+                    st.sync()
+            else:
+                st.sync()
     elif shard == "user":
         # USER shards: the rank owns the user rows [ulo, uhi) and a replica of the item table; B triplets per rank for its
         # own users (items: the whole catalogue, the reference's sampling distribution), all-reduce of the item gradients
@@ -667,6 +676,16 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         "k_rows_apply": B * (72.0 * F + 60.0) - B * (24.0 * F + 28.0) if args.opt == "adam_lazy" else B * (24.0 * F),
         "k_bpr_sample": B * 48.0,
     }
+    deferred = bool(getattr(st, "deferred", False))
+    rows_touched = None
+    if deferred:
+        # the user-side kernel reads / writes only the rows of the batch's distinct users (+ one pre-update row each for the item
+        # segments); counted on one drawn batch
+        rows_touched = int(torch.unique(ops.bpr_sample(ctx, pos_train, B, seed=4242, first_sample=0)[0]).numel())
+        alg["k_bpr_user_seg"] = 28.0 * rows_touched * F + B * (8.0 * F + 32.0)    # theta, m, v of the batch's rows read + written, the
+        #                                                                        pre-update row written, gamma_i / gamma_j gathered
+        alg["k_bpr_catchup"] = 24.0 * rows_touched * F     # the rows it brings up to date (its bound is the replay arithmetic, see valu)
+        alg["k_bpr_flush_users"] = 24.0 * rows_u * F
     dn, dsec = dominant(rep_train)
     step_bytes = 24.0 * (rows_u + rows_i) * F + B * (24.0 * F + 28.0)     # dense-Adam surcharge + per-triplet bytes
     achieved = alg.get(dn, step_bytes) / dsec / 1e9                       # (a kernel without an entry: priced at the whole step's bytes)
@@ -674,6 +693,20 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dn), "traffic_source": traffic_note,
                   "step_GBs": step_bytes / (dt_train / K) / 1e9,
                   "kernels_ms_per_step": {n: v[1] / K for n, v in rep_train.items()}}
+    if deferred:
+        moved = 24.0 * (rows_touched + rows_i) * F + 4.0 * rows_touched * F + B * (24.0 * F + 32.0) + 24.0 * rows_u * F / K
+        roof_train.update({
+            "deferred_decay": f"user rows without triplets in a batch are not moved by that step: their gradient-free Adam updates are replayed "
+                              f"bit for bit when next needed; the {K} timed steps end with the replay of every pending row (k_bpr_flush_users)",
+            "user_rows_per_step": rows_touched,
+            "valu": {"what": "k_bpr_catchup / k_bpr_flush_users replay the postponed updates in registers: one correctly rounded fp32 sqrt and "
+                             "division per element and step -- U F element-steps per optimiser step in the steady state, whatever B is",
+                     "element_steps_per_step": float(rows_u) * F,
+                     "catchup_ms_per_step": rep_train.get("k_bpr_catchup", (0, 0.0))[1] / K,
+                     "flush_ms_per_step": rep_train.get("k_bpr_flush_users", (0, 0.0))[1] / K},
+            "step_GBs_note": "step_GBs prices the step at SURVEY 8d's bytes (every row of both tables moved each step) -- work-equivalent, "
+                             "it may exceed the HBM peak; step_GBs_moved = the bytes this form has to move (batch rows + 1/K of the final replay)",
+            "step_GBs_moved": moved / (dt_train / K) / 1e9})
     if pipelined:
         # the timed steps overlap the NEXT batch's sampler / prep / sort with this step's kernels: `achieved` is the dominant
         # kernel's duration inside that timed region (it shares HBM with the look-ahead work), the breakdown above and the
@@ -764,6 +797,7 @@ def sweep_leg(args, ctx, data):
                 barrier(1)
                 t0 = time.perf_counter()
                 st.train_loop(pos, steps * B, B, 42, drawn, lr, l_w, l_b)
+                st.sync()                                    # deferred decay: the pending row updates belong to these steps
                 barrier(1)
                 dts.append(time.perf_counter() - t0)
                 drawn += steps * B
@@ -772,7 +806,8 @@ def sweep_leg(args, ctx, data):
             step_bytes = dense_bytes + B * ((24.0 if opt == "adam_tf_dense" else 72.0) * F + 28.0)
             out.append({"optimizer": opt, "batch": B, "steps": steps, "value": B * steps / dt, "unit": "pairs/s",
                         "ms_per_step": dt / steps * 1e3, "repeats_ms_per_step": [d / steps * 1e3 for d in dts],
-                        "step_GBs_algorithmic": step_bytes / (dt / steps) / 1e9})
+                        "step_GBs_algorithmic": step_bytes / (dt / steps) / 1e9,
+                        **({"deferred_decay": True} if getattr(st, "deferred", False) else {})})
         st.pop_loss()
         del st
         torch.cuda.empty_cache()

@@ -773,6 +773,11 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
     bool sorted = (algo == EL_BPR_SORTED);
     if (algo == EL_BPR_AUTO) sorted = (B >= 2048 || st.uslot) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I);
     if (st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE && algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I)) sorted = true;
+    if (st.Gu_last) {
+        EL_REQUIRE(algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I),
+                   "el_bprmf_train_step: the deferred decay (Gu_last) needs the SORTED path and its workspace");
+        sorted = true;
+    }
     EL_REQUIRE(sorted || !st.uslot, "el_bprmf_train_step: compact user-gradient rows (uslot) need the SORTED path and its workspace");
     EL_REQUIRE(sorted || !(st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE), "el_bprmf_train_step: a second user table (Gu_next) needs the SORTED path and its workspace");
     if (sorted)
@@ -1133,7 +1138,7 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
             if (int rc = el_bprmf_train_step(ctx, stream, &cur, bu + off, bi + off, bj + off, n, lr, l_w, l_b, opt,
                                              first_step + (int32_t)k, adam ? lr_t_host[k] : 0.f, loss_out, algo, ws, ws_bytes))
                 return rc;
-            if (cur.Gu_next && opt == EL_OPT_ADAM_TF_DENSE) {      // fused user side: the step left the current table in Gu_next
+            if (cur.Gu_next && !cur.Gu_last && opt == EL_OPT_ADAM_TF_DENSE) {      // fused user side: the step left the current table in Gu_next
                 float* t = cur.Gu;
                 cur.Gu = cur.Gu_next;
                 cur.Gu_next = t;

@@ -26,6 +26,10 @@ __device__ __forceinline__ void ldv(const float* p, float* dst) {
         dst[1] = t.y;
         dst[2] = t.z;
         dst[3] = t.w;
+    } else if (VW == 2) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        dst[0] = t.x;
+        dst[VW - 1] = t.y;
     } else {
         dst[0] = p[0];
     }
@@ -34,6 +38,8 @@ template <int VW>
 __device__ __forceinline__ void stv(float* p, const float* src) {
     if (VW == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(src[0], src[1], src[2], src[3]);
+    } else if (VW == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(src[0], src[VW - 1]);
     } else {
         p[0] = src[0];
     }
@@ -78,11 +84,35 @@ struct SegParams {
     float l_w, l_b;
     int32_t step;
     double* loss_out;
+    // item segments: gamma_u of triplet b = ubase[uidx[b], :]  (NULL = st.Gu / bu: the user table itself, by user id; the deferred
+    // decay points them at the pre-update rows the user-side kernel left in Gu_old, by segment head position)
+    const float* ubase;
+    const int32_t* uidx;
+};
+
+struct FusedParams {
+    const int32_t* rowptr;    // [U + 1]
+    float* Gu_new;            // [U, F]: the updated user rows (Gu keeps the pre-update values for the item segments)
+    float lr_t, b1, b2, eps;
+    // deferred decay (el_bprmf_state.Gu_last): only the rows with triplets in the batch are read; their missed gradient-free steps
+    // (last, t - 1] are replayed in registers first, the caught-up row goes to old_rows[head position] for the item segments
+    // (hpos[b] = that position, per triplet) and theta is updated IN PLACE
+    int32_t* last;            // [U]
+    float* old_rows;          // [>= B, F]
+    int32_t* hpos;            // [B]
+    const float* hist;        // lr_t of step s at hist[s & hist_mask]
+    int hist_mask;
+    int32_t t;                // this optimiser step
 };
 
 // ---- user segments -----------------------------------------------------------------------
-template <int VW, int CPL>
-__global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
+// DEFER (el_bprmf_state.Gu_last, the deferred decay): the step's whole user side on the batch's rows only.  k_bpr_catchup brought
+// the rows of the batch's users to step t - 1 just before; a group owns every segment whose head lies in its chunk (the compact
+// rule below), and where the two-kernel form writes the gradient row, this form takes Keras' Adam step on the row right away:
+// m, v (fetched when the segment starts) and theta updated IN PLACE, the pre-update theta left in old_rows[head] for the item
+// segments, hpos[b] = head for every triplet of the segment, Gu_last[user] = t.  Work proportional to B, whatever U is.
+template <int VW, int CPL, bool DEFER>
+__global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f) {
     const int F = p.st.F, lpt = p.lpt;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = gid / lpt;
@@ -92,7 +122,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
     // Compact user-gradient rows (el_bprmf_state.uslot): a segment belongs, whole, to the group whose chunk holds its HEAD --
     // that group walks on past its chunk end, the next one skips the positions of a segment that began before its chunk
     // (user segments are short: Poisson(B/U)).  Every row is then one plain store into gGu_rows[head position].
-    const bool compact = p.st.uslot != nullptr;
+    const bool compact = DEFER || p.st.uslot != nullptr;
     if (compact && p0 < p1) {
         while (p0 < p1 && p0 > 0 && p.keys[p0] == p.keys[p0 - 1]) ++p0;
         if (p0 < p1)
@@ -103,8 +133,32 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
         int64_t cur = -1, head = 0;
         bool started_inside = false;
         float gu[CPL][VW], acc[CPL][VW];
+        float mrow[DEFER ? CPL : 1][VW], vrow[DEFER ? CPL : 1][VW];
         int cnt = 0;
         auto flush = [&](bool ends_inside) {
+            if (DEFER) {
+                const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+                const float w = (float)cnt * p.l_w;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int e = (sub + q * lpt) * VW;
+                    if (e < F) {
+                        float tn[VW], mn[VW], vn[VW];
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            const float g = acc[q][x] + w * gu[q][x];
+                            tn[x] = gu[q][x], mn[x] = mrow[DEFER ? q : 0][x], vn[x] = vrow[DEFER ? q : 0][x];
+                            el_adam_elem(tn[x], mn[x], vn[x], g, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                        }
+                        stv<VW>(f.old_rows + head * F + e, gu[q]);          // the pre-update row, for the item segments
+                        stv<VW>(p.st.Gu + cur * F + e, tn);
+                        stv<VW>(p.st.mGu + cur * F + e, mn);
+                        stv<VW>(p.st.vGu + cur * F + e, vn);
+                    }
+                }
+                if (sub == 0) f.last[cur] = f.t;
+                return;
+            }
             float* g = compact ? p.st.gGu_rows + head * F : p.st.gGu + cur * F;
             const float w = (float)cnt * p.l_w;
 #pragma unroll
@@ -192,7 +246,20 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p) {
                                 gu[q][x] = rgu[t][q][x];
                                 acc[q][x] = 0.f;
                             }
+                        if (DEFER) {                             // the row's Adam slots: needed when the segment ends
+#pragma unroll
+                            for (int q = 0; q < CPL; ++q) {
+                                const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                                for (int x = 0; x < VW; ++x) mrow[DEFER ? q : 0][x] = vrow[DEFER ? q : 0][x] = 0.f;
+                                if (e < F) {
+                                    ldv<VW>(p.st.mGu + key * F + e, mrow[DEFER ? q : 0]);
+                                    ldv<VW>(p.st.vGu + key * F + e, vrow[DEFER ? q : 0]);
+                                }
+                            }
+                        }
                     }
+                    if (DEFER && sub == 0) f.hpos[b] = (int32_t)head;
                     float sb = 0.f;
                     if (p.cml) {
                         sb = 2.0f * p.s[b];                          // d|u-j|^2/du - d|u-i|^2/du = 2 (i - j), times dloss/dD_b
@@ -252,11 +319,6 @@ __global__ __launch_bounds__(256) void k_bpr_rowptr(const u32* __restrict__ keys
     for (int64_t r = prev + 1; r <= key; ++r) rowptr[r] = (int32_t)t;
 }
 
-struct FusedParams {
-    const int32_t* rowptr;    // [U + 1]
-    float* Gu_new;            // [U, F]: the updated user rows (Gu keeps the pre-update values for the item segments)
-    float lr_t, b1, b2, eps;
-};
 
 // One lane group (lpt lanes x 16 B = a row) owns RPG consecutive user rows: it prefetches their theta / m / v, walks the sorted
 // positions of those rows (a contiguous range, rowptr) exactly as k_bpr_user_seg does -- index chains staged in LDS, SUB
@@ -424,6 +486,107 @@ __global__ __launch_bounds__(256) void k_bpr_user_adam(SegParams p, FusedParams 
     }
 }
 
+// deferred decay, start of step t: the rows of the batch's distinct users to step t - 1.  One WAVE per sorted position; the wave
+// on a segment head owns the row: elements e = (lane + 64 q) VW, all 64 lanes on the same replay length (a lane group per row
+// inside the fused kernel left ~15 % of the lanes busy: rows of one wave wait ~10 steps on average, the longest of them ~30).
+// m = v = 0 (a row that never had a gradient) is a fixed point of the gradient-free step: nothing to replay, whatever the gap.
+template <int VW>
+__global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u32* __restrict__ keys, int64_t B, int32_t t,
+                                                     float* __restrict__ hist, int hist_mask, float lr_t) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p == 0 && lane == 0) hist[t & hist_mask] = lr_t;        // lr_t of THIS step into the ring (the replays below read steps < t)
+    if (p >= B) return;
+    const u32 key = keys[p];
+    if (p > 0 && keys[p - 1] == key) return;                   // not a segment head
+    const int64_t row = (int64_t)key;
+    const int last = st.Gu_last[row];
+    const int ns = (t - 1) - last;
+    if (ns <= 0) return;
+    const int F = st.F;
+    bool wrote = false;
+    for (int f0 = 0; f0 < F; f0 += 64 * VW) {
+        const int e = f0 + lane * VW;
+        float th[VW], mm[VW], vv[VW];
+#pragma unroll
+        for (int x = 0; x < VW; ++x) th[x] = mm[x] = vv[x] = 0.f;
+        if (e < F) {
+            ldv<VW>(st.Gu + row * F + e, th);
+            ldv<VW>(st.mGu + row * F + e, mm);
+            ldv<VW>(st.vGu + row * F + e, vv);
+        }
+        bool nz = false;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) nz = nz || mm[x] != 0.f || vv[x] != 0.f;
+        if (__ballot(nz) == 0ull) continue;                     // this chunk of the row is at its fixed point
+        for (int s = 0; s < ns; ++s) {
+            const float lr = hist[(last + 1 + s) & hist_mask];
+#pragma unroll
+            for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], 0.0f, lr, b1, b2, omb1, omb2, eps);
+        }
+        if (e < F) {
+            stv<VW>(st.Gu + row * F + e, th);
+            stv<VW>(st.mGu + row * F + e, mm);
+            stv<VW>(st.vGu + row * F + e, vv);
+        }
+        wrote = true;
+    }
+    (void)wrote;
+    if (lane == 0) st.Gu_last[row] = t - 1;
+}
+
+// deferred decay: every user row up to step t (one lane group per row, grid-stride)
+template <int CPL>
+__global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int lpt, int32_t t, const float* __restrict__ hist, int hist_mask) {
+    constexpr int VW = 4;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int F = st.F;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    const int64_t ngroups = (int64_t)gridDim.x * (256 / lpt);
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpt; row < st.U; row += ngroups) {
+        const int last = st.Gu_last[row];
+        const int ns = t - last;
+        if (ns <= 0) continue;
+        float th[CPL][VW], mm[CPL][VW], vv[CPL][VW];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+#pragma unroll
+            for (int x = 0; x < VW; ++x) th[q][x] = mm[q][x] = vv[q][x] = 0.f;
+            if (e < F) {
+                ldv<VW>(st.Gu + row * F + e, th[q]);
+                ldv<VW>(st.mGu + row * F + e, mm[q]);
+                ldv<VW>(st.vGu + row * F + e, vv[q]);
+            }
+        }
+        bool nz = false;                                        // m = v = 0: a fixed point of the gradient-free step (see k_bpr_user_adam)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int x = 0; x < VW; ++x) nz = nz || mm[q][x] != 0.f || vv[q][x] != 0.f;
+        if (el_group_any(nz, lpt)) {
+            for (int s = 0; s < ns; ++s) {
+                const float lr = hist[(last + 1 + s) & hist_mask];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) el_adam_elem(th[q][x], mm[q][x], vv[q][x], 0.0f, lr, b1, b2, omb1, omb2, eps);
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+                if (e < F) {
+                    stv<VW>(st.Gu + row * F + e, th[q]);
+                    stv<VW>(st.mGu + row * F + e, mm[q]);
+                    stv<VW>(st.vGu + row * F + e, vv[q]);
+                }
+            }
+        }
+        if (sub == 0) st.Gu_last[row] = t;
+    }
+}
+
 // ---- item segments -----------------------------------------------------------------------
 template <int VW, int CPL>
 __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
@@ -489,7 +652,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
             const int64_t b = (int64_t)(pay & 0x7fffffffu);
             const float sb = p.s[b];
             s_key[t] = (p.keys[sbase + t] - p.key_off) | (pay & 0x80000000u);   // item ids < 2^31: the top bit carries the role
-            s_u[t] = (u32)p.bu[b];
+            s_u[t] = (u32)(p.uidx ? p.uidx[b] : p.bu[b]);
             s_cf[t] = (pay >> 31) ? -sb : sb;
             if (p.cml) {
                 const float e2 = p.s2[b];
@@ -511,7 +674,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
                 keyv[t] = (int64_t)(kk & 0x7fffffffu);
                 negv[t] = (kk >> 31) != 0u;
                 cfv[t] = s_cf[tt];
-                const float* pu = p.st.Gu + (int64_t)s_u[tt] * F;
+                const float* pu = (p.ubase ? p.ubase : p.st.Gu) + (int64_t)s_u[tt] * F;
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
                     const int e = (sub + q * lpt) * VW;
@@ -582,6 +745,7 @@ struct SortedWs {
     void* tmp;
     size_t tmp_bytes;
     int32_t* rowptr;       // [U + 1] first sorted position of every user row (fused user-side kernel)
+    int32_t* hpos;         // [B] per triplet: sorted head position of its user's segment (deferred decay)
     size_t total;
 };
 
@@ -608,6 +772,7 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
     w->tmp_bytes = t1 > t2 ? t1 : t2;
     w->tmp = take(w->tmp_bytes);
     w->rowptr = (int32_t*)take((size_t)(U + 1) * 4);
+    w->hpos = (int32_t*)take((size_t)B * 4);
     w->total = off;
     return 0;
 }
@@ -642,8 +807,39 @@ int el_pick_lpt(int F, int vw, int* cpl);
 int el_bprmf_apply_items_adam(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, float lr_t);      // el_bpr.hip
 
 // user side of the step as ONE kernel (el_bprmf_state.Gu_next): rowptr, then segments + Adam over every user row
+static int launch_flush_users(const el_bprmf_state& st, hipStream_t s, int32_t t) {
+    int cpl = 1;
+    const int lpt = el_pick_lpt(st.F, 4, &cpl);
+    EL_REQUIRE(cpl <= 2, "el_bprmf_sync_users: F=%d too large for the deferred decay", st.F);
+    const int64_t groups = st.U, per = 256 / lpt;
+    int64_t grid = (groups + per - 1) / per;
+    if (grid > (1 << 16)) grid = 1 << 16;
+    const int mask = st.lr_hist_cap - 1;
+    if (cpl == 1) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<1>, dim3((unsigned)grid), dim3(256), 0, s, st, lpt, t, st.lr_hist, mask);
+    else EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<2>, dim3((unsigned)grid), dim3(256), 0, s, st, lpt, t, st.lr_hist, mask);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+static int check_deferred(const el_bprmf_state& st) {
+    EL_REQUIRE(st.Gu_last && st.lr_hist && st.lr_hist_cap >= 4 && (st.lr_hist_cap & (st.lr_hist_cap - 1)) == 0,
+               "el_bprmf: deferred decay needs Gu_last, lr_hist and a power-of-two lr_hist_cap >= 4");
+    EL_REQUIRE(st.mGu && st.vGu && st.F % 4 == 0 && (((uintptr_t)st.Gu | (uintptr_t)st.mGu | (uintptr_t)st.vGu) & 15) == 0,
+               "el_bprmf: deferred decay needs Adam slots, F %% 4 == 0 and 16-byte aligned tables");
+    return 0;
+}
+
+extern "C" int el_bprmf_sync_users(el_ctx* ctx, void* stream, const el_bprmf_state* stp, int32_t step) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(stp != nullptr && step >= 0, "el_bprmf_sync_users: bad arguments");
+    if (stp->Gu_last == nullptr || step == 0) return 0;
+    if (int rc = check_deferred(*stp)) return rc;
+    return launch_flush_users(*stp, (hipStream_t)stream, step);
+}
+
 static int launch_user_adam(const SegParams& pu, hipStream_t s, int64_t B, const SortedWs& w, int lpt, int cpl, float lr_t) {
     FusedParams f;
+    memset(&f, 0, sizeof(f));
     f.rowptr = w.rowptr;
     f.Gu_new = pu.st.Gu_next;
     f.lr_t = lr_t, f.b1 = 0.9f, f.b2 = 0.999f, f.eps = 1e-7f;
@@ -662,8 +858,22 @@ static int launch_user_adam(const SegParams& pu, hipStream_t s, int64_t B, const
     return 0;
 }
 
+// deferred decay: the batch's rows to step t - 1 (one wave per row), then the user segments with the Adam step on each row
+static int launch_user_catchup(const SegParams& pu, hipStream_t s, int64_t B, const SortedWs& w, float lr_t, FusedParams* f) {
+    memset(f, 0, sizeof(*f));
+    f->lr_t = lr_t, f->b1 = 0.9f, f->b2 = 0.999f, f->eps = 1e-7f;
+    f->last = pu.st.Gu_last, f->old_rows = pu.st.Gu_old, f->hpos = w.hpos;
+    f->hist = pu.st.lr_hist, f->hist_mask = pu.st.lr_hist_cap - 1, f->t = pu.step;
+    const int F = pu.st.F;                                      // elements per lane so that the 64 lanes of a wave span a row
+    const unsigned gc = (unsigned)((B + 3) / 4);
+    if (F >= 256) EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<4>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
+    else if (F >= 128) EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<2>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
+    else EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<1>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
+    return 0;
+}
+
 template <int VW>
-static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w, bool fused = false, float lr_t = 0.f) {
+static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w, bool fused = false, float lr_t = 0.f, bool defer = false) {
     int cpl = 1;
     const int lpt = el_pick_lpt(base.st.F, VW, &cpl);
     EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build", base.st.F);
@@ -680,15 +890,21 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     pi.n = 2 * B;
     pi.chunk = item_chunk_for(B);
     pi.lpt = lpt;
+    if (defer) pi.ubase = base.st.Gu_old, pi.uidx = w.hpos;      // the pre-update user rows, one per distinct user of the batch
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
     const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
+    FusedParams fz;
+    memset(&fz, 0, sizeof(fz));
 #define EL_SEG(CPL_)                                                                                      \
     do {                                                                                                  \
-        if (fused) {                                                                                      \
+        if (defer) {                                                                                      \
+            if (int rc = launch_user_catchup(pu, s, B, w, lr_t, &fz)) return rc;                          \
+            EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+        } else if (fused) {                                                                               \
             if (int rc = launch_user_adam(pu, s, B, w, lpt, cpl, lr_t)) return rc;                        \
         } else {                                                                                          \
-            EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_>), dim3(gridU), dim3(256), ldsU, s, pu);  \
+            EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, false>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
         }                                                                                                 \
         EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi);      \
     } while (0)
@@ -737,15 +953,28 @@ static int sorted_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, con
     // fused user side (el_bprmf_state.Gu_next): segments + Keras Adam over every user row in one kernel, new rows to Gu_next
     int cplq = 1;
     el_pick_lpt(st.F, 4, &cplq);
-    const bool fused = st.Gu_next != nullptr && opt == EL_OPT_ADAM_TF_DENSE && vec && !rows_mode && cplq <= 2 &&
-                       (((uintptr_t)st.Gu_next | (uintptr_t)st.mGu | (uintptr_t)st.vGu) & 15) == 0;
-    if (st.Gu_next != nullptr && opt == EL_OPT_ADAM_TF_DENSE)
+    // deferred decay (el_bprmf_state.Gu_last): the fused user-side kernel on the batch's rows only, theta updated in place
+    const bool defer = st.Gu_last != nullptr && opt == EL_OPT_ADAM_TF_DENSE;
+    if (st.Gu_last != nullptr) {
+        EL_REQUIRE(opt == EL_OPT_ADAM_TF_DENSE, "el_bprmf: with the deferred decay on (Gu_last) the user rows are only current after "
+                   "el_bprmf_sync_users; gradient-only / other-optimiser calls take a state with Gu_last = NULL after that sync");
+        if (int rc = check_deferred(st)) return rc;
+        EL_REQUIRE(vec && !rows_mode && cplq <= 2, "el_bprmf_train_step: deferred decay needs F %% 4 == 0, F <= 512 and 16-byte aligned tables");
+        EL_REQUIRE(st.Gu_old != nullptr && st.Gu_old_cap >= B && ((uintptr_t)st.Gu_old & 15) == 0,
+                   "el_bprmf_train_step: deferred decay needs Gu_old with >= B rows (%lld < %lld)", (long long)st.Gu_old_cap, (long long)B);
+        // the lr history is a ring: no row may fall more than half of it behind
+        if (step > 1 && (step - 1) % (st.lr_hist_cap / 2) == 0)
+            if (int rc = launch_flush_users(st, s, step - 1)) return rc;
+    }
+    const bool fused = defer || (st.Gu_next != nullptr && opt == EL_OPT_ADAM_TF_DENSE && vec && !rows_mode && cplq <= 2 &&
+                                 (((uintptr_t)st.Gu_next | (uintptr_t)st.mGu | (uintptr_t)st.vGu) & 15) == 0);
+    if (st.Gu_next != nullptr && opt == EL_OPT_ADAM_TF_DENSE && !defer)
         EL_REQUIRE(fused, "el_bprmf_train_step: Gu_next needs F %% 4 == 0, F <= 512 and 16-byte aligned tables");
     if (st.uslot && !fused) {
         EL_REQUIRE(st.gGu_rows != nullptr && st.gGu_cap >= B, "el_bprmf_train_step: compact user-gradient rows need gGu_rows with >= B rows (%lld < %lld)",
                    (long long)st.gGu_cap, (long long)B);
     }
-    int rc = vec ? launch_segs<4>(base, s, B, w, fused, lr_t) : launch_segs<1>(base, s, B, w);
+    int rc = vec ? launch_segs<4>(base, s, B, w, fused, lr_t, defer) : launch_segs<1>(base, s, B, w);
     if (rc) return rc;
     if (opt < 0) return 0;                           // gradients only (el_bprmf_grads)
     if (fused) return el_bprmf_apply_items_adam(ctx, s, st, lr_t);

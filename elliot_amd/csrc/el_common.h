@@ -196,6 +196,14 @@ __device__ __forceinline__ T el_group_sum(T v, int width) {
     return v;
 }
 
+// true in every lane of an aligned group of `width` lanes (a power of two <= 64) when any of them holds true
+__device__ __forceinline__ bool el_group_any(bool v, int width) {
+    const unsigned long long b = __ballot(v);
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long m = width >= 64 ? ~0ull : (((1ull << width) - 1ull) << (lane & ~(width - 1)));
+    return (b & m) != 0ull;
+}
+
 // first position p in [lo, hi) with idx[p] >= x (idx ascending), hi if none
 __device__ __forceinline__ int64_t el_lower_bound(const int32_t* __restrict__ idx, int64_t lo, int64_t hi,
                                                   int32_t x) {

@@ -203,11 +203,13 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
         float dlogit = 0.f;                                             // d/dlogit: zero where the clip is active
         if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n_div;
         if (lane == 0) st.dlogit[b] = dlogit;
+        // d loss / d (pre-activation of the last Dense(relu) layer) = dlogit w_f where its output is positive: the ReLU derivative
+        // is taken here, where the output row is in registers
 #pragma unroll
-        for (int q = 0; q < NMF_HEAD_Q; ++q) acc[q] += dlogit * val[q];
-        if (st.use_mlp) {
-            float* dh = st.dact[st.n_layers - 1] + b * (int64_t)Hl;
-            for (int f = lane; f < Hl; f += 64) dh[f] = dlogit * st.hw[F + f];
+        for (int q = 0; q < NMF_HEAD_Q; ++q) {
+            acc[q] += dlogit * val[q];
+            const int f = lane + 64 * q;
+            if (f >= F && f < NF) st.dact[st.n_layers - 1][b * (int64_t)Hl + (f - F)] = val[q] > 0.f ? dlogit * st.hw[f] : 0.f;
         }
         bacc += dlogit;
     }
@@ -257,6 +259,32 @@ __global__ __launch_bounds__(256) void k_relu_bwd_colsum(float* __restrict__ d, 
         }
     }
     part[threadIdx.x] = s;
+    __syncthreads();
+    if (tr == 0 && c < units) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += part[r * W + tc];
+        if (t != 0.f) atomicAdd(gb + c, t);
+    }
+}
+
+// bias gradient alone: gb[c] += sum_b d[b, c] (gb zeroed by the caller); d already carries the ReLU derivative (k_nmf_head
+// applies it for the last layer).  Same walk as k_relu_bwd_colsum, one read of d and nothing else.
+__global__ __launch_bounds__(256) void k_nmf_colsum(const float* __restrict__ d, int64_t n, int64_t units, float* __restrict__ gb) {
+    __shared__ float part[256];
+    const int W = units < 256 ? (int)units : 256, R = 256 / W;
+    const int tc = threadIdx.x % W, tr = threadIdx.x / W;
+    const int64_t c = (int64_t)blockIdx.x * W + tc;
+    float s0 = 0.f, s1 = 0.f;
+    if (tr < R && c < units) {
+        int64_t b = (int64_t)blockIdx.y * R + tr;
+        const int64_t stride = (int64_t)gridDim.y * R;
+        for (; b + stride < n; b += 2 * stride) {
+            s0 += d[b * units + c];
+            s1 += d[(b + stride) * units + c];
+        }
+        if (b < n) s0 += d[b * units + c];
+    }
+    part[threadIdx.x] = s0 + s1;
     __syncthreads();
     if (tr == 0 && c < units) {
         float t = 0.f;
@@ -355,35 +383,149 @@ __device__ __forceinline__ NmfRowTabs nmf_row_tabs(const el_nmf_state& st, int s
     return r;
 }
 
-// steps (s0, s1] without a gradient on the elements f = f0 + lane + 64 q (q < Q, f < D) of one row; lr_hist is indexed from s0 + 1
-template <int Q>
-__device__ __forceinline__ void nmf_replay_chunk(float* __restrict__ th, float* __restrict__ m, float* __restrict__ v, int D, int f0,
-                                                 int lane, const float* __restrict__ lr_from, int nsteps) {
+// A wave owns one row of every table of a side at a time: NT tables x Q float-pairs (or floats) per lane.
+//   VW = 2: lane holds elements 2 lane + 128 q, +1 (rows of an even dimension start 8-byte aligned); VW = 1: lane + 64 q.
+template <int VW, int Q>
+struct NmfRowRegs {
+    float a[2][Q][VW], m[2][Q][VW], v[2][Q][VW];
+};
+
+template <int VW, int Q, bool WITH_TH>
+__device__ __forceinline__ void nmf_rows_load(NmfRowRegs<VW, Q>& r, const NmfRowTabs& rt, int64_t row, int f0, int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int f = f0 + (lane + 64 * q) * VW;
+#pragma unroll
+            for (int x = 0; x < VW; ++x) r.a[k][q][x] = r.m[k][q][x] = r.v[k][q][x] = 0.f;
+            if (k < rt.n && f < rt.D[k]) {
+                const int64_t o = row * rt.D[k] + f;
+                if (VW == 2) {
+                    if (WITH_TH) {
+                        const float2 t = *reinterpret_cast<const float2*>(rt.th[k] + o);
+                        r.a[k][q][0] = t.x, r.a[k][q][VW - 1] = t.y;
+                    }
+                    const float2 mm = *reinterpret_cast<const float2*>(rt.m[k] + o), vv = *reinterpret_cast<const float2*>(rt.v[k] + o);
+                    r.m[k][q][0] = mm.x, r.m[k][q][VW - 1] = mm.y;
+                    r.v[k][q][0] = vv.x, r.v[k][q][VW - 1] = vv.y;
+                } else {
+                    if (WITH_TH) r.a[k][q][0] = rt.th[k][o];
+                    r.m[k][q][0] = rt.m[k][o];
+                    r.v[k][q][0] = rt.v[k][o];
+                }
+            }
+        }
+}
+
+template <int VW, int Q>
+__device__ __forceinline__ void nmf_rows_store(const float (&val)[2][Q][VW], float* const (&dst)[2], const NmfRowTabs& rt, int64_t row,
+                                               int f0, int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int f = f0 + (lane + 64 * q) * VW;
+            if (k < rt.n && f < rt.D[k]) {
+                float* d = dst[k] + row * rt.D[k] + f;
+                if (VW == 2) *reinterpret_cast<float2*>(d) = make_float2(val[k][q][0], val[k][q][VW - 1]);
+                else d[0] = val[k][q][0];
+            }
+        }
+}
+
+// nsteps gradient-free steps on the registers (theta too when WITH_TH): exactly el_adam_elem with g = 0
+template <int VW, int Q, bool WITH_TH>
+__device__ __forceinline__ void nmf_rows_replay(NmfRowRegs<VW, Q>& r, const float* __restrict__ lr_from, int nsteps) {
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    float a[Q], mm[Q], vv[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int f = f0 + lane + 64 * q;
-        a[q] = mm[q] = vv[q] = 0.f;
-        if (f < D) a[q] = th[f], mm[q] = m[f], vv[q] = v[f];
-    }
     for (int s = 0; s < nsteps; ++s) {
-        const float lr = lr_from[s];
+        const float lr = WITH_TH ? lr_from[s] : 0.f;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) el_adam_elem(a[q], mm[q], vv[q], 0.0f, lr, b1, b2, omb1, omb2, eps);
-    }
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int f = f0 + lane + 64 * q;
-        if (f < D) th[f] = a[q], m[f] = mm[q], v[f] = vv[q];
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int x = 0; x < VW; ++x) {
+                    if (WITH_TH) {
+                        el_adam_elem(r.a[k][q][x], r.m[k][q][x], r.v[k][q][x], 0.0f, lr, b1, b2, omb1, omb2, eps);
+                    } else {
+                        r.m[k][q][x] = r.m[k][q][x] * b1 + 0.0f * omb1;           // the first two lines of el_adam_elem
+                        r.v[k][q][x] = r.v[k][q][x] * b2 + (0.0f * 0.0f) * omb2;
+                    }
+                }
     }
 }
 
-__device__ __forceinline__ void nmf_replay_row(float* th, float* m, float* v, int D, int lane, const float* lr_from, int nsteps) {
-    if (D <= 64) nmf_replay_chunk<1>(th, m, v, D, 0, lane, lr_from, nsteps);
-    else if (D <= 128) nmf_replay_chunk<2>(th, m, v, D, 0, lane, lr_from, nsteps);
-    else
-        for (int f0 = 0; f0 < D; f0 += 256) nmf_replay_chunk<4>(th, m, v, D, f0, lane, lr_from, nsteps);
+// MODE 0 (catch-up): theta of the row to step t - 1 (m, v are read, replayed in registers and NOT written: k_nmf_apply_rows
+//                    replays them again -- two multiplications per step -- when it rewrites them anyway)
+// MODE 1 (apply):    m, v to step t - 1, then step t with the gradient row; theta, m, v written, gradient row zeroed
+// MODE 2 (flush):    theta, m, v to step t
+template <int VW, int Q, int MODE>
+__device__ __forceinline__ void nmf_row_pass(const el_nmf_state& st, const NmfRowTabs& rt, int64_t row, int lane, int last, int32_t t, float lr_t) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const int nsteps = (MODE == 2 ? t : t - 1) - last;
+    const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
+    const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
+    for (int f0 = 0; f0 < Dmax; f0 += 64 * Q * VW) {
+        NmfRowRegs<VW, Q> r;
+        nmf_rows_load<VW, Q, true>(r, rt, row, f0, lane);
+        float g[2][Q][VW];
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int f = f0 + (lane + 64 * q) * VW;
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) g[k][q][x] = 0.f;
+                    if (k < rt.n && f < rt.D[k]) {
+                        const float* gp = rt.g[k] + row * rt.D[k] + f;
+                        if (VW == 2) {
+                            const float2 t2 = *reinterpret_cast<const float2*>(gp);
+                            g[k][q][0] = t2.x, g[k][q][VW - 1] = t2.y;
+                        } else {
+                            g[k][q][0] = gp[0];
+                        }
+                    }
+                }
+            nmf_rows_replay<VW, Q, false>(r, lr_from, nsteps);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) el_adam_elem(r.a[k][q][x], r.m[k][q][x], r.v[k][q][x], g[k][q][x], lr_t, b1, b2, omb1, omb2, eps);
+        } else {
+            nmf_rows_replay<VW, Q, true>(r, lr_from, nsteps);
+        }
+        float* const dth[2] = {rt.th[0], rt.th[1]};
+        nmf_rows_store<VW, Q>(r.a, dth, rt, row, f0, lane);
+        if (MODE != 0) {
+            float* const dm[2] = {rt.m[0], rt.m[1]};
+            float* const dv[2] = {rt.v[0], rt.v[1]};
+            nmf_rows_store<VW, Q>(r.m, dm, rt, row, f0, lane);
+            nmf_rows_store<VW, Q>(r.v, dv, rt, row, f0, lane);
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) g[k][q][x] = 0.f;
+            float* const dg[2] = {rt.g[0], rt.g[1]};
+            nmf_rows_store<VW, Q>(g, dg, rt, row, f0, lane);
+        }
+    }
+}
+
+// VW = 2 when every table row starts 8-byte aligned (even dimensions); one chunk of 128 (VW 2) / 64 (VW 1) elements per lane pass
+template <int MODE>
+__device__ __forceinline__ void nmf_row_dispatch(const el_nmf_state& st, const NmfRowTabs& rt, int64_t row, int lane, int last, int32_t t,
+                                                 float lr_t) {
+    const bool even = (rt.D[0] % 2 == 0) && (rt.n < 2 || rt.D[1] % 2 == 0);
+    if (even) nmf_row_pass<2, 1, MODE>(st, rt, row, lane, last, t, lr_t);
+    else nmf_row_pass<1, 1, MODE>(st, rt, row, lane, last, t, lr_t);
 }
 
 __global__ __launch_bounds__(256) void k_nmf_catchup(el_nmf_state st, const int32_t* __restrict__ bu, const int32_t* __restrict__ bi,
@@ -402,22 +544,15 @@ __global__ __launch_bounds__(256) void k_nmf_catchup(el_nmf_state st, const int3
     }
     own = __builtin_amdgcn_readfirstlane(own);
     last = __builtin_amdgcn_readfirstlane(last);
-    const int nsteps = (t - 1) - last;
-    if (!own || nsteps <= 0) return;
-    const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
+    if (!own || (t - 1) - last <= 0) return;
     const NmfRowTabs rt = nmf_row_tabs(st, side);
-    for (int k = 0; k < rt.n; ++k) {
-        const int64_t off = row * rt.D[k];
-        nmf_replay_row(rt.th[k] + off, rt.m[k] + off, rt.v[k] + off, rt.D[k], lane, lr_from, nsteps);
-    }
-    if (lane == 0) st.row_last[side][row] = t - 1;
+    nmf_row_dispatch<0>(st, rt, row, lane, last, t, 0.f);
 }
 
 // step t on the rows this batch owns: Keras sparse apply with the accumulated gradient row (duplicates already summed); the
 // gradient row is zero again afterwards
 __global__ __launch_bounds__(256) void k_nmf_apply_rows(el_nmf_state st, const int32_t* __restrict__ bu, const int32_t* __restrict__ bi,
                                                         int64_t n, int32_t t, float lr_t) {
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= 2 * n) return;
@@ -425,18 +560,9 @@ __global__ __launch_bounds__(256) void k_nmf_apply_rows(el_nmf_state st, const i
     const int64_t b = p - (side ? n : 0);
     if (!st.row_own[(int64_t)side * st.Bmax + b]) return;
     const int64_t row = side ? bi[b] : bu[b];
+    const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
     const NmfRowTabs rt = nmf_row_tabs(st, side);
-    for (int k = 0; k < rt.n; ++k) {
-        const int64_t off = row * rt.D[k];
-        float *th = rt.th[k] + off, *g = rt.g[k] + off, *m = rt.m[k] + off, *v = rt.v[k] + off;
-        for (int f = lane; f < rt.D[k]; f += 64) {
-            float a = th[f], mm = m[f], vv = v[f];
-            const float gg = g[f];
-            el_adam_elem(a, mm, vv, gg, lr_t, b1, b2, omb1, omb2, eps);
-            th[f] = a, m[f] = mm, v[f] = vv;
-            if (gg != 0.f) g[f] = 0.f;
-        }
-    }
+    nmf_row_dispatch<1>(st, rt, row, lane, last, t, lr_t);
     if (lane == 0) st.row_last[side][row] = t;
 }
 
@@ -445,14 +571,9 @@ __global__ __launch_bounds__(256) void k_nmf_flush_rows(el_nmf_state st, int sid
     const int lane = threadIdx.x & 63;
     const NmfRowTabs rt = nmf_row_tabs(st, side);
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-        const int last = st.row_last[side][row];
-        const int nsteps = t - last;
-        if (nsteps <= 0) continue;
-        const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
-        for (int k = 0; k < rt.n; ++k) {
-            const int64_t off = row * rt.D[k];
-            nmf_replay_row(rt.th[k] + off, rt.m[k] + off, rt.v[k] + off, rt.D[k], lane, lr_from, nsteps);
-        }
+        const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
+        if (t - last <= 0) continue;
+        nmf_row_dispatch<2>(st, rt, row, lane, last, t, 0.f);
         if (lane == 0) st.row_last[side][row] = t;
     }
 }
@@ -502,8 +623,10 @@ static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
 static inline bool nmf_deferred(const el_nmf_state* st) { return st->row_last[0] != nullptr; }
 
 // every embedding row current at st->opt_step (no-op in the eager form and when nothing is pending)
-static int nmf_sync(el_ctx* ctx, hipStream_t s, el_nmf_state* st) {
-    if (!nmf_deferred(st) || st->flushed_step >= st->opt_step) return 0;
+static int nmf_sync(el_ctx* ctx, hipStream_t s, el_nmf_state* st, bool inside_step = false) {
+    if (!nmf_deferred(st)) return 0;
+    EL_REQUIRE(inside_step || st->batch_n == 0, "el_nmf: the tables cannot be read between el_nmf_grads and el_nmf_apply (deferred decay)");
+    if (st->flushed_step >= st->opt_step) return 0;
     const int64_t rows[2] = {st->U, st->I};
     for (int side = 0; side < 2; ++side) {
         int64_t g = (rows[side] + 3) / 4;
@@ -526,6 +649,8 @@ extern "C" int el_nmf_sync_tables(el_ctx* ctx, void* stream, el_nmf_state* st) {
 // deferred decay, start of step t = opt_step + 1: record lr_t, elect the owners of the batch's rows and bring those rows to t - 1
 static int nmf_begin_rows(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n) {
     const int32_t t = st->opt_step + 1;
+    if (t - st->hist_base >= st->lr_hist_cap)            // history full: bring every row to t - 1, restart the history at t
+        if (int rc = nmf_sync(ctx, s, st)) return rc;
     st->claim_seq += 1;
     if (st->claim_seq <= 0) {                            // 2^31 gradient evaluations: start the claim numbers again
         EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[0], 0, (size_t)st->U * 4, s));
@@ -584,25 +709,34 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
                      int64_t n, int64_t n_div, double* loss_out) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
-    if (nmf_deferred(st))
+    if (nmf_deferred(st)) {
+        EL_REQUIRE(st->batch_n == 0, "el_nmf_grads: the previous el_nmf_grads has not been applied (deferred decay: the batch's rows are "
+                   "half-way between two steps until el_nmf_apply)");
         if (int rc = nmf_begin_rows(ctx, s, st, u, i, n)) return rc;
+    }
     if (int rc = nmf_forward(ctx, s, st, u, i, n, true)) return rc;
     EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
     if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
+    if (st->use_mlp)
+        for (int l = 0; l < st->n_layers; ++l) EL_CHECK_HIP(hipMemsetAsync(st->gb[l], 0, (size_t)st->units[l] * 4, s));
+    // the head leaves dact[last] = d loss / d pre-activation of the last layer (its ReLU derivative applied where the output row is
+    // in registers anyway); the layers below take theirs in k_relu_bwd_colsum together with the bias gradient
     EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out, n_div);
     if (st->use_mlp) {
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
             const float* in = (l == 0) ? st->X0 : st->act[l - 1];
             const int64_t kin = (l == 0) ? 2 * (int64_t)st->E : st->units[l - 1];
-            EL_CHECK_HIP(hipMemsetAsync(st->gb[l], 0, (size_t)units * 4, s));
             {
                 const int W = units < 256 ? (int)units : 256, R = 256 / W;
                 const unsigned gx = (unsigned)((units + W - 1) / W);
                 int64_t gy = ((int64_t)ctx->cus * 8 + gx - 1) / gx, rows = (n + R - 1) / R;
                 if (gy > rows) gy = rows;
-                EL_LAUNCH("k_relu_bwd_colsum", k_relu_bwd_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], st->act[l], n,
-                          units, st->gb[l]);
+                if (l == st->n_layers - 1)       // the head applied this layer's ReLU derivative already: column sums only
+                    EL_LAUNCH("k_nmf_colsum", k_nmf_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], n, units, st->gb[l]);
+                else
+                    EL_LAUNCH("k_relu_bwd_colsum", k_relu_bwd_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], st->act[l], n,
+                              units, st->gb[l]);
             }
             if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
             float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
@@ -627,10 +761,7 @@ static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t) {
     if (nmf_deferred(st)) {
         EL_REQUIRE(st->batch_u && st->batch_i && st->batch_n >= 1, "el_nmf_apply: deferred decay applies the rows of the preceding el_nmf_grads");
         const int32_t t = st->opt_step + 1;
-        if (t - st->hist_base >= st->lr_hist_cap) {                 // history full: bring every row to t - 1, restart the history at t
-            // (the batch's own rows are at t - 1 already; the flush leaves them alone)
-            if (int rc = nmf_sync(ctx, s, st)) return rc;
-        }
+        EL_REQUIRE(t - st->hist_base < st->lr_hist_cap, "el_nmf_apply: lr history overrun");        // (nmf_begin_rows made room)
         EL_LAUNCH("k_nmf_hist_set", k_nmf_hist_set, dim3(1), dim3(1), 0, s, st->lr_hist, t - st->hist_base, lr_t);
         EL_LAUNCH("k_nmf_apply_rows", k_nmf_apply_rows, dim3((unsigned)((2 * st->batch_n + 3) / 4)), dim3(256), 0, s, *st, st->batch_u,
                   st->batch_i, st->batch_n, t, lr_t);

@@ -475,10 +475,17 @@ def tune_table_layout(ctx, rows, F, compact=False):
 class BprmfDeviceState:
     """Gu/Gi/Bi + gradient accumulators + Adam slots in HBM (BPRMF_batch_model.py:39-44)."""
 
-    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None, fused_user_step=None):
+    _LR_HIST = 1 << 16          # lr_t ring of the deferred decay (a power of two)
+
+    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None, fused_user_step=None, deferred=None):
         """compact_user_grads: user-row gradients as compact rows + per-user stamps (el_bprmf_state.uslot) instead of a dense
         [U,F] accumulator -- the dense Adam pass then reads a gradient only for the batch's users and re-zeroes nothing.
-        None = automatic (TF-dense Adam on a user table of >= 64 MB with F % 4 == 0), True / False force it."""
+        None = automatic (TF-dense Adam on a user table of >= 64 MB with F % 4 == 0), True / False force it.
+        deferred: Keras' every-row Adam decay of the USER table postponed per row and replayed bit for bit when a batch next
+        contains the user or when the table is read (el_bprmf_state.Gu_last): a step moves only the batch's user rows.  It pays
+        when a batch touches a small part of the users (10 M users, 1 M triplets: the user side of the step 7.2 -> ~2 ms) and costs
+        when it touches most of them (B = U: +10 %), so None = decided at the first training call: on when 4 B <= U and the fused
+        user-side step applies (EL_BPR_DEFERRED=0 / 1 force it); reading `.Gu` syncs, `.mGu` / `.vGu` want sync() first."""
         self.ctx = ctx
         self.opt = OPTIMIZERS[optimizer] if isinstance(optimizer, str) else int(optimizer)
         dev = ctx.device
@@ -495,6 +502,12 @@ class BprmfDeviceState:
         self.fused = bool(self.compact and fused_user_step is not False and os.environ.get("EL_FUSED_USER", "1") != "0"
                           and int(Gu.shape[1]) <= 512)
         self.Gu_next = None
+        env_d = os.environ.get("EL_BPR_DEFERRED")
+        if deferred is None and env_d in ("0", "1"):
+            deferred = env_d == "1"
+        self._deferred_auto = bool(self.fused and deferred is None)    # decided by the first batch size (_resolve_deferred)
+        self.deferred = bool(self.fused and deferred is True)
+        self._pending = False
 
         def own(x, dt):
             if isinstance(x, np.ndarray):
@@ -510,7 +523,8 @@ class BprmfDeviceState:
         if self.opt == EL_OPT_ADAM_TF_DENSE and self.U * self.F * 4 >= (64 << 20):
             # the dense Adam pass streams these at once: one allocation, tuned distance (tune_table_layout)
             gap = tune_table_layout(ctx, self.U, self.F, compact=self.compact)
-            if self.compact and self.fused:
+            if self.compact and self.fused and not self.deferred:
+                # (deferred=None: the pair is allocated; if the first batch turns the deferred decay on, Gu_next just stays unused)
                 (self.Gu, self.mGu, self.vGu, self.Gu_next), self._user_block = _strided_tables(self.U, self.F, 4, gap, dev)
                 self.gGu = None
             elif self.compact:
@@ -522,7 +536,7 @@ class BprmfDeviceState:
             self.layout_gap = gap
         else:
             self.Gu = own(Gu, torch.float32)
-            if self.fused:
+            if self.fused and not self.deferred:
                 self.Gu_next = torch.empty_like(self.Gu)
             self.gGu = None if self.compact else z(self.Gu)
             self.mGu = z(self.Gu) if adam else None
@@ -556,12 +570,85 @@ class BprmfDeviceState:
             tGu=self.tGu.data_ptr() if rows else None, tGi=self.tGi.data_ptr() if rows else None,
             tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F,
             Gu_next=self.Gu_next.data_ptr() if self.Gu_next is not None else None)
+        self.Gu_last = self.Gu_old = self.lr_hist = None
+        if self.deferred:
+            self._enable_deferred()
+
+    def _enable_deferred(self):
+        dev = self.ctx.device
+        self.deferred = True
+        self.Gu_last = torch.full((self.U,), int(self._step), dtype=torch.int32, device=dev)     # every row is current now
+        self.lr_hist = torch.zeros(self._LR_HIST, dtype=torch.float32, device=dev)
+        self._c.Gu_last, self._c.lr_hist, self._c.lr_hist_cap = self.Gu_last.data_ptr(), self.lr_hist.data_ptr(), self._LR_HIST
+        if getattr(self, "_user_block", None) is None and not self._deferred_auto:
+            self.Gu_next = None                                  # in-place updates: the second table is not needed
+            self._c.Gu_next = None
+
+    def _resolve_deferred(self, B):
+        """A state built with deferred=None follows the batch size: the deferred decay pays when a batch leaves most user rows
+        alone (4 B <= U), the every-row fused step when it touches most of them.  Switching costs one replay of the pending rows."""
+        if self._deferred_auto and int(B) != getattr(self, "_resolved_B", None):
+            self._resolved_B = int(B)
+            want = 4 * int(B) <= self.U
+            if want != self.deferred:
+                auto = self._deferred_auto
+                self.set_deferred(want)
+                self._deferred_auto = auto
+
+    # -- deferred decay of the user table (el_bprmf_state.Gu_last) ----------------------------------------------------------
+    @property
+    def Gu(self):
+        """The user table, every row current (pending row updates of the deferred decay are replayed first)."""
+        if self._pending:
+            self.sync()
+        return self._Gu
+
+    @Gu.setter
+    def Gu(self, t):
+        self._Gu = t
+
+    def sync(self):
+        """Deferred decay: bring every user row (theta, m, v) to the current step; no-op otherwise."""
+        if self.deferred and self._pending:
+            self._pending = False
+            check(self.ctx.lib.el_bprmf_sync_users(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self._step)),
+                  "el_bprmf_sync_users")
+
+    def set_deferred(self, on):
+        """Switch the deferred decay off (data-parallel owners that run the step as grads + collective + apply) or on again."""
+        on = bool(on)
+        self._deferred_auto = False
+        if on == self.deferred:
+            return
+        if on:
+            if not self.fused:
+                raise ValueError("the deferred decay needs the fused user-side step (TF-dense Adam, compact user gradients, F % 4 == 0)")
+            self._enable_deferred()
+            return
+        self.sync()
+        self.deferred = False
+        self._c.Gu_last = self._c.lr_hist = self._c.Gu_old = None
+        self._c.lr_hist_cap, self._c.Gu_old_cap = 0, 0
+        self.Gu_last = self.Gu_old = self.lr_hist = None
+        if self.fused:                                          # the fused user-side step needs its second table from here on
+            if self.Gu_next is None:
+                self.Gu_next = torch.empty_like(self._Gu)
+            self._c.Gu_next = self.Gu_next.data_ptr()
+
+    def _ensure_old(self, B):
+        self._resolve_deferred(B)
+        if self.deferred and (self.Gu_old is None or self.Gu_old.shape[0] < B):
+            self.Gu_old = torch.empty((int(B), self.F), dtype=torch.float32, device=self.ctx.device)
+            self._c.Gu_old, self._c.Gu_old_cap = self.Gu_old.data_ptr(), int(B)
 
     def _swap_user_tables(self, steps=1):
         """After `steps` fused train steps the current user table is the other one of the pair (include/elliot_hip.h, Gu_next)."""
+        if self.deferred:
+            self._pending = True                                # in place; rows outside the batches wait for their replay
+            return
         if self.fused and steps % 2:
-            self.Gu, self.Gu_next = self.Gu_next, self.Gu
-            self._c.Gu, self._c.Gu_next = self.Gu.data_ptr(), self.Gu_next.data_ptr()
+            self._Gu, self.Gu_next = self.Gu_next, self._Gu
+            self._c.Gu, self._c.Gu_next = self._Gu.data_ptr(), self.Gu_next.data_ptr()
             for c in getattr(self, "_c_clones", ()):
                 c.Gu, c.Gu_next = self._c.Gu, self._c.Gu_next
 
@@ -574,6 +661,9 @@ class BprmfDeviceState:
         value = int(value)
         if self.compact and value < self._step:
             self.uslot.zero_()                 # stamps of later steps must not be mistaken for this step's gradient rows
+        if getattr(self, "deferred", False) and value != self._step + 1 and value != self._step:
+            self.sync()                        # a jump of the step counter: every row current at the old count, then re-stamped
+            self.Gu_last.fill_(value)
         self._step = value
 
     def ensure_rows(self, B):
@@ -600,8 +690,10 @@ class BprmfDeviceState:
     def train_step(self, u, i, j, lr, l_w, l_b, algo="auto"):
         """BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80).  u,i,j: int32 device tensors.
         The batch loss is accumulated into self.loss (device double) -- no host sync here."""
-        self.step += 1
         B = u.numel()
+        if self.compact:
+            self._resolve_deferred(B)           # (before the step counter moves: switching the deferred decay stamps the rows with it)
+        self.step += 1
         lr_t = adam_lr_t(lr, self.step)
         algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
         ws, ws_bytes = None, 0
@@ -610,6 +702,7 @@ class BprmfDeviceState:
                 raise ValueError("compact user-gradient rows need the sorted gradient path")
             if not self.fused:
                 self.ensure_rows(B)
+            self._ensure_old(B)
         if algo == _lib.EL_BPR_SORTED or (algo == _lib.EL_BPR_AUTO and B >= 2048) or self.compact:
             need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
             if self._ws is None or self._ws.numel() < need:
@@ -631,6 +724,10 @@ class BprmfDeviceState:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         self.ensure_rows(B)
+        if self.deferred:
+            # the two-call form runs the every-row pass (apply); the rows are brought up to date and the feature stands aside
+            self.sync()
+            self._c.Gu_last = None
         check(self.ctx.lib.el_bprmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
                                           _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(l_w), float(l_b),
                                           int(self.step + 1), _ptr(self.loss, torch.float64), C.c_void_p(self._ws.data_ptr()),
@@ -641,6 +738,9 @@ class BprmfDeviceState:
         self.step += 1
         check(self.ctx.lib.el_bprmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), float(lr), int(self.opt),
                                           int(self.step), float(adam_lr_t(lr, self.step))), "el_bprmf_apply")
+        if self.deferred:
+            self.Gu_last.fill_(self.step)                      # the every-row pass moved every row
+            self._c.Gu_last = self.Gu_last.data_ptr()
 
     # -- the step in two halves for a software pipeline: ordering a batch (prep + radix sort) reads only its triplets, so the
     #    batch of step t+1 can be drawn and ordered on a side stream while step t's segment kernels and optimiser pass run
@@ -662,6 +762,7 @@ class BprmfDeviceState:
             raise ValueError("train_step_presorted: the dense optimisers only (adam_tf_dense, sgd_dense)")
         if not self.fused:
             self.ensure_rows(B)
+        self._ensure_old(B)
         self.step += 1
         check(self.ctx.lib.el_bprmf_train_step_presorted(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
                                                          _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(lr), float(l_w),
@@ -683,6 +784,7 @@ class BprmfDeviceState:
         # (kept alive on self: the library may copy the table with an asynchronous memcpy on the stream)
         if not self.fused:
             self.ensure_rows(B)
+        self._ensure_old(B)
         need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))) if (B >= 2048 or self.compact) else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
@@ -696,7 +798,7 @@ class BprmfDeviceState:
             lr_t.ctypes.data_as(C.c_void_p), _ptr(self.loss, torch.float64), algo,
             C.c_void_p(self._ws.data_ptr()) if need else None, self._ws.numel() if need else 0,
             C.c_void_p(buf.data_ptr()), lneed, C.c_void_p(sampler_meta(self.ctx, pos).data_ptr())), "el_bprmf_train_loop")
-        self.step += steps
+        self._step += steps                                     # (consecutive steps: not a jump of the counter)
         self._swap_user_tables(steps)
         return steps
 

@@ -277,7 +277,7 @@ class HipBackend:
         if optimizer not in ("adam", "adam_tf_dense", "sgd"):
             raise ValueError("item-sharded training supports the dense optimisers (adam_tf_dense, sgd)")
         self.ctx = ctx
-        self.state = ops.BprmfDeviceState(ctx, Gu, Gi_shard, Bi_shard, optimizer="sgd_dense" if optimizer == "sgd" else optimizer,
+        self.state = ops.BprmfDeviceState(ctx, Gu, Gi_shard, Bi_shard, optimizer="sgd_dense" if optimizer == "sgd" else optimizer, deferred=False,
                                           compact_user_grads=False)     # el_rows_segment_sum fills the dense accumulator
         self._ws = None
         self._ws2 = None
@@ -344,7 +344,7 @@ class HipDenseBackend:
         Gu_pad = torch.zeros((self.Us * world, F), dtype=torch.float32, device=dev)
         Gu_pad[:U].copy_(Gu)
         # state of the gradient pass: whole (padded) user table, local item shard; no optimiser slots needed for Gu
-        self.state = ops.BprmfDeviceState(ctx, Gu_pad, Gi_shard, Bi_shard, optimizer="sgd_dense")
+        self.state = ops.BprmfDeviceState(ctx, Gu_pad, Gi_shard, Bi_shard, optimizer="sgd_dense", deferred=False)
         del Gu_pad
         st = self.state
         self.opt = ops.OPTIMIZERS["sgd_dense" if optimizer == "sgd" else optimizer]
@@ -438,7 +438,8 @@ class HipUserShardBackend:
         if optimizer not in ("adam", "adam_tf_dense", "sgd"):
             raise ValueError("sharded training supports the dense optimisers (adam_tf_dense, sgd)")
         self.ctx = ctx
-        self.state = ops.BprmfDeviceState(ctx, Gu_shard, Gi, Bi, optimizer="sgd_dense" if optimizer == "sgd" else optimizer)
+        # (the step runs as grads + all-reduce + apply here: the every-row passes, no deferred decay of the user rows)
+        self.state = ops.BprmfDeviceState(ctx, Gu_shard, Gi, Bi, optimizer="sgd_dense" if optimizer == "sgd" else optimizer, deferred=False)
         self._ws = None
 
     def _workspace(self, B):

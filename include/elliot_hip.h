@@ -40,7 +40,8 @@ typedef struct el_ctx el_ctx;
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
                             *    el_nmf_score_topk, el_gmf_item_image; el_bprmf_state.Gu_next + el_bprmf_train_step_presorted;
                             *    el_host_split_flags_state; el_nmf_state ends in the deferred-decay fields (row_last ..
-                            *    batch_n) and the el_nmf_* calls take it non-const; el_nmf_sync_tables                */
+                            *    batch_n) and the el_nmf_* calls take it non-const; el_nmf_sync_tables; el_bprmf_state ends
+                            *    in Gu_last .. lr_hist_cap, el_bprmf_sync_users                                         */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -160,6 +161,21 @@ typedef struct el_bprmf_state {
      * before its next call (el_bprmf_train_loop does it per batch and leaves the current table in Gu when the number of batches
      * is even, in Gu_next when it is odd).  F % 4 == 0, F <= 512, 16-byte aligned tables.                                  */
     float* Gu_next;   /* [U,F] or NULL */
+    /* Optional deferred decay of the user table (Gu_last == NULL = off).  Keras' Adam moves EVERY user row at every step --
+     * m <- b1 m, v <- b2 v, theta <- theta - lr_t m / (sqrt(v) + eps) -- with or without a gradient.  For a row
+     * without triplets in the batch that update reads nothing but the row itself, so it is postponed and replayed in registers --
+     * the same fp32 operations on the same operands in the same order, hence the same bits -- when a batch next contains the user
+     * (inside the fused user-side kernel, before the row is used) or when el_bprmf_sync_users is called.  A step then moves only
+     * the rows of the batch's users: at 10 M users and 1 M triplets per batch a tenth of the 15 GB the every-row pass streams.
+     * Every (element, step) update is still performed exactly once.  The update is IN PLACE (Gu_next is not used); the item-side
+     * gradients read the pre-update user rows from Gu_old, where the user-side kernel leaves one row per distinct user of the batch.
+     * Needs EL_OPT_ADAM_TF_DENSE, the SORTED gradient path, F % 4 == 0, F <= 512, consecutive `step` values from call to call,
+     * and el_bprmf_sync_users(step) before anything else reads Gu / mGu / vGu (el_score_topk, el_bprmf_grads, a checkpoint).
+     *   Gu_last  int32[U], zero-initialised: the optimiser step each user row is current at
+     *   Gu_old   float[Gu_old_cap, F], Gu_old_cap >= the batch size of every step
+     *   lr_hist  float[lr_hist_cap], lr_hist_cap a power of two >= 4: the library keeps lr_t of step s at lr_hist[s % cap] and
+     *            brings every row up to date by itself every cap / 2 steps                                              */
+    int32_t* Gu_last; float* Gu_old; int64_t Gu_old_cap; float* lr_hist; int32_t lr_hist_cap;
 } el_bprmf_state;
 
 /* How the duplicate-row gradient sum (OptimizerV2's segment-sum of IndexedSlices) is formed. */
@@ -184,6 +200,10 @@ int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                         const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                         float lr, float l_w, float l_b, int opt, int32_t step,
                         float lr_t, double* loss_out, int algo, void* ws, size_t ws_bytes);
+
+/* Deferred decay (el_bprmf_state.Gu_last): replays the postponed gradient-free Adam steps of every user row so that Gu, mGu, vGu
+ * hold exactly what the every-row form holds after `step` optimiser steps.  No-op when Gu_last is NULL.                     */
+int el_bprmf_sync_users(el_ctx* ctx, void* stream, const el_bprmf_state* st, int32_t step);
 
 /* ---- BPR-MF across GPUs: item-sharded tables (new design; the reference is single-device) -- */
 

@@ -110,7 +110,7 @@ def test_bprmf_summed_gradients_match_oracle_tightly(ctx, compact, F, B, U, I):
     Gu, Gi, Bi = _setup(rs, U, I, F)
     be = parallel.HipUserShardBackend(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
     if be.state.compact != compact:
-        be.state = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=compact)
+        be.state = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=compact, deferred=False)
     st = be.state
     u = rs.randint(0, U, B).astype(np.int32)
     i = (rs.zipf(1.3, B) % I).astype(np.int32)             # Zipf items: the hottest row collects a large share of the batch
@@ -511,8 +511,8 @@ def test_fused_user_side_equals_the_two_kernel_form_bit_for_bit(ctx, F, U):
     Gu, Gi, Bi = _setup(rs, U, I, F)
     lr, l_w, l_b = 0.01, 0.1, 0.001
     a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, fused_user_step=False)
-    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True)
-    assert b.fused and not a.fused and b.Gu_next is not None
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False)
+    assert b.fused and not a.fused and b.Gu_next is not None and not b.deferred
     for s in range(5):
         n = B if s != 3 else 2500                                  # a short batch: most rows have no triplet
         t = ops.bpr_sample(ctx, pos, n, seed=7, first_sample=s * B)
@@ -549,3 +549,70 @@ def test_fused_user_side_equals_the_two_kernel_form_bit_for_bit(ctx, F, U):
         st.grads(t[0], t[1], t[2], l_w, l_b)
         st.apply(lr)
     assert torch.equal(a.Gu.view(torch.int32), b.Gu.view(torch.int32))
+
+
+@pytest.mark.parametrize("F,U,hist", [(128, 5003, None), (64, 1024, 8), (256, 2001, 4)])
+def test_deferred_decay_of_the_user_table_equals_the_every_row_pass_bit_for_bit(ctx, F, U, hist, monkeypatch):
+    """el_bprmf_state.Gu_last: a step moves only the user rows of its batch, the gradient-free Adam steps of every other row are
+    replayed when a batch next contains the user or when the table is read.  Against the every-row fused form on the same batches:
+    theta, m, v of the user table BIT-identical at every read -- after stretches of steps that leave most users untouched (batches
+    drawn for a tenth of the users), after a read in the middle, through train_step, train_step_presorted and train_loop, with a
+    4- / 8-step lr ring whose half-way flushes kick in, and across a grads() + apply() pair (the every-row pass on a deferred
+    state).  The item side is the same code in both; EL_ICHUNK makes its summation order fixed (one lane group walks the whole
+    sorted batch: no chunk-crossing atomics), so both runs see identical inputs at every step."""
+    from elliot_amd.synthetic import zipf_csr
+    monkeypatch.setenv("EL_ICHUNK", str(1 << 20))
+    if hist:
+        monkeypatch.setattr(ops.BprmfDeviceState, "_LR_HIST", hist)
+    rs = np.random.RandomState(F + U)
+    I, B = 700, 4096
+    indptr, indices = zipf_csr(U, I, mean_log=2.0, sigma_log=0.9, dmin=1, dmax=150, seed=F)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    # positives of the first tenth of the users only: batches drawn from it leave the other rows waiting
+    cut = int(indptr[U // 10])
+    ip2 = np.minimum(indptr, cut)
+    few = ops.DeviceCSR(ip2, indices[:cut].copy(), I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False)
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=True)
+    assert a.fused and not a.deferred and b.deferred and b.Gu_next is None
+
+    def same(tag):
+        b.sync()
+        for name in ("Gu", "mGu", "vGu", "Gi", "mGi", "vGi", "Bi"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (tag, name, int((x != y).sum()), float((x - y).abs().max()))
+
+    for s in range(14):
+        src = pos if s in (0, 6, 13) else few
+        n = B if s != 3 else 600
+        t = ops.bpr_sample(ctx, src, n, seed=7, first_sample=s * B)
+        for st in (a, b):
+            if s % 3 == 1:
+                ws = st.sort_workspace(n)
+                st.presort(t[0], t[1], t[2], ws)
+                st.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, ws)
+            else:
+                st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        la, lb = a.pop_loss(), b.pop_loss()
+        assert abs(la - lb) <= 2e-6 * abs(la), (s, la, lb)
+        if s in (0, 5, 12, 13):
+            same(s)
+    # the table read through the property is current without an explicit sync
+    a.train_loop(few, 5 * B, B, 11, 0, lr, l_w, l_b)
+    b.train_loop(few, 5 * B, B, 11, 0, lr, l_w, l_b)
+    assert b._pending
+    assert torch.equal(a.Gu.view(torch.int32), b.Gu.view(torch.int32)) and not b._pending
+    same("loop")
+    # grads() + apply(): the every-row two-kernel form on both; the deferred state carries on afterwards
+    t = ops.bpr_sample(ctx, pos, B, seed=9, first_sample=0)
+    for st in (a, b):
+        st.grads(t[0], t[1], t[2], l_w, l_b)
+        st.apply(lr)
+    same("apply")
+    t = ops.bpr_sample(ctx, few, B, seed=10, first_sample=0)
+    for st in (a, b):
+        st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+    same("after apply")

@@ -250,13 +250,13 @@ def _adam_np(th, m, v, g, lr_t):
     th[...] = th - (f(lr_t) * m) / (np.sqrt(v) + eps)
 
 
-@pytest.mark.parametrize("model,F,hist", [("neumf", 128, None), ("neumf", 40, 4), ("gmf", 64, 3), ("neumf", 300, 5)])
+@pytest.mark.parametrize("model,F,hist", [("neumf", 128, None), ("neumf", 40, 4), ("gmf", 64, 3), ("neumf", 300, 5), ("gmf", 33, None)])
 def test_deferred_decay_replays_the_every_row_adam_bit_for_bit(ctx, model, F, hist, monkeypatch):
     """The embedding tables under the deferred decay (el_nmf_state.row_last) against an EAGER shadow on the host that moves every
     row at every step with the device's own gradient rows: theta, m, v of all four tables bit-identical whenever the tables are
     read -- after long stretches without a read (rows untouched for 9 steps are replayed at once), after reads in the middle
     (forward / weights / scoring sync), with duplicate rows in a batch, rows that are never touched, and with a 3..5-step lr
-    history that fills up and restarts.  F = 300 takes the chunked row loop, 40 the sub-wave one."""
+    history that fills up and restarts.  F = 300 takes the chunked row loop, 40 the sub-wave one, 33 (odd: rows not 8-byte aligned) the scalar one."""
     if hist:
         monkeypatch.setattr(ops.NmfDeviceState, "_LR_HIST", hist)
     U, I, B, lr = 900, 700, 256, 0.01
