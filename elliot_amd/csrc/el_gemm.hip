@@ -508,12 +508,25 @@ __global__ __launch_bounds__(256) void k_gemm_sk_fix(GemmParams p) {
     for (int tb = 0; tb < TN; ++tb) {
         const int64_t e = ((int64_t)((ta * TN + tb) * 4 + g) * 256 + tid) * 4;
         float4 a = *reinterpret_cast<const float4*>(first + e);
-        for (int64_t w = wa + 1; w <= wb; ++w) {
-            const float4 b = *reinterpret_cast<const float4*>(p.ws + (2 * w) * (int64_t)(BM * BN) + e);
-            a.x += b.x;
-            a.y += b.y;
-            a.z += b.z;
-            a.w += b.w;
+        // the partial tiles are added in workgroup order (deterministic), but FETCHED eight at a time: a product with a huge K and
+        // few tiles (dW = X^T dY, K = the batch) has ~60 contributors per tile, and one dependent 16-byte load per addition made
+        // this kernel a chain of ~60 memory latencies (66 us per launch at the NeuMF shapes)
+        for (int64_t w0 = wa + 1; w0 <= wb; w0 += 8) {
+            float4 b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t w = (w0 + j <= wb) ? w0 + j : wb;
+                b[j] = *reinterpret_cast<const float4*>(p.ws + (2 * w) * (int64_t)(BM * BN) + e);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (w0 + j <= wb) {
+                    a.x += b[j].x;
+                    a.y += b[j].y;
+                    a.z += b[j].z;
+                    a.w += b[j].w;
+                }
+            }
         }
         acc[tb] = a;
     }

@@ -248,7 +248,27 @@ __global__ __launch_bounds__(256) void k_relu_bwd_colsum(float* __restrict__ d, 
     const int64_t c = (int64_t)blockIdx.x * W + tc;
     float s = 0.f;
     if (tr < R && c < units) {
-        for (int64_t b = (int64_t)blockIdx.y * R + tr; b < n; b += (int64_t)gridDim.y * R) {
+        // four rows per trip: eight loads in flight per thread (one row per trip left the pass latency-bound at ~4 TB/s)
+        const int64_t stride = (int64_t)gridDim.y * R;
+        int64_t b = (int64_t)blockIdx.y * R + tr;
+        for (; b + 3 * stride < n; b += 4 * stride) {
+            float v[4], yy[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t e = (b + k * stride) * units + c;
+                v[k] = d[e];
+                yy[k] = y[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(yy[k] > 0.f)) {
+                    v[k] = 0.f;
+                    d[(b + k * stride) * units + c] = 0.f;
+                }
+                s += v[k];
+            }
+        }
+        for (; b < n; b += stride) {
             const int64_t e = b * units + c;
             float v = d[e];
             if (!(y[e] > 0.f)) {
@@ -496,6 +516,16 @@ __device__ __forceinline__ void nmf_row_pass(const el_nmf_state& st, const NmfRo
 #pragma unroll
                     for (int x = 0; x < VW; ++x) el_adam_elem(r.a[k][q][x], r.m[k][q][x], r.v[k][q][x], g[k][q][x], lr_t, b1, b2, omb1, omb2, eps);
         } else {
+            // m = v = 0 (rows that never had a gradient) is a fixed point of the gradient-free step -- m <- 0, v <- 0,
+            // theta <- theta - lr 0 / (0 + eps) = theta: nothing to replay and nothing to write, whatever the gap
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) nz = nz || r.m[k][q][x] != 0.f || r.v[k][q][x] != 0.f;
+            if (__ballot(nz) == 0ull) continue;
             nmf_rows_replay<VW, Q, true>(r, lr_from, nsteps);
         }
         float* const dth[2] = {rt.th[0], rt.th[1]};
@@ -555,6 +585,8 @@ __global__ __launch_bounds__(256) void k_nmf_apply_rows(el_nmf_state st, const i
                                                         int64_t n, int32_t t, float lr_t) {
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p == 0 && lane == 0) st.lr_hist[t - st.hist_base] = lr_t;        // this step's lr_t for later replays (the replays of this
+    //                                                                      kernel read steps < t only)
     if (p >= 2 * n) return;
     const int side = p >= n ? 1 : 0;
     const int64_t b = p - (side ? n : 0);
@@ -577,8 +609,6 @@ __global__ __launch_bounds__(256) void k_nmf_flush_rows(el_nmf_state st, int sid
         if (lane == 0) st.row_last[side][row] = t;
     }
 }
-
-__global__ void k_nmf_hist_set(float* hist, int32_t idx, float lr_t) { hist[idx] = lr_t; }
 
 // ---- host -------------------------------------------------------------------------------------------------------
 static unsigned g1(int64_t n, el_ctx* ctx) {
@@ -762,7 +792,6 @@ static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t) {
         EL_REQUIRE(st->batch_u && st->batch_i && st->batch_n >= 1, "el_nmf_apply: deferred decay applies the rows of the preceding el_nmf_grads");
         const int32_t t = st->opt_step + 1;
         EL_REQUIRE(t - st->hist_base < st->lr_hist_cap, "el_nmf_apply: lr history overrun");        // (nmf_begin_rows made room)
-        EL_LAUNCH("k_nmf_hist_set", k_nmf_hist_set, dim3(1), dim3(1), 0, s, st->lr_hist, t - st->hist_base, lr_t);
         EL_LAUNCH("k_nmf_apply_rows", k_nmf_apply_rows, dim3((unsigned)((2 * st->batch_n + 3) / 4)), dim3(256), 0, s, *st, st->batch_u,
                   st->batch_i, st->batch_n, t, lr_t);
         st->batch_u = st->batch_i = nullptr, st->batch_n = 0;
