@@ -511,7 +511,17 @@ __global__ __launch_bounds__(256) void k_gemm_sk_fix(GemmParams p) {
         // the partial tiles are added in workgroup order (deterministic), but FETCHED eight at a time: a product with a huge K and
         // few tiles (dW = X^T dY, K = the batch) has ~60 contributors per tile, and one dependent 16-byte load per addition made
         // this kernel a chain of ~60 memory latencies (66 us per launch at the NeuMF shapes)
-        for (int64_t w0 = wa + 1; w0 <= wb; w0 += 8) {
+        int64_t w0 = wa + 1;
+        if (wb - wa <= 2) {                                     // a tile cut once or twice (many-tile products): nothing to batch
+            for (; w0 <= wb; ++w0) {
+                const float4 b = *reinterpret_cast<const float4*>(p.ws + (2 * w0) * (int64_t)(BM * BN) + e);
+                a.x += b.x;
+                a.y += b.y;
+                a.z += b.z;
+                a.w += b.w;
+            }
+        }
+        for (; w0 <= wb; w0 += 8) {
             float4 b[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
