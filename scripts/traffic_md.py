@@ -19,6 +19,14 @@ for leg, w in s["workloads"].items():
         U, I, F, B = c["users"], c["items"], c["factors"], c["batch"]
         alg = {"k_adam_rows_Gu": 24 * U * F, "k_adam_dense_Gi": 24 * I * F, "k_bpr_user_seg": B * (16 * F + 28), "k_bpr_item_seg": 2 * B * (8 * F + 12),
                "k_bpr_sample": 48 * B, "k_bpr_user_adam": 24 * U * F + B * (8 * F + 28)}
+        if 4 * B <= U:
+            # deferred decay of the user table (the state turns it on when 4 B <= U): the user side moves the rows of the batch's
+            # distinct users only -- expected U (1 - exp(-B / U)) of them for uniformly drawn users
+            import math
+            rows = U * (1.0 - math.exp(-B / U))
+            alg["k_bpr_user_seg"] = 28 * rows * F + B * (8 * F + 32)      # theta, m, v read + written, old row written, gamma_i / gamma_j
+            alg["k_bpr_catchup"] = 24 * rows * F                           # upper bound: every one of those rows replayed and rewritten
+            alg["k_bpr_flush_users"] = 24 * U * F
         print(f"## {leg}: BPRMF {U:,} users x {I:,} items, d = {F}, B = {B:,}, top-k block {c['topk_block']:,}\n")
     else:
         print(f"## {leg}: {c}\n")
@@ -35,6 +43,8 @@ for leg, w in s["workloads"].items():
     print()
 print("Algorithmic bytes: SURVEY 8d figures x the units of one launch (DESIGN.md 6): dense Adam 24 B / parameter; the fused user-side kernel")
 print("`k_bpr_user_adam` = 24 B / parameter of the user table + `8 F + 28` B / triplet (gamma_i, gamma_j gathers); user segments `16 F + 28` B /")
-print("triplet, item segments `8 F + 12` B / occurrence (2 per triplet), sampler 48 B / triplet.  Ratios below 1 are L2 / Infinity-Cache hits on")
+print("triplet (with the deferred decay of the user table, workloads with 4 B <= U: theta, m, v of the batch's distinct users read + written and the")
+print("pre-update row written, `28 F` B / row, + `8 F + 32` B / triplet; `k_bpr_catchup` at most 24 F B / row -- rows whose m = v = 0 are skipped),")
+print("item segments `8 F + 12` B / occurrence (2 per triplet), sampler 48 B / triplet.  Ratios below 1 are L2 / Infinity-Cache hits on")
 print("re-used rows (hot items).  The rocPRIM rows average the step's 3 M-pair sort together with the 10^8-element sorts torch runs while the")
 print("synthetic data set is generated in the same process; `k_gemm_f32` rows of the vae / neumf legs average launches of many shapes.")
