@@ -491,21 +491,10 @@ __global__ __launch_bounds__(256) void k_bpr_user_adam(SegParams p, FusedParams 
 // inside the fused kernel left ~15 % of the lanes busy: rows of one wave wait ~10 steps on average, the longest of them ~30).
 // m = v = 0 (a row that never had a gradient) is a fixed point of the gradient-free step: nothing to replay, whatever the gap.
 template <int VW>
-__global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u32* __restrict__ keys, int64_t B, int32_t t,
-                                                     float* __restrict__ hist, int hist_mask, float lr_t) {
+__device__ __forceinline__ void bpr_replay_row(const el_bprmf_state& st, int64_t row, int lane, int last, int ns, const float* __restrict__ hist,
+                                               int hist_mask) {
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p == 0 && lane == 0) hist[t & hist_mask] = lr_t;        // lr_t of THIS step into the ring (the replays below read steps < t)
-    if (p >= B) return;
-    const u32 key = keys[p];
-    if (p > 0 && keys[p - 1] == key) return;                   // not a segment head
-    const int64_t row = (int64_t)key;
-    const int last = st.Gu_last[row];
-    const int ns = (t - 1) - last;
-    if (ns <= 0) return;
     const int F = st.F;
-    bool wrote = false;
     for (int f0 = 0; f0 < F; f0 += 64 * VW) {
         const int e = f0 + lane * VW;
         float th[VW], mm[VW], vv[VW];
@@ -530,60 +519,36 @@ __global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u3
             stv<VW>(st.mGu + row * F + e, mm);
             stv<VW>(st.vGu + row * F + e, vv);
         }
-        wrote = true;
     }
-    (void)wrote;
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u32* __restrict__ keys, int64_t B, int32_t t,
+                                                     float* __restrict__ hist, int hist_mask, float lr_t) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p == 0 && lane == 0) hist[t & hist_mask] = lr_t;        // lr_t of THIS step into the ring (the replays below read steps < t)
+    if (p >= B) return;
+    const u32 key = keys[p];
+    if (p > 0 && keys[p - 1] == key) return;                   // not a segment head
+    const int64_t row = (int64_t)key;
+    const int last = st.Gu_last[row];
+    const int ns = (t - 1) - last;
+    if (ns <= 0) return;
+    bpr_replay_row<VW>(st, row, lane, last, ns, hist, hist_mask);
     if (lane == 0) st.Gu_last[row] = t - 1;
 }
 
-// deferred decay: every user row up to step t (one lane group per row, grid-stride)
-template <int CPL>
-__global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int lpt, int32_t t, const float* __restrict__ hist, int hist_mask) {
-    constexpr int VW = 4;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    const int F = st.F;
-    const int sub = (int)(threadIdx.x & (lpt - 1));
-    const int64_t ngroups = (int64_t)gridDim.x * (256 / lpt);
-    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpt; row < st.U; row += ngroups) {
+// deferred decay: every user row up to step t (one WAVE per row, grid-stride; same row walk as k_bpr_catchup)
+template <int VW>
+__global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < st.U; row += (int64_t)gridDim.x * 4) {
         const int last = st.Gu_last[row];
         const int ns = t - last;
         if (ns <= 0) continue;
-        float th[CPL][VW], mm[CPL][VW], vv[CPL][VW];
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const int e = (sub + q * lpt) * VW;
-#pragma unroll
-            for (int x = 0; x < VW; ++x) th[q][x] = mm[q][x] = vv[q][x] = 0.f;
-            if (e < F) {
-                ldv<VW>(st.Gu + row * F + e, th[q]);
-                ldv<VW>(st.mGu + row * F + e, mm[q]);
-                ldv<VW>(st.vGu + row * F + e, vv[q]);
-            }
-        }
-        bool nz = false;                                        // m = v = 0: a fixed point of the gradient-free step (see k_bpr_user_adam)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q)
-#pragma unroll
-            for (int x = 0; x < VW; ++x) nz = nz || mm[q][x] != 0.f || vv[q][x] != 0.f;
-        if (el_group_any(nz, lpt)) {
-            for (int s = 0; s < ns; ++s) {
-                const float lr = hist[(last + 1 + s) & hist_mask];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) el_adam_elem(th[q][x], mm[q][x], vv[q][x], 0.0f, lr, b1, b2, omb1, omb2, eps);
-            }
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                const int e = (sub + q * lpt) * VW;
-                if (e < F) {
-                    stv<VW>(st.Gu + row * F + e, th[q]);
-                    stv<VW>(st.mGu + row * F + e, mm[q]);
-                    stv<VW>(st.vGu + row * F + e, vv[q]);
-                }
-            }
-        }
-        if (sub == 0) st.Gu_last[row] = t;
+        bpr_replay_row<VW>(st, row, lane, last, ns, hist, hist_mask);
+        if (lane == 0) st.Gu_last[row] = t;
     }
 }
 
@@ -779,14 +744,17 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
 
 // (u, b), (U + i, b), (U + j, b | neg) -> one stable radix sort: the first B sorted entries are the user side, the next 2B
 // the item side (every user key is below every item key)
+// with_rowptr: also rowptr[U + 1] of the sorted user keys (the every-row fused user kernel walks rows, not positions) -- here, not
+// in front of that kernel, so that a pipelined step prepares it on the side stream together with the sort
 static int sort_batch(hipStream_t s, const SortedWs& w, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
-                      int64_t U, int64_t I) {
+                      int64_t U, int64_t I, bool with_rowptr) {
     EL_REQUIRE(U + I < (1LL << 32) && 3 * B < (1LL << 32), "sorted gradient path: U + I and 3B must fit 32-bit sort keys");
     EL_LAUNCH("k_bpr_prep", k_bpr_prep, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, w.keyU_in, w.valU_in,
               w.keyI_in, w.valI_in, (u32)U);
     ElKernelTimer t("rocprim_radix_sort_pairs", s);
     size_t tb = w.tmp_bytes;
     EL_CHECK_HIP(rocprim::radix_sort_pairs(w.tmp, tb, w.keyU_in, w.keyU, w.valU_in, w.valU, (unsigned)(3 * B), 0, bits_for(U + I), s));
+    if (with_rowptr) EL_LAUNCH("k_bpr_rowptr", k_bpr_rowptr, dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, s, w.keyU, B, U, w.rowptr);
     return 0;
 }
 
@@ -808,15 +776,13 @@ int el_bprmf_apply_items_adam(el_ctx* ctx, hipStream_t s, const el_bprmf_state& 
 
 // user side of the step as ONE kernel (el_bprmf_state.Gu_next): rowptr, then segments + Adam over every user row
 static int launch_flush_users(const el_bprmf_state& st, hipStream_t s, int32_t t) {
-    int cpl = 1;
-    const int lpt = el_pick_lpt(st.F, 4, &cpl);
-    EL_REQUIRE(cpl <= 2, "el_bprmf_sync_users: F=%d too large for the deferred decay", st.F);
-    const int64_t groups = st.U, per = 256 / lpt;
-    int64_t grid = (groups + per - 1) / per;
-    if (grid > (1 << 16)) grid = 1 << 16;
+    EL_REQUIRE(st.F % 4 == 0 && st.F <= 512, "el_bprmf_sync_users: F=%d outside the deferred decay's range", st.F);
+    int64_t grid = (st.U + 3) / 4;
+    if (grid > (1 << 18)) grid = 1 << 18;
     const int mask = st.lr_hist_cap - 1;
-    if (cpl == 1) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<1>, dim3((unsigned)grid), dim3(256), 0, s, st, lpt, t, st.lr_hist, mask);
-    else EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<2>, dim3((unsigned)grid), dim3(256), 0, s, st, lpt, t, st.lr_hist, mask);
+    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<4>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<2>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<1>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -843,7 +809,7 @@ static int launch_user_adam(const SegParams& pu, hipStream_t s, int64_t B, const
     f.rowptr = w.rowptr;
     f.Gu_new = pu.st.Gu_next;
     f.lr_t = lr_t, f.b1 = 0.9f, f.b2 = 0.999f, f.eps = 1e-7f;
-    EL_LAUNCH("k_bpr_rowptr", k_bpr_rowptr, dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, s, w.keyU, B, pu.st.U, w.rowptr);
+    // (rowptr was filled behind the sort: sort_batch)
     static const int rpg = [] { const char* e = getenv("EL_FUSED_RPG"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 8) ? v : 4; }();
     const int64_t groups = (pu.st.U + rpg - 1) / rpg;
     const unsigned grid = (unsigned)((groups * lpt + 255) / 256);
@@ -933,7 +899,7 @@ static int sorted_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, con
                ws_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
     if (!presorted)
-        if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
+        if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I, st.Gu_next != nullptr && st.Gu_last == nullptr)) return rc;
     if (st.uslot) {
         EL_REQUIRE(vec && ((uintptr_t)st.gGu_rows & 15) == 0 && !rows_mode && (opt == EL_OPT_ADAM_TF_DENSE || opt < 0),
                    "el_bprmf_train_step: compact user-gradient rows need F %% 4 == 0, 16-byte aligned tables and the TF-dense Adam");
@@ -996,7 +962,7 @@ int el_bpr_sorted_cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st
     SortedWs w;
     EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_cml_train_step: segment workspace too small (%zu < %zu)", ws_bytes, w.total);
-    if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I)) return rc;
+    if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I, false)) return rc;
     SegParams base;
     memset(&base, 0, sizeof(base));
     base.st = st;
@@ -1026,7 +992,7 @@ extern "C" int el_bprmf_presort(el_ctx* ctx, void* stream, const int32_t* u, con
     SortedWs w;
     EL_REQUIRE(carve_ws(B, U, I, (char*)ws, &w) == 0, "el_bprmf_presort: rocprim size query failed");
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_presort: workspace too small (%zu < %zu)", ws_bytes, w.total);
-    return sort_batch((hipStream_t)stream, w, u, i, j, B, U, I);
+    return sort_batch((hipStream_t)stream, w, u, i, j, B, U, I, true);
 }
 
 extern "C" int el_bprmf_grads_presorted(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u, const int32_t* i,
