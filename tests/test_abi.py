@@ -91,3 +91,30 @@ def test_header_is_plain_c():
         if f.endswith(".h"):
             subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, f)],
                            check=True)
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every state struct of include/elliot_hip.h against its ctypes mirror in elliot_amd/_lib.py: same size, every field at the
+    same offset (a C program built from the header prints offsetof / sizeof; the structs grow at their end with the ABI version,
+    and a field added on one side only would silently shift everything behind it)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"el_bprmf_state": _lib.BprmfState, "el_bprsgd_state": _lib.BprsgdState, "el_vae_state": _lib.VaeState,
+             "el_nmf_state": _lib.NmfState, "el_pwmf_state": _lib.PwmfState}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "elliot_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'    printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'    printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), (cname, out[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
