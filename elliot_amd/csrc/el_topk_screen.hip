@@ -21,14 +21,15 @@
 //           max per ACCUMULATOR POSITION: item tile row (64 of them) -> 64 disjoint item groups per user ("slot maxima").
 //   thr     k_screen_thr           per user: slots whose maximum may belong to a masked (train) item are dropped -- the
 //           masked items of the best slots are re-scored on the VALU and compared with a tolerance; T = kA-th largest
-//           surviving slot maximum, thr = T - 2 E_u.  With stride 1 and kA = k, T is RIGOROUS (k distinct unmasked items
-//           reach it); otherwise T is a GUESS aimed at rank ~3k that k_screen_final verifies (screen_policy below).
+//           surviving slot maximum, thr = T - b E_u.  With stride 1 and kA = k, T is RIGOROUS (k distinct unmasked items
+//           reach it) and b = 2; otherwise T is a GUESS aimed at rank ~5k that k_screen_final verifies (screen_policy below),
+//           and b in [0.75, 1.5] follows the spacing of the user's top scores (see the kernel).
 //   pass 2  k_screen_pass<MODE 2>  the GEMM over every tile (bit-identical s'), epilogue = max over the 16 accumulators of a
 //           lane against thr; the rare hit appends one record (tile, row block, row mask) + its s' to the user's list
 //           (surv + nnz_u slots, masked or not).
 //   final   k_screen_final         per user: expand records, drop masked items, second-level screen on the recorded s',
-//           exact fp32 chain for what is left, sort, VERIFY: k candidates with an exact score >= T - E_u prove that no
-//           non-candidate (s' < T - 2 E_u, hence exact < T - E_u) belongs to the top-k; write.
+//           exact fp32 chain for what is left, sort, VERIFY: k candidates with an exact score >= V = thr + E_u prove that no
+//           non-candidate (s' < thr, hence exact < thr + E_u) belongs to the top-k; write.
 //   Users that fail the verification, have fewer than kA clean slots, a non-finite bound, or more than `surv` unmasked hits
 //   are flagged and recomputed exactly (el_topk_run_list in el_topk.hip), so the result is exact for every input.
 //
@@ -214,11 +215,12 @@ struct ScreenParams {
     int32_t* ulist;              // [n_users] flagged users (relative ids), filled by k_screen_flags
     int32_t* ulist_n;            // [1]
     const void* zeros;           // >= 16 bytes of zeros in device memory (LDS-DMA source of rows past the catalogue's end)
-    float* Tg;                   // [n_users] the threshold guess T (thr = T - 2E); k_screen_final verifies it
+    float* Tg;                   // [n_users] V = thr + E: the level the k-th exact score must reach (k_screen_final verifies it)
     float* Eu;                   // [n_users] E_u
     float* nuv;                  // [n_users] ||u|| (with margin), k_screen_thr
     float* duv;                  // [n_users] ||u - bf16(u)||
     float2* inorm;               // [I_local] (||bf16(i)||, ||i - bf16(i)||) per item (with margins), k_screen_prep
+    float band, band_min;        // thr = T - b E_u, b in [band_min, band] per user (k_screen_thr); 2 = the band a rigorous T needs
     int kA;                      // T = kA-th largest clean slot maximum (== k with stride 1: T is then rigorous)
     int surv;                    // unmasked hits a user may have before it is sent to the exact fallback (128 or 512)
     int stride;                  // pass 1 visits tiles t with t % stride == 0
@@ -578,7 +580,7 @@ __global__ SCR_LB void k_screen_thr(ScreenParams sp) {
     const int kA = sp.kA;
     int R = kA + 8 < SCR_TI ? kA + 8 : SCR_TI;
     bool good = false;
-    float T = 0.f;
+    float T = 0.f, D = INFINITY;
     for (int lo = 0; lo < SCR_TI && !good; lo = R, R = SCR_TI) {
         // one lane per masked item, 64 in flight: index (coalesced) -> slot -> is the slot in this round? -> bf16 row dot
         for (int64_t eb = e0; eb < e1; eb += 64) {
@@ -620,12 +622,29 @@ __global__ SCR_LB void k_screen_thr(ScreenParams sp) {
             for (int q = 1; q < kA; ++q) clean &= clean - 1ull;
             T = el_key_score(keys[__ffsll((long long)clean) - 1]);
             good = true;
+            // how far the guess may sit above the true k-th score is a matter of RANKS (the sample's kA-th maximum lands a few
+            // ranks either side of its target), so the slack under it is sized by the local spacing of the top scores: D = the
+            // drop over the next four clean slot maxima (~ 4 x stride ranks of the catalogue)
+            u64 c3 = clean;
+            for (int q = 0; q < 4; ++q) c3 &= c3 - 1ull;
+            D = c3 ? T - el_key_score(keys[__ffsll((long long)c3) - 1]) : INFINITY;
         }
     }
     if (lane == 0) {
         good = good && (E < INFINITY);
-        sp.thr[ur] = good ? (T - 2.0f * E) : INFINITY;
-        sp.Tg[ur] = T;
+        // thr = T - b E.  Every item outside the candidate list has s' < thr, hence an exact score < thr + E =: V, and
+        // k_screen_final accepts the user iff its k-th exact score reaches V (the exact fallback takes the others).  b = 2 (V = T - E)
+        // can never reject a RIGOROUS T.  A guessed T is aimed well below the k-th score (rank ~5 k of the catalogue), so the part of
+        // the band beyond E -- slack for the guess -- is mostly unused, and E, a worst-case bound, is ~50 ranks wide at the top of a
+        // trained table: b = 2 collects 212 records per user there, b = 0.75 (V = T + E / 4) 127 and still rejects nobody (4.76 ->
+        // 4.22 ms per block).  On fresh tables E is a rank or two wide and V moves with it: 11 users of 131 072 rejected at b = 2 or
+        // 1.5, 39 at 1, 86 at 0.75 (each costs the fallback ~5 us; b = 1.5 is the fastest there).  The regime shows in the data:
+        // r = D / E, the drop over four slot maxima in units of E, is ~0.6 on the trained tables and >> 1 on fresh ones:
+        // b = clamp(0.5 + 0.4 r, band_min, band).
+        float bnd = sp.band;
+        if (sp.band_min < sp.band && E > 0.f && D < INFINITY) bnd = fminf(sp.band, fmaxf(sp.band_min, 0.5f + 0.4f * (D / E)));
+        sp.thr[ur] = good ? (T - bnd * E) : INFINITY;
+        sp.Tg[ur] = T - (bnd - 1.0f) * E;                       // V
         sp.Eu[ur] = E;
         sp.nuv[ur] = nu;
         sp.duv[ur] = du;
@@ -834,8 +853,8 @@ __global__ SCR_LB void k_screen_final(ScreenParams sp) {
         return;
     }
     // the threshold was a guess unless pass 1 saw every tile (kA == k): it was good enough iff k survivors have an exact
-    // score >= T - E, because every item that is NOT a survivor has s' < T - 2E, hence an exact score < T - E
-    if (!(el_key_score(surv[p.k - 1]) >= sp.Tg[ur] - sp.Eu[ur])) {
+    // score >= V = thr + E, because every item that is NOT a survivor has s' < thr, hence an exact score < thr + E
+    if (!(el_key_score(surv[p.k - 1]) >= sp.Tg[ur])) {            // Tg = V = thr + E (k_screen_thr)
         if (lane == 0) sp.ovf[ur] = 1;
         return;
     }
@@ -879,6 +898,7 @@ bool el_topk_screen_eligible(int F, int k, const void* cand) { return cand == nu
 // k_screen_final verifies it per user (exact fallback otherwise).  surv = unmasked hits a user may have.
 struct ScreenPolicy {
     int stride, kA, surv;
+    float band, band_min;
 };
 
 static ScreenPolicy screen_policy(int k, int64_t I_local) {
@@ -887,6 +907,7 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
     q.stride = 1;
     q.kA = k;
     q.surv = 128;
+    q.band = q.band_min = 2.0f;
     if (k <= 12) {
         // every 8th tile from 60 K items (round 2: at I = 100 K pass 1 drops 0.66 -> 0.36 ms and the sample of 12.5 K items still
         // gives a usable guess: 4.52 -> 4.24 ms per 131 072-user block, nobody falls back; scripts/screen_sweep.sh), every 4th
@@ -915,7 +936,15 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
         const int v = atoi(se);
         if (v >= 1 && v <= 56) q.kA = v;
     }
-    if (q.stride > 1 || q.kA != k) q.surv = 512;
+    if (q.stride > 1 || q.kA != k) {
+        q.surv = 512;
+        q.band = 1.5f, q.band_min = 0.75f;                      // a guessed T: the band follows the spacing of the top scores (k_screen_thr)
+        if (const char* se = getenv("EL_SCREEN_BAND")) {        // experiments: "max[,min]" (one number: a fixed band)
+            float hi = 2.0f, lo = 1.0f;
+            const int n = sscanf(se, "%f,%f", &hi, &lo);
+            if (n >= 1 && hi >= 0.25f && hi <= 2.0f) q.band = hi, q.band_min = (n >= 2 && lo >= 0.25f && lo <= hi) ? lo : hi;
+        }
+    }
     return q;
 }
 
@@ -1029,6 +1058,8 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     sp.stride = pol.stride;
     sp.zeros = g_el_cur_ctx->zeros;
     sp.kA = pol.kA;
+    sp.band = pol.band;
+    sp.band_min = pol.band_min;
     sp.ulist_n = (int32_t*)(stats + 2);
     void* fb_scratch = base;
     const size_t fb_bytes = el_topk_list_scratch_bytes(n_users, p.I_local, p.k);
