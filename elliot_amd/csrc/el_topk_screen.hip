@@ -23,7 +23,7 @@
 //           masked items of the best slots are re-scored on the VALU and compared with a tolerance; T = kA-th largest
 //           surviving slot maximum, thr = T - b E_u.  With stride 1 and kA = k, T is RIGOROUS (k distinct unmasked items
 //           reach it) and b = 2; otherwise T is a GUESS aimed at rank ~5k that k_screen_final verifies (screen_policy below),
-//           and b in [0.75, 1.5] follows the spacing of the user's top scores (see the kernel).
+//           and b in [1, 1.5] follows the spacing of the user's top scores (see the kernel).
 //   pass 2  k_screen_pass<MODE 2>  the GEMM over every tile (bit-identical s'), epilogue = max over the 16 accumulators of a
 //           lane against thr; the rare hit appends one record (tile, row block, row mask) + its s' to the user's list
 //           (surv + nnz_u slots, masked or not).
@@ -640,7 +640,8 @@ __global__ SCR_LB void k_screen_thr(ScreenParams sp) {
         // 4.22 ms per block).  On fresh tables E is a rank or two wide and V moves with it: 11 users of 131 072 rejected at b = 2 or
         // 1.5, 39 at 1, 86 at 0.75 (each costs the fallback ~5 us; b = 1.5 is the fastest there).  The regime shows in the data:
         // r = D / E, the drop over four slot maxima in units of E, is ~0.6 on the trained tables and >> 1 on fresh ones:
-        // b = clamp(0.5 + 0.4 r, band_min, band).
+        // b = clamp(0.5 + 0.4 r, band_min, band) with band_min = 1 (V = T: the k-th exact score has to reach the guess itself;
+        // 0.75 already sends a hundred users of the bench's lightly trained tables to the fallback: 4.49 against 4.26 ms).
         float bnd = sp.band;
         if (sp.band_min < sp.band && E > 0.f && D < INFINITY) bnd = fminf(sp.band, fmaxf(sp.band_min, 0.5f + 0.4f * (D / E)));
         sp.thr[ur] = good ? (T - bnd * E) : INFINITY;
@@ -938,7 +939,7 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
     }
     if (q.stride > 1 || q.kA != k) {
         q.surv = 512;
-        q.band = 1.5f, q.band_min = 0.75f;                      // a guessed T: the band follows the spacing of the top scores (k_screen_thr)
+        q.band = 1.5f, q.band_min = 1.0f;                       // a guessed T: the band follows the spacing of the top scores (k_screen_thr)
         if (const char* se = getenv("EL_SCREEN_BAND")) {        // experiments: "max[,min]" (one number: a fixed band)
             float hi = 2.0f, lo = 1.0f;
             const int n = sscanf(se, "%f,%f", &hi, &lo);
