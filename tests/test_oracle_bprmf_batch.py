@@ -106,3 +106,43 @@ def test_train_step_decreases_loss_and_matches_manual_composition():
     o2 = ob.BPRMFBatchOracle(Gu, Gi, Bi, lr=0.01, l_w=0.1, l_b=0.001)
     o2.train_step((u, i, j))
     assert np.array_equal(o2.Gu, th)
+
+
+def test_postponed_gradient_free_adam_steps_replay_to_the_same_bits():
+    """The invariant the device's deferred decay rests on, on the oracle itself: Keras' sparse apply moves
+    EVERY row at every step, but for a row without a gradient the update reads nothing except that row -- so postponing it and
+    replaying the missed steps later (the same fp32 operations, same order, each step's own lr_t) gives the same bits as moving
+    the row at every step.  Eager table against a lazily caught-up one over 30 steps with random touched sets, rows never
+    touched, rows touched in bursts."""
+    from oracle.bprmf_batch import adam_tf_sparse_apply
+    rs = np.random.RandomState(4)
+    R, F, T, lr = 300, 12, 30, 0.01
+    th0 = rs.standard_normal((R, F)).astype(np.float32)
+    eager = [th0.copy(), np.zeros_like(th0), np.zeros_like(th0)]
+    lazy = [th0.copy(), np.zeros_like(th0), np.zeros_like(th0)]
+    last = np.zeros(R, np.int64)
+
+    def catch_up(rows, upto):
+        """rows of the lazy table to step `upto`: every missed gradient-free step, in order, with that step's lr_t"""
+        for r in rows:
+            for s in range(last[r] + 1, upto + 1):
+                z = np.zeros((1, F), np.float32)
+                sl = [a[r:r + 1] for a in lazy]
+                adam_tf_sparse_apply(sl[0], sl[1], sl[2], z, lr, s)
+            last[r] = max(last[r], upto)
+
+    for t in range(1, T + 1):
+        n = 0 if t % 7 == 0 else rs.randint(1, 40)
+        rows = np.unique(rs.randint(0, R // 2 if t % 2 else R - 20, n))        # the last 20 rows never get a gradient
+        g = np.zeros((R, F), np.float32)
+        g[rows] = rs.standard_normal((len(rows), F)).astype(np.float32)
+        adam_tf_sparse_apply(eager[0], eager[1], eager[2], g, lr, t)          # every row, every step
+        catch_up(rows, t - 1)                                                 # the batch's rows to t - 1 ...
+        for r in rows:                                                        # ... then step t with their gradient
+            sl = [a[r:r + 1] for a in lazy]
+            adam_tf_sparse_apply(sl[0], sl[1], sl[2], g[r:r + 1], lr, t)
+            last[r] = t
+        if t in (11, T):                                                      # a read of the whole table: flush
+            catch_up(range(R), t)
+            for a, b in zip(eager, lazy):
+                assert np.array_equal(a, b), t
