@@ -165,32 +165,48 @@ __global__ __launch_bounds__(256) void k_nmf_gather(el_nmf_state st, const int32
 // every wave keeps its share in registers (feature f = lane + 64 q), the four waves of a workgroup are combined in LDS and
 // each workgroup issues one atomic per feature -- per-sample atomics on those few addresses cost 6.4 ms at B = 262 144.
 #define NMF_HEAD_Q 16                                    // features per lane held in registers: F + Hl <= 1024
+// Q = ceil((F + Hl) / 64) rounded up to a power of two (host): the feature loops carry no dead iterations; the head weights
+// sit in registers; the NEXT sample's row is fetched while this one's reduction / exp / log chain runs.
+template <int Q>
 __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* __restrict__ label, int64_t n, int mode,
                                                   float* out_prob, double* loss_out, int64_t n_div) {
     __shared__ float wsum[4];
-    __shared__ float facc[4][64 * NMF_HEAD_Q];
+    __shared__ float facc[4][64 * Q];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int F = st.use_mf ? st.F : 0;
     const int Hl = st.use_mlp ? st.units[st.n_layers - 1] : 0;
     const int NF = F + Hl;
     const float hbias = st.head_bias ? st.hb[0] : 0.f;
-    float acc[NMF_HEAD_Q];
+    const float* act_last = st.use_mlp ? st.act[st.n_layers - 1] : nullptr;
+    float* dact_last = st.use_mlp ? st.dact[st.n_layers - 1] : nullptr;
+    float acc[Q], hwr[Q];
 #pragma unroll
-    for (int q = 0; q < NMF_HEAD_Q; ++q) acc[q] = 0.f;
+    for (int q = 0; q < Q; ++q) {
+        acc[q] = 0.f;
+        const int f = lane + 64 * q;
+        hwr[q] = f < NF ? st.hw[f] : 0.f;
+    }
+    auto fetch = [&](int64_t b, float (&v)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int f = lane + 64 * q;
+            v[q] = 0.f;
+            if (f < NF) v[q] = f < F ? st.MF[b * F + f] : act_last[b * (int64_t)Hl + (f - F)];
+        }
+    };
     float bacc = 0.f, myloss = 0.f;
-    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n; b += (int64_t)gridDim.x * 4) {
-        const float* hlast = st.use_mlp ? st.act[st.n_layers - 1] + b * (int64_t)Hl : nullptr;
-        float val[NMF_HEAD_Q];
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wv;
+    float nxt[Q];
+    if (b < n) fetch(b, nxt);
+    for (; b < n; b += stride) {
+        float val[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) val[q] = nxt[q];
+        if (b + stride < n) fetch(b + stride, nxt);
         float part = 0.f;
 #pragma unroll
-        for (int q = 0; q < NMF_HEAD_Q; ++q) {
-            const int f = lane + 64 * q;
-            val[q] = 0.f;
-            if (f < NF) {
-                val[q] = f < F ? st.MF[b * F + f] : hlast[f - F];
-                part += val[q] * st.hw[f];
-            }
-        }
+        for (int q = 0; q < Q; ++q) part += val[q] * hwr[q];    // (features beyond NF: 0 * 0; same order of the live terms as before)
         const float logit = el_group_sum(part, 64) + hbias;
         const float p = 1.0f / (1.0f + expf(-logit));
         if (mode == 0) {
@@ -206,16 +222,16 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
         // d loss / d (pre-activation of the last Dense(relu) layer) = dlogit w_f where its output is positive: the ReLU derivative
         // is taken here, where the output row is in registers
 #pragma unroll
-        for (int q = 0; q < NMF_HEAD_Q; ++q) {
+        for (int q = 0; q < Q; ++q) {
             acc[q] += dlogit * val[q];
             const int f = lane + 64 * q;
-            if (f >= F && f < NF) st.dact[st.n_layers - 1][b * (int64_t)Hl + (f - F)] = val[q] > 0.f ? dlogit * st.hw[f] : 0.f;
+            if (f >= F && f < NF) dact_last[b * (int64_t)Hl + (f - F)] = val[q] > 0.f ? dlogit * hwr[q] : 0.f;
         }
         bacc += dlogit;
     }
     if (mode == 0) return;
 #pragma unroll
-    for (int q = 0; q < NMF_HEAD_Q; ++q) facc[wv][lane + 64 * q] = acc[q];
+    for (int q = 0; q < Q; ++q) facc[wv][lane + 64 * q] = acc[q];
     float wl = el_group_sum(myloss, 64);
     if (lane == 0) wsum[wv] = wl;
     __syncthreads();
@@ -228,6 +244,20 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
         const double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
         if (tot != 0.0) atomicAdd(loss_out, tot);
     }
+}
+
+static void launch_nmf_head(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const float* label, int64_t n, int mode, float* out_prob,
+                            double* loss_out, int64_t n_div, unsigned grid) {
+    const int NF = (st->use_mf ? st->F : 0) + (st->use_mlp ? st->units[st->n_layers - 1] : 0);
+    const int nq = (NF + 63) / 64;
+#define EL_HEAD(Q_) EL_LAUNCH("k_nmf_head", k_nmf_head<Q_>, dim3(grid), dim3(256), 0, s, *st, label, n, mode, out_prob, loss_out, n_div)
+    if (nq <= 1) EL_HEAD(1);
+    else if (nq <= 2) EL_HEAD(2);
+    else if (nq <= 4) EL_HEAD(4);
+    else if (nq <= 8) EL_HEAD(8);
+    else EL_HEAD(16);
+#undef EL_HEAD
+    (void)ctx;
 }
 
 // in place: d <- d * (y > 0)   (relu backward)
@@ -681,12 +711,12 @@ static int nmf_begin_rows(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const in
     const int32_t t = st->opt_step + 1;
     if (t - st->hist_base >= st->lr_hist_cap)            // history full: bring every row to t - 1, restart the history at t
         if (int rc = nmf_sync(ctx, s, st)) return rc;
-    st->claim_seq += 1;
-    if (st->claim_seq <= 0) {                            // 2^31 gradient evaluations: start the claim numbers again
+    if (st->claim_seq >= 0x7ffffffe || st->claim_seq < 0) {     // 2^31 gradient evaluations: start the claim numbers again
         EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[0], 0, (size_t)st->U * 4, s));
         EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[1], 0, (size_t)st->I * 4, s));
-        st->claim_seq = 1;
+        st->claim_seq = 0;
     }
+    st->claim_seq += 1;
     EL_LAUNCH("k_nmf_catchup", k_nmf_catchup, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, s, *st, u, i, n, t, st->claim_seq);
     EL_CHECK_LAUNCH();
     st->batch_u = u, st->batch_i = i, st->batch_n = n;
@@ -728,7 +758,7 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, el_nmf_state* st, const
     hipStream_t s = (hipStream_t)stream;
     if (int rc = nmf_sync(ctx, s, st)) return rc;
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
-    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, (const float*)nullptr, n, 0, out_prob, (double*)nullptr, n);
+    launch_nmf_head(ctx, s, st, nullptr, n, 0, out_prob, nullptr, n, head_grid(n, ctx));
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -751,7 +781,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
         for (int l = 0; l < st->n_layers; ++l) EL_CHECK_HIP(hipMemsetAsync(st->gb[l], 0, (size_t)st->units[l] * 4, s));
     // the head leaves dact[last] = d loss / d pre-activation of the last layer (its ReLU derivative applied where the output row is
     // in registers anyway); the layers below take theirs in k_relu_bwd_colsum together with the bias gradient
-    EL_LAUNCH("k_nmf_head", k_nmf_head, dim3(head_grid(n, ctx)), dim3(256), 0, s, *st, label, n, 1, nullptr, loss_out, n_div);
+    launch_nmf_head(ctx, s, st, label, n, 1, nullptr, loss_out, n_div, head_grid(n, ctx));
     if (st->use_mlp) {
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
