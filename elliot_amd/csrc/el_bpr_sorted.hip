@@ -687,8 +687,8 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
 // the item side (16 -> 128 positions: 0.84 -> 0.35 ms at B = 1M) as long as enough groups remain to fill the chip.
 static int item_chunk_for(int64_t B) {
     if (const char* e = getenv("EL_ICHUNK")) return atoi(e);
-    int64_t c = (2 * B) / 16384;
-    return (int)(c < 16 ? 16 : (c > 256 ? 256 : c));
+    int64_t c = (2 * B) / 8192;                          // (round 3, with the fused user side: 256 at B = 2^20 -- 1.275 -> 1.25 ms per step;
+    return (int)(c < 16 ? 16 : (c > 256 ? 256 : c));     //  128: 0.259, 256: 0.247, 384: 0.256, 512: 0.277 ms for the item segments)
 }
 static int user_chunk_for(int64_t B) {
     if (const char* e = getenv("EL_UCHUNK")) return atoi(e);
