@@ -36,6 +36,7 @@ class BprmfState(C.Structure):
         ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32),
         ("uslot", _i64p), ("gGu_rows", _f32p), ("gGu_cap", C.c_int64), ("Gu_next", _f32p),
         ("Gu_last", _i32p), ("Gu_old", _f32p), ("Gu_old_cap", C.c_int64), ("lr_hist", _f32p), ("lr_hist_cap", C.c_int32),
+        ("Gi_last", _i32p), ("Gi_defer", C.c_int32),
     ]
 
 
@@ -188,6 +189,7 @@ PROTOTYPES = {
                                     _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, C.c_size_t]),
     "el_gmf_item_image": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int32, _f32p]),
     "el_bprmf_sync_users": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), C.c_int32]),
+    "el_bprmf_sync_items": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), C.c_int32]),
     "el_bprmf_train_loop_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "el_bprmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i64p, _i32p, C.c_uint64, C.c_uint64,
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,

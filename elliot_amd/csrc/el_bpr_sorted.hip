@@ -491,19 +491,18 @@ __global__ __launch_bounds__(256) void k_bpr_user_adam(SegParams p, FusedParams 
 // inside the fused kernel left ~15 % of the lanes busy: rows of one wave wait ~10 steps on average, the longest of them ~30).
 // m = v = 0 (a row that never had a gradient) is a fixed point of the gradient-free step: nothing to replay, whatever the gap.
 template <int VW>
-__device__ __forceinline__ void bpr_replay_row(const el_bprmf_state& st, int64_t row, int lane, int last, int ns, const float* __restrict__ hist,
-                                               int hist_mask) {
+__device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* __restrict__ tm, float* __restrict__ tv, int F, int64_t row, int lane,
+                                               int last, int ns, const float* __restrict__ hist, int hist_mask) {
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    const int F = st.F;
     for (int f0 = 0; f0 < F; f0 += 64 * VW) {
         const int e = f0 + lane * VW;
         float th[VW], mm[VW], vv[VW];
 #pragma unroll
         for (int x = 0; x < VW; ++x) th[x] = mm[x] = vv[x] = 0.f;
         if (e < F) {
-            ldv<VW>(st.Gu + row * F + e, th);
-            ldv<VW>(st.mGu + row * F + e, mm);
-            ldv<VW>(st.vGu + row * F + e, vv);
+            ldv<VW>(tth + row * F + e, th);
+            ldv<VW>(tm + row * F + e, mm);
+            ldv<VW>(tv + row * F + e, vv);
         }
         bool nz = false;
 #pragma unroll
@@ -515,9 +514,9 @@ __device__ __forceinline__ void bpr_replay_row(const el_bprmf_state& st, int64_t
             for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], 0.0f, lr, b1, b2, omb1, omb2, eps);
         }
         if (e < F) {
-            stv<VW>(st.Gu + row * F + e, th);
-            stv<VW>(st.mGu + row * F + e, mm);
-            stv<VW>(st.vGu + row * F + e, vv);
+            stv<VW>(tth + row * F + e, th);
+            stv<VW>(tm + row * F + e, mm);
+            stv<VW>(tv + row * F + e, vv);
         }
     }
 }
@@ -535,7 +534,7 @@ __global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u3
     const int last = st.Gu_last[row];
     const int ns = (t - 1) - last;
     if (ns <= 0) return;
-    bpr_replay_row<VW>(st, row, lane, last, ns, hist, hist_mask);
+    bpr_replay_row<VW>(st.Gu, st.mGu, st.vGu, st.F, row, lane, last, ns, hist, hist_mask);
     if (lane == 0) st.Gu_last[row] = t - 1;
 }
 
@@ -547,24 +546,110 @@ __global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int3
         const int last = st.Gu_last[row];
         const int ns = t - last;
         if (ns <= 0) continue;
-        bpr_replay_row<VW>(st, row, lane, last, ns, hist, hist_mask);
+        bpr_replay_row<VW>(st.Gu, st.mGu, st.vGu, st.F, row, lane, last, ns, hist, hist_mask);
         if (lane == 0) st.Gu_last[row] = t;
     }
 }
 
+// ---- fused item side (el_bprmf_state.Gi_last): replay kernels of the item table --------------------------------------------------
+// The item rows are the user rows' case again (k_bpr_catchup / k_bpr_flush_users) plus one bias element per row.  A wave replays
+// a row's factors; the biases are replayed by their own small kernel, one LANE per row (64 rows' gaps per wave instead of one
+// whole wave walking a single element), launched BEFORE the row kernel, which is the one that advances Gi_last.
+__device__ __forceinline__ void bpr_replay_bias(const el_bprmf_state& st, int64_t row, int last, int ns, const float* __restrict__ hist,
+                                                int hist_mask) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    float th = st.Bi[row], mm = st.mBi[row], vv = st.vBi[row];
+    if (mm == 0.f && vv == 0.f) return;                         // fixed point of the gradient-free step
+    for (int s = 0; s < ns; ++s) el_adam_elem(th, mm, vv, 0.0f, hist[(last + 1 + s) & hist_mask], b1, b2, omb1, omb2, eps);
+    st.Bi[row] = th, st.mBi[row] = mm, st.vBi[row] = vv;
+}
+
+// start of step t, deferred item decay: biases of the batch's distinct items to step t - 1 (one lane per sorted item position;
+// heads work)
+__global__ __launch_bounds__(256) void k_bpr_catchup_ibias(el_bprmf_state st, const u32* __restrict__ keys, u32 key_off, int64_t n, int32_t t,
+                                                           const float* __restrict__ hist, int hist_mask) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const u32 key = keys[p];
+    if (p > 0 && keys[p - 1] == key) return;
+    const int64_t row = (int64_t)(key - key_off);
+    const int last = st.Gi_last[row];
+    const int ns = (t - 1) - last;
+    if (ns > 0) bpr_replay_bias(st, row, last, ns, hist, hist_mask);
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void k_bpr_catchup_items(el_bprmf_state st, const u32* __restrict__ keys, u32 key_off, int64_t n, int32_t t,
+                                                           const float* __restrict__ hist, int hist_mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const u32 key = keys[p];
+    if (p > 0 && keys[p - 1] == key) return;                   // not a segment head
+    const int64_t row = (int64_t)(key - key_off);
+    const int last = st.Gi_last[row];
+    const int ns = (t - 1) - last;
+    if (ns <= 0) return;
+    bpr_replay_row<VW>(st.Gi, st.mGi, st.vGi, st.F, row, lane, last, ns, hist, hist_mask);
+    if (lane == 0) st.Gi_last[row] = t - 1;
+}
+
+// every item row (bias: one lane per row; factors: one wave per row, grid-stride) up to step t (lr_t of step t is in the ring: the
+// fused item-segment kernel of that step put it there)
+__global__ __launch_bounds__(256) void k_bpr_flush_ibias(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= st.I) return;
+    const int last = st.Gi_last[row];
+    const int ns = t - last;
+    if (ns > 0) bpr_replay_bias(st, row, last, ns, hist, hist_mask);
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void k_bpr_flush_items(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < st.I; row += (int64_t)gridDim.x * 4) {
+        const int last = st.Gi_last[row];
+        const int ns = t - last;
+        if (ns <= 0) continue;
+        bpr_replay_row<VW>(st.Gi, st.mGi, st.vGi, st.F, row, lane, last, ns, hist, hist_mask);
+        if (lane == 0) st.Gi_last[row] = t;
+    }
+}
+
 // ---- item segments -----------------------------------------------------------------------
-template <int VW, int CPL>
-__global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
+// IFUSE (el_bprmf_state.Gi_last): the step's whole item side on the batch's rows.  Where the two-pass form writes the gradient row
+// of a segment into gGi, this form takes Keras' Adam step on the item row right away -- theta (it is the L2 term's operand
+// anyway), m, v and the bias with its slots, IN PLACE -- and stamps Gi_last[item] = t.  The three rows of a segment head are
+// fetched together with the gamma_u gathers of its SUB-batch, so a walk over cold items (a new segment at nearly every position)
+// keeps as many loads in flight as the two-pass walk did.  A segment cut by a chunk boundary (the popular items of a Zipf
+// catalogue) still adds its partial rows into gGi / gBi with atomics; the partial that holds the segment's first position puts
+// the item on the step's split list, and k_bpr_item_split -- the next launch -- takes the step on the listed rows from the
+// accumulated gradient and clears it.  (No in-kernel "last partial" hand-over: an agent-scope fence on this part writes back the
+// XCD's L2 -- measured: 0.25 -> 0.92 ms for the item segments at configs[1] with one fence pair per chunk.)
+// (The user-side kernel of the step ran before: nothing else reads an item row here.)
+struct ItemFuse {
+    int32_t* last;       // [I]
+    int32_t* split;      // [0] = number of listed rows (zeroed before the launch), [1 ..] = the rows
+    float* hist;         // lr ring: this kernel records lr_t of step t for the replays that follow
+    int hist_mask;
+    float lr_t, b1, b2, eps;
+    int32_t t;
+};
+
+template <int VW, int CPL, bool IFUSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_bpr_item_seg(SegParams p, ItemFuse f) {
     const int F = p.st.F, lpt = p.lpt;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = gid / lpt;
     const int sub = (int)(threadIdx.x & (lpt - 1));
+    if (IFUSE && gid == 0) f.hist[f.t & f.hist_mask] = f.lr_t;
     const int64_t p0 = grp * p.chunk;
     if (p0 >= p.n) return;
     const int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
     int64_t cur = -1;
     bool started_inside = false;
     float acc[CPL][VW];
+    float rrow[IFUSE ? CPL : 1][VW], mrow[IFUSE ? CPL : 1][VW], vrow[IFUSE ? CPL : 1][VW];
     float bacc = 0.f, bacc2 = 0.f;
     int cpos = 0, cneg = 0;
     auto flush = [&](bool ends_inside) {
@@ -573,12 +658,44 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
         // CML: d/di of +-|u - i|^2 adds -(sum of the coefficients) times the row itself
         const float w = (float)(cpos + cneg) * p.l_w - (p.cml ? bacc : 0.f);
         const bool plain = started_inside && ends_inside;
+        if (IFUSE && plain) {
+            const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+                if (e < F) {
+                    float tn[VW], mn[VW], vn[VW];
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) {
+                        const float gg = acc[q][x] + w * rrow[IFUSE ? q : 0][x];
+                        tn[x] = rrow[IFUSE ? q : 0][x], mn[x] = mrow[IFUSE ? q : 0][x], vn[x] = vrow[IFUSE ? q : 0][x];
+                        el_adam_elem(tn[x], mn[x], vn[x], gg, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                    }
+                    stv<VW>(p.st.Gi + cur * F + e, tn);
+                    stv<VW>(p.st.mGi + cur * F + e, mn);
+                    stv<VW>(p.st.vGi + cur * F + e, vn);
+                }
+            }
+            if (sub == 0) {
+                float beta = p.st.Bi[cur], mb = p.st.mBi[cur], vb = p.st.vBi[cur];
+                const float gb = bacc + p.l_b * (float)cpos * beta + (p.l_b / 10.0f) * (float)cneg * beta;
+                el_adam_elem(beta, mb, vb, gb, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                p.st.Bi[cur] = beta, p.st.mBi[cur] = mb, p.st.vBi[cur] = vb;
+                f.last[cur] = f.t;
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int e = (sub + q * lpt) * VW;
             if (e < F) {
                 float r[VW], v[VW];
-                ldv<VW>(pr + e, r);
+                if (IFUSE) {
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) r[x] = rrow[IFUSE ? q : 0][x];
+                } else {
+                    ldv<VW>(pr + e, r);
+                }
 #pragma unroll
                 for (int x = 0; x < VW; ++x) v[x] = acc[q][x] + w * r[x];
                 if (plain) {
@@ -601,6 +718,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
                 p.st.tBi[cur] = p.step;
             }
         }
+        if (IFUSE && started_inside && sub == 0) f.split[1 + atomicAdd(f.split, 1)] = (int32_t)cur;
     };
     // staged index chains, as in k_bpr_user_seg: BPR_ISTG positions per stage (key, payload -> s_b, u_b)
     extern __shared__ unsigned char seg_lds[];
@@ -609,7 +727,8 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
     u32* s_u = reinterpret_cast<u32*>(seg_lds) + (1 * ngl + gl) * BPR_ISTG;
     float* s_cf = reinterpret_cast<float*>(seg_lds) + (2 * ngl + gl) * BPR_ISTG;      // +s_b (positive item) / -s_b (negative)
     float* s_cf2 = reinterpret_cast<float*>(seg_lds) + (3 * ngl + gl) * BPR_ISTG;     // CML: +-dloss/dE_b
-    constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
+    // positions whose loads are in flight together (IFUSE: each may bring the three rows of a segment head along)
+    constexpr int SUB = IFUSE ? (CPL == 1 ? 2 : 1) : ((CPL == 1) ? 4 : (CPL == 2 ? 2 : 1));
     for (int64_t sbase = p0; sbase < p1; sbase += BPR_ISTG) {
         const int cs = (int)((p1 - sbase < BPR_ISTG) ? p1 - sbase : BPR_ISTG);
         for (int t = sub; t < cs; t += lpt) {
@@ -631,6 +750,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
             float cfv[SUB];
             bool negv[SUB], okv[SUB];
             float rr[SUB][CPL][VW];
+            float hr[IFUSE ? SUB : 1][CPL][VW], hm[IFUSE ? SUB : 1][CPL][VW], hv[IFUSE ? SUB : 1][CPL][VW];   // rows of the segment heads
 #pragma unroll
             for (int t = 0; t < SUB; ++t) {
                 okv[t] = base + t < cs;
@@ -640,12 +760,22 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
                 negv[t] = (kk >> 31) != 0u;
                 cfv[t] = s_cf[tt];
                 const float* pu = (p.ubase ? p.ubase : p.st.Gu) + (int64_t)s_u[tt] * F;
+                const bool headt = IFUSE && okv[t] && keyv[t] != (t == 0 ? cur : keyv[t > 0 ? t - 1 : 0]);
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
                     const int e = (sub + q * lpt) * VW;
 #pragma unroll
                     for (int x = 0; x < VW; ++x) rr[t][q][x] = 0.f;
                     if (okv[t] && e < F) ldv<VW>(pu + e, rr[t][q]);
+                    if (IFUSE) {
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) hr[IFUSE ? t : 0][q][x] = hm[IFUSE ? t : 0][q][x] = hv[IFUSE ? t : 0][q][x] = 0.f;
+                        if (headt && e < F) {
+                            ldv<VW>(p.st.Gi + keyv[t] * F + e, hr[IFUSE ? t : 0][q]);
+                            ldv<VW>(p.st.mGi + keyv[t] * F + e, hm[IFUSE ? t : 0][q]);
+                            ldv<VW>(p.st.vGi + keyv[t] * F + e, hv[IFUSE ? t : 0][q]);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -662,6 +792,16 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
                     for (int q = 0; q < CPL; ++q)
 #pragma unroll
                         for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+                    if (IFUSE) {                                 // the row and its Adam slots (fetched with the SUB-batch above)
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                            for (int x = 0; x < VW; ++x) {
+                                rrow[IFUSE ? q : 0][x] = hr[IFUSE ? t : 0][q][x];
+                                mrow[IFUSE ? q : 0][x] = hm[IFUSE ? t : 0][q][x];
+                                vrow[IFUSE ? q : 0][x] = hv[IFUSE ? t : 0][q][x];
+                            }
+                    }
                 }
                 const float coef = cfv[t];
 #pragma unroll
@@ -681,12 +821,52 @@ __global__ __launch_bounds__(256) void k_bpr_item_seg(SegParams p) {
     flush(p1 == p.n || (int64_t)(p.keys[p1] - p.key_off) != cur);
 }
 
+// the rows the fused item segments put on the split list (segments cut by a chunk boundary): Keras' Adam step from the gradient the
+// partials accumulated in gGi / gBi, accumulators cleared, Gi_last stamped.  One lane group per listed row.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_bpr_item_split(el_bprmf_state st, ItemFuse f, int lpt) {
+    constexpr int VW = 4;
+    const int F = st.F;
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    if (g >= (int64_t)f.split[0]) return;
+    const int64_t row = (int64_t)f.split[1 + g];
+    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+        if (e < F) {
+            float th[VW], mm[VW], vv[VW], gg[VW], zz[VW];
+            ldv<VW>(st.Gi + row * F + e, th);
+            ldv<VW>(st.mGi + row * F + e, mm);
+            ldv<VW>(st.vGi + row * F + e, vv);
+            ldv<VW>(st.gGi + row * F + e, gg);
+#pragma unroll
+            for (int x = 0; x < VW; ++x) {
+                el_adam_elem(th[x], mm[x], vv[x], gg[x], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                zz[x] = 0.f;
+            }
+            stv<VW>(st.Gi + row * F + e, th);
+            stv<VW>(st.mGi + row * F + e, mm);
+            stv<VW>(st.vGi + row * F + e, vv);
+            stv<VW>(st.gGi + row * F + e, zz);
+        }
+    }
+    if (sub == 0) {
+        float beta = st.Bi[row], mb = st.mBi[row], vb = st.vBi[row];
+        el_adam_elem(beta, mb, vb, st.gBi[row], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+        st.Bi[row] = beta, st.mBi[row] = mb, st.vBi[row] = vb;
+        st.gBi[row] = 0.f;
+        f.last[row] = f.t;
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------
 // Positions per lane group.  Popular items (Zipf) own segments of tens of thousands of occurrences; every chunk that
 // does not contain a whole segment ends with an atomic flush onto the same few cache lines, so long chunks matter for
 // the item side (16 -> 128 positions: 0.84 -> 0.35 ms at B = 1M) as long as enough groups remain to fill the chip.
 static int item_chunk_for(int64_t B) {
-    if (const char* e = getenv("EL_ICHUNK")) return atoi(e);
+    if (const char* e = getenv("EL_ICHUNK")) return atoi(e) < 16 ? 16 : atoi(e);     // (>= 16: the split list is sized for it)
     int64_t c = (2 * B) / 8192;                          // (round 3, with the fused user side: 256 at B = 2^20 -- 1.275 -> 1.25 ms per step;
     return (int)(c < 16 ? 16 : (c > 256 ? 256 : c));     //  128: 0.259, 256: 0.247, 384: 0.256, 512: 0.277 ms for the item segments)
 }
@@ -711,6 +891,7 @@ struct SortedWs {
     size_t tmp_bytes;
     int32_t* rowptr;       // [U + 1] first sorted position of every user row (fused user-side kernel)
     int32_t* hpos;         // [B] per triplet: sorted head position of its user's segment (deferred decay)
+    int32_t* split;        // [1 + B / 8 + 2] fused item side: rows whose segment a chunk boundary cut (count, then the rows)
     size_t total;
 };
 
@@ -738,6 +919,7 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
     w->tmp = take(w->tmp_bytes);
     w->rowptr = (int32_t*)take((size_t)(U + 1) * 4);
     w->hpos = (int32_t*)take((size_t)B * 4);
+    w->split = (int32_t*)take((size_t)(B / 8 + 4) * 4);
     w->total = off;
     return 0;
 }
@@ -803,6 +985,49 @@ extern "C" int el_bprmf_sync_users(el_ctx* ctx, void* stream, const el_bprmf_sta
     return launch_flush_users(*stp, (hipStream_t)stream, step);
 }
 
+// ---- fused item side: replay launches ----------------------------------------------------------------------------------------
+static int check_item_fuse(const el_bprmf_state& st) {
+    EL_REQUIRE(st.Gi_last && st.lr_hist && st.lr_hist_cap >= 4 && (st.lr_hist_cap & (st.lr_hist_cap - 1)) == 0,
+               "el_bprmf: the fused item side needs Gi_last, lr_hist and a power-of-two lr_hist_cap >= 4");
+    EL_REQUIRE(st.mGi && st.vGi && st.mBi && st.vBi && st.gGi && st.gBi && st.F % 4 == 0 &&
+               (((uintptr_t)st.Gi | (uintptr_t)st.mGi | (uintptr_t)st.vGi | (uintptr_t)st.gGi) & 15) == 0,
+               "el_bprmf: the fused item side needs Adam slots, the accumulators gGi / gBi, F %% 4 == 0 and 16-byte aligned tables");
+    return 0;
+}
+
+static int launch_flush_items(const el_bprmf_state& st, hipStream_t s, int32_t t) {
+    const int mask = st.lr_hist_cap - 1;
+    EL_LAUNCH("k_bpr_flush_ibias", k_bpr_flush_ibias, dim3((unsigned)((st.I + 255) / 256)), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    int64_t grid = (st.I + 3) / 4;
+    if (grid > (1 << 18)) grid = 1 << 18;
+    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<4>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<2>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<1>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// start of step t with Gi_defer: the rows of the batch's distinct items (biases first: the row kernel advances Gi_last) to t - 1
+static int launch_catchup_items(const el_bprmf_state& st, hipStream_t s, const SortedWs& w, int64_t B, int32_t t) {
+    const int mask = st.lr_hist_cap - 1;
+    const int64_t n = 2 * B;
+    const u32 off = (u32)st.U;
+    EL_LAUNCH("k_bpr_catchup_ibias", k_bpr_catchup_ibias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+    const unsigned gc = (unsigned)((n + 3) / 4);
+    if (st.F >= 256) EL_LAUNCH("k_bpr_catchup_items", k_bpr_catchup_items<4>, dim3(gc), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+    else if (st.F >= 128) EL_LAUNCH("k_bpr_catchup_items", k_bpr_catchup_items<2>, dim3(gc), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+    else EL_LAUNCH("k_bpr_catchup_items", k_bpr_catchup_items<1>, dim3(gc), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+    return 0;
+}
+
+extern "C" int el_bprmf_sync_items(el_ctx* ctx, void* stream, const el_bprmf_state* stp, int32_t step) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(stp != nullptr && step >= 0, "el_bprmf_sync_items: bad arguments");
+    if (stp->Gi_last == nullptr || step == 0) return 0;
+    if (int rc = check_item_fuse(*stp)) return rc;
+    return launch_flush_items(*stp, (hipStream_t)stream, step);
+}
+
 static int launch_user_adam(const SegParams& pu, hipStream_t s, int64_t B, const SortedWs& w, int lpt, int cpl, float lr_t) {
     FusedParams f;
     memset(&f, 0, sizeof(f));
@@ -839,7 +1064,8 @@ static int launch_user_catchup(const SegParams& pu, hipStream_t s, int64_t B, co
 }
 
 template <int VW>
-static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w, bool fused = false, float lr_t = 0.f, bool defer = false) {
+static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const SortedWs& w, bool fused = false, float lr_t = 0.f, bool defer = false,
+                       bool ifuse = false) {
     int cpl = 1;
     const int lpt = el_pick_lpt(base.st.F, VW, &cpl);
     EL_REQUIRE(cpl <= 4, "el_bprmf_train_step: F=%d too large for this build", base.st.F);
@@ -862,6 +1088,12 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
     FusedParams fz;
     memset(&fz, 0, sizeof(fz));
+    ItemFuse fi;
+    memset(&fi, 0, sizeof(fi));
+    if (ifuse) {
+        fi.last = base.st.Gi_last, fi.split = w.split, fi.hist = base.st.lr_hist, fi.hist_mask = base.st.lr_hist_cap - 1;
+        fi.lr_t = lr_t, fi.b1 = 0.9f, fi.b2 = 0.999f, fi.eps = 1e-7f, fi.t = base.step;
+    }
 #define EL_SEG(CPL_)                                                                                      \
     do {                                                                                                  \
         if (defer) {                                                                                      \
@@ -872,7 +1104,13 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
         } else {                                                                                          \
             EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, false>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
         }                                                                                                 \
-        EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi);      \
+        if (ifuse) {                                                                                      \
+            EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));                                               \
+            EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridI), dim3(256), ldsI, s, pi, fi);   \
+            EL_LAUNCH("k_bpr_item_split", (k_bpr_item_split<CPL_>), dim3(gridI), dim3(256), 0, s, pi.st, fi, lpt);       \
+        } else {                                                                                          \
+            EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi);    \
+        }                                                                                                 \
     } while (0)
     if (cpl == 1) EL_SEG(1);
     else if (cpl == 2) EL_SEG(2);
@@ -940,9 +1178,25 @@ static int sorted_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, con
         EL_REQUIRE(st.gGu_rows != nullptr && st.gGu_cap >= B, "el_bprmf_train_step: compact user-gradient rows need gGu_rows with >= B rows (%lld < %lld)",
                    (long long)st.gGu_cap, (long long)B);
     }
-    int rc = vec ? launch_segs<4>(base, s, B, w, fused, lr_t, defer) : launch_segs<1>(base, s, B, w);
+    // fused item side (el_bprmf_state.Gi_last): the item segments take the Adam step on their rows; rows outside the batch are
+    // replayed at the end of the step (Gi_defer == 0) or when next needed (Gi_defer != 0: caught up here, before the user side
+    // gathers them)
+    const bool ifuse = st.Gi_last != nullptr;
+    if (ifuse) {
+        EL_REQUIRE(opt == EL_OPT_ADAM_TF_DENSE && fused && vec && !rows_mode,
+                   "el_bprmf: the fused item side (Gi_last) runs with EL_OPT_ADAM_TF_DENSE and the fused user side (Gu_next or Gu_last) only; "
+                   "gradient-only / other-optimiser calls take a state with Gi_last = NULL after el_bprmf_sync_items");
+        if (int rc = check_item_fuse(st)) return rc;
+        if (st.Gi_defer) {
+            if (step > 1 && (step - 1) % (st.lr_hist_cap / 2) == 0)          // the lr ring: no row may fall more than half of it behind
+                if (int rc = launch_flush_items(st, s, step - 1)) return rc;
+            if (int rc = launch_catchup_items(st, s, w, B, step)) return rc;
+        }
+    }
+    int rc = vec ? launch_segs<4>(base, s, B, w, fused, lr_t, defer, ifuse) : launch_segs<1>(base, s, B, w);
     if (rc) return rc;
     if (opt < 0) return 0;                           // gradients only (el_bprmf_grads)
+    if (ifuse) return st.Gi_defer ? 0 : launch_flush_items(st, s, step);
     if (fused) return el_bprmf_apply_items_adam(ctx, s, st, lr_t);
     return el_bprmf_apply_optimizer(ctx, s, st, u, i, j, B, lr, opt, step, lr_t);
 }
@@ -1208,7 +1462,9 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     const int64_t gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridI = (unsigned)((gi * lpt + 255) / 256);
     const size_t ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
-#define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_>), dim3(gridI), dim3(256), ldsI, s, pi)
+    ItemFuse fi;
+    memset(&fi, 0, sizeof(fi));
+#define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi)
     if (vec) {
         if (cpl == 1) EL_IS(4, 1); else if (cpl == 2) EL_IS(4, 2); else EL_IS(4, 4);
     } else {

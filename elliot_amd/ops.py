@@ -477,7 +477,8 @@ class BprmfDeviceState:
 
     _LR_HIST = 1 << 16          # lr_t ring of the deferred decay (a power of two)
 
-    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None, fused_user_step=None, deferred=None):
+    def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None, fused_user_step=None, deferred=None,
+                 fused_item_step=None, item_deferred=None):
         """compact_user_grads: user-row gradients as compact rows + per-user stamps (el_bprmf_state.uslot) instead of a dense
         [U,F] accumulator -- the dense Adam pass then reads a gradient only for the batch's users and re-zeroes nothing.
         None = automatic (TF-dense Adam on a user table of >= 64 MB with F % 4 == 0), True / False force it.
@@ -485,7 +486,14 @@ class BprmfDeviceState:
         contains the user or when the table is read (el_bprmf_state.Gu_last): a step moves only the batch's user rows.  It pays
         when a batch touches a small part of the users (10 M users, 1 M triplets: the user side of the step 7.2 -> ~2 ms) and costs
         when it touches most of them (B = U: +10 %), so None = decided at the first training call: on when 4 B <= U and the fused
-        user-side step applies (EL_BPR_DEFERRED=0 / 1 force it); reading `.Gu` syncs, `.mGu` / `.vGu` want sync() first."""
+        user-side step applies (EL_BPR_DEFERRED=0 / 1 force it); reading `.Gu` syncs, `.mGu` / `.vGu` want sync() first.
+        fused_item_step: the item side of the step as ONE kernel (el_bprmf_state.Gi_last): the item segments take Keras' Adam step on
+        their rows in place, no dense gradient table is written, re-read and cleared.  None = whenever the fused user side applies
+        (EL_FUSED_ITEM=0 turns it off); grads() / apply() always run the two-pass form.
+        item_deferred: with the fused item side, the item rows a batch leaves alone wait for their gradient-free Adam updates like the
+        user rows do (replayed bit for bit when a batch next contains the item, or on sync() / reading `.Gi` / `.Bi`); False = they
+        are replayed at the end of every step.  None = decided by the first batch size: on when 2 B <= I (EL_BPR_ITEM_DEFERRED=0 / 1
+        force it)."""
         self.ctx = ctx
         self.opt = OPTIMIZERS[optimizer] if isinstance(optimizer, str) else int(optimizer)
         dev = ctx.device
@@ -508,15 +516,22 @@ class BprmfDeviceState:
         self._deferred_auto = bool(self.fused and deferred is None)    # decided by the first batch size (_resolve_deferred)
         self.deferred = bool(self.fused and deferred is True)
         self._pending = False
+        self.item_fused = bool(self.fused and fused_item_step is not False and os.environ.get("EL_FUSED_ITEM", "1") != "0")
+        env_i = os.environ.get("EL_BPR_ITEM_DEFERRED")
+        if item_deferred is None and env_i in ("0", "1"):
+            item_deferred = env_i == "1"
+        self._item_deferred_auto = bool(self.item_fused and item_deferred is None)
+        self.item_deferred = bool(self.item_fused and item_deferred is True)
+        self._pending_items = False
 
         def own(x, dt):
             if isinstance(x, np.ndarray):
                 x = torch.from_numpy(np.ascontiguousarray(x))
             return x.to(device=dev, dtype=dt).contiguous().clone()
 
-        self.Gi, self.Bi = own(Gi, torch.float32), own(Bi, torch.float32)
+        self._Gi, self._Bi = own(Gi, torch.float32), own(Bi, torch.float32)
         self.U, self.F = int(Gu.shape[0]), int(Gu.shape[1])
-        self.I = self.Gi.shape[0]
+        self.I = self._Gi.shape[0]
         z = torch.zeros_like
         adam = self.opt in (EL_OPT_ADAM_TF_DENSE, EL_OPT_ADAM_LAZY)
         self.uslot = self.gGu_rows = None
@@ -549,10 +564,10 @@ class BprmfDeviceState:
         self.item_grad_flat = torch.zeros(rows_end + self.I, dtype=torch.float32, device=dev)
         self.gGi = self.item_grad_flat[:self.I * self.F].view(self.I, self.F)
         self.gBi = self.item_grad_flat[rows_end:]
-        self.mGi = z(self.Gi) if adam else None
-        self.vGi = z(self.Gi) if adam else None
-        self.mBi = z(self.Bi) if adam else None
-        self.vBi = z(self.Bi) if adam else None
+        self.mGi = z(self._Gi) if adam else None
+        self.vGi = z(self._Gi) if adam else None
+        self.mBi = z(self._Bi) if adam else None
+        self.vBi = z(self._Bi) if adam else None
         rows = self.opt in (EL_OPT_ADAM_LAZY, EL_OPT_SGD) and optimizer != "sgd_dense"
         self.tGu = torch.zeros(self.U, dtype=torch.int32, device=dev) if rows else None
         self.tGi = torch.zeros(self.I, dtype=torch.int32, device=dev) if rows else None
@@ -561,7 +576,7 @@ class BprmfDeviceState:
         self._step = 0
         self._ws = None
         self._c = BprmfState(
-            Gu=self.Gu.data_ptr(), Gi=self.Gi.data_ptr(), Bi=self.Bi.data_ptr(),
+            Gu=self._Gu.data_ptr(), Gi=self._Gi.data_ptr(), Bi=self._Bi.data_ptr(),
             gGu=self.gGu.data_ptr() if self.gGu is not None else None, gGi=self.gGi.data_ptr(), gBi=self.gBi.data_ptr(),
             uslot=self.uslot.data_ptr() if self.compact else None, gGu_rows=None, gGu_cap=0,
             mGu=self.mGu.data_ptr() if adam else None, vGu=self.vGu.data_ptr() if adam else None,
@@ -571,15 +586,27 @@ class BprmfDeviceState:
             tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F,
             Gu_next=self.Gu_next.data_ptr() if self.Gu_next is not None else None)
         self.Gu_last = self.Gu_old = self.lr_hist = None
+        self.Gi_last = None
         if self.deferred:
             self._enable_deferred()
+        if self.item_fused:
+            # fused item side: the step each item row is current at
+            self.Gi_last = torch.zeros(self.I, dtype=torch.int32, device=dev)
+            self._ensure_hist()
+            self._c.Gi_last, self._c.Gi_defer = self.Gi_last.data_ptr(), int(self.item_deferred)
+
+    def _ensure_hist(self):
+        """The ring of the last _LR_HIST bias-corrected step sizes (what the replay of postponed row updates reads)."""
+        if self.lr_hist is None:
+            self.lr_hist = torch.zeros(self._LR_HIST, dtype=torch.float32, device=self.ctx.device)
+            self._c.lr_hist, self._c.lr_hist_cap = self.lr_hist.data_ptr(), self._LR_HIST
 
     def _enable_deferred(self):
         dev = self.ctx.device
         self.deferred = True
         self.Gu_last = torch.full((self.U,), int(self._step), dtype=torch.int32, device=dev)     # every row is current now
-        self.lr_hist = torch.zeros(self._LR_HIST, dtype=torch.float32, device=dev)
-        self._c.Gu_last, self._c.lr_hist, self._c.lr_hist_cap = self.Gu_last.data_ptr(), self.lr_hist.data_ptr(), self._LR_HIST
+        self._ensure_hist()
+        self._c.Gu_last = self.Gu_last.data_ptr()
         if getattr(self, "_user_block", None) is None and not self._deferred_auto:
             self.Gu_next = None                                  # in-place updates: the second table is not needed
             self._c.Gu_next = None
@@ -587,13 +614,19 @@ class BprmfDeviceState:
     def _resolve_deferred(self, B):
         """A state built with deferred=None follows the batch size: the deferred decay pays when a batch leaves most user rows
         alone (4 B <= U), the every-row fused step when it touches most of them.  Switching costs one replay of the pending rows."""
-        if self._deferred_auto and int(B) != getattr(self, "_resolved_B", None):
-            self._resolved_B = int(B)
+        if int(B) == getattr(self, "_resolved_B", None):
+            return
+        self._resolved_B = int(B)
+        if self._deferred_auto:
             want = 4 * int(B) <= self.U
             if want != self.deferred:
                 auto = self._deferred_auto
                 self.set_deferred(want)
                 self._deferred_auto = auto
+        if self._item_deferred_auto:
+            # the item side: a batch draws B negatives uniformly over the catalogue (custom_sampler.py:39-41) and B positives: it pays
+            # when those leave most item rows alone
+            self.set_item_deferred(2 * int(B) <= self.I, _auto=True)
 
     # -- deferred decay of the user table (el_bprmf_state.Gu_last) ----------------------------------------------------------
     @property
@@ -607,12 +640,42 @@ class BprmfDeviceState:
     def Gu(self, t):
         self._Gu = t
 
+    @property
+    def Gi(self):
+        """The item table, every row current (pending row updates of the deferred item decay are replayed first)."""
+        if self._pending_items:
+            self.sync()
+        return self._Gi
+
+    @property
+    def Bi(self):
+        if self._pending_items:
+            self.sync()
+        return self._Bi
+
     def sync(self):
-        """Deferred decay: bring every user row (theta, m, v) to the current step; no-op otherwise."""
+        """Deferred decay: bring every user row and every item row (theta, m, v) to the current step; no-op otherwise."""
         if self.deferred and self._pending:
             self._pending = False
             check(self.ctx.lib.el_bprmf_sync_users(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self._step)),
                   "el_bprmf_sync_users")
+        if self.item_fused and self._pending_items:
+            self._pending_items = False
+            check(self.ctx.lib.el_bprmf_sync_items(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self._step)),
+                  "el_bprmf_sync_items")
+
+    def set_item_deferred(self, on, _auto=False):
+        """Fused item side: let the item rows a batch leaves alone wait for their gradient-free updates (True) or replay them at
+        the end of every step (False)."""
+        on = bool(on) and self.item_fused
+        if not _auto:
+            self._item_deferred_auto = False
+        if on == self.item_deferred:
+            return
+        if not on:
+            self.sync()
+        self.item_deferred = on
+        self._c.Gi_defer = int(on)
 
     def set_deferred(self, on):
         """Switch the deferred decay off (data-parallel owners that run the step as grads + collective + apply) or on again."""
@@ -627,9 +690,9 @@ class BprmfDeviceState:
             return
         self.sync()
         self.deferred = False
-        self._c.Gu_last = self._c.lr_hist = self._c.Gu_old = None
-        self._c.lr_hist_cap, self._c.Gu_old_cap = 0, 0
-        self.Gu_last = self.Gu_old = self.lr_hist = None
+        self._c.Gu_last = self._c.Gu_old = None
+        self._c.Gu_old_cap = 0
+        self.Gu_last = self.Gu_old = None                       # (the lr ring stays: the fused item side reads it too)
         if self.fused:                                          # the fused user-side step needs its second table from here on
             if self.Gu_next is None:
                 self.Gu_next = torch.empty_like(self._Gu)
@@ -658,13 +721,44 @@ class BprmfDeviceState:
 
     @step.setter
     def step(self, value):
+        """Moving the counter from outside (a checkpoint's count, a data-parallel owner's begin_step) is not an optimiser step:
+        every row is first brought up to date at the old count and then stamped with the new one.  (The training calls of this
+        class advance the counter through _advance.)"""
         value = int(value)
         if self.compact and value < self._step:
             self.uslot.zero_()                 # stamps of later steps must not be mistaken for this step's gradient rows
-        if getattr(self, "deferred", False) and value != self._step + 1 and value != self._step:
-            self.sync()                        # a jump of the step counter: every row current at the old count, then re-stamped
-            self.Gu_last.fill_(value)
+        if value != self._step:
+            if getattr(self, "deferred", False):
+                self.sync()
+                self.Gu_last.fill_(value)
+            if getattr(self, "item_fused", False):
+                self.sync()
+                self.Gi_last.fill_(value)
         self._step = value
+
+    def _advance(self, n=1):
+        """The counter of a training call: the library performs (or postpones, per row) exactly these optimiser steps."""
+        self._step += int(n)
+
+    def _after_steps(self, steps=1):
+        self._swap_user_tables(steps)
+        if self.item_fused and self.item_deferred:
+            self._pending_items = True
+
+    def _two_pass(self, on):
+        """grads() / apply() run the every-row two-pass form: the per-row features stand aside (rows current first) and come back
+        with every row stamped at the step the dense pass left it at."""
+        if on:
+            self.sync()
+            self._c.Gu_last = None
+            self._c.Gi_last = None
+            return
+        if self.deferred:
+            self.Gu_last.fill_(self._step)
+            self._c.Gu_last = self.Gu_last.data_ptr()
+        if self.item_fused:
+            self.Gi_last.fill_(self._step)
+            self._c.Gi_last = self.Gi_last.data_ptr()
 
     def ensure_rows(self, B):
         """Compact mode: gradient rows for a batch of B triplets (slot = sorted position of a user's first occurrence)."""
@@ -693,7 +787,7 @@ class BprmfDeviceState:
         B = u.numel()
         if self.compact:
             self._resolve_deferred(B)           # (before the step counter moves: switching the deferred decay stamps the rows with it)
-        self.step += 1
+        self._advance()
         lr_t = adam_lr_t(lr, self.step)
         algo = BPR_ALGOS[algo] if isinstance(algo, str) else int(algo)
         ws, ws_bytes = None, 0
@@ -714,7 +808,7 @@ class BprmfDeviceState:
                                                self.opt, int(self.step), float(lr_t), _ptr(self.loss, torch.float64),
                                                algo, ws, ws_bytes),
               "el_bprmf_train_step")
-        self._swap_user_tables()
+        self._after_steps()
 
     def grads(self, u, i, j, l_w, l_b):
         """First half of train_step: loss + the summed row gradients of the batch (what OptimizerV2 receives after its segment
@@ -724,10 +818,9 @@ class BprmfDeviceState:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         self.ensure_rows(B)
-        if self.deferred:
-            # the two-call form runs the every-row pass (apply); the rows are brought up to date and the feature stands aside
-            self.sync()
-            self._c.Gu_last = None
+        if self.deferred or self.item_fused:
+            # the two-call form runs the every-row passes (apply); the rows are brought up to date and the features stand aside
+            self._two_pass(True)
         check(self.ctx.lib.el_bprmf_grads(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
                                           _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(l_w), float(l_b),
                                           int(self.step + 1), _ptr(self.loss, torch.float64), C.c_void_p(self._ws.data_ptr()),
@@ -735,12 +828,13 @@ class BprmfDeviceState:
 
     def apply(self, lr):
         """Second half: the optimiser (TF-dense Adam / dense SGD) on the accumulated gradients; accumulators come back clean."""
-        self.step += 1
+        if self.deferred or self.item_fused:
+            self._two_pass(True)                               # (apply() without a grads() in front: the same stand-aside)
+        self._advance()
         check(self.ctx.lib.el_bprmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), float(lr), int(self.opt),
                                           int(self.step), float(adam_lr_t(lr, self.step))), "el_bprmf_apply")
-        if self.deferred:
-            self.Gu_last.fill_(self.step)                      # the every-row pass moved every row
-            self._c.Gu_last = self.Gu_last.data_ptr()
+        if self.deferred or self.item_fused:
+            self._two_pass(False)                              # the every-row passes moved every row
 
     # -- the step in two halves for a software pipeline: ordering a batch (prep + radix sort) reads only its triplets, so the
     #    batch of step t+1 can be drawn and ordered on a side stream while step t's segment kernels and optimiser pass run
@@ -763,13 +857,13 @@ class BprmfDeviceState:
         if not self.fused:
             self.ensure_rows(B)
         self._ensure_old(B)
-        self.step += 1
+        self._advance()
         check(self.ctx.lib.el_bprmf_train_step_presorted(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32, "u"),
                                                          _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), int(B), float(lr), float(l_w),
                                                          float(l_b), int(self.opt), int(self.step), float(adam_lr_t(lr, self.step)),
                                                          _ptr(self.loss, torch.float64), C.c_void_p(ws.data_ptr()), ws.numel()),
               "el_bprmf_train_step_presorted")
-        self._swap_user_tables()
+        self._after_steps()
 
     def train_loop(self, pos, events, B, seed, first_sample, lr, l_w, l_b, algo="auto"):
         """One epoch of `for batch in sampler.step(events, B): train_step(batch)` (BPRMF_batch.py:100-109) from a single
@@ -798,8 +892,8 @@ class BprmfDeviceState:
             lr_t.ctypes.data_as(C.c_void_p), _ptr(self.loss, torch.float64), algo,
             C.c_void_p(self._ws.data_ptr()) if need else None, self._ws.numel() if need else 0,
             C.c_void_p(buf.data_ptr()), lneed, C.c_void_p(sampler_meta(self.ctx, pos).data_ptr())), "el_bprmf_train_loop")
-        self._step += steps                                     # (consecutive steps: not a jump of the counter)
-        self._swap_user_tables(steps)
+        self._advance(steps)                                    # (consecutive steps: not a jump of the counter)
+        self._after_steps(steps)
         return steps
 
     def pop_loss(self):

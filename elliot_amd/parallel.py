@@ -438,8 +438,10 @@ class HipUserShardBackend:
         if optimizer not in ("adam", "adam_tf_dense", "sgd"):
             raise ValueError("sharded training supports the dense optimisers (adam_tf_dense, sgd)")
         self.ctx = ctx
-        # (the step runs as grads + all-reduce + apply here: the every-row passes, no deferred decay of the user rows)
-        self.state = ops.BprmfDeviceState(ctx, Gu_shard, Gi, Bi, optimizer="sgd_dense" if optimizer == "sgd" else optimizer, deferred=False)
+        # (the step runs as grads + all-reduce + apply here: the every-row two-pass form -- no second user table, no deferred
+        # decay, no fused item side: the item gradients have to exist as a table for the all-reduce anyway)
+        self.state = ops.BprmfDeviceState(ctx, Gu_shard, Gi, Bi, optimizer="sgd_dense" if optimizer == "sgd" else optimizer, deferred=False,
+                                          fused_user_step=False)
         self._ws = None
 
     def _workspace(self, B):

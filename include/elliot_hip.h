@@ -34,14 +34,16 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 4   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
+#define EL_ABI_VERSION 5   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
                             * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*
                             * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
                             *    el_nmf_score_topk, el_gmf_item_image; el_bprmf_state.Gu_next + el_bprmf_train_step_presorted;
                             *    el_host_split_flags_state; el_nmf_state ends in the deferred-decay fields (row_last ..
                             *    batch_n) and the el_nmf_* calls take it non-const; el_nmf_sync_tables; el_bprmf_state ends
-                            *    in Gu_last .. lr_hist_cap, el_bprmf_sync_users                                         */
+                            *    in Gu_last .. lr_hist_cap, el_bprmf_sync_users
+                            * 5: el_bprmf_state ends in Gi_last / Gi_defer (item side of the step fused with its
+                            *    Adam pass), el_bprmf_sync_items                                                        */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -176,6 +178,21 @@ typedef struct el_bprmf_state {
      *   lr_hist  float[lr_hist_cap], lr_hist_cap a power of two >= 4: the library keeps lr_t of step s at lr_hist[s % cap] and
      *            brings every row up to date by itself every cap / 2 steps                                              */
     int32_t* Gu_last; float* Gu_old; int64_t Gu_old_cap; float* lr_hist; int32_t lr_hist_cap;
+    /* Optional fused item side (Gi_last == NULL = off: the item segments write the dense accumulators gGi / gBi and a dense Adam
+     * pass reads and clears them).  With Gi_last, the SORTED gradient path and EL_OPT_ADAM_TF_DENSE, the item-segment kernel takes
+     * Keras' Adam step on an item row (factors, bias and their slots, IN PLACE) the moment the row's segment is complete -- the
+     * gradient row of an item never goes to HBM; a segment cut by a chunk boundary (the popular items of a Zipf catalogue) adds its
+     * partial rows into gGi / gBi with atomics as before, and a short second launch takes the step on exactly those rows from the
+     * accumulated gradient and clears it.  Rows without an occurrence in the batch still owe Keras' gradient-free update
+     * (m <- b1 m, v <- b2 v, theta moves):
+     *   Gi_defer == 0  they are brought to step t by a replay pass at the end of every step (every row current after each call);
+     *   Gi_defer != 0  they wait (the deferred decay of the user table, applied to the item table): a row is replayed -- bit for bit
+     *                  -- at the start of the next step whose batch contains the item (before the user side gathers it) or by
+     *                  el_bprmf_sync_items, which must run before anything else reads Gi / Bi / their slots.  Needs lr_hist.
+     * Same operations in the same order as the two-pass form: identical bits wherever that form's own summation order is fixed
+     * (segments inside one chunk).  gGi / gBi stay required and are zero on entry and exit; F % 4 == 0, 16-byte aligned tables.
+     *   Gi_last  int32[I], zero-initialised: the optimiser step each item row (factors + bias) is current at                 */
+    int32_t* Gi_last; int32_t Gi_defer;
 } el_bprmf_state;
 
 /* How the duplicate-row gradient sum (OptimizerV2's segment-sum of IndexedSlices) is formed. */
@@ -204,6 +221,9 @@ int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st,
 /* Deferred decay (el_bprmf_state.Gu_last): replays the postponed gradient-free Adam steps of every user row so that Gu, mGu, vGu
  * hold exactly what the every-row form holds after `step` optimiser steps.  No-op when Gu_last is NULL.                     */
 int el_bprmf_sync_users(el_ctx* ctx, void* stream, const el_bprmf_state* st, int32_t step);
+/* The same for the item table (el_bprmf_state.Gi_last with Gi_defer): Gi, Bi and their Adam slots as the every-row form holds them
+ * after `step` optimiser steps.  No-op when Gi_last is NULL.                                                                */
+int el_bprmf_sync_items(el_ctx* ctx, void* stream, const el_bprmf_state* st, int32_t step);
 
 /* ---- BPR-MF across GPUs: item-sharded tables (new design; the reference is single-device) -- */
 

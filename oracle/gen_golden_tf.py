@@ -44,7 +44,7 @@ def adam_slots(opt, var):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def gen_bprmf_batch(ref, out, tf):
+def gen_bprmf_batch(ref, out, tf, prefix="tf_"):
     mod = load_by_path(ref, "elliot/recommender/latent_factor_models/BPRMF_batch/BPRMF_batch_model.py", "ref_bprmf_batch_model")
     U, I, F, lr, l_w, l_b = 40, 30, 8, 0.001, 0.1, 0.001
     rs = np.random.RandomState(0)
@@ -106,12 +106,12 @@ def gen_bprmf_batch(ref, out, tf):
     tmask[1, ::2] = False
     v, ix = m.get_top_k(tf.constant(tied), tf.constant(tmask), k=6)
     res.update({"tied": tied, "tied_mask": tmask, "tied_val": v.numpy(), "tied_idx": ix.numpy()})
-    np.savez_compressed(os.path.join(out, "tf_bprmf_batch.npz"), **res)
-    print("wrote tf_bprmf_batch.npz")
+    np.savez_compressed(os.path.join(out, f"{prefix}bprmf_batch.npz"), **res)
+    print(f"wrote {prefix}bprmf_batch.npz")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def gen_multivae(ref, out, tf):
+def gen_multivae(ref, out, tf, prefix="tf_"):
     mod = load_by_path(ref, "elliot/recommender/autoencoders/vae/multi_vae_model.py", "ref_multi_vae_model")
     I, H, L, B, lr = 60, 24, 8, 16, 0.001
     rs = np.random.RandomState(1)
@@ -139,12 +139,12 @@ def gen_multivae(ref, out, tf):
         res[f"loss{step}"] = np.float32(loss.numpy())
         for n, v in zip(names, tw):
             res[f"{n}_{step + 1}"] = v.numpy()
-    np.savez_compressed(os.path.join(out, "tf_multivae.npz"), **res)
-    print("wrote tf_multivae.npz")
+    np.savez_compressed(os.path.join(out, f"{prefix}multivae.npz"), **res)
+    print(f"wrote {prefix}multivae.npz")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def gen_neumf(ref, out, tf):
+def gen_neumf(ref, out, tf, prefix="tf_"):
     mod = load_by_path(ref, "elliot/recommender/neural/NeuMF/neural_matrix_factorization_model.py", "ref_neumf_model")
     U, I, F, lr = 30, 25, 8, 0.002
     units = (4 * F, 2 * F, F)
@@ -181,11 +181,11 @@ def gen_neumf(ref, out, tf):
     res.update({"sat_u": u, "sat_y": y, "sat_p": out_p, "sat_loss": np.float32(loss.numpy())})
     for n, v in enumerate(tw):
         res[f"w{n}_sat"] = v.numpy()
-    np.savez_compressed(os.path.join(out, "tf_neumf.npz"), **res)
-    print("wrote tf_neumf.npz")
+    np.savez_compressed(os.path.join(out, f"{prefix}neumf.npz"), **res)
+    print(f"wrote {prefix}neumf.npz")
 
 
-def gen_gmf(ref, out, tf):
+def gen_gmf(ref, out, tf, prefix="tf_"):
     mod = load_by_path(ref, "elliot/recommender/neural/GeneralizedMF/generalized_matrix_factorization_model.py", "ref_gmf_model")
     U, I, F, lr = 20, 18, 6, 0.002
     rs = np.random.RandomState(3)
@@ -208,8 +208,8 @@ def gen_gmf(ref, out, tf):
             res[f"w{n}_{step + 1}"] = v.numpy()
     ug, ig = np.meshgrid(np.arange(U, dtype=np.int64), np.arange(I, dtype=np.int64), indexing="ij")
     res["recs"] = m.get_recs((tf.constant(ug), tf.constant(ig))).numpy()
-    np.savez_compressed(os.path.join(out, "tf_gmf.npz"), **res)
-    print("wrote tf_gmf.npz")
+    np.savez_compressed(os.path.join(out, f"{prefix}gmf.npz"), **res)
+    print(f"wrote {prefix}gmf.npz")
 
 
 def main():

@@ -207,22 +207,28 @@ def main():
                 if per > 0.02:
                     print(f"    {n}: {per:.3f} ms/call  {2.0 * U * I * F / per / 1e9:.1f} TFLOP/s")
         return
-    ctx.timing(True)
-    if False:
-        pass
-    else:
-        st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=a.opt)
-        for it in range(a.iters):
-            u, i, j = ops.bpr_sample(ctx, pos, a.batch, seed=3, first_sample=it * a.batch)
-            st.train_step(u, i, j, 0.001, 0.1, 0.001, algo=a.algo if a.algo in ("auto", "atomic", "sorted") else "auto")
-        torch.cuda.synchronize()
-        rep = ctx.timing_report()
-        tot = 0
-        for n, (c, ms) in rep.items():
-            print(f"{n}: {ms / a.iters:.4f} ms/step ({c} launches)")
-            tot += ms / a.iters
-        print(f"total {tot:.4f} ms/step -> {a.batch / tot * 1e3 / 1e6:.1f} M pairs/s")
-
+    st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=a.opt)
+    algo = a.algo if a.algo in ("auto", "atomic", "sorted") else "auto"
+    warm = 3
+    for it in range(warm + a.iters):
+        if it == warm:
+            st.sync()
+            torch.cuda.synchronize()
+            ctx.timing(True)
+            ctx.timing_report()
+            t0 = time.perf_counter()
+        u, i, j = ops.bpr_sample(ctx, pos, a.batch, seed=3, first_sample=it * a.batch)
+        st.train_step(u, i, j, 0.001, 0.1, 0.001, algo=algo)
+    st.sync()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / a.iters * 1e3
+    rep = ctx.timing_report()
+    tot = 0
+    for n, (c, ms) in rep.items():
+        print(f"{n}: {ms / a.iters:.4f} ms/step ({c} launches)")
+        tot += ms / a.iters
+    print(f"total {tot:.4f} ms/step (wall with events {wall:.4f}) -> {a.batch / tot * 1e3 / 1e6:.1f} M pairs/s; "
+          f"deferred users={st.deferred} item_fused={st.item_fused} item_deferred={st.item_deferred}")
 
 if __name__ == "__main__":
     main()

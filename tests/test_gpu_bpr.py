@@ -110,7 +110,8 @@ def test_bprmf_summed_gradients_match_oracle_tightly(ctx, compact, F, B, U, I):
     Gu, Gi, Bi = _setup(rs, U, I, F)
     be = parallel.HipUserShardBackend(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
     if be.state.compact != compact:
-        be.state = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=compact, deferred=False)
+        be.state = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=compact, deferred=False,
+                                        fused_user_step=False)              # (what the backend builds: the two-pass form)
     st = be.state
     u = rs.randint(0, U, B).astype(np.int32)
     i = (rs.zipf(1.3, B) % I).astype(np.int32)             # Zipf items: the hottest row collects a large share of the batch
@@ -511,8 +512,8 @@ def test_fused_user_side_equals_the_two_kernel_form_bit_for_bit(ctx, F, U):
     Gu, Gi, Bi = _setup(rs, U, I, F)
     lr, l_w, l_b = 0.01, 0.1, 0.001
     a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, fused_user_step=False)
-    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False)
-    assert b.fused and not a.fused and b.Gu_next is not None and not b.deferred
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False, fused_item_step=False)
+    assert b.fused and not a.fused and b.Gu_next is not None and not b.deferred and not b.item_fused
     for s in range(5):
         n = B if s != 3 else 2500                                  # a short batch: most rows have no triplet
         t = ops.bpr_sample(ctx, pos, n, seed=7, first_sample=s * B)
@@ -616,3 +617,111 @@ def test_deferred_decay_of_the_user_table_equals_the_every_row_pass_bit_for_bit(
         st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
         st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
     same("after apply")
+
+
+@pytest.mark.parametrize("F,I,defer,hist", [(128, 3001, False, None), (64, 700, True, 8), (256, 5000, True, None), (16, 901, True, 4),
+                                            (128, 2000, None, None)])
+def test_fused_item_side_equals_the_two_pass_form_bit_for_bit(ctx, F, I, defer, hist, monkeypatch):
+    """el_bprmf_state.Gi_last: the item segments take Keras' Adam step on their rows in place (no dense gradient table written,
+    re-read and cleared); the rows a batch leaves alone are replayed at the end of every step (item_deferred=False) or when a batch
+    next contains the item / the table is read (item_deferred=True).  Against the two-pass form (k_bpr_item_seg -> gGi ->
+    k_adam_dense_pair) on the same batches: Gi, Bi and their Adam slots BIT-identical at every read, the user table too (it reads
+    the item rows) -- through train_step, train_step_presorted, train_loop, a grads() + apply() pair in the middle, stretches of
+    batches whose positives AND negatives stay inside an eighth of the catalogue (rows wait up to 9 steps), a 4- / 8-entry lr ring
+    whose half-way flushes kick in.  EL_ICHUNK pins the summation order of both forms (one lane group walks the whole sorted batch);
+    segments cut by chunk boundaries are exercised by the next test.  defer=None: the state decides by the batch size (2 B <= I)."""
+    monkeypatch.setenv("EL_ICHUNK", str(1 << 20))
+    if hist:
+        monkeypatch.setattr(ops.BprmfDeviceState, "_LR_HIST", hist)
+    rs = np.random.RandomState(F + I)
+    U, B = 4000, (4096 if defer is not None else 512)
+    indptr, indices = zipf_csr(U, I, mean_log=2.0, sigma_log=0.9, dmin=1, dmax=150, seed=F)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    # positives inside the first eighth of the catalogue only; negatives restricted to the same range by the sampler
+    cutI = max(I // 8, 8)
+    keep = indices < cutI
+    ip2 = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), indptr[:-1]) * (np.diff(indptr) > 0))]).astype(np.int64)
+    few = ops.DeviceCSR(ip2, indices[keep].astype(np.int32), I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False, fused_item_step=False)
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False, fused_item_step=True,
+                             item_deferred=defer)
+    assert not a.item_fused and b.item_fused and b.fused
+
+    def same(tag):
+        b.sync()
+        assert not b._pending_items
+        for name in ("Gi", "mGi", "vGi", "Bi", "mBi", "vBi", "Gu", "mGu", "vGu"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (tag, name, int((x != y).sum()), float((x - y).abs().max()))
+        assert float(b.gGi.abs().max()) == 0.0 and float(b.gBi.abs().max()) == 0.0
+        assert int(b.Gi_last.min()) == b.step and int(b.Gi_last.max()) == b.step
+
+    for s in range(14):
+        narrow = s not in (0, 6, 13)
+        n = B if s != 3 else 600
+        t = ops.bpr_sample(ctx, few if narrow else pos, n, seed=7, first_sample=s * B, item_lo=0, item_hi=cutI if narrow else I)
+        for st in (a, b):
+            if s % 3 == 1:
+                ws = st.sort_workspace(n)
+                st.presort(t[0], t[1], t[2], ws)
+                st.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, ws)
+            else:
+                st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        la, lb = a.pop_loss(), b.pop_loss()
+        assert abs(la - lb) <= 2e-6 * abs(la), (s, la, lb)
+        if s in (0, 5, 12, 13):
+            same(s)
+    if defer is None:
+        assert b.item_deferred == (2 * B <= I)
+    elif defer:
+        assert b.item_deferred
+    a.train_loop(few, 5 * B, B, 11, 0, lr, l_w, l_b)
+    b.train_loop(few, 5 * B, B, 11, 0, lr, l_w, l_b)
+    assert b._pending_items == bool(b.item_deferred)
+    assert torch.equal(a.Bi.view(torch.int32), b.Bi.view(torch.int32)) and not b._pending_items
+    same("loop")
+    t = ops.bpr_sample(ctx, pos, B, seed=9, first_sample=0)
+    for st in (a, b):
+        st.grads(t[0], t[1], t[2], l_w, l_b)
+        st.apply(lr)
+    same("apply")
+    t = ops.bpr_sample(ctx, few, B, seed=10, first_sample=0, item_lo=0, item_hi=cutI)
+    for st in (a, b):
+        st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+    same("after apply")
+
+
+@pytest.mark.parametrize("chunk", [16, 64])
+@pytest.mark.parametrize("defer", [False, True])
+def test_fused_item_side_with_segments_cut_by_chunk_boundaries(ctx, chunk, defer, monkeypatch):
+    """Zipf catalogue, small chunks: the popular items' segments span many lane groups, whose partial rows meet in gGi / gBi through
+    atomics; the rows go on the step's split list and a second launch takes the Adam step from the accumulated gradient and clears it.  The order of those atomic
+    additions is the hardware's in both forms, so the comparison with the two-pass form is to fp32 re-association accuracy -- and
+    exact on every row whose segment lies inside one chunk; the accumulators come back zero, every row is stamped."""
+    monkeypatch.setenv("EL_ICHUNK", str(chunk))
+    F, U, I, B = 128, 3000, 1200, 8192
+    rs = np.random.RandomState(chunk)
+    indptr, indices = zipf_csr(U, I, mean_log=2.5, sigma_log=0.9, dmin=1, dmax=200, seed=5)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False, fused_item_step=False)
+    b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=False, fused_item_step=True,
+                             item_deferred=defer)
+    for s in range(6):
+        t = ops.bpr_sample(ctx, pos, B, seed=3, first_sample=s * B)
+        for st in (a, b):
+            st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+    b.sync()
+    assert float(b.gGi.abs().max()) == 0.0 and float(b.gBi.abs().max()) == 0.0
+    assert int(b.Gi_last.min()) == 6 and int(b.Gi_last.max()) == 6
+    for name in ("Gi", "mGi", "vGi", "Bi", "Gu"):
+        x, y = cpu(getattr(a, name)), cpu(getattr(b, name))
+        # Adam's normalised step turns a last-bit difference of a tiny gradient sum into a difference of up to ~lr in theta on
+        # isolated elements; the bulk agrees to rounding
+        assert (np.abs(x - y) > 2e-6).mean() < 2e-3 and np.abs(x - y).max() < 12 * lr, (name, np.abs(x - y).max())
+    la, lb = a.pop_loss(), b.pop_loss()
+    assert abs(la - lb) <= 1e-5 * abs(la)
