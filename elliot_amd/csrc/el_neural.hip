@@ -9,7 +9,7 @@
 //   mf   = Umf[u] * Imf[i]                               (element-wise)
 //   mlp  = relu-MLP([Umlp[u] ; Imlp[i]])                 (Dense(relu) x n_layers, el_gemm.hip, MFMA fp32)
 //   y    = sigmoid(w . [mf ; mlp] + b0)                  (GMF: mf only, no bias, w = edge_weight h)
-//   loss = keras BinaryCrossentropy: mean_b -(t log p + (1-t) log(1-p)), p clipped to [1e-7, 1-1e-7]
+//   loss = keras BinaryCrossentropy: mean_b -(t log(p + 1e-7) + (1-t) log(1 - p + 1e-7)), p clipped to [1e-7, 1-1e-7] first
 // Embedding tables receive IndexedSlices gradients -> Keras Adam sparse apply (every row decays/moves, SURVEY
 // A.4, k_adam_dense of el_bpr.hip); Dense kernels/biases and the head use the dense ApplyAdam arithmetic.
 // Gathers/scatters are HBM-bound row operations (one lane group per sample, 16 B per lane); the MLP is GEMM-bound.
@@ -214,10 +214,15 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
             continue;
         }
         const float t = label[b];
-        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);          // keras backend epsilon clipping
-        if (lane == 0) myloss += -(t * logf(pc) + (1.0f - t) * logf(1.0f - pc)) / (float)n_div;
+        // K.binary_crossentropy (oracle/tf_clauses.py: bce_clips_probabilities_at_1e7, bce_adds_epsilon_inside_log): the probability
+        // clipped to [1e-7, 1 - 1e-7], epsilon added again inside both logarithms
+        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);
+        if (lane == 0) myloss += -(t * logf(pc + 1e-7f) + (1.0f - t) * logf((1.0f - pc) + 1e-7f)) / (float)n_div;
         float dlogit = 0.f;                                             // d/dlogit: zero where the clip is active
-        if (p > 1e-7f && p < 1.0f - 1e-7f) dlogit = (p - t) / (float)n_div;
+        if (p > 1e-7f && p < 1.0f - 1e-7f) {
+            const float dp = -(t / (p + 1e-7f) - (1.0f - t) / ((1.0f - p) + 1e-7f));      // through the logarithms ...
+            dlogit = dp * (p * (1.0f - p)) / (float)n_div;                                 // ... and the sigmoid
+        }
         if (lane == 0) st.dlogit[b] = dlogit;
         // d loss / d (pre-activation of the last Dense(relu) layer) = dlogit w_f where its output is positive: the ReLU derivative
         // is taken here, where the output row is in registers

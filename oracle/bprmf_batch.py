@@ -73,9 +73,9 @@ def adam_tf_sparse_apply(theta, m, v, g, lr, t):
         rows = np.flatnonzero(np.any(np.reshape(g, (g.shape[0], -1)) != 0, axis=1))
         return adam_lazy_apply(theta, m, v, g, rows, lr, t)
     m *= f(BETA1)
-    m += g * f(1.0 - BETA1)
+    m += g * tf_clauses.one_minus(BETA1)
     v *= f(BETA2)
-    v += (g * g) * f(1.0 - BETA2)
+    v += (g * g) * tf_clauses.one_minus(BETA2)
     if tf_clauses.get("adam_epsilon_outside_sqrt_with_folded_bias_correction"):
         theta -= (lr_t * m) / (np.sqrt(v) + f(EPS))
     else:                                                                # "epsilon hat" form
@@ -88,8 +88,8 @@ def adam_lazy_apply(theta, m, v, g, rows, lr, t):
     f = np.float32
     lr_t = adam_lr_t(lr, t)
     rows = np.unique(rows)
-    m[rows] = m[rows] * f(BETA1) + g[rows] * f(1.0 - BETA1)
-    v[rows] = v[rows] * f(BETA2) + (g[rows] * g[rows]) * f(1.0 - BETA2)
+    m[rows] = m[rows] * f(BETA1) + g[rows] * tf_clauses.one_minus(BETA1)
+    v[rows] = v[rows] * f(BETA2) + (g[rows] * g[rows]) * tf_clauses.one_minus(BETA2)
     theta[rows] = theta[rows] - (lr_t * m[rows]) / (np.sqrt(v[rows]) + f(EPS))
 
 

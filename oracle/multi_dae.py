@@ -11,6 +11,8 @@ of oracle/multi_vae.py, whose helpers are reused.
 """
 import numpy as np
 
+from . import tf_clauses
+
 from .multi_vae import BETA1, BETA2, EPS, adam_lr_t, glorot_normal, log_softmax
 
 NAMES = ("W1", "b1", "Wm", "bm", "W3", "b3", "W4", "b4")
@@ -71,8 +73,8 @@ class MultiDAEOracle:
         f = np.float32
         for k in NAMES:
             gg = g[k].astype(np.float32)
-            self.m[k] += (gg - self.m[k]) * f(1 - BETA1)
-            self.v[k] += (gg * gg - self.v[k]) * f(1 - BETA2)
+            self.m[k] += (gg - self.m[k]) * tf_clauses.one_minus(BETA1)
+            self.v[k] += (gg * gg - self.v[k]) * tf_clauses.one_minus(BETA2)
             self.w[k] -= (self.m[k] * a) / (np.sqrt(self.v[k]) + f(EPS))
         return float(loss)
 

@@ -114,8 +114,8 @@ class MultiVAEOracle:
         f = np.float32
         for k in NAMES:
             gg = g[k].astype(np.float32)
-            self.m[k] += (gg - self.m[k]) * f(1 - BETA1)
-            self.v[k] += (gg * gg - self.v[k]) * f(1 - BETA2)
+            self.m[k] += (gg - self.m[k]) * tf_clauses.one_minus(BETA1)
+            self.v[k] += (gg * gg - self.v[k]) * tf_clauses.one_minus(BETA2)
             self.w[k] -= (self.m[k] * a) / (np.sqrt(self.v[k]) + f(EPS))
         return float(loss)
 

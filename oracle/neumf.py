@@ -71,15 +71,24 @@ def forward(w, u, i, dtype=np.float32, masks=None):
 
 
 def bce(p, y):
-    pc = np.clip(p, 1e-7, 1 - 1e-7) if tf_clauses.get("bce_clips_probabilities_at_1e7") else p        # [TF] clause, oracle/tf_clauses.py
-    return float(-np.mean(y * np.log(pc) + (1 - y) * np.log(1 - pc)))
+    """keras.losses.BinaryCrossentropy() on probabilities [TF clauses bce_clips_probabilities_at_1e7, bce_adds_epsilon_inside_log]."""
+    dt = np.asarray(p).dtype.type
+    pc = np.clip(p, dt(1e-7), dt(1) - dt(1e-7)) if tf_clauses.get("bce_clips_probabilities_at_1e7") else p
+    eps = dt(1e-7) if tf_clauses.get("bce_adds_epsilon_inside_log") else dt(0)
+    return float(-np.mean(y * np.log(pc + eps) + (1 - y) * np.log(1 - pc + eps)))
 
 
 def gradients(w, c, u, i, y):
     n = len(y)
     p = c["p"]
+    dt = p.dtype.type
     live = ((p > 1e-7) & (p < 1 - 1e-7)) if tf_clauses.get("bce_clips_probabilities_at_1e7") else np.ones(p.shape, bool)
-    dlogit = np.where(live, (p - y) / n, 0.0).astype(p.dtype)
+    if tf_clauses.get("bce_adds_epsilon_inside_log"):
+        # d loss / d p through the two logarithms, then the sigmoid's p (1 - p)
+        dp = -(y / (p + dt(1e-7)) - (1 - y) / (1 - p + dt(1e-7)))
+        dlogit = np.where(live, dp * (p * (1 - p)) / n, 0.0).astype(p.dtype)
+    else:
+        dlogit = np.where(live, (p - y) / n, 0.0).astype(p.dtype)
     g = {"hw": c["cat"].T @ dlogit}
     if "hb" in w:
         g["hb"] = np.array([dlogit.sum()])
@@ -120,8 +129,8 @@ class NeuMFOracle:
         f = np.float32
         a = adam_lr_t(self.lr, self.t)
         g = g.astype(np.float32)
-        m += (g - m) * f(1 - BETA1)
-        v += (g * g - v) * f(1 - BETA2)
+        m += (g - m) * tf_clauses.one_minus(BETA1)
+        v += (g * g - v) * tf_clauses.one_minus(BETA2)
         th -= (m * a) / (np.sqrt(v) + f(EPS))
 
     def train_step(self, u, i, y, masks=None):

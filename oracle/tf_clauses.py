@@ -40,8 +40,28 @@ CLAUSES = {
     "bce_clips_probabilities_at_1e7": True,
     # A.2/A.5  tf.nn.l2_loss(x) = sum(x^2) / 2.                                   BPRMF_batch_model.py:68-72
     "l2_loss_is_half_sum_of_squares": True,
+    # A.4  (round 4, found by executing the reference's files on oracle/tf_shim) Adam's (1 - beta) factors are float32 TENSOR
+    #      arithmetic: `1 - beta_1_t` with beta_1_t = identity(hyper('beta_1', float32)) in OptimizerV2._prepare_local, `T(1) - beta1`
+    #      inside the fused ApplyAdam kernel -- i.e. fl32(1 - fl32(0.999)) = 0.00099998713, not fl32(1 - 0.999) = 0.001 (1.3e-5 apart,
+    #      which v carries).  The device kernels always computed `1.0f - 0.999f`.  False: the double-precision difference, rounded.
+    "adam_one_minus_beta_in_fp32": True,
+    # A.8  (round 4, same source) K.binary_crossentropy on probabilities adds epsilon() INSIDE the logarithms, after the clip:
+    #      -(y log(p + 1e-7) + (1 - y) log(1 - p + 1e-7)) -- 2 % of the loss of a saturated prediction (log 2.2e-7 vs log 1.2e-7),
+    #      a relative 1e-7 / p elsewhere; the gradient follows the same expression.  False: plain logarithms of the clipped value.
+    #      (The other branch of that function -- a y_pred produced DIRECTLY by a Sigmoid op is traced back to its logits -- does not
+    #      apply: the models' outputs reach the loss through a nested tf.function call / tf.squeeze.)
+    #                                                                           neural_matrix_factorization_model.py:72,102
+    "bce_adds_epsilon_inside_log": True,
 }
 
 
 def get(name):
     return CLAUSES[name]
+
+
+def one_minus(beta):
+    """(1 - beta) as Keras' Adam forms it (clause adam_one_minus_beta_in_fp32), a numpy float32."""
+    import numpy as np
+    if CLAUSES["adam_one_minus_beta_in_fp32"]:
+        return np.float32(1.0) - np.float32(beta)
+    return np.float32(1.0 - beta)

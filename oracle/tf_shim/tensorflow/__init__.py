@@ -360,7 +360,7 @@ class _Adam:
         folded = tf_clauses.get("adam_epsilon_outside_sqrt_with_folded_bias_correction")
         lr_t = float(f(self.lr) * np.sqrt(f(1) - b2p) / (f(1) - b1p))
         b1, b2, eps = f(self.b1), f(self.b2), f(self.eps)
-        omb1, omb2 = float(f(1) - b1), float(f(1) - b2)
+        omb1, omb2 = float(tf_clauses.one_minus(self.b1)), float(tf_clauses.one_minus(self.b2))     # [clause adam_one_minus_beta_in_fp32]
         with torch.no_grad():
             for g, var in grads_and_vars:
                 if g is None:

@@ -73,7 +73,7 @@ class _BinaryCrossentropy:
             p = p.squeeze(-1)
         if tf_clauses.get("bce_clips_probabilities_at_1e7"):
             p = tf.clip_by_value(Tensor(p), 1e-7, 1.0 - 1e-7).t
-        eps = 1e-7
+        eps = 1e-7 if tf_clauses.get("bce_adds_epsilon_inside_log") else 0.0
         bce = y * torch.log(p + eps) + (1 - y) * torch.log(1 - p + eps)
         return Tensor((-bce).mean())
 

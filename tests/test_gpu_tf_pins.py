@@ -1,5 +1,9 @@
-"""The DEVICE path against TensorFlow's own outputs (tests/golden/tf_*.npz from oracle/gen_golden_tf.py; "parity unpinned" and an
-expected failure while the files are absent -- TensorFlow 2.3.2 cannot be installed in the build container)."""
+"""The DEVICE path against what the reference's own model files compute.
+  family "tf_"      tests/golden/tf_*.npz from oracle/gen_golden_tf.py under the real tensorflow==2.3.2: "parity unpinned" and an expected
+                    failure while the files are absent (TensorFlow cannot be installed in the build container);
+  family "tfshim_"  tests/golden/tfshim_*.npz from oracle/gen_golden_tfshim.py: the same UNMODIFIED reference files executed on the
+                    torch stand-in of oracle/tf_shim (file-level algebra from the reference's source, library clauses as recalled in
+                    oracle/tf_clauses.py) -- committed, must pass."""
 import os
 
 import numpy as np
@@ -14,15 +18,20 @@ from tests.helpers import tf_pins
 pytestmark = pytest.mark.gpu
 
 
-def _fixture(name):
-    path = os.path.join(GOLDEN, f"tf_{name}.npz")
+FAMILIES = ["tf_", "tfshim_"]
+
+
+def _fixture(name, family="tf_"):
+    path = os.path.join(GOLDEN, f"{family}{name}.npz")
     if not os.path.exists(path):
+        assert family == "tf_", f"{path} is a committed fixture (oracle/gen_golden_tfshim.py)"
         pytest.xfail(f"parity unpinned: tests/golden/tf_{name}.npz absent (oracle/gen_golden_tf.py needs tensorflow==2.3.2)")
     return np.load(path, allow_pickle=False)
 
 
-def test_device_bprmf_batch_steps_and_topk_equal_tensorflow(ctx):
-    d = _fixture("bprmf_batch")
+@pytest.mark.parametrize("family", FAMILIES)
+def test_device_bprmf_batch_steps_and_topk_equal_tensorflow(ctx, family):
+    d = _fixture("bprmf_batch", family)
     lr, l_w, l_b = float(d["lr"]), float(d["l_w"]), float(d["l_b"])
     dev = ctx.device
     for compact in (False, True):
@@ -53,8 +62,9 @@ def _excl_of(mask):
     return ip, ix
 
 
-def test_device_neumf_steps_and_get_recs_equal_tensorflow(ctx):
-    d = _fixture("neumf")
+@pytest.mark.parametrize("family", FAMILIES)
+def test_device_neumf_steps_and_get_recs_equal_tensorflow(ctx, family):
+    d = _fixture("neumf", family)
     lr = float(d["lr"])
     st = ops.NmfDeviceState(ctx, tf_pins._nmf_weights(d, 0), max_batch=64)
     dev = ctx.device
@@ -72,3 +82,58 @@ def test_device_neumf_steps_and_get_recs_equal_tensorflow(ctx):
     order = np.lexsort((np.tile(np.arange(I), (U, 1)), -d["recs"]), axis=1)[:, :5]
     near_tie = np.abs(np.diff(np.take_along_axis(d["recs"], np.lexsort((np.tile(np.arange(I), (U, 1)), -d["recs"]), axis=1)[:, :6], 1))).min(1) < 4e-6
     assert np.array_equal(cpu(idx)[~near_tie], order[~near_tie])
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_device_neumf_saturated_loss_equals_tensorflow(ctx, family):
+    """BinaryCrossentropy where the probabilities collapse to 0 / 1 in fp32 (head weights x 200): the clip AND the epsilon inside the
+    logarithms decide the loss there (oracle/tf_clauses.py)."""
+    d = _fixture("neumf", family)
+    w = tf_pins._nmf_weights(d, 3)
+    w["hw"] = w["hw"] * np.float32(200.0)
+    st = ops.NmfDeviceState(ctx, w, max_batch=64)
+    dev = ctx.device
+    u = torch.from_numpy(d["sat_u"].astype(np.int32)).to(dev)
+    st.train_step(u, u, torch.from_numpy(d["sat_y"]).to(dev), float(d["lr"]))
+    assert abs(st.pop_loss() - float(d["sat_loss"])) <= 1e-4 * abs(float(d["sat_loss"]))
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_device_gmf_steps_equal_tensorflow(ctx, family):
+    d = _fixture("gmf", family)
+    lr = float(d["lr"])
+    st = ops.NmfDeviceState(ctx, tf_pins._nmf_weights(d, 0), max_batch=64)
+    dev = ctx.device
+    for s in range(2):
+        u, i = (torch.from_numpy(d[f"{n}{s}"].astype(np.int32)).to(dev) for n in ("u", "i"))
+        st.train_step(u, i, torch.from_numpy(d[f"y{s}"]).to(dev), lr)
+        assert abs(st.pop_loss() - float(d[f"loss{s}"])) <= 1e-4 * abs(float(d[f"loss{s}"]))
+    got, exp = st.weights(), tf_pins._nmf_weights(d, 2)
+    for k, v in exp.items():
+        tf_pins._close_vars(k, got[k], v, lr)
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_device_multivae_steps_equal_tensorflow(ctx, family):
+    d = _fixture("multivae", family)
+    names = [str(n) for n in d["names"]]
+    lr = float(d["lr"])
+    w0 = {n: d[f"{n}_0"] for n in names}
+    x, eps = d["x"], d["eps"]
+    B, I = x.shape
+    st = ops.VaeDeviceState(ctx, w0, max_batch=B)
+    dev = ctx.device
+    rows = np.arange(B)
+    nz = [np.flatnonzero(x[r]) for r in rows]
+    ip = np.concatenate([[0], np.cumsum([len(z) for z in nz])]).astype(np.int64)
+    ix = (np.concatenate(nz) if ip[-1] else np.zeros(0)).astype(np.int32)
+    csr = ops.DeviceCSR(ip, ix, I, dev)
+    r = torch.arange(B, dtype=torch.int32, device=dev)
+    e = torch.from_numpy(eps).to(dev)
+    for s in range(3):
+        st.train_step(csr, r, lr, float(d[f"anneal{s}"]), eps=e)
+        loss = st.pop_loss()
+        assert abs(loss - float(d[f"loss{s}"])) <= 1e-4 * abs(float(d[f"loss{s}"])), (s, loss, float(d[f"loss{s}"]))
+    got = st.weights()
+    for n in names:
+        tf_pins._close_vars(n, got[n], d[f"{n}_3"], lr)

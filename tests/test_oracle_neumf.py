@@ -15,8 +15,9 @@ def _torch_loss(w, u, i, y):
             x = torch.relu(x @ W + b)
         parts.append(x)
     logit = torch.cat(parts, 1) @ w["hw"] + (w["hb"][0] if "hb" in w else 0)
+    # K.binary_crossentropy as oracle/tf_clauses.py reads it: clip to [1e-7, 1 - 1e-7], epsilon added again inside the logarithms
     p = torch.clamp(torch.sigmoid(logit), 1e-7, 1 - 1e-7)
-    return -(y * torch.log(p) + (1 - y) * torch.log(1 - p)).mean()
+    return -(y * torch.log(p + 1e-7) + (1 - y) * torch.log(1 - p + 1e-7)).mean()
 
 
 def _check(w, U, I):
@@ -82,7 +83,7 @@ def test_dropout_masks_enter_forward_and_backward_like_autograd():
         x = torch.relu((x * torch.tensor(masks[l].astype(np.float64))) @ W + b)
     logit = torch.cat([tw["Umf"][tu] * tw["Imf"][ti], x], 1) @ tw["hw"] + tw["hb"][0]
     p = torch.clamp(torch.sigmoid(logit), 1e-7, 1 - 1e-7)
-    loss = -(ty * torch.log(p) + (1 - ty) * torch.log(1 - p)).mean()
+    loss = -(ty * torch.log(p + 1e-7) + (1 - ty) * torch.log(1 - p + 1e-7)).mean()
     loss.backward()
     assert abs(float(loss.detach()) - on.bce(c["p"], y)) < 1e-12
     for k, v in g.items():
