@@ -5,17 +5,20 @@ One JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1  workload = BASELINE.json configs[1]: BPRMF d=128 on synthetic 1M users x 100K items (SURVEY.md 8d "S-1M"),
-       inputs resident in HBM before the timed region.
+N = 1  workload = the shape BASELINE.json's metric / north_star quote their target on: BPRMF d=128 on synthetic 10M users x 1M items
+       (SURVEY.md 8d "S-10M"; it fits one MI355X: tables + Adam slots 17 GB, positives' CSR 3.3 GB), inputs resident in HBM before
+       the timed region.
          step (train) : sample B triplets on the device -> gather -> BPR loss -> Adam (TF-dense semantics, the reference's
                         BPRMF_batch_model.train_step) for one batch of B = --batch triplets; software-pipelined: the sampler,
                         prep and radix sort of step t+1 (they never read the model) run on a side stream under step t
          step (top-k) : fused score + masked top-k for one block of --topk-block users against the full catalogue
-       `value` is the training throughput (pairs/s); the top-k leg is reported under "topk".  Secondary legs follow
-       (parity-test configurations of BASELINE.json, here with their own rooflines): "c4_one_gpu" = the same two steps at
-       north_star's target shape, 10 M users x 1 M items, resident on one GPU; "vae" = Mult-VAE at the ML-20M shape
-       (configs[2]), "neumf" = NeuMF d=128 at the per-GPU shape of configs[3] under user sharding.
-N > 1  one process per GPU.  `python bench.py --gpus N` launches itself under torch.distributed.run when WORLD_SIZE is not
+       `value` is the training throughput (pairs/s); the top-k leg is reported under "topk" and as topk_users_per_s /
+       topk_ms_per_block / topk_frac at the top level.  Secondary legs follow (parity-test configurations of BASELINE.json, here
+       with their own rooflines): "c2" = the same two steps at BASELINE configs[1] (1 M users x 100 K items: the headline of rounds
+       1-3), with the batch sweep and the plugin end-to-end leg on its data; "c5_per_gpu" = configs[4]'s per-GPU shape; "vae" =
+       Mult-VAE at the ML-20M shape (configs[2]), "neumf" = NeuMF d=128 at the per-GPU shape of configs[3] under user sharding.
+N > 1  the SAME 10M x 1M x 128 model partitioned over the ranks (what north_star's "at 1/2/4/8 MI355X" names), B triplets per
+       rank and step.  One process per GPU.  `python bench.py --gpus N` launches itself under torch.distributed.run when WORLD_SIZE is not
        set (the driver's own torchrun launch is honoured as is).  Primary leg: USER shards (the rank's user rows + a replica
        of the item table, all-reduce of the item gradients, collective-free top-k).  Second leg "item_shard": north_star's
        partitioning (item rows sharded, user-gradient exchange, all-gather + merge of partial top-k).  Each leg reports the
@@ -53,8 +56,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of K steps per leg; the median repeat is the leg's time")
-    ap.add_argument("--users", type=int, default=1_000_000)
-    ap.add_argument("--items", type=int, default=100_000)
+    ap.add_argument("--users", type=int, default=10_000_000, help="headline shape: north_star's target (10M users x 1M items x 128)")
+    ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--factors", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1 << 20)
     ap.add_argument("--topk-block", type=int, default=131072)
@@ -71,8 +74,8 @@ def parse():
                     help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial "
                          "top-k (default: user for --shard user, item for the item-shard leg)")
     ap.add_argument("--legs", default="auto",
-                    help="comma list of bpr,item_shard,sweep,plugin,c4,c5,vae,neumf,metrics (auto: N=1 -> all but item_shard; N>1 -> bpr,item_shard)")
-    ap.add_argument("--c4-shape", default="10000000,1000000", help="users,items of the c4 leg (north_star's target shape on ONE GPU)")
+                    help="comma list of bpr,item_shard,c2,sweep,plugin,c5,vae,neumf,metrics (auto: N=1 -> all but item_shard; N>1 -> bpr,item_shard)")
+    ap.add_argument("--c2-shape", default="1000000,100000", help="users,items of the c2 leg (BASELINE configs[1]; sweep and plugin legs run on its data)")
     ap.add_argument("--c5-shape", default="6250000,5000000,256",
                     help="users,items,factors of the c5 leg (BASELINE configs[4] = 50M x 5M x 256 on 8 GPUs: the per-GPU shape under user sharding)")
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
@@ -361,10 +364,23 @@ def cpu_baseline(args, host):
     out = {"kind": "port", "cores": cores, "host_cpu_count": os.cpu_count(), "unit": "pairs/s"}
     rs = np.random.RandomState(0)
     B = args.batch
-    u = torch.from_numpy(rs.randint(0, args.users, B))
+    # the N-thread restatement keeps three copies of the tables (theta, m, v) + temporaries of the same size: the whole shape when
+    # the host has the memory for it, else the first users of it (a bounded sample of the same workload; the dense Adam pass -- the
+    # part of a step that does not depend on B -- then covers fewer rows, which flatters the CPU)
+    Uc = args.users
+    need = 6.5 * (args.users + args.items) * args.factors * 4
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:  # noqa: BLE001
+        avail = 0
+    if avail < need + (8 << 30):
+        Uc = max(1, min(args.users, int((max(avail, 16 << 30) - (8 << 30)) / (6.5 * args.factors * 4)) - args.items))
+    Gu_h = host["Gu"][:Uc]
+    u = torch.from_numpy(rs.randint(0, Uc, B))
     i = torch.from_numpy(rs.randint(0, args.items, B))
     j = torch.from_numpy(rs.randint(0, args.items, B))
-    m = tc.BprmfBatchTorchCpu(host["Gu"], host["Gi"], host["Bi"], 0.001, 0.1, 0.001)
+    m = tc.BprmfBatchTorchCpu(Gu_h, host["Gi"], host["Bi"], 0.001, 0.1, 0.001)
     m.train_step(u, i, j)                                   # warm-up (page faults of the optimiser slots)
     t0 = time.perf_counter()
     n = 0
@@ -374,11 +390,11 @@ def cpu_baseline(args, host):
     dt = time.perf_counter() - t0
     out["value"] = B * n / dt
     out["sample"] = (f"oracle/torch_cpu.py BprmfBatchTorchCpu.train_step (restatement of BPRMF_batch_model.py:58-80 with Keras dense "
-                     f"Adam; TF 2.3.2 not installable), {n} steps of B={B} on U={args.users}, I={args.items}, F={args.factors}, fp32, "
-                     f"{cores} torch threads; {dt:.2f}s")
+                     f"Adam; TF 2.3.2 not installable), {n} steps of B={B} on U={Uc}" + (f" (the first {Uc} of {args.users} users: host memory)" if Uc < args.users else "")
+                     + f", I={args.items}, F={args.factors}, fp32, {cores} torch threads; {dt:.2f}s")
     del m
-    # top-k: matmul + where + top_k on blocks of 4096 users
-    Ub = 4096
+    # top-k: matmul + where + top_k on blocks of users (the [Ub, I] score block is materialised, as the reference does: 4 GB per block)
+    Ub = 4096 if args.items <= 250_000 else 1024
     Gu, Gi, Bi = (torch.from_numpy(host[k]) for k in ("Gu", "Gi", "Bi"))
     indptr, indices = torch.from_numpy(host["indptr"]), torch.from_numpy(host["indices"]).to(torch.int64)
     t0 = time.perf_counter()
@@ -394,11 +410,13 @@ def cpu_baseline(args, host):
     out["topk"] = {"value": nu_done / dt, "unit": "users/s", "cores": cores, "kind": "port",
                    "sample": f"oracle/torch_cpu.py predict_topk (addmm + masked fill + torch.topk; BPRMF_batch_model.py:83-88), "
                              f"{nu_done} users x {args.items} items in blocks of {Ub}, F={args.factors}, k={args.k}, {cores} threads; {dt:.2f}s"}
-    # ---- the parity oracles themselves, one core
+    del Gu, indices
+    # ---- the parity oracles themselves, one core, on the first users of the shape (a NumPy Adam pass over 11 M rows takes ~20 s)
     p1 = {"cores": 1, "kind": "port"}
     Bc = min(args.batch, 1 << 16)
-    un, inn, jn = (x[:Bc].numpy() for x in (u, i, j))
-    orc = ob.BPRMFBatchOracle(host["Gu"], host["Gi"], host["Bi"], 0.001, 0.1, 0.001, optimizer=args.opt)
+    U1 = min(args.users, 1_000_000)
+    un, inn, jn = (rs.randint(0, U1, Bc), i[:Bc].numpy(), j[:Bc].numpy())
+    orc = ob.BPRMFBatchOracle(host["Gu"][:U1], host["Gi"], host["Bi"], 0.001, 0.1, 0.001, optimizer=args.opt)
     t0 = time.perf_counter()
     n = 0
     while n < 1 or time.perf_counter() - t0 < budget * 0.6:
@@ -406,8 +424,10 @@ def cpu_baseline(args, host):
         n += 1
     dt = time.perf_counter() - t0
     p1["value"], p1["unit"] = Bc * n / dt, "pairs/s"
-    p1["sample"] = f"oracle/bprmf_batch.py train_step ({args.opt}), {n} steps, B={Bc}, NumPy fp32 single thread; {dt:.2f}s"
-    nu = args.cpu_topk_users
+    p1["sample"] = (f"oracle/bprmf_batch.py train_step ({args.opt}), {n} steps, B={Bc}, U={U1}" + (f" (the first {U1} of {args.users} users)" if U1 < args.users else "")
+                    + f", I={args.items}, NumPy fp32 single thread; {dt:.2f}s")
+    del orc
+    nu = args.cpu_topk_users if args.items <= 250_000 else max(32, args.cpu_topk_users // 8)
     t0 = time.perf_counter()
     cref.score_topk_f32(host["Gu"][:nu], host["Gi"], host["Bi"], 0, nu, args.k,
                         excl=(host["indptr"][:nu + 1], host["indices"][:int(host["indptr"][nu])]))
@@ -416,6 +436,27 @@ def cpu_baseline(args, host):
                   "sample": f"oracle/c/el_oracle.c orc_score_topk_f32 (fmaf chain, the bit-exact checker), {nu} users x {args.items} items; {dt:.2f}s"}
     out["port_1core"] = p1
     return out
+
+
+def cover_batches(st, indptr, indices, cover_users, cover_items, U, I, B, lr, l_w, l_b, algo="auto"):
+    """Untimed train steps that give the first `cover_users` user rows and the first `cover_items` item rows a gradient once (users in
+    order with one of their positives each, negatives in item order): afterwards no row of the covered tables sits at the m = v = 0
+    fixed point of the gradient-free Adam step, which the replay kernels of the deferred decay skip."""
+    dev = indptr.device
+    n_cover = -(-max(cover_users, cover_items) // B)
+    ar = torch.arange(B, dtype=torch.int64, device=dev)
+    deg = indptr[1:] - indptr[:-1]
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)
+    for c in range(n_cover):
+        uu = (ar + c * B) % U
+        off = (torch.rand(B, device=dev, generator=g) * deg[uu].to(torch.float32)).to(torch.int64)
+        off = torch.minimum(off, deg[uu] - 1).clamp_(min=0)
+        ii = indices[(indptr[uu] + off).clamp_(max=indices.numel() - 1)]
+        jj = ((ar + c * B) % I).to(torch.int32)
+        st.train_step(uu.to(torch.int32), ii.to(torch.int32), jj, lr, l_w, l_b, algo=algo)
+    st.sync()
+    st.pop_loss()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -482,6 +523,12 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                 sampler.side.wait_stream(torch.cuda.current_stream())
             breakdown_step = train_step_sequential
         pop_loss = st.pop_loss
+        # Steady state of the deferred decay before anything is timed: a row that never had a gradient (m = v = 0) is a fixed point
+        # of the gradient-free Adam step and the replay kernels skip it, so a short run from fresh tables would replay far fewer
+        # element-steps than a long one.  "Cover" batches give EVERY user row and EVERY item row a gradient once (users in order,
+        # one of their positives each; negatives in item order): ceil(max(U, I) / B) extra untimed steps, the same train_step.
+        if args.opt == "adam_tf_dense" and (4 * B <= U or 2 * B <= I):
+            cover_batches(st, indptr, indices, U if 4 * B <= U else 0, I if 2 * B <= I else 0, U, I, B, lr, l_w, l_b, args.train_algo)
         # deferred decay of the user table (the state turns it on at its first batch when 4 B <= U): the timed region ends with
         # the replay of every postponed row update -- each (element, step) update of Keras' every-row Adam is inside the timed
         # region.  A no-op in the every-row form.
@@ -678,6 +725,18 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     }
     deferred = bool(getattr(st, "deferred", False))
     rows_touched = None
+    item_fused = bool(getattr(st, "item_fused", False)) and not sharded
+    item_deferred = bool(getattr(st, "item_deferred", False)) and item_fused
+    items_touched = None
+    if item_fused:
+        # fused item side: the segments gather gamma_u per occurrence and move theta, m, v (+ bias) of the batch's distinct items in
+        # place; counted on one drawn batch
+        tb = ops.bpr_sample(ctx, pos_train, B, seed=4242, first_sample=0)
+        items_touched = int(torch.unique(torch.cat([tb[1], tb[2]])).numel())
+        alg["k_bpr_item_seg"] = 2.0 * B * (4.0 * F + 12.0) + 24.0 * items_touched * (F + 1)
+        alg["k_bpr_flush_items"] = 24.0 * (rows_i - items_touched) * F      # every-step form: the rows the batch left alone, one step each
+        alg["k_bpr_catchup_items"] = 24.0 * items_touched * F
+        del tb
     if deferred:
         # the user-side kernel reads / writes only the rows of the batch's distinct users (+ one pre-update row each for the item
         # segments); counted on one drawn batch
@@ -687,10 +746,11 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         alg["k_bpr_catchup"] = 24.0 * rows_touched * F     # the rows it brings up to date (its bound is the replay arithmetic, see valu)
         alg["k_bpr_flush_users"] = 24.0 * rows_u * F
     dn, dsec = dominant(rep_train)
-    if deferred and dn in ("k_bpr_catchup", "k_bpr_flush_users"):
+    valu_bound = ("k_bpr_catchup", "k_bpr_flush_users") + (("k_bpr_catchup_items", "k_bpr_flush_items") if item_deferred else ())
+    if (deferred or item_deferred) and dn in valu_bound:
         # the replay kernels are bound by the fp32 sqrt / division rate of the VALUs, not by HBM (their figures go under
         # `roofline.valu`): the HBM roofline of the leg is that of its largest bandwidth-bound kernel
-        hb = {n: v for n, v in rep_train.items() if n not in ("k_bpr_catchup", "k_bpr_flush_users")}
+        hb = {n: v for n, v in rep_train.items() if n not in valu_bound}
         dn = max(hb, key=lambda n: hb[n][1])
         cnt_, ms_ = getattr(rep_train, "live", {}).get(dn, rep_train[dn])
         if cnt_ == 0:
@@ -702,20 +762,26 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dn), "traffic_source": traffic_note,
                   "step_GBs": step_bytes / (dt_train / K) / 1e9,
                   "kernels_ms_per_step": {n: v[1] / K for n, v in rep_train.items()}}
+    if item_fused:
+        roof_train.update({"item_side": "fused: item segments + Keras Adam on the batch's item rows in place (k_bpr_item_seg, k_bpr_item_split); "
+                                        + ("rows outside the batch wait for their gradient-free updates (deferred, replayed when next needed)"
+                                           if item_deferred else "rows outside the batch replayed at the end of every step (k_bpr_flush_items)"),
+                           "item_rows_per_step": items_touched})
     if deferred:
-        moved = 24.0 * (rows_touched + rows_i) * F + 4.0 * rows_touched * F + B * (24.0 * F + 32.0) + 24.0 * rows_u * F / K
+        item_rows_moved = (items_touched if item_deferred else rows_i) if item_fused else rows_i
+        moved = 24.0 * (rows_touched + item_rows_moved) * F + 4.0 * rows_touched * F + B * (24.0 * F + 32.0) + 24.0 * rows_u * F / K
         roof_train.update({
             "deferred_decay": f"user rows without triplets in a batch are not moved by that step: their gradient-free Adam updates are replayed "
                               f"bit for bit when next needed; the {K} timed steps end with the replay of every pending row (k_bpr_flush_users)",
             "user_rows_per_step": rows_touched,
             "valu": {"what": "k_bpr_catchup / k_bpr_flush_users replay the postponed updates in registers: one correctly rounded fp32 sqrt and "
                              "division per element and step -- U F element-steps per optimiser step in the steady state, whatever B is",
-                     "element_steps_per_step": float(rows_u) * F,
+                     "element_steps_per_step": float(rows_u) * F + (float(rows_i) * F if item_deferred else 0.0),
+                     "steady_state": "every row was given a gradient once before the timed region (cover batches): none sits at the m = v = 0 "
+                                     "fixed point the replay kernels skip",
                      "catchup_ms_per_step": rep_train.get("k_bpr_catchup", (0, 0.0))[1] / K,
                      "flush_ms_per_step": rep_train.get("k_bpr_flush_users", (0, 0.0))[1] / K,
-                     "note": "rows that never had a gradient (m = v = 0: a fixed point of the gradient-free step) are skipped by both kernels, "
-                             "so a short run from fresh tables replays fewer element-steps than the steady state's U F per step; the "
-                             "replay loop itself sustains ~1.2e12 element-steps/s (DESIGN 3.2)"},
+                     "note": "the replay loop sustains ~1.2e12 element-steps/s (DESIGN 3.2)"},
             "step_GBs_note": "step_GBs prices the step at SURVEY 8d's bytes (every row of both tables moved each step) -- work-equivalent, "
                              "it may exceed the HBM peak; step_GBs_moved = the bytes this form has to move (batch rows + 1/K of the final replay)",
             "step_GBs_moved": moved / (dt_train / K) / 1e9})
@@ -786,7 +852,7 @@ def sweep_leg(args, ctx, data):
     sparse apply moves EVERY row each step, 24 (U + I) F bytes whatever B is) and for the touched-rows-only Adam (adam_lazy: a
     documented deviation, what a user who does not need TF's semantics would run).  Each point is one el_bprmf_train_loop call
     (sampler + step per batch launched back to back inside the library, the plugin's fused-epoch path) of `steps` batches,
-    median of --repeats, on fresh tables."""
+    median of --repeats, after cover batches that gave every user row a gradient (steady state of the deferred decay)."""
     from elliot_amd import ops
     dev = ctx.device
     U, I, F = args.users, args.items, args.factors
@@ -800,6 +866,10 @@ def sweep_leg(args, ctx, data):
         st = ops.BprmfDeviceState(ctx, (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * lim_u,
                                   (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i, torch.zeros(I, device=dev), optimizer=opt)
         drawn = 0
+        if opt == "adam_tf_dense":
+            # steady state of the deferred points: every user row gets a gradient once before anything is timed (round-3 sweeps
+            # started from rows at the m = v = 0 fixed point and climbed 0.170 -> 0.212 ms at B = 4 096 as the rows woke up)
+            cover_batches(st, data["indptr"], data["indices"], U, 0, U, I, min(U, 1 << 20), lr, l_w, l_b)
         for B in (4096, 65536, 1 << 20):
             steps = args.steps * (1 if B >= (1 << 20) else 4)
             st.train_loop(pos, args.warmup * B, B, 42, drawn, lr, l_w, l_b)
@@ -1064,10 +1134,11 @@ def main():
     U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
     sharded = world > 1 or args.force_sharded
     legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else
-                                                            ["bpr", "metrics", "sweep", "plugin", "c4", "c5", "vae", "neumf"])
+                                                            ["bpr", "c2", "metrics", "sweep", "plugin", "c5", "vae", "neumf"])
 
     # ---------------- synthetic inputs, resident in HBM -------------------------------------------
-    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+    # headline: north_star's target shape (every rank builds the same CSR and keeps its part)
+    indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234 if (U, I) != (10_000_000, 1_000_000) else 4321)
     data = {"indptr": indptr, "indices": indices, "pos": ops.DeviceCSR.from_tensors(indptr, indices, I)}
     if args.comm == "abi" and sharded:
         from elliot_amd import parallel
@@ -1075,32 +1146,31 @@ def main():
 
     want_cpu = world == 1 and not args.no_cpu_baseline
     topk_shard = args.topk_shard or ("user" if args.shard == "user" else "item")
-    main_leg = bpr_leg(args, ctx, world, rank, data, args.shard, topk_shard, with_metrics="metrics" in legs, keep_host=want_cpu and rank == 0)
+    main_leg = bpr_leg(args, ctx, world, rank, data, args.shard, topk_shard, with_metrics="metrics" in legs and "c2" not in legs,
+                       keep_host=want_cpu and rank == 0)
     second = None
     if "item_shard" in legs and sharded and args.shard == "user":
         torch.cuda.empty_cache()
         second = bpr_leg(args, ctx, world, rank, data, "item", args.topk_shard or "item")
-    sweep = plugin = None
-    if world == 1 and not args.force_sharded:
-        if "sweep" in legs:
-            sweep = sweep_leg(args, ctx, data)
-        if "plugin" in legs:
-            plugin = plugin_e2e_leg(args, ctx, data)
-            torch.cuda.empty_cache()
     del data, indptr, indices
     torch.cuda.empty_cache()
-    vae = neumf = c4 = c5 = None
+    sweep = plugin = vae = neumf = c2 = c5 = None
     if world == 1 and not args.force_sharded:
-        if "c4" in legs:
-            # north_star's target shape (BASELINE configs[3] sizes: 10 M users x 1 M items, d = 128) resident on ONE GPU: the same
-            # two steps as the headline leg, 10x the rows (tables + Adam moments 16.9 GB, exclusion CSR 3.3 GB)
-            a4 = argparse.Namespace(**vars(args))
-            a4.users, a4.items = (int(x) for x in args.c4_shape.split(","))
-            ip4, ix4 = zipf_csr_device(a4.users, a4.items, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=4321)
-            d4 = {"indptr": ip4, "indices": ix4, "pos": ops.DeviceCSR.from_tensors(ip4, ix4, a4.items)}
-            c4 = bpr_leg(a4, ctx, world, rank, d4, "user", "user")
-            c4["workload"] = f"BPRMF d={F}, synthetic {a4.users} users x {a4.items} items on one GPU (north_star target shape)"
-            del d4, ip4, ix4
+        if "c2" in legs or "sweep" in legs or "plugin" in legs:
+            # BASELINE configs[1] (1 M users x 100 K items, d = 128: the headline of rounds 1-3): the same two steps, the every-row fused
+            # kernels (B = U: a batch touches most user rows), + the batch sweep and the plugin end-to-end leg on its data
+            a2 = argparse.Namespace(**vars(args))
+            a2.users, a2.items = (int(x) for x in args.c2_shape.split(","))
+            ip2, ix2 = zipf_csr_device(a2.users, a2.items, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+            d2 = {"indptr": ip2, "indices": ix2, "pos": ops.DeviceCSR.from_tensors(ip2, ix2, a2.items)}
+            if "c2" in legs:
+                c2 = bpr_leg(a2, ctx, world, rank, d2, "user", "user", with_metrics="metrics" in legs)
+                c2["workload"] = f"BPRMF d={F}, synthetic {a2.users} users x {a2.items} items (BASELINE configs[1])"
+            if "sweep" in legs:
+                sweep = sweep_leg(a2, ctx, d2)
+            if "plugin" in legs:
+                plugin = plugin_e2e_leg(a2, ctx, d2)
+            del d2, ip2, ix2
             torch.cuda.empty_cache()
         if "c5" in legs:
             # BASELINE configs[4] (BPRMF d=256, 50 M users x 5 M items on 8 GPUs) at its PER-GPU shape under user sharding: the rank's
@@ -1126,17 +1196,24 @@ def main():
         return
 
     host = main_leg.pop("_host", None)
+    tk = main_leg["topk"]
     line = {
         "metric": "BPR-MF positive-pairs/sec + full-catalog top-k users/sec",
         "value": main_leg["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_leg["ms_per_step"], "repeats_ms_per_step": main_leg["repeats_ms_per_step"], "repeats": REPEATS,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
-                   else f"BPRMF d={F}, synthetic {U} users x {I} items",
+        # the second half of the metric, at the top level (the full object is "topk")
+        "topk_users_per_s": tk["value"], "topk_ms_per_block": tk["ms_per_step"], "topk_frac": tk["roofline"]["frac"],
+        "config": {"workload": ("BPRMF d=128, synthetic 10M users x 1M items (the shape BASELINE.json's metric / north_star quote the target on; "
+                                "fits one MI355X)" if (U, I, F) == (10_000_000, 1_000_000, 128)
+                                else "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
+                                else f"BPRMF d={F}, synthetic {U} users x {I} items"),
                    "users": U, "items": I, "factors": F, "interactions": main_leg["interactions"], "batch": B,
                    "batch_per_gpu": B, "optimizer": args.opt, "topk_block": main_leg["topk_block"], "k": k,
                    "parallelism": main_leg["parallelism"] + ("; top-k: see topk.sharding" if sharded else ""),
+                   "scaling_note": ("one model of this shape partitioned over the ranks (user rows sharded, item table replicated), B triplets "
+                                    "per rank and step: the batch grows with N, the tables do not") if sharded else None,
                    "world_size_observed": world, "backend": backend, "collectives_through": args.comm if sharded else None},
         "loss_per_pair_last": main_leg["loss_per_pair_last"],
         "roofline": main_leg["roofline"],
@@ -1148,9 +1225,9 @@ def main():
     if second is not None:
         line["item_shard"] = {kk: second[kk] for kk in ("value", "unit", "ms_per_step", "scaling", "parallelism", "loss_per_pair_last",
                                                        "roofline", "topk", "collectives") if kk in second}
-    if c4 is not None:
-        line["c4_one_gpu"] = {kk: c4[kk] for kk in ("workload", "value", "unit", "ms_per_step", "repeats_ms_per_step", "interactions", "loss_per_pair_last",
-                                                    "roofline", "topk") if kk in c4}
+    if c2 is not None:
+        line["c2"] = {kk: c2[kk] for kk in ("workload", "value", "unit", "ms_per_step", "repeats_ms_per_step", "interactions", "loss_per_pair_last",
+                                            "roofline", "topk", "metrics") if kk in c2}
     if c5 is not None:
         line["c5_per_gpu"] = {kk: c5[kk] for kk in ("workload", "value", "unit", "ms_per_step", "repeats_ms_per_step", "interactions",
                                                     "loss_per_pair_last", "roofline", "topk") if kk in c5}

@@ -341,8 +341,11 @@ class HipDenseBackend:
         U, F = Gu.shape
         self.U, self.F = int(U), int(F)
         self.Us = user_shard_rows(self.U, world)
-        Gu_pad = torch.zeros((self.Us * world, F), dtype=torch.float32, device=dev)
-        Gu_pad[:U].copy_(Gu)
+        if self.Us * world == self.U and isinstance(Gu, torch.Tensor):
+            Gu_pad = Gu                                             # nothing to pad (a 51 GB table at configs[4]: no second copy)
+        else:
+            Gu_pad = torch.zeros((self.Us * world, F), dtype=torch.float32, device=dev)
+            Gu_pad[:U].copy_(Gu if isinstance(Gu, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(Gu)))
         # state of the gradient pass: whole (padded) user table, local item shard; no optimiser slots needed for Gu
         self.state = ops.BprmfDeviceState(ctx, Gu_pad, Gi_shard, Bi_shard, optimizer="sgd_dense", deferred=False)
         del Gu_pad

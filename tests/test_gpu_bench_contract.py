@@ -41,6 +41,9 @@ def check_common(d, n_gpus=1):
     for r in (d["roofline"], d["topk"]["roofline"]):
         check_roofline(r)
     assert d["topk"]["value"] > 0 and d["topk"]["unit"] == "users/s"
+    # the second half of the metric is also at the top level of the line (the driver's record keeps top-level scalars)
+    assert d["topk_users_per_s"] == d["topk"]["value"] and d["topk_ms_per_block"] == d["topk"]["ms_per_step"]
+    assert d["topk_frac"] == d["topk"]["roofline"]["frac"]
 
 
 def test_default_line_has_every_field():
@@ -70,12 +73,13 @@ def test_pipelined_and_plain_training_step_lines():
 
 def test_secondary_legs_carry_their_rooflines():
     """vae = BASELINE configs[2], neumf = configs[3] per-GPU shape; here at toy shapes (the default shapes run in bench.py itself)."""
-    d = run_bench("--legs", "bpr,c4,vae,neumf", "--no-cpu-baseline", "--vae-shape", "3000,1500,96,32,256", "--neumf-shape", "5000,3000,32,8192",
-                  "--c4-shape", "300000,40000")
+    d = run_bench("--legs", "bpr,c2,metrics,vae,neumf", "--no-cpu-baseline", "--vae-shape", "3000,1500,96,32,256", "--neumf-shape", "5000,3000,32,8192",
+                  "--c2-shape", "30000,4000")
     check_common(d)
-    c4 = d["c4_one_gpu"]                                   # north_star's target shape on one GPU (here small)
-    assert c4["value"] > 0 and c4["unit"] == "pairs/s" and c4["topk"]["value"] > 0 and "300000 users x 40000 items" in c4["workload"]
-    for r in (c4["roofline"], c4["topk"]["roofline"]):
+    c2 = d["c2"]                                           # BASELINE configs[1] beside the headline (here small)
+    assert c2["value"] > 0 and c2["unit"] == "pairs/s" and c2["topk"]["value"] > 0 and "30000 users x 4000 items" in c2["workload"]
+    assert c2["metrics"]["value"] > 0
+    for r in (c2["roofline"], c2["topk"]["roofline"]):
         check_roofline(r)
     for leg, unit in (("vae", "users/s"), ("neumf", "samples/s")):
         assert d[leg]["value"] > 0 and d[leg]["unit"] == unit and d[leg]["workload"]
@@ -84,9 +88,10 @@ def test_secondary_legs_carry_their_rooflines():
 
 
 def test_sweep_plugin_and_c5_legs():
-    """batch_sweep (B x optimiser grid through el_bprmf_train_loop), plugin_e2e (external.BPRMF_batch through RecMixin.train() +
-    evaluate()), c5_per_gpu (BASELINE configs[4] per-GPU shape; here small, d = 256) -- every leg reports its repeats."""
-    d = run_bench("--legs", "bpr,sweep,plugin,c5", "--no-cpu-baseline", "--c5-shape", "200000,30000,256", "--repeats", "2")
+    """batch_sweep (B x optimiser grid through el_bprmf_train_loop) and plugin_e2e (external.BPRMF_batch through RecMixin.train() +
+    evaluate()) on the c2 leg's data, c5_per_gpu (BASELINE configs[4] per-GPU shape; here small, d = 256) -- every leg reports its
+    repeats."""
+    d = run_bench("--legs", "bpr,sweep,plugin,c5", "--no-cpu-baseline", "--c5-shape", "200000,30000,256", "--repeats", "2", "--c2-shape", "60000,8000")
     check_common(d)
     assert d["repeats"] == 2 and len(d["repeats_ms_per_step"]) == 2 and min(d["repeats_ms_per_step"]) <= d["ms_per_step"] <= max(d["repeats_ms_per_step"])
     pts = d["batch_sweep"]["points"]
@@ -138,3 +143,14 @@ def test_collectives_through_the_c_abi_one_rank():
     check_common(d)
     assert d["config"]["collectives_through"] == "abi"
     assert d["collectives"][0]["op"] == "all_reduce" and d["collectives"][0]["ms"] > 0
+
+
+def test_deferred_legs_are_timed_in_their_steady_state():
+    """A shape whose batches leave most rows alone (4 B <= U, 2 B <= I): the user AND the item table run their deferred decay, the line
+    says so, and the timed region starts after cover batches gave every row a gradient (no row at the m = v = 0 fixed point)."""
+    cmd_extra = ("--legs", "bpr", "--no-cpu-baseline", "--users", "300000", "--items", "150000", "--batch", "65536")
+    d = run_bench(*cmd_extra)
+    r = d["roofline"]
+    assert "deferred_decay" in r and r["valu"]["steady_state"] and "item_side" in r and "deferred" in r["item_side"]
+    assert r["valu"]["element_steps_per_step"] == (300000 + 150000) * 64
+    assert 0 < r["item_rows_per_step"] <= 2 * 65536 and 0 < r["user_rows_per_step"] <= 65536

@@ -1,5 +1,8 @@
-"""BASELINE configs[3] at its PER-GPU shape under user sharding at N = 8: NeuMF d = 128, tower 512-256-128, 1.25 M users x 1 M
-items, batch 262 144 -- the shape of bench.py's `neumf` leg.  The NumPy oracle cannot run at this size; these properties can:
+"""BASELINE configs[3] (NeuMF d = 128, tower 512-256-128, 10 M users x 1 M items over 8 GPUs) at BOTH per-GPU shapes, batch 262 144:
+  "user"  1.25 M users x 1 M items   -- user tables sharded, item tables replicated (the shape of bench.py's `neumf` leg)
+  "item"  10 M users x 125 K items   -- north_star's / configs[3]'s wording: item tables sharded, the two 10 M x 128 user tables
+                                        replicated on every rank (5 GB each + gradient table + Adam slots: 41 GB of user-side state)
+The NumPy oracle cannot run at this size; these properties can:
 
   optimiser   the deferred decay of the four embedding tables (el_nmf_state.row_last) against Keras' every-row Adam
               on a SAMPLE of rows: a host shadow moves the sampled rows at every step (el_adam_elem in NumPy fp32) with the
@@ -20,8 +23,9 @@ from tests.gpu_util import cpu
 
 pytestmark = pytest.mark.gpu
 
-U, I, F, B, LR = 1_250_000, 1_000_000, 128, 262_144, 0.001
+F, B, LR = 128, 262_144, 0.001
 UNITS = (4 * F, 2 * F, F)
+SHAPES = {"user": (1_250_000, 1_000_000), "item": (10_000_000, 125_000)}
 
 
 def _adam_np(th, m, v, g, lr_t):
@@ -32,9 +36,11 @@ def _adam_np(th, m, v, g, lr_t):
     th[...] = th - (f(lr_t) * m) / (np.sqrt(v) + eps)
 
 
-@pytest.fixture(scope="module")
-def c3(ctx):
+@pytest.fixture(scope="module", params=["user", "item"])
+def c3(ctx, request):
     dev = ctx.device
+    U, I = SHAPES[request.param]
+    torch.cuda.empty_cache()
     indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=77)
     pos = ops.DeviceCSR.from_tensors(indptr, indices, I)
     g = torch.Generator(device=dev)
@@ -52,7 +58,9 @@ def c3(ctx):
     assert st.deferred                                           # the form bench.py's neumf leg runs
     del w
     torch.cuda.empty_cache()
-    return {"pos": pos, "st": st}
+    yield {"pos": pos, "st": st, "U": U, "I": I}
+    del st, pos
+    torch.cuda.empty_cache()
 
 
 def _loss64(st, u, i, y):
@@ -65,12 +73,12 @@ def _loss64(st, u, i, y):
     for W, b in zip(st.W, st.b):
         x = torch.relu(x @ W.to(d) + b.to(d))
     logit = torch.cat([mf, x], dim=1) @ st.hw.to(d) + st.hb.to(d)
-    p = torch.sigmoid(logit).clamp(1e-7, 1 - 1e-7)
-    return float(-(y.to(d) * torch.log(p) + (1 - y.to(d)) * torch.log(1 - p)).mean())
+    p = torch.sigmoid(logit).clamp(1e-7, 1 - 1e-7)                # K.binary_crossentropy: clip, then epsilon inside the logarithms
+    return float(-(y.to(d) * torch.log(p + 1e-7) + (1 - y.to(d)) * torch.log(1 - p + 1e-7)).mean())
 
 
 def test_deferred_decay_at_the_configs3_shard_shape_on_sampled_rows(ctx, c3):
-    st, pos, dev = c3["st"], c3["pos"], ctx.device
+    st, pos, dev, U, I = c3["st"], c3["pos"], ctx.device, c3["U"], c3["I"]
     rs = np.random.RandomState(3)
     hot_items = torch.topk(torch.bincount(pos.indices.long(), minlength=I).float(), 64).indices
     rows = {0: torch.from_numpy(np.unique(rs.randint(0, U, 2048))).to(dev),
@@ -108,7 +116,7 @@ def test_deferred_decay_at_the_configs3_shard_shape_on_sampled_rows(ctx, c3):
 
 
 def test_scoring_reads_the_synced_tables_at_full_size(ctx, c3):
-    st, pos, dev = c3["st"], c3["pos"], ctx.device
+    st, pos, dev, I = c3["st"], c3["pos"], ctx.device, c3["I"]
     k, nu = 10, 8
     for step in range(2):                                        # leave row updates pending
         u, i, y = ops.pointwise_sample(ctx, pos, B, seed=12, first_sample=step * B)
