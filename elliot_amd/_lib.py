@@ -190,6 +190,7 @@ PROTOTYPES = {
     "el_gmf_item_image": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int32, _f32p]),
     "el_bprmf_sync_users": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), C.c_int32]),
     "el_bprmf_sync_items": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), C.c_int32]),
+    "el_selftest_replay_math": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "el_bprmf_train_loop_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "el_bprmf_train_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i64p, _i32p, C.c_uint64, C.c_uint64,
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,

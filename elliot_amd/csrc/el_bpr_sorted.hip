@@ -493,7 +493,6 @@ __global__ __launch_bounds__(256) void k_bpr_user_adam(SegParams p, FusedParams 
 template <int VW>
 __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* __restrict__ tm, float* __restrict__ tv, int F, int64_t row, int lane,
                                                int last, int ns, const float* __restrict__ hist, int hist_mask) {
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     for (int f0 = 0; f0 < F; f0 += 64 * VW) {
         const int e = f0 + lane * VW;
         float th[VW], mm[VW], vv[VW];
@@ -508,11 +507,7 @@ __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* _
 #pragma unroll
         for (int x = 0; x < VW; ++x) nz = nz || mm[x] != 0.f || vv[x] != 0.f;
         if (__ballot(nz) == 0ull) continue;                     // this chunk of the row is at its fixed point
-        for (int s = 0; s < ns; ++s) {
-            const float lr = hist[(last + 1 + s) & hist_mask];
-#pragma unroll
-            for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], 0.0f, lr, b1, b2, omb1, omb2, eps);
-        }
+        el_adam_replay<VW>(th, mm, vv, ns, [&](int s) { return hist[(last + 1 + s) & hist_mask]; });
         if (e < F) {
             stv<VW>(tth + row * F + e, th);
             stv<VW>(tm + row * F + e, mm);
@@ -983,6 +978,84 @@ extern "C" int el_bprmf_sync_users(el_ctx* ctx, void* stream, const el_bprmf_sta
     if (stp->Gu_last == nullptr || step == 0) return 0;
     if (int rc = check_deferred(*stp)) return rc;
     return launch_flush_users(*stp, (hipStream_t)stream, step);
+}
+
+// ---- self-test of the packed replay arithmetic (el_common.h: el_pk_sqrt, el_pk_div, el_adam_replay2) ----------------------------
+// out[0] = floats v in [2^-96, 2^96] (ALL of them: 1 610 612 736) with el_pk_sqrt(v) != sqrtf(v)
+// out[1] = of n_pairs pseudo-random (num, den) pairs spanning the guard range -- half of them with neighbouring mantissas, the
+//          near-tie quotients -- those with el_pk_div != num / den
+// out[2] = of n_pairs (theta, m, v, lr) tuples inside the guard, those where EL_REPLAY_CHUNK packed steps differ from el_adam_elem
+__global__ __launch_bounds__(256) void k_selftest_sqrt(u64* out) {
+    const u32 lo = (127u - 96u) << 23, hi = (127u + 96u) << 23;
+    u64 bad = 0;
+    for (u64 b = lo + ((u64)blockIdx.x * 256 + threadIdx.x) * 2; b < hi; b += (u64)gridDim.x * 512) {
+        el_f2 v;
+        v.x = __uint_as_float((u32)b), v.y = __uint_as_float((u32)b + 1u);
+        const el_f2 s = el_pk_sqrt(v);
+        bad += (__float_as_uint(s.x) != __float_as_uint(sqrtf(v.x))) + (__float_as_uint(s.y) != __float_as_uint(sqrtf(v.y)));
+    }
+    if (bad) atomicAdd((unsigned long long*)out, (unsigned long long)bad);
+}
+__device__ __forceinline__ u64 selftest_mix(u64& s) {
+    u64 z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_selftest_div(int iters, u64* out) {
+    u64 s = 0x1234ull + ((u64)blockIdx.x * 256 + threadIdx.x) * 0x9E37ull, bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        el_f2 a, b;
+        for (int h = 0; h < 2; ++h) {
+            const u64 r = selftest_mix(s);
+            const u32 ma = (u32)r & 0x7fffffu;
+            const u32 mb = (it & 1) ? ((ma + (u32)(r >> 60)) & 0x7fffffu) : ((u32)(r >> 23) & 0x7fffffu);
+            const u32 ea = 127 - 90 + (u32)((r >> 46) % 120), eb = 127 - 24 + (u32)((r >> 53) % 54);     // |num| in [2^-90, 2^30), den in [2^-24, 2^30)
+            const float av = __uint_as_float(((u32)(r >> 63) << 31) | (ea << 23) | ma), bv = __uint_as_float((eb << 23) | mb);
+            if (h == 0) a.x = av, b.x = bv; else a.y = av, b.y = bv;
+        }
+        const el_f2 q = el_pk_div(a, b);
+        bad += (__float_as_uint(q.x) != __float_as_uint(a.x / b.x)) + (__float_as_uint(q.y) != __float_as_uint(a.y / b.y));
+    }
+    if (bad) atomicAdd((unsigned long long*)(out + 1), (unsigned long long)bad);
+}
+__global__ __launch_bounds__(256) void k_selftest_step(int iters, u64* out) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    u64 s = 0x77ull + ((u64)blockIdx.x * 256 + threadIdx.x) * 0x51ull, bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        float th[2], mm[2], vv[2];
+        for (int h = 0; h < 2; ++h) {
+            const u64 r = selftest_mix(s);
+            th[h] = __uint_as_float(((u32)(r >> 62) << 31) | ((127u - 20u + (u32)(r % 24)) << 23) | ((u32)(r >> 8) & 0x7fffffu));
+            mm[h] = __uint_as_float(((u32)(r >> 61) << 31) | ((127u - 58u + (u32)((r >> 32) % 88)) << 23) | ((u32)(r >> 9) & 0x7fffffu));
+            vv[h] = __uint_as_float(((127u - 89u + (u32)((r >> 40) % 149)) << 23) | ((u32)(r >> 17) & 0x7fffffu));
+        }
+        const float lr = __uint_as_float(((127u - 30u + (u32)(selftest_mix(s) % 30)) << 23) | ((u32)s & 0x7fffffu));
+        if (!(el_replay_ok(mm[0], vv[0]) && el_replay_ok(mm[1], vv[1]) && el_replay_lr_ok(lr))) continue;
+        el_f2 T = {th[0], th[1]}, M = {mm[0], mm[1]}, V = {vv[0], vv[1]};
+        for (int k = 0; k < EL_REPLAY_CHUNK; ++k) {
+            el_adam_replay2(T, M, V, lr);
+            for (int h = 0; h < 2; ++h) el_adam_elem(th[h], mm[h], vv[h], 0.0f, lr, b1, b2, omb1, omb2, eps);
+        }
+        bad += (__float_as_uint(T.x) != __float_as_uint(th[0])) + (__float_as_uint(T.y) != __float_as_uint(th[1])) +
+               (__float_as_uint(M.x) != __float_as_uint(mm[0])) + (__float_as_uint(V.y) != __float_as_uint(vv[1]));
+    }
+    if (bad) atomicAdd((unsigned long long*)(out + 2), (unsigned long long)bad);
+}
+
+extern "C" int el_selftest_replay_math(el_ctx* ctx, void* stream, int64_t n_pairs, uint64_t* out3) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(out3 != nullptr && n_pairs >= 0, "el_selftest_replay_math: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    EL_CHECK_HIP(hipMemsetAsync(out3, 0, 24, s));
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, s, (u64*)out3);
+    const int iters = (int)((n_pairs + 2 * 4096 * 256 - 1) / (2 * 4096 * 256));
+    if (iters > 0) {
+        hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(256), 0, s, iters, (u64*)out3);
+        hipLaunchKernelGGL(k_selftest_step, dim3(4096), dim3(256), 0, s, iters, (u64*)out3);
+    }
+    EL_CHECK_LAUNCH();
+    return 0;
 }
 
 // ---- fused item side: replay launches ----------------------------------------------------------------------------------------

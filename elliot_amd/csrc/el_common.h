@@ -252,6 +252,130 @@ __device__ __forceinline__ void el_adam_elem(float& th, float& m, float& v, floa
     th = th - (lr_t * m) / (sqrtf(v) + eps);
 }
 
+// ---- the gradient-free Adam step of the deferred decay on packed fp32 instructions -------------------------------------------
+// A row that waits for its postponed updates is replayed with g = 0: per element and step one IEEE square root and one IEEE
+// division, which the compiler expands into ~37 VALU issue slots (v_sqrt + neighbour test + scaling; div_scale x 2, v_rcp, five
+// fma, div_fmas, div_fixup).  el_adam_replay2 takes the SAME step on two elements at once with v_pk_mul / v_pk_add / v_pk_fma:
+//   sqrt   v_rsq + Goldschmidt / Markstein in fma only: y = rsq(v); g = v y; h = y / 2; r = 1/2 - h g; g += g r; h += h r;
+//          g += (v - g g) h -- equal to sqrtf() for EVERY float in [2^-96, 2^96] (checked exhaustively on the device, 1.6e9 inputs:
+//          scripts/exp/replay_math.hip, tests/test_gpu_bpr.py::test_packed_replay_arithmetic_is_exact)
+//   div    the compiler's own expansion without v_div_scale / the scale of v_div_fmas / v_div_fixup, which are the identity while the
+//          numerator is above 2^-103, the quotient normal and the exponents less than 96 apart
+// -- 18.5 issue slots per element and step, the same bits.  el_replay_ok is the guard: inside it the next EL_REPLAY_CHUNK steps
+// stay in the ranges above (m shrinks by 0.9 per step, v by 0.999; lr in [2^-30, 1]); a wave with any element outside (zeros,
+// denormals, huge values) takes those steps with el_adam_elem.
+typedef float el_f2 __attribute__((ext_vector_type(2)));
+#define EL_REPLAY_CHUNK 8
+
+__device__ __forceinline__ bool el_replay_ok(float m, float v) {
+    const u32 mb = __float_as_uint(m) & 0x7fffffffu, vb = __float_as_uint(v);
+    return (mb - ((127u - 58u) << 23)) < (88u << 23) &&          // |m| in [2^-58, 2^30)
+           (vb - ((127u - 89u) << 23)) < (149u << 23);           // v in [2^-89, 2^60)
+}
+__device__ __forceinline__ bool el_replay_lr_ok(float lr) { return lr >= 9.3132257e-10f && lr <= 1.0f; }     // [2^-30, 1]
+
+__device__ __forceinline__ el_f2 el_pk_sqrt(el_f2 v) {           // == sqrtf per element for v in [2^-96, 2^96]
+    const el_f2 half = {0.5f, 0.5f};
+    el_f2 y;
+    y.x = __builtin_amdgcn_rsqf(v.x), y.y = __builtin_amdgcn_rsqf(v.y);
+    el_f2 g = v * y, h = y * 0.5f;
+    const el_f2 r = __builtin_elementwise_fma(-h, g, half);
+    g = __builtin_elementwise_fma(g, r, g);
+    h = __builtin_elementwise_fma(h, r, h);
+    const el_f2 d = __builtin_elementwise_fma(-g, g, v);
+    return __builtin_elementwise_fma(d, h, g);
+}
+__device__ __forceinline__ el_f2 el_pk_div(el_f2 num, el_f2 den) {  // == num / den per element inside the no-scaling region
+    const el_f2 one = {1.f, 1.f};
+    el_f2 r0;
+    r0.x = __builtin_amdgcn_rcpf(den.x), r0.y = __builtin_amdgcn_rcpf(den.y);
+    const el_f2 e = __builtin_elementwise_fma(-den, r0, one);
+    const el_f2 r1 = __builtin_elementwise_fma(e, r0, r0);
+    const el_f2 q0 = num * r1;
+    const el_f2 m0 = __builtin_elementwise_fma(-den, q0, num);
+    const el_f2 q1 = __builtin_elementwise_fma(m0, r1, q0);
+    const el_f2 m1 = __builtin_elementwise_fma(-den, q1, num);
+    return __builtin_elementwise_fma(m1, r1, q1);
+}
+__device__ __forceinline__ void el_adam_replay2(el_f2& th, el_f2& m, el_f2& v, float lr) {
+    const el_f2 zero = {0.f, 0.f};
+    m = m * 0.9f + zero;                                          // m*b1 + g*(1-b1), v*b2 + (g*g)*(1-b2) with g = 0
+    v = v * 0.999f + zero;
+    th = th - el_pk_div(m * lr, el_pk_sqrt(v) + 1e-7f);           // theta - (lr_t m) / (sqrt(v) + eps)
+}
+
+// ns gradient-free steps on the VW elements a lane holds (wave-uniform ns; lr of step k at lrs(k)).  Elements at the m = v = 0
+// fixed point of the step (rows or slots that never had a gradient, lanes past the end of a row) do not keep a wave off the packed
+// path: they ride along and get their values back.
+template <int VW, typename LR>
+__device__ __forceinline__ void el_adam_replay(float (&th)[VW], float (&mm)[VW], float (&vv)[VW], int ns, LR lrs) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+#ifdef EL_REPLAY_SIMPLE                                            // (A/B builds: the plain loop of rounds 3)
+    for (int s = 0; s < ns; ++s) {
+        const float lr = lrs(s);
+#pragma unroll
+        for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], 0.0f, lr, b1, b2, omb1, omb2, eps);
+    }
+    return;
+#endif
+    for (int s0 = 0; s0 < ns; s0 += EL_REPLAY_CHUNK) {
+        const int c = ns - s0 < EL_REPLAY_CHUNK ? ns - s0 : EL_REPLAY_CHUNK;
+        // the chunk's step sizes first, all loads in flight together (a load per step in front of its arithmetic serialises the
+        // ring's latency with it: measured +25 % on the whole kernel)
+        float lrv[EL_REPLAY_CHUNK];
+#pragma unroll
+        for (int k = 0; k < EL_REPLAY_CHUNK; ++k) lrv[k] = lrs(s0 + (k < c ? k : 0));
+#ifdef EL_NO_PACKED_REPLAY                                         // (A/B builds: scripts/exp/build_variants.sh)
+        bool fast = false, dead = true;
+        if (false) {
+#else
+        bool fast = VW >= 2, dead = true;
+        if (VW >= 2) {
+#endif
+            bool ok = true;
+#pragma unroll
+            for (int x = 0; x < VW; ++x) {
+                ok = ok & el_replay_ok(mm[x], vv[x]);
+                dead = dead & (mm[x] == 0.f) & (vv[x] == 0.f);
+            }
+            ok = ok | dead;
+#pragma unroll
+            for (int k = 0; k < EL_REPLAY_CHUNK; ++k) ok = ok & el_replay_lr_ok(lrv[k]);
+            fast = __ballot(!ok) == 0ull;
+        }
+        if (fast) {
+            el_f2 T[VW >= 2 ? VW / 2 : 1], M[VW >= 2 ? VW / 2 : 1], V[VW >= 2 ? VW / 2 : 1];
+#pragma unroll
+            for (int x = 0; x + 1 < VW; x += 2) {
+                T[x / 2].x = th[x], T[x / 2].y = th[x + 1];
+                M[x / 2].x = mm[x], M[x / 2].y = mm[x + 1];
+                V[x / 2].x = vv[x], V[x / 2].y = vv[x + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < EL_REPLAY_CHUNK; ++k) {
+                if (k < c) {
+#pragma unroll
+                    for (int x = 0; x + 1 < VW; x += 2) el_adam_replay2(T[x / 2], M[x / 2], V[x / 2], lrv[k]);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x + 1 < VW; x += 2) {
+                th[x] = dead ? th[x] : T[x / 2].x, th[x + 1] = dead ? th[x + 1] : T[x / 2].y;
+                mm[x] = dead ? 0.f : M[x / 2].x, mm[x + 1] = dead ? 0.f : M[x / 2].y;
+                vv[x] = dead ? 0.f : V[x / 2].x, vv[x + 1] = dead ? 0.f : V[x / 2].y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL_REPLAY_CHUNK; ++k) {
+                if (k < c) {
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], 0.0f, lrv[k], b1, b2, omb1, omb2, eps);
+                }
+            }
+        }
+    }
+}
+
 // ---- per-user record of the samplers (el_bpr_sampler_meta_build) -------------------------------------------------------
 struct __attribute__((aligned(64))) SamplerRec {
     int64_t r0;      // row start in the positives CSR

@@ -492,21 +492,25 @@ __device__ __forceinline__ void nmf_rows_store(const float (&val)[2][Q][VW], flo
 // nsteps gradient-free steps on the registers (theta too when WITH_TH): exactly el_adam_elem with g = 0
 template <int VW, int Q, bool WITH_TH>
 __device__ __forceinline__ void nmf_rows_replay(NmfRowRegs<VW, Q>& r, const float* __restrict__ lr_from, int nsteps) {
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    const float b1 = 0.9f, b2 = 0.999f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    if (WITH_TH) {
+        // (el_common.h: the step on packed fp32 instructions where the values allow it, el_adam_elem otherwise -- the same bits;
+        // the element groups are independent, so each runs its own loop over the steps)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) el_adam_replay<VW>(r.a[k][q], r.m[k][q], r.v[k][q], nsteps, [&](int s) { return lr_from[s]; });
+        return;
+    }
     for (int s = 0; s < nsteps; ++s) {
-        const float lr = WITH_TH ? lr_from[s] : 0.f;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int q = 0; q < Q; ++q)
 #pragma unroll
                 for (int x = 0; x < VW; ++x) {
-                    if (WITH_TH) {
-                        el_adam_elem(r.a[k][q][x], r.m[k][q][x], r.v[k][q][x], 0.0f, lr, b1, b2, omb1, omb2, eps);
-                    } else {
-                        r.m[k][q][x] = r.m[k][q][x] * b1 + 0.0f * omb1;           // the first two lines of el_adam_elem
-                        r.v[k][q][x] = r.v[k][q][x] * b2 + (0.0f * 0.0f) * omb2;
-                    }
+                    r.m[k][q][x] = r.m[k][q][x] * b1 + 0.0f * omb1;           // the first two lines of el_adam_elem
+                    r.v[k][q][x] = r.v[k][q][x] * b2 + (0.0f * 0.0f) * omb2;
                 }
     }
 }

@@ -59,6 +59,20 @@ static bool ns_shape_ok(const el_nmf_state* st) {
     return H3 <= H3P;
 }
 
+static int ns_cap_for_k(int k);
+// dynamic LDS of k_nmf_score for a list capacity `cap` (the weights' staging area + one candidate list per wave, as ns_launch asks
+// for it); the one architecture this library is built for (gfx950) gives a workgroup 160 KB
+static const size_t NS_LDS_LIMIT = 160u * 1024u;
+static size_t ns_lds_bytes(const el_nmf_state* st, int cap) {
+    const int H1P = (int)ns_up(st->units[0], 16);
+    int H2P = (int)ns_up(st->units[1], 32);
+    if (H2P == 96) H2P = 128;
+    if (H2P > 128 && H2P < 256) H2P = 256;
+    const int H3P = H2P >= 256 ? 128 : (H2P >= 128 ? 64 : 32);
+    const int FP = st->use_mf ? (int)ns_up(st->F, 8) : 0;
+    return (size_t)(2 * H2P * 16 + 2 * H1P + H2P + 2 * H3P + 2 * (FP > 0 ? FP : 8)) * 4 + (size_t)NS_WAVES * cap * 8 + (size_t)NS_WAVES * 16;
+}
+
 static int ns_pick_split(el_ctx* ctx, int64_t n_users, int64_t n_items, int k, bool cand) {
     if (cand) return 1;
     int64_t want = ((int64_t)ctx->cus * 3 + n_users - 1) / n_users;      // ~3 workgroups per CU in all
@@ -529,7 +543,8 @@ static int ns_cap_for_k(int k) {
 }
 
 extern "C" int el_nmf_score_supported(const el_nmf_state* st, int32_t k) {
-    return (st != nullptr && ns_shape_ok(st) && k >= 1 && k <= 448) ? 1 : 0;
+    if (st == nullptr || !ns_shape_ok(st) || k < 1 || k > 448) return 0;
+    return ns_lds_bytes(st, ns_cap_for_k(k)) <= NS_LDS_LIMIT ? 1 : 0;       // (callers fall back to the pair route otherwise)
 }
 
 extern "C" size_t el_nmf_score_ws_bytes(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int32_t k, int with_cand) {

@@ -1271,14 +1271,17 @@ class NmfDeviceState:
         return out
 
     def train_step(self, u, i, label, lr):
-        self.step += 1
+        n = u.numel()
+        if n == 0:
+            return                                                   # (the library takes no optimiser step on an empty batch either)
         self._margin = _PW_MARGIN
         self._next_mask()
-        n = u.numel()
+        t = self.step + 1                                            # the counter moves only when the library has taken the step
         check(self.ctx.lib.el_nmf_train_step(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32),
-                                             _ptr(i, torch.int32), _ptr(label, torch.float32), int(n), int(self.step),
-                                             float(adam_lr_t(lr, self.step)), _ptr(self.loss, torch.float64)),
+                                             _ptr(i, torch.int32), _ptr(label, torch.float32), int(n), int(t),
+                                             float(adam_lr_t(lr, t)), _ptr(self.loss, torch.float64)),
               "el_nmf_train_step")
+        self.step = t
 
     def grads(self, u, i, label, n_global=None):
         """Forward + loss + backward only (multi-GPU: the BCE mean runs over n_global samples); gradients stay in the
@@ -1295,10 +1298,11 @@ class NmfDeviceState:
                                         int(n if n_global is None else n_global), _ptr(self.loss, torch.float64)), "el_nmf_grads")
 
     def apply(self, lr):
-        self.step += 1
         self._margin = _PW_MARGIN
-        check(self.ctx.lib.el_nmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(self.step),
-                                        float(adam_lr_t(lr, self.step))), "el_nmf_apply")
+        t = self.step + 1
+        check(self.ctx.lib.el_nmf_apply(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(t),
+                                        float(adam_lr_t(lr, t))), "el_nmf_apply")
+        self.step = t
 
     def replicated_grads(self, shard="user"):
         """Gradient tensors of the variables every rank holds a full copy of: Dense layers, head, and the embedding tables

@@ -225,6 +225,16 @@ int el_bprmf_sync_users(el_ctx* ctx, void* stream, const el_bprmf_state* st, int
  * after `step` optimiser steps.  No-op when Gi_last is NULL.                                                                */
 int el_bprmf_sync_items(el_ctx* ctx, void* stream, const el_bprmf_state* st, int32_t step);
 
+/* Self-test of the arithmetic the replay kernels of the deferred decay run (test infrastructure inside the library: the functions
+ * under test are device code).  A postponed gradient-free Adam step costs one IEEE square root and one IEEE division per element;
+ * the replay kernels take it on packed fp32 instructions with hand-expanded sequences that must return the compiler's bits:
+ *   out3[0]  floats in [2^-96, 2^96] -- ALL 1 610 612 736 of them -- whose packed square root differs from sqrtf()
+ *   out3[1]  of ~n_pairs pseudo-random (numerator, denominator) pairs over the guard range, half with neighbouring mantissas,
+ *            those whose packed quotient differs from `/`
+ *   out3[2]  of ~n_pairs random (theta, m, v, lr_t) inside the guard, those where 8 packed steps differ from the reference step
+ * out3: device uint64[3].  All three must be 0 (tests/test_gpu_bpr.py::test_packed_replay_arithmetic_is_exact).             */
+int el_selftest_replay_math(el_ctx* ctx, void* stream, int64_t n_pairs, uint64_t* out3);
+
 /* ---- BPR-MF across GPUs: item-sharded tables (new design; the reference is single-device) -- */
 
 /* Step 1 on rank r: st holds the replicated user table (Gu [U,F]) and the LOCAL item shard (Gi [I_r,F],

@@ -725,3 +725,15 @@ def test_fused_item_side_with_segments_cut_by_chunk_boundaries(ctx, chunk, defer
         assert (np.abs(x - y) > 2e-6).mean() < 2e-3 and np.abs(x - y).max() < 12 * lr, (name, np.abs(x - y).max())
     la, lb = a.pop_loss(), b.pop_loss()
     assert abs(la - lb) <= 1e-5 * abs(la)
+
+
+def test_packed_replay_arithmetic_is_exact(ctx):
+    """The replay kernels of the deferred decay take the gradient-free Adam step on packed fp32 instructions (el_common.h:
+    el_adam_replay2): a square root by v_rsq + fma refinements and a division by v_rcp + fma refinements instead of the compiler's
+    IEEE expansions -- half the issue slots, and the SAME bits: the square root is compared with sqrtf() for EVERY float of the range
+    the guard admits (1.6e9 inputs, exhaustive), the division on 2^31 pairs (random and near-tie mantissas over the guard's
+    exponent range) with `/`, the whole step on 2^31 random states with el_adam_elem."""
+    import ctypes as C
+    out = torch.zeros(3, dtype=torch.int64, device=ctx.device)
+    ops.check(ctx.lib.el_selftest_replay_math(ctx.handle, ctx.stream(), 1 << 31, C.c_void_p(out.data_ptr())), "el_selftest_replay_math")
+    assert out.tolist() == [0, 0, 0], out.tolist()
