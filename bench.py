@@ -774,14 +774,16 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
             "deferred_decay": f"user rows without triplets in a batch are not moved by that step: their gradient-free Adam updates are replayed "
                               f"bit for bit when next needed; the {K} timed steps end with the replay of every pending row (k_bpr_flush_users)",
             "user_rows_per_step": rows_touched,
-            "valu": {"what": "k_bpr_catchup / k_bpr_flush_users replay the postponed updates in registers: one correctly rounded fp32 sqrt and "
-                             "division per element and step -- U F element-steps per optimiser step in the steady state, whatever B is",
+            "valu": {"what": "k_bpr_user_seg (a row's missed steps when its segment starts) and k_bpr_flush_users replay the postponed updates in "
+                             "registers: one correctly rounded fp32 sqrt and division per element and step, on packed fp32 instructions -- U F "
+                             "element-steps per optimiser step in the steady state, whatever B is; the user-segment kernel's HBM fraction "
+                             "above is that of a kernel that also carries this arithmetic",
                      "element_steps_per_step": float(rows_u) * F + (float(rows_i) * F if item_deferred else 0.0),
                      "steady_state": "every row was given a gradient once before the timed region (cover batches): none sits at the m = v = 0 "
                                      "fixed point the replay kernels skip",
                      "catchup_ms_per_step": rep_train.get("k_bpr_catchup", (0, 0.0))[1] / K,
                      "flush_ms_per_step": rep_train.get("k_bpr_flush_users", (0, 0.0))[1] / K,
-                     "note": "the replay loop sustains ~1.2e12 element-steps/s (DESIGN 3.2)"},
+                     "note": "a bare replay loop sustains 1.1e12 (compiler sqrt / div) and 1.7e12 (packed) element-steps/s (scripts/exp/replay_math.hip)"},
             "step_GBs_note": "step_GBs prices the step at SURVEY 8d's bytes (every row of both tables moved each step) -- work-equivalent, "
                              "it may exceed the HBM peak; step_GBs_moved = the bytes this form has to move (batch rows + 1/K of the final replay)",
             "step_GBs_moved": moved / (dt_train / K) / 1e9})

@@ -88,6 +88,7 @@ struct SegParams {
     // decay points them at the pre-update rows the user-side kernel left in Gu_old, by segment head position)
     const float* ubase;
     const int32_t* uidx;
+    int pair4;           // user segments with a row across 64 lanes x 2 elements: dot products summed in the 32 x 4 order
 };
 
 struct FusedParams {
@@ -100,9 +101,10 @@ struct FusedParams {
     int32_t* last;            // [U]
     float* old_rows;          // [>= B, F]
     int32_t* hpos;            // [B]
-    const float* hist;        // lr_t of step s at hist[s & hist_mask]
+    float* hist;              // lr_t of step s at hist[s & hist_mask]
     int hist_mask;
     int32_t t;                // this optimiser step
+    int replay;               // 1: k_bpr_user_seg<DEFER> brings a row to step t - 1 itself when its segment starts (no k_bpr_catchup launch)
 };
 
 // ---- user segments -----------------------------------------------------------------------
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = gid / lpt;
     const int sub = (int)(threadIdx.x & (lpt - 1));
+    if (DEFER && f.replay && gid == 0) f.hist[f.t & f.hist_mask] = f.lr_t;     // lr_t of THIS step into the ring (replays here read steps < t)
     int64_t p0 = grp * p.chunk;
     int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
     // Compact user-gradient rows (el_bprmf_state.uslot): a segment belongs, whole, to the group whose chunk holds its HEAD --
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                 acc[q][x] = 0.f;
                             }
                         if (DEFER) {                             // the row's Adam slots: needed when the segment ends
+                            const int lastv = f.replay ? f.last[key] : 0;
 #pragma unroll
                             for (int q = 0; q < CPL; ++q) {
                                 const int e = (sub + q * lpt) * VW;
@@ -255,6 +259,22 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                 if (e < F) {
                                     ldv<VW>(p.st.mGu + key * F + e, mrow[DEFER ? q : 0]);
                                     ldv<VW>(p.st.vGu + key * F + e, vrow[DEFER ? q : 0]);
+                                }
+                            }
+                            // the row's postponed gradient-free steps (last, t - 1], in registers, before anything uses it (what
+                            // k_bpr_catchup did in a launch of its own, reading and writing the three rows once more)
+                            const int nsr = f.replay ? (f.t - 1) - lastv : 0;
+                            if (nsr > 0) {
+                                bool nz = false;
+#pragma unroll
+                                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                                    for (int x = 0; x < VW; ++x) nz = nz || mrow[DEFER ? q : 0][x] != 0.f || vrow[DEFER ? q : 0][x] != 0.f;
+                                if (el_group_any(nz, lpt)) {     // (m = v = 0: the fixed point of the step, whatever the gap)
+#pragma unroll
+                                    for (int q = 0; q < CPL; ++q)
+                                        el_adam_replay<VW>(gu[q], mrow[DEFER ? q : 0], vrow[DEFER ? q : 0], nsr,
+                                                           [&](int s2) { return f.hist[(lastv + 1 + s2) & f.hist_mask]; });
                                 }
                             }
                         }
@@ -275,8 +295,25 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                 dpj += gu[q][x] * rgj[t][q][x];
                                 nsq += gu[q][x] * gu[q][x] + rgi[t][q][x] * rgi[t][q][x] + rgj[t][q][x] * rgj[t][q][x];
                             }
-                        dpi = el_group_sum(dpi, lpt);
-                        dpj = el_group_sum(dpj, lpt);
+                        if (VW == 2 && CPL == 1 && p.pair4) {
+                            // a row across 64 lanes x 2 elements, summed in the order of the 32 lanes x 4 elements form (the
+                            // every-row kernel's): lane pair (2l, 2l + 1) = that form's lane l -- ((0 + p0) + p1) in the even
+                            // lane, then (.. + p2) + p3 in the odd one, then the same butterfly over the 32 pair sums
+                            const bool odd = (sub & 1) != 0;
+                            const float ei = __shfl_xor(dpi, 1, 64), ej = __shfl_xor(dpj, 1, 64);
+                            float ti = (ei + gu[0][0] * rgi[t][0][0]) + gu[0][VW - 1] * rgi[t][0][VW - 1];
+                            float tj = (ej + gu[0][0] * rgj[t][0][0]) + gu[0][VW - 1] * rgj[t][0][VW - 1];
+                            const float oi = __shfl_xor(ti, 1, 64), oj = __shfl_xor(tj, 1, 64);
+                            dpi = odd ? ti : oi;
+                            dpj = odd ? tj : oj;
+                            for (int o = 32; o >= 2; o >>= 1) {
+                                dpi += __shfl_xor(dpi, o, 64);
+                                dpj += __shfl_xor(dpj, o, 64);
+                            }
+                        } else {
+                            dpi = el_group_sum(dpi, lpt);
+                            dpj = el_group_sum(dpj, lpt);
+                        }
                         const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
                         const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
                         const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
@@ -1128,6 +1165,11 @@ static int launch_user_catchup(const SegParams& pu, hipStream_t s, int64_t B, co
     f->lr_t = lr_t, f->b1 = 0.9f, f->b2 = 0.999f, f->eps = 1e-7f;
     f->last = pu.st.Gu_last, f->old_rows = pu.st.Gu_old, f->hpos = w.hpos;
     f->hist = pu.st.lr_hist, f->hist_mask = pu.st.lr_hist_cap - 1, f->t = pu.step;
+    // the batch's rows to step t - 1: inside the segment kernel (default; F % 4 == 0 is given here), or as a launch of its own
+    // (EL_BPR_USER_CATCHUP=separate: one wave per row, the rows read and written once more -- 0.77 ms of the 3.3 ms step at 10M x 1M)
+    static const bool separate = [] { const char* e = getenv("EL_BPR_USER_CATCHUP"); return e && strcmp(e, "separate") == 0; }();
+    f->replay = separate ? 0 : 1;
+    if (!separate) return 0;
     const int F = pu.st.F;                                      // elements per lane so that the 64 lanes of a wave span a row
     const unsigned gc = (unsigned)((B + 3) / 4);
     if (F >= 256) EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<4>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
@@ -1161,6 +1203,11 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
     FusedParams fz;
     memset(&fz, 0, sizeof(fz));
+    // (EL_BPR_USER_WAVE_ROWS=1: measured 1.35 against 1.24 ms for the two-groups-per-wave form at 10M x 1M x 128 -- the replay's lane
+    //  utilisation was not the bound, the loads in flight per wave are; kept as an experiment switch, off)
+    static const bool vw2 = [] { const char* e = getenv("EL_BPR_USER_WAVE_ROWS"); return e && atoi(e) == 1; }();
+    static const bool sep = [] { const char* e = getenv("EL_BPR_USER_CATCHUP"); return e && strcmp(e, "separate") == 0; }();
+    const bool wave_rows = defer && VW == 4 && vw2 && !sep && base.st.F > 64 && base.st.F <= 128;
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
     if (ifuse) {
@@ -1171,7 +1218,16 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     do {                                                                                                  \
         if (defer) {                                                                                      \
             if (int rc = launch_user_catchup(pu, s, B, w, lr_t, &fz)) return rc;                          \
-            EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+            if (wave_rows) {                                                                              \
+                /* a row across the whole wave (64 lanes x 8 B at F = 128): the replay of a segment head then runs on all lanes -- with \
+                   two 32-lane groups per wave each group replays its own gap while the other idles */        \
+                SegParams pw = pu;                                                                        \
+                pw.lpt = 64, pw.pair4 = 1;                                                                \
+                const unsigned gridW = (unsigned)((gu * 64 + 255) / 256);                                 \
+                EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 6 * 4, s, pw, fz);  \
+            } else {                                                                                      \
+                EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+            }                                                                                             \
         } else if (fused) {                                                                               \
             if (int rc = launch_user_adam(pu, s, B, w, lpt, cpl, lr_t)) return rc;                        \
         } else {                                                                                          \
