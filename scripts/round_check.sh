@@ -8,11 +8,11 @@ cd $R
 mkdir -p gpurun_out/$TAG
 (timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -x 2>&1 | tail -25) > gpurun_out/$TAG/pytest.log
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > gpurun_out/$TAG/smoke.log
-(timeout 600 python bench.py 2> gpurun_out/$TAG/bench.err | tail -1) > gpurun_out/$TAG/bench_line.json
+(timeout 900 python bench.py 2> gpurun_out/$TAG/bench.err | tail -1) > gpurun_out/$TAG/bench_line.json
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/$TAG/bench_prof.log 2>&1
 python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline ($TAG)" > gpurun_out/$TAG/bench_kernel_stats.md 2>&1
 rm -rf gpurun_out/$TAG/prof
-# the headline leg alone: the c4 leg launches the same kernels on 10x the rows, which would blur the per-kernel averages above
+# the headline leg alone (10M x 1M x 128): the other legs launch the same kernels on other shapes, which would blur the per-kernel averages above
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics > gpurun_out/$TAG/bench_prof_bpr.log 2>&1
 python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics ($TAG; headline leg only: BASELINE configs[1] training step + top-k block + metrics)" > gpurun_out/$TAG/bench_kernel_stats_bpr.md 2>&1
 rm -rf gpurun_out/$TAG/prof
