@@ -14,7 +14,7 @@ python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3
 rm -rf gpurun_out/$TAG/prof
 # the headline leg alone (10M x 1M x 128): the other legs launch the same kernels on other shapes, which would blur the per-kernel averages above
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics > gpurun_out/$TAG/bench_prof_bpr.log 2>&1
-python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics ($TAG; headline leg only: BASELINE configs[1] training step + top-k block + metrics)" > gpurun_out/$TAG/bench_kernel_stats_bpr.md 2>&1
+python scripts/rocpd_summary.py gpurun_out/$TAG/prof/bench_results.db "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs bpr,metrics ($TAG; headline leg only: 10M x 1M x 128 training step + top-k block + metrics)" > gpurun_out/$TAG/bench_kernel_stats_bpr.md 2>&1
 rm -rf gpurun_out/$TAG/prof
 if [ "$2" = "traffic" ]; then bash scripts/collect_traffic.sh > gpurun_out/$TAG/traffic.log 2>&1; fi
 tail -4 gpurun_out/$TAG/pytest.log; tail -1 gpurun_out/$TAG/smoke.log; cut -c1-1800 gpurun_out/$TAG/bench_line.json; tail -5 gpurun_out/$TAG/bench.err
