@@ -650,7 +650,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     dt_train, rep_train = timed(ctx, world, train_step, W, K, finish_train, fn_breakdown=breakdown_step)
     loss = pop_loss()
     prepare_topk()
-    dt_topk, rep_topk = timed(ctx, world, topk_step, W, K)
+    Kt = int(getattr(args, "topk_steps", 0) or K)            # (a leg whose top-k block takes 0.3 s times fewer of them than training steps)
+    dt_topk, rep_topk = timed(ctx, world, topk_step, min(W, Kt), Kt)
 
     # ---- the fp32-only MFMA kernel beside the screened one: its arithmetic IS the reference's fp32 matmul form, the screened
     #      route returns the same bits after its exact re-score (tests/test_gpu_topk.py)
@@ -700,7 +701,7 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         fragile = ops.fragile_users(ctx, st.Gu, st.Gi, st.Bi, 0, Ub, k, excl=pos)
 
     pairs_per_s = world * B * K / dt_train            # B triplets per rank and step
-    users_per_s = (world if (topk_by_user or user_sharded) else 1) * Ub * K / dt_topk
+    users_per_s = (world if (topk_by_user or user_sharded) else 1) * Ub * Kt / dt_topk
     traffic, traffic_note = load_traffic(U, I, F, B, Ub, world if not args.force_sharded else 0)
 
     # train roofline: algorithmic bytes of the dominant kernel (DESIGN.md "algorithmic bytes")
@@ -807,8 +808,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                  "dtype": "bf16 MFMA screen + f32 exact re-score" if screened else "f32",
                  **({"measured_ceiling_random_operands": MFMA_BF16_RANDOM_TFLOPS, "frac_of_measured_ceiling": ach_t / MFMA_BF16_RANDOM_TFLOPS}
                     if screened else {}),
-                 "effective_TFLOPs": flops / (dt_topk / K) / 1e12,
-                 "kernels_ms_per_step": {n: v[1] / K for n, v in rep_topk.items()}}
+                 "effective_TFLOPs": flops / (dt_topk / Kt) / 1e12,
+                 "kernels_ms_per_step": {n: v[1] / Kt for n, v in rep_topk.items()}}
     if not sharded:
         par = "single"
     elif exchange == "user":
@@ -827,7 +828,7 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         "value": pairs_per_s, "unit": "pairs/s", "ms_per_step": dt_train / K * 1e3, "repeats_ms_per_step": rep_train.repeats_ms,
         "scaling": "weak",
         "parallelism": par, "loss_per_pair_last": loss / (B * world * max(rep_train.calls, 1)), "roofline": roof_train,
-        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / K * 1e3, "repeats_ms_per_step": rep_topk.repeats_ms,
+        "topk": {"value": users_per_s, "unit": "users/s", "ms_per_step": dt_topk / Kt * 1e3, "repeats_ms_per_step": rep_topk.repeats_ms, "steps": Kt,
                  "scaling": "weak" if (topk_by_user or user_sharded or not sharded) else "strong",
                  "sharding": topk_sharding, "roofline": roof_topk},
         "interactions": int(pos.nnz), "topk_block": Ub,
@@ -1176,16 +1177,17 @@ def main():
             torch.cuda.empty_cache()
         if "c5" in legs:
             # BASELINE configs[4] (BPRMF d=256, 50 M users x 5 M items on 8 GPUs) at its PER-GPU shape under user sharding: the rank's
-            # 6.25 M user rows + a replica of the 5 M-item table (~ 50 GB of tables and optimiser state); fewer steps per repeat --
-            # a top-k block against 5 M items takes ~0.35 s
+            # 6.25 M user rows + a replica of the 5 M-item table (~ 50 GB of tables and optimiser state); fewer top-k blocks per repeat --
+            # a block against 5 M items takes ~0.3 s (the training steps keep K: their timed region ends with the replay of every pending
+            # row, which K amortises)
             a5 = argparse.Namespace(**vars(args))
             a5.users, a5.items, a5.factors = (int(x) for x in args.c5_shape.split(","))
-            a5.steps, a5.warmup = max(2, min(args.steps, 5)), min(args.warmup, 2)
+            a5.topk_steps = max(2, min(args.steps, 5))
             ip5, ix5 = zipf_csr_device(a5.users, a5.items, dev, mean_log=3.0, sigma_log=1.0, dmin=5, dmax=2000, seed=5432)
             d5 = {"indptr": ip5, "indices": ix5, "pos": ops.DeviceCSR.from_tensors(ip5, ix5, a5.items)}
             c5 = bpr_leg(a5, ctx, world, rank, d5, "user", "user")
             c5["workload"] = (f"BPRMF d={a5.factors}, synthetic {a5.users} users x {a5.items} items = the per-GPU shape of BASELINE configs[4] "
-                              f"(50M x 5M x 256 over 8 GPUs) under user sharding; {a5.steps} steps per repeat")
+                              f"(50M x 5M x 256 over 8 GPUs) under user sharding; {a5.steps} training steps / {a5.topk_steps} top-k blocks per repeat")
             del d5, ip5, ix5
             torch.cuda.empty_cache()
         if "vae" in legs:

@@ -93,6 +93,7 @@ class PwmfState(C.Structure):
 
 
 EL_TOPK_ITEMS_UNCHANGED = 0x100
+EL_NMF_SCREEN = 0x200
 EL_PW_MSE, EL_PW_MSE_SIGMOID, EL_PW_LOGISTIC = 0, 1, 2
 EL_PW_ADAM, EL_PW_ADAGRAD = 0, 1
 EL_PW_BOTH, EL_PW_ITEMS, EL_PW_USERS = 0, 1, 2
@@ -184,6 +185,7 @@ PROTOTYPES = {
                                     C.c_int32, C.c_float, _f64p]),
     "el_nmf_sync_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState)]),
     "el_nmf_score_supported": (C.c_int, [C.POINTER(NmfState), C.c_int32]),
+    "el_nmf_screen_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "el_nmf_score_ws_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(NmfState), C.c_int64, C.c_int64, C.c_int32, C.c_int]),
     "el_nmf_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                     _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, C.c_size_t]),

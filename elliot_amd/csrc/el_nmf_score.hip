@@ -45,6 +45,9 @@ static inline int64_t ns_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; 
 // ---- workspace ----------------------------------------------------------------------------------------------------------
 struct NsLayout {
     size_t ctl, W1a, W1b, b1P, W2P, W3P, b2D, b3D, hwD, hwmf, PI, PU, pidx, pval, total;
+    // screened route (el_nmf_score_topk with EL_NMF_SCREEN): half-precision stage images of W2 / W3, accumulator-order vectors, half-precision image of
+    // PI + the residual norm of every row, the bound's constants, one candidate region per (user, wave slice)
+    size_t W2B, W3B, b2E, b3E, hwE, PIB, Rn, cst, upb, thr, tidx, regi, regc, sflag;
     int H1P, H2P, H3P, FP, NC1, NC2, S;
 };
 
@@ -70,7 +73,7 @@ static size_t ns_lds_bytes(const el_nmf_state* st, int cap) {
     if (H2P > 128 && H2P < 256) H2P = 256;
     const int H3P = H2P >= 256 ? 128 : (H2P >= 128 ? 64 : 32);
     const int FP = st->use_mf ? (int)ns_up(st->F, 8) : 0;
-    return (size_t)(2 * H2P * 16 + 2 * H1P + H2P + 2 * H3P + 2 * (FP > 0 ? FP : 8)) * 4 + (size_t)NS_WAVES * cap * 8 + (size_t)NS_WAVES * 16;
+    return (size_t)(2 * H2P * 16 + 2 * H1P + H2P + 2 * H3P + 2 * (FP > 0 ? FP : 8)) * 4 + (size_t)NS_WAVES * cap * 8 + (size_t)NS_WAVES * 16 + 16;
 }
 
 static int ns_pick_split(el_ctx* ctx, int64_t n_users, int64_t n_items, int k, bool cand) {
@@ -83,7 +86,7 @@ static int ns_pick_split(el_ctx* ctx, int64_t n_users, int64_t n_items, int k, b
     return (int)(want < 1 ? 1 : want);
 }
 
-static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int k, bool cand) {
+static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int k, bool cand, bool screen = false) {
     NsLayout L;
     memset(&L, 0, sizeof(L));
     L.H1P = (int)ns_up(st->units[0], 16);
@@ -111,6 +114,23 @@ static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, 
     L.PU = take((size_t)(n_users > 0 ? n_users : 1) * L.H1P * 4);
     L.pidx = take((size_t)L.S * (n_users > 0 ? n_users : 1) * k * 4);
     L.pval = take((size_t)L.S * (n_users > 0 ? n_users : 1) * k * 4);
+    if (screen) {
+        L.W2B = take((size_t)ns_up(L.H1P, 32) * L.H2P * 2);
+        L.W3B = take((size_t)L.H2P * L.H3P * 2);
+        L.b2E = take((size_t)L.H2P * 4);
+        L.b3E = take((size_t)L.H3P * 4);
+        L.hwE = take((size_t)L.H3P * 4);
+        L.PIB = take((size_t)(I_local > 0 ? I_local : 1) * L.H1P * 2);
+        L.Rn = take((size_t)(I_local > 0 ? I_local : 1) * 4);
+        L.cst = take(64);
+        const size_t nu = (size_t)(n_users > 0 ? n_users : 1), ni = (size_t)(I_local > 0 ? I_local : 1);
+        L.upb = take(nu * ni * 4);                       // upper bound logit' + E of every pair
+        L.thr = take(nu * (size_t)k * 4);                // merged top-k of the lower bounds (its last column = the user's threshold)
+        L.tidx = take(nu * (size_t)k * 4);
+        L.regi = take(nu * ni * 4);                      // candidates of slice s of user u: compacted at the start of the slice's own range
+        L.regc = take((size_t)L.S * nu * 4);
+        L.sflag = take(64);
+    }
     L.total = o;
     return L;
 }
@@ -237,6 +257,10 @@ struct NsParams {
     int32_t* part_idx;
     float* part_val;
     int S, cap;
+    // region mode (second stage of the screened route): wave slice s of user u scores the reg_cnt[u * S + s] candidates stored at
+    // the start of the slice's own position range, reg_idx[u * I_local + pos_lo(s) ..] (already free of masked items)
+    const int32_t* reg_idx;
+    const int32_t* reg_cnt;
 };
 
 // 16 bytes at (wave-uniform base) + (32-bit per-thread byte offset): the `global_load_dwordx4 v, v_off, s[base]` form -- one offset
@@ -278,10 +302,24 @@ __global__ __launch_bounds__(NS_THREADS) void k_nmf_score(NsParams p) {
         c1 = p.t.cand_indptr[user + 1];
         ncand = c1 - c0;
     }
-    const bool use_excl = (p.t.excl_indptr != nullptr) && (p.t.cand_indptr == nullptr);
+    const bool region = p.reg_cnt != nullptr;
+    const bool use_excl = (p.t.excl_indptr != nullptr) && (p.t.cand_indptr == nullptr) && !region;
     const int s = blockIdx.y * NS_WAVES + w;             // this wave's slice of the positions
-    const int64_t pos_lo = ncand * s / p.S, pos_hi = ncand * (s + 1) / p.S;
-    const int64_t max_len = (ncand + p.S - 1) / p.S;
+    int64_t pos_lo = ncand * s / p.S, pos_hi = ncand * (s + 1) / p.S;
+    int64_t max_len = (ncand + p.S - 1) / p.S;
+    const int32_t* rlist = nullptr;
+    if (region) {
+        const int64_t rg = urel * p.S + s;
+        rlist = p.reg_idx + urel * p.t.I_local + pos_lo;
+        pos_lo = 0, pos_hi = p.reg_cnt[rg];
+        // the workgroup's waves walk the same number of tiles (barriers): the longest of their eight lists
+        int* tmax = reinterpret_cast<int*>(keys_all + (size_t)NS_WAVES * p.cap) + NS_WAVES * 4;
+        if (tid == 0) *tmax = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(tmax, (int)pos_hi);
+        __syncthreads();
+        max_len = *tmax;
+    }
     const int T = (int)((max_len + 31) / 32);            // every wave of the grid row walks the same number of tiles (barriers)
 
     // per-user vectors -> LDS
@@ -320,7 +358,10 @@ __global__ __launch_bounds__(NS_THREADS) void k_nmf_score(NsParams p) {
         int32_t gitem = -1;
         int64_t il = 0;
         if (valid) {
-            if (p.t.cand_indptr) {
+            if (region) {
+                gitem = rlist[pos];
+                il = (int64_t)gitem - p.t.item_offset;
+            } else if (p.t.cand_indptr) {
                 gitem = p.t.cand_indices[c0 + pos];
                 il = (int64_t)gitem - p.t.item_offset;
                 valid = il >= 0 && il < p.t.I_local;
@@ -526,13 +567,502 @@ __global__ __launch_bounds__(NS_THREADS) void k_nmf_score(NsParams p) {
         } else {
             // padding = the lowest masked items: of this wave's own item range (disjoint ranges -> no duplicates after the merge); with
             // a candidate list the positions are not item ranges: slice 0 alone pads, the other slices leave empty entries
-            oi = p.t.cand_indptr ? (s == 0 ? el_fill_masked(p.t, e0, e1, c0, c1, t - nv) : -1)
-                                 : el_fill_masked_range(p.t, p.t.item_offset + pos_lo, p.t.item_offset + pos_hi, e0, e1, c0, c1, t - nv);
+            oi = region ? -1
+                 : p.t.cand_indptr ? (s == 0 ? el_fill_masked(p.t, e0, e1, c0, c1, t - nv) : -1)
+                                   : el_fill_masked_range(p.t, p.t.item_offset + pos_lo, p.t.item_offset + pos_hi, e0, e1, c0, c1, t - nv);
             ov = -INFINITY;
         }
         p.part_idx[orow + t] = oi;
         p.part_val[orow + t] = ov;
     }
+}
+
+// =========================================================================================================================
+// Screened route (EL_NMF_SCREEN): layers 2-3 on the half-precision matrix instruction with a per-pair error bound, the exact fp32 kernel
+// above only on the pairs that can still belong to the answer.
+//
+// The fp32 kernel sits at 0.82 of the fp32 MFMA peak and still needs 0.33 s per 128 users against 1 M items: 36 F^2 flop per pair
+// are what they are.  v_mfma_f32_32x32x16_f16 is 16x faster, and its result need not be right, only boundedly wrong (half precision
+// keeps 11 bits where bf16 keeps 8, and the bound decides everything: the survivors are a Gaussian tail in E / sigma(logit)):
+//   x   = relu(PU_u + b1 + PI_i)                      the exact kernel's layer-1 activation (fp32)
+//   x'' = relu((PU_u + b1) + h(PI_i)), x' = h(x'')    h = round to half;  ||x' - x|| <= dh1 = R_i + ||x'' - x'|| + 4 u32 ||x'||,
+//                                                     R_i = ||PI_i - h(PI_i)|| per item (k_nmf_pib), ||x'' - x'|| MEASURED per pair
+//   z2' - z2 = W2h^T (x' - x) + (W2h - W2)^T x + (fp32 accumulation of both kernels)        W2h = h(W2)
+//   ||z2' - z2|| <= s2 dh1 + (d2 + g2) (||x'|| + dh1),    s2 = ||W2h||_2, d2 = ||W2h - W2||_2 (SPECTRAL norms: a ReLU network's layers
+//   are Lipschitz in them; Frobenius or column-sum bounds accumulate sqrt(width) per layer and exceed the spread of the logits),
+//   g2 = 3.4 K 2^-24 ||W2h||_F (k_nmf_specnorm)
+//   y'' = relu(z2' + b2), y' = h(y''):   dh2 = ||y' - h2|| <= dz2 + ||y'' - y'|| + 4 u32 ||y'||      (ReLU is 1-Lipschitz)
+//   dz3 <= s3 dh2 + (d3 + g3) (||y'|| + dh2),   h3' = relu(z3' + b3) in fp32
+//   |logit' - logit| <= E = 1.02 ||hw_mlp||_2 dz3 + 4e-5 sum |head terms|   (the mf part runs the exact kernel's own fp32 ops)
+// ||x'|| and ||y'|| are the pair's own (summed in the kernel), the norms of the four matrices come from a power iteration on the
+// device per call (k_nmf_specnorm, + 10 %, capped by the Frobenius norm).  Selection: k_nmf_screen writes the UPPER bound logit' + E of
+// every pair and keeps, per wave slice, the k largest LOWER bounds logit' - E of unmasked items; the merge of the slices gives the user's
+// threshold T = the k-th largest lower bound of the whole catalogue (k items are certainly at or above T, so nothing whose upper bound
+// is below T can be in the exact top-k); k_nmf_compact collects the unmasked items with upper bound >= T slice by slice, the exact
+// kernel scores those (NsParams.reg_*) and the usual merge returns the lists -- the same index lists and logit bits as the unscreened
+// call, because the exact kernel computes them.  When more than a quarter of the pairs survive (the bound is a worst case over
+// directions; a network whose logits barely move between items leaves it no room) or a user has fewer than k candidates, the
+// call takes the unscreened route.
+#define NSB_KS 2                                         // 16-wide k-steps per LDS stage of the weight images
+typedef unsigned short u16;
+typedef _Float16 ns_h8 __attribute__((ext_vector_type(8)));
+typedef float ns_f8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32 ns_f2h(float x) { return (u32)__builtin_bit_cast(unsigned short, (_Float16)x); }     // v_cvt_f16_f32: nearest even
+__device__ __forceinline__ float ns_h2f(u32 h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+
+struct NsPackB {
+    const float *W2, *b2, *W3, *b3, *hw;
+    u16 *W2B, *W3B;
+    float *b2E, *b3E, *hwE;
+    int H1, H2, H3, F, H1Q, H2P, H3P;                   // H1Q = H1P rounded up to a whole stage (32 k)
+};
+
+// stage images [stage][ks][mt][m][g][8 halves]: what lane (m, g) feeds the matrix instruction as its A fragment of k-step ks
+// (row m of output tile mt, k positions 8 g .. 8 g + 7).  Layer 2: position p of a 16-wide chunk is k = chunk + ns_perm16(p), the
+// order of the PI / PU / b1P images.  Layer 3: its k index runs over the layer-2 ACCUMULATORS -- lane (n, g) holds rows
+// 4 g + 8 q + t of tile mt in registers r = 4 q + t, and hands registers 0..7 to k-step 2 mt, 8..15 to k-step 2 mt + 1.
+__global__ __launch_bounds__(256) void k_nmf_pack_h16(NsPackB q) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n2 = (int64_t)q.H1Q * q.H2P;
+    if (e < n2) {
+        const int MT = q.H2P / 32;
+        const int j = (int)(e & 7), g = (int)((e >> 3) & 1), m = (int)((e >> 4) & 31);
+        const int64_t rest = e >> 9;
+        const int mt = (int)(rest % MT), ks = (int)((rest / MT) % NSB_KS), st = (int)(rest / MT / NSB_KS);
+        const int kpos = 32 * st + 16 * ks + 8 * g + j;
+        const int k = (kpos & ~15) + ns_perm16(kpos & 15), feat = 32 * mt + m;
+        q.W2B[e] = (u16)ns_f2h((k < q.H1 && feat < q.H2) ? q.W2[(int64_t)k * q.H2 + feat] : 0.f);
+    }
+    const int64_t n3 = (int64_t)q.H2P * q.H3P;
+    if (e < n3) {
+        const int MT = q.H3P / 32;
+        const int j = (int)(e & 7), g = (int)((e >> 3) & 1), m = (int)((e >> 4) & 31);
+        const int64_t rest = e >> 9;
+        const int mt = (int)(rest % MT), ks = (int)((rest / MT) % NSB_KS), st = (int)(rest / MT / NSB_KS);
+        const int c2 = NSB_KS * st + ks, src_mt = c2 >> 1, qq = 2 * (c2 & 1) + (j >> 2), t = j & 3;
+        const int f2 = 32 * src_mt + 4 * g + 8 * qq + t, feat = 32 * mt + m;
+        q.W3B[e] = (u16)ns_f2h((f2 < q.H2 && feat < q.H3) ? q.W3[(int64_t)f2 * q.H3 + feat] : 0.f);
+    }
+    // per-feature vectors in accumulator order [tile][g][r]: feature 32 tile + 4 g + 8 (r / 4) + r % 4
+    if (e < q.H2P) {
+        const int tile = (int)e >> 5, g = ((int)e >> 4) & 1, r = (int)e & 15, f = 32 * tile + 4 * g + 8 * (r >> 2) + (r & 3);
+        q.b2E[e] = f < q.H2 ? q.b2[f] : 0.f;
+    }
+    if (e < q.H3P) {
+        const int tile = (int)e >> 5, g = ((int)e >> 4) & 1, r = (int)e & 15, f = 32 * tile + 4 * g + 8 * (r >> 2) + (r & 3);
+        q.b3E[e] = f < q.H3 ? q.b3[f] : 0.f;
+        q.hwE[e] = f < q.H3 ? q.hw[q.F + f] : 0.f;
+    }
+}
+
+// half-precision image of the PI rows + R_i = ||PI_i - h(PI_i)||_2 (one wave per item; skipped with the PI image when the items are unchanged)
+__global__ __launch_bounds__(256) void k_nmf_pib(const float* __restrict__ PI, int64_t I, int H1P, u16* __restrict__ PIB, float* __restrict__ Rn,
+                                                 const unsigned long long* __restrict__ rebuild) {
+    if (rebuild && *rebuild == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= I) return;
+    float ss = 0.f;
+    for (int c = lane; c < H1P; c += 64) {
+        const float v = PI[row * H1P + c];
+        const u32 h = ns_f2h(v);
+        PIB[row * H1P + c] = (u16)h;
+        const float d = v - ns_h2f(h);
+        ss = __builtin_fmaf(d, d, ss);
+    }
+    ss = el_group_sum(ss, 64);
+    if (lane == 0) Rn[row] = sqrtf(ss) * 1.0001f;
+}
+
+// cst[0..7] = s2, d2, g2, s3, d3, g3, ||hw_mlp||_2, 0.  Block b = 0..3: spectral norm (power iteration on W^T W, 80 steps, + 10 %) of
+// h(W2), h(W2) - W2, h(W3), h(W3) - W3; the Frobenius norms ride along in blocks 0 and 2; block 4: the head weights.
+__global__ __launch_bounds__(256) void k_nmf_specnorm(const float* __restrict__ W2, int K2, int N2, const float* __restrict__ W3, int K3, int N3,
+                                                      const float* __restrict__ hw, int F, float* __restrict__ cst) {
+    __shared__ float xs[256], ys[1024], red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    auto bsum = [&](float v) {
+        v = el_group_sum(v, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    if (b == 4) {
+        float ss = 0.f;
+        for (int f = tid; f < N3; f += 256) ss += hw[F + f] * hw[F + f];
+        ss = bsum(ss);
+        if (tid == 0) cst[6] = sqrtf(ss) * 1.0001f, cst[7] = 0.f;
+        return;
+    }
+    const float* W = b < 2 ? W2 : W3;
+    const int K = b < 2 ? K2 : K3, N = b < 2 ? N2 : N3;
+    const bool resid = (b & 1) != 0;
+    auto val = [&](int k, int n) {
+        const float w = W[(int64_t)k * N + n], wb = ns_h2f(ns_f2h(w));
+        return resid ? wb - w : wb;
+    };
+    xs[tid] = tid < N ? 1.0f + 0.37f * (float)((tid * 2654435761u) >> 28) : 0.f;      // a start vector with all signs and sizes mixed
+    __syncthreads();
+    float lam = 0.f;
+    for (int it = 0; it < 80; ++it) {
+        for (int k = tid; k < K; k += 256) {                     // y = W x
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) a = __builtin_fmaf(val(k, n), xs[n], a);
+            ys[k] = a;
+        }
+        __syncthreads();
+        float z = 0.f;                                           // z = W^T y (thread = column)
+        if (tid < N)
+            for (int k = 0; k < K; ++k) z = __builtin_fmaf(val(k, tid), ys[k], z);
+        const float nz = bsum(tid < N ? z * z : 0.f), nx = bsum(tid < N ? xs[tid] * xs[tid] : 0.f);
+        lam = nx > 0.f ? sqrtf(sqrtf(nz / nx)) : 0.f;            // ||W^T W x|| / ||x|| -> sigma_max^2
+        __syncthreads();
+        if (tid < N) xs[tid] = nz > 0.f ? z * rsqrtf(nz) : 0.f;
+        __syncthreads();
+    }
+    // the iteration approaches sigma_max from below (slowly for noise-like spectra, which the rounding errors have): + 10 %, and never
+    // more than the Frobenius norm, which is an upper bound outright
+    float ss = 0.f;
+    for (int e = tid; e < K * N; e += 256) {
+        const float v = val(e / N, e % N);
+        ss += v * v;
+    }
+    ss = bsum(ss);
+    const float fro = sqrtf(ss) * 1.0001f;
+    if (tid == 0) cst[b < 2 ? b : b + 1] = fminf(lam * 1.10f, fro) + 1e-30f;
+    // g = 3.4 K 2^-24 ||W||_F: the exact kernel's fma chain (K u) + this kernel's matrix instruction (taken as two roundings per
+    // product and per accumulate: (K + K / 16) 2 u), both against sum |w| |x| <= || |W| ||_2 ||x|| <= ||W||_F ||x||
+    if (!resid && tid == 0) cst[b < 2 ? 2 : 5] = 3.4f * (float)K * 5.96e-8f * fro * 1.01f;
+}
+
+struct NsScreenParams {
+    const u16 *W2B, *W3B, *PIB;
+    const float *Rn, *cst, *b2E, *b3E, *hwE;
+    float* up;                                           // [n_users][I_local] upper bound logit' + E
+    int NST1;                                            // layer-2 stages (32 k each)
+};
+
+// NSW waves per workgroup: 8 share a stage image among more pairs, 4 leave a wave the whole register file of its SIMD (the widest
+// network keeps 128 + 64 accumulator registers alive next to the operand fragments)
+template <int H2P, int H3P, int NSW>
+__global__ __launch_bounds__(NSW * 64) void k_nmf_screen(NsParams p, NsScreenParams q) {
+    constexpr int NTH = NSW * 64;
+    constexpr int MT2 = H2P / 32, MT3 = H3P / 32, NS3 = H2P / 32;
+    constexpr int ST2 = NSB_KS * H2P * 32, ST3 = NSB_KS * H3P * 32;          // bytes of one stage image
+    constexpr int NSTG = (ST2 / 16 + NTH - 1) / NTH;            // 16-byte staging registers per thread and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wbuf = smem;                                   // [2][ST2]
+    float* aus = reinterpret_cast<float*>(smem + 2 * ST2);    // [H1Q]  (PU_u + b1), chunk order, zero past H1P
+    float* b2s = aus + q.NST1 * 32;                      // [H2P] accumulator order
+    float* b3s = b2s + H2P;                              // [H3P]
+    float* hws = b3s + H3P;                              // [H3P]
+    float* ums = hws + H3P;                              // [FP]
+    float* hms = ums + (p.FP > 0 ? p.FP : 8);            // [FP]
+    float* cs = hms + (p.FP > 0 ? p.FP : 8);             // [8]
+    u64* keys_all = reinterpret_cast<u64*>(cs + 8);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
+    u64* keys = keys_all + (size_t)w * p.cap;
+    int* cnt_s = reinterpret_cast<int*>(keys_all + (size_t)NSW * p.cap) + w * 4;
+
+    const int64_t urel = blockIdx.x;
+    const int64_t user = p.t.u_start + urel;
+    int64_t e0 = 0, e1 = 0;
+    if (p.t.excl_indptr) {
+        e0 = p.t.excl_indptr[user];
+        e1 = p.t.excl_indptr[user + 1];
+    }
+    const bool use_excl = p.t.excl_indptr != nullptr;
+    const int64_t ncand = p.t.I_local;
+    const int s = blockIdx.y * NSW + w;
+    const int64_t pos_lo = ncand * s / p.S, pos_hi = ncand * (s + 1) / p.S;
+    const int64_t max_len = (ncand + p.S - 1) / p.S;
+    const int T = (int)((max_len + 31) / 32);
+
+    for (int t = tid; t < q.NST1 * 32; t += NTH) aus[t] = t < p.H1P ? p.PU[urel * p.H1P + t] + p.b1P[t] : 0.f;
+    for (int t = tid; t < H2P; t += NTH) b2s[t] = q.b2E[t];
+    for (int t = tid; t < H3P; t += NTH) {
+        b3s[t] = q.b3E[t];
+        hws[t] = q.hwE[t];
+    }
+    for (int t = tid; t < p.FP; t += NTH) {
+        const int half = t / (p.FP / 2), f = 2 * (t % (p.FP / 2)) + half;
+        ums[t] = f < p.F ? p.Umf[user * (int64_t)p.F + f] : 0.f;
+        hms[t] = p.hwmf[t];
+    }
+    if (tid < 8) cs[tid] = q.cst[tid];
+    float4 stg[NSTG];
+#pragma unroll
+    for (int x = 0; x < NSTG; ++x) {
+        const int e4 = tid + x * NTH;
+        if (e4 < ST2 / 16) reinterpret_cast<float4*>(wbuf)[e4] = reinterpret_cast<const float4*>(q.W2B)[e4];
+    }
+    __syncthreads();
+    const float hbias = p.hb ? *p.hb : 0.f;
+    const float s2 = cs[0], d2 = cs[1], g2 = cs[2], s3 = cs[3], d3 = cs[4], g3 = cs[5], hwn = cs[6];
+    int par = 0, cnt = 0;
+    float tau = -INFINITY;
+    float* uprow = q.up + urel * p.t.I_local;
+    const int aoff = n * 32 + h * 16;                    // byte offset of this lane's A fragment inside a 32-row tile image
+
+    for (int tile = 0; tile < T; ++tile) {
+        const int64_t pos = pos_lo + (int64_t)tile * 32 + n;
+        const bool valid = pos < pos_hi;
+        const int64_t il = valid ? pos : 0;
+        const int32_t gitem = valid ? (int32_t)(p.t.item_offset + pos) : -1;
+        // ---------------- layer 2 in half precision: acc2[feature][pair] --------------------------------------------------------------
+        floatx16 acc2[MT2];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+        const uint4* pirow = reinterpret_cast<const uint4*>(q.PIB + il * (int64_t)p.H1P) + h;   // 8 positions per 16 bytes
+        const int npv = p.H1P / 8;                        // 16-byte pieces of a PI row
+        uint4 pv = pirow[0];
+        float nrm1 = 0.f, dn1 = 0.f;
+        for (int st = 0; st < q.NST1; ++st) {
+            const bool more2 = st + 1 < q.NST1;
+            const char* src = more2 ? reinterpret_cast<const char*>(q.W2B) + (size_t)(st + 1) * ST2 : reinterpret_cast<const char*>(q.W3B);
+            const int lim = more2 ? ST2 / 16 : ST3 / 16;
+#pragma unroll
+            for (int x = 0; x < NSTG; ++x) {
+                const int e4 = tid + x * NTH;
+                if (e4 < lim) stg[x] = *reinterpret_cast<const float4*>(src + (size_t)e4 * 16);
+            }
+            const char* wb = wbuf + par * ST2;
+#pragma unroll
+            for (int ks = 0; ks < NSB_KS; ++ks) {
+                const int kk = st * NSB_KS + ks;           // 16-wide k-step; this lane's positions 16 kk + 8 h .. + 7
+                const int nxt = 2 * (kk + 1);
+                const uint4 pn = (nxt + h < npv) ? pirow[nxt] : pv;
+                const float4* a4 = reinterpret_cast<const float4*>(aus + kk * 16 + 8 * h);
+                const float4 a0 = a4[0], a1 = a4[1];
+                const bool live = 2 * kk + h < npv;        // (H1P a multiple of 16, the stage of 32: the last half stage may be padding)
+                union {
+                    uint4 u;
+                    ns_h8 v;
+                } pq;
+                pq.u = pv;
+                const ns_f8 pf = __builtin_convertvector(pq.v, ns_f8);
+                ns_f8 xv;
+                xv[0] = fmaxf(a0.x + pf[0], 0.f), xv[1] = fmaxf(a0.y + pf[1], 0.f), xv[2] = fmaxf(a0.z + pf[2], 0.f), xv[3] = fmaxf(a0.w + pf[3], 0.f);
+                xv[4] = fmaxf(a1.x + pf[4], 0.f), xv[5] = fmaxf(a1.y + pf[5], 0.f), xv[6] = fmaxf(a1.z + pf[6], 0.f), xv[7] = fmaxf(a1.w + pf[7], 0.f);
+                if (!live) xv = (ns_f8)(0.f);
+                const ns_h8 xb = __builtin_convertvector(xv, ns_h8);          // v_cvt_f16_f32, round to nearest even
+                {
+                    const ns_f8 xr = __builtin_convertvector(xb, ns_f8);     // what the matrix instruction sees; xv - xr is exact in fp32
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const float d = xv[x] - xr[x];
+                        nrm1 = __builtin_fmaf(xr[x], xr[x], nrm1);
+                        dn1 = __builtin_fmaf(d, d, dn1);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) {
+                    const ns_h8 a = *reinterpret_cast<const ns_h8*>(wb + (size_t)(ks * MT2 + mt) * 1024 + aoff);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb, acc2[mt], 0, 0, 0);
+                }
+                pv = pn;
+            }
+            float4* dst = reinterpret_cast<float4*>(wbuf + (par ^ 1) * ST2);
+#pragma unroll
+            for (int x = 0; x < NSTG; ++x) {
+                const int e4 = tid + x * NTH;
+                if (e4 < lim) dst[e4] = stg[x];
+            }
+            __syncthreads();
+            par ^= 1;
+        }
+        // ---------------- head, mf part (the exact kernel's own operations on this half-wave's parity) --------------------------
+        float acc = 0.f, aabs = 0.f;
+        if (p.FP > 0) {
+            int moff = h * (p.FP / 2);
+            asm volatile("" : "+v"(moff));
+            const float* irow = p.Imf + il * (int64_t)p.F;
+            const bool vec = (p.F & 7) == 0;
+            for (int j = 0; j < p.FP / 8; ++j) {
+                float v[8];
+                if (vec) {
+                    const float4 x0 = reinterpret_cast<const float4*>(irow)[2 * j], x1 = reinterpret_cast<const float4*>(irow)[2 * j + 1];
+                    v[0] = x0.x, v[1] = x0.y, v[2] = x0.z, v[3] = x0.w, v[4] = x1.x, v[5] = x1.y, v[6] = x1.z, v[7] = x1.w;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) v[x] = (8 * j + x) < p.F ? irow[8 * j + x] : 0.f;
+                }
+                const float4 uu = *reinterpret_cast<const float4*>(ums + moff + 4 * j);
+                const float4 ww = *reinterpret_cast<const float4*>(hms + moff + 4 * j);
+                const float t0 = uu.x * (h ? v[1] : v[0]), t1 = uu.y * (h ? v[3] : v[2]), t2 = uu.z * (h ? v[5] : v[4]), t3 = uu.w * (h ? v[7] : v[6]);
+                acc = __builtin_fmaf(ww.x, t0, acc), aabs = __builtin_fmaf(fabsf(ww.x), fabsf(t0), aabs);
+                acc = __builtin_fmaf(ww.y, t1, acc), aabs = __builtin_fmaf(fabsf(ww.y), fabsf(t1), aabs);
+                acc = __builtin_fmaf(ww.z, t2, acc), aabs = __builtin_fmaf(fabsf(ww.z), fabsf(t2), aabs);
+                acc = __builtin_fmaf(ww.w, t3, acc), aabs = __builtin_fmaf(fabsf(ww.w), fabsf(t3), aabs);
+            }
+        }
+        // ---------------- layer 3 in half precision: y' = h(relu(acc2 + b2)) tile by tile -- the 16 accumulators of tile mt ARE the B
+        // fragments of layer-3 k-steps 2 mt and 2 mt + 1 = stage mt of the W3 image, so a tile is converted, consumed and dead
+        floatx16 acc3[MT3];
+#pragma unroll
+        for (int mt = 0; mt < MT3; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[mt][r] = 0.f;
+        float nrm2 = 0.f, dn2 = 0.f;
+        int hoff = h * 16;
+        asm volatile("" : "+v"(hoff));
+#pragma unroll
+        for (int st = 0; st < NS3; ++st) {
+            const bool more3 = st + 1 < NS3;
+            const char* src = more3 ? reinterpret_cast<const char*>(q.W3B) + (size_t)(st + 1) * ST3 : reinterpret_cast<const char*>(q.W2B);
+            const int lim = more3 ? ST3 / 16 : ST2 / 16;       // (after the last W3 stage: stage 0 of W2 for the next tile)
+#pragma unroll
+            for (int x = 0; x < NSTG; ++x) {
+                const int e4 = tid + x * NTH;
+                if (e4 < lim) stg[x] = *reinterpret_cast<const float4*>(src + (size_t)e4 * 16);
+            }
+            const char* wb = wbuf + par * ST2;
+            const float4* bb = reinterpret_cast<const float4*>(b2s + st * 32 + hoff);
+#pragma unroll
+            for (int ks = 0; ks < NSB_KS; ++ks) {
+                const float4 b0 = bb[2 * ks], b1 = bb[2 * ks + 1];
+                ns_f8 yv;
+                yv[0] = fmaxf(acc2[st][8 * ks + 0] + b0.x, 0.f);
+                yv[1] = fmaxf(acc2[st][8 * ks + 1] + b0.y, 0.f);
+                yv[2] = fmaxf(acc2[st][8 * ks + 2] + b0.z, 0.f);
+                yv[3] = fmaxf(acc2[st][8 * ks + 3] + b0.w, 0.f);
+                yv[4] = fmaxf(acc2[st][8 * ks + 4] + b1.x, 0.f);
+                yv[5] = fmaxf(acc2[st][8 * ks + 5] + b1.y, 0.f);
+                yv[6] = fmaxf(acc2[st][8 * ks + 6] + b1.z, 0.f);
+                yv[7] = fmaxf(acc2[st][8 * ks + 7] + b1.w, 0.f);
+                const ns_h8 yq = __builtin_convertvector(yv, ns_h8);
+                {
+                    const ns_f8 yr = __builtin_convertvector(yq, ns_f8);
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const float d = yv[x] - yr[x];
+                        nrm2 = __builtin_fmaf(yr[x], yr[x], nrm2);
+                        dn2 = __builtin_fmaf(d, d, dn2);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT3; ++mt) {
+                    const ns_h8 a = *reinterpret_cast<const ns_h8*>(wb + (size_t)(ks * MT3 + mt) * 1024 + aoff);
+                    acc3[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, yq, acc3[mt], 0, 0, 0);
+                }
+            }
+            float4* dst = reinterpret_cast<float4*>(wbuf + (par ^ 1) * ST2);
+#pragma unroll
+            for (int x = 0; x < NSTG; ++x) {
+                const int e4 = tid + x * NTH;
+                if (e4 < lim) dst[e4] = stg[x];
+            }
+            __syncthreads();
+            par ^= 1;
+        }
+        int hoff3 = h * 16;
+        asm volatile("" : "+v"(hoff3));
+#pragma unroll
+        for (int mt = 0; mt < MT3; ++mt) {
+            const float4* bb = reinterpret_cast<const float4*>(b3s + mt * 32 + hoff3);
+            const float4* hh = reinterpret_cast<const float4*>(hws + mt * 32 + hoff3);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float4 b = bb[x], gq = hh[x];
+                const float y0 = fmaxf(acc3[mt][4 * x + 0] + b.x, 0.f), y1 = fmaxf(acc3[mt][4 * x + 1] + b.y, 0.f);
+                const float y2 = fmaxf(acc3[mt][4 * x + 2] + b.z, 0.f), y3 = fmaxf(acc3[mt][4 * x + 3] + b.w, 0.f);
+                acc = __builtin_fmaf(gq.x, y0, acc), aabs = __builtin_fmaf(fabsf(gq.x), y0, aabs);
+                acc = __builtin_fmaf(gq.y, y1, acc), aabs = __builtin_fmaf(fabsf(gq.y), y1, aabs);
+                acc = __builtin_fmaf(gq.z, y2, acc), aabs = __builtin_fmaf(fabsf(gq.z), y2, aabs);
+                acc = __builtin_fmaf(gq.w, y3, acc), aabs = __builtin_fmaf(fabsf(gq.w), y3, aabs);
+            }
+        }
+        // both half-waves hold the pair's partial sums: combine
+        const float logit = (acc + __uint_as_float(el_partner32(__float_as_uint(acc), h))) + hbias;
+        aabs += __uint_as_float(el_partner32(__float_as_uint(aabs), h));
+        nrm1 += __uint_as_float(el_partner32(__float_as_uint(nrm1), h));
+        nrm2 += __uint_as_float(el_partner32(__float_as_uint(nrm2), h));
+        dn1 += __uint_as_float(el_partner32(__float_as_uint(dn1), h));
+        dn2 += __uint_as_float(el_partner32(__float_as_uint(dn2), h));
+        // ---------------- the pair's error bound (header) ------------------------------------------------------------------------
+        const float r1 = sqrtf(nrm1) * 1.0001f, r2 = sqrtf(nrm2) * 1.0001f;
+        const float dh1 = q.Rn[il] + sqrtf(dn1) * 1.0001f + 2.4e-7f * r1;
+        const float dz2 = s2 * dh1 + d2 * (r1 + dh1) + g2 * (r1 + dh1);
+        const float dh2 = dz2 + sqrtf(dn2) * 1.0001f + 2.4e-7f * r2;
+        const float dz3 = s3 * dh2 + d3 * (r2 + dh2) + g3 * (r2 + dh2);
+        const float E = 1.02f * hwn * dz3 + 4e-5f * (aabs + fabsf(hbias)) + 1e-30f;
+        // an activation past the half-precision range (inf, then NaN) leaves nothing to bound: the pair goes to the exact kernel
+        const bool bounded = E < INFINITY && fabsf(logit) < INFINITY;
+        const float lo = bounded ? logit - E : -INFINITY, up = bounded ? logit + E : INFINITY;
+        // ---------------- upper bounds out; the slice's k largest lower bounds of unmasked items (lanes 0..31 carry the 32 pairs) --------
+        if (valid && h == 0) uprow[pos] = up;
+        bool hit = valid && h == 0 && (lo >= tau);
+        if (hit && use_excl) hit = !el_row_contains(p.t.excl_indices, e0, e1, gitem);
+        const u64 bal = __ballot(hit);
+        if (bal) {
+            const int offp = __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit) keys[cnt + offp] = el_make_key(lo, gitem);
+            cnt += __popcll(bal);
+        }
+        if (cnt > p.cap - 32) {
+            if (lane == 0) *cnt_s = cnt;
+            tau = el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
+            cnt = cnt < p.t.k ? cnt : p.t.k;
+        }
+    }
+    if (lane == 0) *cnt_s = cnt;
+    el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
+    const int nv = cnt < p.t.k ? cnt : p.t.k;
+    const int64_t orow = ((int64_t)s * (p.t.u_stop - p.t.u_start) + urel) * p.t.k;
+    for (int t = lane; t < p.t.k; t += 64) {
+        p.part_idx[orow + t] = t < nv ? el_key_item(keys[t]) : -1;
+        p.part_val[orow + t] = t < nv ? el_key_score(keys[t]) : -INFINITY;
+    }
+}
+
+// the unmasked items of slice s of user u whose upper bound reaches the user's threshold T (= the k-th largest lower bound over the
+// catalogue; -inf when fewer than k unmasked items exist), compacted in ascending order at the start of the slice's own position
+// range.  One wave per (user, slice).
+__global__ __launch_bounds__(256) void k_nmf_compact(TopkParams t, const float* __restrict__ up, const float* __restrict__ thr, int S,
+                                                     int32_t* __restrict__ reg_idx, int32_t* __restrict__ reg_cnt, int32_t* sflag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_users = t.u_stop - t.u_start;
+    if (rg >= n_users * S) return;
+    const int64_t urel = rg / S;
+    const int s = (int)(rg % S);
+    const int64_t user = t.u_start + urel;
+    const float T = thr[urel * t.k + (t.k - 1)];
+    int64_t e0 = 0, e1 = 0;
+    if (t.excl_indptr) {
+        e0 = t.excl_indptr[user];
+        e1 = t.excl_indptr[user + 1];
+    }
+    const int64_t pos_lo = t.I_local * s / S, pos_hi = t.I_local * (s + 1) / S;
+    const float* urow = up + urel * t.I_local;
+    int32_t* out = reg_idx + urel * t.I_local + pos_lo;
+    int cnt = 0;
+    for (int64_t base = pos_lo; base < pos_hi; base += 64) {
+        const int64_t pos = base + lane;
+        bool c = pos < pos_hi && urow[pos] >= T;
+        const int32_t gitem = (int32_t)(t.item_offset + pos);
+        if (c && t.excl_indptr) c = !el_row_contains(t.excl_indices, e0, e1, gitem);
+        const u64 b = __ballot(c);
+        if (c) out[cnt + __popcll(b & ((1ull << lane) - 1ull))] = gitem;       // (cnt + prefix <= pos - pos_lo: never past the reader)
+        cnt += __popcll(b);
+    }
+    if (lane == 0) {
+        reg_cnt[rg] = cnt;
+        atomicAdd(reinterpret_cast<unsigned long long*>(sflag + 2), (unsigned long long)cnt);
+    }
+}
+
+// a user whose regions hold fewer than k candidates (a nearly empty catalogue after masking, non-finite logits) sends the call
+// through the unscreened route, which pads such rows the way top_k(where(mask, preds, -inf)) does
+__global__ __launch_bounds__(256) void k_nmf_reg_check(const int32_t* __restrict__ reg_cnt, int64_t n_users, int S, int k, int32_t* sflag) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    int64_t tot = 0;
+    for (int s = 0; s < S; ++s) tot += reg_cnt[u * S + s];
+    if (tot < k) atomicOr(sflag, 2);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
@@ -547,18 +1077,39 @@ extern "C" int el_nmf_score_supported(const el_nmf_state* st, int32_t k) {
     return ns_lds_bytes(st, ns_cap_for_k(k)) <= NS_LDS_LIMIT ? 1 : 0;       // (callers fall back to the pair route otherwise)
 }
 
+// with_cand: 0 = dense scoring, 1 = + a candidate-list scratch, 2 = + the screened route's buffers (EL_NMF_SCREEN)
 extern "C" size_t el_nmf_score_ws_bytes(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int32_t k, int with_cand) {
     if (!ctx || !st || !ns_shape_ok(st) || k < 1) return 0;
-    return ns_layout(ctx, st, n_users, I_local, k, with_cand != 0).total;
+    return ns_layout(ctx, st, n_users, I_local, k, with_cand == 1, with_cand == 2).total;
+}
+
+extern "C" int el_nmf_screen_stats(el_ctx* ctx, int64_t* exact_pairs, int* fell_back) {
+    EL_REQUIRE(ctx != nullptr, "el_nmf_screen_stats: null context");
+    if (exact_pairs) *exact_pairs = ctx->nmf_screen_cands;
+    if (fell_back) *fell_back = ctx->nmf_screen_fallback ? 1 : 0;
+    return 0;
 }
 
 template <int H2P, int H3P>
 static int ns_launch(const NsParams& p, int64_t n_users, int nsplit, hipStream_t s) {
     const size_t lds = (size_t)(2 * H2P * 16 + 2 * p.H1P + H2P + 2 * H3P + 2 * (p.FP > 0 ? p.FP : 8)) * 4 + (size_t)NS_WAVES * p.cap * 8 +
-                       (size_t)NS_WAVES * 16;
+                       (size_t)NS_WAVES * 16 + 16;
     auto kern = k_nmf_score<H2P, H3P>;
     EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     EL_LAUNCH("k_nmf_score", kern, dim3((unsigned)n_users, (unsigned)nsplit), dim3(NS_THREADS), lds, s, p);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int H2P, int H3P, int NSW>
+static int ns_launch_screen(const NsParams& p, const NsScreenParams& q, int64_t n_users, int nsplit, hipStream_t s) {
+    const size_t lds = (size_t)2 * NSB_KS * H2P * 32 + (size_t)(q.NST1 * 32 + H2P + 2 * H3P + 2 * (p.FP > 0 ? p.FP : 8) + 8) * 4 +
+                       (size_t)NSW * p.cap * 8 + (size_t)NSW * 16;
+    EL_REQUIRE(lds <= NS_LDS_LIMIT, "el_nmf_score_topk: the screened kernel needs %zu bytes of LDS", lds);
+    auto kern = k_nmf_screen<H2P, H3P, NSW>;
+    EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (the slices of a user are numbered blockIdx.y * NSW + wave: NS_WAVES / NSW grid rows per grid row of the exact kernel)
+    EL_LAUNCH("k_nmf_screen", kern, dim3((unsigned)n_users, (unsigned)(nsplit * (NS_WAVES / NSW))), dim3(NSW * 64), lds, s, p, q);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -583,7 +1134,13 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
     EL_REQUIRE(out_idx && out_val, "el_nmf_score_topk: null output");
     EL_REQUIRE(n_users <= 0x7fffffffLL / 2, "el_nmf_score_topk: too many users per call");
     const bool cand = cand_indptr != nullptr;
-    const NsLayout L = ns_layout(ctx, st, n_users, I_local, k, cand);
+    // screened route: half-precision matrix instruction + per-pair error bound first, the exact kernel on the surviving pairs (same lists, same
+    // logit bits); a catalogue too small to be worth it, or a candidate list, takes the exact kernel alone
+    const bool screen = (flags & EL_NMF_SCREEN) != 0 && !cand && I_local >= 4096 && k <= 256;
+    // (el_nmf_screen_stats: what the exact kernel scores, and whether a call that asked for the screen goes without it)
+    ctx->nmf_screen_cands = cand ? -1 : n_users * I_local;
+    ctx->nmf_screen_fallback = (flags & EL_NMF_SCREEN) != 0 && !screen;
+    const NsLayout L = ns_layout(ctx, st, n_users, I_local, k, cand, screen);
     EL_REQUIRE(ws != nullptr && ws_bytes >= L.total, "el_nmf_score_topk: workspace too small (%zu < %zu; el_nmf_score_ws_bytes)", ws_bytes, L.total);
     EL_REQUIRE(((uintptr_t)ws & 15) == 0, "el_nmf_score_topk: workspace must be 16-byte aligned");
     EL_REQUIRE(!st->use_mf || (((uintptr_t)st->tab[1] & 15) == 0), "el_nmf_score_topk: item MF table must be 16-byte aligned");
@@ -653,6 +1210,61 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
     p.hb = st->head_bias ? st->hb : nullptr;
     const int nsplit = L.S / NS_WAVES;
     int rc;
+    if (screen) {
+        NsPackB qb;
+        qb.W2 = st->W[1], qb.b2 = st->b[1], qb.W3 = st->W[2], qb.b3 = st->b[2], qb.hw = st->hw;
+        qb.W2B = (u16*)(base + L.W2B), qb.W3B = (u16*)(base + L.W3B);
+        qb.b2E = (float*)(base + L.b2E), qb.b3E = (float*)(base + L.b3E), qb.hwE = (float*)(base + L.hwE);
+        qb.H1 = st->units[0], qb.H2 = st->units[1], qb.H3 = st->units[2], qb.F = q.F;
+        qb.H1Q = (int)ns_up(L.H1P, 32), qb.H2P = L.H2P, qb.H3P = L.H3P;
+        int64_t nb = (int64_t)qb.H1Q * L.H2P;
+        if ((int64_t)L.H2P * L.H3P > nb) nb = (int64_t)L.H2P * L.H3P;
+        EL_LAUNCH("k_nmf_pack_h16", k_nmf_pack_h16, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, qb);
+        EL_LAUNCH("k_nmf_specnorm", k_nmf_specnorm, dim3(5), dim3(256), 0, s, (const float*)st->W[1], (int)st->units[0], (int)st->units[1],
+                  (const float*)st->W[2], (int)st->units[1], (int)st->units[2], (const float*)st->hw, (int)q.F, (float*)(base + L.cst));
+        // the half-precision image of PI follows the PI image (same rebuild flag), unless this workspace has not held one yet
+        const bool have_pib = ctx->nmf_pib_ws == ws && claim;
+        EL_LAUNCH("k_nmf_pib", k_nmf_pib, dim3((unsigned)((I_local + 3) / 4)), dim3(256), 0, s, (const float*)(base + L.PI), I_local, L.H1P,
+                  (u16*)(base + L.PIB), (float*)(base + L.Rn), have_pib ? (const unsigned long long*)(ctl + 2) : (const unsigned long long*)nullptr);
+        ctx->nmf_pib_ws = ws;
+        EL_CHECK_HIP(hipMemsetAsync(base + L.sflag, 0, 16, s));
+        NsScreenParams sq;
+        sq.W2B = qb.W2B, sq.W3B = qb.W3B, sq.PIB = (const u16*)(base + L.PIB), sq.Rn = (const float*)(base + L.Rn);
+        sq.cst = (const float*)(base + L.cst), sq.b2E = qb.b2E, sq.b3E = qb.b3E, sq.hwE = qb.hwE;
+        sq.up = (float*)(base + L.upb), sq.NST1 = qb.H1Q / 32;
+        const char* ew = getenv("EL_NMF_SCREEN_WAVES");                  // (tuning knob; read per call: an evaluation call, not a hot loop)
+        const int nsw = ew ? atoi(ew) : 0;
+        if (L.H2P == 256) rc = (nsw == 8) ? ns_launch_screen<256, 128, 8>(p, sq, n_users, nsplit, s) : ns_launch_screen<256, 128, 4>(p, sq, n_users, nsplit, s);
+        else if (L.H2P == 128) rc = (nsw == 4) ? ns_launch_screen<128, 64, 4>(p, sq, n_users, nsplit, s) : ns_launch_screen<128, 64, 8>(p, sq, n_users, nsplit, s);
+        else if (L.H2P == 64) rc = ns_launch_screen<64, 32, 8>(p, sq, n_users, nsplit, s);
+        else rc = ns_launch_screen<32, 32, 8>(p, sq, n_users, nsplit, s);
+        if (rc) return rc;
+        // the user's threshold: k-th largest lower bound over the slices' lists
+        float* thr = (float*)(base + L.thr);
+        if (int rc2 = el_topk_merge(ctx, stream, p.part_idx, p.part_val, L.S, n_users, k, (int32_t*)(base + L.tidx), thr)) return rc2;
+        int32_t* regi = (int32_t*)(base + L.regi);
+        int32_t* regc = (int32_t*)(base + L.regc);
+        int32_t* sflag = (int32_t*)(base + L.sflag);
+        EL_LAUNCH("k_nmf_compact", k_nmf_compact, dim3((unsigned)((n_users * L.S + 3) / 4)), dim3(256), 0, s, p.t, (const float*)sq.up, (const float*)thr,
+                  L.S, regi, regc, sflag);
+        EL_LAUNCH("k_nmf_reg_check", k_nmf_reg_check, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, s, (const int32_t*)regc, n_users, L.S, (int)k,
+                  sflag);
+        int32_t hflag[4] = {0, 0, 0, 0};
+        EL_CHECK_HIP(hipMemcpyAsync(hflag, sflag, sizeof(hflag), hipMemcpyDeviceToHost, s));
+        EL_CHECK_HIP(hipStreamSynchronize(s));              // (an evaluation call: its results are read by the host next anyway)
+        unsigned long long ncands = 0;
+        memcpy(&ncands, hflag + 2, 8);
+        // worth it when the exact kernel is left with less than a quarter of the pairs (EL_NMF_SCREEN_MAXFRAC overrides)
+        const char* ef = getenv("EL_NMF_SCREEN_MAXFRAC");
+        const double maxfrac = ef ? atof(ef) : 0.25;
+        const bool use = hflag[0] == 0 && (double)ncands <= maxfrac * (double)n_users * (double)I_local;
+        if (use) ctx->nmf_screen_cands = (int64_t)ncands;
+        ctx->nmf_screen_fallback = !use;
+        if (use) {
+            p.reg_idx = regi, p.reg_cnt = regc;
+            p.t.excl_indptr = nullptr, p.t.excl_indices = nullptr;     // the regions are free of masked items already
+        }
+    }
     if (L.H2P == 256) rc = ns_launch<256, 128>(p, n_users, nsplit, s);
     else if (L.H2P == 128) rc = ns_launch<128, 64>(p, n_users, nsplit, s);
     else if (L.H2P == 64) rc = ns_launch<64, 32>(p, n_users, nsplit, s);

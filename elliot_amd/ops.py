@@ -1332,12 +1332,18 @@ class NmfDeviceState:
         """True when el_nmf_score_topk takes this network and list length (three Dense layers, units <= (1024, 256, 128), ...)."""
         return bool(self.use_mlp and self.ctx.lib.el_nmf_score_supported(C.byref(self._c), int(k)))
 
-    def score_topk_logits(self, u_start, u_stop, k, excl=None, cand=None, item_offset=0, I_local=None, items_unchanged=False):
+    def score_topk_logits(self, u_start, u_stop, k, excl=None, cand=None, item_offset=0, I_local=None, items_unchanged=False, screen=None):
         """el_nmf_score_topk: the k best unmasked items of users [u_start, u_stop) by (logit desc, item asc) and their logits --
-        layer 1 in its separable form, layers 2-3 and the head per (user, item) pair on fp32 MFMA tiles, selection fused."""
+        layer 1 in its separable form, layers 2-3 and the head per (user, item) pair on fp32 MFMA tiles, selection fused.
+        screen (None = on unless EL_NMF_SCREEN=0; full-catalogue calls only): layers 2-3 first on the half-precision matrix instruction
+        with a per-pair error bound, the fp32 kernel on the surviving pairs -- the same lists and logit bits (EL_NMF_SCREEN in the header)."""
         n = int(u_stop) - int(u_start)
         I_local = self.I - int(item_offset) if I_local is None else int(I_local)
-        need = int(self.ctx.lib.el_nmf_score_ws_bytes(self.ctx.handle, C.byref(self._c), n, I_local, int(k), 1 if cand is not None else 0))
+        if screen is None:
+            screen = os.environ.get("EL_NMF_SCREEN", "1") != "0"
+        screen = bool(screen) and cand is None
+        need = int(self.ctx.lib.el_nmf_score_ws_bytes(self.ctx.handle, C.byref(self._c), n, I_local, int(k),
+                                                      1 if cand is not None else (2 if screen else 0)))
         if need == 0:
             raise _lib.ElliotHipError("el_nmf_score_topk does not take this network shape / k (NmfDeviceState.fused_supported)")
         ws = getattr(self, "_score_ws", None)
@@ -1350,9 +1356,15 @@ class NmfDeviceState:
         cp, ci = _csr_ptrs(cand)
         check(self.ctx.lib.el_nmf_score_topk(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(u_start), int(u_stop),
                                              int(item_offset), I_local, ep, ei, cp, ci, int(k), _ptr(out_idx), _ptr(out_val),
-                                             _lib.EL_TOPK_ITEMS_UNCHANGED if items_unchanged else 0, C.c_void_p(ws.data_ptr()),
-                                             ws.numel()), "el_nmf_score_topk")
+                                             (_lib.EL_TOPK_ITEMS_UNCHANGED if items_unchanged else 0) | (_lib.EL_NMF_SCREEN if screen else 0),
+                                             C.c_void_p(ws.data_ptr()), ws.numel()), "el_nmf_score_topk")
         return out_idx, out_val
+
+    def screen_stats(self):
+        """(pairs the exact kernel scored, fell back to the unscreened route) of the last screened score_topk_logits call."""
+        pairs, fb = C.c_int64(0), C.c_int(0)
+        self.ctx.lib.el_nmf_screen_stats(self.ctx.handle, C.byref(pairs), C.byref(fb))
+        return int(pairs.value), bool(fb.value)
 
     def _dot_tables(self, items_unchanged):
         """The MF-only network (GMF; NeuMF with is_mlp_train False) is sigmoid(<Umf[u], Imf[i] * h> (+ b)): tables for the fused

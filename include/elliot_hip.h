@@ -349,7 +349,13 @@ enum {
      * item-side bf16 image of that call instead of deriving it again.  Ignored unless workspace, tables and shape match --
      * and VERIFIED: a 64-bit hash of every element of Gi / Bi (read-only pass on the device, no host synchronisation) is
      * compared with the hash the image was built from; tables updated in place at the same address rebuild the image. */
-    EL_TOPK_ITEMS_UNCHANGED = 0x100
+    EL_TOPK_ITEMS_UNCHANGED = 0x100,
+    /* el_nmf_score_topk only: layers 2-3 first on the half-precision matrix instruction with a per-pair error bound (spectral norms
+     * of the rounded weights and of their rounding errors, the pair's own activation norms and measured rounding residuals), the
+     * fp32 kernel then only on the pairs whose upper bound reaches the user's k-th best lower bound: the same index lists and logit
+     * bits.  Needs the workspace of el_nmf_score_ws_bytes(..., with_cand = 2); synchronises the stream once (a 16-byte flag read);
+     * takes the unscreened route when the bound leaves more than a quarter of the pairs (el_nmf_screen_stats tells).            */
+    EL_NMF_SCREEN = 0x200
 };
 
 /* Replaces: BPRMF_batch_model.predict + get_top_k (BPRMF_batch_model.py:83-88) and
@@ -578,7 +584,11 @@ int el_nmf_sync_tables(el_ctx* ctx, void* stream, el_nmf_state* st);
  *          device-side hash of both arrays, no host synchronisation
  *   ws   : el_nmf_score_ws_bytes(...) bytes, 16-byte aligned (item projection I_local x units[0] x 4 bytes + per-block scratch)  */
 int el_nmf_score_supported(const el_nmf_state* st, int32_t k);
+/* with_cand: 0 = full catalogue, 1 = candidate lists, 2 = full catalogue with room for the screened route (EL_NMF_SCREEN)        */
 size_t el_nmf_score_ws_bytes(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, int64_t I_local, int32_t k, int with_cand);
+/* Diagnostics of the last el_nmf_score_topk call on this ctx: pairs the exact fp32 kernel scored (-1 for a candidate-list call),
+ * and whether a call that asked for EL_NMF_SCREEN went without it (1: too many survivors, a user short of k, a small shard). */
+int el_nmf_screen_stats(el_ctx* ctx, int64_t* exact_pairs, int* fell_back);
 int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, int64_t u_start, int64_t u_stop,
                       int64_t item_offset, int64_t I_local, const int64_t* excl_indptr, const int32_t* excl_indices,
                       const int64_t* cand_indptr, const int32_t* cand_indices, int32_t k, int32_t* out_idx, float* out_val,

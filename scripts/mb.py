@@ -122,11 +122,15 @@ def main():
             st.recommend(0, nu, a.k, excl=pos)
             torch.cuda.synchronize()
             ctx.timing(True)
+            t0 = time.perf_counter()
             for it in range(a.iters):
                 st.recommend((it + 1) * nu, (it + 2) * nu, a.k, excl=pos, items_unchanged=True)
             torch.cuda.synchronize()
+            print(f"wall (with per-kernel timing events): {(time.perf_counter() - t0) * 1e3 / a.iters:.3f} ms/call of {nu} users")
             for n, (c, ms) in sorted(ctx.timing_report().items(), key=lambda kv: -kv[1][1]):
                 print(f"{n}: {ms / a.iters:.4f} ms/call ({c // a.iters} launches/call)")
+            pairs, fb = st.screen_stats()
+            print(f"screen: exact pairs of the last call {pairs} = {pairs / max(nu * I, 1):.5f} of the block, fell back: {fb}")
             return
         ctx.timing(True)
         for it in range(a.iters + 2):

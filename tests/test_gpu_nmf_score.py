@@ -218,3 +218,76 @@ def test_unsupported_tower_takes_the_pair_route(ctx):
     assert torch.equal(idx, ri) and torch.equal(val, rv)
     with pytest.raises(Exception):
         st.score_topk_logits(0, U, 5)
+
+
+# ---------------------------------------------------------------------------------------------------- screened route (EL_NMF_SCREEN)
+@pytest.mark.parametrize("F,units,k,I", [(128, None, 10, 30000), (64, None, 20, 9000), (32, [128, 64, 32], 10, 6000), (16, [72, 40, 16], 50, 5000),
+                                         (128, None, 100, 12000)])
+def test_screened_route_returns_the_unscreened_lists_and_logit_bits(ctx, F, units, k, I, monkeypatch):
+    """EL_NMF_SCREEN: layers 2-3 on the bf16 matrix instruction with a per-pair error bound, a per-user threshold from the lower
+    bounds, the fp32 kernel on the pairs whose upper bound reaches it.  The answer is the fp32 kernel's: index lists and logit bits
+    equal the unscreened call's -- with an exclusion CSR, without, on an item shard with its offset, with the item image kept from
+    the previous call.  (EL_NMF_SCREEN_MAXFRAC = 1: the candidate route runs whatever share of the pairs survives.)"""
+    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    U = 48
+    w = _weights(U, I, F, seed=F + k, units=units)
+    st = ops.NmfDeviceState(ctx, w, max_batch=1024)
+    rs = np.random.RandomState(3)
+    ip, ix = random_excl(rs, U, I, 0, 60)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    for kwargs in ({"excl": excl}, {}, {"excl": excl, "item_offset": 1000, "I_local": I - 1500}):
+        ref_i, ref_v = st.score_topk_logits(0, U, k, screen=False, **kwargs)
+        got_i, got_v = st.score_topk_logits(0, U, k, screen=True, **kwargs)
+        pairs, fell_back = st.screen_stats()
+        n_items = kwargs.get("I_local", I)
+        assert fell_back == (n_items < 4096)                       # (a shard this small is not worth two passes: exact kernel alone)
+        assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32)), (kwargs.keys(), int((got_i != ref_i).sum()))
+        assert k * U <= pairs <= U * n_items and (fell_back or pairs < 0.5 * U * n_items), (pairs, U * n_items)
+        again_i, again_v = st.score_topk_logits(0, U, k, screen=True, items_unchanged=True, **kwargs)
+        assert torch.equal(again_i, ref_i) and torch.equal(again_v.view(torch.int32), ref_v.view(torch.int32))
+    # a sub-range of the users
+    ref_i, ref_v = st.score_topk_logits(7, 29, k, excl=excl, screen=False)
+    got_i, got_v = st.score_topk_logits(7, 29, k, excl=excl, screen=True)
+    assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
+
+
+def test_screened_route_at_d128_matches_the_oracle(ctx, monkeypatch):
+    """... and the oracle itself (orc_nmf_logits + the masked top-k) on a sample of users against 100 000 items."""
+    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    U, I, F, k = 16, 100_000, 128, 10
+    w = _weights(U, I, F, seed=77)
+    st = ops.NmfDeviceState(ctx, w, max_batch=1024)
+    rs = np.random.RandomState(5)
+    ip, ix = random_excl(rs, U, I, 0, 200)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    idx, val = st.score_topk_logits(0, U, k, excl=excl, screen=True)
+    pairs, fell_back = st.screen_stats()
+    assert not fell_back and k * U <= pairs <= 0.05 * U * I, (pairs, fell_back)
+    ei, ev = _oracle_topk(w, 0, 4, k, excl=(ip, ix))
+    assert_topk_equal("nmf_screen_d128", cpu(idx[:4]), cpu(val[:4]), ei, ev)
+
+
+def test_screened_route_falls_back_when_too_many_pairs_survive_or_a_row_is_short(ctx, monkeypatch):
+    """More surviving pairs than EL_NMF_SCREEN_MAXFRAC of the block, or a user with fewer than k unmasked items, sends the call
+    through the unscreened route: same answer, `fell_back` set."""
+    U, I, F, k = 12, 8000, 32, 10
+    w = _weights(U, I, F, seed=9)
+    st = ops.NmfDeviceState(ctx, w, max_batch=512)
+    ref_i, ref_v = st.score_topk_logits(0, U, k, screen=False)
+    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "0.0001")           # 9.6 pairs: fewer than the k * U the lists themselves need
+    got_i, got_v = st.score_topk_logits(0, U, k, screen=True)
+    pairs, fell_back = st.screen_stats()
+    assert fell_back and pairs == U * I                           # the exact kernel scored every pair
+    assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
+    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    # user 3 keeps only 4 unmasked items
+    keep = np.array([5, 77, 4000, 7999])
+    rows = [np.zeros(0, np.int32)] * U
+    rows[3] = np.setdiff1d(np.arange(I), keep).astype(np.int32)
+    ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    excl = ops.DeviceCSR(ip, np.concatenate(rows).astype(np.int32), I, ctx.device)
+    st3 = ops.NmfDeviceState(ctx, w, max_batch=512)
+    ref_i, ref_v = st3.score_topk_logits(0, U, k, excl=excl, screen=False)
+    got_i, got_v = st3.score_topk_logits(0, U, k, excl=excl, screen=True)
+    assert st3.screen_stats()[1]
+    assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
