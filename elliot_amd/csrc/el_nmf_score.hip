@@ -47,7 +47,7 @@ struct NsLayout {
     size_t ctl, W1a, W1b, b1P, W2P, W3P, b2D, b3D, hwD, hwmf, PI, PU, pidx, pval, total;
     // screened route (el_nmf_score_topk with EL_NMF_SCREEN): half-precision stage images of W2 / W3, accumulator-order vectors, half-precision image of
     // PI + the residual norm of every row, the bound's constants, one candidate region per (user, wave slice)
-    size_t W2B, W3B, b2E, b3E, hwE, PIB, Rn, cst, upb, thr, tidx, regi, regc, sflag;
+    size_t W2B, W3B, b2E, b3E, hwE, PIB, Rn, cst, gram, upb, thr, tidx, regi, regc, sflag;
     int H1P, H2P, H3P, FP, NC1, NC2, S;
 };
 
@@ -115,14 +115,15 @@ static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, 
     L.pidx = take((size_t)L.S * (n_users > 0 ? n_users : 1) * k * 4);
     L.pval = take((size_t)L.S * (n_users > 0 ? n_users : 1) * k * 4);
     if (screen) {
-        L.W2B = take((size_t)ns_up(L.H1P, 32) * L.H2P * 2);
+        L.W2B = take((size_t)ns_up(L.H1P, 256) * L.H2P * 2);
         L.W3B = take((size_t)L.H2P * L.H3P * 2);
         L.b2E = take((size_t)L.H2P * 4);
         L.b3E = take((size_t)L.H3P * 4);
         L.hwE = take((size_t)L.H3P * 4);
         L.PIB = take((size_t)(I_local > 0 ? I_local : 1) * L.H1P * 2);
         L.Rn = take((size_t)(I_local > 0 ? I_local : 1) * 4);
-        L.cst = take(64);
+        L.cst = take(256);                               // 8 constants, then the traces of the squarings (k_nmf_gram_sq)
+        L.gram = take((size_t)4 * 2 * 65536 * 4);
         const size_t nu = (size_t)(n_users > 0 ? n_users : 1), ni = (size_t)(I_local > 0 ? I_local : 1);
         L.upb = take(nu * ni * 4);                       // upper bound logit' + E of every pair
         L.thr = take(nu * (size_t)k * 4);                // merged top-k of the lower bounds (its last column = the user's threshold)
@@ -585,27 +586,28 @@ __global__ __launch_bounds__(NS_THREADS) void k_nmf_score(NsParams p) {
 // are what they are.  v_mfma_f32_32x32x16_f16 is 16x faster, and its result need not be right, only boundedly wrong (half precision
 // keeps 11 bits where bf16 keeps 8, and the bound decides everything: the survivors are a Gaussian tail in E / sigma(logit)):
 //   x   = relu(PU_u + b1 + PI_i)                      the exact kernel's layer-1 activation (fp32)
-//   x'' = relu((PU_u + b1) + h(PI_i)), x' = h(x'')    h = round to half;  ||x' - x|| <= dh1 = R_i + ||x'' - x'|| + 4 u32 ||x'||,
-//                                                     R_i = ||PI_i - h(PI_i)|| per item (k_nmf_pib), ||x'' - x'|| MEASURED per pair
+//   x'  = relu_h(h(PU_u + b1) +_h h(PI_i))            h = round to half, +_h / relu_h = packed half arithmetic (one rounding);
+//   ||x' - x|| <= dh1 = R_i + R_u + uh ||x'|| + 4 u32 ||x'||,   R_i = ||PI_i - h(PI_i)|| per item (k_nmf_pib), R_u the same for the
+//                                                     user's vector (per workgroup), uh = 2^-11 (1 + 2^-11)
 //   z2' - z2 = W2h^T (x' - x) + (W2h - W2)^T x + (fp32 accumulation of both kernels)        W2h = h(W2)
 //   ||z2' - z2|| <= s2 dh1 + (d2 + g2) (||x'|| + dh1),    s2 = ||W2h||_2, d2 = ||W2h - W2||_2 (SPECTRAL norms: a ReLU network's layers
 //   are Lipschitz in them; Frobenius or column-sum bounds accumulate sqrt(width) per layer and exceed the spread of the logits),
-//   g2 = 3.4 K 2^-24 ||W2h||_F (k_nmf_specnorm)
-//   y'' = relu(z2' + b2), y' = h(y''):   dh2 = ||y' - h2|| <= dz2 + ||y'' - y'|| + 4 u32 ||y'||      (ReLU is 1-Lipschitz)
+//   g2 = 3.4 K 2^-24 ||W2h||_F (k_nmf_spec_finish)
+//   y' = h(relu(z2' + b2)):   dh2 = ||y' - h2|| <= dz2 + uh ||y'|| + 4 u32 ||y'||      (ReLU is 1-Lipschitz)
 //   dz3 <= s3 dh2 + (d3 + g3) (||y'|| + dh2),   h3' = relu(z3' + b3) in fp32
-//   |logit' - logit| <= E = 1.02 ||hw_mlp||_2 dz3 + 4e-5 sum |head terms|   (the mf part runs the exact kernel's own fp32 ops)
+//   |logit' - logit| <= E = 1.02 ||hw_mlp||_2 dz3 + 4e-5 sum |head terms|   (mf part: the same fp32 products, another order)
 // ||x'|| and ||y'|| are the pair's own (summed in the kernel), the norms of the four matrices come from a power iteration on the
-// device per call (k_nmf_specnorm, + 10 %, capped by the Frobenius norm).  Selection: k_nmf_screen writes the UPPER bound logit' + E of
+// device per call (k_nmf_gram ...: upper bounds from the trace of (W^T W)^16).  Selection: k_nmf_screen writes the UPPER bound logit' + E of
 // every pair and keeps, per wave slice, the k largest LOWER bounds logit' - E of unmasked items; the merge of the slices gives the user's
 // threshold T = the k-th largest lower bound of the whole catalogue (k items are certainly at or above T, so nothing whose upper bound
 // is below T can be in the exact top-k); k_nmf_compact collects the unmasked items with upper bound >= T slice by slice, the exact
 // kernel scores those (NsParams.reg_*) and the usual merge returns the lists -- the same index lists and logit bits as the unscreened
-// call, because the exact kernel computes them.  When more than a quarter of the pairs survive (the bound is a worst case over
+// call, because the exact kernel computes them.  When more than half of the pairs survive (the bound is a worst case over
 // directions; a network whose logits barely move between items leaves it no room) or a user has fewer than k candidates, the
 // call takes the unscreened route.
-#define NSB_KS 2                                         // 16-wide k-steps per LDS stage of the weight images
 typedef unsigned short u16;
 typedef _Float16 ns_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ns_h2 __attribute__((ext_vector_type(2)));
 typedef float ns_f8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ u32 ns_f2h(float x) { return (u32)__builtin_bit_cast(unsigned short, (_Float16)x); }     // v_cvt_f16_f32: nearest even
@@ -615,10 +617,10 @@ struct NsPackB {
     const float *W2, *b2, *W3, *b3, *hw;
     u16 *W2B, *W3B;
     float *b2E, *b3E, *hwE;
-    int H1, H2, H3, F, H1Q, H2P, H3P;                   // H1Q = H1P rounded up to a whole stage (32 k)
+    int H1, H2, H3, F, H1Q, H2P, H3P;                   // H1Q = 16 x the layer-2 k-steps of the kernel (256 or 512)
 };
 
-// stage images [stage][ks][mt][m][g][8 halves]: what lane (m, g) feeds the matrix instruction as its A fragment of k-step ks
+// fragment images [k-step][mt][m][g][8 halves]: what lane (m, g) feeds the matrix instruction as its A fragment of the k-step
 // (row m of output tile mt, k positions 8 g .. 8 g + 7).  Layer 2: position p of a 16-wide chunk is k = chunk + ns_perm16(p), the
 // order of the PI / PU / b1P images.  Layer 3: its k index runs over the layer-2 ACCUMULATORS -- lane (n, g) holds rows
 // 4 g + 8 q + t of tile mt in registers r = 4 q + t, and hands registers 0..7 to k-step 2 mt, 8..15 to k-step 2 mt + 1.
@@ -629,8 +631,8 @@ __global__ __launch_bounds__(256) void k_nmf_pack_h16(NsPackB q) {
         const int MT = q.H2P / 32;
         const int j = (int)(e & 7), g = (int)((e >> 3) & 1), m = (int)((e >> 4) & 31);
         const int64_t rest = e >> 9;
-        const int mt = (int)(rest % MT), ks = (int)((rest / MT) % NSB_KS), st = (int)(rest / MT / NSB_KS);
-        const int kpos = 32 * st + 16 * ks + 8 * g + j;
+        const int mt = (int)(rest % MT), c2 = (int)(rest / MT);
+        const int kpos = 16 * c2 + 8 * g + j;
         const int k = (kpos & ~15) + ns_perm16(kpos & 15), feat = 32 * mt + m;
         q.W2B[e] = (u16)ns_f2h((k < q.H1 && feat < q.H2) ? q.W2[(int64_t)k * q.H2 + feat] : 0.f);
     }
@@ -639,8 +641,8 @@ __global__ __launch_bounds__(256) void k_nmf_pack_h16(NsPackB q) {
         const int MT = q.H3P / 32;
         const int j = (int)(e & 7), g = (int)((e >> 3) & 1), m = (int)((e >> 4) & 31);
         const int64_t rest = e >> 9;
-        const int mt = (int)(rest % MT), ks = (int)((rest / MT) % NSB_KS), st = (int)(rest / MT / NSB_KS);
-        const int c2 = NSB_KS * st + ks, src_mt = c2 >> 1, qq = 2 * (c2 & 1) + (j >> 2), t = j & 3;
+        const int mt = (int)(rest % MT), c2 = (int)(rest / MT);
+        const int src_mt = c2 >> 1, qq = 2 * (c2 & 1) + (j >> 2), t = j & 3;
         const int f2 = 32 * src_mt + 4 * g + 8 * qq + t, feat = 32 * mt + m;
         q.W3B[e] = (u16)ns_f2h((f2 < q.H2 && feat < q.H3) ? q.W3[(int64_t)f2 * q.H3 + feat] : 0.f);
     }
@@ -675,95 +677,155 @@ __global__ __launch_bounds__(256) void k_nmf_pib(const float* __restrict__ PI, i
     if (lane == 0) Rn[row] = sqrtf(ss) * 1.0001f;
 }
 
-// cst[0..7] = s2, d2, g2, s3, d3, g3, ||hw_mlp||_2, 0.  Block b = 0..3: spectral norm (power iteration on W^T W, 80 steps, + 10 %) of
-// h(W2), h(W2) - W2, h(W3), h(W3) - W3; the Frobenius norms ride along in blocks 0 and 2; block 4: the head weights.
-__global__ __launch_bounds__(256) void k_nmf_specnorm(const float* __restrict__ W2, int K2, int N2, const float* __restrict__ W3, int K3, int N3,
-                                                      const float* __restrict__ hw, int F, float* __restrict__ cst) {
-    __shared__ float xs[256], ys[1024], red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    auto bsum = [&](float v) {
-        v = el_group_sum(v, 64);
+// cst[0..7] = s2, d2, g2, s3, d3, g3, ||hw_mlp||_2, 0 -- the constants of the bound above.  The four spectral norms (of h(W2), h(W2) - W2,
+// h(W3), h(W3) - W3) are UPPER bounds, not estimates: with G = V^T V (N x N, N <= 256) and M_0 = G / tr G, M_{j+1} = (M_j / tr M_j)^2,
+//   sigma_max(V)^2 = tr G * lambda_max(M_0),   lambda_max(M_j / tr M_j) <= sqrt(tr M_{j+1} * lambda_max(M_{j+1} / tr M_{j+1})),   lambda_max(.) <= 1
+// (the Schatten-32 norm after four squarings: (sum sigma_i^32)^(1/32), a few percent above sigma_max for these spectra, where a power
+// iteration approaches it from below).  Matrix m = 0..3 as listed; one workgroup per 16 rows of the N x N product.
+struct NsSpec {
+    const float *W2, *W3, *hw;
+    int K2, N2, K3, N3, F;
+    float* gram;                                         // [4 matrices][2][256 * 256]
+    float* cst;
+};
+__device__ __forceinline__ float ns_spec_val(const NsSpec& q, int m, int k, int n) {
+    const float w = m < 2 ? q.W2[(int64_t)k * q.N2 + n] : q.W3[(int64_t)k * q.N3 + n];
+    const float wh = ns_h2f(ns_f2h(w));
+    return (m & 1) ? wh - w : wh;
+}
+// G = V^T V: thread = column j, 16 rows i per workgroup
+__global__ __launch_bounds__(256) void k_nmf_gram(NsSpec q) {
+    const int m = blockIdx.y, K = m < 2 ? q.K2 : q.K3, N = m < 2 ? q.N2 : q.N3;
+    const int i0 = blockIdx.x * 16, j = threadIdx.x;
+    if (i0 >= N) return;
+    __shared__ float vi[16];
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < K; ++k) {
         __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = v;
+        if (j < 16) vi[j] = (i0 + j) < N ? ns_spec_val(q, m, k, i0 + j) : 0.f;
         __syncthreads();
-        return (red[0] + red[1]) + (red[2] + red[3]);
-    };
-    if (b == 4) {
+        const float vj = j < N ? ns_spec_val(q, m, k, j) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(vi[r], vj, acc[r]);
+    }
+    float* G = q.gram + (size_t)m * 2 * 65536;
+    if (j < N)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (i0 + r < N) G[(i0 + r) * 256 + j] = acc[r];
+}
+// trace of an N x N matrix held with row stride 256, the same order of additions in every workgroup
+__device__ __forceinline__ float ns_trace(const float* __restrict__ A, int N, float* red) {
+    const int tid = threadIdx.x;
+    float v = tid < N ? A[tid * 256 + tid] : 0.f;
+    v = el_group_sum(v, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// out = (in / tr in)^2; trs[m][step] = tr in
+__global__ __launch_bounds__(256) void k_nmf_gram_sq(NsSpec q, int step, float* __restrict__ trs) {
+    const int m = blockIdx.y, N = m < 2 ? q.N2 : q.N3;
+    const int i0 = blockIdx.x * 16, j = threadIdx.x;
+    if (i0 >= N) return;
+    __shared__ float red[4], ai[16];
+    const float* in = q.gram + ((size_t)m * 2 + (step & 1)) * 65536;
+    float* out = q.gram + ((size_t)m * 2 + ((step + 1) & 1)) * 65536;
+    const float tr = ns_trace(in, N, red);
+    if (blockIdx.x == 0 && j == 0) trs[m * 8 + step] = tr;
+    const float inv = tr > 0.f ? 1.0f / tr : 0.f;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < N; ++k) {
+        __syncthreads();
+        if (j < 16) ai[j] = (i0 + j) < N ? in[(i0 + j) * 256 + k] * inv : 0.f;
+        __syncthreads();
+        const float bj = j < N ? in[k * 256 + j] * inv : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(ai[r], bj, acc[r]);
+    }
+    if (j < N)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (i0 + r < N) out[(i0 + r) * 256 + j] = acc[r];
+}
+#define NS_SPEC_SQ 4
+__global__ __launch_bounds__(256) void k_nmf_spec_finish(NsSpec q, const float* __restrict__ trs) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    if (m == 4) {                                        // the head weights of the MLP part
         float ss = 0.f;
-        for (int f = tid; f < N3; f += 256) ss += hw[F + f] * hw[F + f];
-        ss = bsum(ss);
-        if (tid == 0) cst[6] = sqrtf(ss) * 1.0001f, cst[7] = 0.f;
+        for (int f = tid; f < q.N3; f += 256) ss += q.hw[q.F + f] * q.hw[q.F + f];
+        ss = el_group_sum(ss, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        if (tid == 0) q.cst[6] = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * 1.0001f, q.cst[7] = 0.f;
         return;
     }
-    const float* W = b < 2 ? W2 : W3;
-    const int K = b < 2 ? K2 : K3, N = b < 2 ? N2 : N3;
-    const bool resid = (b & 1) != 0;
-    auto val = [&](int k, int n) {
-        const float w = W[(int64_t)k * N + n], wb = ns_h2f(ns_f2h(w));
-        return resid ? wb - w : wb;
-    };
-    xs[tid] = tid < N ? 1.0f + 0.37f * (float)((tid * 2654435761u) >> 28) : 0.f;      // a start vector with all signs and sizes mixed
-    __syncthreads();
-    float lam = 0.f;
-    for (int it = 0; it < 80; ++it) {
-        for (int k = tid; k < K; k += 256) {                     // y = W x
-            float a = 0.f;
-            for (int n = 0; n < N; ++n) a = __builtin_fmaf(val(k, n), xs[n], a);
-            ys[k] = a;
-        }
-        __syncthreads();
-        float z = 0.f;                                           // z = W^T y (thread = column)
-        if (tid < N)
-            for (int k = 0; k < K; ++k) z = __builtin_fmaf(val(k, tid), ys[k], z);
-        const float nz = bsum(tid < N ? z * z : 0.f), nx = bsum(tid < N ? xs[tid] * xs[tid] : 0.f);
-        lam = nx > 0.f ? sqrtf(sqrtf(nz / nx)) : 0.f;            // ||W^T W x|| / ||x|| -> sigma_max^2
-        __syncthreads();
-        if (tid < N) xs[tid] = nz > 0.f ? z * rsqrtf(nz) : 0.f;
-        __syncthreads();
+    const int K = m < 2 ? q.K2 : q.K3, N = m < 2 ? q.N2 : q.N3;
+    const float trl = ns_trace(q.gram + ((size_t)m * 2 + (NS_SPEC_SQ & 1)) * 65536, N, red);     // tr M_p
+    if (tid != 0) return;
+    float lam = 1.0f;                                    // lambda_max(M_p / tr M_p) <= 1
+    for (int jstep = NS_SPEC_SQ; jstep >= 1; --jstep) {  // lambda_max(M_{j-1} / tr M_{j-1}) = sqrt(tr M_j * lambda_max(M_j / tr M_j))
+        const float tj = jstep == NS_SPEC_SQ ? trl : trs[m * 8 + jstep];
+        lam = sqrtf(tj * lam) * 1.0001f;
     }
-    // the iteration approaches sigma_max from below (slowly for noise-like spectra, which the rounding errors have): + 10 %, and never
-    // more than the Frobenius norm, which is an upper bound outright
-    float ss = 0.f;
-    for (int e = tid; e < K * N; e += 256) {
-        const float v = val(e / N, e % N);
-        ss += v * v;
-    }
-    ss = bsum(ss);
-    const float fro = sqrtf(ss) * 1.0001f;
-    if (tid == 0) cst[b < 2 ? b : b + 1] = fminf(lam * 1.10f, fro) + 1e-30f;
-    // g = 3.4 K 2^-24 ||W||_F: the exact kernel's fma chain (K u) + this kernel's matrix instruction (taken as two roundings per
+    const float trG = trs[m * 8 + 0];                    // tr G = ||V||_F^2
+    const float fro = sqrtf(trG) * 1.0001f;
+    // + 1 %: the fp32 sums of the squarings (N <= 256 terms; worst for a flat spectrum, where the cap below takes over anyway);
+    // never more than the Frobenius norm
+    const float sig = fminf(sqrtf(trG * lam) * 1.01f, fro) + 1e-30f;
+    q.cst[m < 2 ? m : m + 1] = sig;
+    // g = 3.4 K 2^-24 ||W||_F: the exact kernel's fma chain (K u) + this route's matrix instruction (taken as two roundings per
     // product and per accumulate: (K + K / 16) 2 u), both against sum |w| |x| <= || |W| ||_2 ||x|| <= ||W||_F ||x||
-    if (!resid && tid == 0) cst[b < 2 ? 2 : 5] = 3.4f * (float)K * 5.96e-8f * fro * 1.01f;
+    if ((m & 1) == 0) q.cst[m < 2 ? 2 : 5] = 3.4f * (float)K * 5.96e-8f * fro * 1.01f;
 }
 
 struct NsScreenParams {
     const u16 *W2B, *W3B, *PIB;
-    const float *Rn, *cst, *b2E, *b3E, *hwE;
+    const float *Rn, *cst, *b2E, *b3E, *hwE, *hw;        // hw: the head weights as the model holds them ([F mf ; H3 mlp])
     float* up;                                           // [n_users][I_local] upper bound logit' + E
-    int NST1;                                            // layer-2 stages (32 k each)
 };
 
-// NSW waves per workgroup: 8 share a stage image among more pairs, 4 leave a wave the whole register file of its SIMD (the widest
-// network keeps 128 + 64 accumulator registers alive next to the operand fragments)
-template <int H2P, int H3P, int NSW>
-__global__ __launch_bounds__(NSW * 64) void k_nmf_screen(NsParams p, NsScreenParams q) {
-    constexpr int NTH = NSW * 64;
-    constexpr int MT2 = H2P / 32, MT3 = H3P / 32, NS3 = H2P / 32;
-    constexpr int ST2 = NSB_KS * H2P * 32, ST3 = NSB_KS * H3P * 32;          // bytes of one stage image
-    constexpr int NSTG = (ST2 / 16 + NTH - 1) / NTH;            // 16-byte staging registers per thread and stage
+// One workgroup of 8 waves = one user x 8 consecutive slices of the item range, 32 pairs (one matrix-instruction column tile) at a time:
+//   P1  all 512 threads build the tile's x' in LDS as B fragments (16 threads per pair, 16-byte pieces of the PI image and the mf row
+//       prefetched one tile ahead; v_pk_add_f16 / v_pk_max_f16 / v_dot2_f32_f16: 1.5 instructions per element), and the mf part of the head
+//   P2  wave w owns output features 32 w .. 32 w + 31 of layer 2: its slice of W2 lives in REGISTERS for the whole kernel (4 VGPRs
+//       per 16-wide k-step: nothing is streamed, nothing waits on a barrier inside the k loop), x' comes from LDS, one matrix
+//       instruction per k-step; relu(. + b2) -> half -> LDS as the layer-3 B fragments
+//   P3  waves 0 .. H3P / 32 - 1: layer 3 (W3 image resident in LDS), relu(. + b3) . hw -> the pair's partial logits
+//   P4  wave 4, one tile behind, while layer 3 of the next tile runs: error bound, upper bound out, the k largest lower bounds of
+//       the range (one list per workgroup)
+// NSTM = 16-wide k-steps of layer 2 (units[0] padded to 256 or 512).
+#define NSC_WAVES 8
+#define NSC_P4 4                                         // the wave that finishes tiles (no layer-3 tile: H3P <= 128)
+template <int H2P, int H3P, int NSTM>
+__global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScreenParams q) {
+    constexpr int NTH = NSC_WAVES * 64;
+    constexpr int NT2 = H2P / 32, NT3 = H3P / 32, NK3 = H2P / 16;
+    constexpr int NCH = 2 * NSTM, CPT = NCH / 16;       // 8-position pieces of a PI row; pieces per thread (16 threads per pair)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wbuf = smem;                                   // [2][ST2]
-    float* aus = reinterpret_cast<float*>(smem + 2 * ST2);    // [H1Q]  (PU_u + b1), chunk order, zero past H1P
-    float* b2s = aus + q.NST1 * 32;                      // [H2P] accumulator order
+    char* xs = smem;                                     // [NSTM][lane = 32 g + pair, swizzled][8 halves]   B fragments of layer 2
+    char* ys = xs + NSTM * 1024;                         // [NK3][lane][8]                         B fragments of layer 3
+    char* w3s = ys + NK3 * 1024;                         // [NK3][NT3][row m][g][8]                A fragments of layer 3
+    _Float16* aus = reinterpret_cast<_Float16*>(w3s + (size_t)NK3 * NT3 * 1024);   // [NSTM * 16]  h(PU_u + b1) (image order), zero past H1P
+    float* b2s = reinterpret_cast<float*>(aus + NSTM * 16);    // [H2P] accumulator order
     float* b3s = b2s + H2P;                              // [H3P]
     float* hws = b3s + H3P;                              // [H3P]
     float* ums = hws + H3P;                              // [FP]
     float* hms = ums + (p.FP > 0 ? p.FP : 8);            // [FP]
     float* cs = hms + (p.FP > 0 ? p.FP : 8);             // [8]
-    u64* keys_all = reinterpret_cast<u64*>(cs + 8);
+    float* rus = cs + 8;                                 // [8] per-wave parts of ||(PU_u + b1) - h(PU_u + b1)||^2
+    float* pq1 = rus + 8;                                // [2 parity][4: nrm1, mf, |mf|, R_i][32]
+    float* pq2 = pq1 + 2 * 4 * 32;                       // [2][8 waves][32]  nrm2 parts
+    float* pq3 = pq2 + 2 * 8 * 32;                       // [2][4 tiles][2: logit, |.|][32]
+    u64* keys = reinterpret_cast<u64*>(pq3 + 2 * 4 * 2 * 32);
+    int* cnt_s = reinterpret_cast<int*>(keys + p.cap);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
-    u64* keys = keys_all + (size_t)w * p.cap;
-    int* cnt_s = reinterpret_cast<int*>(keys_all + (size_t)NSW * p.cap) + w * 4;
 
     const int64_t urel = blockIdx.x;
     const int64_t user = p.t.u_start + urel;
@@ -774,227 +836,103 @@ __global__ __launch_bounds__(NSW * 64) void k_nmf_screen(NsParams p, NsScreenPar
     }
     const bool use_excl = p.t.excl_indptr != nullptr;
     const int64_t ncand = p.t.I_local;
-    const int s = blockIdx.y * NSW + w;
-    const int64_t pos_lo = ncand * s / p.S, pos_hi = ncand * (s + 1) / p.S;
-    const int64_t max_len = (ncand + p.S - 1) / p.S;
-    const int T = (int)((max_len + 31) / 32);
+    const int s0 = blockIdx.y * NSC_WAVES;               // this workgroup's slices s0 .. s0 + 7 of the exact kernel's S
+    const int64_t pos_lo = ncand * s0 / p.S, pos_hi = ncand * (s0 + NSC_WAVES) / p.S;
+    const int T = (int)((pos_hi - pos_lo + 31) / 32);
 
-    for (int t = tid; t < q.NST1 * 32; t += NTH) aus[t] = t < p.H1P ? p.PU[urel * p.H1P + t] + p.b1P[t] : 0.f;
+    {
+        float rs = 0.f;
+        for (int t = tid; t < NSTM * 16; t += NTH) {
+            const float a = t < p.H1P ? p.PU[urel * p.H1P + t] + p.b1P[t] : 0.f;
+            const _Float16 ah = (_Float16)a;
+            aus[t] = ah;
+            const float d = a - (float)ah;
+            rs = __builtin_fmaf(d, d, rs);
+        }
+        rs = el_group_sum(rs, 64);
+        if (lane == 0) rus[w] = rs;
+    }
     for (int t = tid; t < H2P; t += NTH) b2s[t] = q.b2E[t];
     for (int t = tid; t < H3P; t += NTH) {
         b3s[t] = q.b3E[t];
         hws[t] = q.hwE[t];
     }
     for (int t = tid; t < p.FP; t += NTH) {
-        const int half = t / (p.FP / 2), f = 2 * (t % (p.FP / 2)) + half;
-        ums[t] = f < p.F ? p.Umf[user * (int64_t)p.F + f] : 0.f;
-        hms[t] = p.hwmf[t];
+        ums[t] = t < p.F ? p.Umf[user * (int64_t)p.F + t] : 0.f;
+        hms[t] = t < p.F ? q.hw[t] : 0.f;
     }
     if (tid < 8) cs[tid] = q.cst[tid];
-    float4 stg[NSTG];
+    for (int e4 = tid; e4 < NK3 * NT3 * 64; e4 += NTH) reinterpret_cast<float4*>(w3s)[e4] = reinterpret_cast<const float4*>(q.W3B)[e4];
+    // this wave's slice of the W2 image: A fragment of k-step ks = 16 bytes at [ks][tile w][lane]
+    ns_h8 wreg[NSTM];
+    if (w < NT2) {
 #pragma unroll
-    for (int x = 0; x < NSTG; ++x) {
-        const int e4 = tid + x * NTH;
-        if (e4 < ST2 / 16) reinterpret_cast<float4*>(wbuf)[e4] = reinterpret_cast<const float4*>(q.W2B)[e4];
+        for (int ks = 0; ks < NSTM; ++ks)
+            wreg[ks] = *reinterpret_cast<const ns_h8*>(reinterpret_cast<const char*>(q.W2B) + (size_t)(ks * NT2 + w) * 1024 + n * 32 + h * 16);
     }
-    __syncthreads();
     const float hbias = p.hb ? *p.hb : 0.f;
-    const float s2 = cs[0], d2 = cs[1], g2 = cs[2], s3 = cs[3], d3 = cs[4], g3 = cs[5], hwn = cs[6];
-    int par = 0, cnt = 0;
+    int cnt = 0;
     float tau = -INFINITY;
     float* uprow = q.up + urel * p.t.I_local;
-    const int aoff = n * 32 + h * 16;                    // byte offset of this lane's A fragment inside a 32-row tile image
-
-    for (int tile = 0; tile < T; ++tile) {
-        const int64_t pos = pos_lo + (int64_t)tile * 32 + n;
-        const bool valid = pos < pos_hi;
-        const int64_t il = valid ? pos : 0;
-        const int32_t gitem = valid ? (int32_t)(p.t.item_offset + pos) : -1;
-        // ---------------- layer 2 in half precision: acc2[feature][pair] --------------------------------------------------------------
-        floatx16 acc2[MT2];
+    // P1 roles: pair pp of the tile, piece lane pj of 16
+    const int pp = tid >> 4, pj = tid & 15;
+    const int npv = p.H1P / 8;                           // live 16-byte pieces of a PI row
+    const bool vecf = (p.F & 3) == 0;
+    uint4 pre[CPT];
+    float4 mpre[2];                                      // this thread's first two 4-feature pieces of the item's mf row (F <= 128: all)
+    float rpre = 0.f;                                    // R_i (thread 0 of the pair)
+    auto prefetch = [&](int tile) {
+        const int64_t pos = pos_lo + (int64_t)tile * 32 + pp;
+        const int64_t il = pos < pos_hi ? pos : pos_lo;
+        const uint4* row = reinterpret_cast<const uint4*>(q.PIB + il * (int64_t)p.H1P);
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
-        const uint4* pirow = reinterpret_cast<const uint4*>(q.PIB + il * (int64_t)p.H1P) + h;   // 8 positions per 16 bytes
-        const int npv = p.H1P / 8;                        // 16-byte pieces of a PI row
-        uint4 pv = pirow[0];
-        float nrm1 = 0.f, dn1 = 0.f;
-        for (int st = 0; st < q.NST1; ++st) {
-            const bool more2 = st + 1 < q.NST1;
-            const char* src = more2 ? reinterpret_cast<const char*>(q.W2B) + (size_t)(st + 1) * ST2 : reinterpret_cast<const char*>(q.W3B);
-            const int lim = more2 ? ST2 / 16 : ST3 / 16;
-#pragma unroll
-            for (int x = 0; x < NSTG; ++x) {
-                const int e4 = tid + x * NTH;
-                if (e4 < lim) stg[x] = *reinterpret_cast<const float4*>(src + (size_t)e4 * 16);
-            }
-            const char* wb = wbuf + par * ST2;
-#pragma unroll
-            for (int ks = 0; ks < NSB_KS; ++ks) {
-                const int kk = st * NSB_KS + ks;           // 16-wide k-step; this lane's positions 16 kk + 8 h .. + 7
-                const int nxt = 2 * (kk + 1);
-                const uint4 pn = (nxt + h < npv) ? pirow[nxt] : pv;
-                const float4* a4 = reinterpret_cast<const float4*>(aus + kk * 16 + 8 * h);
-                const float4 a0 = a4[0], a1 = a4[1];
-                const bool live = 2 * kk + h < npv;        // (H1P a multiple of 16, the stage of 32: the last half stage may be padding)
-                union {
-                    uint4 u;
-                    ns_h8 v;
-                } pq;
-                pq.u = pv;
-                const ns_f8 pf = __builtin_convertvector(pq.v, ns_f8);
-                ns_f8 xv;
-                xv[0] = fmaxf(a0.x + pf[0], 0.f), xv[1] = fmaxf(a0.y + pf[1], 0.f), xv[2] = fmaxf(a0.z + pf[2], 0.f), xv[3] = fmaxf(a0.w + pf[3], 0.f);
-                xv[4] = fmaxf(a1.x + pf[4], 0.f), xv[5] = fmaxf(a1.y + pf[5], 0.f), xv[6] = fmaxf(a1.z + pf[6], 0.f), xv[7] = fmaxf(a1.w + pf[7], 0.f);
-                if (!live) xv = (ns_f8)(0.f);
-                const ns_h8 xb = __builtin_convertvector(xv, ns_h8);          // v_cvt_f16_f32, round to nearest even
-                {
-                    const ns_f8 xr = __builtin_convertvector(xb, ns_f8);     // what the matrix instruction sees; xv - xr is exact in fp32
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) {
-                        const float d = xv[x] - xr[x];
-                        nrm1 = __builtin_fmaf(xr[x], xr[x], nrm1);
-                        dn1 = __builtin_fmaf(d, d, dn1);
-                    }
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) {
-                    const ns_h8 a = *reinterpret_cast<const ns_h8*>(wb + (size_t)(ks * MT2 + mt) * 1024 + aoff);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb, acc2[mt], 0, 0, 0);
-                }
-                pv = pn;
-            }
-            float4* dst = reinterpret_cast<float4*>(wbuf + (par ^ 1) * ST2);
-#pragma unroll
-            for (int x = 0; x < NSTG; ++x) {
-                const int e4 = tid + x * NTH;
-                if (e4 < lim) dst[e4] = stg[x];
-            }
-            __syncthreads();
-            par ^= 1;
+        for (int i = 0; i < CPT; ++i) {
+            const int c = pj + 16 * i;
+            pre[i] = c < npv ? row[c] : make_uint4(0u, 0u, 0u, 0u);
         }
-        // ---------------- head, mf part (the exact kernel's own operations on this half-wave's parity) --------------------------
-        float acc = 0.f, aabs = 0.f;
-        if (p.FP > 0) {
-            int moff = h * (p.FP / 2);
-            asm volatile("" : "+v"(moff));
+        if (pj == 0) rpre = q.Rn[il];
+        if (p.FP > 0 && vecf) {
             const float* irow = p.Imf + il * (int64_t)p.F;
-            const bool vec = (p.F & 7) == 0;
-            for (int j = 0; j < p.FP / 8; ++j) {
-                float v[8];
-                if (vec) {
-                    const float4 x0 = reinterpret_cast<const float4*>(irow)[2 * j], x1 = reinterpret_cast<const float4*>(irow)[2 * j + 1];
-                    v[0] = x0.x, v[1] = x0.y, v[2] = x0.z, v[3] = x0.w, v[4] = x1.x, v[5] = x1.y, v[6] = x1.z, v[7] = x1.w;
-                } else {
 #pragma unroll
-                    for (int x = 0; x < 8; ++x) v[x] = (8 * j + x) < p.F ? irow[8 * j + x] : 0.f;
-                }
-                const float4 uu = *reinterpret_cast<const float4*>(ums + moff + 4 * j);
-                const float4 ww = *reinterpret_cast<const float4*>(hms + moff + 4 * j);
-                const float t0 = uu.x * (h ? v[1] : v[0]), t1 = uu.y * (h ? v[3] : v[2]), t2 = uu.z * (h ? v[5] : v[4]), t3 = uu.w * (h ? v[7] : v[6]);
-                acc = __builtin_fmaf(ww.x, t0, acc), aabs = __builtin_fmaf(fabsf(ww.x), fabsf(t0), aabs);
-                acc = __builtin_fmaf(ww.y, t1, acc), aabs = __builtin_fmaf(fabsf(ww.y), fabsf(t1), aabs);
-                acc = __builtin_fmaf(ww.z, t2, acc), aabs = __builtin_fmaf(fabsf(ww.z), fabsf(t2), aabs);
-                acc = __builtin_fmaf(ww.w, t3, acc), aabs = __builtin_fmaf(fabsf(ww.w), fabsf(t3), aabs);
-            }
+            for (int i = 0; i < 2; ++i) mpre[i] = (4 * pj + 64 * i) < p.F ? *reinterpret_cast<const float4*>(irow + 4 * pj + 64 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // ---------------- layer 3 in half precision: y' = h(relu(acc2 + b2)) tile by tile -- the 16 accumulators of tile mt ARE the B
-        // fragments of layer-3 k-steps 2 mt and 2 mt + 1 = stage mt of the W3 image, so a tile is converted, consumed and dead
-        floatx16 acc3[MT3];
+    };
+    if (T > 0) prefetch(0);
+    __syncthreads();
+
+    // P4 of one tile: error bound, upper bound out, the range's k largest lower bounds.  One wave (the first without a layer-3 tile),
+    // one tile behind the others, while layer 3 of the next tile runs.
+    const float ru = sqrtf(((rus[0] + rus[1]) + (rus[2] + rus[3])) + ((rus[4] + rus[5]) + (rus[6] + rus[7]))) * 1.0001f;
+    auto finish_tile = [&](int tile) {
+        const int par = tile & 1;
+        const int64_t pos = pos_lo + (int64_t)tile * 32 + n;
+        const bool valid = pos < pos_hi && h == 0;
+        const int32_t gitem = valid ? (int32_t)(p.t.item_offset + pos) : -1;
+        const float* o1 = pq1 + par * 128 + n;
+        float nrm1 = o1[0], acc = o1[32], aabs = o1[64], nrm2 = 0.f;
+        const float rni = o1[96];
 #pragma unroll
-        for (int mt = 0; mt < MT3; ++mt)
+        for (int x = 0; x < NT2; ++x) nrm2 += pq2[(par * 8 + x) * 32 + n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc3[mt][r] = 0.f;
-        float nrm2 = 0.f, dn2 = 0.f;
-        int hoff = h * 16;
-        asm volatile("" : "+v"(hoff));
-#pragma unroll
-        for (int st = 0; st < NS3; ++st) {
-            const bool more3 = st + 1 < NS3;
-            const char* src = more3 ? reinterpret_cast<const char*>(q.W3B) + (size_t)(st + 1) * ST3 : reinterpret_cast<const char*>(q.W2B);
-            const int lim = more3 ? ST3 / 16 : ST2 / 16;       // (after the last W3 stage: stage 0 of W2 for the next tile)
-#pragma unroll
-            for (int x = 0; x < NSTG; ++x) {
-                const int e4 = tid + x * NTH;
-                if (e4 < lim) stg[x] = *reinterpret_cast<const float4*>(src + (size_t)e4 * 16);
-            }
-            const char* wb = wbuf + par * ST2;
-            const float4* bb = reinterpret_cast<const float4*>(b2s + st * 32 + hoff);
-#pragma unroll
-            for (int ks = 0; ks < NSB_KS; ++ks) {
-                const float4 b0 = bb[2 * ks], b1 = bb[2 * ks + 1];
-                ns_f8 yv;
-                yv[0] = fmaxf(acc2[st][8 * ks + 0] + b0.x, 0.f);
-                yv[1] = fmaxf(acc2[st][8 * ks + 1] + b0.y, 0.f);
-                yv[2] = fmaxf(acc2[st][8 * ks + 2] + b0.z, 0.f);
-                yv[3] = fmaxf(acc2[st][8 * ks + 3] + b0.w, 0.f);
-                yv[4] = fmaxf(acc2[st][8 * ks + 4] + b1.x, 0.f);
-                yv[5] = fmaxf(acc2[st][8 * ks + 5] + b1.y, 0.f);
-                yv[6] = fmaxf(acc2[st][8 * ks + 6] + b1.z, 0.f);
-                yv[7] = fmaxf(acc2[st][8 * ks + 7] + b1.w, 0.f);
-                const ns_h8 yq = __builtin_convertvector(yv, ns_h8);
-                {
-                    const ns_f8 yr = __builtin_convertvector(yq, ns_f8);
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) {
-                        const float d = yv[x] - yr[x];
-                        nrm2 = __builtin_fmaf(yr[x], yr[x], nrm2);
-                        dn2 = __builtin_fmaf(d, d, dn2);
-                    }
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT3; ++mt) {
-                    const ns_h8 a = *reinterpret_cast<const ns_h8*>(wb + (size_t)(ks * MT3 + mt) * 1024 + aoff);
-                    acc3[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, yq, acc3[mt], 0, 0, 0);
-                }
-            }
-            float4* dst = reinterpret_cast<float4*>(wbuf + (par ^ 1) * ST2);
-#pragma unroll
-            for (int x = 0; x < NSTG; ++x) {
-                const int e4 = tid + x * NTH;
-                if (e4 < lim) dst[e4] = stg[x];
-            }
-            __syncthreads();
-            par ^= 1;
+        for (int x = 0; x < NT3; ++x) {
+            const float* o3 = pq3 + (par * 4 + x) * 64 + n;
+            acc += o3[0], aabs += o3[32];
         }
-        int hoff3 = h * 16;
-        asm volatile("" : "+v"(hoff3));
-#pragma unroll
-        for (int mt = 0; mt < MT3; ++mt) {
-            const float4* bb = reinterpret_cast<const float4*>(b3s + mt * 32 + hoff3);
-            const float4* hh = reinterpret_cast<const float4*>(hws + mt * 32 + hoff3);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const float4 b = bb[x], gq = hh[x];
-                const float y0 = fmaxf(acc3[mt][4 * x + 0] + b.x, 0.f), y1 = fmaxf(acc3[mt][4 * x + 1] + b.y, 0.f);
-                const float y2 = fmaxf(acc3[mt][4 * x + 2] + b.z, 0.f), y3 = fmaxf(acc3[mt][4 * x + 3] + b.w, 0.f);
-                acc = __builtin_fmaf(gq.x, y0, acc), aabs = __builtin_fmaf(fabsf(gq.x), y0, aabs);
-                acc = __builtin_fmaf(gq.y, y1, acc), aabs = __builtin_fmaf(fabsf(gq.y), y1, aabs);
-                acc = __builtin_fmaf(gq.z, y2, acc), aabs = __builtin_fmaf(fabsf(gq.z), y2, aabs);
-                acc = __builtin_fmaf(gq.w, y3, acc), aabs = __builtin_fmaf(fabsf(gq.w), y3, aabs);
-            }
-        }
-        // both half-waves hold the pair's partial sums: combine
-        const float logit = (acc + __uint_as_float(el_partner32(__float_as_uint(acc), h))) + hbias;
-        aabs += __uint_as_float(el_partner32(__float_as_uint(aabs), h));
-        nrm1 += __uint_as_float(el_partner32(__float_as_uint(nrm1), h));
-        nrm2 += __uint_as_float(el_partner32(__float_as_uint(nrm2), h));
-        dn1 += __uint_as_float(el_partner32(__float_as_uint(dn1), h));
-        dn2 += __uint_as_float(el_partner32(__float_as_uint(dn2), h));
-        // ---------------- the pair's error bound (header) ------------------------------------------------------------------------
-        const float r1 = sqrtf(nrm1) * 1.0001f, r2 = sqrtf(nrm2) * 1.0001f;
-        const float dh1 = q.Rn[il] + sqrtf(dn1) * 1.0001f + 2.4e-7f * r1;
+        const float logit = acc + hbias;
+        const float s2 = cs[0], d2 = cs[1], g2 = cs[2], s3 = cs[3], d3 = cs[4], g3 = cs[5], hwn = cs[6];
+        const float uh = 4.886e-4f;                        // > 2^-11 (1 + 2^-11): one rounding to half, against the rounded value
+        // (+ 1.5e-3: v_dot2_f32_f16 may drop subnormal halves, 512 squares below 2^-28 each)
+        const float r1 = sqrtf(nrm1) * 1.0001f + 1.5e-3f, r2 = sqrtf(nrm2) * 1.0001f;
+        const float dh1 = rni + ru + uh * r1 + 2.4e-7f * r1;
         const float dz2 = s2 * dh1 + d2 * (r1 + dh1) + g2 * (r1 + dh1);
-        const float dh2 = dz2 + sqrtf(dn2) * 1.0001f + 2.4e-7f * r2;
+        const float dh2 = dz2 + uh * r2 + 2.4e-7f * r2;
         const float dz3 = s3 * dh2 + d3 * (r2 + dh2) + g3 * (r2 + dh2);
         const float E = 1.02f * hwn * dz3 + 4e-5f * (aabs + fabsf(hbias)) + 1e-30f;
         // an activation past the half-precision range (inf, then NaN) leaves nothing to bound: the pair goes to the exact kernel
         const bool bounded = E < INFINITY && fabsf(logit) < INFINITY;
         const float lo = bounded ? logit - E : -INFINITY, up = bounded ? logit + E : INFINITY;
-        // ---------------- upper bounds out; the slice's k largest lower bounds of unmasked items (lanes 0..31 carry the 32 pairs) --------
-        if (valid && h == 0) uprow[pos] = up;
-        bool hit = valid && h == 0 && (lo >= tau);
+        if (valid) uprow[pos] = up;
+        bool hit = valid && (lo >= tau);
         if (hit && use_excl) hit = !el_row_contains(p.t.excl_indices, e0, e1, gitem);
         const u64 bal = __ballot(hit);
         if (bal) {
@@ -1007,14 +945,175 @@ __global__ __launch_bounds__(NSW * 64) void k_nmf_screen(NsParams p, NsScreenPar
             tau = el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
             cnt = cnt < p.t.k ? cnt : p.t.k;
         }
+    };
+
+    for (int tile = 0; tile < T; ++tile) {
+        const int par = tile & 1;
+        // ---------------- P1: x' tile in packed half arithmetic, ||x'||^2, mf part -------------------------------------------------
+#ifdef EXP_SKIP_P1
+        if (tile == 0)
+#endif
+        {
+            float nrm1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int c = pj + 16 * i;
+                union {
+                    uint4 u;
+                    ns_h2 v[4];
+                } pi, au, xq;
+                pi.u = pre[i];                            // (zero past the live pieces, like aus: x' = 0 there)
+                au.u = *reinterpret_cast<const uint4*>(aus + 8 * c);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    xq.v[x] = __builtin_elementwise_max(au.v[x] + pi.v[x], (ns_h2)(_Float16)0);      // v_pk_add_f16, v_pk_max_f16
+                    nrm1 = __builtin_amdgcn_fdot2(xq.v[x], xq.v[x], nrm1, false);
+                }
+                // row ks = c / 2, slot (32 g + pair) ^ (2 (ks & 3) + g): the 8 lanes of a store group (one pair, 4 k-steps x 2 halves)
+                // land in 8 different 16-byte columns instead of one
+                *reinterpret_cast<uint4*>(xs + (size_t)(c >> 1) * 1024 + (size_t)((((c & 1) * 32 + pp) ^ (2 * ((c >> 1) & 3) + (c & 1))) * 16)) = xq.u;
+            }
+            float acc = 0.f, aabs = 0.f;
+            if (p.FP > 0) {
+                const int64_t pos = pos_lo + (int64_t)tile * 32 + pp;
+                const int64_t il = pos < pos_hi ? pos : pos_lo;
+                const float* irow = p.Imf + il * (int64_t)p.F;
+                int it = 0;
+                for (int f0 = 4 * pj; f0 < p.F; f0 += 64, ++it) {
+                    float v[4];
+                    if (vecf) {
+                        const float4 x0 = it == 0 ? mpre[0] : (it == 1 ? mpre[1] : *reinterpret_cast<const float4*>(irow + f0));
+                        v[0] = x0.x, v[1] = x0.y, v[2] = x0.z, v[3] = x0.w;
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) v[x] = (f0 + x) < p.F ? irow[f0 + x] : 0.f;
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const float t0 = ums[f0 + x] * v[x];
+                        acc = __builtin_fmaf(hms[f0 + x], t0, acc), aabs = __builtin_fmaf(fabsf(hms[f0 + x]), fabsf(t0), aabs);
+                    }
+                }
+            }
+            nrm1 = el_group_sum(nrm1, 16), acc = el_group_sum(acc, 16), aabs = el_group_sum(aabs, 16);
+            if (pj == 0) {
+                float* o = pq1 + par * 128 + pp;
+                o[0] = nrm1, o[32] = acc, o[64] = aabs, o[96] = rpre;
+            }
+            if (tile + 1 < T) prefetch(tile + 1);
+        }
+        __syncthreads();
+        // ---------------- P2: layer 2, this wave's 32 features x the tile's 32 pairs ----------------------------------------------
+#ifdef EXP_SKIP_P2
+        if (w < NT2 && tile == 0) {
+#else
+        if (w < NT2) {
+#endif
+            floatx16 ca;                                   // (one chain: a matrix instruction that accumulates onto its predecessor's
+#pragma unroll                                           //  result issues back to back, and the other wave of the SIMD fills what is left)
+            for (int r = 0; r < 16; ++r) ca[r] = 0.f;
+            const char* xl[4];                              // (the swizzle of P1: slot ^ (2 (ks & 3) + h))
+#pragma unroll
+            for (int x = 0; x < 4; ++x) xl[x] = xs + (size_t)((lane ^ h) ^ (2 * x)) * 16;
+            // B fragments four k-steps ahead of the matrix instructions that use them (left alone the compiler hoists all NSTM loads)
+            ns_h8 bq[2][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) bq[0][x] = *reinterpret_cast<const ns_h8*>(xl[x] + x * 1024);
+#pragma unroll
+            for (int g4 = 0; g4 < NSTM / 4; ++g4) {
+                if (g4 + 1 < NSTM / 4) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) bq[(g4 + 1) & 1][x] = *reinterpret_cast<const ns_h8*>(xl[x] + (4 * (g4 + 1) + x) * 1024);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[4 * g4 + x], bq[g4 & 1][x], ca, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // y' = h(relu(z2' + b2)): registers 0..7 are this lane's B fragment of layer-3 k-step 2 w, 8..15 of 2 w + 1 (W3 image order)
+            const float4* bb = reinterpret_cast<const float4*>(b2s + w * 32 + h * 16);
+            float nrm2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float4 q0 = bb[2 * kk], q1 = bb[2 * kk + 1];
+                ns_f8 yv;
+                yv[0] = fmaxf(ca[8 * kk + 0] + q0.x, 0.f), yv[1] = fmaxf(ca[8 * kk + 1] + q0.y, 0.f);
+                yv[2] = fmaxf(ca[8 * kk + 2] + q0.z, 0.f), yv[3] = fmaxf(ca[8 * kk + 3] + q0.w, 0.f);
+                yv[4] = fmaxf(ca[8 * kk + 4] + q1.x, 0.f), yv[5] = fmaxf(ca[8 * kk + 5] + q1.y, 0.f);
+                yv[6] = fmaxf(ca[8 * kk + 6] + q1.z, 0.f), yv[7] = fmaxf(ca[8 * kk + 7] + q1.w, 0.f);
+                union {
+                    ns_h8 v;
+                    ns_h2 d[4];
+                } yq;
+                yq.v = __builtin_convertvector(yv, ns_h8);               // v_cvt_pk_f16_f32, round to nearest even
+#pragma unroll
+                for (int x = 0; x < 4; ++x) nrm2 = __builtin_amdgcn_fdot2(yq.d[x], yq.d[x], nrm2, false);
+                *reinterpret_cast<ns_h8*>(ys + (size_t)(2 * w + kk) * 1024 + (size_t)lane * 16) = yq.v;
+            }
+            nrm2 += __uint_as_float(el_partner32(__float_as_uint(nrm2), h));
+            if (h == 0) pq2[(par * 8 + w) * 32 + n] = nrm2;
+        }
+        __syncthreads();
+        // ---------------- P3: layer 3 + head, one 32-feature tile per wave; P4 of the previous tile on the first wave without one ----
+#ifdef EXP_SKIP_P3
+        if (w < NT3 && tile == 0) {
+#else
+        if (w < NT3) {
+#endif
+            floatx16 ca;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ca[r] = 0.f;
+            const char* yl = ys + (size_t)lane * 16;
+            const char* wl = w3s + (size_t)w * 1024 + n * 32 + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < NK3; ++ks)
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const ns_h8*>(wl + (size_t)ks * NT3 * 1024),
+                                                            *reinterpret_cast<const ns_h8*>(yl + ks * 1024), ca, 0, 0, 0);
+            const float4* bb = reinterpret_cast<const float4*>(b3s + w * 32 + h * 16);
+            const float4* hh = reinterpret_cast<const float4*>(hws + w * 32 + h * 16);
+            float acc = 0.f, aabs = 0.f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float4 b = bb[x], gq = hh[x];
+                const float y0 = fmaxf(ca[4 * x + 0] + b.x, 0.f), y1 = fmaxf(ca[4 * x + 1] + b.y, 0.f);
+                const float y2 = fmaxf(ca[4 * x + 2] + b.z, 0.f), y3 = fmaxf(ca[4 * x + 3] + b.w, 0.f);
+                acc = __builtin_fmaf(gq.x, y0, acc), aabs = __builtin_fmaf(fabsf(gq.x), y0, aabs);
+                acc = __builtin_fmaf(gq.y, y1, acc), aabs = __builtin_fmaf(fabsf(gq.y), y1, aabs);
+                acc = __builtin_fmaf(gq.z, y2, acc), aabs = __builtin_fmaf(fabsf(gq.z), y2, aabs);
+                acc = __builtin_fmaf(gq.w, y3, acc), aabs = __builtin_fmaf(fabsf(gq.w), y3, aabs);
+            }
+            acc += __uint_as_float(el_partner32(__float_as_uint(acc), h));
+            aabs += __uint_as_float(el_partner32(__float_as_uint(aabs), h));
+            if (h == 0) {
+                float* o = pq3 + (par * 4 + w) * 64 + n;
+                o[0] = acc, o[32] = aabs;
+            }
+#ifdef EXP_SKIP_P4
+        } else if (w == NSC_P4 && tile == 1) {
+#else
+        } else if (w == NSC_P4 && tile > 0) {
+#endif
+            finish_tile(tile - 1);                         // (its parity's sums are not rewritten before the next tile's phases, all past the barrier below)
+        }
+        __syncthreads();
     }
-    if (lane == 0) *cnt_s = cnt;
-    el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
-    const int nv = cnt < p.t.k ? cnt : p.t.k;
-    const int64_t orow = ((int64_t)s * (p.t.u_stop - p.t.u_start) + urel) * p.t.k;
-    for (int t = lane; t < p.t.k; t += 64) {
-        p.part_idx[orow + t] = t < nv ? el_key_item(keys[t]) : -1;
-        p.part_val[orow + t] = t < nv ? el_key_score(keys[t]) : -INFINITY;
+    if (w == NSC_P4 && T > 0) finish_tile(T - 1);
+    // one list per workgroup, filed under its first slice; the other seven stay empty for the merge
+    const int64_t nu = p.t.u_stop - p.t.u_start;
+    if (w == NSC_P4) {
+        if (lane == 0) *cnt_s = cnt;
+        el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
+        const int nv = cnt < p.t.k ? cnt : p.t.k;
+        const int64_t orow = ((int64_t)s0 * nu + urel) * p.t.k;
+        for (int t = lane; t < p.t.k; t += 64) {
+            p.part_idx[orow + t] = t < nv ? el_key_item(keys[t]) : -1;
+            p.part_val[orow + t] = t < nv ? el_key_score(keys[t]) : -INFINITY;
+        }
+    } else {
+        const int64_t orow = ((int64_t)(s0 + (w < NSC_P4 ? w + 1 : w)) * nu + urel) * p.t.k;
+        for (int t = lane; t < p.t.k; t += 64) {
+            p.part_idx[orow + t] = -1;
+            p.part_val[orow + t] = -INFINITY;
+        }
     }
 }
 
@@ -1101,15 +1200,16 @@ static int ns_launch(const NsParams& p, int64_t n_users, int nsplit, hipStream_t
     return 0;
 }
 
-template <int H2P, int H3P, int NSW>
+template <int H2P, int H3P, int NSTM>
 static int ns_launch_screen(const NsParams& p, const NsScreenParams& q, int64_t n_users, int nsplit, hipStream_t s) {
-    const size_t lds = (size_t)2 * NSB_KS * H2P * 32 + (size_t)(q.NST1 * 32 + H2P + 2 * H3P + 2 * (p.FP > 0 ? p.FP : 8) + 8) * 4 +
-                       (size_t)NSW * p.cap * 8 + (size_t)NSW * 16;
+    const size_t lds = (size_t)(NSTM + H2P / 16 + (H2P / 16) * (H3P / 32)) * 1024 +
+                       (size_t)(NSTM * 8 + H2P + 2 * H3P + 2 * (p.FP > 0 ? p.FP : 8) + 16 + 2 * 4 * 32 + 2 * 8 * 32 + 2 * 4 * 2 * 32) * 4 +
+                       (size_t)p.cap * 8 + 16;
     EL_REQUIRE(lds <= NS_LDS_LIMIT, "el_nmf_score_topk: the screened kernel needs %zu bytes of LDS", lds);
-    auto kern = k_nmf_screen<H2P, H3P, NSW>;
+    auto kern = k_nmf_screen<H2P, H3P, NSTM>;
     EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // (the slices of a user are numbered blockIdx.y * NSW + wave: NS_WAVES / NSW grid rows per grid row of the exact kernel)
-    EL_LAUNCH("k_nmf_screen", kern, dim3((unsigned)n_users, (unsigned)(nsplit * (NS_WAVES / NSW))), dim3(NSW * 64), lds, s, p, q);
+    // (one workgroup = the NS_WAVES slices one workgroup of the exact kernel covers)
+    EL_LAUNCH("k_nmf_screen", kern, dim3((unsigned)n_users, (unsigned)nsplit), dim3(NSC_WAVES * 64), lds, s, p, q);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -1136,7 +1236,7 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
     const bool cand = cand_indptr != nullptr;
     // screened route: half-precision matrix instruction + per-pair error bound first, the exact kernel on the surviving pairs (same lists, same
     // logit bits); a catalogue too small to be worth it, or a candidate list, takes the exact kernel alone
-    const bool screen = (flags & EL_NMF_SCREEN) != 0 && !cand && I_local >= 4096 && k <= 256;
+    const bool screen = (flags & EL_NMF_SCREEN) != 0 && !cand && I_local >= 4096 && k <= 256 && ns_up(st->units[0], 16) <= 512;
     // (el_nmf_screen_stats: what the exact kernel scores, and whether a call that asked for the screen goes without it)
     ctx->nmf_screen_cands = cand ? -1 : n_users * I_local;
     ctx->nmf_screen_fallback = (flags & EL_NMF_SCREEN) != 0 && !screen;
@@ -1216,12 +1316,20 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         qb.W2B = (u16*)(base + L.W2B), qb.W3B = (u16*)(base + L.W3B);
         qb.b2E = (float*)(base + L.b2E), qb.b3E = (float*)(base + L.b3E), qb.hwE = (float*)(base + L.hwE);
         qb.H1 = st->units[0], qb.H2 = st->units[1], qb.H3 = st->units[2], qb.F = q.F;
-        qb.H1Q = (int)ns_up(L.H1P, 32), qb.H2P = L.H2P, qb.H3P = L.H3P;
+        qb.H1Q = L.H1P <= 256 ? 256 : 512, qb.H2P = L.H2P, qb.H3P = L.H3P;
         int64_t nb = (int64_t)qb.H1Q * L.H2P;
         if ((int64_t)L.H2P * L.H3P > nb) nb = (int64_t)L.H2P * L.H3P;
         EL_LAUNCH("k_nmf_pack_h16", k_nmf_pack_h16, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, qb);
-        EL_LAUNCH("k_nmf_specnorm", k_nmf_specnorm, dim3(5), dim3(256), 0, s, (const float*)st->W[1], (int)st->units[0], (int)st->units[1],
-                  (const float*)st->W[2], (int)st->units[1], (int)st->units[2], (const float*)st->hw, (int)q.F, (float*)(base + L.cst));
+        {
+            NsSpec sp;
+            sp.W2 = st->W[1], sp.W3 = st->W[2], sp.hw = st->hw;
+            sp.K2 = st->units[0], sp.N2 = st->units[1], sp.K3 = st->units[1], sp.N3 = st->units[2], sp.F = q.F;
+            sp.gram = (float*)(base + L.gram), sp.cst = (float*)(base + L.cst);
+            float* trs = sp.cst + 16;
+            EL_LAUNCH("k_nmf_gram", k_nmf_gram, dim3(16, 4), dim3(256), 0, s, sp);
+            for (int step = 0; step < NS_SPEC_SQ; ++step) EL_LAUNCH("k_nmf_gram_sq", k_nmf_gram_sq, dim3(16, 4), dim3(256), 0, s, sp, step, trs);
+            EL_LAUNCH("k_nmf_spec_finish", k_nmf_spec_finish, dim3(5), dim3(256), 0, s, sp, (const float*)trs);
+        }
         // the half-precision image of PI follows the PI image (same rebuild flag), unless this workspace has not held one yet
         const bool have_pib = ctx->nmf_pib_ws == ws && claim;
         EL_LAUNCH("k_nmf_pib", k_nmf_pib, dim3((unsigned)((I_local + 3) / 4)), dim3(256), 0, s, (const float*)(base + L.PI), I_local, L.H1P,
@@ -1231,13 +1339,12 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         NsScreenParams sq;
         sq.W2B = qb.W2B, sq.W3B = qb.W3B, sq.PIB = (const u16*)(base + L.PIB), sq.Rn = (const float*)(base + L.Rn);
         sq.cst = (const float*)(base + L.cst), sq.b2E = qb.b2E, sq.b3E = qb.b3E, sq.hwE = qb.hwE;
-        sq.up = (float*)(base + L.upb), sq.NST1 = qb.H1Q / 32;
-        const char* ew = getenv("EL_NMF_SCREEN_WAVES");                  // (tuning knob; read per call: an evaluation call, not a hot loop)
-        const int nsw = ew ? atoi(ew) : 0;
-        if (L.H2P == 256) rc = (nsw == 8) ? ns_launch_screen<256, 128, 8>(p, sq, n_users, nsplit, s) : ns_launch_screen<256, 128, 4>(p, sq, n_users, nsplit, s);
-        else if (L.H2P == 128) rc = (nsw == 4) ? ns_launch_screen<128, 64, 4>(p, sq, n_users, nsplit, s) : ns_launch_screen<128, 64, 8>(p, sq, n_users, nsplit, s);
-        else if (L.H2P == 64) rc = ns_launch_screen<64, 32, 8>(p, sq, n_users, nsplit, s);
-        else rc = ns_launch_screen<32, 32, 8>(p, sq, n_users, nsplit, s);
+        sq.up = (float*)(base + L.upb), sq.hw = st->hw;
+        const bool k16 = L.H1P <= 256;
+        if (L.H2P == 256) rc = k16 ? ns_launch_screen<256, 128, 16>(p, sq, n_users, nsplit, s) : ns_launch_screen<256, 128, 32>(p, sq, n_users, nsplit, s);
+        else if (L.H2P == 128) rc = k16 ? ns_launch_screen<128, 64, 16>(p, sq, n_users, nsplit, s) : ns_launch_screen<128, 64, 32>(p, sq, n_users, nsplit, s);
+        else if (L.H2P == 64) rc = k16 ? ns_launch_screen<64, 32, 16>(p, sq, n_users, nsplit, s) : ns_launch_screen<64, 32, 32>(p, sq, n_users, nsplit, s);
+        else rc = k16 ? ns_launch_screen<32, 32, 16>(p, sq, n_users, nsplit, s) : ns_launch_screen<32, 32, 32>(p, sq, n_users, nsplit, s);
         if (rc) return rc;
         // the user's threshold: k-th largest lower bound over the slices' lists
         float* thr = (float*)(base + L.thr);
@@ -1254,9 +1361,9 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         EL_CHECK_HIP(hipStreamSynchronize(s));              // (an evaluation call: its results are read by the host next anyway)
         unsigned long long ncands = 0;
         memcpy(&ncands, hflag + 2, 8);
-        // worth it when the exact kernel is left with less than a quarter of the pairs (EL_NMF_SCREEN_MAXFRAC overrides)
+        // worth it when the exact kernel is left with less than half of the pairs (the screen costs a sixth of it; EL_NMF_SCREEN_MAXFRAC overrides)
         const char* ef = getenv("EL_NMF_SCREEN_MAXFRAC");
-        const double maxfrac = ef ? atof(ef) : 0.25;
+        const double maxfrac = ef ? atof(ef) : 0.5;
         const bool use = hflag[0] == 0 && (double)ncands <= maxfrac * (double)n_users * (double)I_local;
         if (use) ctx->nmf_screen_cands = (int64_t)ncands;
         ctx->nmf_screen_fallback = !use;

@@ -1335,15 +1335,27 @@ class NmfDeviceState:
     def score_topk_logits(self, u_start, u_stop, k, excl=None, cand=None, item_offset=0, I_local=None, items_unchanged=False, screen=None):
         """el_nmf_score_topk: the k best unmasked items of users [u_start, u_stop) by (logit desc, item asc) and their logits --
         layer 1 in its separable form, layers 2-3 and the head per (user, item) pair on fp32 MFMA tiles, selection fused.
-        screen (None = on unless EL_NMF_SCREEN=0; full-catalogue calls only): layers 2-3 first on the half-precision matrix instruction
-        with a per-pair error bound, the fp32 kernel on the surviving pairs -- the same lists and logit bits (EL_NMF_SCREEN in the header)."""
+        screen (full-catalogue calls only): layers 2-3 first on the half-precision matrix instruction with a per-pair error bound, the
+        fp32 kernel on the surviving pairs -- the same lists and logit bits (EL_NMF_SCREEN in the header).  True / False force it;
+        None (default; EL_NMF_SCREEN=1 / 0 in the environment force it too) screens, and when a call had to take the unscreened
+        route (the bound depends on the weights: el_nmf_screen_stats) leaves the next 15 calls unscreened before it tries again."""
         n = int(u_stop) - int(u_start)
         I_local = self.I - int(item_offset) if I_local is None else int(I_local)
-        if screen is None:
-            screen = os.environ.get("EL_NMF_SCREEN", "1") != "0"
+        auto = screen is None
+        if auto:
+            env = os.environ.get("EL_NMF_SCREEN", "auto")
+            if env in ("0", "1"):
+                screen, auto = env == "1", False
+            else:
+                screen = True
         screen = bool(screen) and cand is None
+        use = screen
+        if auto and screen and getattr(self, "_screen_skip", 0) > 0:
+            self._screen_skip -= 1
+            use = False
         need = int(self.ctx.lib.el_nmf_score_ws_bytes(self.ctx.handle, C.byref(self._c), n, I_local, int(k),
-                                                      1 if cand is not None else (2 if screen else 0)))
+                                                      1 if cand is not None else (2 if screen else 0)))   # (auto: room for the screen
+        #                                                                                   on every call, one workspace for the evaluation)
         if need == 0:
             raise _lib.ElliotHipError("el_nmf_score_topk does not take this network shape / k (NmfDeviceState.fused_supported)")
         ws = getattr(self, "_score_ws", None)
@@ -1356,12 +1368,14 @@ class NmfDeviceState:
         cp, ci = _csr_ptrs(cand)
         check(self.ctx.lib.el_nmf_score_topk(self.ctx.handle, self.ctx.stream(), C.byref(self._c), int(u_start), int(u_stop),
                                              int(item_offset), I_local, ep, ei, cp, ci, int(k), _ptr(out_idx), _ptr(out_val),
-                                             (_lib.EL_TOPK_ITEMS_UNCHANGED if items_unchanged else 0) | (_lib.EL_NMF_SCREEN if screen else 0),
+                                             (_lib.EL_TOPK_ITEMS_UNCHANGED if items_unchanged else 0) | (_lib.EL_NMF_SCREEN if use else 0),
                                              C.c_void_p(ws.data_ptr()), ws.numel()), "el_nmf_score_topk")
+        if auto and use and self.screen_stats()[1]:
+            self._screen_skip = 15
         return out_idx, out_val
 
     def screen_stats(self):
-        """(pairs the exact kernel scored, fell back to the unscreened route) of the last screened score_topk_logits call."""
+        """(pairs the exact fp32 kernel scored, a call that asked for the screen went without it) of the last score_topk_logits call."""
         pairs, fb = C.c_int64(0), C.c_int(0)
         self.ctx.lib.el_nmf_screen_stats(self.ctx.handle, C.byref(pairs), C.byref(fb))
         return int(pairs.value), bool(fb.value)

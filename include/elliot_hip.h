@@ -354,7 +354,7 @@ enum {
      * of the rounded weights and of their rounding errors, the pair's own activation norms and measured rounding residuals), the
      * fp32 kernel then only on the pairs whose upper bound reaches the user's k-th best lower bound: the same index lists and logit
      * bits.  Needs the workspace of el_nmf_score_ws_bytes(..., with_cand = 2); synchronises the stream once (a 16-byte flag read);
-     * takes the unscreened route when the bound leaves more than a quarter of the pairs (el_nmf_screen_stats tells).            */
+     * takes the unscreened route when the bound leaves more than half of the pairs (el_nmf_screen_stats tells).            */
     EL_NMF_SCREEN = 0x200
 };
 
