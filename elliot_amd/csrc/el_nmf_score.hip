@@ -120,7 +120,7 @@ static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, 
         L.b2E = take((size_t)L.H2P * 4);
         L.b3E = take((size_t)L.H3P * 4);
         L.hwE = take((size_t)L.H3P * 4);
-        L.PIB = take((size_t)(I_local > 0 ? I_local : 1) * L.H1P * 2);
+        L.PIB = take((size_t)(I_local > 0 ? I_local : 1) * ns_up(L.H1P, 256) * 2);
         L.Rn = take((size_t)(I_local > 0 ? I_local : 1) * 4);
         L.cst = take(256);                               // 8 constants, then the traces of the squarings (k_nmf_gram_sq)
         L.gram = take((size_t)4 * 2 * 65536 * 4);
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(NS_THREADS) void k_nmf_score(NsParams p) {
 //   y' = h(relu(z2' + b2)):   dh2 = ||y' - h2|| <= dz2 + uh ||y'|| + 4 u32 ||y'||      (ReLU is 1-Lipschitz)
 //   dz3 <= s3 dh2 + (d3 + g3) (||y'|| + dh2),   h3' = relu(z3' + b3) in fp32
 //   |logit' - logit| <= E = 1.02 ||hw_mlp||_2 dz3 + 4e-5 sum |head terms|   (mf part: the same fp32 products, another order)
-// ||x'|| and ||y'|| are the pair's own (summed in the kernel), the norms of the four matrices come from a power iteration on the
-// device per call (k_nmf_gram ...: upper bounds from the trace of (W^T W)^16).  Selection: k_nmf_screen writes the UPPER bound logit' + E of
+// ||x'|| and ||y'|| are the pair's own (summed in the kernel), the norms of the four matrices are computed on the device per
+// call (k_nmf_gram ...: upper bounds from the trace of (W^T W)^16).  Selection: k_nmf_screen writes the UPPER bound logit' + E of
 // every pair and keeps, per wave slice, the k largest LOWER bounds logit' - E of unmasked items; the merge of the slices gives the user's
 // threshold T = the k-th largest lower bound of the whole catalogue (k items are certainly at or above T, so nothing whose upper bound
 // is below T can be in the exact top-k); k_nmf_compact collects the unmasked items with upper bound >= T slice by slice, the exact
@@ -659,17 +659,17 @@ __global__ __launch_bounds__(256) void k_nmf_pack_h16(NsPackB q) {
 }
 
 // half-precision image of the PI rows + R_i = ||PI_i - h(PI_i)||_2 (one wave per item; skipped with the PI image when the items are unchanged)
-__global__ __launch_bounds__(256) void k_nmf_pib(const float* __restrict__ PI, int64_t I, int H1P, u16* __restrict__ PIB, float* __restrict__ Rn,
+__global__ __launch_bounds__(256) void k_nmf_pib(const float* __restrict__ PI, int64_t I, int H1P, int KP, u16* __restrict__ PIB, float* __restrict__ Rn,
                                                  const unsigned long long* __restrict__ rebuild) {
     if (rebuild && *rebuild == 0ull) return;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= I) return;
     float ss = 0.f;
-    for (int c = lane; c < H1P; c += 64) {
-        const float v = PI[row * H1P + c];
+    for (int c = lane; c < KP; c += 64) {                // rows of KP = 16 x the screen kernel's k-steps, zero past H1P
+        const float v = c < H1P ? PI[row * H1P + c] : 0.f;
         const u32 h = ns_f2h(v);
-        PIB[row * H1P + c] = (u16)h;
+        PIB[row * KP + c] = (u16)h;
         const float d = v - ns_h2f(h);
         ss = __builtin_fmaf(d, d, ss);
     }
@@ -785,6 +785,19 @@ __global__ __launch_bounds__(256) void k_nmf_spec_finish(NsSpec q, const float* 
     if ((m & 1) == 0) q.cst[m < 2 ? 2 : 5] = 3.4f * (float)K * 5.96e-8f * fro * 1.01f;
 }
 
+// sum over the aligned 16 lanes of a row, in every lane of the row (four v_add_f32 with row_ror: no LDS traffic)
+__device__ __forceinline__ float ns_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// workgroup barrier for LDS hand-overs only: waits for this wave's LDS operations, NOT for its global loads in flight (__syncthreads()
+// carries a fence that drains vmcnt as well -- the next tile's prefetched rows would be waited for at every barrier)
+__device__ __forceinline__ void ns_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct NsScreenParams {
     const u16 *W2B, *W3B, *PIB;
     const float *Rn, *cst, *b2E, *b3E, *hwE, *hw;        // hw: the head weights as the model holds them ([F mf ; H3 mlp])
@@ -816,9 +829,9 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
     float* b2s = reinterpret_cast<float*>(aus + NSTM * 16);    // [H2P] accumulator order
     float* b3s = b2s + H2P;                              // [H3P]
     float* hws = b3s + H3P;                              // [H3P]
-    float* ums = hws + H3P;                              // [FP]
-    float* hms = ums + (p.FP > 0 ? p.FP : 8);            // [FP]
-    float* cs = hms + (p.FP > 0 ? p.FP : 8);             // [8]
+    float* ums = hws + H3P;                              // [128]  (F <= 128 on this route, zero past F)
+    float* hms = ums + 128;                              // [128]
+    float* cs = hms + 128;                               // [8]
     float* rus = cs + 8;                                 // [8] per-wave parts of ||(PU_u + b1) - h(PU_u + b1)||^2
     float* pq1 = rus + 8;                                // [2 parity][4: nrm1, mf, |mf|, R_i][32]
     float* pq2 = pq1 + 2 * 4 * 32;                       // [2][8 waves][32]  nrm2 parts
@@ -857,8 +870,8 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
         b3s[t] = q.b3E[t];
         hws[t] = q.hwE[t];
     }
-    for (int t = tid; t < p.FP; t += NTH) {
-        ums[t] = t < p.F ? p.Umf[user * (int64_t)p.F + t] : 0.f;
+    for (int t = tid; t < 128; t += NTH) {
+        ums[t] = t < p.F ? p.Umf[user * (int64_t)p.F + t] : 0.f;      // (p.F = 0 without an mf part)
         hms[t] = t < p.F ? q.hw[t] : 0.f;
     }
     if (tid < 8) cs[tid] = q.cst[tid];
@@ -876,26 +889,23 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
     float* uprow = q.up + urel * p.t.I_local;
     // P1 roles: pair pp of the tile, piece lane pj of 16
     const int pp = tid >> 4, pj = tid & 15;
-    const int npv = p.H1P / 8;                           // live 16-byte pieces of a PI row
-    const bool vecf = (p.F & 3) == 0;
     uint4 pre[CPT];
-    float4 mpre[2];                                      // this thread's first two 4-feature pieces of the item's mf row (F <= 128: all)
+    float4 mpre[2];                                      // this thread's two 4-feature pieces of the item's mf row (F <= 128, F % 4 == 0)
     float rpre = 0.f;                                    // R_i (thread 0 of the pair)
+    const bool mf0 = 4 * pj < p.F, mf1 = 4 * pj + 64 < p.F;
     auto prefetch = [&](int tile) {
+#ifdef EXP_SAMEROW
+        tile = 0;
+#endif
         const int64_t pos = pos_lo + (int64_t)tile * 32 + pp;
         const int64_t il = pos < pos_hi ? pos : pos_lo;
-        const uint4* row = reinterpret_cast<const uint4*>(q.PIB + il * (int64_t)p.H1P);
+        const uint4* row = reinterpret_cast<const uint4*>(q.PIB + il * (int64_t)(NSTM * 16)) + pj;   // (rows padded with zeros to NSTM k-steps)
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = pj + 16 * i;
-            pre[i] = c < npv ? row[c] : make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int i = 0; i < CPT; ++i) pre[i] = row[16 * i];
         if (pj == 0) rpre = q.Rn[il];
-        if (p.FP > 0 && vecf) {
-            const float* irow = p.Imf + il * (int64_t)p.F;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) mpre[i] = (4 * pj + 64 * i) < p.F ? *reinterpret_cast<const float4*>(irow + 4 * pj + 64 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const float* irow = p.Imf + il * (int64_t)p.F + 4 * pj;
+        mpre[0] = mf0 ? *reinterpret_cast<const float4*>(irow) : make_float4(0.f, 0.f, 0.f, 0.f);
+        mpre[1] = mf1 ? *reinterpret_cast<const float4*>(irow + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     if (T > 0) prefetch(0);
     __syncthreads();
@@ -974,35 +984,23 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
                 *reinterpret_cast<uint4*>(xs + (size_t)(c >> 1) * 1024 + (size_t)((((c & 1) * 32 + pp) ^ (2 * ((c >> 1) & 3) + (c & 1))) * 16)) = xq.u;
             }
             float acc = 0.f, aabs = 0.f;
-            if (p.FP > 0) {
-                const int64_t pos = pos_lo + (int64_t)tile * 32 + pp;
-                const int64_t il = pos < pos_hi ? pos : pos_lo;
-                const float* irow = p.Imf + il * (int64_t)p.F;
-                int it = 0;
-                for (int f0 = 4 * pj; f0 < p.F; f0 += 64, ++it) {
-                    float v[4];
-                    if (vecf) {
-                        const float4 x0 = it == 0 ? mpre[0] : (it == 1 ? mpre[1] : *reinterpret_cast<const float4*>(irow + f0));
-                        v[0] = x0.x, v[1] = x0.y, v[2] = x0.z, v[3] = x0.w;
-                    } else {
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) v[x] = (f0 + x) < p.F ? irow[f0 + x] : 0.f;
-                    }
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const float t0 = ums[f0 + x] * v[x];
-                        acc = __builtin_fmaf(hms[f0 + x], t0, acc), aabs = __builtin_fmaf(fabsf(hms[f0 + x]), fabsf(t0), aabs);
-                    }
-                }
+            for (int i = 0; i < 2; ++i) {                  // (all zero without an mf part)
+                const float4 uu = *reinterpret_cast<const float4*>(ums + 4 * pj + 64 * i), ww = *reinterpret_cast<const float4*>(hms + 4 * pj + 64 * i);
+                const float t0 = uu.x * mpre[i].x, t1 = uu.y * mpre[i].y, t2 = uu.z * mpre[i].z, t3 = uu.w * mpre[i].w;
+                acc = __builtin_fmaf(ww.x, t0, acc), aabs = __builtin_fmaf(fabsf(ww.x), fabsf(t0), aabs);
+                acc = __builtin_fmaf(ww.y, t1, acc), aabs = __builtin_fmaf(fabsf(ww.y), fabsf(t1), aabs);
+                acc = __builtin_fmaf(ww.z, t2, acc), aabs = __builtin_fmaf(fabsf(ww.z), fabsf(t2), aabs);
+                acc = __builtin_fmaf(ww.w, t3, acc), aabs = __builtin_fmaf(fabsf(ww.w), fabsf(t3), aabs);
             }
-            nrm1 = el_group_sum(nrm1, 16), acc = el_group_sum(acc, 16), aabs = el_group_sum(aabs, 16);
+            nrm1 = ns_row16_sum(nrm1), acc = ns_row16_sum(acc), aabs = ns_row16_sum(aabs);
             if (pj == 0) {
                 float* o = pq1 + par * 128 + pp;
                 o[0] = nrm1, o[32] = acc, o[64] = aabs, o[96] = rpre;
             }
             if (tile + 1 < T) prefetch(tile + 1);
         }
-        __syncthreads();
+        ns_lds_barrier();
         // ---------------- P2: layer 2, this wave's 32 features x the tile's 32 pairs ----------------------------------------------
 #ifdef EXP_SKIP_P2
         if (w < NT2 && tile == 0) {
@@ -1052,7 +1050,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
             nrm2 += __uint_as_float(el_partner32(__float_as_uint(nrm2), h));
             if (h == 0) pq2[(par * 8 + w) * 32 + n] = nrm2;
         }
-        __syncthreads();
+        ns_lds_barrier();
         // ---------------- P3: layer 3 + head, one 32-feature tile per wave; P4 of the previous tile on the first wave without one ----
 #ifdef EXP_SKIP_P3
         if (w < NT3 && tile == 0) {
@@ -1094,7 +1092,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
 #endif
             finish_tile(tile - 1);                         // (its parity's sums are not rewritten before the next tile's phases, all past the barrier below)
         }
-        __syncthreads();
+        ns_lds_barrier();
     }
     if (w == NSC_P4 && T > 0) finish_tile(T - 1);
     // one list per workgroup, filed under its first slice; the other seven stay empty for the merge
@@ -1203,7 +1201,7 @@ static int ns_launch(const NsParams& p, int64_t n_users, int nsplit, hipStream_t
 template <int H2P, int H3P, int NSTM>
 static int ns_launch_screen(const NsParams& p, const NsScreenParams& q, int64_t n_users, int nsplit, hipStream_t s) {
     const size_t lds = (size_t)(NSTM + H2P / 16 + (H2P / 16) * (H3P / 32)) * 1024 +
-                       (size_t)(NSTM * 8 + H2P + 2 * H3P + 2 * (p.FP > 0 ? p.FP : 8) + 16 + 2 * 4 * 32 + 2 * 8 * 32 + 2 * 4 * 2 * 32) * 4 +
+                       (size_t)(NSTM * 8 + H2P + 2 * H3P + 2 * 128 + 16 + 2 * 4 * 32 + 2 * 8 * 32 + 2 * 4 * 2 * 32) * 4 +
                        (size_t)p.cap * 8 + 16;
     EL_REQUIRE(lds <= NS_LDS_LIMIT, "el_nmf_score_topk: the screened kernel needs %zu bytes of LDS", lds);
     auto kern = k_nmf_screen<H2P, H3P, NSTM>;
@@ -1236,7 +1234,8 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
     const bool cand = cand_indptr != nullptr;
     // screened route: half-precision matrix instruction + per-pair error bound first, the exact kernel on the surviving pairs (same lists, same
     // logit bits); a catalogue too small to be worth it, or a candidate list, takes the exact kernel alone
-    const bool screen = (flags & EL_NMF_SCREEN) != 0 && !cand && I_local >= 4096 && k <= 256 && ns_up(st->units[0], 16) <= 512;
+    const bool screen = (flags & EL_NMF_SCREEN) != 0 && !cand && I_local >= 4096 && k <= 256 && ns_up(st->units[0], 16) <= 512 &&
+                        (!st->use_mf || ((st->F & 3) == 0 && st->F <= 128));
     // (el_nmf_screen_stats: what the exact kernel scores, and whether a call that asked for the screen goes without it)
     ctx->nmf_screen_cands = cand ? -1 : n_users * I_local;
     ctx->nmf_screen_fallback = (flags & EL_NMF_SCREEN) != 0 && !screen;
@@ -1333,7 +1332,7 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         // the half-precision image of PI follows the PI image (same rebuild flag), unless this workspace has not held one yet
         const bool have_pib = ctx->nmf_pib_ws == ws && claim;
         EL_LAUNCH("k_nmf_pib", k_nmf_pib, dim3((unsigned)((I_local + 3) / 4)), dim3(256), 0, s, (const float*)(base + L.PI), I_local, L.H1P,
-                  (u16*)(base + L.PIB), (float*)(base + L.Rn), have_pib ? (const unsigned long long*)(ctl + 2) : (const unsigned long long*)nullptr);
+                  (int)(L.H1P <= 256 ? 256 : 512), (u16*)(base + L.PIB), (float*)(base + L.Rn), have_pib ? (const unsigned long long*)(ctl + 2) : (const unsigned long long*)nullptr);
         ctx->nmf_pib_ws = ws;
         EL_CHECK_HIP(hipMemsetAsync(base + L.sflag, 0, 16, s));
         NsScreenParams sq;
