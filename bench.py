@@ -1004,18 +1004,38 @@ def neumf_leg(args, ctx):
             st.recommend(s0, s0 + nu, args.k, excl=pos, items_unchanged=blk[0] > 1)
 
         dt_k, rep_k = timed(ctx, 1, topk_step, ws_, ks)
+        pairs, fell_back = st.screen_stats()
         pair_flops = 2.0 * (units[0] * units[1] + units[1] * units[2])
-        ksec = rep_k.live.get("k_nmf_score", rep_k.get("k_nmf_score", (1, 0.0)))
-        ksec = ksec[1] / max(ksec[0], 1) * 1e-3
-        ach_k = pair_flops * nu * I / ksec / 1e12 if ksec > 0 else 0.0
+
+        def kernel_tflops(name):
+            c, ms_k = rep_k.live.get(name, rep_k.get(name, (1, 0.0)))
+            sec = ms_k / max(c, 1) * 1e-3
+            return pair_flops * nu * I / sec / 1e12 if sec > 0 else 0.0
+
+        # the same block through the fp32 kernel alone (screen=False): what the screened route is measured against
+        def exact_step():
+            st.score_topk_logits(0, nu, args.k + 2, excl=pos, items_unchanged=True, screen=False)
+
+        dt_x, rep_x = timed(ctx, 1, exact_step, 0, 1)
+        xc, xms = rep_x.live.get("k_nmf_score", rep_x.get("k_nmf_score", (1, 0.0)))
+        ach_x = pair_flops * nu * I / (xms / max(xc, 1) * 1e-3) / 1e12 if xms > 0 else 0.0
+        screened = "k_nmf_screen" in rep_k and not fell_back
+        ach_k = kernel_tflops("k_nmf_screen") if screened else kernel_tflops("k_nmf_score")
+        peak_k = MFMA_BF16_PEAK_TFLOPS if screened else MFMA_F32_PEAK_TFLOPS     # (f16 and bf16 share the dense rate)
         tk = {"value": nu * ks / dt_k, "unit": "users/s", "ms_per_step": dt_k / ks * 1e3, "repeats_ms_per_step": rep_k.repeats_ms,
               "steps": ks, "users_per_step": nu,
               "what": f"NeuMF get_recs + get_top_k (neural_matrix_factorization_model.py:119-148) of {nu} users x {I} items, k={args.k}: "
-                      f"el_nmf_score_topk (layer 1 separable, layers 2-3 + head per pair on fp32 MFMA, selection fused) + sigmoid link "
-                      f"+ re-rank; the reference's route materialises {nu} x {I} x {4 * F} activations",
-              "roofline": {"kernel": "k_nmf_score", "bound": "mfma", "achieved": ach_k, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach_k / MFMA_F32_PEAK_TFLOPS, "traffic": ntraffic.get("k_nmf_score") if nu == 128 else None,
-                           "traffic_source": nnote, "dtype": "f32",
+                      f"el_nmf_score_topk (layer 1 separable; EL_NMF_SCREEN: layers 2-3 on the half-precision matrix instruction with a "
+                      f"per-pair error bound, then layers 2-3 + head on fp32 MFMA for the pairs that can still reach the list; selection "
+                      f"fused; lists and logit bits are the fp32 kernel's) + sigmoid link + re-rank; the reference's route materialises "
+                      f"{nu} x {I} x {4 * F} activations",
+              "screen": {"used": bool(screened), "exact_pairs": pairs, "exact_pairs_frac": pairs / float(nu * I), "fell_back": bool(fell_back)},
+              "unscreened": {"ms_per_step": dt_x * 1e3, "users_per_s": nu / dt_x, "k_nmf_score_TFLOPs": ach_x,
+                             "k_nmf_score_frac_of_f32_mfma_peak": ach_x / MFMA_F32_PEAK_TFLOPS},
+              "roofline": {"kernel": "k_nmf_screen" if screened else "k_nmf_score", "bound": "mfma", "achieved": ach_k, "peak": peak_k,
+                           "unit": "TFLOP/s", "frac": ach_k / peak_k,
+                           "traffic": ntraffic.get("k_nmf_screen" if screened else "k_nmf_score") if nu == 128 else None,
+                           "traffic_source": nnote, "dtype": "f16" if screened else "f32",
                            "flops_per_pair": pair_flops, "flops_per_pair_reference_form": 2.0 * (2 * F * units[0] + units[0] * units[1] + units[1] * units[2]),
                            "kernels_ms_per_step": {n: v[1] / ks for n, v in rep_k.items()}}}
     mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # fwd 36 F^2 + 4 F per sample, x3 fwd + bwd

@@ -894,9 +894,6 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
     float rpre = 0.f;                                    // R_i (thread 0 of the pair)
     const bool mf0 = 4 * pj < p.F, mf1 = 4 * pj + 64 < p.F;
     auto prefetch = [&](int tile) {
-#ifdef EXP_SAMEROW
-        tile = 0;
-#endif
         const int64_t pos = pos_lo + (int64_t)tile * 32 + pp;
         const int64_t il = pos < pos_hi ? pos : pos_lo;
         const uint4* row = reinterpret_cast<const uint4*>(q.PIB + il * (int64_t)(NSTM * 16)) + pj;   // (rows padded with zeros to NSTM k-steps)
@@ -960,9 +957,6 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
     for (int tile = 0; tile < T; ++tile) {
         const int par = tile & 1;
         // ---------------- P1: x' tile in packed half arithmetic, ||x'||^2, mf part -------------------------------------------------
-#ifdef EXP_SKIP_P1
-        if (tile == 0)
-#endif
         {
             float nrm1 = 0.f;
 #pragma unroll
@@ -1002,11 +996,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
         }
         ns_lds_barrier();
         // ---------------- P2: layer 2, this wave's 32 features x the tile's 32 pairs ----------------------------------------------
-#ifdef EXP_SKIP_P2
-        if (w < NT2 && tile == 0) {
-#else
         if (w < NT2) {
-#endif
             floatx16 ca;                                   // (one chain: a matrix instruction that accumulates onto its predecessor's
 #pragma unroll                                           //  result issues back to back, and the other wave of the SIMD fills what is left)
             for (int r = 0; r < 16; ++r) ca[r] = 0.f;
@@ -1052,11 +1042,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
         }
         ns_lds_barrier();
         // ---------------- P3: layer 3 + head, one 32-feature tile per wave; P4 of the previous tile on the first wave without one ----
-#ifdef EXP_SKIP_P3
-        if (w < NT3 && tile == 0) {
-#else
         if (w < NT3) {
-#endif
             floatx16 ca;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ca[r] = 0.f;
@@ -1085,11 +1071,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
                 float* o = pq3 + (par * 4 + w) * 64 + n;
                 o[0] = acc, o[32] = aabs;
             }
-#ifdef EXP_SKIP_P4
-        } else if (w == NSC_P4 && tile == 1) {
-#else
         } else if (w == NSC_P4 && tile > 0) {
-#endif
             finish_tile(tile - 1);                         // (its parity's sums are not rewritten before the next tile's phases, all past the barrier below)
         }
         ns_lds_barrier();

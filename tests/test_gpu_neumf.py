@@ -207,10 +207,15 @@ def test_neumf_step_at_d128_matches_oracle(ctx):
             own = float(np.sqrt(np.mean((np.asarray(b32, np.float64).reshape(a.shape) - b64) ** 2)))
             tol = max(2e-5 * scale, 64 * own)
             err = np.abs(a - b64)
-            # a ReLU that takes the other branch moves ONE sample's contribution in a whole column of that layer's (and the
-            # layers' below) kernel gradient: up to a few columns may carry such a 1e-3-of-scale difference
+            # a ReLU that takes the other branch moves ONE sample's contribution: in a whole column of that layer's kernel gradient
+            # (up to a few columns may carry such a 1e-3-of-scale difference) -- and, through delta = (delta' W^T) * relu', in EVERY
+            # entry of the kernel gradients of the layers below it, by one sample's share of a 65 536-term sum (a few 1e-4 of the
+            # largest entry; which units sit within round-off of 0 changes from run to run with the order of the embedding atomics
+            # of step 1, about one run in three has such a unit in the top layer)
             frac = 0.05 if isinstance(what, tuple) else 1e-3
-            assert float((err > tol).mean()) <= frac and float(err.max()) <= 0.05 * scale, (s, what, float(err.max()), tol, scale)
+            few_off = float((err > tol).mean()) <= frac
+            one_sample = isinstance(what, tuple) and float(err.max()) <= 5e-3 * scale
+            assert (few_off or one_sample) and float(err.max()) <= 0.05 * scale, (s, what, float((err > tol).mean()), float(err.max()), tol, scale)
 
         for k in names + ["hw", "hb"]:
             close(got_g[k], g[k], g64[k], k)
