@@ -576,6 +576,181 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float* __restrict__ w
     C[m * ldc + n] = el_act(s, act);
 }
 
+// ---- fp32 GEMM on the bf16 matrix instruction: three-way split operands ---------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of v_mfma_f32_32x32x16_bf16.  An fp32 number is the exact sum of three bf16 numbers
+// (a = a0 + a1 + a2 + eps, |eps| <= 2^-24 |a|: a0 = the upper 16 bits of a, a1 = the upper 16 bits of a - a0, a2 = those of
+// a - a0 - a1 -- both differences are exact in fp32), and a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + O(2^-24 |a b|):
+// six bf16 products per fp32 product, each exact in the instruction's fp32 accumulator arithmetic, 16 / 6 = 2.7x the fp32
+// instruction's rate at the rounding level of fp32 itself (the terms left out, a1 b2 + a2 b1 + a2 b2, are below 3 * 2^-24 |a b|;
+// a different summation order of the same fp32 products moves a dot product by more).  The parity tests of the Dense layers
+// (tests/test_gpu_dense.py, test_gpu_neumf.py, test_gpu_gemm.py) hold at their fp32 tolerances; EL_GEMM_SPLIT=0 selects the
+// fp32 instruction (k_gemm_f32_v above).
+//   * block tile 128 x 128, BK = 32 (two k-steps), 256 threads, two workgroups per CU
+//   * staging: global -> registers (8 float4 per thread, the next tile in flight under the matrix instructions) -> split -> LDS as
+//     FRAGMENT images, one per plane (below)
+//   * per k-step and consumer wave 15 fragment loads (ds_read_b128) and 24 matrix instructions (lowest-order products first)
+//   * gridDim.z splits K (few tiles, long K: the dW products over the batch); partials go to the workspace, k_gemm_reduce sums them
+constexpr int B3_BM = 128, B3_BN = 128, B3_BK = 32;
+typedef __bf16 b3_h8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive k values of one row -> the three planes' 16-byte fragment pieces
+__device__ __forceinline__ void b3_split8(const float (&v)[8], uint4& p0, uint4& p1, uint4& p2) {
+    unsigned int h0[8], h1[8], h2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned int u = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u & 0xffff0000u);
+        const unsigned int u1 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        h0[e] = u, h1[e] = u1, h2[e] = __float_as_uint(r2);
+    }
+    // upper halves of two words into one: bytes (hi.3, hi.2, lo.3, lo.2)
+    p0 = make_uint4(__builtin_amdgcn_perm(h0[1], h0[0], 0x07060302u), __builtin_amdgcn_perm(h0[3], h0[2], 0x07060302u),
+                    __builtin_amdgcn_perm(h0[5], h0[4], 0x07060302u), __builtin_amdgcn_perm(h0[7], h0[6], 0x07060302u));
+    p1 = make_uint4(__builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u), __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u),
+                    __builtin_amdgcn_perm(h1[5], h1[4], 0x07060302u), __builtin_amdgcn_perm(h1[7], h1[6], 0x07060302u));
+    p2 = make_uint4(__builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u), __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u),
+                    __builtin_amdgcn_perm(h2[5], h2[4], 0x07060302u), __builtin_amdgcn_perm(h2[7], h2[6], 0x07060302u));
+}
+
+// One operand tile (128 rows x 32 k) from global memory into 8 float4 registers of each of 128 threads (t = 0..127), then split and
+// stored as the planes' fragment images img[plane][q = k / 8][pos] (16 bytes each: 8 consecutive k of one row), where image position
+// pos <-> row 4 (pos & 31) + (pos >> 5): the 32-row tile T = pos / 32 of the matrix instruction holds the rows = T (mod 4) -- a
+// permutation the epilogue undoes, chosen so that BOTH storage orders stage with conflict-free 16-byte LDS stores (the 8 lanes of a
+// store group write 8 consecutive positions) and the fragment reads are one contiguous kilobyte per wave-instruction:
+//   KC (operand stored with k contiguous, row stride ld): thread t = position t, the 32 k values of its row (8 float4)
+//   XC (row index contiguous, k stride ld): thread t = rows 4 r4 .. 4 r4 + 3 (r4 = t & 31: one float4) x the 8 k values of q = t / 32
+// Out of range (row >= nX, k >= k_end): zeros, fetched from a block of zeros -- a select on the address, no branch (a float4 is
+// whole inside or whole outside: alignment contract of the fast path).
+template <bool KC>
+__device__ __forceinline__ void b3_load(const float* __restrict__ X, int64_t ld, int64_t nX, int64_t x0, int64_t k_end, int64_t k0, int t,
+                                        const float* __restrict__ zeros, float4 (&rg)[8]) {
+    if (KC) {
+        const int64_t row = x0 + 4 * (t & 31) + (t >> 5);
+        const float* src = X + row * ld + k0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rg[j] = *reinterpret_cast<const float4*>((row < nX && k0 + 4 * j < k_end) ? src + 4 * j : zeros);
+    } else {
+        const int64_t row = x0 + 4 * (t & 31);
+        const int q = t >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int64_t k = k0 + 8 * q + kk;
+            rg[kk] = *reinterpret_cast<const float4*>((row < nX && k < k_end) ? X + k * ld + row : zeros);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void b3_store(const float4 (&rg)[8], char* img, int t) {
+    constexpr int PLANE = 4 * 128 * 16;                 // bytes of one plane: four 8-k groups x 128 positions x 16
+    if (KC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v[8] = {rg[2 * q].x, rg[2 * q].y, rg[2 * q].z, rg[2 * q].w, rg[2 * q + 1].x, rg[2 * q + 1].y, rg[2 * q + 1].z, rg[2 * q + 1].w};
+            uint4 p0, p1, p2;
+            b3_split8(v, p0, p1, p2);
+            char* dst = img + (q * 128 + t) * 16;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + PLANE) = p1;
+            *reinterpret_cast<uint4*>(dst + 2 * PLANE) = p2;
+        }
+    } else {
+        const int r4 = t & 31, q = t >> 5;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            float v[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) v[kk] = mi == 0 ? rg[kk].x : (mi == 1 ? rg[kk].y : (mi == 2 ? rg[kk].z : rg[kk].w));
+            uint4 p0, p1, p2;
+            b3_split8(v, p0, p1, p2);
+            char* dst = img + (q * 128 + mi * 32 + r4) * 16;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + PLANE) = p1;
+            *reinterpret_cast<uint4*>(dst + 2 * PLANE) = p2;
+        }
+    }
+}
+
+// workgroup barrier for the LDS hand-over only: __syncthreads() carries a fence that also drains the global loads in flight --
+// every k tile would wait out a trip to memory
+__device__ __forceinline__ void b3_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 256 threads = 4 waves, two workgroups per CU (one stages while the other runs its matrix instructions): threads 0..127 stage the
+// A tile, 128..255 the B tile; wave w computes the row tile w (rows = w mod 4 of the block's 128) against all four column tiles, so
+// that a lane ends up with four ADJACENT columns (4 n + 0..3) of each of its rows: the epilogue stores float4, rows of 512
+// contiguous bytes per wave-instruction.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
+    constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * IMG];   // A image, B image (48 KB)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, g = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * B3_BM, n0 = (int64_t)blockIdx.x * B3_BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * p.kchunk;
+    const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+    const int t = tid & 127;
+    const bool stA = tid < 128;
+    float4 rg[8];
+    auto fetch = [&](int64_t k0) {
+        if (stA) b3_load<AKC>(p.A, p.lda, p.M, m0, kend, k0, t, p.zeros, rg);
+        else b3_load<BKC>(p.B, p.ldb, p.N, n0, kend, k0, t, p.zeros, rg);
+    };
+    auto stash = [&]() {
+        if (stA) b3_store<AKC>(rg, lds, t);
+        else b3_store<BKC>(rg, lds + IMG, t);
+    };
+    floatx16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    fetch(kbeg);
+    // fragment offsets: k-step s, lane (n, g) -> group q = 2 s + g, position 32 T + n
+    const int fa = (g * 128 + 32 * w + n) * 16, fb = IMG + (g * 128 + n) * 16;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += B3_BK) {
+        b3_lds_barrier();                                 // the previous tile's fragments are read
+        stash();
+        b3_lds_barrier();
+        fetch(k0 + B3_BK);                                // (past kend: zeros, never stored)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            b3_h8 a[3], b[4][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: register r of column tile j = row 4 (8 (r / 4) + 4 g + r % 4) + w of the block, column 4 n + j
+    float* out = p.ws ? p.ws + (int64_t)blockIdx.z * p.M * p.N : p.C;
+    const int64_t ldo = p.ws ? p.N : p.ldc;
+    const int64_t col = n0 + 4 * n;
+    const int act = p.ws ? EL_ACT_NONE : p.act;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!p.ws && p.bias && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);     // (N % 4 == 0 on this path; bias 16-byte aligned: checked by the host)
+    if (col < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + 4 * (8 * (r >> 2) + 4 * g + (r & 3)) + w;
+            float4 v = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
+            if (act == EL_ACT_RELU) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+            else if (act != EL_ACT_NONE) v = make_float4(el_act(v.x, act), el_act(v.y, act), el_act(v.z, act), el_act(v.w, act));
+            if (row < p.M) *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+        }
+    }
+}
+
 static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
     const int64_t target = (int64_t)ctx->cus * 2;
@@ -693,7 +868,27 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
     int splits = 1;
     GemmPlan pl = gemm_plan(ctx, M, N, K);
     const bool fast = fast0 && ws != nullptr && ws_bytes >= (size_t)2 * pl.P * (64 * pl.tm) * (64 * pl.tn) * 4;
-    if (fast) {
+    // three-way split on the bf16 matrix instruction (header of k_gemm_b3): the default wherever the fast path's alignment holds
+    const char* esplit = getenv("EL_GEMM_SPLIT");          // (read per call: the tests time and compare both forms in one process)
+    const bool split_on = !(esplit && atoi(esplit) == 0);
+    // (products under 2 GFLOP -- the 512 x 400 x 600 class -- are latency-bound: the one-launch small-tile path below stays faster)
+    const bool outvec = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
+    if (split_on && fast0 && outvec && 2.0 * (double)M * (double)N * (double)K >= 2.0e9) {
+        splits = gemm_splits(ctx, M, N, K);
+        if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * 4)) splits = 1;
+        p.kchunk = ((K + splits - 1) / splits + B3_BK - 1) / B3_BK * B3_BK;
+        if (p.kchunk < B3_BK) p.kchunk = B3_BK;
+        splits = (int)((K + p.kchunk - 1) / p.kchunk);
+        if (splits < 1) splits = 1;
+        p.ws = splits > 1 ? (float*)ws : nullptr;
+        p.zeros = ctx->zeros;
+        dim3 grid((unsigned)((N + B3_BN - 1) / B3_BN), (unsigned)((M + B3_BM - 1) / B3_BM), (unsigned)splits);
+        // A is k-contiguous unless transposed ([K, M]); B ([K, N]) is k-contiguous when transposed ([N, K])
+        if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
+        else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
+        else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
+        else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);
+    } else if (fast) {
         p.ws = (float*)ws;
         p.units = pl.units;
         p.nkt = pl.nkt;

@@ -32,6 +32,27 @@ def test_gemm_matches_fp64(ctx, tA, tB, M, N, K):
     assert np.abs(got - np.maximum(ref + bias, 0)).max() < tol
 
 
+@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_three_way_split_is_fp32_grade(ctx, tA, tB, monkeypatch):
+    """k_gemm_b3 (fp32 operands as three bf16 planes, six products on the bf16 matrix instruction) against the fp32 matrix
+    instruction on the same operands -- entries spread over 12 orders of magnitude, sums that cancel: its error against fp64 stays
+    within 2x the fp32 instruction's own (both are a few ulp of sum |a b|), edge tiles and a split K included."""
+    rs = np.random.RandomState(7)
+    for M, N, K in ((520, 644, 4096), (136, 260, 40000)):
+        A = (rs.normal(size=(K, M) if tA else (M, K)) * 10.0 ** rs.uniform(-6, 6, size=(K, M) if tA else (M, K))).astype(np.float32)
+        Bm = (rs.normal(size=(N, K) if tB else (K, N)) * 10.0 ** rs.uniform(-6, 6, size=(N, K) if tB else (K, N))).astype(np.float32)
+        d = ctx.device
+        a64, b64 = (A.T if tA else A).astype(np.float64), (Bm.T if tB else Bm).astype(np.float64)
+        ref, mag = a64 @ b64, np.abs(a64) @ np.abs(b64)
+        monkeypatch.setenv("EL_GEMM_SPLIT", "1")
+        got3 = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
+        monkeypatch.setenv("EL_GEMM_SPLIT", "0")
+        got1 = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
+        e3, e1 = np.abs(got3 - ref) / mag, np.abs(got1 - ref) / mag
+        assert e3.max() <= max(2.0 * e1.max(), 4 * 2.0 ** -24), (M, N, K, float(e3.max()), float(e1.max()))
+        assert np.sqrt((e3 ** 2).mean()) <= 2.0 * np.sqrt((e1 ** 2).mean()) + 2.0 ** -26, (float(np.sqrt((e3 ** 2).mean())), float(np.sqrt((e1 ** 2).mean())))
+
+
 def test_gemm_unaligned_leading_dims(ctx):
     rs = np.random.RandomState(5)
     A = rs.normal(size=(70, 33)).astype(np.float32)       # lda = 33: scalar load path
