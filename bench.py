@@ -46,6 +46,23 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
+# k_gemm_b3 (the Dense layers' default): fp32 operands as three bf16 planes, six bf16 products per fp32 product -- the ceiling of an
+# fp32-grade product on the bf16 matrix instruction
+MFMA_B3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
+
+
+def gemm_roofline(rep, flops, steps):
+    """Roofline entry of the dense-layer GEMM launches of one step: the three-way-split kernel where it ran (its flop count is the fp32
+    product's, its peak the bf16 instruction's / 6), the fp32 matrix instruction otherwise (EL_GEMM_SPLIT=0, small shapes)."""
+    gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / steps
+    b3 = sum(v[1] for n, v in rep.items() if n == "k_gemm_b3") / steps
+    ach = flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    split = b3 > 0.5 * gms
+    peak = MFMA_B3_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+    return gms, {"kernel": "k_gemm_b3" if split else "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                 "frac": ach / peak, "frac_of_f32_instruction_peak": ach / MFMA_F32_PEAK_TFLOPS,
+                 "dtype": "f32 operands and results; products on v_mfma_f32_32x32x16_bf16 as three bf16 planes per operand, six per fp32 "
+                          "product, fp32 accumulation (error at fp32 rounding level: tests/test_gpu_dense.py)" if split else "f32"}
 MFMA_BF16_RANDOM_TFLOPS = 1800.0  # what a bare stream of that instruction sustains on random operands (power-limited; measured:
 #                                   scripts/exp/mfma_rate.hip, profiles/r02_mfma_ceiling.md: 1.77-1.85 PFLOP/s, 2.48 on zeros)
 
@@ -937,17 +954,14 @@ def vae_leg(args, ctx):
     #   fwd  h->mv (H x 2L), z->h2 (L x H), h2->logits (H x I);  bwd: two products each
     gemm_flops = B * 2.0 * (H * 2 * L + L * H + H * I) * 3
     alg_flops = B * (2400.0 * I + 720000.0) * 2.5                      # dense-input formulation, fwd x 2.5
-    gname = "k_gemm_f32"
     vtraffic, vnote = (load_traffic(0, 0, 0, 0, 0, 1, leg="vae") if args.vae_shape == "138493,26744,600,200,512" else ({}, "non-default shape"))
-    gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / K
-    ach = gemm_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    gms, groof = gemm_roofline(rep, gemm_flops, K)
     return {"value": B * K / dt, "unit": "users/s", "ms_per_step": ms,
             "workload": f"MultiVAE {U} users x {I} items (ML-20M shape, BASELINE configs[2]), hidden {H}, latent {L}, batch {B}, "
                         f"{int(csr.nnz)} interactions ({nnz_row:.0f}/user), Adam, anneal schedule of multi_vae.py:105-108",
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
-            "roofline": {"kernel": gname, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": vtraffic.get("k_gemm_f32_per_step"), "traffic_unit": "HBM bytes of the kernel's launches of ONE step",
-                         "traffic_source": vnote, "dtype": "f32",
+            "roofline": {**groof, "traffic": vtraffic.get("k_gemm_per_step", vtraffic.get("k_gemm_f32_per_step")),
+                         "traffic_unit": "HBM bytes of the GEMM launches of ONE step", "traffic_source": vnote,
                          "flops_per_step_gemm": gemm_flops, "gemm_ms_per_step": gms,
                          "step_TFLOPs_dense_gemm": gemm_flops / (ms * 1e-3) / 1e12,
                          "step_TFLOPs_survey8d": alg_flops / (ms * 1e-3) / 1e12,
@@ -1039,8 +1053,7 @@ def neumf_leg(args, ctx):
                            "flops_per_pair": pair_flops, "flops_per_pair_reference_form": 2.0 * (2 * F * units[0] + units[0] * units[1] + units[1] * units[2]),
                            "kernels_ms_per_step": {n: v[1] / ks for n, v in rep_k.items()}}}
     mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # fwd 36 F^2 + 4 F per sample, x3 fwd + bwd
-    gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / K
-    ach = mlp_flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    gms, groof = gemm_roofline(rep, mlp_flops, K)
     emb_bytes = 24.0 * 2 * (U + I) * F                                 # Keras Adam moves every row of the 4 embedding tables
     ams = sum(v[1] for n, v in rep.items() if n.startswith("k_adam_dense")) / K
     rows_ms = sum(v[1] for n, v in rep.items() if n in ("k_nmf_catchup", "k_nmf_apply_rows", "k_nmf_flush_rows")) / K
@@ -1052,9 +1065,8 @@ def neumf_leg(args, ctx):
                            f"all of them)" if st.deferred else ", one dense pass per table and step)"),
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             **({"topk": tk} if tk is not None else {}),
-            "roofline": {"kernel": "k_gemm_f32", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": ntraffic.get("k_gemm_f32_per_step"),
-                         "traffic_unit": "HBM bytes of the kernel's launches of ONE step", "traffic_source": nnote, "dtype": "f32",
+            "roofline": {**groof, "traffic": ntraffic.get("k_gemm_per_step", ntraffic.get("k_gemm_f32_per_step")),
+                         "traffic_unit": "HBM bytes of the GEMM launches of ONE step", "traffic_source": nnote,
                          "flops_per_step_mlp": mlp_flops, "gemm_ms_per_step": gms,
                          "step_TFLOPs_mlp": mlp_flops / (ms * 1e-3) / 1e12,
                          "adam_tables_GBs": emb_bytes / (ams * 1e-3) / 1e9 if ams > 0 else None,

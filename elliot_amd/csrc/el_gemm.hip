@@ -712,24 +712,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
         stash();
         b3_lds_barrier();
         fetch(k0 + B3_BK);                                // (past kend: zeros, never stored)
+        // both k-steps' fragments first (the second step's loads complete under the first step's matrix instructions); per product
+        // term the four column tiles in turn: consecutive matrix instructions never wait for each other's accumulator
+        b3_h8 a[2][3], b[2][4][3];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            b3_h8 a[3], b[4][3];
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                a[pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
+                a[s][pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
+                for (int j = 0; j < 4; ++j) b[s][j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
-            }
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][2], b[s][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][2], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][0], acc[j], 0, 0, 0);
         }
     }
     // epilogue: register r of column tile j = row 4 (8 (r / 4) + 4 g + r % 4) + w of the block, column 4 n + j

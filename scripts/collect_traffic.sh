@@ -43,6 +43,8 @@ def short(name):
         return "k_adam_rows_Gu"
     if base.startswith("k_gemm_f32"):
         return "k_gemm_f32"
+    if base.startswith("k_gemm_b3"):
+        return "k_gemm_b3"
     return base
 res = collections.defaultdict(lambda: collections.defaultdict(dict))
 for f in sorted(glob.glob("$OUT/*/*counter_collection.csv")):

@@ -21,11 +21,15 @@ def per_launch(kernels, cfg, leg):
         f, w = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
         if not f or not w:
             continue
-        if leg in ("vae", "neumf") and k in ("k_gemm_f32", "k_gemm_reduce", "k_adam_dense", "k_adam_apply_dense"):
+        if leg in ("vae", "neumf") and k in ("k_gemm_f32", "k_gemm_b3", "k_gemm_reduce", "k_adam_dense", "k_adam_apply_dense"):
             steps = float(cfg.get("steps_profiled", 1))
             out[k + "_per_step"] = (2.0 * f["KiB_total"] + w["KiB_total"]) * 1024.0 / steps
         else:
             out[k] = (2.0 * f["KiB_per_dispatch"] + w["KiB_per_dispatch"]) * 1024.0
+    if leg in ("vae", "neumf"):                          # every GEMM launch of a step: the split kernel, the fp32 one (small shapes), the split-K sums
+        g = [out[k] for k in ("k_gemm_f32_per_step", "k_gemm_b3_per_step", "k_gemm_reduce_per_step") if k in out]
+        if g:
+            out["k_gemm_per_step"] = sum(g)
     if "k_adam_dense" in out and leg in ("c2", "c4", "c5"):
         # one kernel name, launches of different sizes per step (item table, item bias; the user table too in the dense form):
         # split the per-step total by element counts
