@@ -416,7 +416,11 @@ int el_dense_topk(el_ctx* ctx, void* stream, const float* preds, int64_t ld,
  *   C[M,N] = act(op(A) op(B) + bias[N]);  act: 0 none, 1 tanh, 2 relu, 3 sigmoid
  *   transA = 0: A is [M,K] row-major (lda >= K); 1: A is stored [K,M] (lda >= M)
  *   transB = 0: B is [K,N] row-major (ldb >= N); 1: B is stored [N,K] (ldb >= K)
- * ws: el_gemm_ws_bytes(...) bytes enable the deterministic split-K path for small M*N.        */
+ * ws: el_gemm_ws_bytes(...) bytes enable the deterministic split-K path for small M*N.
+ * Arithmetic: fp32 operands and results.  Aligned products of 2 GFLOP and more run on v_mfma_f32_32x32x16_bf16 with every
+ * operand split into three bf16 planes -- six bf16 products per fp32 product, fp32 accumulation, error at the level of fp32
+ * rounding (csrc/el_gemm.hip: k_gemm_b3; tests/test_gpu_dense.py); EL_GEMM_SPLIT=0 in the environment keeps everything on
+ * v_mfma_f32_32x32x2_f32.  Neither form promises a summation order (the scoring kernels do: el_score_topk*, el_nmf_score_topk). */
 size_t el_gemm_ws_bytes(el_ctx* ctx, int64_t M, int64_t N, int64_t K);
 int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
