@@ -802,9 +802,11 @@ struct NsScreenParams {
     const u16 *W2B, *W3B, *PIB;
     const float *Rn, *cst, *b2E, *b3E, *hwE, *hw;        // hw: the head weights as the model holds them ([F mf ; H3 mlp])
     float* up;                                           // [n_users][I_local] upper bound logit' + E
+    int spb;                                             // slices (of the exact kernel's S) per workgroup: 1, 2, 4 or 8
 };
 
-// One workgroup of 8 waves = one user x 8 consecutive slices of the item range, 32 pairs (one matrix-instruction column tile) at a time:
+// One workgroup of 8 waves = NSC_UB users x 8 consecutive slices of the item range, one user x 32 items (one matrix-instruction column
+// tile of pairs) at a time; an item tile's rows are fetched once and serve the workgroup's users in turn:
 //   P1  all 512 threads build the tile's x' in LDS as B fragments (16 threads per pair, 16-byte pieces of the PI image and the mf row
 //       prefetched one tile ahead; v_pk_add_f16 / v_pk_max_f16 / v_dot2_f32_f16: 1.5 instructions per element), and the mf part of the head
 //   P2  wave w owns output features 32 w .. 32 w + 31 of layer 2: its slice of W2 lives in REGISTERS for the whole kernel (4 VGPRs
@@ -816,6 +818,9 @@ struct NsScreenParams {
 // NSTM = 16-wide k-steps of layer 2 (units[0] padded to 256 or 512).
 #define NSC_WAVES 8
 #define NSC_P4 4                                         // the wave that finishes tiles (no layer-3 tile: H3P <= 128)
+#ifndef NSC_UB
+#define NSC_UB 4                                         // users per workgroup: an item tile's rows are fetched once for all of them
+#endif
 template <int H2P, int H3P, int NSTM>
 __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScreenParams q) {
     constexpr int NTH = NSC_WAVES * 64;
@@ -825,55 +830,62 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
     char* xs = smem;                                     // [NSTM][lane = 32 g + pair, swizzled][8 halves]   B fragments of layer 2
     char* ys = xs + NSTM * 1024;                         // [NK3][lane][8]                         B fragments of layer 3
     char* w3s = ys + NK3 * 1024;                         // [NK3][NT3][row m][g][8]                A fragments of layer 3
-    _Float16* aus = reinterpret_cast<_Float16*>(w3s + (size_t)NK3 * NT3 * 1024);   // [NSTM * 16]  h(PU_u + b1) (image order), zero past H1P
-    float* b2s = reinterpret_cast<float*>(aus + NSTM * 16);    // [H2P] accumulator order
+    _Float16* aus = reinterpret_cast<_Float16*>(w3s + (size_t)NK3 * NT3 * 1024);   // [UB][NSTM * 16]  h(PU_u + b1) (image order), zero past H1P
+    float* b2s = reinterpret_cast<float*>(aus + NSC_UB * NSTM * 16);    // [H2P] accumulator order
     float* b3s = b2s + H2P;                              // [H3P]
     float* hws = b3s + H3P;                              // [H3P]
-    float* ums = hws + H3P;                              // [128]  (F <= 128 on this route, zero past F)
-    float* hms = ums + 128;                              // [128]
+    float* ums = hws + H3P;                              // [UB][128]  (F <= 128 on this route, zero past F)
+    float* hms = ums + NSC_UB * 128;                     // [128]
     float* cs = hms + 128;                               // [8]
-    float* rus = cs + 8;                                 // [8] per-wave parts of ||(PU_u + b1) - h(PU_u + b1)||^2
-    float* pq1 = rus + 8;                                // [2 parity][4: nrm1, mf, |mf|, R_i][32]
+    float* rus = cs + 8;                                 // [UB][8] per-wave parts of ||(PU_u + b1) - h(PU_u + b1)||^2
+    float* pq1 = rus + NSC_UB * 8;                       // [2 parity][4: nrm1, mf, |mf|, R_i][32]
     float* pq2 = pq1 + 2 * 4 * 32;                       // [2][8 waves][32]  nrm2 parts
     float* pq3 = pq2 + 2 * 8 * 32;                       // [2][4 tiles][2: logit, |.|][32]
-    u64* keys = reinterpret_cast<u64*>(pq3 + 2 * 4 * 2 * 32);
-    int* cnt_s = reinterpret_cast<int*>(keys + p.cap);
+    int64_t* es = reinterpret_cast<int64_t*>(pq3 + 2 * 4 * 2 * 32);      // [UB][2] the users' exclusion rows
+    float* taus = reinterpret_cast<float*>(es + NSC_UB * 2);              // [UB] list thresholds ...
+    int* cnts = reinterpret_cast<int*>(taus + NSC_UB);                   // [UB] ... and fills (kept by the finishing wave between its turns)
+    u64* keys = reinterpret_cast<u64*>(cnts + NSC_UB);                   // [UB][cap]
+    int* cnt_s = reinterpret_cast<int*>(keys + (size_t)NSC_UB * p.cap);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
 
-    const int64_t urel = blockIdx.x;
-    const int64_t user = p.t.u_start + urel;
-    int64_t e0 = 0, e1 = 0;
-    if (p.t.excl_indptr) {
-        e0 = p.t.excl_indptr[user];
-        e1 = p.t.excl_indptr[user + 1];
+    const int64_t nu = p.t.u_stop - p.t.u_start;
+    const int64_t urel0 = (int64_t)blockIdx.x * NSC_UB;
+    const int nub = (int)((nu - urel0) < NSC_UB ? (nu - urel0) : NSC_UB);      // users of this workgroup
+    if (tid < nub) {
+        const int64_t user = p.t.u_start + urel0 + tid;
+        es[2 * tid] = p.t.excl_indptr ? p.t.excl_indptr[user] : 0;
+        es[2 * tid + 1] = p.t.excl_indptr ? p.t.excl_indptr[user + 1] : 0;
+        taus[tid] = -INFINITY;
+        cnts[tid] = 0;
     }
     const bool use_excl = p.t.excl_indptr != nullptr;
     const int64_t ncand = p.t.I_local;
-    const int s0 = blockIdx.y * NSC_WAVES;               // this workgroup's slices s0 .. s0 + 7 of the exact kernel's S
-    const int64_t pos_lo = ncand * s0 / p.S, pos_hi = ncand * (s0 + NSC_WAVES) / p.S;
+    const int s0 = blockIdx.y * q.spb;                   // this workgroup's slices s0 .. s0 + spb - 1 of the exact kernel's S
+    const int64_t pos_lo = ncand * s0 / p.S, pos_hi = ncand * (s0 + q.spb) / p.S;
     const int T = (int)((pos_hi - pos_lo + 31) / 32);
 
-    {
+    for (int uu = 0; uu < nub; ++uu) {
         float rs = 0.f;
         for (int t = tid; t < NSTM * 16; t += NTH) {
-            const float a = t < p.H1P ? p.PU[urel * p.H1P + t] + p.b1P[t] : 0.f;
+            const float a = t < p.H1P ? p.PU[(urel0 + uu) * p.H1P + t] + p.b1P[t] : 0.f;
             const _Float16 ah = (_Float16)a;
-            aus[t] = ah;
+            aus[uu * NSTM * 16 + t] = ah;
             const float d = a - (float)ah;
             rs = __builtin_fmaf(d, d, rs);
         }
         rs = el_group_sum(rs, 64);
-        if (lane == 0) rus[w] = rs;
+        if (lane == 0) rus[uu * 8 + w] = rs;
     }
     for (int t = tid; t < H2P; t += NTH) b2s[t] = q.b2E[t];
     for (int t = tid; t < H3P; t += NTH) {
         b3s[t] = q.b3E[t];
         hws[t] = q.hwE[t];
     }
-    for (int t = tid; t < 128; t += NTH) {
-        ums[t] = t < p.F ? p.Umf[user * (int64_t)p.F + t] : 0.f;      // (p.F = 0 without an mf part)
-        hms[t] = t < p.F ? q.hw[t] : 0.f;
+    for (int t = tid; t < 128 * nub; t += NTH) {
+        const int uu = t >> 7, f = t & 127;
+        ums[t] = f < p.F ? p.Umf[(p.t.u_start + urel0 + uu) * (int64_t)p.F + f] : 0.f;      // (p.F = 0 without an mf part)
     }
+    for (int t = tid; t < 128; t += NTH) hms[t] = t < p.F ? q.hw[t] : 0.f;
     if (tid < 8) cs[tid] = q.cst[tid];
     for (int e4 = tid; e4 < NK3 * NT3 * 64; e4 += NTH) reinterpret_cast<float4*>(w3s)[e4] = reinterpret_cast<const float4*>(q.W3B)[e4];
     // this wave's slice of the W2 image: A fragment of k-step ks = 16 bytes at [ks][tile w][lane]
@@ -884,9 +896,6 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
             wreg[ks] = *reinterpret_cast<const ns_h8*>(reinterpret_cast<const char*>(q.W2B) + (size_t)(ks * NT2 + w) * 1024 + n * 32 + h * 16);
     }
     const float hbias = p.hb ? *p.hb : 0.f;
-    int cnt = 0;
-    float tau = -INFINITY;
-    float* uprow = q.up + urel * p.t.I_local;
     // P1 roles: pair pp of the tile, piece lane pj of 16
     const int pp = tid >> 4, pj = tid & 15;
     uint4 pre[CPT];
@@ -909,9 +918,14 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
 
     // P4 of one tile: error bound, upper bound out, the range's k largest lower bounds.  One wave (the first without a layer-3 tile),
     // one tile behind the others, while layer 3 of the next tile runs.
-    const float ru = sqrtf(((rus[0] + rus[1]) + (rus[2] + rus[3])) + ((rus[4] + rus[5]) + (rus[6] + rus[7]))) * 1.0001f;
-    auto finish_tile = [&](int tile) {
-        const int par = tile & 1;
+    auto finish_tile = [&](int tile, int uu, int par) {
+        const float* ruu = rus + uu * 8;
+        const float ru = sqrtf(((ruu[0] + ruu[1]) + (ruu[2] + ruu[3])) + ((ruu[4] + ruu[5]) + (ruu[6] + ruu[7]))) * 1.0001f;
+        const int64_t e0 = es[2 * uu], e1 = es[2 * uu + 1];
+        float tau = taus[uu];
+        int cnt = cnts[uu];
+        u64* ukeys = keys + (size_t)uu * p.cap;
+        float* uprow = q.up + (urel0 + uu) * p.t.I_local;
         const int64_t pos = pos_lo + (int64_t)tile * 32 + n;
         const bool valid = pos < pos_hi && h == 0;
         const int32_t gitem = valid ? (int32_t)(p.t.item_offset + pos) : -1;
@@ -944,18 +958,24 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
         const u64 bal = __ballot(hit);
         if (bal) {
             const int offp = __popcll(bal & ((1ull << lane) - 1ull));
-            if (hit) keys[cnt + offp] = el_make_key(lo, gitem);
+            if (hit) ukeys[cnt + offp] = el_make_key(lo, gitem);
             cnt += __popcll(bal);
         }
         if (cnt > p.cap - 32) {
             if (lane == 0) *cnt_s = cnt;
-            tau = el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
+            tau = el_wave_compact(ukeys, cnt_s, p.cap, p.t.k, lane);
             cnt = cnt < p.t.k ? cnt : p.t.k;
         }
+        if (lane == 0) taus[uu] = tau, cnts[uu] = cnt;
     };
 
-    for (int tile = 0; tile < T; ++tile) {
-        const int par = tile & 1;
+    // iterations = (tile, user): the tile's item rows sit in the prefetch registers for all of the workgroup's users
+    int par = 0, ptile = 0, puu = 0;
+    bool first = true;
+    for (int tile = 0; tile < T; ++tile)
+    for (int uu = 0; uu < nub; ++uu, par ^= 1) {
+        const _Float16* uaus = aus + uu * NSTM * 16;
+        const float* uums = ums + uu * 128;
         // ---------------- P1: x' tile in packed half arithmetic, ||x'||^2, mf part -------------------------------------------------
         {
             float nrm1 = 0.f;
@@ -967,7 +987,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
                     ns_h2 v[4];
                 } pi, au, xq;
                 pi.u = pre[i];                            // (zero past the live pieces, like aus: x' = 0 there)
-                au.u = *reinterpret_cast<const uint4*>(aus + 8 * c);
+                au.u = *reinterpret_cast<const uint4*>(uaus + 8 * c);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     xq.v[x] = __builtin_elementwise_max(au.v[x] + pi.v[x], (ns_h2)(_Float16)0);      // v_pk_add_f16, v_pk_max_f16
@@ -980,8 +1000,8 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
             float acc = 0.f, aabs = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {                  // (all zero without an mf part)
-                const float4 uu = *reinterpret_cast<const float4*>(ums + 4 * pj + 64 * i), ww = *reinterpret_cast<const float4*>(hms + 4 * pj + 64 * i);
-                const float t0 = uu.x * mpre[i].x, t1 = uu.y * mpre[i].y, t2 = uu.z * mpre[i].z, t3 = uu.w * mpre[i].w;
+                const float4 uv = *reinterpret_cast<const float4*>(uums + 4 * pj + 64 * i), ww = *reinterpret_cast<const float4*>(hms + 4 * pj + 64 * i);
+                const float t0 = uv.x * mpre[i].x, t1 = uv.y * mpre[i].y, t2 = uv.z * mpre[i].z, t3 = uv.w * mpre[i].w;
                 acc = __builtin_fmaf(ww.x, t0, acc), aabs = __builtin_fmaf(fabsf(ww.x), fabsf(t0), aabs);
                 acc = __builtin_fmaf(ww.y, t1, acc), aabs = __builtin_fmaf(fabsf(ww.y), fabsf(t1), aabs);
                 acc = __builtin_fmaf(ww.z, t2, acc), aabs = __builtin_fmaf(fabsf(ww.z), fabsf(t2), aabs);
@@ -992,7 +1012,7 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
                 float* o = pq1 + par * 128 + pp;
                 o[0] = nrm1, o[32] = acc, o[64] = aabs, o[96] = rpre;
             }
-            if (tile + 1 < T) prefetch(tile + 1);
+            if (uu + 1 == nub && tile + 1 < T) prefetch(tile + 1);       // (the registers are free after the last user's turn)
         }
         ns_lds_barrier();
         // ---------------- P2: layer 2, this wave's 32 features x the tile's 32 pairs ----------------------------------------------
@@ -1071,28 +1091,35 @@ __global__ __launch_bounds__(NSC_WAVES * 64) void k_nmf_screen(NsParams p, NsScr
                 float* o = pq3 + (par * 4 + w) * 64 + n;
                 o[0] = acc, o[32] = aabs;
             }
-        } else if (w == NSC_P4 && tile > 0) {
-            finish_tile(tile - 1);                         // (its parity's sums are not rewritten before the next tile's phases, all past the barrier below)
+        } else if (w == NSC_P4 && !first) {
+            finish_tile(ptile, puu, par ^ 1);              // (its parity's sums are not rewritten before the next iteration's phases, all past the barrier below)
         }
         ns_lds_barrier();
+        ptile = tile, puu = uu, first = false;
     }
-    if (w == NSC_P4 && T > 0) finish_tile(T - 1);
-    // one list per workgroup, filed under its first slice; the other seven stay empty for the merge
-    const int64_t nu = p.t.u_stop - p.t.u_start;
-    if (w == NSC_P4) {
-        if (lane == 0) *cnt_s = cnt;
-        el_wave_compact(keys, cnt_s, p.cap, p.t.k, lane);
-        const int nv = cnt < p.t.k ? cnt : p.t.k;
-        const int64_t orow = ((int64_t)s0 * nu + urel) * p.t.k;
-        for (int t = lane; t < p.t.k; t += 64) {
-            p.part_idx[orow + t] = t < nv ? el_key_item(keys[t]) : -1;
-            p.part_val[orow + t] = t < nv ? el_key_score(keys[t]) : -INFINITY;
-        }
-    } else {
-        const int64_t orow = ((int64_t)(s0 + (w < NSC_P4 ? w + 1 : w)) * nu + urel) * p.t.k;
-        for (int t = lane; t < p.t.k; t += 64) {
-            p.part_idx[orow + t] = -1;
-            p.part_val[orow + t] = -INFINITY;
+    if (w == NSC_P4 && !first) finish_tile(ptile, puu, par ^ 1);
+    // one list per user and workgroup, filed under the workgroup's first slice; its other slices stay empty for the merge
+    for (int uu = 0; uu < nub; ++uu) {
+        if (w == NSC_P4) {
+            el_wave_lds_sync();
+            const int cnt = cnts[uu];
+            u64* ukeys = keys + (size_t)uu * p.cap;
+            if (lane == 0) *cnt_s = cnt;
+            el_wave_compact(ukeys, cnt_s, p.cap, p.t.k, lane);
+            const int nv = cnt < p.t.k ? cnt : p.t.k;
+            const int64_t orow = ((int64_t)s0 * nu + urel0 + uu) * p.t.k;
+            for (int t = lane; t < p.t.k; t += 64) {
+                p.part_idx[orow + t] = t < nv ? el_key_item(ukeys[t]) : -1;
+                p.part_val[orow + t] = t < nv ? el_key_score(ukeys[t]) : -INFINITY;
+            }
+        } else {
+            for (int sl = 1 + (w < NSC_P4 ? w : w - 1); sl < q.spb; sl += NSC_WAVES - 1) {
+                const int64_t orow = ((int64_t)(s0 + sl) * nu + urel0 + uu) * p.t.k;
+                for (int t = lane; t < p.t.k; t += 64) {
+                    p.part_idx[orow + t] = -1;
+                    p.part_val[orow + t] = -INFINITY;
+                }
+            }
         }
     }
 }
@@ -1183,13 +1210,12 @@ static int ns_launch(const NsParams& p, int64_t n_users, int nsplit, hipStream_t
 template <int H2P, int H3P, int NSTM>
 static int ns_launch_screen(const NsParams& p, const NsScreenParams& q, int64_t n_users, int nsplit, hipStream_t s) {
     const size_t lds = (size_t)(NSTM + H2P / 16 + (H2P / 16) * (H3P / 32)) * 1024 +
-                       (size_t)(NSTM * 8 + H2P + 2 * H3P + 2 * 128 + 16 + 2 * 4 * 32 + 2 * 8 * 32 + 2 * 4 * 2 * 32) * 4 +
-                       (size_t)p.cap * 8 + 16;
+                       (size_t)(NSC_UB * NSTM * 8 + H2P + 2 * H3P + (NSC_UB + 1) * 128 + 8 + NSC_UB * 8 + 2 * 4 * 32 + 2 * 8 * 32 + 2 * 4 * 2 * 32) * 4 +
+                       (size_t)NSC_UB * (16 + 8) + (size_t)NSC_UB * p.cap * 8 + 16;
     EL_REQUIRE(lds <= NS_LDS_LIMIT, "el_nmf_score_topk: the screened kernel needs %zu bytes of LDS", lds);
     auto kern = k_nmf_screen<H2P, H3P, NSTM>;
     EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // (one workgroup = the NS_WAVES slices one workgroup of the exact kernel covers)
-    EL_LAUNCH("k_nmf_screen", kern, dim3((unsigned)n_users, (unsigned)nsplit), dim3(NSC_WAVES * 64), lds, s, p, q);
+    EL_LAUNCH("k_nmf_screen", kern, dim3((unsigned)((n_users + NSC_UB - 1) / NSC_UB), (unsigned)(nsplit * NS_WAVES / q.spb)), dim3(NSC_WAVES * 64), lds, s, p, q);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -1321,6 +1347,13 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         sq.W2B = qb.W2B, sq.W3B = qb.W3B, sq.PIB = (const u16*)(base + L.PIB), sq.Rn = (const float*)(base + L.Rn);
         sq.cst = (const float*)(base + L.cst), sq.b2E = qb.b2E, sq.b3E = qb.b3E, sq.hwE = qb.hwE;
         sq.up = (float*)(base + L.upb), sq.hw = st->hw;
+        // slices per workgroup: ~3 workgroups per CU over (user groups) x (S / spb) ranges
+        {
+            const int64_t groups = (n_users + NSC_UB - 1) / NSC_UB;
+            int spb = NS_WAVES;
+            while (spb > 1 && groups * (L.S / spb) < (int64_t)ctx->cus * 3) spb >>= 1;
+            sq.spb = spb;
+        }
         const bool k16 = L.H1P <= 256;
         if (L.H2P == 256) rc = k16 ? ns_launch_screen<256, 128, 16>(p, sq, n_users, nsplit, s) : ns_launch_screen<256, 128, 32>(p, sq, n_users, nsplit, s);
         else if (L.H2P == 128) rc = k16 ? ns_launch_screen<128, 64, 16>(p, sq, n_users, nsplit, s) : ns_launch_screen<128, 64, 32>(p, sq, n_users, nsplit, s);
