@@ -46,7 +46,13 @@ class NeuMF(RecMixin, BaseRecommenderModel):
         return "_".join(["NeuMF", self.get_base_params_shortcut(), self.get_params_shortcut()])
 
     def _recommendation_block(self):
-        return max(1, min(4096, (8 * self._model.state.Bmax) // max(self._num_items, 1)))
+        pairs = (8 * self._model.state.Bmax) // max(self._num_items, 1)       # the pair route walks a block in chunks of Bmax pairs
+        st = self._model.state
+        if st.use_mlp and st.fused_supported(min(self._num_items, 10 + 64)):
+            # the fused scoring kernels hold no [users, items] activations: blocks of up to 2^27 pairs (128 users x 1 M items; the
+            # screened route's per-pair bounds and candidate regions are 8 bytes a pair) amortise the per-call item-side work
+            pairs = max(pairs, (1 << 27) // max(self._num_items, 1))
+        return max(1, min(4096, pairs))
 
     def train(self):
         if self._restore:
