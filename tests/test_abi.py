@@ -118,3 +118,27 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), (cname, out[cname], ctypes.sizeof(cls))
         for fname, _ in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_python_constants_match_the_header_enums(tmp_path):
+    """Every EL_* integer constant of elliot_amd/_lib.py against the enumerator / macro of the same name in include/elliot_hip.h
+    (a C program built from the header prints them): a flag renumbered on one side only would select another kernel silently."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    names = sorted(n for n in dir(_lib) if re.fullmatch(r"EL_[A-Z0-9_]+", n) and isinstance(getattr(_lib, n), int))
+    header = open(os.path.join(REPO, "include", "elliot_hip.h")).read()
+    names = [n for n in names if re.search(r"\b" + n + r"\b", header)]
+    assert {"EL_NMF_SCREEN", "EL_TOPK_ITEMS_UNCHANGED", "EL_TOPK_SCREEN", "EL_OPT_ADAM_TF_DENSE", "EL_ABI_VERSION"} <= set(names) | {"EL_ABI_VERSION"}
+    lines = ['#include <stdio.h>', '#include "elliot_hip.h"', "int main(void) {"]
+    lines += [f'    printf("{n} %lld\\n", (long long)({n}));' for n in names]
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "consts.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "consts"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n in names:
+        assert int(out[n]) == getattr(_lib, n), (n, out[n], getattr(_lib, n))
