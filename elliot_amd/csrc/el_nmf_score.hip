@@ -239,11 +239,16 @@ __global__ __launch_bounds__(256) void k_nmf_proj(const float* __restrict__ X, i
 
 // ---- hash of the tables the PI image is derived from (Imlp, W1) -----------------------------------------------------------
 __global__ void k_items_hash(const float* __restrict__ Gi, const float* __restrict__ Bi, int64_t n_g, int64_t n_b, u64* ctl);   // el_topk_screen.hip
+// ctl[3]: the half-precision image of PI (screened route) is older than PI -- set whenever PI is rebuilt, by screened and
+// unscreened calls alike, cleared by k_nmf_pib_done after the image was rebuilt (a call that forces the rebuild -- a workspace the
+// library has not seen, other tables -- initialises it)
 __global__ void k_nmf_decide(u64* ctl, int force) {
     const bool stale = force || ctl[0] != ctl[1];
     ctl[0] = ctl[1];
     ctl[2] = stale ? 1ull : 0ull;
+    if (stale) ctl[3] = 1ull;
 }
+__global__ void k_nmf_pib_done(u64* ctl) { ctl[3] = 0ull; }
 
 // ---- the fused kernel -----------------------------------------------------------------------------------------------------
 struct NsParams {
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(NS_THREADS) void k_nmf_score(NsParams p) {
 //   |logit' - logit| <= E = 1.02 ||hw_mlp||_2 dz3 + 4e-5 sum |head terms|   (mf part: the same fp32 products, another order)
 // ||x'|| and ||y'|| are the pair's own (summed in the kernel), the norms of the four matrices are computed on the device per
 // call (k_nmf_gram ...: upper bounds from the trace of (W^T W)^16).  Selection: k_nmf_screen writes the UPPER bound logit' + E of
-// every pair and keeps, per wave slice, the k largest LOWER bounds logit' - E of unmasked items; the merge of the slices gives the user's
+// every pair and keeps, per workgroup, the k largest LOWER bounds logit' - E of unmasked items; the merge of the lists gives the user's
 // threshold T = the k-th largest lower bound of the whole catalogue (k items are certainly at or above T, so nothing whose upper bound
 // is below T can be in the exact top-k); k_nmf_compact collects the unmasked items with upper bound >= T slice by slice, the exact
 // kernel scores those (NsParams.reg_*) and the usual merge returns the lists -- the same index lists and logit bits as the unscreened
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(256) void k_nmf_pack_h16(NsPackB q) {
     }
 }
 
-// half-precision image of the PI rows + R_i = ||PI_i - h(PI_i)||_2 (one wave per item; skipped with the PI image when the items are unchanged)
+// half-precision image of the PI rows + R_i = ||PI_i - h(PI_i)||_2 (one wave per item; skipped while *rebuild == 0: ctl[3] above)
 __global__ __launch_bounds__(256) void k_nmf_pib(const float* __restrict__ PI, int64_t I, int H1P, int KP, u16* __restrict__ PIB, float* __restrict__ Rn,
                                                  const unsigned long long* __restrict__ rebuild) {
     if (rebuild && *rebuild == 0ull) return;
@@ -1337,11 +1342,11 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
             for (int step = 0; step < NS_SPEC_SQ; ++step) EL_LAUNCH("k_nmf_gram_sq", k_nmf_gram_sq, dim3(16, 4), dim3(256), 0, s, sp, step, trs);
             EL_LAUNCH("k_nmf_spec_finish", k_nmf_spec_finish, dim3(5), dim3(256), 0, s, sp, (const float*)trs);
         }
-        // the half-precision image of PI follows the PI image (same rebuild flag), unless this workspace has not held one yet
-        const bool have_pib = ctx->nmf_pib_ws == ws && claim;
+        // the half-precision image of PI follows PI: rebuilt when ctl[3] says PI changed since it was last built (an unscreened call in
+        // between may have rebuilt PI for new weights without touching it)
         EL_LAUNCH("k_nmf_pib", k_nmf_pib, dim3((unsigned)((I_local + 3) / 4)), dim3(256), 0, s, (const float*)(base + L.PI), I_local, L.H1P,
-                  (int)(L.H1P <= 256 ? 256 : 512), (u16*)(base + L.PIB), (float*)(base + L.Rn), have_pib ? (const unsigned long long*)(ctl + 2) : (const unsigned long long*)nullptr);
-        ctx->nmf_pib_ws = ws;
+                  (int)(L.H1P <= 256 ? 256 : 512), (u16*)(base + L.PIB), (float*)(base + L.Rn), (const unsigned long long*)(ctl + 3));
+        EL_LAUNCH("k_nmf_pib_done", k_nmf_pib_done, dim3(1), dim3(1), 0, s, ctl);
         EL_CHECK_HIP(hipMemsetAsync(base + L.sflag, 0, 16, s));
         NsScreenParams sq;
         sq.W2B = qb.W2B, sq.W3B = qb.W3B, sq.PIB = (const u16*)(base + L.PIB), sq.Rn = (const float*)(base + L.Rn);

@@ -318,3 +318,23 @@ def test_screened_route_survives_activations_past_the_half_range(ctx, monkeypatc
     ref_i, ref_v = st.score_topk_logits(0, U, k, screen=False)
     got_i, got_v = st.score_topk_logits(0, U, k, screen=True)
     assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
+
+
+def test_screened_route_rebuilds_its_item_image_after_an_unscreened_call_rebuilt_the_projection(ctx):
+    """The half-precision image of the item projection follows the projection even when the call that rebuilt the projection did
+    not screen: screened call (weights v1) -> the item table changes in place -> UNSCREENED call without the unchanged claim
+    (rebuilds the projection) -> screened call WITH the claim (projection kept): its bounds must come from the new image, i.e. the
+    lists are the fp32 kernel's on the new weights."""
+    U, I, F, k, nu = 60_000, 60_000, 64, 10, 32
+    w = on.init_neumf(U, I, F, 21)
+    st = ops.NmfDeviceState(ctx, w, max_batch=1024)
+    st.score_topk_logits(0, nu, k, screen=True)
+    assert not st.screen_stats()[1]
+    rs = torch.Generator(device=ctx.device)
+    rs.manual_seed(4)
+    st.tab[3].copy_((torch.rand(st.tab[3].shape, generator=rs, device=ctx.device) * 2 - 1) * 0.02)     # new Imlp, same address
+    ref_i, ref_v = st.score_topk_logits(0, nu, k, screen=False)                                          # rebuilds the projection
+    got_i, got_v = st.score_topk_logits(0, nu, k, screen=True, items_unchanged=True)
+    pairs, fell_back = st.screen_stats()
+    assert not fell_back and pairs < 0.2 * nu * I, (pairs, fell_back)
+    assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
