@@ -42,6 +42,7 @@ struct el_ctx {
     const float* nmf_W1 = nullptr;
     int64_t nmf_I = 0;
     int nmf_E = 0, nmf_H1 = 0;
+    size_t nmf_PI_off = 0, nmf_PIB_off = 0, nmf_Rn_off = 0;   // where the last call on nmf_ws put PI and its half-precision image (0: none)
     int64_t nmf_screen_cands = 0;        // last el_nmf_score_topk: pairs the exact kernel scored (/ users / I_local = the survival rate)
     bool nmf_screen_fallback = false;    // ... and whether a call that asked for the screen went without it
     // el_bprmf_train_loop: the captured small-batch step sequence (hipGraphExec_t) and the launch parameters it was built for

@@ -111,6 +111,12 @@ static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, 
     L.hwD = take((size_t)L.H3P * 4);
     L.hwmf = take((size_t)(L.FP > 0 ? L.FP : 8) * 4);
     L.PI = take((size_t)(I_local > 0 ? I_local : 1) * L.H1P * 4);
+    // the persistent item-side images come first: nothing before this line depends on the user range, k or the split, so a later call on
+    // the same workspace with a shorter user block (the last block of an evaluation, EL_TOPK_ITEMS_UNCHANGED) finds them where they were built
+    if (screen) {
+        L.PIB = take((size_t)(I_local > 0 ? I_local : 1) * ns_up(L.H1P, 256) * 2);
+        L.Rn = take((size_t)(I_local > 0 ? I_local : 1) * 4);
+    }
     L.PU = take((size_t)(n_users > 0 ? n_users : 1) * L.H1P * 4);
     L.pidx = take((size_t)L.S * (n_users > 0 ? n_users : 1) * k * 4);
     L.pval = take((size_t)L.S * (n_users > 0 ? n_users : 1) * k * 4);
@@ -120,8 +126,6 @@ static NsLayout ns_layout(el_ctx* ctx, const el_nmf_state* st, int64_t n_users, 
         L.b2E = take((size_t)L.H2P * 4);
         L.b3E = take((size_t)L.H3P * 4);
         L.hwE = take((size_t)L.H3P * 4);
-        L.PIB = take((size_t)(I_local > 0 ? I_local : 1) * ns_up(L.H1P, 256) * 2);
-        L.Rn = take((size_t)(I_local > 0 ? I_local : 1) * 4);
         L.cst = take(256);                               // 8 constants, then the traces of the squarings (k_nmf_gram_sq)
         L.gram = take((size_t)4 * 2 * 65536 * 4);
         const size_t nu = (size_t)(n_users > 0 ? n_users : 1), ni = (size_t)(I_local > 0 ? I_local : 1);
@@ -1252,6 +1256,13 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
     // (el_nmf_screen_stats: what the exact kernel scores, and whether a call that asked for the screen goes without it)
     ctx->nmf_screen_cands = cand ? -1 : n_users * I_local;
     ctx->nmf_screen_fallback = (flags & EL_NMF_SCREEN) != 0 && !screen;
+    if (screen) {
+        // the screened route reads its survivor count back (one stream synchronisation per call): it cannot be recorded into a graph
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        EL_CHECK_HIP(hipStreamIsCapturing((hipStream_t)stream, &cs));
+        EL_REQUIRE(cs == hipStreamCaptureStatusNone, "el_nmf_score_topk: EL_NMF_SCREEN synchronises the stream and cannot be captured in a "
+                                                     "graph (call without the flag under capture)");
+    }
     const NsLayout L = ns_layout(ctx, st, n_users, I_local, k, cand, screen);
     EL_REQUIRE(ws != nullptr && ws_bytes >= L.total, "el_nmf_score_topk: workspace too small (%zu < %zu; el_nmf_score_ws_bytes)", ws_bytes, L.total);
     EL_REQUIRE(((uintptr_t)ws & 15) == 0, "el_nmf_score_topk: workspace must be 16-byte aligned");
@@ -1279,8 +1290,12 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         EL_LAUNCH("k_nmf_pack", k_nmf_pack, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, q);
     }
     const float* Imlp = st->tab[3] + item_offset * (int64_t)st->E;
+    // (the claim also needs PI where the last call on this workspace left it: the regions in front of it are sized by the layer widths)
     const bool claim = (flags & EL_TOPK_ITEMS_UNCHANGED) != 0 && ctx->nmf_ws == ws && ctx->nmf_Imlp == Imlp && ctx->nmf_W1 == st->W[0] &&
-                       ctx->nmf_I == I_local && ctx->nmf_E == st->E && ctx->nmf_H1 == st->units[0];
+                       ctx->nmf_I == I_local && ctx->nmf_E == st->E && ctx->nmf_H1 == st->units[0] && ctx->nmf_PI_off == L.PI;
+    // the half-precision image of PI (screened route) is trusted only where the LAST call on this workspace was a screened one that put
+    // it at the same offsets: an unscreened call in between lays its user-side regions over it
+    const bool pib_in_place = claim && ctx->nmf_PIB_off == L.PIB && ctx->nmf_Rn_off == L.Rn && L.PIB != 0;
     if (I_local > 0) {
         EL_CHECK_HIP(hipMemsetAsync(ctl + 1, 0, 8, s));
         const int64_t n_g = I_local * (int64_t)st->E;
@@ -1296,6 +1311,7 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
                   (int64_t)0, I_local, (int)st->E, (const float*)q.W1b, L.H1P, (float*)(base + L.PI), (const unsigned long long*)(ctl + 2));
     }
     ctx->nmf_ws = ws, ctx->nmf_Imlp = Imlp, ctx->nmf_W1 = st->W[0], ctx->nmf_I = I_local, ctx->nmf_E = st->E, ctx->nmf_H1 = st->units[0];
+    ctx->nmf_PI_off = L.PI, ctx->nmf_PIB_off = screen ? L.PIB : 0, ctx->nmf_Rn_off = screen ? L.Rn : 0;
     // ---- user side: PU = Umlp[u_start .. u_stop) W1[:E]
     {
         const size_t lds = (size_t)128 * (st->E + 1) * 4;
@@ -1345,7 +1361,8 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         // the half-precision image of PI follows PI: rebuilt when ctl[3] says PI changed since it was last built (an unscreened call in
         // between may have rebuilt PI for new weights without touching it)
         EL_LAUNCH("k_nmf_pib", k_nmf_pib, dim3((unsigned)((I_local + 3) / 4)), dim3(256), 0, s, (const float*)(base + L.PI), I_local, L.H1P,
-                  (int)(L.H1P <= 256 ? 256 : 512), (u16*)(base + L.PIB), (float*)(base + L.Rn), (const unsigned long long*)(ctl + 3));
+                  (int)(L.H1P <= 256 ? 256 : 512), (u16*)(base + L.PIB), (float*)(base + L.Rn),
+                  pib_in_place ? (const unsigned long long*)(ctl + 3) : (const unsigned long long*)nullptr);
         EL_LAUNCH("k_nmf_pib_done", k_nmf_pib_done, dim3(1), dim3(1), 0, s, ctl);
         EL_CHECK_HIP(hipMemsetAsync(base + L.sflag, 0, 16, s));
         NsScreenParams sq;
@@ -1381,8 +1398,7 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         unsigned long long ncands = 0;
         memcpy(&ncands, hflag + 2, 8);
         // worth it when the exact kernel is left with less than half of the pairs (the screen costs a sixth of it; EL_NMF_SCREEN_MAXFRAC overrides)
-        const char* ef = getenv("EL_NMF_SCREEN_MAXFRAC");
-        const double maxfrac = ef ? atof(ef) : 0.5;
+        static const double maxfrac = [] { const char* ef = getenv("EL_NMF_SCREEN_MAXFRAC"); return ef ? atof(ef) : 0.5; }();   // read once
         const bool use = hflag[0] == 0 && (double)ncands <= maxfrac * (double)n_users * (double)I_local;
         if (use) ctx->nmf_screen_cands = (int64_t)ncands;
         ctx->nmf_screen_fallback = !use;

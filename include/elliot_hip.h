@@ -353,8 +353,11 @@ enum {
     /* el_nmf_score_topk only: layers 2-3 first on the half-precision matrix instruction with a per-pair error bound (spectral norms
      * of the rounded weights and of their rounding errors, the pair's own activation norms and measured rounding residuals), the
      * fp32 kernel then only on the pairs whose upper bound reaches the user's k-th best lower bound: the same index lists and logit
-     * bits.  Needs the workspace of el_nmf_score_ws_bytes(..., with_cand = 2); synchronises the stream once (a 16-byte flag read);
-     * takes the unscreened route when the bound leaves more than half of the pairs (el_nmf_screen_stats tells).            */
+     * bits.  Needs the workspace of el_nmf_score_ws_bytes(..., with_cand = 2); synchronises the stream once (a 16-byte flag read),
+     * so a call with this flag is refused on a stream that is being captured into a graph; takes the unscreened route when the
+     * bound leaves more than half of the pairs (el_nmf_screen_stats tells).  With EL_TOPK_ITEMS_UNCHANGED the half-precision item
+     * image is kept across calls on one workspace whatever their user ranges and k are (it sits in front of every region sized by
+     * them) -- as long as the previous call on that workspace was a screened one; otherwise it is rebuilt.                 */
     EL_NMF_SCREEN = 0x200
 };
 

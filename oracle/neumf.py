@@ -78,7 +78,11 @@ def bce(p, y):
     return float(-np.mean(y * np.log(pc + eps) + (1 - y) * np.log(1 - pc + eps)))
 
 
-def gradients(w, c, u, i, y):
+def gradients(w, c, u, i, y, relu_masks=None):
+    """relu_masks: per Dense layer a boolean [n, units] array used as the ReLU derivative instead of (output > 0) -- the branch
+    pattern another implementation took (the derivative is a step function: a pre-activation within round-off of 0 takes either
+    branch depending on the summation order; tests/test_gpu_neumf.py compares gradients under the device's pattern after checking
+    that the two patterns differ only there)."""
     n = len(y)
     p = c["p"]
     dt = p.dtype.type
@@ -103,7 +107,7 @@ def gradients(w, c, u, i, y):
         d = dlogit[:, None] * hw[None, F:]
         g["W"], g["b"] = [None] * len(w["W"]), [None] * len(w["W"])
         for l in range(len(w["W"]) - 1, -1, -1):
-            d = d * (c["outs"][l] > 0)
+            d = d * ((c["outs"][l] > 0) if relu_masks is None else np.asarray(relu_masks[l], bool))
             g["W"][l] = c["ins"][l].T @ d
             g["b"][l] = d.sum(0)
             d = d @ np.asarray(w["W"][l], p.dtype).T

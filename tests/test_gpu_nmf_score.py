@@ -338,3 +338,31 @@ def test_screened_route_rebuilds_its_item_image_after_an_unscreened_call_rebuilt
     pairs, fell_back = st.screen_stats()
     assert not fell_back and pairs < 0.2 * nu * I, (pairs, fell_back)
     assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
+
+
+@pytest.mark.parametrize("between", ["nothing", "unscreened_call"])
+def test_screened_route_keeps_its_item_image_across_user_blocks_of_other_sizes(ctx, between):
+    """The last, shorter user block of an evaluation reuses the workspace with EL_TOPK_ITEMS_UNCHANGED: the half-precision item image
+    and its residual norms must be found where the full block built them (they sit in front of every region sized by the user range,
+    k or the split), and an unscreened call in between -- whose user-side regions lie over the image -- forces their rebuild.  Lists
+    and logit bits equal the unscreened call's either way, for a shorter block, another k, and a longer block again."""
+    U, I, F = 300, 40_000, 64
+    w = on.init_neumf(U, I, F, 31)
+    st = ops.NmfDeviceState(ctx, w, max_batch=1024)
+    rs = np.random.RandomState(8)
+    ip, ix = random_excl(rs, U, I, 0, 40)
+    excl = ops.DeviceCSR(ip, ix, I, ctx.device)
+    ref = ops.NmfDeviceState(ctx, w, max_batch=1024)                    # its own workspace: never screened
+    st.score_topk_logits(0, 256, 10, excl=excl, screen=True)            # the full block: builds the projection and its image
+    assert not st.screen_stats()[1]
+    ws_ptr = st._score_ws.data_ptr()
+    for (a, b, k) in ((256, 300, 10), (256, 263, 50), (10, 11, 10), (0, 256, 10), (40, 296, 20)):
+        if between == "unscreened_call":
+            st.score_topk_logits(a, b, k, excl=excl, screen=False, items_unchanged=True)
+        got_i, got_v = st.score_topk_logits(a, b, k, excl=excl, screen=True, items_unchanged=True)
+        pairs, fell_back = st.screen_stats()
+        assert st._score_ws.data_ptr() == ws_ptr or k > 10            # (same workspace unless a larger k outgrew it)
+        ws_ptr = st._score_ws.data_ptr()
+        ref_i, ref_v = ref.score_topk_logits(a, b, k, excl=excl, screen=False)
+        assert not fell_back and pairs < 0.25 * (b - a) * I, (a, b, k, pairs, fell_back)     # a garbage image would keep or drop everything
+        assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32)), (a, b, k, between)
