@@ -113,7 +113,12 @@ struct FusedParams {
 // rule below), and where the two-kernel form writes the gradient row, this form takes Keras' Adam step on the row right away:
 // m, v (fetched when the segment starts) and theta updated IN PLACE, the pre-update theta left in old_rows[head] for the item
 // segments, hpos[b] = head for every triplet of the segment, Gu_last[user] = t.  Work proportional to B, whatever U is.
-template <int VW, int CPL, bool DEFER>
+// DEFER, PRE (round 5): the Adam slots m, v of a segment head and its Gu_last stamp are fetched TOGETHER with the row gathers of the
+// SUB positions in flight (a position is a head when its key differs from the one in front of it: known from the staged keys before
+// any row arrives) -- at 10 M users nearly every position of a 1 M-triplet batch starts a segment, and fetching m, v only once the
+// walk reaches the head put a second full memory latency behind every position's gathers (5 L + 4 R per four positions instead of
+// L + 4 R, at three waves per SIMD).
+template <int VW, int CPL, bool DEFER, int SUBD = 0>
 __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f) {
     const int F = p.st.F, lpt = p.lpt;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,24 +198,30 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
         u32* s_j = reinterpret_cast<u32*>(seg_lds) + (3 * ngl + gl) * BPR_USTG;
         float* s_bi = reinterpret_cast<float*>(seg_lds) + (4 * ngl + gl) * BPR_USTG;
         float* s_bj = reinterpret_cast<float*>(seg_lds) + (5 * ngl + gl) * BPR_USTG;
-        constexpr int SUB = (CPL == 1) ? 4 : (CPL == 2 ? 2 : 1);
+        int32_t* s_last = reinterpret_cast<int32_t*>(seg_lds) + (6 * ngl + gl) * BPR_USTG;
+        constexpr int SUB = SUBD > 0 ? SUBD : ((CPL == 1) ? 4 : (CPL == 2 ? 2 : 1));
+        constexpr bool PRE = DEFER && SUBD > 0;                 // m, v, Gu_last of segment heads prefetched with the gathers
         for (int64_t sbase = p0; sbase < p1; sbase += BPR_USTG) {
             const int cs = (int)((p1 - sbase < BPR_USTG) ? p1 - sbase : BPR_USTG);
             for (int t = sub; t < cs; t += lpt) {
                 const u32 b = p.vals[sbase + t];
                 const int32_t ii = p.bi[b], jj = p.bj[b];
-                s_key[t] = p.keys[sbase + t];
+                const u32 kk = p.keys[sbase + t];
+                s_key[t] = kk;
                 s_b[t] = b;
                 s_i[t] = (u32)ii;
                 s_j[t] = (u32)jj;
                 s_bi[t] = p.st.Bi[ii];
                 s_bj[t] = p.st.Bi[jj];
+                if (PRE) s_last[t] = f.replay ? f.last[kk] : 0;
             }
             el_wave_lds_sync();
             for (int base = 0; base < cs; base += SUB) {
                 int64_t keyv[SUB];
                 bool okv[SUB];
                 float rgu[SUB][CPL][VW], rgi[SUB][CPL][VW], rgj[SUB][CPL][VW];
+                float rm[PRE ? SUB : 1][CPL][VW], rv[PRE ? SUB : 1][CPL][VW];
+                int rlast[PRE ? SUB : 1];
 #pragma unroll
                 for (int t = 0; t < SUB; ++t) {
                     okv[t] = base + t < cs;
@@ -219,15 +230,26 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                     const float* pu = p.st.Gu + keyv[t] * F;
                     const float* pi = p.st.Gi + (int64_t)s_i[tt] * F;
                     const float* pj = p.st.Gi + (int64_t)s_j[tt] * F;
+                    // (group-uniform) this position starts a segment: what the walk below finds as key != cur
+                    const bool hd = PRE && okv[t] && (t == 0 ? keyv[0] != cur : keyv[t] != keyv[t > 0 ? t - 1 : 0]);
+                    if (PRE) rlast[PRE ? t : 0] = s_last[tt];
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) {
                         const int e = (sub + q * lpt) * VW;
 #pragma unroll
                         for (int x = 0; x < VW; ++x) rgu[t][q][x] = rgi[t][q][x] = rgj[t][q][x] = 0.f;
+                        if (PRE) {
+#pragma unroll
+                            for (int x = 0; x < VW; ++x) rm[PRE ? t : 0][q][x] = rv[PRE ? t : 0][q][x] = 0.f;
+                        }
                         if (okv[t] && e < F) {
                             ldv<VW>(pu + e, rgu[t][q]);
                             ldv<VW>(pi + e, rgi[t][q]);
                             ldv<VW>(pj + e, rgj[t][q]);
+                            if (hd) {
+                                ldv<VW>(p.st.mGu + keyv[t] * F + e, rm[PRE ? t : 0][q]);
+                                ldv<VW>(p.st.vGu + keyv[t] * F + e, rv[PRE ? t : 0][q]);
+                            }
                         }
                     }
                 }
@@ -250,15 +272,27 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                 acc[q][x] = 0.f;
                             }
                         if (DEFER) {                             // the row's Adam slots: needed when the segment ends
-                            const int lastv = f.replay ? f.last[key] : 0;
+                            int lastv;
+                            if (PRE) {                           // they arrived with the gathers
+                                lastv = rlast[PRE ? t : 0];
 #pragma unroll
-                            for (int q = 0; q < CPL; ++q) {
-                                const int e = (sub + q * lpt) * VW;
+                                for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                                for (int x = 0; x < VW; ++x) mrow[DEFER ? q : 0][x] = vrow[DEFER ? q : 0][x] = 0.f;
-                                if (e < F) {
-                                    ldv<VW>(p.st.mGu + key * F + e, mrow[DEFER ? q : 0]);
-                                    ldv<VW>(p.st.vGu + key * F + e, vrow[DEFER ? q : 0]);
+                                    for (int x = 0; x < VW; ++x) {
+                                        mrow[DEFER ? q : 0][x] = rm[PRE ? t : 0][q][x];
+                                        vrow[DEFER ? q : 0][x] = rv[PRE ? t : 0][q][x];
+                                    }
+                            } else {
+                                lastv = f.replay ? f.last[key] : 0;
+#pragma unroll
+                                for (int q = 0; q < CPL; ++q) {
+                                    const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                                    for (int x = 0; x < VW; ++x) mrow[DEFER ? q : 0][x] = vrow[DEFER ? q : 0][x] = 0.f;
+                                    if (e < F) {
+                                        ldv<VW>(p.st.mGu + key * F + e, mrow[DEFER ? q : 0]);
+                                        ldv<VW>(p.st.vGu + key * F + e, vrow[DEFER ? q : 0]);
+                                    }
                                 }
                             }
                             // the row's postponed gradient-free steps (last, t - 1], in registers, before anything uses it (what
@@ -1200,9 +1234,12 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     if (defer) pi.ubase = base.st.Gu_old, pi.uidx = w.hpos;      // the pre-update user rows, one per distinct user of the batch
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
-    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 6 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
+    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 7 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
     FusedParams fz;
     memset(&fz, 0, sizeof(fz));
+    // EL_BPR_USER_PRE: positions in flight per lane group with the heads' m / v prefetched (0 = the round-4 form: m, v fetched when the
+    // walk reaches the head)
+    static const int upre = [] { const char* e = getenv("EL_BPR_USER_PRE"); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 4) ? v : -1; }();
     // (EL_BPR_USER_WAVE_ROWS=1: measured 1.35 against 1.24 ms for the two-groups-per-wave form at 10M x 1M x 128 -- the replay's lane
     //  utilisation was not the bound, the loads in flight per wave are; kept as an experiment switch, off)
     static const bool vw2 = [] { const char* e = getenv("EL_BPR_USER_WAVE_ROWS"); return e && atoi(e) == 1; }();
@@ -1224,7 +1261,10 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
                 SegParams pw = pu;                                                                        \
                 pw.lpt = 64, pw.pair4 = 1;                                                                \
                 const unsigned gridW = (unsigned)((gu * 64 + 255) / 256);                                 \
-                EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 6 * 4, s, pw, fz);  \
+                EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
+            } else if (VW == 4 && CPL_ <= 2 && upre != 0) {                                               \
+                if (upre == 2 || CPL_ == 2) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 2>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+                else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, (CPL_ == 1 ? 4 : 2)>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
             } else {                                                                                      \
                 EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
             }                                                                                             \

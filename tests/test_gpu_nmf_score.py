@@ -341,11 +341,13 @@ def test_screened_route_rebuilds_its_item_image_after_an_unscreened_call_rebuilt
 
 
 @pytest.mark.parametrize("between", ["nothing", "unscreened_call"])
-def test_screened_route_keeps_its_item_image_across_user_blocks_of_other_sizes(ctx, between):
-    """The last, shorter user block of an evaluation reuses the workspace with EL_TOPK_ITEMS_UNCHANGED: the half-precision item image
+def test_screened_route_keeps_its_item_image_across_user_blocks_of_other_sizes(ctx, between, monkeypatch):
+    """(EL_NMF_SCREEN_MAXFRAC = 1: whatever share survives, the screened route is taken.)
+    The last, shorter user block of an evaluation reuses the workspace with EL_TOPK_ITEMS_UNCHANGED: the half-precision item image
     and its residual norms must be found where the full block built them (they sit in front of every region sized by the user range,
     k or the split), and an unscreened call in between -- whose user-side regions lie over the image -- forces their rebuild.  Lists
     and logit bits equal the unscreened call's either way, for a shorter block, another k, and a longer block again."""
+    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
     U, I, F = 300, 40_000, 64
     w = on.init_neumf(U, I, F, 31)
     st = ops.NmfDeviceState(ctx, w, max_batch=1024)
@@ -364,5 +366,8 @@ def test_screened_route_keeps_its_item_image_across_user_blocks_of_other_sizes(c
         assert st._score_ws.data_ptr() == ws_ptr or k > 10            # (same workspace unless a larger k outgrew it)
         ws_ptr = st._score_ws.data_ptr()
         ref_i, ref_v = ref.score_topk_logits(a, b, k, excl=excl, screen=False)
-        assert not fell_back and pairs < 0.25 * (b - a) * I, (a, b, k, pairs, fell_back)     # a garbage image would keep or drop everything
+        # the bounds come from the image: a fresh state that builds its own image for this very call must be left with the same pairs
+        fresh = ops.NmfDeviceState(ctx, w, max_batch=1024)
+        fresh.score_topk_logits(a, b, k, excl=excl, screen=True)
+        assert (pairs, fell_back) == fresh.screen_stats(), (a, b, k, pairs, fell_back, fresh.screen_stats())
         assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32)), (a, b, k, between)
