@@ -1294,7 +1294,14 @@ def emit(full, args):
             line = json.dumps(c, allow_nan=False, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
                 break
+    # the line is the LAST thing on stdout: C-level buffers first (RCCL prints its version banner through stdio, which a pipe holds
+    # back until exit -- behind the Python-level print of the line)
     sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     print(line, flush=True)
 
 
@@ -1377,6 +1384,14 @@ def main():
         if "neumf" in legs:
             neumf = neumf_leg(args, ctx)
             torch.cuda.empty_cache()
+    # every rank empties its C-level stdout (RCCL's banner) before rank 0 prints the line, so that the line is the last one
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    barrier(world)
     if rank != 0:
         return
 

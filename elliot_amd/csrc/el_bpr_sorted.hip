@@ -1239,7 +1239,7 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     memset(&fz, 0, sizeof(fz));
     // EL_BPR_USER_PRE: positions in flight per lane group with the heads' m / v prefetched (0 = the round-4 form: m, v fetched when the
     // walk reaches the head)
-    static const int upre = [] { const char* e = getenv("EL_BPR_USER_PRE"); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 4) ? v : -1; }();
+    static const int upre = [] { const char* e = getenv("EL_BPR_USER_PRE"); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 4 || v == 8) ? v : -1; }();
     // (EL_BPR_USER_WAVE_ROWS=1: measured 1.35 against 1.24 ms for the two-groups-per-wave form at 10M x 1M x 128 -- the replay's lane
     //  utilisation was not the bound, the loads in flight per wave are; kept as an experiment switch, off)
     static const bool vw2 = [] { const char* e = getenv("EL_BPR_USER_WAVE_ROWS"); return e && atoi(e) == 1; }();
@@ -1261,9 +1261,11 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
                 SegParams pw = pu;                                                                        \
                 pw.lpt = 64, pw.pair4 = 1;                                                                \
                 const unsigned gridW = (unsigned)((gu * 64 + 255) / 256);                                 \
-                EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
+                if (upre == 8) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4, 8>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
+                else if (upre == 4) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4, 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
+                else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
             } else if (VW == 4 && CPL_ <= 2 && upre != 0) {                                               \
-                if (upre == 2 || CPL_ == 2) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 2>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+                if (upre != 4 || CPL_ == 2) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 2>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
                 else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, (CPL_ == 1 ? 4 : 2)>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
             } else {                                                                                      \
                 EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \

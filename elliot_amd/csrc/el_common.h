@@ -43,6 +43,10 @@ struct el_ctx {
     int64_t nmf_I = 0;
     int nmf_E = 0, nmf_H1 = 0;
     size_t nmf_PI_off = 0, nmf_PIB_off = 0, nmf_Rn_off = 0;   // where the last call on nmf_ws put PI and its half-precision image (0: none)
+    // second stream of the library (weight-gradient products of the Mult-VAE backward pass run beside the chain that produces the
+    // input gradients) and the events that order the two; created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t nmf_screen_cands = 0;        // last el_nmf_score_topk: pairs the exact kernel scored (/ users / I_local = the survival rate)
     bool nmf_screen_fallback = false;    // ... and whether a call that asked for the screen went without it
     // el_bprmf_train_loop: the captured small-batch step sequence (hipGraphExec_t) and the launch parameters it was built for

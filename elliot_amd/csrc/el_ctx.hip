@@ -53,6 +53,9 @@ extern "C" int el_ctx_destroy(el_ctx* ctx) {
     }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->loop_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->loop_graph_exec);
+    for (auto e : ctx->side_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
     if (ctx->lr_copied) {
         (void)hipEventSynchronize(ctx->lr_copied);

@@ -54,6 +54,12 @@ struct GemmParams {
     int64_t units, nkt, tiles_n;
     int P, whole_tiles;
     const float* zeros;   // >= 16 bytes of zeros in device memory
+    // k_gemm_b3, XCD-aware workgroup order (1-D grid): tiles that read the same operand strip form a GROUP of `grp` consecutive
+    // workgroups of one XCD (workgroup b runs on XCD b % 8: observed, used for speed only -- any placement is correct)
+    int gx, gy, gz;       // tiles along N, M, K-splits
+    int grp_mode;         // 0: 3-D grid as launched; 1: group = the gy row tiles of one column strip; 2: group = the gx column tiles of one
+    //                       row strip; 3: group = every tile of one K split
+    int ngroups;
 };
 
 __device__ __forceinline__ float el_act(float v, int act) {
@@ -685,8 +691,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
     constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE;
     __shared__ __attribute__((aligned(16))) char lds[2 * IMG];   // A image, B image (48 KB)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, g = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * B3_BM, n0 = (int64_t)blockIdx.x * B3_BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * p.kchunk;
+    // tile of this workgroup.  Launched 3-D (grp_mode 0) the linear workgroup id walks N first, so the four or five row tiles that
+    // share a 26 744-wide column strip of the weights land on different XCDs at different times and every L2 fetches the strip again
+    // (round-4 PMC: 461 MB per launch against 120 MB of operands).  Launched 1-D, the tiles that share a strip are dealt to
+    // consecutive workgroups of ONE XCD: group gi -> XCD gi % 8, its tiles q % grp run side by side on that XCD's CUs.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.grp_mode != 0) {
+        const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
+        const unsigned grp = p.grp_mode == 1 ? (unsigned)p.gy : (p.grp_mode == 2 ? (unsigned)p.gx : (unsigned)(p.gx * p.gy));
+        const unsigned gi = (q / grp) * 8u + xcd, ti = q % grp;
+        if (gi >= (unsigned)p.ngroups) return;
+        if (p.grp_mode == 1) by = ti, bx = gi % (unsigned)p.gx, bz = gi / (unsigned)p.gx;
+        else if (p.grp_mode == 2) bx = ti, by = gi % (unsigned)p.gy, bz = gi / (unsigned)p.gy;
+        else bx = ti % (unsigned)p.gx, by = ti / (unsigned)p.gx, bz = gi;
+    }
+    const int64_t m0 = (int64_t)by * B3_BM, n0 = (int64_t)bx * B3_BN;
+    const int64_t kbeg = (int64_t)bz * p.kchunk;
     const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
     const int t = tid & 127;
     const bool stA = tid < 128;
@@ -740,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
         }
     }
     // epilogue: register r of column tile j = row 4 (8 (r / 4) + 4 g + r % 4) + w of the block, column 4 n + j
-    float* out = p.ws ? p.ws + (int64_t)blockIdx.z * p.M * p.N : p.C;
+    float* out = p.ws ? p.ws + (int64_t)bz * p.M * p.N : p.C;
     const int64_t ldo = p.ws ? p.N : p.ldc;
     const int64_t col = n0 + 4 * n;
     const int act = p.ws ? EL_ACT_NONE : p.act;
@@ -890,6 +910,21 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
         p.ws = splits > 1 ? (float*)ws : nullptr;
         p.zeros = ctx->zeros;
         dim3 grid((unsigned)((N + B3_BN - 1) / B3_BN), (unsigned)((M + B3_BM - 1) / B3_BM), (unsigned)splits);
+        // XCD-aware order (EL_GEMM_XCD=0: the 3-D grid of round 4): with K splits every tile of a split shares its two K chunks (up to
+        // 64 tiles per group); without, the tiles along the SHORTER grid edge share the strip of the longer operand
+        static const bool xcd_on = [] { const char* e = getenv("EL_GEMM_XCD"); return !(e && atoi(e) == 0); }();
+        p.gx = (int)grid.x, p.gy = (int)grid.y, p.gz = (int)grid.z;
+        if (xcd_on && (int64_t)grid.x * grid.y * grid.z >= 16) {
+            int64_t grp = 0;
+            if (splits > 1 && (int64_t)grid.x * grid.y <= 64) p.grp_mode = 3, grp = (int64_t)grid.x * grid.y, p.ngroups = splits;
+            else if (grid.y <= grid.x && grid.y <= 64) p.grp_mode = 1, grp = grid.y, p.ngroups = (int)((int64_t)grid.x * grid.z);
+            else if (grid.x <= 64) p.grp_mode = 2, grp = grid.x, p.ngroups = (int)((int64_t)grid.y * grid.z);
+            if (p.grp_mode != 0) {
+                const int64_t rounds = ((int64_t)p.ngroups + 7) / 8;
+                if (rounds * 8 * grp < (1LL << 31)) grid = dim3((unsigned)(rounds * 8 * grp), 1, 1);
+                else p.grp_mode = 0;
+            }
+        }
         // A is k-contiguous unless transposed ([K, M]); B ([K, N]) is k-contiguous when transposed ([N, K])
         if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
         else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);

@@ -590,33 +590,83 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     else
         EL_LAUNCH("k_vae_softmax", k_vae_softmax<false>, dim3((unsigned)B), dim3(SMX_NT), 0, s, st->logits, rows, indptr, indices, B, I, 1, loss_out, Bd);
     float* dl = st->logits;
+    // Two streams (round 5).  The chain dl -> dh2 -> dz -> d[mu|logvar] -> dh -> dW1 is serial and, below the 26 744-wide product,
+    // made of 512 x {200..600}^2 products that a few dozen workgroups finish in ~20 us each: latency, not throughput.  The weight
+    // gradients dW4, dW3, dW[m|v] and the five bias gradients (column sums) depend on the chain but nothing depends on them until
+    // the optimiser, so they run on the library's second stream beside it (fork after each link, one join at the end).  The side
+    // products take the upper half of the workspace: enabled when each half holds what its products need (a host that sizes the
+    // workspace 2 x el_gemm_ws_bytes gets it; EL_VAE_SIDE=0 turns it off), and when dz does not alias z (dW3 reads z while the
+    // chain writes dz).
+    static const bool side_env = [] { const char* e = getenv("EL_VAE_SIDE"); return !(e && atoi(e) == 0); }();
+    const int64_t LL = st->dae ? L : 2 * L;
+    const size_t half = (st->ws_bytes / 2) & ~(size_t)255;
+    size_t need_side = el_gemm_ws_bytes(ctx, H, I, B), need_main = el_gemm_ws_bytes(ctx, B, H, I);
+    {
+        const size_t a = el_gemm_ws_bytes(ctx, L, H, B), b = el_gemm_ws_bytes(ctx, H, LL, B);
+        const size_t c = el_gemm_ws_bytes(ctx, B, L, H), d = el_gemm_ws_bytes(ctx, B, H, LL), w1 = (size_t)(4 * (I + 1) + 4) * 4;
+        need_side = need_side > a ? need_side : a, need_side = need_side > b ? need_side : b;
+        need_main = need_main > c ? need_main : c, need_main = need_main > d ? need_main : d, need_main = need_main > w1 ? need_main : w1;
+    }
+    bool side_on = side_env && st->ws != nullptr && half >= need_side && half >= need_main && st->dz != st->z;
+    if (side_on && !ctx->side) {
+        if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) ctx->side = nullptr, side_on = false;
+        for (auto& e : ctx->side_ev)
+            if (side_on && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) side_on = false;
+    }
+    if (side_on)
+        for (auto e : ctx->side_ev) side_on = side_on && e != nullptr;
+    hipStream_t ss = side_on ? ctx->side : s;
+    void* ws1 = st->ws;
+    const size_t wsb1 = side_on ? half : st->ws_bytes;
+    void* ws2 = side_on ? (void*)((char*)st->ws + half) : st->ws;
+    const size_t wsb2 = side_on ? half : st->ws_bytes;
+    auto fork = [&](int k) -> int {                       // what the main stream has produced so far is visible to the side stream
+        if (!side_on) return 0;
+        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[k], s));
+        EL_CHECK_HIP(hipStreamWaitEvent(ss, ctx->side_ev[k], 0));
+        return 0;
+    };
     // decoder output layer
-    if (int rc = el_gemm_f32(ctx, s, 1, 0, H, I, B, st->h2, H, dl, I, st->g[6], I, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dW4 = h2^T dl
-    if (int rc = colsum(s, dl, B, I, st->g[7])) return rc;
-    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dh2 = dl W4^T
+    if (int rc = fork(0)) return rc;
+    if (int rc = el_gemm_f32(ctx, ss, 1, 0, H, I, B, st->h2, H, dl, I, st->g[6], I, nullptr, 0, ws2, wsb2)) return rc;   // dW4 = h2^T dl
+    if (int rc = colsum(ss, dl, B, I, st->g[7])) return rc;
+    if (side_on) EL_CHECK_HIP(hipEventRecord(ctx->side_ev[6], ss));                                                       // dl consumed on the side
+    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, ws1, wsb1)) return rc;   // dh2 = dl W4^T
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh2, st->h2, B * H);
-    if (int rc = el_gemm_f32(ctx, s, 1, 0, L, H, B, st->z, L, st->dh2, H, st->g[4], H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dW3 = z^T dh2pre
-    if (int rc = colsum(s, st->dh2, B, H, st->g[5])) return rc;
-    // dz reuses the z buffer after dW3 consumed z
-    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, L, H, st->dh2, H, st->w[4], H, st->dz, L, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dz = dh2pre W3^T
+    if (int rc = fork(1)) return rc;
+    if (int rc = el_gemm_f32(ctx, ss, 1, 0, L, H, B, st->z, L, st->dh2, H, st->g[4], H, nullptr, 0, ws2, wsb2)) return rc;  // dW3 = z^T dh2pre
+    if (int rc = colsum(ss, st->dh2, B, H, st->g[5])) return rc;
+    // (one stream: dz may reuse the z buffer after dW3 consumed z)
+    if (int rc = el_gemm_f32(ctx, s, 0, 1, B, L, H, st->dh2, H, st->w[4], H, st->dz, L, nullptr, 0, ws1, wsb1)) return rc;   // dz = dh2pre W3^T
     if (st->dae) {
         EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * L, ctx)), dim3(256), 0, s, st->dz, st->z, B * L);                       // through tanh
-        if (int rc = el_gemm_f32(ctx, s, 1, 0, H, L, B, st->h, H, st->dz, L, st->g[2], L, nullptr, 0, st->ws, st->ws_bytes)) return rc;    // dWm
-        if (int rc = colsum(s, st->dz, B, L, st->g[3])) return rc;
-        if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, L, st->dz, L, st->w[2], L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;   // dh
+        if (int rc = fork(2)) return rc;
+        if (int rc = el_gemm_f32(ctx, ss, 1, 0, H, L, B, st->h, H, st->dz, L, st->g[2], L, nullptr, 0, ws2, wsb2)) return rc;    // dWm
+        if (int rc = colsum(ss, st->dz, B, L, st->g[3])) return rc;
+        if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, L, st->dz, L, st->w[2], L, st->dh, H, nullptr, 0, ws1, wsb1)) return rc;   // dh
     } else {
         EL_LAUNCH("k_vae_dmv", k_vae_dmv, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, st->dz, st->mv, eps, B, L, anneal, st->dmv, Bd);
-        if (int rc = el_gemm_f32(ctx, s, 1, 0, H, 2 * L, B, st->h, H, st->dmv, 2 * L, st->g[2], 2 * L, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dWmv
-        if (int rc = colsum(s, st->dmv, B, 2 * L, st->g[3])) return rc;
-        if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, 2 * L, st->dmv, 2 * L, st->w[2], 2 * L, st->dh, H, nullptr, 0, st->ws, st->ws_bytes)) return rc;  // dh = dmv Wmv^T
+        if (int rc = fork(2)) return rc;
+        if (int rc = el_gemm_f32(ctx, ss, 1, 0, H, 2 * L, B, st->h, H, st->dmv, 2 * L, st->g[2], 2 * L, nullptr, 0, ws2, wsb2)) return rc;  // dWmv
+        if (int rc = colsum(ss, st->dmv, B, 2 * L, st->g[3])) return rc;
+        if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, 2 * L, st->dmv, 2 * L, st->w[2], 2 * L, st->dh, H, nullptr, 0, ws1, wsb1)) return rc;  // dh = dmv Wmv^T
     }
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh, st->h, B * H);
-    if (int rc = colsum(s, st->dh, B, H, st->g[1])) return rc;
+    if (int rc = fork(3)) return rc;
+    if (int rc = colsum(ss, st->dh, B, H, st->g[1])) return rc;
+    if (side_on) {
+        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[7], ss));             // join: everything the side stream was given
+        EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[6], 0));       // the logits buffer is free again (dW1's scratch lives there)
+    }
+    struct Join {                                                      // (every return path below joins)
+        el_ctx* c; hipStream_t s; bool on;
+        ~Join() { if (on) (void)hipStreamWaitEvent(s, c->side_ev[7], 0); }
+    } join{ctx, s, side_on};
     // dW1 = x~^T dhpre.  Sparse transposition of the batch (k_vae_w1_*) when its scratch fits: counters in the GEMM workspace,
     // the (item-ordered) list of batch rows in the logits buffer (free again: dl was consumed)
     static const bool sparse_on = [] { const char* e = getenv("EL_VAE_SPARSE_W1"); return !(e && atoi(e) == 0); }();
     const int cpl1 = (H / 4 + 63) / 64;
-    if (sparse_on && B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && st->ws_bytes >= (size_t)(4 * (I + 1) + 4) * 4 &&
+    if (sparse_on && B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && wsb1 >= (size_t)(4 * (I + 1) + 4) * 4 &&
         (((uintptr_t)st->dh | (uintptr_t)st->g[0]) & 15) == 0) {
         int32_t* cnt = (int32_t*)st->ws;
         int32_t* off = cnt + (I + 1);
@@ -649,7 +699,7 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     EL_CHECK_HIP(hipMemsetAsync(st->logits, 0, (size_t)B * I * 4, s));
     EL_LAUNCH("k_vae_densify", k_vae_densify, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, st->rnorm, B, I,
               dropout_rate, (u64)dropout_seed, (u32)step, st->logits);
-    if (int rc = el_gemm_f32(ctx, s, 1, 0, I, H, B, st->logits, I, st->dh, H, st->g[0], H, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+    if (int rc = el_gemm_f32(ctx, s, 1, 0, I, H, B, st->logits, I, st->dh, H, st->g[0], H, nullptr, 0, ws1, wsb1)) return rc;
     EL_CHECK_LAUNCH();
     return 0;
 }

@@ -1023,7 +1023,10 @@ class VaeDeviceState:
         self.logits, self.dh2, self.dmv, self.dh, self.rnorm = z(B, I), z(B, H), z(B, 2 * L), z(B, H), z(B)
         need = max(int(ctx.lib.el_gemm_ws_bytes(ctx.handle, *mnk)) for mnk in
                    ((B, H, I), (B, L, H), (B, H, 2 * L), (H, 2 * L, B), (L, H, B), (B, 2 * L, H), (H, I, B)))
-        self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        # twice what the products (and the dW1 scratch) need: el_vae_grads then runs the weight-gradient products on the library's
+        # second stream with the upper half as their workspace (el_vae.hip, vae_grads)
+        need = max(need, (4 * (I + 1) + 4) * 4)
+        self._ws = torch.empty(2 * ((max(need, 16) + 255) // 256 * 256) + 256, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.step = 0
         arr = lambda ts: (C.c_void_p * 8)(*[x.data_ptr() for x in ts])
