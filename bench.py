@@ -105,6 +105,10 @@ def parse():
                          "kernels and optimiser pass run (default: pipelined, 1.47 -> 1.41 ms per step; same kernels, same results)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trained-epochs", type=float, default=1.0, help="N = 1: epochs of further training before the top-k block is timed a second "
+                                                                     "time on trained tables (0: skip)")
+    ap.add_argument("--neumf-trained-steps", type=int, default=3000, help="neumf leg: further training steps before its scoring step is timed a "
+                                                                        "second time (0: skip)")
     ap.add_argument("--legs-file", default=None, help="where the full per-leg report goes (default: bench_legs.json beside bench.py; "
                                                       "the stdout line is the compact summary)")
     ap.add_argument("--cpu-topk-users", type=int, default=640)
@@ -503,6 +507,7 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     coll = data.get("coll") or parallel._Collectives()
     sharded = world > 1 or args.force_sharded
     collectives = []                                                          # (what, op, bytes per rank and call, callable)
+    cover_steps = 0
     if not sharded:
         st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
         pos_train = pos
@@ -548,6 +553,7 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         # one of their positives each; negatives in item order): ceil(max(U, I) / B) extra untimed steps, the same train_step.
         if args.opt == "adam_tf_dense" and (4 * B <= U or 2 * B <= I):
             cover_batches(st, indptr, indices, U if 4 * B <= U else 0, I if 2 * B <= I else 0, U, I, B, lr, l_w, l_b, args.train_algo)
+            cover_steps = -(-max(U if 4 * B <= U else 0, I if 2 * B <= I else 0) // B)
         # deferred decay of the user table (the state turns it on at its first batch when 4 B <= U): the timed region ends with
         # the replay of every postponed row update -- each (element, step) update of Keras' every-row Adam is inside the timed
         # region.  A no-op in the every-row form.
@@ -671,6 +677,9 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     prepare_topk()
     Kt = int(getattr(args, "topk_steps", 0) or K)            # (a leg whose top-k block takes 0.3 s times fewer of them than training steps)
     dt_topk, rep_topk = timed(ctx, world, topk_step, min(W, Kt), Kt)
+    single = world == 1 and not args.force_sharded
+    steps_so_far = int(rep_train.calls) + cover_steps
+    scr0 = ops.topk_screen_stats(ctx) if single else None     # (before any other scoring call: the diagnostics are the last call's)
 
     # ---- the fp32-only MFMA kernel beside the screened one: its arithmetic IS the reference's fp32 matmul form, the screened
     #      route returns the same bits after its exact re-score (tests/test_gpu_topk.py)
@@ -689,6 +698,28 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                      "roofline": {"kernel": n32, "bound": "mfma", "achieved": 2.0 * Ub * I * F / s32 / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": 2.0 * Ub * I * F / s32 / 1e12 / MFMA_F32_PEAK_TFLOPS, "dtype": "f32",
                                   "kernels_ms_per_step": {n: v[1] / K32 for n, v in rep32.items()}}}
+
+    # ---- the same block on TRAINED tables.  The screened route's work depends on the model: a trained BPR model puts its large-norm
+    #      (popular) items at the top of every list, exactly where the bf16 bound is widest.  After one more EPOCH
+    #      of training (`transactions` = nnz triplets, BPRMF_batch.py:95-109) the block is timed again, with the records the bf16 pass keeps
+    #      per user and the users that fall back to the exact kernels
+    trained = None
+    if single and args.trained_epochs > 0:
+        n_more = max(1, int(args.trained_epochs * int(pos.nnz)) // B)
+        for _ in range(n_more):
+            train_step()
+        if finish_train:
+            finish_train()
+        pop_loss()
+        Kt2 = max(2, min(Kt, 5))
+        dt_tr, rep_tr = timed(ctx, world, topk_step, 1, Kt2)
+        scr1 = ops.topk_screen_stats(ctx)
+        tn2, tsec2 = dominant(rep_tr)
+        trained = {"train_steps_before": steps_so_far + n_more, "value": Ub * Kt2 / dt_tr, "unit": "users/s", "ms_per_step": dt_tr / Kt2 * 1e3,
+                   "steps": Kt2, "records_per_user": scr1["records_per_user"], "fallback_users": scr1["fallback_users"],
+                   "kernel": tn2, "kernel_frac": (2.0 * Ub * I * F / tsec2 / 1e12) / (MFMA_BF16_PEAK_TFLOPS if tn2.startswith("k_screen") else MFMA_F32_PEAK_TFLOPS),
+                   "kernels_ms_per_step": {n: v[1] / Kt2 for n, v in rep_tr.items()},
+                   "what": f"the same top-k block after {n_more} more training steps ({args.trained_epochs:g} epoch(s) of {int(pos.nnz)} triplets)"}
 
     # ---- accuracy metrics from the index tensor: one block of users, synthetic held-out set -------------
     met = None
@@ -854,6 +885,10 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
                  "sharding": topk_sharding, "roofline": roof_topk},
         "interactions": int(pos.nnz), "topk_block": Ub,
     }
+    if scr0 is not None and scr0["users"]:
+        res["topk"]["screen"] = {"train_steps_before": steps_so_far, "records_per_user": scr0["records_per_user"], "fallback_users": scr0["fallback_users"]}
+    if trained is not None:
+        res["topk"]["trained"] = trained
     if fragile is not None:
         res["topk"]["fragile_users"] = fragile
     if f32_entry is not None:
@@ -1056,6 +1091,25 @@ def neumf_leg(args, ctx):
                            "traffic_source": nnote, "dtype": "f16" if screened else "f32",
                            "flops_per_pair": pair_flops, "flops_per_pair_reference_form": 2.0 * (2 * F * units[0] + units[0] * units[1] + units[1] * units[2]),
                            "kernels_ms_per_step": {n: v[1] / ks for n, v in rep_k.items()}}}
+        # ---- the same scoring step on a TRAINED network: the share of pairs the bound leaves to the exact kernel grows as the weights
+        #      move away from their initialisation (0.003 % -> 31 % over 3 000 steps); the line reports both ends
+        n_tr = int(getattr(args, "neumf_trained_steps", 0))
+        if n_tr > 0:
+            for _ in range(n_tr):
+                step()
+            st.sync()
+            st.pop_loss()
+            st._screen_skip = 0                                          # (the default policy gets a fresh try on the trained weights)
+            blk[0] = 0
+            dt_t, rep_t = timed(ctx, 1, topk_step, 1, ks)
+            pairs_t, fb_t = st.screen_stats()
+            scr_t = "k_nmf_screen" in rep_t and not fb_t
+            c_t, ms_t = rep_t.live.get("k_nmf_screen", rep_t.get("k_nmf_screen", (1, 0.0)))
+            tk["trained"] = {"train_steps_before": int(rep.calls) + n_tr, "value": nu * ks / dt_t, "unit": "users/s", "ms_per_step": dt_t / ks * 1e3,
+                             "screen": {"used": bool(scr_t), "exact_pairs": pairs_t, "exact_pairs_frac": pairs_t / float(nu * I), "fell_back": bool(fb_t)},
+                             "k_nmf_screen_TFLOPs": (pair_flops * nu * I / (ms_t / max(c_t, 1) * 1e-3) / 1e12) if ms_t > 0 else None,
+                             "kernels_ms_per_step": {n: v[1] / ks for n, v in rep_t.items()}}
+            tk["screen"]["train_steps_before"] = int(rep.calls)
     mlp_flops = B * (36.0 * F * F + 4.0 * F) * 3                       # fwd 36 F^2 + 4 F per sample, x3 fwd + bwd
     gms, groof = gemm_roofline(rep, mlp_flops, K)
     emb_bytes = 24.0 * 2 * (U + I) * F                                 # Keras Adam moves every row of the 4 embedding tables
@@ -1194,8 +1248,12 @@ def _topk_summary(t):
     if "fp32_mfma" in t:
         out["fp32_kernel_users_per_s"] = t["fp32_mfma"].get("value")
         out["fp32_kernel_frac"] = (t["fp32_mfma"].get("roofline") or {}).get("frac")
+    if "screen" in t and "records_per_user" in t["screen"]:
+        out["records_per_user"] = t["screen"]["records_per_user"]
+        out["train_steps_before"] = t["screen"].get("train_steps_before")
     if "trained" in t:
-        out["trained"] = t["trained"]
+        tr = t["trained"]
+        out["trained"] = {k: tr.get(k) for k in ("train_steps_before", "value", "ms_per_step", "records_per_user", "fallback_users", "kernel_frac")}
     return out
 
 
@@ -1254,7 +1312,11 @@ def compact_line(full):
                          "roofline": _roof(n.get("roofline"), ("gemm_ms_per_step",)),
                          "topk": {"users_per_s": nt.get("value"), "ms_per_step": nt.get("ms_per_step"),
                                   "roofline": _roof(nt.get("roofline")), "survivor_frac": (nt.get("screen") or {}).get("exact_pairs_frac"),
-                                  **({"trained": nt["trained"]} if "trained" in nt else {})} if nt else None,
+                                  "train_steps_before": (nt.get("screen") or {}).get("train_steps_before"),
+                                  **({"trained": {"train_steps_before": nt["trained"].get("train_steps_before"),
+                                                  "users_per_s": nt["trained"].get("value"), "ms_per_step": nt["trained"].get("ms_per_step"),
+                                                  "survivor_frac": nt["trained"]["screen"].get("exact_pairs_frac"),
+                                                  "fell_back": nt["trained"]["screen"].get("fell_back")}} if "trained" in nt else {})} if nt else None,
                          "workload": "NeuMF d=128, 1.25M users x 1M items (configs[3] per GPU), B=262144"}
     if legs:
         line["legs"] = legs

@@ -159,6 +159,7 @@ PROTOTYPES = {
     "el_rec_metrics": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _f32p,
                                  C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "el_score_topk_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int]),
+    "el_topk_screen_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "el_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int64, C.c_int32, _i64p, _i32p, _i64p, _i32p, C.c_int32, _i32p, _f32p,
                                 C.c_int, C.c_void_p, C.c_size_t]),

@@ -36,6 +36,10 @@ struct el_ctx {
     const float* prep_Bi = nullptr;
     int64_t prep_I = 0;
     int prep_F = 0;
+    // last screened el_score_topk call: where its per-user record counters and its flagged-user counter live (el_topk_screen_stats)
+    const int32_t* scr_cnt = nullptr;
+    const int32_t* scr_flagged = nullptr;
+    int64_t scr_users = 0;
     // el_nmf_score_topk: what the PI image (item-side layer-1 projection) in the last workspace was derived from
     const void* nmf_ws = nullptr;
     const float* nmf_Imlp = nullptr;

@@ -778,11 +778,122 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
     }
 }
 
-static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
+// ---- the same product with the operand staging on waves of its own (round 5) -----------------------------------------------
+// k_gemm_b3 above makes every wave do both jobs in turn: split + store the next tile (≈ 180 VALU instructions and 12 LDS stores per
+// lane), then read the fragments and issue 48 matrix instructions; while a workgroup stages, its matrix pipes idle, and the overlap
+// rests on the second workgroup of the CU being in the other phase (measured: matrix pipes busy half the time, 150-180 TFLOP/s).
+// Here a workgroup is 8 waves -- two per SIMD: waves 0-3 CONSUME (fragment reads + matrix instructions, nothing else), waves 4-7
+// PRODUCE (global loads of tile t + 2, split + store of tile t + 1 into the other LDS buffer) -- so each SIMD always has a wave with
+// matrix work and a wave with vector work to issue from, and the two pipes run side by side by construction.  Two 48 KB buffers, one
+// workgroup per CU, one LDS-only barrier per k tile.  Same split, same fragment images, same products in the same order, same
+// epilogue as k_gemm_b3: the results are bit-identical to it.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void k_gemm_b3w(GemmParams p) {
+    constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE, BUF = 2 * IMG;
+    extern __shared__ __attribute__((aligned(16))) char b3w_lds[];            // two buffers of (A image, B image): 96 KB
+    const int tid = threadIdx.x;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.grp_mode != 0) {                                                     // XCD-aware order: see k_gemm_b3
+        const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
+        const unsigned grp = p.grp_mode == 1 ? (unsigned)p.gy : (p.grp_mode == 2 ? (unsigned)p.gx : (unsigned)(p.gx * p.gy));
+        const unsigned gi = (q / grp) * 8u + xcd, ti = q % grp;
+        if (gi >= (unsigned)p.ngroups) return;
+        if (p.grp_mode == 1) by = ti, bx = gi % (unsigned)p.gx, bz = gi / (unsigned)p.gx;
+        else if (p.grp_mode == 2) bx = ti, by = gi % (unsigned)p.gy, bz = gi / (unsigned)p.gy;
+        else bx = ti % (unsigned)p.gx, by = ti / (unsigned)p.gx, bz = gi;
+    }
+    const int64_t m0 = (int64_t)by * B3_BM, n0 = (int64_t)bx * B3_BN;
+    const int64_t kbeg = (int64_t)bz * p.kchunk;
+    const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+    const int nit = kend > kbeg ? (int)((kend - kbeg + B3_BK - 1) / B3_BK) : 0;
+    if (tid >= 256) {
+        // ---- producer waves: threads 0..127 of the four stage the A tile, 128..255 the B tile (the roles of k_gemm_b3's staging half)
+        const int pt = tid - 256, t = pt & 127;
+        const bool stA = pt < 128;
+        float4 rg[8];
+        auto fetch = [&](int64_t k0) {
+            if (stA) b3_load<AKC>(p.A, p.lda, p.M, m0, kend, k0, t, p.zeros, rg);
+            else b3_load<BKC>(p.B, p.ldb, p.N, n0, kend, k0, t, p.zeros, rg);
+        };
+        auto stash = [&](char* buf) {
+            if (stA) b3_store<AKC>(rg, buf, t);
+            else b3_store<BKC>(rg, buf + IMG, t);
+        };
+        fetch(kbeg);
+        stash(b3w_lds);
+        fetch(kbeg + B3_BK);                                 // (past kend: zeros, never stored)
+        b3_lds_barrier();                                    // buffer 0 holds tile 0
+        for (int it = 0; it < nit; ++it) {
+            if (it + 1 < nit) {
+                stash(b3w_lds + ((it + 1) & 1) * BUF);       // the buffer the consumers left at the previous barrier
+                fetch(kbeg + (int64_t)(it + 2) * B3_BK);
+            }
+            b3_lds_barrier();
+        }
+        return;
+    }
+    // ---- consumer waves: wave w = row tile w against the four column tiles, as in k_gemm_b3
+    const int lane = tid & 63, w = tid >> 6, n = lane & 31, g = lane >> 5;
+    floatx16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int fa = (g * 128 + 32 * w + n) * 16, fb = IMG + (g * 128 + n) * 16;
+    b3_lds_barrier();
+    for (int it = 0; it < nit; ++it) {
+        const char* lds = b3w_lds + (it & 1) * BUF;
+        b3_h8 a[2][3], b[2][4][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[s][pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[s][j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
+            }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][2], b[s][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][2], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][0], acc[j], 0, 0, 0);
+        }
+        b3_lds_barrier();                                    // fragments of this buffer are in registers; the next one is complete
+    }
+    float* out = p.ws ? p.ws + (int64_t)bz * p.M * p.N : p.C;
+    const int64_t ldo = p.ws ? p.N : p.ldc;
+    const int64_t col = n0 + 4 * n;
+    const int act = p.ws ? EL_ACT_NONE : p.act;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!p.ws && p.bias && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);
+    if (col < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + 4 * (8 * (r >> 2) + 4 * g + (r & 3)) + w;
+            float4 v = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
+            if (act == EL_ACT_RELU) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+            else if (act != EL_ACT_NONE) v = make_float4(el_act(v.x, act), el_act(v.y, act), el_act(v.z, act), el_act(v.w, act));
+            if (row < p.M) *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+        }
+    }
+}
+
+static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K, int wg_per_cu = 2) {
     const int64_t tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
-    const int64_t target = (int64_t)ctx->cus * 2;
+    const int64_t target = (int64_t)ctx->cus * wg_per_cu;
     if (tiles >= target / 2 || K < 4 * GBK) return 1;
-    int64_t s = (target + tiles - 1) / tiles;
+    // as many splits as keep tiles x splits within the resident workgroups (rounding UP left 520 workgroups for 512 places at
+    // 512 x 600 x 26 744: eight of them ran a second round alone)
+    int64_t s = target / tiles;
     const int64_t maxs = K / (2 * GBK);
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
@@ -900,8 +1011,11 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
     const bool split_on = !(esplit && atoi(esplit) == 0);
     // (products under 2 GFLOP -- the 512 x 400 x 600 class -- are latency-bound: the one-launch small-tile path below stays faster)
     const bool outvec = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
+    // EL_GEMM_B3W=0: the round-4 kernel (every wave stages and multiplies in turn, two workgroups per CU)
+    const char* ew = getenv("EL_GEMM_B3W");
+    const bool b3w = !(ew && atoi(ew) == 0);
     if (split_on && fast0 && outvec && 2.0 * (double)M * (double)N * (double)K >= 2.0e9) {
-        splits = gemm_splits(ctx, M, N, K);
+        splits = gemm_splits(ctx, M, N, K, b3w ? 1 : 2);
         if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * 4)) splits = 1;
         p.kchunk = ((K + splits - 1) / splits + B3_BK - 1) / B3_BK * B3_BK;
         if (p.kchunk < B3_BK) p.kchunk = B3_BK;
@@ -916,7 +1030,9 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
         p.gx = (int)grid.x, p.gy = (int)grid.y, p.gz = (int)grid.z;
         if (xcd_on && (int64_t)grid.x * grid.y * grid.z >= 16) {
             int64_t grp = 0;
-            if (splits > 1 && (int64_t)grid.x * grid.y <= 64) p.grp_mode = 3, grp = (int64_t)grid.x * grid.y, p.ngroups = splits;
+            // (K splits: one group = every tile of a split was measured SLOWER -- 26 groups over 8 XCDs leave two XCDs a third more
+            //  work: 0.152 -> 0.176 ms at 512 x 600 x 26 744; left on the 3-D grid)
+            if (splits > 1) p.grp_mode = 0;
             else if (grid.y <= grid.x && grid.y <= 64) p.grp_mode = 1, grp = grid.y, p.ngroups = (int)((int64_t)grid.x * grid.z);
             else if (grid.x <= 64) p.grp_mode = 2, grp = grid.x, p.ngroups = (int)((int64_t)grid.y * grid.z);
             if (p.grp_mode != 0) {
@@ -926,7 +1042,20 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
             }
         }
         // A is k-contiguous unless transposed ([K, M]); B ([K, N]) is k-contiguous when transposed ([N, K])
-        if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
+        if (b3w) {
+            constexpr int LDSW = 2 * 2 * 3 * 4 * 128 * 16;            // two buffers x (A, B) x three planes x 8 KB
+#define EL_B3W(AK_, BK_)                                                                                                            \
+    do {                                                                                                                            \
+        auto kern = k_gemm_b3w<AK_, BK_>;                                                                                           \
+        EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW));   \
+        EL_LAUNCH("k_gemm_b3", kern, grid, dim3(512), (size_t)LDSW, s, p);                                                          \
+    } while (0)
+            if (!transA && !transB) EL_B3W(true, false);
+            else if (!transA && transB) EL_B3W(true, true);
+            else if (transA && !transB) EL_B3W(false, false);
+            else EL_B3W(false, true);
+#undef EL_B3W
+        } else if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
         else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
         else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
         else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);

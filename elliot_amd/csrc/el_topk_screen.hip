@@ -1132,5 +1132,40 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     TopkParams pw = p;
     pw.ulist = sp.ulist;
     pw.ulist_n = sp.ulist_n;
+    ctx->scr_cnt = sp.cnt, ctx->scr_flagged = sp.ulist_n, ctx->scr_users = n_users;
     return el_topk_run_list(pw, fb_scratch, fb_bytes, st);
+}
+
+// Diagnostics of the last screened el_score_topk call on this ctx (its workspace must still be alive): records pass 2 appended over
+// all users of the block (one record = up to 16 candidate items of one user), users sent to the exact fallback.
+__global__ __launch_bounds__(256) void k_screen_count(const int32_t* __restrict__ cnt, int64_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) s += (unsigned long long)(cnt[t] > 0 ? cnt[t] : 0);
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+extern "C" int el_topk_screen_stats(el_ctx* ctx, void* stream, int64_t* users, int64_t* records, int64_t* flagged_users) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(users && records && flagged_users, "el_topk_screen_stats: null output");
+    *users = *records = *flagged_users = 0;
+    if (!ctx->scr_cnt || ctx->scr_users <= 0) return 0;               // no screened call yet
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* d = nullptr;
+    EL_CHECK_HIP(hipMalloc((void**)&d, 8));
+    unsigned long long h = 0;
+    int32_t nf = 0;
+    hipError_t e = hipMemsetAsync(d, 0, 8, s);
+    if (e == hipSuccess) {
+        int64_t g = (ctx->scr_users + 255) / 256;
+        if (g > 1024) g = 1024;
+        hipLaunchKernelGGL(k_screen_count, dim3((unsigned)g), dim3(256), 0, s, ctx->scr_cnt, ctx->scr_users, d);
+        e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&nf, ctx->scr_flagged, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    EL_CHECK_HIP(e);
+    *users = ctx->scr_users, *records = (int64_t)h, *flagged_users = nf;
+    return 0;
 }

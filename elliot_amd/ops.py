@@ -272,6 +272,15 @@ def rec_metrics(ctx, rec_idx, test, threshold, cutoff, u_start=0, sums=None, per
     return (sums, rows) if per_user else sums
 
 
+def topk_screen_stats(ctx):
+    """Diagnostics of the last screened score_topk call (el_topk_screen_stats; synchronises): users of the block, records the bf16 pass
+    kept for them, users that took the exact fallback."""
+    u, r, f = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    check(ctx.lib.el_topk_screen_stats(ctx.handle, ctx.stream(), C.byref(u), C.byref(r), C.byref(f)), "el_topk_screen_stats")
+    return {"users": int(u.value), "records": int(r.value), "records_per_user": (r.value / u.value) if u.value else 0.0,
+            "fallback_users": int(f.value)}
+
+
 def fragile_users(ctx, Gu, Gi, Bi, u_start, u_stop, k, excl=None, cand=None, item_offset=0, algo="auto", flags=False):
     """Fragile-user report: how many of the users [u_start, u_stop) have a rank-k / rank-(k+1) score gap
     below the fp32 re-association bound F 2^-23 |u| max|i| -- for those (and only those) the top-k SET could differ under
@@ -969,8 +978,9 @@ def sgd_levels(u_host, i_host, j_host, U, I):
 ACTS = {None: 0, "none": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
 
 
-def gemm(ctx, A, B, transA=False, transB=False, bias=None, act=None, out=None):
-    """C = act(op(A) op(B) + bias) through el_gemm_f32 (keras Dense forward / backward products)."""
+def gemm(ctx, A, B, transA=False, transB=False, bias=None, act=None, out=None, ws=True):
+    """C = act(op(A) op(B) + bias) through el_gemm_f32 (keras Dense forward / backward products).  ws=False: no workspace (the
+    library then never splits K)."""
     M = A.shape[1] if transA else A.shape[0]
     K = A.shape[0] if transA else A.shape[1]
     N = B.shape[0] if transB else B.shape[1]
@@ -979,7 +989,7 @@ def gemm(ctx, A, B, transA=False, transB=False, bias=None, act=None, out=None):
         raise ValueError(f"inner dimensions differ: {K} vs {Kb}")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=ctx.device)
-    need = int(ctx.lib.el_gemm_ws_bytes(ctx.handle, int(M), int(N), int(K)))
+    need = int(ctx.lib.el_gemm_ws_bytes(ctx.handle, int(M), int(N), int(K))) if ws else 0
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=ctx.device) if need else None
     check(ctx.lib.el_gemm_f32(ctx.handle, ctx.stream(), int(bool(transA)), int(bool(transB)), int(M), int(N), int(K),
                               _ptr(A, torch.float32, "A"), int(A.stride(0)), _ptr(B, torch.float32, "B"),

@@ -394,6 +394,12 @@ int el_score_topk_f64(el_ctx* ctx, void* stream,
                       const int64_t* cand_indptr, const int32_t* cand_indices,
                       int32_t k, int32_t* out_idx, double* out_val);
 
+/* Diagnostics of the last SCREENED el_score_topk call on this ctx (synchronises the stream; the call's workspace must still be
+ * alive): users of the block, 64-bit records the bf16 pass appended for them (one record = the up-to-16 items of one lane that
+ * reached the user's threshold: what the exact fp32 re-scoring starts from), users that took the exact fallback.  Zeros when no
+ * screened call has run.  No reference counterpart (the reference materialises every score).                                    */
+int el_topk_screen_stats(el_ctx* ctx, void* stream, int64_t* users, int64_t* records, int64_t* flagged_users);
+
 /* Merge G partial top-k lists per user (item shards / item splits) into one, with the
  * same (score desc, index asc) rule.  parts_idx int32[G, n_users, k] (index -1 =
  * empty), parts_val float[G, n_users, k].  New design: the reference has

@@ -53,6 +53,39 @@ def test_gemm_three_way_split_is_fp32_grade(ctx, tA, tB, monkeypatch):
         assert np.sqrt((e3 ** 2).mean()) <= 2.0 * np.sqrt((e1 ** 2).mean()) + 2.0 ** -26, (float(np.sqrt((e3 ** 2).mean())), float(np.sqrt((e1 ** 2).mean())))
 
 
+@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_with_staging_waves_equals_the_one_role_kernel_bit_for_bit(ctx, tA, tB, monkeypatch):
+    """k_gemm_b3w (four waves stage, four multiply, two LDS buffers) performs the products of k_gemm_b3 in the same order on the same
+    fragment images: identical bits -- whole tiles, edge tiles, a K that is no multiple of the k tile, a split K (same split count
+    forced through the workspace-less call is not possible, so the split case compares against fp64 instead), bias + activation in
+    the epilogue, the XCD-aware workgroup order on and off."""
+    rs = np.random.RandomState(11)
+    d = ctx.device
+    for M, N, K in ((512, 26744, 600), (600, 1304, 1500), (260, 520, 8004), (128, 1028, 8000)):
+        A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+        Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+        bias = rs.normal(size=N).astype(np.float32)
+        At, Bt, bt = torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), torch.from_numpy(bias).to(d)
+        outs = {}
+        for w, x in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("EL_GEMM_B3W", w)
+            monkeypatch.setenv("EL_GEMM_XCD", x)
+            outs[(w, x)] = (ops.gemm(ctx, At, Bt, tA, tB, ws=False).clone(), ops.gemm(ctx, At, Bt, tA, tB, bias=bt, act="relu", ws=False).clone())
+        ref = outs[("0", "0")]
+        for key, val in outs.items():
+            assert torch.equal(val[0].view(torch.int32), ref[0].view(torch.int32)), (M, N, K, key)
+            assert torch.equal(val[1].view(torch.int32), ref[1].view(torch.int32)), (M, N, K, key)
+    # long K, few tiles: the split-K form (partials in the workspace + k_gemm_reduce) of either kernel against fp64
+    M, N, K = 512, 600, 26744
+    A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+    ref = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
+    for w in ("1", "0"):
+        monkeypatch.setenv("EL_GEMM_B3W", w)
+        got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
+        assert np.abs(got - ref).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02, w
+
+
 def test_gemm_unaligned_leading_dims(ctx):
     rs = np.random.RandomState(5)
     A = rs.normal(size=(70, 33)).astype(np.float32)       # lda = 33: scalar load path
