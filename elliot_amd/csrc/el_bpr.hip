@@ -787,6 +787,13 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
                    "el_bprmf_train_step: the deferred decay (Gu_last) needs the SORTED path and its workspace");
         sorted = true;
     }
+    if (st.Gi_last) {
+        // (the fused item side stamps Gi_last per row: a step on another path would leave the stamps behind and a later sorted step
+        //  would replay gradient-free updates on rows that are already current)
+        EL_REQUIRE(algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I),
+                   "el_bprmf_train_step: the fused item side (Gi_last) needs the SORTED path and its workspace");
+        sorted = true;
+    }
     EL_REQUIRE(sorted || !st.uslot, "el_bprmf_train_step: compact user-gradient rows (uslot) need the SORTED path and its workspace");
     EL_REQUIRE(sorted || !(st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE), "el_bprmf_train_step: a second user table (Gu_next) needs the SORTED path and its workspace");
     if (sorted)

@@ -94,6 +94,12 @@ struct ElKernelTimer {
 };
 
 void el_set_error(const char* fmt, ...);
+// (el_gemm.hip; library-internal, not exported: the C ABI's el_gemm_f32 is its plain form)
+struct el_ctx;
+__attribute__((visibility("hidden"))) int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                                        const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                                        const float* bias, int act, const float* rmask, int64_t ldy, float* colsum, void* ws,
+                                                        size_t ws_bytes, int* fused);
 
 #define EL_CHECK_HIP(expr)                                                                \
     do {                                                                                  \

@@ -56,6 +56,11 @@ struct GemmParams {
     const float* zeros;   // >= 16 bytes of zeros in device memory
     // k_gemm_b3, XCD-aware workgroup order (1-D grid): tiles that read the same operand strip form a GROUP of `grp` consecutive
     // workgroups of one XCD (workgroup b runs on XCD b % 8: observed, used for speed only -- any placement is correct)
+    // k_gemm_b3 epilogue of a Dense layer's backward pass (el_gemm_f32_x): C <- C where rmask > 0 else 0 (the ReLU derivative of the layer
+    // below, taken from its OUTPUT), colsum[n] += sum_m C[m, n] (that layer's bias gradient; colsum zeroed by the caller)
+    const float* rmask;
+    int64_t ldy;
+    float* colsum;
     int gx, gy, gz;       // tiles along N, M, K-splits
     int grp_mode;         // 0: 3-D grid as launched; 1: group = the gy row tiles of one column strip; 2: group = the gx column tiles of one
     //                       row strip; 3: group = every tile of one K split
@@ -766,6 +771,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
     const int act = p.ws ? EL_ACT_NONE : p.act;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!p.ws && p.bias && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);     // (N % 4 == 0 on this path; bias 16-byte aligned: checked by the host)
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < p.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -773,8 +779,47 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
             float4 v = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
             if (act == EL_ACT_RELU) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
             else if (act != EL_ACT_NONE) v = make_float4(el_act(v.x, act), el_act(v.y, act), el_act(v.z, act), el_act(v.w, act));
-            if (row < p.M) *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+            if (row < p.M) {
+                if (p.rmask) {                                          // (workgroup-uniform; the host never sets it with split K)
+                    const float4 y = *reinterpret_cast<const float4*>(p.rmask + row * p.ldy + col);
+                    v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+                    cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
+                }
+                *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+            }
         }
+    }
+    if (p.rmask) {
+        // column sums of the tile: the two lane halves hold different rows of the same four columns, the four waves different rows
+        // again -- one atomic per column and tile (the bias gradient's summation order is the hardware's, as in k_relu_bwd_colsum)
+        cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64), cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
+        __syncthreads();                                                // every wave is done with the fragment images
+        float* red = reinterpret_cast<float*>(lds);
+        if (g == 0) *reinterpret_cast<float4*>(red + w * 128 + 4 * n) = cs;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const float t4 = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            if (t4 != 0.f) atomicAdd(p.colsum + n0 + tid, t4);
+        }
+    }
+}
+
+// one staging role of k_gemm_b3w (below): tile 0 into buffer 0, then per k tile: split + store tile it + 1 into the other buffer, issue
+// the loads of tile it + 2, LDS-only barrier (the loads stay in flight across it)
+template <bool KC>
+__device__ __forceinline__ void b3w_produce(const float* __restrict__ X, int64_t ld, int64_t nX, int64_t x0, int64_t kbeg, int64_t kend, int nit,
+                                            int t, const float* __restrict__ zeros, char* lds, int img_off, int buf_bytes) {
+    float4 rg[8];
+    b3_load<KC>(X, ld, nX, x0, kend, kbeg, t, zeros, rg);
+    b3_store<KC>(rg, lds + img_off, t);
+    b3_load<KC>(X, ld, nX, x0, kend, kbeg + B3_BK, t, zeros, rg);       // (past kend: zeros, never stored)
+    b3_lds_barrier();                                                    // buffer 0 holds tile 0
+    for (int it = 0; it < nit; ++it) {
+        if (it + 1 < nit) {
+            b3_store<KC>(rg, lds + ((it + 1) & 1) * buf_bytes + img_off, t);     // the buffer the consumers left at the previous barrier
+            b3_load<KC>(X, ld, nX, x0, kend, kbeg + (int64_t)(it + 2) * B3_BK, t, zeros, rg);
+        }
+        b3_lds_barrier();
     }
 }
 
@@ -788,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
 // workgroup per CU, one LDS-only barrier per k tile.  Same split, same fragment images, same products in the same order, same
 // epilogue as k_gemm_b3: the results are bit-identical to it.
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512) void k_gemm_b3w(GemmParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_b3w(GemmParams p) {
     constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE, BUF = 2 * IMG;
     extern __shared__ __attribute__((aligned(16))) char b3w_lds[];            // two buffers of (A image, B image): 96 KB
     const int tid = threadIdx.x;
@@ -807,29 +852,13 @@ __global__ __launch_bounds__(512) void k_gemm_b3w(GemmParams p) {
     const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
     const int nit = kend > kbeg ? (int)((kend - kbeg + B3_BK - 1) / B3_BK) : 0;
     if (tid >= 256) {
-        // ---- producer waves: threads 0..127 of the four stage the A tile, 128..255 the B tile (the roles of k_gemm_b3's staging half)
-        const int pt = tid - 256, t = pt & 127;
-        const bool stA = pt < 128;
-        float4 rg[8];
-        auto fetch = [&](int64_t k0) {
-            if (stA) b3_load<AKC>(p.A, p.lda, p.M, m0, kend, k0, t, p.zeros, rg);
-            else b3_load<BKC>(p.B, p.ldb, p.N, n0, kend, k0, t, p.zeros, rg);
-        };
-        auto stash = [&](char* buf) {
-            if (stA) b3_store<AKC>(rg, buf, t);
-            else b3_store<BKC>(rg, buf + IMG, t);
-        };
-        fetch(kbeg);
-        stash(b3w_lds);
-        fetch(kbeg + B3_BK);                                 // (past kend: zeros, never stored)
-        b3_lds_barrier();                                    // buffer 0 holds tile 0
-        for (int it = 0; it < nit; ++it) {
-            if (it + 1 < nit) {
-                stash(b3w_lds + ((it + 1) & 1) * BUF);       // the buffer the consumers left at the previous barrier
-                fetch(kbeg + (int64_t)(it + 2) * B3_BK);
-            }
-            b3_lds_barrier();
-        }
+        // ---- producer waves: waves 4, 5 stage the A tile, waves 6, 7 the B tile (the roles of k_gemm_b3's staging halves).  The
+        // role is decided on a SCALAR (readfirstlane): each role runs its own straight-line loop -- with a per-lane `if (A) ... else
+        // ...` inside one loop the compiler joins the two arms in front of the last load and waits there for every load in flight
+        // (s_waitcnt vmcnt(0) ahead of the barrier: a full memory latency per k tile, measured 0.75 -> 0.94 ms at 4096^3)
+        const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (pw < 6) b3w_produce<AKC>(p.A, p.lda, p.M, m0, kbeg, kend, nit, tid - 256, p.zeros, b3w_lds, 0, BUF);
+        else b3w_produce<BKC>(p.B, p.ldb, p.N, n0, kbeg, kend, nit, tid - 384, p.zeros, b3w_lds, IMG, BUF);
         return;
     }
     // ---- consumer waves: wave w = row tile w against the four column tiles, as in k_gemm_b3
@@ -897,6 +926,7 @@ static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K, int wg_per_
     const int64_t maxs = K / (2 * GBK);
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
+    if (s >= 8) s &= ~(int64_t)7;                        // equal shares for the 8 XCDs (the XCD-aware order groups the tiles of a split)
     return s < 1 ? 1 : (int)s;
 }
 
@@ -977,6 +1007,16 @@ static int gemm_launch_tile(el_ctx* ctx, const GemmParams& p, const GemmPlan& pl
 extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                            const float* bias, int act, void* ws, size_t ws_bytes) {
+    return el_gemm_f32_x(ctx, stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, nullptr, 0, nullptr, ws, ws_bytes, nullptr);
+}
+
+// el_gemm_f32 + the optional backward epilogue of a Dense layer (library-internal: el_neural.hip).  rmask / colsum: C is masked with
+// the ReLU derivative of rmask [M, ldy] and its column sums are ADDED to colsum[N] inside the GEMM's epilogue -- when the product runs on
+// k_gemm_b3 without a K split; *fused tells (0: C holds the plain product, the caller applies mask and sums itself).
+int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, const float* rmask, int64_t ldy,
+                  float* colsum, void* ws, size_t ws_bytes, int* fused) {
+    if (fused) *fused = 0;
     if (int rc = el_bind(ctx)) return rc;
     EL_REQUIRE(A && B && C, "el_gemm_f32: null matrix");
     EL_REQUIRE(M >= 0 && N >= 0 && K >= 0, "el_gemm_f32: negative dimension");
@@ -1011,9 +1051,10 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
     const bool split_on = !(esplit && atoi(esplit) == 0);
     // (products under 2 GFLOP -- the 512 x 400 x 600 class -- are latency-bound: the one-launch small-tile path below stays faster)
     const bool outvec = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
-    // EL_GEMM_B3W=0: the round-4 kernel (every wave stages and multiplies in turn, two workgroups per CU)
+    // EL_GEMM_B3W=1: the kernel with staging waves of its own, one workgroup per CU (measured: 3-4 % ahead on the long-K weight-gradient
+    // products, 5-20 % behind on the short-K ones -- both forms run at the rate their tiles are fed from beyond L2; off by default)
     const char* ew = getenv("EL_GEMM_B3W");
-    const bool b3w = !(ew && atoi(ew) == 0);
+    const bool b3w = ew && atoi(ew) == 1;
     if (split_on && fast0 && outvec && 2.0 * (double)M * (double)N * (double)K >= 2.0e9) {
         splits = gemm_splits(ctx, M, N, K, b3w ? 1 : 2);
         if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * 4)) splits = 1;
@@ -1023,6 +1064,12 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
         if (splits < 1) splits = 1;
         p.ws = splits > 1 ? (float*)ws : nullptr;
         p.zeros = ctx->zeros;
+        const bool want_mask = rmask != nullptr && colsum != nullptr;
+        const bool fuse_mask = want_mask && splits == 1 && !b3w && ldy % 4 == 0 && ((uintptr_t)rmask % 16 == 0) && ldy >= N;
+        if (fuse_mask) {
+            p.rmask = rmask, p.ldy = ldy, p.colsum = colsum;
+            if (fused) *fused = 1;
+        }
         dim3 grid((unsigned)((N + B3_BN - 1) / B3_BN), (unsigned)((M + B3_BM - 1) / B3_BM), (unsigned)splits);
         // XCD-aware order (EL_GEMM_XCD=0: the 3-D grid of round 4): with K splits every tile of a split shares its two K chunks (up to
         // 64 tiles per group); without, the tiles along the SHORTER grid edge share the strip of the longer operand
@@ -1030,10 +1077,12 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
         p.gx = (int)grid.x, p.gy = (int)grid.y, p.gz = (int)grid.z;
         if (xcd_on && (int64_t)grid.x * grid.y * grid.z >= 16) {
             int64_t grp = 0;
-            // (K splits: one group = every tile of a split was measured SLOWER -- 26 groups over 8 XCDs leave two XCDs a third more
-            //  work: 0.152 -> 0.176 ms at 512 x 600 x 26 744; left on the 3-D grid)
-            if (splits > 1) p.grp_mode = 0;
-            else if (grid.y <= grid.x && grid.y <= 64) p.grp_mode = 1, grp = grid.y, p.ngroups = (int)((int64_t)grid.x * grid.z);
+            // (K splits: one group = every tile of a split -- they read the same two K chunks.  Only with a split count that deals
+            //  the XCDs equal shares: 26 groups over 8 XCDs left two of them a third more work, 0.152 -> 0.176 ms at 512 x 600 x 26 744;
+            //  gemm_splits rounds to a multiple of 8 for that reason)
+            if (splits > 1) {
+                if (splits % 8 == 0 && (int64_t)grid.x * grid.y <= 64) p.grp_mode = 3, grp = (int64_t)grid.x * grid.y, p.ngroups = splits;
+            } else if (grid.y <= grid.x && grid.y <= 64) p.grp_mode = 1, grp = grid.y, p.ngroups = (int)((int64_t)grid.x * grid.z);
             else if (grid.x <= 64) p.grp_mode = 2, grp = grid.x, p.ngroups = (int)((int64_t)grid.y * grid.z);
             if (p.grp_mode != 0) {
                 const int64_t rounds = ((int64_t)p.ngroups + 7) / 8;

@@ -792,11 +792,16 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
     // in registers anyway); the layers below take theirs in k_relu_bwd_colsum together with the bias gradient
     launch_nmf_head(ctx, s, st, label, n, 1, nullptr, loss_out, n_div, head_grid(n, ctx));
     if (st->use_mlp) {
+        // (round 5) the ReLU derivative and the bias gradient of layer l - 1 ride in the epilogue of the product that writes its input
+        // gradient (el_gemm_f32_x: one write of d instead of write + read + write, no read of d for the column sums) -- without Dropout
+        // (its mask comes between the product and the ReLU test) and where the product runs on the split kernel unsplit
+        static const bool fuse_env = [] { const char* e = getenv("EL_NMF_FUSE_RELU_BWD"); return !(e && atoi(e) == 0); }();
+        bool done_below = false;                  // dact[l] already carries layer l's ReLU derivative and gb[l] its column sums
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
             const float* in = (l == 0) ? st->X0 : st->act[l - 1];
             const int64_t kin = (l == 0) ? 2 * (int64_t)st->E : st->units[l - 1];
-            {
+            if (!done_below) {
                 const int W = units < 256 ? (int)units : 256, R = 256 / W;
                 const unsigned gx = (unsigned)((units + W - 1) / W);
                 int64_t gy = ((int64_t)ctx->cus * 8 + gx - 1) / gx, rows = (n + R - 1) / R;
@@ -807,9 +812,15 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
                     EL_LAUNCH("k_relu_bwd_colsum", k_relu_bwd_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], st->act[l], n,
                               units, st->gb[l]);
             }
+            done_below = false;
             if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
             float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
-            if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+            if (l >= 1 && fuse_env && !(st->dropout > 0.f)) {
+                int fused = 0;
+                if (int rc = el_gemm_f32_x(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->act[l - 1], kin,
+                                           st->gb[l - 1], st->ws, st->ws_bytes, &fused)) return rc;
+                done_below = fused != 0;
+            } else if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, st->ws_bytes)) return rc;
             // gradient w.r.t. the DROPPED input -> w.r.t. the layer below: the same mask again.  (The relu test of the layer
             // below then reads its dropped output: zero exactly where this mask is zero, positive where it was positive.)
             if (st->dropout > 0.f) nmf_dropout(s, st, din, n, kin, l);

@@ -104,6 +104,7 @@ class BPRMF_batch_model:
     # -- checkpoints (same keys as the NumPy model's pickle, BPRMF_model.py:119-139, plus optimiser slots) ----
     def get_model_state(self):
         st = self.state
+        st.sync()                     # deferred decay: every row of both tables AND of their Adam slots current before anything is read
         d = {"_user_factors": st.Gu.cpu().numpy(), "_item_factors": st.Gi.cpu().numpy(),
              "_item_bias": st.Bi.cpu().numpy(), "_step": st.step}
         for n in ("mGu", "vGu", "mGi", "vGi", "mBi", "vBi"):

@@ -429,7 +429,11 @@ int el_dense_topk(el_ctx* ctx, void* stream, const float* preds, int64_t ld,
  * Arithmetic: fp32 operands and results.  Aligned products of 2 GFLOP and more run on v_mfma_f32_32x32x16_bf16 with every
  * operand split into three bf16 planes -- six bf16 products per fp32 product, fp32 accumulation, error at the level of fp32
  * rounding (csrc/el_gemm.hip: k_gemm_b3; tests/test_gpu_dense.py); EL_GEMM_SPLIT=0 in the environment keeps everything on
- * v_mfma_f32_32x32x2_f32.  Neither form promises a summation order (the scoring kernels do: el_score_topk*, el_nmf_score_topk). */
+ * v_mfma_f32_32x32x2_f32.  Neither form promises a summation order (the scoring kernels do: el_score_topk*, el_nmf_score_topk).
+ * Non-finite operands: the split form computes the lower planes as a - upper(a), so an INFINITE operand yields NaN planes and the
+ * entries it reaches come out NaN where the fp32 instruction returns +-Inf (or NaN: Inf * 0); a NaN operand gives NaN in both
+ * forms.  Finite operands never produce a non-finite plane.  (The models' activations and weights are finite; a caller that relies
+ * on Inf propagation sets EL_GEMM_SPLIT=0.)                                                                                    */
 size_t el_gemm_ws_bytes(el_ctx* ctx, int64_t M, int64_t N, int64_t K);
 int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
