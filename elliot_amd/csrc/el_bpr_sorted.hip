@@ -1104,12 +1104,19 @@ __global__ __launch_bounds__(256) void k_selftest_step(int iters, u64* out) {
         const float lr = __uint_as_float(((127u - 30u + (u32)(selftest_mix(s) % 30)) << 23) | ((u32)s & 0x7fffffu));
         if (!(el_replay_ok(mm[0], vv[0]) && el_replay_ok(mm[1], vv[1]) && el_replay_lr_ok(lr))) continue;
         el_f2 T = {th[0], th[1]}, M = {mm[0], mm[1]}, V = {vv[0], vv[1]};
+        // (the production form: the first step of a chunk seeds its square root with v_rsq, the following ones with the root of the
+        //  step before -- el_adam_replay2s; the step size moves from step to step as it does in a run: lr_t of Adam's bias correction)
+        el_f2 SG, SH;
         for (int k = 0; k < EL_REPLAY_CHUNK; ++k) {
-            el_adam_replay2(T, M, V, lr);
-            for (int h = 0; h < 2; ++h) el_adam_elem(th[h], mm[h], vv[h], 0.0f, lr, b1, b2, omb1, omb2, eps);
+            const float lrk = lr * (1.0f - 0.01f * (float)k);
+            if (k == 0) el_adam_replay2s<true>(T, M, V, lrk, SG, SH);
+            else el_adam_replay2s<false>(T, M, V, lrk, SG, SH);
+            for (int h = 0; h < 2; ++h) el_adam_elem(th[h], mm[h], vv[h], 0.0f, lrk, b1, b2, omb1, omb2, eps);
         }
         bad += (__float_as_uint(T.x) != __float_as_uint(th[0])) + (__float_as_uint(T.y) != __float_as_uint(th[1])) +
-               (__float_as_uint(M.x) != __float_as_uint(mm[0])) + (__float_as_uint(V.y) != __float_as_uint(vv[1]));
+               (__float_as_uint(M.x) != __float_as_uint(mm[0])) + (__float_as_uint(M.y) != __float_as_uint(mm[1])) +
+               (__float_as_uint(V.x) != __float_as_uint(vv[0])) + (__float_as_uint(V.y) != __float_as_uint(vv[1])) +
+               (__float_as_uint(SG.x) != __float_as_uint(sqrtf(vv[0]))) + (__float_as_uint(SG.y) != __float_as_uint(sqrtf(vv[1])));
     }
     if (bad) atomicAdd((unsigned long long*)(out + 2), (unsigned long long)bad);
 }

@@ -321,6 +321,38 @@ __device__ __forceinline__ void el_adam_replay2(el_f2& th, el_f2& m, el_f2& v, f
     th = th - el_pk_div(m * lr, el_pk_sqrt(v) + 1e-7f);           // theta - (lr_t m) / (sqrt(v) + eps)
 }
 
+// The same step inside a run of consecutive steps (round 5): sqrt(v) of step k is sqrt(0.999 v) of step k - 1 -- the correctly rounded
+// root s and the refined half-reciprocal h of the step before, scaled by sqrt(b2) and 1 / sqrt(b2), are a seed of the accuracy
+// v_rsq gives (2^-22; v' = RN(b2 v), s = RN(sqrt v), two constant roundings, one product rounding), so the refinement and the final
+// residual step RN(g + h (v' - g g)) that follow return the correctly rounded root again (the residual is exact in the fma, a square
+// root is never a rounding tie) -- without the transcendental instruction, a quarter-rate one.  Inside the guard of el_replay_ok m
+// and v stay normal and non-zero through a chunk, so the `+ 0` of m b1 + g (1 - b1) with g = 0 (which only turns a -0 product into
+// +0) is the identity there and is left out.  Checked against el_adam_elem on 2^31 random 8-step runs on every box
+// (el_selftest_replay_math, out[2]) and by the bit-for-bit tests of the deferred decay.
+#define EL_SQRT_B2 0.9994998574256897f       // RN(sqrt(0.999f))
+#define EL_RSQRT_B2 1.0005003213882446f      // RN(1 / sqrt(0.999f))
+template <bool FIRST>
+__device__ __forceinline__ void el_adam_replay2s(el_f2& th, el_f2& m, el_f2& v, float lr, el_f2& G, el_f2& H) {
+    const el_f2 half = {0.5f, 0.5f};
+    m = m * 0.9f;
+    v = v * 0.999f;
+    el_f2 g, h;
+    if (FIRST) {
+        el_f2 y;
+        y.x = __builtin_amdgcn_rsqf(v.x), y.y = __builtin_amdgcn_rsqf(v.y);
+        g = v * y, h = y * 0.5f;
+    } else {
+        g = G * EL_SQRT_B2, h = H * EL_RSQRT_B2;
+    }
+    const el_f2 r = __builtin_elementwise_fma(-h, g, half);
+    g = __builtin_elementwise_fma(g, r, g);
+    h = __builtin_elementwise_fma(h, r, h);
+    const el_f2 d = __builtin_elementwise_fma(-g, g, v);
+    G = __builtin_elementwise_fma(d, h, g);                        // == sqrtf(v) per element
+    H = h;
+    th = th - el_pk_div(m * lr, G + 1e-7f);                        // theta - (lr_t m) / (sqrt(v) + eps)
+}
+
 // ns gradient-free steps on the VW elements a lane holds (wave-uniform ns; lr of step k at lrs(k)).  Elements at the m = v = 0
 // fixed point of the step (rows or slots that never had a gradient, lanes past the end of a row) do not keep a wave off the packed
 // path: they ride along and get their values back.
@@ -362,6 +394,24 @@ __device__ __forceinline__ void el_adam_replay(float (&th)[VW], float (&mm)[VW],
         }
         if (fast) {
             el_f2 T[VW >= 2 ? VW / 2 : 1], M[VW >= 2 ? VW / 2 : 1], V[VW >= 2 ? VW / 2 : 1];
+#ifndef EL_REPLAY_UNSEEDED
+            el_f2 SG[VW >= 2 ? VW / 2 : 1], SH[VW >= 2 ? VW / 2 : 1];    // sqrt(v) and its half-reciprocal of the step before
+#pragma unroll
+            for (int x = 0; x + 1 < VW; x += 2) {
+                T[x / 2].x = th[x], T[x / 2].y = th[x + 1];
+                M[x / 2].x = mm[x], M[x / 2].y = mm[x + 1];
+                V[x / 2].x = vv[x], V[x / 2].y = vv[x + 1];
+            }
+#pragma unroll
+            for (int x = 0; x + 1 < VW; x += 2) el_adam_replay2s<true>(T[x / 2], M[x / 2], V[x / 2], lrv[0], SG[x / 2], SH[x / 2]);   // (c >= 1)
+#pragma unroll
+            for (int k = 1; k < EL_REPLAY_CHUNK; ++k) {
+                if (k < c) {
+#pragma unroll
+                    for (int x = 0; x + 1 < VW; x += 2) el_adam_replay2s<false>(T[x / 2], M[x / 2], V[x / 2], lrv[k], SG[x / 2], SH[x / 2]);
+                }
+            }
+#else                                                                  // (A/B builds: every step seeds its square root with v_rsq)
 #pragma unroll
             for (int x = 0; x + 1 < VW; x += 2) {
                 T[x / 2].x = th[x], T[x / 2].y = th[x + 1];
@@ -375,6 +425,7 @@ __device__ __forceinline__ void el_adam_replay(float (&th)[VW], float (&mm)[VW],
                     for (int x = 0; x + 1 < VW; x += 2) el_adam_replay2(T[x / 2], M[x / 2], V[x / 2], lrv[k]);
                 }
             }
+#endif
 #pragma unroll
             for (int x = 0; x + 1 < VW; x += 2) {
                 th[x] = dead ? th[x] : T[x / 2].x, th[x + 1] = dead ? th[x + 1] : T[x / 2].y;

@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 5   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
+#define EL_ABI_VERSION 6   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
                             * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*
                             * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
@@ -43,7 +43,9 @@ typedef struct el_ctx el_ctx;
                             *    batch_n) and the el_nmf_* calls take it non-const; el_nmf_sync_tables; el_bprmf_state ends
                             *    in Gu_last .. lr_hist_cap, el_bprmf_sync_users
                             * 5: el_bprmf_state ends in Gi_last / Gi_defer (item side of the step fused with its
-                            *    Adam pass), el_bprmf_sync_items                                                        */
+                            *    Adam pass), el_bprmf_sync_items
+                            * 6: el_topk_screen_stats (diagnostics of the screened top-k; no struct changes: a host built
+                            *    against 5 runs unchanged)                                                               */
 
 /* ---- context ---------------------------------------------------------------- */
 
