@@ -985,7 +985,17 @@ def vae_leg(args, ctx):
         it[0] += 1
         st.train_step(csr, perm[b * B:(b + 1) * B], 0.001, min(0.2, it[0] / 200000.0), eps=eps)
 
-    dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False)
+    def step_one_stream():
+        # the per-kernel breakdown: the same kernels back to back on one stream (the step proper runs the weight-gradient products, the
+        # column sums and the index of the sparse first-layer gradient on the library's second stream: elapsed times of kernels that
+        # overlap mean nothing)
+        os.environ["EL_VAE_SIDE"] = "0"
+        try:
+            step()
+        finally:
+            os.environ.pop("EL_VAE_SIDE", None)
+
+    dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False, fn_breakdown=step_one_stream)
     loss = st.pop_loss()
     ms = dt / K * 1e3
     nnz_row = float(csr.nnz) / U
@@ -1038,7 +1048,16 @@ def neumf_leg(args, ctx):
 
     # the timed region ends with st.sync(): under the deferred decay (el_nmf_state.row_last) the postponed every-row updates of
     # the K steps are replayed there -- every (element, step) update of Keras' Adam is inside the timed region
-    dt, rep = timed(ctx, 1, step, W, K, finish=st.sync, events_in_timed_region=False)
+    def step_one_stream():
+        # the per-kernel breakdown: the same kernels on one stream (the step proper runs the tower's weight-gradient products on the library's
+        # second stream beside the embedding kernels: elapsed times of overlapping kernels mean nothing)
+        os.environ["EL_NMF_SIDE"] = "0"
+        try:
+            step()
+        finally:
+            os.environ.pop("EL_NMF_SIDE", None)
+
+    dt, rep = timed(ctx, 1, step, W, K, finish=st.sync, events_in_timed_region=False, fn_breakdown=step_one_stream)
     loss = st.pop_loss()
     ms = dt / K * 1e3
     # ---- full-catalogue scoring + top-k: el_nmf_score_topk on a block of users against the leg's whole catalogue.

@@ -51,6 +51,7 @@ struct el_ctx {
     // input gradients) and the events that order the two; created on first use
     hipStream_t side = nullptr;
     hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool side_join_pending = false;      // el_nmf_train_step: the side stream's weight gradients are joined inside the apply half
     int64_t nmf_screen_cands = 0;        // last el_nmf_score_topk: pairs the exact kernel scored (/ users / I_local = the survival rate)
     bool nmf_screen_fallback = false;    // ... and whether a call that asked for the screen went without it
     // el_bprmf_train_loop: the captured small-batch step sequence (hipGraphExec_t) and the launch parameters it was built for
@@ -94,8 +95,9 @@ struct ElKernelTimer {
 };
 
 void el_set_error(const char* fmt, ...);
-// (el_gemm.hip; library-internal, not exported: the C ABI's el_gemm_f32 is its plain form)
 struct el_ctx;
+__attribute__((visibility("hidden"))) bool el_side_stream_ready(el_ctx* ctx);      // (el_ctx.hip) creates ctx->side / side_ev on first use
+// (el_gemm.hip; library-internal, not exported: the C ABI's el_gemm_f32 is its plain form)
 __attribute__((visibility("hidden"))) int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                                                         const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                                                         const float* bias, int act, const float* rmask, int64_t ldy, float* colsum, void* ws,

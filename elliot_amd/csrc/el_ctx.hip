@@ -44,6 +44,20 @@ extern "C" int el_ctx_create(int device, el_ctx** out) {
     return 0;
 }
 
+bool el_side_stream_ready(el_ctx* ctx) {
+    if (!ctx) return false;
+    if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
+        ctx->side = nullptr;
+        return false;
+    }
+    for (auto& e : ctx->side_ev)
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            e = nullptr;
+            return false;
+        }
+    return true;
+}
+
 extern "C" int el_ctx_destroy(el_ctx* ctx) {
     if (!ctx) return 0;
     if (g_el_cur_ctx == ctx) g_el_cur_ctx = nullptr;

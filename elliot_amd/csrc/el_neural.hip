@@ -774,8 +774,10 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, el_nmf_state* st, const
 
 // forward, BinaryCrossentropy (mean over n_div samples: n_div = n, or the global batch when several ranks share a step),
 // backward: every gradient buffer of the state is complete on exit
+// defer_join (el_nmf_train_step): the weight-gradient products may still be running on the library's second stream when this returns;
+// nmf_apply waits for them after it has launched the embedding rows' step (ctx->side_join_pending)
 static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, const float* label,
-                     int64_t n, int64_t n_div, double* loss_out) {
+                     int64_t n, int64_t n_div, double* loss_out, bool defer_join = false) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
     if (nmf_deferred(st)) {
@@ -796,6 +798,23 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
         // gradient (el_gemm_f32_x: one write of d instead of write + read + write, no read of d for the column sums) -- without Dropout
         // (its mask comes between the product and the ReLU test) and where the product runs on the split kernel unsplit
         static const bool fuse_env = [] { const char* e = getenv("EL_NMF_FUSE_RELU_BWD"); return !(e && atoi(e) == 0); }();
+        // Two streams (round 5): the weight gradients gW[l] = in^T dact[l] (K = the batch: split-K products, 1.0 of the 3.2 ms the
+        // tower's products take) are needed by the optimiser only; the chain dact[last] -> ... -> dX0 -> embedding scatter -> embedding
+        // rows' Adam step does not wait for them.  They run on the library's second stream, forked as each dact[l] becomes final, and
+        // overlap with the chain's bandwidth-bound tail (k_nmf_scatter, k_nmf_apply_rows).  Their split-K partials take the upper half of
+        // the workspace (a host that sizes it 2 x el_gemm_ws_bytes gets the overlap; EL_NMF_SIDE=0 turns it off).
+        const char* side_e = getenv("EL_NMF_SIDE");             // (per call: bench.py's per-kernel breakdown runs one stream)
+        size_t need_w = 0;
+        for (int l = 0; l < st->n_layers; ++l) {
+            const size_t a = el_gemm_ws_bytes(ctx, l == 0 ? 2 * (int64_t)st->E : st->units[l - 1], st->units[l], n);
+            need_w = a > need_w ? a : need_w;
+        }
+        const size_t half = (st->ws_bytes / 2) & ~(size_t)255;
+        bool side_on = !(side_e && atoi(side_e) == 0) && st->ws != nullptr && half >= need_w && n >= 4096 && !ctx->side_join_pending;
+        if (side_on) side_on = el_side_stream_ready(ctx);
+        hipStream_t ss = side_on ? ctx->side : s;
+        void* ws_w = side_on ? (void*)((char*)st->ws + half) : st->ws;
+        const size_t wsb_w = side_on ? half : st->ws_bytes, wsb_d = side_on ? half : st->ws_bytes;
         bool done_below = false;                  // dact[l] already carries layer l's ReLU derivative and gb[l] its column sums
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
@@ -806,28 +825,44 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
                 const unsigned gx = (unsigned)((units + W - 1) / W);
                 int64_t gy = ((int64_t)ctx->cus * 8 + gx - 1) / gx, rows = (n + R - 1) / R;
                 if (gy > rows) gy = rows;
-                if (l == st->n_layers - 1)       // the head applied this layer's ReLU derivative already: column sums only
-                    EL_LAUNCH("k_nmf_colsum", k_nmf_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], n, units, st->gb[l]);
-                else
+                if (l == st->n_layers - 1) {     // the head applied this layer's ReLU derivative already: column sums only
+                    if (side_on) {               // (nothing on the chain needs them: second stream, behind the head)
+                        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));
+                        EL_CHECK_HIP(hipStreamWaitEvent(ss, ctx->side_ev[4], 0));
+                    }
+                    EL_LAUNCH("k_nmf_colsum", k_nmf_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, ss, st->dact[l], n, units, st->gb[l]);
+                } else
                     EL_LAUNCH("k_relu_bwd_colsum", k_relu_bwd_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], st->act[l], n,
                               units, st->gb[l]);
             }
             done_below = false;
-            if (int rc = el_gemm_f32(ctx, s, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+            if (side_on) {                        // dact[l] is final: its weight gradient goes to the side stream
+                EL_CHECK_HIP(hipEventRecord(ctx->side_ev[l & 3], s));
+                EL_CHECK_HIP(hipStreamWaitEvent(ss, ctx->side_ev[l & 3], 0));
+            }
+            if (int rc = el_gemm_f32(ctx, ss, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, ws_w, wsb_w)) return rc;
             float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
             if (l >= 1 && fuse_env && !(st->dropout > 0.f)) {
                 int fused = 0;
                 if (int rc = el_gemm_f32_x(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->act[l - 1], kin,
-                                           st->gb[l - 1], st->ws, st->ws_bytes, &fused)) return rc;
+                                           st->gb[l - 1], st->ws, wsb_d, &fused)) return rc;
                 done_below = fused != 0;
-            } else if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, st->ws_bytes)) return rc;
+            } else if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, wsb_d)) return rc;
             // gradient w.r.t. the DROPPED input -> w.r.t. the layer below: the same mask again.  (The relu test of the layer
             // below then reads its dropped output: zero exactly where this mask is zero, positive where it was positive.)
             if (st->dropout > 0.f) nmf_dropout(s, st, din, n, kin, l);
         }
+        if (side_on) {
+            EL_CHECK_HIP(hipEventRecord(ctx->side_ev[7], ss));           // every weight gradient is complete
+            ctx->side_join_pending = true;
+        }
     }
     EL_LAUNCH("k_nmf_scatter", k_nmf_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
     EL_CHECK_LAUNCH();
+    if (ctx->side_join_pending && !defer_join) {                         // el_nmf_grads: the caller reads the gradients next
+        EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[7], 0));
+        ctx->side_join_pending = false;
+    }
     return 0;
 }
 
@@ -845,6 +880,10 @@ static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t) {
         EL_LAUNCH("k_nmf_apply_rows", k_nmf_apply_rows, dim3((unsigned)((2 * st->batch_n + 3) / 4)), dim3(256), 0, s, *st, st->batch_u,
                   st->batch_i, st->batch_n, t, lr_t);
         st->batch_u = st->batch_i = nullptr, st->batch_n = 0;
+    }
+    if (ctx->side_join_pending) {                  // the Dense layers' weight gradients (second stream) before their Adam step
+        EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[7], 0));
+        ctx->side_join_pending = false;
     }
     for (int t = 0; t < 4 && !nmf_deferred(st); ++t) {
         const bool on = (t < 2) ? st->use_mf : st->use_mlp;
@@ -880,7 +919,7 @@ extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, el_nmf_state* st, co
     if (int rc = nmf_check(st, n, true)) return rc;
     EL_REQUIRE(u && i && label && loss_out && step >= 1, "el_nmf_train_step: bad arguments");
     if (nmf_deferred(st)) EL_REQUIRE(step == st->opt_step + 1, "el_nmf_train_step: step %d does not follow the state's %d applied steps", (int)step, (int)st->opt_step);
-    if (int rc = nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n, loss_out)) return rc;
+    if (int rc = nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n, loss_out, true)) return rc;
     return nmf_apply(ctx, (hipStream_t)stream, st, lr_t);
 }
 

@@ -597,8 +597,10 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     // products take the upper half of the workspace: enabled when each half holds what its products need (a host that sizes the
     // workspace 2 x el_gemm_ws_bytes gets it; EL_VAE_SIDE=0 turns it off), and when dz does not alias z (dW3 reads z while the
     // chain writes dz).
-    static const bool side_env = [] { const char* e = getenv("EL_VAE_SIDE"); return !(e && atoi(e) == 0); }();
+    const char* side_e = getenv("EL_VAE_SIDE");             // (read per call: bench.py's per-kernel breakdown pass runs one stream)
+    const bool side_env = !(side_e && atoi(side_e) == 0);
     const int64_t LL = st->dae ? L : 2 * L;
+    const size_t w1_bytes = ((size_t)(4 * (I + 1) + 4) * 4 + 255) & ~(size_t)255;     // dW1's index arrays (below)
     const size_t half = (st->ws_bytes / 2) & ~(size_t)255;
     size_t need_side = el_gemm_ws_bytes(ctx, H, I, B), need_main = el_gemm_ws_bytes(ctx, B, H, I);
     {
@@ -607,19 +609,34 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
         need_side = need_side > a ? need_side : a, need_side = need_side > b ? need_side : b;
         need_main = need_main > c ? need_main : c, need_main = need_main > d ? need_main : d, need_main = need_main > w1 ? need_main : w1;
     }
-    bool side_on = side_env && st->ws != nullptr && half >= need_side && half >= need_main && st->dz != st->z;
-    if (side_on && !ctx->side) {
-        if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) ctx->side = nullptr, side_on = false;
-        for (auto& e : ctx->side_ev)
-            if (side_on && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) side_on = false;
-    }
-    if (side_on)
-        for (auto e : ctx->side_ev) side_on = side_on && e != nullptr;
+    bool side_on = side_env && st->ws != nullptr && half >= need_side + w1_bytes && half >= need_main && st->dz != st->z;
+    if (side_on) side_on = el_side_stream_ready(ctx);
     hipStream_t ss = side_on ? ctx->side : s;
     void* ws1 = st->ws;
     const size_t wsb1 = side_on ? half : st->ws_bytes;
     void* ws2 = side_on ? (void*)((char*)st->ws + half) : st->ws;
-    const size_t wsb2 = side_on ? half : st->ws_bytes;
+    const size_t wsb2 = side_on ? half - w1_bytes : st->ws_bytes;
+    // dW1 = x~^T dhpre by sparse transposition of the batch (k_vae_w1_*) when its scratch fits.  Its index arrays (per-item counts,
+    // offsets, cursors, the heavy-item list) depend on the batch alone, the (item-ordered) list of batch rows goes into the logits
+    // buffer once dl is consumed: with two streams the side stream builds all of it beside the chain (arrays at the end of its half
+    // of the workspace), and the main stream only runs the two kernels that need dh.
+    static const bool sparse_on = [] { const char* e = getenv("EL_VAE_SPARSE_W1"); return !(e && atoi(e) == 0); }();
+    const int cpl1 = (H / 4 + 63) / 64;
+    const bool sparse_w1 = sparse_on && B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && st->ws != nullptr &&
+                           wsb1 >= (size_t)(4 * (I + 1) + 4) * 4 && (((uintptr_t)st->dh | (uintptr_t)st->g[0]) & 15) == 0;
+    int32_t* cnt = side_on ? (int32_t*)((char*)st->ws + half + wsb2) : (int32_t*)st->ws;
+    int32_t* off = cnt + (I + 1);
+    int32_t* cursor = off + (I + 1);
+    int32_t* heavy = cursor + (I + 1);                              // [1 + I]
+    int32_t* pairs = (int32_t*)st->logits;                          // <= B * I entries: every batch row has <= I nonzeros
+    auto w1_index = [&](hipStream_t q, bool wait_dl_readers) -> int {
+        EL_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(I + 1) * 4, q));
+        EL_LAUNCH("k_vae_w1_count", k_vae_w1_count, dim3((unsigned)B), dim3(256), 0, q, rows, indptr, indices, cnt);
+        EL_LAUNCH("k_vae_w1_scan", k_vae_w1_scan, dim3(1), dim3(1024), 0, q, cnt, I, off, cursor, heavy);
+        if (wait_dl_readers) EL_CHECK_HIP(hipStreamWaitEvent(q, ctx->side_ev[4], 0));      // dh2 = dl W4^T (main stream) has read dl
+        EL_LAUNCH("k_vae_w1_fill", k_vae_w1_fill, dim3((unsigned)B), dim3(256), 0, q, rows, indptr, indices, cursor, pairs);
+        return 0;
+    };
     auto fork = [&](int k) -> int {                       // what the main stream has produced so far is visible to the side stream
         if (!side_on) return 0;
         EL_CHECK_HIP(hipEventRecord(ctx->side_ev[k], s));
@@ -632,6 +649,11 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     if (int rc = colsum(ss, dl, B, I, st->g[7])) return rc;
     if (side_on) EL_CHECK_HIP(hipEventRecord(ctx->side_ev[6], ss));                                                       // dl consumed on the side
     if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, ws1, wsb1)) return rc;   // dh2 = dl W4^T
+    if (side_on && sparse_w1) {
+        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));                                                                 // ... and on the main one
+        if (int rc = w1_index(ss, true)) return rc;
+        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[5], ss));                                                                // the batch's index is built
+    }
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh2, st->h2, B * H);
     if (int rc = fork(1)) return rc;
     if (int rc = el_gemm_f32(ctx, ss, 1, 0, L, H, B, st->z, L, st->dh2, H, st->g[4], H, nullptr, 0, ws2, wsb2)) return rc;  // dW3 = z^T dh2pre
@@ -662,21 +684,9 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
         el_ctx* c; hipStream_t s; bool on;
         ~Join() { if (on) (void)hipStreamWaitEvent(s, c->side_ev[7], 0); }
     } join{ctx, s, side_on};
-    // dW1 = x~^T dhpre.  Sparse transposition of the batch (k_vae_w1_*) when its scratch fits: counters in the GEMM workspace,
-    // the (item-ordered) list of batch rows in the logits buffer (free again: dl was consumed)
-    static const bool sparse_on = [] { const char* e = getenv("EL_VAE_SPARSE_W1"); return !(e && atoi(e) == 0); }();
-    const int cpl1 = (H / 4 + 63) / 64;
-    if (sparse_on && B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && wsb1 >= (size_t)(4 * (I + 1) + 4) * 4 &&
-        (((uintptr_t)st->dh | (uintptr_t)st->g[0]) & 15) == 0) {
-        int32_t* cnt = (int32_t*)st->ws;
-        int32_t* off = cnt + (I + 1);
-        int32_t* cursor = off + (I + 1);
-        int32_t* pairs = (int32_t*)st->logits;                      // <= B * I entries: every batch row has <= I nonzeros
-        EL_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(I + 1) * 4, s));
-        EL_LAUNCH("k_vae_w1_count", k_vae_w1_count, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, cnt);
-        int32_t* heavy = cursor + (I + 1);                          // [1 + I]
-        EL_LAUNCH("k_vae_w1_scan", k_vae_w1_scan, dim3(1), dim3(1024), 0, s, cnt, I, off, cursor, heavy);
-        EL_LAUNCH("k_vae_w1_fill", k_vae_w1_fill, dim3((unsigned)B), dim3(256), 0, s, rows, indptr, indices, cursor, pairs);
+    if (sparse_w1) {
+        if (side_on) EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[5], 0));      // built on the side stream (above)
+        else if (int rc = w1_index(s, false)) return rc;                           // one stream: counters in the GEMM workspace, here
         int cap = 1024;                                             // presence flags: >= 64 batch rows per wave
         while (cap < B) cap <<= 1;
         const size_t lds = (size_t)W1_NW * (H / 4) * 16 + (size_t)cap;

@@ -1035,8 +1035,9 @@ class VaeDeviceState:
                    ((B, H, I), (B, L, H), (B, H, 2 * L), (H, 2 * L, B), (L, H, B), (B, 2 * L, H), (H, I, B)))
         # twice what the products (and the dW1 scratch) need: el_vae_grads then runs the weight-gradient products on the library's
         # second stream with the upper half as their workspace (el_vae.hip, vae_grads)
-        need = max(need, (4 * (I + 1) + 4) * 4)
-        self._ws = torch.empty(2 * ((max(need, 16) + 255) // 256 * 256) + 256, dtype=torch.uint8, device=dev)
+        w1 = ((4 * (I + 1) + 4) * 4 + 255) // 256 * 256         # dW1's index arrays: at the end of the side half
+        need = max(need, w1)
+        self._ws = torch.empty(2 * ((max(need, 16) + 255) // 256 * 256 + w1) + 256, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.step = 0
         arr = lambda ts: (C.c_void_p * 8)(*[x.data_ptr() for x in ts])
@@ -1244,7 +1245,9 @@ class NmfDeviceState:
         for l in range(len(self.units)):
             for mnk in ((B, dims[l + 1], dims[l]), (dims[l], dims[l + 1], B), (B, dims[l], dims[l + 1])):
                 need = max(need, int(ctx.lib.el_gemm_ws_bytes(ctx.handle, *mnk)))
-        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        # twice the products' need: the weight-gradient products of the backward pass then run on the library's second stream with the
+        # upper half as their split-K workspace (el_neural.hip, nmf_grads)
+        self._ws = torch.empty(2 * ((need + 255) // 256 * 256) + 256, dtype=torch.uint8, device=dev)
 
     def ensure_batch(self, n):
         """Grow the activation buffers to hold a batch of n samples: the reference takes ONE optimiser step per batch
