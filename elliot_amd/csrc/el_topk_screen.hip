@@ -993,7 +993,11 @@ static int launch_pass(const ScreenParams& sp, hipStream_t st) {
     ScreenParams q = sp;
     // pace keeping: only when every workgroup of the launch is resident at once (a workgroup that has not started would hold its XCD
     // back for the bounded naps of every check), at most 64 per XCD, and the sweep is long enough for drift to matter
-    static const bool pace_env = [] { const char* e = getenv("EL_SCREEN_PACE"); return !(e && atoi(e) == 0); }();
+    // (EL_SCREEN_PACE=1 turns it on.  Measured, round 5: 131 072 users x 1 M x 128 with it 26.1 ms per pass-2 launch against 25.9
+    //  without; at the 5 M x 256 shard the two workgroups a CU would need do not fit beside each other (162 VGPRs), the launch runs in two
+    //  rounds and the condition below keeps it off -- FETCH_SIZE 735 GiB per launch either way.  The pass is not bound by where its item
+    //  tiles come from; left in as a switch, off.)
+    static const bool pace_env = [] { const char* e = getenv("EL_SCREEN_PACE"); return e && atoi(e) == 1; }();
     q.prog = nullptr;
     const int64_t group_bytes = (int64_t)NSUB * SCR_TI * FP * 2;
     const int64_t groups = ((q.t.I_local + SCR_TI - 1) / SCR_TI / (MODE == 1 ? q.stride : 1) + NSUB - 1) / NSUB;
