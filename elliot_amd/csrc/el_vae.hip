@@ -649,7 +649,12 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     if (int rc = colsum(ss, dl, B, I, st->g[7])) return rc;
     if (side_on) EL_CHECK_HIP(hipEventRecord(ctx->side_ev[6], ss));                                                       // dl consumed on the side
     if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, ws1, wsb1)) return rc;   // dh2 = dl W4^T
-    if (side_on && sparse_w1) {
+    // (EL_VAE_SIDE_INDEX=1: the index of the sparse dW1 on the side stream as well.  Measured and left off: 0.831-0.837 ms per step, what
+    //  ONE stream takes (0.830), against 0.782 with the index on the chain's own stream -- the side stream then has to wait for the chain's
+    //  dl W4^T before it may overwrite dl with the row list, and everything queued behind that wait starts late)
+    static const bool side_index = [] { const char* e = getenv("EL_VAE_SIDE_INDEX"); return e && atoi(e) == 1; }();
+    const bool index_on_side = side_on && sparse_w1 && side_index;
+    if (index_on_side) {
         EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));                                                                 // ... and on the main one
         if (int rc = w1_index(ss, true)) return rc;
         EL_CHECK_HIP(hipEventRecord(ctx->side_ev[5], ss));                                                                // the batch's index is built
@@ -685,8 +690,8 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
         ~Join() { if (on) (void)hipStreamWaitEvent(s, c->side_ev[7], 0); }
     } join{ctx, s, side_on};
     if (sparse_w1) {
-        if (side_on) EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[5], 0));      // built on the side stream (above)
-        else if (int rc = w1_index(s, false)) return rc;                           // one stream: counters in the GEMM workspace, here
+        if (index_on_side) EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[5], 0));      // built on the side stream (above)
+        else if (int rc = w1_index(s, false)) return rc;                                  // on this stream, here (dl is consumed: ev 6 above)
         int cap = 1024;                                             // presence flags: >= 64 batch rows per wave
         while (cap < B) cap <<= 1;
         const size_t lds = (size_t)W1_NW * (H / 4) * 16 + (size_t)cap;
