@@ -574,9 +574,16 @@ static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const
 
 // forward, loss (batch means over Bd rows: Bd = B, or the global batch when several ranks share a step) and backward: the eight
 // gradient buffers st->g[] are complete on exit
+// Adam on the variables whose bit is set in `mask` (bit k = variable k of W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4); defined below
+static int vae_apply_vars(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t, unsigned mask);
+
+// early_lr_t >= 0 (el_vae_train_step): with two streams the output layer's Adam step (W4, b4: half of the optimiser's bytes) is taken
+// on the side stream as soon as its gradients are complete and the chain's dl W4^T has read W4 -- beside the chain's latency-bound
+// tail instead of after it; *early_mask tells vae_apply which variables are done
 static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
                      const int32_t* rows, int64_t B, int64_t Bd, const float* eps, float anneal, float dropout_rate,
-                     uint64_t dropout_seed, int32_t step, double* loss_out) {
+                     uint64_t dropout_seed, int32_t step, double* loss_out, float early_lr_t = -1.f, unsigned* early_mask = nullptr) {
+    if (early_mask) *early_mask = 0u;
     if (int rc = vae_check(st, B)) return rc;
     EL_REQUIRE(indptr && indices && rows && loss_out && step >= 1 && Bd >= B, "el_vae: bad arguments");
     for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t], "el_vae: gradient buffers missing");
@@ -649,6 +656,15 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     if (int rc = colsum(ss, dl, B, I, st->g[7])) return rc;
     if (side_on) EL_CHECK_HIP(hipEventRecord(ctx->side_ev[6], ss));                                                       // dl consumed on the side
     if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, ws1, wsb1)) return rc;   // dh2 = dl W4^T
+    // (EL_VAE_EARLY_ADAM=1.  Measured and left off: 0.770-0.781 ms per step against 0.768 -- with two streams the chip is busy end to
+    //  end, moving 0.45 GB of optimiser traffic under the chain's tail only takes bandwidth from the kernels it runs beside)
+    static const bool early_env = [] { const char* e = getenv("EL_VAE_EARLY_ADAM"); return e && atoi(e) == 1; }();
+    if (side_on && early_env && early_lr_t >= 0.f && early_mask != nullptr) {
+        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));                                    // W4's last reader of this step
+        EL_CHECK_HIP(hipStreamWaitEvent(ss, ctx->side_ev[4], 0));
+        if (int rc = vae_apply_vars(ctx, ss, st, early_lr_t, 0xC0u)) return rc;              // W4, b4 (their gradients: this stream, above)
+        *early_mask = 0xC0u;
+    }
     // (EL_VAE_SIDE_INDEX=1: the index of the sparse dW1 on the side stream as well.  Measured and left off: 0.831-0.837 ms per step, what
     //  ONE stream takes (0.830), against 0.782 with the index on the chain's own stream -- the side stream then has to wait for the chain's
     //  dl W4^T before it may overwrite dl with the row list, and everything queued behind that wait starts late)
@@ -769,7 +785,7 @@ __global__ __launch_bounds__(256) void k_adam_apply_oct(AdamOct t, float alpha, 
     }
 }
 
-static int vae_apply(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t) {
+static int vae_apply_vars(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t, unsigned mask) {
     for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t] && st->m[t] && st->v[t], "el_vae: optimiser buffers missing");
     const int H = st->H, L = st->L;
     const int64_t I = st->I;
@@ -778,20 +794,28 @@ static int vae_apply(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float l
     AdamOct t;
     int64_t big = 0;
     for (int k = 0; k < 8; ++k) {
-        t.th[k] = (float*)st->w[k], t.g[k] = (float*)st->g[k], t.m[k] = (float*)st->m[k], t.v[k] = (float*)st->v[k], t.n[k] = sizes[k];
-        if (sizes[k] > big) big = sizes[k];
+        t.th[k] = (float*)st->w[k], t.g[k] = (float*)st->g[k], t.m[k] = (float*)st->m[k], t.v[k] = (float*)st->v[k];
+        t.n[k] = ((mask >> k) & 1u) ? sizes[k] : 0;
+        if (t.n[k] > big) big = t.n[k];
     }
+    if (big == 0) return 0;
     EL_LAUNCH("k_adam_apply_dense", k_adam_apply_oct, dim3(grid1d(big / 4 + 1, ctx)), dim3(256), 0, s, t, lr_t, 0.9f, 0.999f, 1e-7f);
     EL_CHECK_LAUNCH();
     return 0;
+}
+
+static int vae_apply(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t, unsigned done_mask = 0u) {
+    return vae_apply_vars(ctx, s, st, lr_t, 0xFFu & ~done_mask);
 }
 
 extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr,
                                  const int32_t* indices, const int32_t* rows, int64_t B, const float* eps, float anneal,
                                  float dropout_rate, uint64_t dropout_seed, int32_t step, float lr_t, double* loss_out) {
     if (int rc = el_bind(ctx)) return rc;
-    if (int rc = vae_grads(ctx, (hipStream_t)stream, st, indptr, indices, rows, B, B, eps, anneal, dropout_rate, dropout_seed, step, loss_out)) return rc;
-    return vae_apply(ctx, (hipStream_t)stream, st, lr_t);
+    unsigned early = 0u;
+    if (int rc = vae_grads(ctx, (hipStream_t)stream, st, indptr, indices, rows, B, B, eps, anneal, dropout_rate, dropout_seed, step, loss_out,
+                           lr_t, &early)) return rc;
+    return vae_apply(ctx, (hipStream_t)stream, st, lr_t, early);
 }
 
 extern "C" int el_vae_grads(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
