@@ -62,6 +62,7 @@ struct GemmParams {
     int64_t ldy;
     float* colsum;
     int gx, gy, gz;       // tiles along N, M, K-splits
+    int nlin;             // k_gemm_b3p: linear tile ids 0 .. nlin - 1 (the one-tile kernel's grid size)
     int grp_mode;         // 0: 3-D grid as launched; 1: group = the gy row tiles of one column strip; 2: group = the gx column tiles of one
     //                       row strip; 3: group = every tile of one K split
     int ngroups;
@@ -804,6 +805,144 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
     }
 }
 
+// ---- k_gemm_b3 over several tiles per workgroup (round 5) -----------------------------------------------------------------------
+// The short-K products of the NeuMF tower (K = 128 ... 512: 4 to 16 k tiles per output tile) pay a prologue -- the first operand
+// tiles cross the memory system with nothing to overlap them -- and an epilogue per 128 x 128 tile: 4.2 us of CU time per k tile
+// against 2.9 at 4096^3.  Here a workgroup walks its tiles lin = blockIdx.x, + gridDim.x, ... (the same linear order as the one-tile
+// kernel: XCD-aware groups when grp_mode says so), and the fetch that the last k step of a tile would spend on zeros loads the FIRST
+// k tile of the next output tile instead: the pipeline stays primed across tiles, the epilogue's stores run under loads already in
+// flight.  Same staging, fragments, products and epilogue per tile as k_gemm_b3: bit-identical results.
+struct B3Tile {
+    int64_t m0, n0, kbeg, kend;
+    unsigned bz;
+};
+__device__ __forceinline__ bool b3_decode(const GemmParams& p, unsigned lin, B3Tile& t) {
+    unsigned bx, by, bz;
+    if (p.grp_mode != 0) {
+        const unsigned xcd = lin & 7u, q = lin >> 3;
+        const unsigned grp = p.grp_mode == 1 ? (unsigned)p.gy : (p.grp_mode == 2 ? (unsigned)p.gx : (unsigned)(p.gx * p.gy));
+        const unsigned gi = (q / grp) * 8u + xcd, ti = q % grp;
+        if (gi >= (unsigned)p.ngroups) return false;
+        if (p.grp_mode == 1) by = ti, bx = gi % (unsigned)p.gx, bz = gi / (unsigned)p.gx;
+        else if (p.grp_mode == 2) bx = ti, by = gi % (unsigned)p.gy, bz = gi / (unsigned)p.gy;
+        else bx = ti % (unsigned)p.gx, by = ti / (unsigned)p.gx, bz = gi;
+    } else {
+        bx = lin % (unsigned)p.gx;
+        const unsigned r = lin / (unsigned)p.gx;
+        by = r % (unsigned)p.gy, bz = r / (unsigned)p.gy;
+        if (bz >= (unsigned)p.gz) return false;
+    }
+    t.m0 = (int64_t)by * B3_BM, t.n0 = (int64_t)bx * B3_BN, t.bz = bz;
+    t.kbeg = (int64_t)bz * p.kchunk;
+    t.kend = (t.kbeg + p.kchunk < p.K) ? t.kbeg + p.kchunk : p.K;
+    return true;
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void k_gemm_b3p(GemmParams p) {
+    constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * IMG];   // A image, B image (48 KB)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, g = lane >> 5;
+    const int t = tid & 127;
+    const bool stA = tid < 128;
+    const unsigned nlin = (unsigned)p.nlin, stride = gridDim.x;
+    unsigned lin = blockIdx.x;
+    B3Tile cur, nxt;
+    while (lin < nlin && !b3_decode(p, lin, cur)) lin += stride;
+    if (lin >= nlin) return;
+    float4 rg[8];
+    auto fetch = [&](const B3Tile& T, int64_t k0) {
+        if (stA) b3_load<AKC>(p.A, p.lda, p.M, T.m0, T.kend, k0, t, p.zeros, rg);
+        else b3_load<BKC>(p.B, p.ldb, p.N, T.n0, T.kend, k0, t, p.zeros, rg);
+    };
+    auto stash = [&]() {
+        if (stA) b3_store<AKC>(rg, lds, t);
+        else b3_store<BKC>(rg, lds + IMG, t);
+    };
+    const int fa = (g * 128 + 32 * w + n) * 16, fb = IMG + (g * 128 + n) * 16;
+    fetch(cur, cur.kbeg);
+    for (;;) {
+        unsigned lin2 = lin + stride;
+        bool has_next = false;
+        while (lin2 < nlin && !(has_next = b3_decode(p, lin2, nxt))) lin2 += stride;
+        floatx16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int64_t k0 = cur.kbeg; k0 < cur.kend; k0 += B3_BK) {
+            b3_lds_barrier();                                 // the previous tile's fragments (and the epilogue's sums) are read
+            stash();
+            b3_lds_barrier();
+            if (k0 + B3_BK < cur.kend) fetch(cur, k0 + B3_BK);
+            else if (has_next) fetch(nxt, nxt.kbeg);          // the next output tile's first operands: in flight under the epilogue
+            b3_h8 a[2][3], b[2][4][3];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[s][pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[s][j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][2], b[s][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][2], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][0], acc[j], 0, 0, 0);
+            }
+        }
+        // epilogue of `cur` (as in k_gemm_b3)
+        float* out = p.ws ? p.ws + (int64_t)cur.bz * p.M * p.N : p.C;
+        const int64_t ldo = p.ws ? p.N : p.ldc;
+        const int64_t col = cur.n0 + 4 * n;
+        const int act = p.ws ? EL_ACT_NONE : p.act;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.ws && p.bias && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < p.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = cur.m0 + 4 * (8 * (r >> 2) + 4 * g + (r & 3)) + w;
+                float4 v = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
+                if (act == EL_ACT_RELU) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+                else if (act != EL_ACT_NONE) v = make_float4(el_act(v.x, act), el_act(v.y, act), el_act(v.z, act), el_act(v.w, act));
+                if (row < p.M) {
+                    if (p.rmask) {
+                        const float4 y = *reinterpret_cast<const float4*>(p.rmask + row * p.ldy + col);
+                        v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+                        cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
+                    }
+                    *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+                }
+            }
+        }
+        if (p.rmask) {
+            cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64), cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
+            b3_lds_barrier();                                            // every wave is done with the fragment images
+            float* red = reinterpret_cast<float*>(lds);
+            if (g == 0) *reinterpret_cast<float4*>(red + w * 128 + 4 * n) = cs;
+            b3_lds_barrier();
+            if (tid < 128 && cur.n0 + tid < p.N) {
+                const float t4 = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+                if (t4 != 0.f) atomicAdd(p.colsum + cur.n0 + tid, t4);
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        lin = lin2;
+    }
+}
+
 // one staging role of k_gemm_b3w (below): tile 0 into buffer 0, then per k tile: split + store tile it + 1 into the other buffer, issue
 // the loads of tile it + 2, LDS-only barrier (the loads stay in flight across it)
 template <bool KC>
@@ -1104,10 +1243,28 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
             else if (transA && !transB) EL_B3W(false, false);
             else EL_B3W(false, true);
 #undef EL_B3W
-        } else if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
-        else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
-        else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
-        else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);
+        } else {
+            // EL_GEMM_PERSIST=1: several tiles per workgroup (k_gemm_b3p) where a workgroup slot would see four tiles or more of at most
+            // 32 k tiles each.  Measured and left off: the NeuMF tower's short-K products 4-7 % SLOWER (0.537 -> 0.574, 0.475 -> 0.508,
+            // 0.464 -> 0.482 ms) -- with two workgroups per CU the other workgroup already covers a tile's prologue and epilogue, and the
+            // tile loop costs 50-60 more VGPRs; bit-identical, kept as a switch (tests/test_gpu_dense.py runs both)
+            const char* ep = getenv("EL_GEMM_PERSIST");
+            const bool persist_on = ep && atoi(ep) == 1;
+            const int64_t total = (int64_t)grid.x * grid.y * grid.z, slots = (int64_t)ctx->cus * 2;
+            const int64_t ktiles = (p.kchunk + B3_BK - 1) / B3_BK;
+            if (persist_on && total >= 4 * slots && ktiles <= 32 && total < (1LL << 31)) {
+                p.nlin = (int)total;
+                if (p.grp_mode == 0) p.gx = (int)grid.x, p.gy = (int)grid.y, p.gz = (int)grid.z;
+                const dim3 pg((unsigned)slots, 1, 1);                   // (a multiple of 8: a workgroup's tiles stay on its XCD)
+                if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<true, false>), pg, dim3(256), 0, s, p);
+                else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<true, true>), pg, dim3(256), 0, s, p);
+                else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<false, false>), pg, dim3(256), 0, s, p);
+                else EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<false, true>), pg, dim3(256), 0, s, p);
+            } else if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
+            else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
+            else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
+            else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);
+        }
     } else if (fast) {
         p.ws = (float*)ws;
         p.units = pl.units;

@@ -86,6 +86,31 @@ def test_gemm_with_staging_waves_equals_the_one_role_kernel_bit_for_bit(ctx, tA,
         assert np.abs(got - ref).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02, w
 
 
+@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_with_several_tiles_per_workgroup_equals_the_one_tile_kernel_bit_for_bit(ctx, tA, tB, monkeypatch):
+    """k_gemm_b3p (a workgroup walks several output tiles, the next tile's first operands in flight under the epilogue of the current
+    one) against k_gemm_b3 on products it is chosen for (>= 4 tiles per workgroup slot, short K): identical bits, with edge tiles in
+    both dimensions, a K that is no multiple of the k tile, bias + ReLU in the epilogue, XCD-aware order on and off."""
+    rs = np.random.RandomState(13)
+    d = ctx.device
+    for M, N, K in ((8200, 4100, 260), (33000, 1028, 128)):
+        A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+        Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+        bias = rs.normal(size=N).astype(np.float32)
+        At, Bt, bt = torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), torch.from_numpy(bias).to(d)
+        outs = {}
+        for pz, x in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("EL_GEMM_PERSIST", pz)
+            monkeypatch.setenv("EL_GEMM_XCD", x)
+            outs[(pz, x)] = (ops.gemm(ctx, At, Bt, tA, tB, ws=False).clone(), ops.gemm(ctx, At, Bt, tA, tB, bias=bt, act="relu", ws=False).clone())
+        ref = outs[("0", "0")]
+        for key, val in outs.items():
+            assert torch.equal(val[0].view(torch.int32), ref[0].view(torch.int32)), (M, N, K, key)
+            assert torch.equal(val[1].view(torch.int32), ref[1].view(torch.int32)), (M, N, K, key)
+        r64 = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
+        assert np.abs(cpu(ref[0]) - r64).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02
+
+
 def test_gemm_unaligned_leading_dims(ctx):
     rs = np.random.RandomState(5)
     A = rs.normal(size=(70, 33)).astype(np.float32)       # lda = 33: scalar load path
