@@ -989,11 +989,15 @@ def vae_leg(args, ctx):
         # the per-kernel breakdown: the same kernels back to back on one stream (the step proper runs the weight-gradient products, the
         # column sums and the index of the sparse first-layer gradient on the library's second stream: elapsed times of kernels that
         # overlap mean nothing)
+        prev = os.environ.get("EL_VAE_SIDE")
         os.environ["EL_VAE_SIDE"] = "0"
         try:
             step()
         finally:
-            os.environ.pop("EL_VAE_SIDE", None)
+            if prev is None:
+                os.environ.pop("EL_VAE_SIDE", None)
+            else:
+                os.environ["EL_VAE_SIDE"] = prev
 
     dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False, fn_breakdown=step_one_stream)
     loss = st.pop_loss()
@@ -1051,11 +1055,15 @@ def neumf_leg(args, ctx):
     def step_one_stream():
         # the per-kernel breakdown: the same kernels on one stream (the step proper runs the tower's weight-gradient products on the library's
         # second stream beside the embedding kernels: elapsed times of overlapping kernels mean nothing)
+        prev = os.environ.get("EL_NMF_SIDE")
         os.environ["EL_NMF_SIDE"] = "0"
         try:
             step()
         finally:
-            os.environ.pop("EL_NMF_SIDE", None)
+            if prev is None:
+                os.environ.pop("EL_NMF_SIDE", None)
+            else:
+                os.environ["EL_NMF_SIDE"] = prev
 
     dt, rep = timed(ctx, 1, step, W, K, finish=st.sync, events_in_timed_region=False, fn_breakdown=step_one_stream)
     loss = st.pop_loss()

@@ -465,7 +465,10 @@ typedef struct el_vae_state {
     float* dmv;      /* [Bmax,2L]                               */
     float* dh;       /* [Bmax,H]                                */
     float* rnorm;    /* [Bmax]     1/||x_b||                    */
-    void* ws;        /* split-K workspace (may be NULL)         */
+    void* ws;        /* GEMM workspace (may be NULL): max of el_gemm_ws_bytes over the step's products.  With 2 x that (+ 2 x the
+                      * 16 (I + 1) + 16 bytes of the sparse first-layer gradient's index, each half rounded up to 256) el_vae_grads /
+                      * el_vae_train_step run the weight-gradient products and the bias column sums on the library's second
+                      * stream beside the chain that produces the input gradients (same kernels, same results)            */
     size_t ws_bytes;
     int32_t dae;     /* 1: MultiDAE (autoencoders/dae/multi_dae_model.py:19-139): the encoder head is
                       * z = tanh(h Wm + bm) with w[2] = Wm [H,L], w[3] = bm [L] (mv / dmv unused), no sampling,
@@ -522,7 +525,9 @@ typedef struct el_nmf_state {
     float* dlogit;  /* [Bmax]                                     */
     float* act[4];  /* [Bmax, units[l]]                           */
     float* dact[4];
-    void* ws; size_t ws_bytes;   /* GEMM split-K workspace */
+    void* ws; size_t ws_bytes;   /* GEMM workspace: max of el_gemm_ws_bytes over the tower's products; with 2 x that, el_nmf_grads /
+                                  * el_nmf_train_step run the tower's weight-gradient products on the library's second stream
+                                  * beside the embedding kernels (same kernels, same results)                              */
     /* keras Dropout(dropout) in front of every Dense of the MLP tower (neural_matrix_factorization_model.py:58-61),
      * active in train_step only: x <- x * keep / (1 - dropout), keep ~ Bernoulli(1 - dropout) from Philox4x32-10 with
      * counter (sample row, column / 4, drop_step, layer) and key drop_seed; the caller advances drop_step per step.
