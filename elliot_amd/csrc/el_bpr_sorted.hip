@@ -931,10 +931,19 @@ __global__ __launch_bounds__(256) void k_bpr_item_split(el_bprmf_state st, ItemF
 // Positions per lane group.  Popular items (Zipf) own segments of tens of thousands of occurrences; every chunk that
 // does not contain a whole segment ends with an atomic flush onto the same few cache lines, so long chunks matter for
 // the item side (16 -> 128 positions: 0.84 -> 0.35 ms at B = 1M) as long as enough groups remain to fill the chip.
-static int item_chunk_for(int64_t B) {
+static int item_chunk_for(int64_t B, int64_t I) {
     if (const char* e = getenv("EL_ICHUNK")) return atoi(e) < 16 ? 16 : atoi(e);     // (>= 16: the split list is sized for it)
     int64_t c = (2 * B) / 8192;                          // (round 3, with the fused user side: 256 at B = 2^20 -- 1.275 -> 1.25 ms per step;
-    return (int)(c < 16 ? 16 : (c > 256 ? 256 : c));     //  128: 0.259, 256: 0.247, 384: 0.256, 512: 0.277 ms for the item segments)
+    c = c < 16 ? 16 : (c > 256 ? 256 : c);               //  128: 0.259, 256: 0.247, 384: 0.256, 512: 0.277 ms for the item segments at 100 K items)
+    // Round 5: that optimum belongs to LONG segments (100 K items under 2^21 positions: 20 per item).  With a catalogue the batch
+    // barely covers -- 1 M items: 2.7 positions per distinct item, 5 M: 1.2 -- nearly every position starts a segment with three row
+    // fetches of its own, and what counts is lane groups in flight, not rows reused inside a group: a quarter of the chunk.  Measured
+    // at 10 M x 1 M x 128 (one box, ms per step / item segments): 16: 2.98 / 0.95, 32: 2.67 / 0.73, 48: 2.63 / 0.68, 64: 2.62-2.66 / 0.69,
+    // 96: 2.63 / 0.70, 128: 2.65 / 0.71, 192: 2.80 / 0.81, 256: 2.75 / 0.73, 384: 2.90 / 0.88; at 6.25 M x 5 M x 256: 16: 5.67, 32: 5.80,
+    // 64: 5.84, 256: 5.93.
+    const double cover = I > 0 ? (double)I * (1.0 - exp(-2.0 * (double)B / (double)I)) : 1.0;     // expected distinct items of 2 B draws
+    if (cover > 0.0 && 2.0 * (double)B / cover < 8.0) c = c / 4 < 16 ? 16 : c / 4;
+    return (int)c;
 }
 static int user_chunk_for(int64_t B) {
     if (const char* e = getenv("EL_UCHUNK")) return atoi(e);
@@ -1236,7 +1245,7 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     pi.vals = w.valI;
     pi.key_off = (u32)base.st.U;
     pi.n = 2 * B;
-    pi.chunk = item_chunk_for(B);
+    pi.chunk = item_chunk_for(B, base.st.I);
     pi.lpt = lpt;
     if (defer) pi.ubase = base.st.Gu_old, pi.uidx = w.hpos;      // the pre-update user rows, one per distinct user of the batch
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
@@ -1635,7 +1644,7 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     pi.keys = w.keyI;
     pi.vals = w.valI;
     pi.n = 2 * B;
-    pi.chunk = item_chunk_for(B);
+    pi.chunk = item_chunk_for(B, st.I);
     pi.lpt = lpt;
     const int64_t gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridI = (unsigned)((gi * lpt + 255) / 256);
