@@ -587,6 +587,78 @@ __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* _
     }
 }
 
+// Flush walk shared by k_bpr_flush_users / k_bpr_flush_items (round 5).  The round-4 kernels gave a wave one row at a time: its stamp
+// (a 4-byte load), then -- dependent on it -- the three rows, the replay, three stores: two memory round trips per 1.5 KB with one row
+// in flight per wave (k_bpr_flush_items: 3.2 TB/s with three waves in four leaving right after the stamp).  Here a wave owns 64
+// consecutive rows: their stamps in ONE coalesced load (lane = row), the pending rows by ballot, then the pending rows two at a time --
+// both rows' theta / m / v in flight together -- each replayed for its own gap exactly as bpr_replay_row does (same element order, same
+// arithmetic: the bit-for-bit tests of the deferred decay cover it).  Rows wider than one pass of the wave (F > 64 VW) keep the old walk.
+template <int VW>
+__device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float* __restrict__ tm, float* __restrict__ tv, int32_t* __restrict__ last_arr,
+                                                 int F, int64_t n_rows, int64_t row0, int lane, int32_t t, const float* __restrict__ hist, int hist_mask) {
+    const int64_t myrow = row0 + lane;
+    const int mylast = myrow < n_rows ? last_arr[myrow] : t;
+    unsigned long long pend = __ballot(t - mylast > 0);
+    if (pend == 0ull) return;
+    if (F > 64 * VW) {                                          // several passes per row: one row at a time
+        while (pend) {
+            const int l = __builtin_ctzll(pend);
+            pend &= pend - 1;
+            const int last = __shfl(mylast, l, 64);
+            bpr_replay_row<VW>(tth, tm, tv, F, row0 + l, lane, last, t - last, hist, hist_mask);
+        }
+        if (t - mylast > 0) last_arr[myrow] = t;
+        return;
+    }
+    const int e = lane * VW;
+    const bool live = e < F;
+    while (pend) {
+        const int l0 = __builtin_ctzll(pend);
+        pend &= pend - 1;
+        const bool two = pend != 0ull;
+        const int l1 = two ? __builtin_ctzll(pend) : l0;
+        if (two) pend &= pend - 1;
+        const int64_t r0 = row0 + l0, r1 = row0 + l1;
+        float th0[VW], mm0[VW], vv0[VW], th1[VW], mm1[VW], vv1[VW];
+#pragma unroll
+        for (int x = 0; x < VW; ++x) th0[x] = mm0[x] = vv0[x] = th1[x] = mm1[x] = vv1[x] = 0.f;
+        if (live) {
+            ldv<VW>(tth + r0 * F + e, th0);
+            ldv<VW>(tm + r0 * F + e, mm0);
+            ldv<VW>(tv + r0 * F + e, vv0);
+            if (two) {
+                ldv<VW>(tth + r1 * F + e, th1);
+                ldv<VW>(tm + r1 * F + e, mm1);
+                ldv<VW>(tv + r1 * F + e, vv1);
+            }
+        }
+        const int last0 = __shfl(mylast, l0, 64), last1 = __shfl(mylast, l1, 64);
+        bool nz0 = false, nz1 = false;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+            nz0 = nz0 || mm0[x] != 0.f || vv0[x] != 0.f;
+            nz1 = nz1 || mm1[x] != 0.f || vv1[x] != 0.f;
+        }
+        if (__ballot(nz0) != 0ull) {                           // (m = v = 0: the fixed point of the step, nothing to replay or write)
+            el_adam_replay<VW>(th0, mm0, vv0, t - last0, [&](int s2) { return hist[(last0 + 1 + s2) & hist_mask]; });
+            if (live) {
+                stv<VW>(tth + r0 * F + e, th0);
+                stv<VW>(tm + r0 * F + e, mm0);
+                stv<VW>(tv + r0 * F + e, vv0);
+            }
+        }
+        if (two && __ballot(nz1) != 0ull) {
+            el_adam_replay<VW>(th1, mm1, vv1, t - last1, [&](int s2) { return hist[(last1 + 1 + s2) & hist_mask]; });
+            if (live) {
+                stv<VW>(tth + r1 * F + e, th1);
+                stv<VW>(tm + r1 * F + e, mm1);
+                stv<VW>(tv + r1 * F + e, vv1);
+            }
+        }
+    }
+    if (t - mylast > 0) last_arr[myrow] = t;
+}
+
 template <int VW>
 __global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u32* __restrict__ keys, int64_t B, int32_t t,
                                                      float* __restrict__ hist, int hist_mask, float lr_t) {
@@ -608,13 +680,8 @@ __global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u3
 template <int VW>
 __global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < st.U; row += (int64_t)gridDim.x * 4) {
-        const int last = st.Gu_last[row];
-        const int ns = t - last;
-        if (ns <= 0) continue;
-        bpr_replay_row<VW>(st.Gu, st.mGu, st.vGu, st.F, row, lane, last, ns, hist, hist_mask);
-        if (lane == 0) st.Gu_last[row] = t;
-    }
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < st.U; row0 += (int64_t)gridDim.x * 256)
+        bpr_flush_rows64<VW>(st.Gu, st.mGu, st.vGu, st.Gu_last, st.F, st.U, row0, lane, t, hist, hist_mask);
 }
 
 // ---- fused item side (el_bprmf_state.Gi_last): replay kernels of the item table --------------------------------------------------
@@ -673,13 +740,8 @@ __global__ __launch_bounds__(256) void k_bpr_flush_ibias(el_bprmf_state st, int3
 template <int VW>
 __global__ __launch_bounds__(256) void k_bpr_flush_items(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < st.I; row += (int64_t)gridDim.x * 4) {
-        const int last = st.Gi_last[row];
-        const int ns = t - last;
-        if (ns <= 0) continue;
-        bpr_replay_row<VW>(st.Gi, st.mGi, st.vGi, st.F, row, lane, last, ns, hist, hist_mask);
-        if (lane == 0) st.Gi_last[row] = t;
-    }
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < st.I; row0 += (int64_t)gridDim.x * 256)
+        bpr_flush_rows64<VW>(st.Gi, st.mGi, st.vGi, st.Gi_last, st.F, st.I, row0, lane, t, hist, hist_mask);
 }
 
 // ---- item segments -----------------------------------------------------------------------
@@ -1034,7 +1096,7 @@ int el_bprmf_apply_items_adam(el_ctx* ctx, hipStream_t s, const el_bprmf_state& 
 // user side of the step as ONE kernel (el_bprmf_state.Gu_next): rowptr, then segments + Adam over every user row
 static int launch_flush_users(const el_bprmf_state& st, hipStream_t s, int32_t t) {
     EL_REQUIRE(st.F % 4 == 0 && st.F <= 512, "el_bprmf_sync_users: F=%d outside the deferred decay's range", st.F);
-    int64_t grid = (st.U + 3) / 4;
+    int64_t grid = (st.U + 255) / 256;                       // a wave owns 64 consecutive rows
     if (grid > (1 << 18)) grid = 1 << 18;
     const int mask = st.lr_hist_cap - 1;
     if (st.F >= 256) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<4>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
@@ -1158,7 +1220,7 @@ static int check_item_fuse(const el_bprmf_state& st) {
 static int launch_flush_items(const el_bprmf_state& st, hipStream_t s, int32_t t) {
     const int mask = st.lr_hist_cap - 1;
     EL_LAUNCH("k_bpr_flush_ibias", k_bpr_flush_ibias, dim3((unsigned)((st.I + 255) / 256)), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    int64_t grid = (st.I + 3) / 4;
+    int64_t grid = (st.I + 255) / 256;                       // a wave owns 64 consecutive rows
     if (grid > (1 << 18)) grid = 1 << 18;
     if (st.F >= 256) EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<4>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
     else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<2>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
