@@ -1260,10 +1260,7 @@ def _roof(r, extra=()):
     if not r:
         return None
     keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic") + tuple(extra)
-    out = {k: r.get(k) for k in keys if k in r or k in ("traffic",)}
-    if out.get("traffic") is not None:
-        out["traffic_source"] = "builder's rocprofv3 PMC pass (profiles/traffic.json), not this run"
-    return out
+    return {k: r.get(k) for k in keys if k in r or k in ("traffic",)}
 
 
 def _topk_summary(t):
@@ -1354,6 +1351,15 @@ def compact_line(full):
                                 "topk": {k: (cb.get("topk") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
                                 **({"reference": cb["reference"]} if "reference" in cb else {})}
     line["legs_file"] = full.get("legs_file")
+    # every non-null `traffic` in the line comes from the same place: said once
+    def _any_traffic(o):
+        if isinstance(o, dict):
+            return any((k == "traffic" and v is not None) or _any_traffic(v) for k, v in o.items())
+        if isinstance(o, list):
+            return any(_any_traffic(v) for v in o)
+        return False
+    if _any_traffic(line):
+        line["traffic_source"] = "builder's rocprofv3 PMC passes (profiles/traffic.json, same kernel sources), not this run"
     return _r(line)
 
 

@@ -36,7 +36,7 @@ def test_compact_line_of_the_fattest_report_is_small_strict_and_complete():
         assert key in d, key
     assert "10M users x 1M items" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
-    assert set(("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["traffic"] == 5.14e9 and "builder" in r["traffic_source"]
+    assert set(("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["traffic"] == 5.14e9 and "builder" in d["traffic_source"]
     assert d["topk"]["roofline"]["traffic"] is None            # NaN -> null
     assert not any(k.endswith("GBs") and isinstance(v, float) and v > r["peak"] for k, v in r.items())
     cb = d["cpu_baseline"]
