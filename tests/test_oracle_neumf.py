@@ -117,3 +117,42 @@ def test_c_oracle_logits_equal_the_network_in_fp64():
         w2["hw"] = w["hw"][F:].copy()
         p2 = on.forward(w2, u, i, dtype=np.float64)["p"].reshape(U, I)
         assert np.abs(cref.nmf_logits(w2, np.arange(U)) - (np.log(p2) - np.log1p(-p2))).max() < 5e-6
+
+
+def test_gradients_under_a_given_relu_branch_pattern():
+    """gradients(relu_masks=...) (the hook tests/test_gpu_neumf.py uses to compare under the DEVICE's audited branch pattern): the
+    network's own pattern reproduces the default gradients bit for bit; flipping ONE unit of the top layer to 'on' changes the kernel
+    gradient of that layer in that unit's column only -- by exactly that sample's input row times its upstream derivative -- and moves
+    every layer below it by one sample's contribution."""
+    U, I, F, n = 30, 40, 8, 64
+    w = on.init_neumf(U, I, F, 5)
+    rs = np.random.RandomState(2)
+    w = {k: ([x.astype(np.float64) * 3 for x in v] if isinstance(v, list) else v.astype(np.float64) * 3) for k, v in w.items()}
+    w["b"] = [rs.normal(scale=0.1, size=b.shape) for b in w["b"]]
+    u, i = rs.randint(0, U, n), rs.randint(0, I, n)
+    y = rs.randint(0, 2, n).astype(np.float64)
+    c = on.forward(w, u, i, dtype=np.float64)
+    g0 = on.gradients(w, c, u, i, y)
+    own = [o > 0 for o in c["outs"]]
+    g1 = on.gradients(w, c, u, i, y, relu_masks=own)
+    for k in ("Umf", "Imf", "Umlp", "Imlp", "hw", "hb"):
+        assert np.array_equal(g0[k], g1[k]), k
+    for l in range(3):
+        assert np.array_equal(g0["W"][l], g1["W"][l]) and np.array_equal(g0["b"][l], g1["b"][l]), l
+    # one 'off' unit of the top layer taken as 'on'
+    top = len(own) - 1
+    rows, cols = np.nonzero(~own[top])
+    r, col = int(rows[0]), int(cols[0])
+    flipped = [m.copy() for m in own]
+    flipped[top][r, col] = True
+    g2 = on.gradients(w, c, u, i, y, relu_masks=flipped)
+    dW = g2["W"][top] - g0["W"][top]
+    other = np.delete(dW, col, axis=1)
+    assert np.abs(other).max() == 0.0                                       # only that unit's column moves in its own layer
+    p = c["p"][r]
+    dlogit = -(y[r] / (p + 1e-7) - (1 - y[r]) / (1 - p + 1e-7)) * p * (1 - p) / n if (1e-7 < p < 1 - 1e-7) else 0.0
+    d_unit = dlogit * w["hw"][F + col]                                      # upstream derivative of that unit for that sample
+    assert np.allclose(dW[:, col], c["ins"][top][r] * d_unit, rtol=1e-12, atol=1e-18)
+    assert np.isclose(g2["b"][top][col] - g0["b"][top][col], d_unit, rtol=1e-12, atol=1e-18)
+    if d_unit != 0.0:
+        assert np.abs(g2["W"][0] - g0["W"][0]).max() > 0.0                   # ... and every layer below sees one sample's contribution
