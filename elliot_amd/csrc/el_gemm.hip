@@ -1191,7 +1191,8 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
     // (products under 2 GFLOP -- the 512 x 400 x 600 class -- are latency-bound: the one-launch small-tile path below stays faster)
     const bool outvec = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
     // EL_GEMM_B3W=1: the kernel with staging waves of its own, one workgroup per CU (measured: 3-4 % ahead on the long-K weight-gradient
-    // products, 5-20 % behind on the short-K ones -- both forms run at the rate their tiles are fed from beyond L2; off by default)
+    // products, 5-20 % behind on the short-K ones; off by default.  Neither form is bound by the memory system: L2 hit rate 62-80 %,
+    // <= 2 TB/s from the fabric, profiles/r05_pmc_gemm_feed.md)
     const char* ew = getenv("EL_GEMM_B3W");
     const bool b3w = ew && atoi(ew) == 1;
     if (split_on && fast0 && outvec && 2.0 * (double)M * (double)N * (double)K >= 2.0e9) {
