@@ -590,10 +590,10 @@ __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* _
 // Flush walk shared by k_bpr_flush_users / k_bpr_flush_items (round 5).  The round-4 kernels gave a wave one row at a time: its stamp
 // (a 4-byte load), then -- dependent on it -- the three rows, the replay, three stores: two memory round trips per 1.5 KB with one row
 // in flight per wave (k_bpr_flush_items: 3.2 TB/s with three waves in four leaving right after the stamp).  Here a wave owns 64
-// consecutive rows: their stamps in ONE coalesced load (lane = row), the pending rows by ballot, then the pending rows two at a time --
-// both rows' theta / m / v in flight together -- each replayed for its own gap exactly as bpr_replay_row does (same element order, same
+// consecutive rows: their stamps in ONE coalesced load (lane = row), the pending rows by ballot, then the pending rows NR at a time --
+// their theta / m / v in flight together -- each replayed for its own gap exactly as bpr_replay_row does (same element order, same
 // arithmetic: the bit-for-bit tests of the deferred decay cover it).  Rows wider than one pass of the wave (F > 64 VW) keep the old walk.
-template <int VW>
+template <int VW, int NR>
 __device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float* __restrict__ tm, float* __restrict__ tv, int32_t* __restrict__ last_arr,
                                                  int F, int64_t n_rows, int64_t row0, int lane, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int64_t myrow = row0 + lane;
@@ -613,46 +613,41 @@ __device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float*
     const int e = lane * VW;
     const bool live = e < F;
     while (pend) {
-        const int l0 = __builtin_ctzll(pend);
-        pend &= pend - 1;
-        const bool two = pend != 0ull;
-        const int l1 = two ? __builtin_ctzll(pend) : l0;
-        if (two) pend &= pend - 1;
-        const int64_t r0 = row0 + l0, r1 = row0 + l1;
-        float th0[VW], mm0[VW], vv0[VW], th1[VW], mm1[VW], vv1[VW];
+        int ls[NR];
+        bool on[NR];
 #pragma unroll
-        for (int x = 0; x < VW; ++x) th0[x] = mm0[x] = vv0[x] = th1[x] = mm1[x] = vv1[x] = 0.f;
-        if (live) {
-            ldv<VW>(tth + r0 * F + e, th0);
-            ldv<VW>(tm + r0 * F + e, mm0);
-            ldv<VW>(tv + r0 * F + e, vv0);
-            if (two) {
-                ldv<VW>(tth + r1 * F + e, th1);
-                ldv<VW>(tm + r1 * F + e, mm1);
-                ldv<VW>(tv + r1 * F + e, vv1);
+        for (int r = 0; r < NR; ++r) {
+            on[r] = pend != 0ull;
+            ls[r] = on[r] ? __builtin_ctzll(pend) : ls[r > 0 ? r - 1 : 0];
+            if (r == 0 && !on[r]) ls[r] = 0;
+            if (on[r]) pend &= pend - 1;
+        }
+        float th[NR][VW], mm[NR][VW], vv[NR][VW];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+            for (int x = 0; x < VW; ++x) th[r][x] = mm[r][x] = vv[r][x] = 0.f;
+            if (live && on[r]) {
+                const int64_t row = row0 + ls[r];
+                ldv<VW>(tth + row * F + e, th[r]);
+                ldv<VW>(tm + row * F + e, mm[r]);
+                ldv<VW>(tv + row * F + e, vv[r]);
             }
         }
-        const int last0 = __shfl(mylast, l0, 64), last1 = __shfl(mylast, l1, 64);
-        bool nz0 = false, nz1 = false;
 #pragma unroll
-        for (int x = 0; x < VW; ++x) {
-            nz0 = nz0 || mm0[x] != 0.f || vv0[x] != 0.f;
-            nz1 = nz1 || mm1[x] != 0.f || vv1[x] != 0.f;
-        }
-        if (__ballot(nz0) != 0ull) {                           // (m = v = 0: the fixed point of the step, nothing to replay or write)
-            el_adam_replay<VW>(th0, mm0, vv0, t - last0, [&](int s2) { return hist[(last0 + 1 + s2) & hist_mask]; });
+        for (int r = 0; r < NR; ++r) {
+            if (!on[r]) continue;                              // (wave-uniform)
+            const int lastr = __shfl(mylast, ls[r], 64);
+            bool nz = false;
+#pragma unroll
+            for (int x = 0; x < VW; ++x) nz = nz || mm[r][x] != 0.f || vv[r][x] != 0.f;
+            if (__ballot(nz) == 0ull) continue;                // (m = v = 0: the fixed point of the step, nothing to replay or write)
+            el_adam_replay<VW>(th[r], mm[r], vv[r], t - lastr, [&](int s2) { return hist[(lastr + 1 + s2) & hist_mask]; });
             if (live) {
-                stv<VW>(tth + r0 * F + e, th0);
-                stv<VW>(tm + r0 * F + e, mm0);
-                stv<VW>(tv + r0 * F + e, vv0);
-            }
-        }
-        if (two && __ballot(nz1) != 0ull) {
-            el_adam_replay<VW>(th1, mm1, vv1, t - last1, [&](int s2) { return hist[(last1 + 1 + s2) & hist_mask]; });
-            if (live) {
-                stv<VW>(tth + r1 * F + e, th1);
-                stv<VW>(tm + r1 * F + e, mm1);
-                stv<VW>(tv + r1 * F + e, vv1);
+                const int64_t row = row0 + ls[r];
+                stv<VW>(tth + row * F + e, th[r]);
+                stv<VW>(tm + row * F + e, mm[r]);
+                stv<VW>(tv + row * F + e, vv[r]);
             }
         }
     }
@@ -677,11 +672,11 @@ __global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u3
 }
 
 // deferred decay: every user row up to step t (one WAVE per row, grid-stride; same row walk as k_bpr_catchup)
-template <int VW>
+template <int VW, int NR>
 __global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < st.U; row0 += (int64_t)gridDim.x * 256)
-        bpr_flush_rows64<VW>(st.Gu, st.mGu, st.vGu, st.Gu_last, st.F, st.U, row0, lane, t, hist, hist_mask);
+        bpr_flush_rows64<VW, NR>(st.Gu, st.mGu, st.vGu, st.Gu_last, st.F, st.U, row0, lane, t, hist, hist_mask);
 }
 
 // ---- fused item side (el_bprmf_state.Gi_last): replay kernels of the item table --------------------------------------------------
@@ -737,11 +732,11 @@ __global__ __launch_bounds__(256) void k_bpr_flush_ibias(el_bprmf_state st, int3
     if (ns > 0) bpr_replay_bias(st, row, last, ns, hist, hist_mask);
 }
 
-template <int VW>
+template <int VW, int NR>
 __global__ __launch_bounds__(256) void k_bpr_flush_items(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < st.I; row0 += (int64_t)gridDim.x * 256)
-        bpr_flush_rows64<VW>(st.Gi, st.mGi, st.vGi, st.Gi_last, st.F, st.I, row0, lane, t, hist, hist_mask);
+        bpr_flush_rows64<VW, NR>(st.Gi, st.mGi, st.vGi, st.Gi_last, st.F, st.I, row0, lane, t, hist, hist_mask);
 }
 
 // ---- item segments -----------------------------------------------------------------------
@@ -1099,9 +1094,11 @@ static int launch_flush_users(const el_bprmf_state& st, hipStream_t s, int32_t t
     int64_t grid = (st.U + 255) / 256;                       // a wave owns 64 consecutive rows
     if (grid > (1 << 18)) grid = 1 << 18;
     const int mask = st.lr_hist_cap - 1;
-    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<4>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<2>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else EL_LAUNCH("k_bpr_flush_users", k_bpr_flush_users<1>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    static const int nr = [] { const char* e = getenv("EL_BPR_FLUSH_ROWS"); const int v = e ? atoi(e) : 0; return v == 4 ? 4 : 2; }();   // rows in flight per wave
+    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<4, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else if (st.F >= 128 && nr == 4) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<2, 4>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -1222,9 +1219,11 @@ static int launch_flush_items(const el_bprmf_state& st, hipStream_t s, int32_t t
     EL_LAUNCH("k_bpr_flush_ibias", k_bpr_flush_ibias, dim3((unsigned)((st.I + 255) / 256)), dim3(256), 0, s, st, t, st.lr_hist, mask);
     int64_t grid = (st.I + 255) / 256;                       // a wave owns 64 consecutive rows
     if (grid > (1 << 18)) grid = 1 << 18;
-    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<4>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<2>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else EL_LAUNCH("k_bpr_flush_items", k_bpr_flush_items<1>, dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    static const int nr = [] { const char* e = getenv("EL_BPR_FLUSH_ROWS"); const int v = e ? atoi(e) : 0; return v == 4 ? 4 : 2; }();   // rows in flight per wave
+    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<4, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else if (st.F >= 128 && nr == 4) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<2, 4>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    else EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -1317,7 +1316,7 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     memset(&fz, 0, sizeof(fz));
     // EL_BPR_USER_PRE: positions in flight per lane group with the heads' m / v prefetched (0 = the round-4 form: m, v fetched when the
     // walk reaches the head)
-    static const int upre = [] { const char* e = getenv("EL_BPR_USER_PRE"); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 4 || v == 8) ? v : -1; }();
+    static const int upre = [] { const char* e = getenv("EL_BPR_USER_PRE"); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 3 || v == 4 || v == 8) ? v : -1; }();
     // (EL_BPR_USER_WAVE_ROWS=1: measured 1.35 against 1.24 ms for the two-groups-per-wave form at 10M x 1M x 128 -- the replay's lane
     //  utilisation was not the bound, the loads in flight per wave are; kept as an experiment switch, off)
     static const bool vw2 = [] { const char* e = getenv("EL_BPR_USER_WAVE_ROWS"); return e && atoi(e) == 1; }();
@@ -1343,7 +1342,8 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
                 else if (upre == 4) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4, 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
                 else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
             } else if (VW == 4 && CPL_ <= 2 && upre != 0) {                                               \
-                if (upre != 4 || CPL_ == 2) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 2>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+                if (upre == 3 && CPL_ == 1) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 3>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+                else if (upre != 4 || CPL_ == 2) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 2>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
                 else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, (CPL_ == 1 ? 4 : 2)>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
             } else {                                                                                      \
                 EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
