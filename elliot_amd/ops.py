@@ -573,8 +573,17 @@ class BprmfDeviceState:
         self.item_grad_flat = torch.zeros(rows_end + self.I, dtype=torch.float32, device=dev)
         self.gGi = self.item_grad_flat[:self.I * self.F].view(self.I, self.F)
         self.gBi = self.item_grad_flat[rows_end:]
-        self.mGi = z(self._Gi) if adam else None
-        self.vGi = z(self._Gi) if adam else None
+        self._item_block = None
+        item_gap = os.environ.get("EL_ITEM_LAYOUT_GAP_MIB")
+        if adam and item_gap is not None and self.I * self.F * 4 >= (64 << 20):
+            # experiment (round 5): theta, m, v of the item table carved from ONE allocation a fixed distance apart, instead of three
+            # allocations wherever the allocator puts them -- k_bpr_item_seg is bimodal from process to process
+            (gi2, self.mGi, self.vGi), self._item_block = _strided_tables(self.I, self.F, 3, int(float(item_gap) * (1 << 20)), dev)
+            gi2.copy_(self._Gi)
+            self._Gi = gi2
+        else:
+            self.mGi = z(self._Gi) if adam else None
+            self.vGi = z(self._Gi) if adam else None
         self.mBi = z(self._Bi) if adam else None
         self.vBi = z(self._Bi) if adam else None
         rows = self.opt in (EL_OPT_ADAM_LAZY, EL_OPT_SGD) and optimizer != "sgd_dense"
