@@ -174,56 +174,7 @@ def dist_setup(args):
     return world, rank, local, backend
 
 
-class PrefetchSampler:
-    """BPR triplets of step t+1 are drawn on a side stream while step t trains: the sampler (custom_sampler.py:31-46) does not
-    depend on the model, so a training loop can always run it one batch ahead.  Two triplet buffers, events both ways."""
-
-    def __init__(self, ctx, pos, B, seed, enabled=True, presort_state=None):
-        from elliot_amd import ops
-        dev = ctx.device
-        self.ops, self.ctx, self.pos, self.B, self.seed, self.enabled = ops, ctx, pos, B, seed, enabled
-        # presort_state: a BprmfDeviceState -- the batch is also ORDERED (prep + radix sort, which read only the triplets) ahead
-        # of its step, into one workspace per buffer
-        self.state = presort_state if enabled else None
-        self.ws = [presort_state.sort_workspace(B) for _ in range(2)] if self.state is not None else [None, None]
-        self.bufs = [tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3)) for _ in range(2)]
-        self.side = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.free = [None, None]
-        self.cur, self.ctr = 0, 0
-        if enabled:
-            self._issue(0)
-
-    def _draw(self, b):
-        self.ops.bpr_sample(self.ctx, self.pos, self.B, seed=self.seed, first_sample=self.ctr, out=self.bufs[b])
-        self.ctr += self.B
-        if self.state is not None:
-            self.state.presort(*self.bufs[b], self.ws[b])
-
-    def _issue(self, b):
-        self.side.wait_stream(torch.cuda.current_stream())           # (first use / anything the caller queued before)
-        with torch.cuda.stream(self.side):
-            if self.free[b] is not None:
-                self.side.wait_event(self.free[b])                    # the training step that read this buffer is done
-            self._draw(b)
-            self.ready[b].record(self.side)
-
-    def next(self):
-        """Triplets of this step (valid on the current stream)."""
-        b = self.cur
-        if not self.enabled:
-            self._draw(b)
-            return self.bufs[b], b
-        torch.cuda.current_stream().wait_event(self.ready[b])
-        self.cur ^= 1
-        self._issue(self.cur)                                         # next batch: overlaps this step's kernels
-        return self.bufs[b], b
-
-    def release(self, b):
-        if self.enabled:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.free[b] = ev
+from elliot_amd.pipeline import PrefetchSampler, cover_batches, cover_triplets  # noqa: E402,F401  (the step pipeline the tests drive too)
 
 
 def barrier(world):
@@ -459,27 +410,6 @@ def cpu_baseline(args, host):
                   "sample": f"oracle/c/el_oracle.c orc_score_topk_f32 (fmaf chain, the bit-exact checker), {nu} users x {args.items} items; {dt:.2f}s"}
     out["port_1core"] = p1
     return out
-
-
-def cover_batches(st, indptr, indices, cover_users, cover_items, U, I, B, lr, l_w, l_b, algo="auto"):
-    """Untimed train steps that give the first `cover_users` user rows and the first `cover_items` item rows a gradient once (users in
-    order with one of their positives each, negatives in item order): afterwards no row of the covered tables sits at the m = v = 0
-    fixed point of the gradient-free Adam step, which the replay kernels of the deferred decay skip."""
-    dev = indptr.device
-    n_cover = -(-max(cover_users, cover_items) // B)
-    ar = torch.arange(B, dtype=torch.int64, device=dev)
-    deg = indptr[1:] - indptr[:-1]
-    g = torch.Generator(device=dev)
-    g.manual_seed(777)
-    for c in range(n_cover):
-        uu = (ar + c * B) % U
-        off = (torch.rand(B, device=dev, generator=g) * deg[uu].to(torch.float32)).to(torch.int64)
-        off = torch.minimum(off, deg[uu] - 1).clamp_(min=0)
-        ii = indices[(indptr[uu] + off).clamp_(max=indices.numel() - 1)]
-        jj = ((ar + c * B) % I).to(torch.int32)
-        st.train_step(uu.to(torch.int32), ii.to(torch.int32), jj, lr, l_w, l_b, algo=algo)
-    st.sync()
-    st.pop_loss()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -382,6 +382,14 @@ class MtReplaySampler:
 # ------------------------------------------------------------------------------------------
 # BPRMF_batch (TF semantics)
 # ------------------------------------------------------------------------------------------
+def deterministic_item_sums(ctx):
+    """True when the item segments a chunk boundary cuts are summed in a fixed order (no floating-point atomics anywhere in the
+    sorted BPR step): two runs on the same batches then give the same bits, and the fused / deferred forms equal the every-row
+    two-pass form bit for bit at any size."""
+    fn = getattr(ctx.lib, "el_bprmf_deterministic", None)
+    return bool(fn()) if fn is not None else False
+
+
 def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
     """Keras Adam bias-corrected step size, computed in fp32 like TF does."""
     b1p = np.power(np.float32(beta1), np.float32(step))

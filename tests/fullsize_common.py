@@ -1,0 +1,212 @@
+"""Harness of the full-size training parity tests (tests/test_gpu_fullsize_c4.py, _c5.py): the path bench.py's BPR legs run, checked.
+
+`bench_path_vs_two_pass` builds TWO states from the same tables:
+  A  the state bench.py builds (`BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")`: compact user gradients, fused user side
+     with the deferred decay, fused item side, deferred item rows where 2 B <= I) and drives it the way bench.py's timed region does:
+     cover batches through train_step, then `steps` calls of train_step_presorted fed by elliot_amd.pipeline.PrefetchSampler (the batch of
+     step t+1 drawn and sorted on a side stream), on a high-priority stream, no host synchronisation in between, sync() at the end;
+  R  the every-row two-pass form (deferred=False, fused_user_step=False, fused_item_step=False) stepped with grads() + apply() on the
+     SAME triplets afterwards.  Its tables are current after every step, so they feed (a) an independent fp64 evaluation of each batch
+     loss (BPRMF_batch_model.py:65-75) and (b) oracle/bprmf_batch.py's gradients of the triplets that touch a set of sampled rows, with
+     oracle.bprmf_batch.adam_tf_sparse_apply run EVERY step on EVERY sampled row (Keras' every-row semantics, no shortcut).
+Checks (the caller asserts on the returned record too):
+  (i)   every step's loss of A within 1e-4 (north_star's tolerance) of the fp64 evaluation;
+  (ii)  theta of the sampled rows of A (and R) against the oracle recurrence: <= 2e-4 of the entries beyond 2e-5, none beyond 3 lr;
+        R's pre-optimiser gradient rows against the oracle's on the first steps;
+  (iii) A == R on theta, m, v of the sampled rows -- bit for bit when the library sums cut item segments in a fixed order
+        (ops.deterministic_item_sums(ctx)), to fp32 re-association accuracy otherwise -- and over the WHOLE tables to that accuracy.
+"""
+import numpy as np
+import torch
+
+from elliot_amd import ops
+from elliot_amd.pipeline import PrefetchSampler, cover_triplets
+from tests.gpu_util import cpu
+
+
+def oracle_rows(Gu0, Gi0, Bi0, u, i, j, su, si, l_w, l_b):
+    """oracle/bprmf_batch.py gradients (fp32 and fp64) of the sampled user rows `su` / item rows `si` (device int64 tensors): every
+    triplet of the batch that touches a sampled row is pulled out and re-indexed into small tables holding just the rows those
+    triplets reference -- for the sampled rows the sub-batch gradient IS the full-batch gradient."""
+    from oracle import bprmf_batch as ob
+    dev = u.device
+    U, I = Gu0.shape[0], Gi0.shape[0]
+    mu = torch.zeros(U, dtype=torch.bool, device=dev)
+    mu[su] = True
+    mi = torch.zeros(I, dtype=torch.bool, device=dev)
+    mi[si] = True
+    sel = torch.nonzero(mu[u.long()] | mi[i.long()] | mi[j.long()]).flatten()
+    uu, ii, jj = u[sel].long(), i[sel].long(), j[sel].long()
+    users = torch.unique(torch.cat([uu, su]))
+    items = torch.unique(torch.cat([ii, jj, si]))
+    ru = torch.full((U,), -1, dtype=torch.int64, device=dev)
+    ru[users] = torch.arange(users.numel(), device=dev)
+    ri = torch.full((I,), -1, dtype=torch.int64, device=dev)
+    ri[items] = torch.arange(items.numel(), device=dev)
+    gu_s, gi_s, bi_s = cpu(Gu0[users]), cpu(Gi0[items]), cpu(Bi0[items])
+    a = (cpu(ru[uu]), cpu(ri[ii]), cpu(ri[jj]))
+    g32 = ob.gradients(gu_s, gi_s, bi_s, *a, l_w, l_b)                      # (dBi, dGu, dGi)
+    g64 = ob.gradients(gu_s, gi_s, bi_s, *a, l_w, l_b, dtype=np.float64)
+    pu, pi = cpu(ru[su]), cpu(ri[si])
+    return {"n": int(sel.numel()),
+            "gGu": (g32[1][pu], g64[1][pu]), "gGi": (g32[2][pi], g64[2][pi]), "gBi": (g32[0][pi], g64[0][pi])}
+
+
+def loss_fp64(Gu, Gi, Bi, u, i, j, l_w, l_b, piece=1 << 18):
+    """Independent fp64 evaluation of the batch loss (BPRMF_batch_model.py:65-75), in slices."""
+    ref = 0.0
+    for s in range(0, u.numel(), piece):
+        sl = slice(s, s + piece)
+        gu, gi, gj = Gu[u[sl].long()].double(), Gi[i[sl].long()].double(), Gi[j[sl].long()].double()
+        bi, bj = Bi[i[sl].long()].double(), Bi[j[sl].long()].double()
+        d = (bi + (gu * gi).sum(1)) - (bj + (gu * gj).sum(1))
+        ref += float(torch.nn.functional.softplus(-d.clamp(-80.0, 1e8)).sum()
+                     + l_w * 0.5 * ((gu * gu).sum() + (gi * gi).sum() + (gj * gj).sum())
+                     + l_b * 0.5 * (bi * bi).sum() + (l_b / 10) * 0.5 * (bj * bj).sum())
+        del gu, gi, gj
+    return ref
+
+
+def _user_grad_rows(st, su, step):
+    """Rows `su` of the user-row gradients of the last grads() call (compact rows + stamps, or the dense accumulator)."""
+    if not st.compact:
+        return st.gGu[su]
+    ent = st.uslot[su]
+    hit = (ent >> 32) == step
+    rows = st.gGu_rows[(ent & 0xFFFFFFFF).clamp(max=st.gGu_rows.shape[0] - 1)]
+    return torch.where(hit[:, None], rows, torch.zeros_like(rows))
+
+
+def bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, steps, lr, l_w, l_b, n_rows=1024, n_hot=3, seed=42,
+                           grad_check_steps=2):
+    from oracle import bprmf_batch as ob
+    dev = ctx.device
+    U, F = int(Gu.shape[0]), int(Gu.shape[1])
+    I = int(Gi.shape[0])
+    A = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    R = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", deferred=False, fused_user_step=False, fused_item_step=False)
+    assert A.compact and A.fused and A.item_fused, "bench.py's state at this size: compact rows, fused user side, fused item side"
+    assert R.compact and not R.fused and not R.item_fused and not R.deferred
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    su = torch.randperm(U, generator=g, device=dev)[:n_rows]
+    t0 = ops.bpr_sample(ctx, pos, B, seed=seed, first_sample=0)
+    hot = torch.argsort(torch.bincount(torch.cat([t0[1], t0[2]]).long(), minlength=I), descending=True)[:n_hot]
+    si = torch.unique(torch.cat([torch.randperm(I, generator=g, device=dev)[:n_rows], hot]))
+    th = {"Gu": cpu(R.Gu[su]), "Gi": cpu(R.Gi[si]), "Bi": cpu(R.Bi[si])}
+    m = {k: np.zeros_like(x) for k, x in th.items()}
+    v = {k: np.zeros_like(x) for k, x in th.items()}
+    rec = {"loss_A": [], "loss_ref": [], "touch": [], "A": A, "R": R, "su": su, "si": si, "hot": hot}
+
+    def reference_step(u, i, j, check_grads):
+        """R (two-pass, every row) + the oracle recurrence on the sampled rows, one step; returns the fp64 loss of the batch."""
+        exp = oracle_rows(R.Gu, R.Gi, R.Bi, u, i, j, su, si, l_w, l_b)
+        ref = loss_fp64(R.Gu, R.Gi, R.Bi, u, i, j, l_w, l_b)
+        R.grads(u, i, j, l_w, l_b)
+        lossR = R.pop_loss()
+        assert abs(lossR - ref) <= 1e-4 * abs(ref), ("two-pass loss", R.step, lossR, ref)
+        if check_grads:
+            got = {"gGu": cpu(_user_grad_rows(R, su, R.step + 1)), "gGi": cpu(R.gGi[si]), "gBi": cpu(R.gBi[si])}
+            for name in ("gGu", "gGi", "gBi"):
+                e32, e64 = exp[name]
+                scale = float(np.abs(e64).max())
+                err = float(np.abs(got[name] - e64).max())
+                ref_err = float(np.abs(e32.astype(np.float64) - e64).max())
+                assert err <= max(2e-5 * scale, 4 * ref_err), (R.step, name, err, ref_err, scale)
+        R.apply(lr)
+        for name, gname in (("Gu", "gGu"), ("Gi", "gGi"), ("Bi", "gBi")):
+            ob.adam_tf_sparse_apply(th[name], m[name], v[name], exp[gname][0].astype(np.float32), lr, R.step)
+        rec["touch"].append(exp["n"])
+        return ref
+
+    # ---- cover batches (bench.py: every user row -- and every item row where the item side defers -- gets a gradient once) ----
+    cover_users = U if 4 * B <= U else 0
+    cover_items = I if 2 * B <= I else 0
+    n_cover = 0
+    if cover_users or cover_items:
+        for c, (u, i, j) in enumerate(cover_triplets(indptr, indices, cover_users, cover_items, U, I, B)):
+            A.train_step(u, i, j, lr, l_w, l_b)
+            rec["loss_A"].append(A.pop_loss())
+            rec["loss_ref"].append(reference_step(u, i, j, check_grads=c == 0))
+            n_cover += 1
+        A.sync()
+    rec["n_cover"] = n_cover
+    rec["deferred"], rec["item_deferred"] = bool(A.deferred), bool(A.item_deferred)
+
+    # ---- the timed region's loop: pipelined presorted steps on a high-priority stream, no host sync in between ----
+    sampler = PrefetchSampler(ctx, pos, B, seed, enabled=True, presort_state=A)
+    hi = torch.cuda.Stream(device=dev, priority=-1)
+    hi.wait_stream(torch.cuda.current_stream())
+    trip, cum = [], []
+    with torch.cuda.stream(hi):
+        A.loss.zero_()
+    for s in range(steps):
+        with torch.cuda.stream(hi):
+            t, b = sampler.next()
+            A.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, sampler.ws[b])
+            trip.append(tuple(x.clone() for x in t))              # (on the step's stream, before the buffer is handed back)
+            cum.append(A.loss.clone())
+            sampler.release(b)
+    with torch.cuda.stream(hi):
+        pending = (A._pending, A._pending_items)
+        A.sync()
+    torch.cuda.current_stream().wait_stream(hi)
+    torch.cuda.current_stream().wait_stream(sampler.side)
+    torch.cuda.synchronize()
+    rec["pending_before_sync"] = pending
+    cumv = [float(c.item()) for c in cum]
+    for s in range(steps):
+        u, i, j = trip[s]
+        assert torch.equal(u, ops.bpr_sample(ctx, pos, B, seed=seed, first_sample=s * B)[0]), "the look-ahead drew another batch"
+        rec["loss_A"].append(cumv[s] - (cumv[s - 1] if s else 0.0))
+        rec["loss_ref"].append(reference_step(u, i, j, check_grads=s < grad_check_steps))
+    del trip
+    A.loss.zero_()
+    assert A.step == R.step == n_cover + steps
+
+    # (i) every step's loss
+    for s, (x, y) in enumerate(zip(rec["loss_A"], rec["loss_ref"])):
+        assert abs(x - y) <= 1e-4 * abs(y), ("loss", s, x, y)
+    # every row is stamped current
+    if A.Gu_last is not None:
+        assert int(A.Gu_last.min()) == A.step == int(A.Gu_last.max())
+    assert int(A.Gi_last.min()) == A.step == int(A.Gi_last.max())
+    assert not bool(A.gGi.any()) and not bool(A.gBi.any())            # accumulators clean on exit
+
+    # (ii) the oracle recurrence on the sampled rows
+    rec["oracle_err"] = {}
+    for tag, st in (("A", A), ("R", R)):
+        for name, rows in (("Gu", su), ("Gi", si), ("Bi", si)):
+            err = np.abs(cpu(getattr(st, name)[rows]) - th[name])
+            frac, mx = float((err > 2e-5).mean()), float(err.max())
+            rec["oracle_err"][tag + "." + name] = (mx, frac)
+            assert frac <= 2e-4 and mx < 3 * lr, (tag, name, mx, frac)
+    # (iii) bench path == every-row two-pass form
+    exact = ops.deterministic_item_sums(ctx)
+    rec["exact"] = exact
+    rec["vs_two_pass"] = {}
+    for name, rows in (("Gu", su), ("mGu", su), ("vGu", su), ("Gi", si), ("mGi", si), ("vGi", si), ("Bi", si), ("mBi", si), ("vBi", si)):
+        x, y = getattr(A, name)[rows], getattr(R, name)[rows]
+        nbad = int((x.view(torch.int32) != y.view(torch.int32)).sum())
+        rec["vs_two_pass"][name] = (nbad, float((x - y).abs().max()))
+        if exact:
+            assert nbad == 0, ("sampled rows differ from the every-row two-pass form", name, nbad, float((x - y).abs().max()))
+    for name in ("Gu", "mGu", "vGu", "Gi", "mGi", "vGi", "Bi"):
+        x, y = getattr(A, name), getattr(R, name)
+        if exact:
+            nbad = 0
+            for a in range(0, x.shape[0], 1 << 20):                    # (slices: no second copy of a 5 GB table)
+                nbad += int((x[a:a + (1 << 20)].view(torch.int32) != y[a:a + (1 << 20)].view(torch.int32)).sum())
+            rec["vs_two_pass"]["all." + name] = (nbad, 0.0)
+            assert nbad == 0, ("tables differ from the every-row two-pass form", name, nbad)
+        else:
+            big, mx, n = 0, 0.0, 0
+            for a in range(0, x.shape[0], 1 << 20):
+                e = (x[a:a + (1 << 20)] - y[a:a + (1 << 20)]).abs()
+                big += int((e > 2e-6).sum())
+                mx = max(mx, float(e.max()))
+                n += e.numel()
+            rec["vs_two_pass"]["all." + name] = (big / n, mx)
+            # Adam's normalised step turns a last-bit difference of a tiny gradient sum into up to ~lr on isolated elements
+            assert big / n < 2e-3 and mx < 12 * lr, (name, big / n, mx)
+    return rec

@@ -464,7 +464,7 @@ def test_pipelined_step_equals_the_sequential_step(ctx):
     """bench.py's software pipeline -- the batch of step t+1 drawn AND ordered (sampler, prep, radix sort) on a side stream while
     step t's segment kernels and optimiser pass run, the step itself on a high-priority stream -- against the plain sequence of
     train_step calls on the same Philox stream: same triplets, same losses, same weights (hot rows: atomics order only)."""
-    import bench
+    from elliot_amd.pipeline import PrefetchSampler
     from elliot_amd.synthetic import zipf_csr
     rs = np.random.RandomState(91)
     U, I, F, B, steps = 20000, 3000, 64, 8192, 7
@@ -474,7 +474,7 @@ def test_pipelined_step_equals_the_sequential_step(ctx):
     lr, l_w, l_b = 0.01, 0.1, 0.001
     a = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True)
     b = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True)
-    sampler = bench.PrefetchSampler(ctx, pos, B, 42, enabled=True, presort_state=b)
+    sampler = PrefetchSampler(ctx, pos, B, 42, enabled=True, presort_state=b)
     hi = torch.cuda.Stream(device=ctx.device, priority=-1)
     hi.wait_stream(torch.cuda.current_stream())
     la, lb = [], []
