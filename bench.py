@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--opt", default="adam_tf_dense", choices=["adam_tf_dense", "adam_lazy", "sgd"])
     ap.add_argument("--train-algo", default="auto", choices=["auto", "atomic", "sorted"])
+    ap.add_argument("--replay", default="series", choices=["series", "exact"],
+                    help="N = 1, deferred decay: a waiting row's gradient-free Adam steps in closed form (el_bprmf_state.replay_series: O(1) per "
+                         "element; inside the parity tolerances, tests/test_gpu_fullsize_c4.py) or step by step (Keras' bits).  `value` is this "
+                         "mode's; the other mode's training throughput rides under legs.replay_other")
     ap.add_argument("--topk-algo", default="auto", choices=["auto", "screen", "mfma", "simple"])
     ap.add_argument("--shard", default="user", choices=["user", "item"],
                     help="N > 1, primary leg: shard the USER table (item table replicated, all-reduce of item gradients) or the "
@@ -412,6 +416,97 @@ def cpu_baseline(args, host):
     return out
 
 
+def single_gpu_trainer(args, ctx, data, Gu, Gi, Bi, replay):
+    """The single-GPU training loop of a BPR leg: state, (pipelined) step, cover batches -- everything up to the timed region."""
+    from elliot_amd import ops
+    dev = ctx.device
+    U, I, B = args.users, args.items, args.batch
+    indptr, indices, pos = data["indptr"], data["indices"], data["pos"]
+    lr, l_w, l_b = 0.001, 0.1, 0.001                                          # BPRMF_batch.py:66-71 defaults
+    finish_train = breakdown_step = None
+    cover_steps = 0
+    st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt, replay=replay)
+    # Software pipeline of the step: drawing AND ordering a batch (sampler, prep, radix sort) reads only the positives' CSR and
+    # the triplets, never the model -- so the batch of step t+1 is prepared on a side stream while step t's segment kernels and
+    # optimiser pass run (latency-bound work under bandwidth-bound work: 1.47 -> 1.41 ms per step).  Same kernels, same
+    # triplets, same results as the sequential step (the loss of the last step is identical to the last digit).
+    pipelined = (not args.no_pipeline) and args.train_algo in ("auto", "sorted") and B >= 2048 and args.opt == "adam_tf_dense"
+    # (el_bprmf_apply is the dense optimiser pass; the lazy / row-wise optimisers keep the one-call step)
+    sampler = PrefetchSampler(ctx, pos, B, 42, enabled=pipelined, presort_state=st if pipelined else None)
+    hi_prio = torch.cuda.Stream(device=dev, priority=-1) if pipelined else None     # the step's own kernels outrank the look-ahead
+    if hi_prio is not None:
+        hi_prio.wait_stream(torch.cuda.current_stream())
+
+    def train_step():
+        if pipelined:
+            with torch.cuda.stream(hi_prio):
+                t, b = sampler.next()
+                st.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, sampler.ws[b])
+                sampler.release(b)
+            return
+        t, b = sampler.next()
+        st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
+        sampler.release(b)
+
+    if pipelined:
+        seq_drawn = [1 << 40]                                    # (its own part of the Philox stream)
+
+        def train_step_sequential():
+            """The same step with nothing in flight beside it: what the per-kernel breakdown pass runs."""
+            torch.cuda.current_stream().wait_stream(hi_prio)
+            torch.cuda.current_stream().wait_stream(sampler.side)
+            t = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=seq_drawn[0])
+            seq_drawn[0] += B
+            st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
+            hi_prio.wait_stream(torch.cuda.current_stream())
+            sampler.side.wait_stream(torch.cuda.current_stream())
+        breakdown_step = train_step_sequential
+    # Steady state of the deferred decay before anything is timed: a row that never had a gradient (m = v = 0) is a fixed point
+    # of the gradient-free Adam step and the replay kernels skip it, so a short run from fresh tables would replay far fewer
+    # element-steps than a long one.  "Cover" batches give EVERY user row and EVERY item row a gradient once (users in order,
+    # one of their positives each; negatives in item order): ceil(max(U, I) / B) extra untimed steps, the same train_step.
+    if args.opt == "adam_tf_dense" and (4 * B <= U or 2 * B <= I):
+        cover_batches(st, indptr, indices, U if 4 * B <= U else 0, I if 2 * B <= I else 0, U, I, B, lr, l_w, l_b, args.train_algo)
+        cover_steps = -(-max(U if 4 * B <= U else 0, I if 2 * B <= I else 0) // B)
+    # deferred decay of the user table (the state turns it on at its first batch when 4 B <= U): the timed region ends with
+    # the replay of every postponed row update -- each (element, step) update of Keras' every-row Adam is inside the timed
+    # region.  A no-op in the every-row form.
+    def finish_train():
+        if hi_prio is not None:
+            with torch.cuda.stream(hi_prio):
+                st.sync()
+        else:
+            st.sync()
+    return {"st": st, "train_step": train_step, "finish_train": finish_train, "breakdown_step": breakdown_step, "pipelined": pipelined,
+            "cover_steps": cover_steps, "sampler": sampler}
+
+
+def replay_other_leg(args, ctx, data, replay):
+    """The headline training step once more with the OTHER replay mode of the deferred decay (train only: same data, same initial
+    tables, same cover batches, same pipelined timed region ending with the flush of every pending row)."""
+    dev = ctx.device
+    U, I, F, B = args.users, args.items, args.factors, args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    lim_u, lim_i = (6.0 / (U + F)) ** 0.5, (6.0 / (I + F)) ** 0.5
+    Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * lim_u
+    Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i
+    Bi = torch.zeros(I, device=dev)
+    tr = single_gpu_trainer(args, ctx, data, Gu, Gi, Bi, replay)
+    del Gu, Gi, Bi
+    if not tr["st"].deferred and not tr["st"]._deferred_auto:
+        return None
+    dt, rep = timed(ctx, 1, tr["train_step"], args.warmup, args.steps, tr["finish_train"], fn_breakdown=tr["breakdown_step"])
+    loss = tr["st"].pop_loss()
+    K = args.steps
+    return {"replay": replay, "value": B * K / dt, "unit": "pairs/s", "ms_per_step": dt / K * 1e3, "repeats_ms_per_step": rep.repeats_ms,
+            "loss_per_pair_last": loss / (B * K * max(1, len(rep.repeats_ms))) if loss else None,
+            "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()},
+            "what": ("waiting rows brought forward step by step: the same fp32 operations in the same order as Keras' every-row pass (bit-identical "
+                     "tables, tests/test_gpu_bpr.py)" if replay == "exact" else
+                     "waiting rows brought forward in closed form (el_bprmf_state.replay_series)")}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BPR-MF leg (train + top-k), any sharding
 # ---------------------------------------------------------------------------------------------------------------------
@@ -439,60 +534,9 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
     collectives = []                                                          # (what, op, bytes per rank and call, callable)
     cover_steps = 0
     if not sharded:
-        st = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer=args.opt)
-        pos_train = pos
-        # Software pipeline of the step: drawing AND ordering a batch (sampler, prep, radix sort) reads only the positives' CSR and
-        # the triplets, never the model -- so the batch of step t+1 is prepared on a side stream while step t's segment kernels and
-        # optimiser pass run (latency-bound work under bandwidth-bound work: 1.47 -> 1.41 ms per step).  Same kernels, same
-        # triplets, same results as the sequential step (the loss of the last step is identical to the last digit).
-        pipelined = (not args.no_pipeline) and args.train_algo in ("auto", "sorted") and B >= 2048 and args.opt == "adam_tf_dense"
-        # (el_bprmf_apply is the dense optimiser pass; the lazy / row-wise optimisers keep the one-call step)
-        sampler = PrefetchSampler(ctx, pos, B, 42, enabled=pipelined, presort_state=st if pipelined else None)
-        hi_prio = torch.cuda.Stream(device=dev, priority=-1) if pipelined else None     # the step's own kernels outrank the look-ahead
-        if hi_prio is not None:
-            hi_prio.wait_stream(torch.cuda.current_stream())
-
-        def train_step():
-            if pipelined:
-                with torch.cuda.stream(hi_prio):
-                    t, b = sampler.next()
-                    st.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, sampler.ws[b])
-                    sampler.release(b)
-                return
-            t, b = sampler.next()
-            st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
-            sampler.release(b)
-
-        if pipelined:
-            seq_drawn = [1 << 40]                                    # (its own part of the Philox stream)
-
-            def train_step_sequential():
-                """The same step with nothing in flight beside it: what the per-kernel breakdown pass runs."""
-                torch.cuda.current_stream().wait_stream(hi_prio)
-                torch.cuda.current_stream().wait_stream(sampler.side)
-                t = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=seq_drawn[0])
-                seq_drawn[0] += B
-                st.train_step(t[0], t[1], t[2], lr, l_w, l_b, algo=args.train_algo)
-                hi_prio.wait_stream(torch.cuda.current_stream())
-                sampler.side.wait_stream(torch.cuda.current_stream())
-            breakdown_step = train_step_sequential
-        pop_loss = st.pop_loss
-        # Steady state of the deferred decay before anything is timed: a row that never had a gradient (m = v = 0) is a fixed point
-        # of the gradient-free Adam step and the replay kernels skip it, so a short run from fresh tables would replay far fewer
-        # element-steps than a long one.  "Cover" batches give EVERY user row and EVERY item row a gradient once (users in order,
-        # one of their positives each; negatives in item order): ceil(max(U, I) / B) extra untimed steps, the same train_step.
-        if args.opt == "adam_tf_dense" and (4 * B <= U or 2 * B <= I):
-            cover_batches(st, indptr, indices, U if 4 * B <= U else 0, I if 2 * B <= I else 0, U, I, B, lr, l_w, l_b, args.train_algo)
-            cover_steps = -(-max(U if 4 * B <= U else 0, I if 2 * B <= I else 0) // B)
-        # deferred decay of the user table (the state turns it on at its first batch when 4 B <= U): the timed region ends with
-        # the replay of every postponed row update -- each (element, step) update of Keras' every-row Adam is inside the timed
-        # region.  A no-op in the every-row form.
-        def finish_train():
-            if hi_prio is not None:
-                with torch.cuda.stream(hi_prio):
-                    st.sync()
-            else:
-                st.sync()
+        tr = single_gpu_trainer(args, ctx, data, Gu, Gi, Bi, args.replay)
+        st, pos_train, train_step, finish_train, breakdown_step = tr["st"], pos, tr["train_step"], tr["finish_train"], tr["breakdown_step"]
+        pop_loss, pipelined, cover_steps = st.pop_loss, tr["pipelined"], tr["cover_steps"]
     elif shard == "user":
         # USER shards: the rank owns the user rows [ulo, uhi) and a replica of the item table; B triplets per rank for its
         # own users (items: the whole catalogue, the reference's sampling distribution), all-reduce of the item gradients
@@ -752,19 +796,22 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         item_rows_moved = (items_touched if item_deferred else rows_i) if item_fused else rows_i
         moved = 24.0 * (rows_touched + item_rows_moved) * F + 4.0 * rows_touched * F + B * (24.0 * F + 32.0) + 24.0 * rows_u * F / K
         roof_train.update({
-            "deferred_decay": f"user rows without triplets in a batch are not moved by that step: their gradient-free Adam updates are replayed "
-                              f"bit for bit when next needed; the {K} timed steps end with the replay of every pending row (k_bpr_flush_users)",
+            "replay": args.replay,
+            "deferred_decay": f"user rows without triplets in a batch are not moved by that step: their gradient-free Adam updates are taken "
+                              + ("in closed form (four row-level sums over the lr_t history, O(1) per element: el_bprmf_state.replay_series; inside "
+                                 "the oracle tolerances, tests/test_gpu_fullsize_c4.py)" if args.replay == "series" else "step by step, bit for bit,")
+                              + f" when next needed; the {K} timed steps end with the catch-up of every pending row (k_bpr_flush_users)",
             "user_rows_per_step": rows_touched,
-            "valu": {"what": "k_bpr_user_seg (a row's missed steps when its segment starts) and k_bpr_flush_users replay the postponed updates in "
-                             "registers: one correctly rounded fp32 sqrt and division per element and step, on packed fp32 instructions -- U F "
-                             "element-steps per optimiser step in the steady state, whatever B is; the user-segment kernel's HBM fraction "
-                             "above is that of a kernel that also carries this arithmetic",
+            "valu": {"what": ("k_bpr_user_seg and k_bpr_flush_users bring waiting rows forward in closed form: one v_sqrt + one v_rcp + ~10 fp32 "
+                              "operations per ELEMENT and 10 scalar operations per ROW and missed step" if args.replay == "series" else
+                              "k_bpr_user_seg (a row's missed steps when its segment starts) and k_bpr_flush_users replay the postponed updates in "
+                              "registers: one correctly rounded fp32 sqrt and division per element and step, on packed fp32 instructions -- U F "
+                              "element-steps per optimiser step in the steady state, whatever B is; the user-segment kernel's HBM fraction "
+                              "above is that of a kernel that also carries this arithmetic"),
                      "element_steps_per_step": float(rows_u) * F + (float(rows_i) * F if item_deferred else 0.0),
                      "steady_state": "every row was given a gradient once before the timed region (cover batches): none sits at the m = v = 0 "
                                      "fixed point the replay kernels skip",
-                     "catchup_ms_per_step": rep_train.get("k_bpr_catchup", (0, 0.0))[1] / K,
-                     "flush_ms_per_step": rep_train.get("k_bpr_flush_users", (0, 0.0))[1] / K,
-                     "note": "a bare replay loop sustains 1.1e12 (compiler sqrt / div) and 1.7e12 (packed) element-steps/s (scripts/exp/replay_math.hip)"},
+                     "flush_ms_per_step": rep_train.get("k_bpr_flush_users", (0, 0.0))[1] / K},
             "step_GBs_note": "step_GBs_moved = the bytes this form has to move (batch rows + 1/K of the final replay) / step time; SURVEY 8d's "
                              "every-row byte count over the same time is kept outside the roofline object as `survey8d_equivalent_GBs` (a work "
                              "equivalent, not a bandwidth: the deferred decay replays those rows in registers instead of moving them)",
@@ -1230,7 +1277,7 @@ def compact_line(full):
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data", "topk_users_per_s", "topk_ms_per_block", "topk_frac") if k in full}
     cfg = full.get("config", {})
-    line["config"] = {k: cfg[k] for k in ("workload", "users", "items", "factors", "interactions", "batch", "batch_per_gpu", "optimizer",
+    line["config"] = {k: cfg[k] for k in ("workload", "users", "items", "factors", "interactions", "batch", "batch_per_gpu", "optimizer", "replay",
                                           "topk_block", "k", "parallelism", "world_size_observed", "backend", "collectives_through")
                       if cfg.get(k) is not None}
     if "workload" in line["config"]:
@@ -1246,6 +1293,9 @@ def compact_line(full):
     if "item_shard" in full:
         line["item_shard"] = _bpr_summary(full["item_shard"])
     legs = {}
+    if "replay_other" in full:
+        ro = full["replay_other"]
+        legs["replay_" + ro["replay"]] = {"pairs_per_s": ro["value"], "ms_per_step": ro["ms_per_step"]}
     if "c2" in full:
         legs["c2"] = dict(_bpr_summary(full["c2"]), workload="BPRMF d=128, 1M users x 100K items (BASELINE configs[1])")
     if "c5_per_gpu" in full:
@@ -1364,6 +1414,10 @@ def main():
     topk_shard = args.topk_shard or ("user" if args.shard == "user" else "item")
     main_leg = bpr_leg(args, ctx, world, rank, data, args.shard, topk_shard, with_metrics="metrics" in legs and "c2" not in legs,
                        keep_host=want_cpu and rank == 0)
+    other = None
+    if world == 1 and not args.force_sharded and args.opt == "adam_tf_dense" and "bpr" in legs:
+        torch.cuda.empty_cache()
+        other = replay_other_leg(args, ctx, data, "exact" if args.replay == "series" else "series")
     second = None
     if "item_shard" in legs and sharded and args.shard == "user":
         torch.cuda.empty_cache()
@@ -1435,7 +1489,8 @@ def main():
                                 else "BPRMF d=128, synthetic 1M users x 100K items (BASELINE configs[1])" if (U, I, F) == (1_000_000, 100_000, 128)
                                 else f"BPRMF d={F}, synthetic {U} users x {I} items"),
                    "users": U, "items": I, "factors": F, "interactions": main_leg["interactions"], "batch": B,
-                   "batch_per_gpu": B, "optimizer": args.opt, "topk_block": main_leg["topk_block"], "k": k,
+                   "batch_per_gpu": B, "optimizer": args.opt, "replay": args.replay if (not sharded and args.opt == "adam_tf_dense") else None,
+                   "topk_block": main_leg["topk_block"], "k": k,
                    "parallelism": main_leg["parallelism"] + ("; top-k: see topk.sharding" if sharded else ""),
                    "scaling_note": ("one model of this shape partitioned over the ranks (user rows sharded, item table replicated), B triplets "
                                     "per rank and step: the batch grows with N, the tables do not") if sharded else None,
@@ -1447,6 +1502,8 @@ def main():
     for key in ("collectives", "metrics"):
         if key in main_leg:
             line[key] = main_leg[key]
+    if other is not None:
+        line["replay_other"] = other
     if second is not None:
         line["item_shard"] = {kk: second[kk] for kk in ("value", "unit", "ms_per_step", "scaling", "parallelism", "loss_per_pair_last",
                                                        "roofline", "topk", "collectives") if kk in second}

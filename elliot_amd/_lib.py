@@ -36,7 +36,7 @@ class BprmfState(C.Structure):
         ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32),
         ("uslot", _i64p), ("gGu_rows", _f32p), ("gGu_cap", C.c_int64), ("Gu_next", _f32p),
         ("Gu_last", _i32p), ("Gu_old", _f32p), ("Gu_old_cap", C.c_int64), ("lr_hist", _f32p), ("lr_hist_cap", C.c_int32),
-        ("Gi_last", _i32p), ("Gi_defer", C.c_int32),
+        ("Gi_last", _i32p), ("Gi_defer", C.c_int32), ("replay_series", C.c_int32),
     ]
 
 
@@ -108,6 +108,8 @@ PROTOTYPES = {
     "el_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "el_timing_filter": (C.c_int, [C.c_void_p, C.c_char_p]),
     "el_tuning_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "el_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "el_ctx_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "el_comm_unique_id": (C.c_int, [C.c_void_p]),
     "el_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "el_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -88,7 +88,6 @@ struct SegParams {
     // decay points them at the pre-update rows the user-side kernel left in Gu_old, by segment head position)
     const float* ubase;
     const int32_t* uidx;
-    int pair4;           // user segments with a row across 64 lanes x 2 elements: dot products summed in the 32 x 4 order
 };
 
 struct FusedParams {
@@ -104,12 +103,12 @@ struct FusedParams {
     float* hist;              // lr_t of step s at hist[s & hist_mask]
     int hist_mask;
     int32_t t;                // this optimiser step
-    int replay;               // 1: k_bpr_user_seg<DEFER> brings a row to step t - 1 itself when its segment starts (no k_bpr_catchup launch)
 };
 
 // ---- user segments -----------------------------------------------------------------------
-// DEFER (el_bprmf_state.Gu_last, the deferred decay): the step's whole user side on the batch's rows only.  k_bpr_catchup brought
-// the rows of the batch's users to step t - 1 just before; a group owns every segment whose head lies in its chunk (the compact
+// DEFER (el_bprmf_state.Gu_last, the deferred decay): the step's whole user side on the batch's rows only.  A row's postponed
+// gradient-free steps (last, t - 1] are taken in registers when its segment starts (SER: in closed form, el_adam_series_*;
+// otherwise step by step, the same bits as the every-row pass); a group owns every segment whose head lies in its chunk (the compact
 // rule below), and where the two-kernel form writes the gradient row, this form takes Keras' Adam step on the row right away:
 // m, v (fetched when the segment starts) and theta updated IN PLACE, the pre-update theta left in old_rows[head] for the item
 // segments, hpos[b] = head for every triplet of the segment, Gu_last[user] = t.  Work proportional to B, whatever U is.
@@ -118,13 +117,13 @@ struct FusedParams {
 // any row arrives) -- at 10 M users nearly every position of a 1 M-triplet batch starts a segment, and fetching m, v only once the
 // walk reaches the head put a second full memory latency behind every position's gathers (5 L + 4 R per four positions instead of
 // L + 4 R, at three waves per SIMD).
-template <int VW, int CPL, bool DEFER, int SUBD = 0>
+template <int VW, int CPL, bool DEFER, int SUBD = 0, bool SER = false>
 __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f) {
     const int F = p.st.F, lpt = p.lpt;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = gid / lpt;
     const int sub = (int)(threadIdx.x & (lpt - 1));
-    if (DEFER && f.replay && gid == 0) f.hist[f.t & f.hist_mask] = f.lr_t;     // lr_t of THIS step into the ring (replays here read steps < t)
+    if (DEFER && gid == 0) f.hist[f.t & f.hist_mask] = f.lr_t;     // lr_t of THIS step into the ring (replays here read steps < t)
     int64_t p0 = grp * p.chunk;
     int64_t p1 = (p0 + p.chunk < p.n) ? p0 + p.chunk : p.n;
     // Compact user-gradient rows (el_bprmf_state.uslot): a segment belongs, whole, to the group whose chunk holds its HEAD --
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                 s_j[t] = (u32)jj;
                 s_bi[t] = p.st.Bi[ii];
                 s_bj[t] = p.st.Bi[jj];
-                if (PRE) s_last[t] = f.replay ? f.last[kk] : 0;
+                if (PRE) s_last[t] = f.last[kk];
             }
             el_wave_lds_sync();
             for (int base = 0; base < cs; base += SUB) {
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                         vrow[DEFER ? q : 0][x] = rv[PRE ? t : 0][q][x];
                                     }
                             } else {
-                                lastv = f.replay ? f.last[key] : 0;
+                                lastv = f.last[key];
 #pragma unroll
                                 for (int q = 0; q < CPL; ++q) {
                                     const int e = (sub + q * lpt) * VW;
@@ -295,9 +294,8 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                     }
                                 }
                             }
-                            // the row's postponed gradient-free steps (last, t - 1], in registers, before anything uses it (what
-                            // k_bpr_catchup did in a launch of its own, reading and writing the three rows once more)
-                            const int nsr = f.replay ? (f.t - 1) - lastv : 0;
+                            // the row's postponed gradient-free steps (last, t - 1], in registers, before anything uses it
+                            const int nsr = (f.t - 1) - lastv;
                             if (nsr > 0) {
                                 bool nz = false;
 #pragma unroll
@@ -305,10 +303,15 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
 #pragma unroll
                                     for (int x = 0; x < VW; ++x) nz = nz || mrow[DEFER ? q : 0][x] != 0.f || vrow[DEFER ? q : 0][x] != 0.f;
                                 if (el_group_any(nz, lpt)) {     // (m = v = 0: the fixed point of the step, whatever the gap)
+                                    auto lrs = [&](int s2) { return f.hist[(lastv + 1 + s2) & f.hist_mask]; };
+                                    if (SER) {                   // the row-level sums once, then O(1) per element
+                                        const el_series sr = el_adam_series_sums(nsr, lrs);
 #pragma unroll
-                                    for (int q = 0; q < CPL; ++q)
-                                        el_adam_replay<VW>(gu[q], mrow[DEFER ? q : 0], vrow[DEFER ? q : 0], nsr,
-                                                           [&](int s2) { return f.hist[(lastv + 1 + s2) & f.hist_mask]; });
+                                        for (int q = 0; q < CPL; ++q) el_adam_series_apply<VW>(gu[q], mrow[DEFER ? q : 0], vrow[DEFER ? q : 0], sr);
+                                    } else {
+#pragma unroll
+                                        for (int q = 0; q < CPL; ++q) el_adam_replay<VW>(gu[q], mrow[DEFER ? q : 0], vrow[DEFER ? q : 0], nsr, lrs);
+                                    }
                                 }
                             }
                         }
@@ -329,25 +332,8 @@ __global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f
                                 dpj += gu[q][x] * rgj[t][q][x];
                                 nsq += gu[q][x] * gu[q][x] + rgi[t][q][x] * rgi[t][q][x] + rgj[t][q][x] * rgj[t][q][x];
                             }
-                        if (VW == 2 && CPL == 1 && p.pair4) {
-                            // a row across 64 lanes x 2 elements, summed in the order of the 32 lanes x 4 elements form (the
-                            // every-row kernel's): lane pair (2l, 2l + 1) = that form's lane l -- ((0 + p0) + p1) in the even
-                            // lane, then (.. + p2) + p3 in the odd one, then the same butterfly over the 32 pair sums
-                            const bool odd = (sub & 1) != 0;
-                            const float ei = __shfl_xor(dpi, 1, 64), ej = __shfl_xor(dpj, 1, 64);
-                            float ti = (ei + gu[0][0] * rgi[t][0][0]) + gu[0][VW - 1] * rgi[t][0][VW - 1];
-                            float tj = (ej + gu[0][0] * rgj[t][0][0]) + gu[0][VW - 1] * rgj[t][0][VW - 1];
-                            const float oi = __shfl_xor(ti, 1, 64), oj = __shfl_xor(tj, 1, 64);
-                            dpi = odd ? ti : oi;
-                            dpj = odd ? tj : oj;
-                            for (int o = 32; o >= 2; o >>= 1) {
-                                dpi += __shfl_xor(dpi, o, 64);
-                                dpj += __shfl_xor(dpj, o, 64);
-                            }
-                        } else {
-                            dpi = el_group_sum(dpi, lpt);
-                            dpj = el_group_sum(dpj, lpt);
-                        }
+                        dpi = el_group_sum(dpi, lpt);
+                        dpj = el_group_sum(dpj, lpt);
                         const float beta_i = s_bi[base + t], beta_j = s_bj[base + t];
                         const float d = (beta_i + dpi) - (beta_j + dpj);   // x_ui - x_uj  (BPRMF_batch_model.py:53,65)
                         const float dc = fminf(fmaxf(d, -80.0f), 1e8f);
@@ -557,13 +543,15 @@ __global__ __launch_bounds__(256) void k_bpr_user_adam(SegParams p, FusedParams 
     }
 }
 
-// deferred decay, start of step t: the rows of the batch's distinct users to step t - 1.  One WAVE per sorted position; the wave
-// on a segment head owns the row: elements e = (lane + 64 q) VW, all 64 lanes on the same replay length (a lane group per row
-// inside the fused kernel left ~15 % of the lanes busy: rows of one wave wait ~10 steps on average, the longest of them ~30).
-// m = v = 0 (a row that never had a gradient) is a fixed point of the gradient-free step: nothing to replay, whatever the gap.
-template <int VW>
+// One waiting row brought forward ns steps by a whole wave: elements e = (lane + 64 q) VW, all 64 lanes on the same gap (the item
+// catch-up kernel: one wave per sorted position, the wave on a segment head owns the row; the flush walks for rows wider than one
+// pass of the wave).  m = v = 0 (a row that never had a gradient) is a fixed point of the gradient-free step: nothing to do.
+template <int VW, bool SER>
 __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* __restrict__ tm, float* __restrict__ tv, int F, int64_t row, int lane,
                                                int last, int ns, const float* __restrict__ hist, int hist_mask) {
+    auto lrs = [&](int s) { return hist[(last + 1 + s) & hist_mask]; };
+    el_series sr;
+    if (SER) sr = el_adam_series_sums(ns, lrs);                  // (wave-uniform: once per row)
     for (int f0 = 0; f0 < F; f0 += 64 * VW) {
         const int e = f0 + lane * VW;
         float th[VW], mm[VW], vv[VW];
@@ -578,7 +566,8 @@ __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* _
 #pragma unroll
         for (int x = 0; x < VW; ++x) nz = nz || mm[x] != 0.f || vv[x] != 0.f;
         if (__ballot(nz) == 0ull) continue;                     // this chunk of the row is at its fixed point
-        el_adam_replay<VW>(th, mm, vv, ns, [&](int s) { return hist[(last + 1 + s) & hist_mask]; });
+        if (SER) el_adam_series_apply<VW>(th, mm, vv, sr);
+        else el_adam_replay<VW>(th, mm, vv, ns, lrs);
         if (e < F) {
             stv<VW>(tth + row * F + e, th);
             stv<VW>(tm + row * F + e, mm);
@@ -593,7 +582,7 @@ __device__ __forceinline__ void bpr_replay_row(float* __restrict__ tth, float* _
 // consecutive rows: their stamps in ONE coalesced load (lane = row), the pending rows by ballot, then the pending rows NR at a time --
 // their theta / m / v in flight together -- each replayed for its own gap exactly as bpr_replay_row does (same element order, same
 // arithmetic: the bit-for-bit tests of the deferred decay cover it).  Rows wider than one pass of the wave (F > 64 VW) keep the old walk.
-template <int VW, int NR>
+template <int VW, int NR, bool SER>
 __device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float* __restrict__ tm, float* __restrict__ tv, int32_t* __restrict__ last_arr,
                                                  int F, int64_t n_rows, int64_t row0, int lane, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int64_t myrow = row0 + lane;
@@ -605,7 +594,7 @@ __device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float*
             const int l = __builtin_ctzll(pend);
             pend &= pend - 1;
             const int last = __shfl(mylast, l, 64);
-            bpr_replay_row<VW>(tth, tm, tv, F, row0 + l, lane, last, t - last, hist, hist_mask);
+            bpr_replay_row<VW, SER>(tth, tm, tv, F, row0 + l, lane, last, t - last, hist, hist_mask);
         }
         if (t - mylast > 0) last_arr[myrow] = t;
         return;
@@ -642,7 +631,7 @@ __device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float*
 #pragma unroll
             for (int x = 0; x < VW; ++x) nz = nz || mm[r][x] != 0.f || vv[r][x] != 0.f;
             if (__ballot(nz) == 0ull) continue;                // (m = v = 0: the fixed point of the step, nothing to replay or write)
-            el_adam_replay<VW>(th[r], mm[r], vv[r], t - lastr, [&](int s2) { return hist[(lastr + 1 + s2) & hist_mask]; });
+            el_adam_catchup<VW, SER>(th[r], mm[r], vv[r], t - lastr, [&](int s2) { return hist[(lastr + 1 + s2) & hist_mask]; });
             if (live) {
                 const int64_t row = row0 + ls[r];
                 stv<VW>(tth + row * F + e, th[r]);
@@ -654,46 +643,37 @@ __device__ __forceinline__ void bpr_flush_rows64(float* __restrict__ tth, float*
     if (t - mylast > 0) last_arr[myrow] = t;
 }
 
-template <int VW>
-__global__ __launch_bounds__(256) void k_bpr_catchup(el_bprmf_state st, const u32* __restrict__ keys, int64_t B, int32_t t,
-                                                     float* __restrict__ hist, int hist_mask, float lr_t) {
-    const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p == 0 && lane == 0) hist[t & hist_mask] = lr_t;        // lr_t of THIS step into the ring (the replays below read steps < t)
-    if (p >= B) return;
-    const u32 key = keys[p];
-    if (p > 0 && keys[p - 1] == key) return;                   // not a segment head
-    const int64_t row = (int64_t)key;
-    const int last = st.Gu_last[row];
-    const int ns = (t - 1) - last;
-    if (ns <= 0) return;
-    bpr_replay_row<VW>(st.Gu, st.mGu, st.vGu, st.F, row, lane, last, ns, hist, hist_mask);
-    if (lane == 0) st.Gu_last[row] = t - 1;
-}
-
-// deferred decay: every user row up to step t (one WAVE per row, grid-stride; same row walk as k_bpr_catchup)
-template <int VW, int NR>
+// deferred decay: every user row up to step t (a wave per 64 consecutive rows, grid-stride)
+template <int VW, int NR, bool SER>
 __global__ __launch_bounds__(256) void k_bpr_flush_users(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < st.U; row0 += (int64_t)gridDim.x * 256)
-        bpr_flush_rows64<VW, NR>(st.Gu, st.mGu, st.vGu, st.Gu_last, st.F, st.U, row0, lane, t, hist, hist_mask);
+        bpr_flush_rows64<VW, NR, SER>(st.Gu, st.mGu, st.vGu, st.Gu_last, st.F, st.U, row0, lane, t, hist, hist_mask);
 }
 
 // ---- fused item side (el_bprmf_state.Gi_last): replay kernels of the item table --------------------------------------------------
 // The item rows are the user rows' case again (k_bpr_catchup / k_bpr_flush_users) plus one bias element per row.  A wave replays
 // a row's factors; the biases are replayed by their own small kernel, one LANE per row (64 rows' gaps per wave instead of one
 // whole wave walking a single element), launched BEFORE the row kernel, which is the one that advances Gi_last.
+template <bool SER>
 __device__ __forceinline__ void bpr_replay_bias(const el_bprmf_state& st, int64_t row, int last, int ns, const float* __restrict__ hist,
                                                 int hist_mask) {
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     float th = st.Bi[row], mm = st.mBi[row], vv = st.vBi[row];
     if (mm == 0.f && vv == 0.f) return;                         // fixed point of the gradient-free step
-    for (int s = 0; s < ns; ++s) el_adam_elem(th, mm, vv, 0.0f, hist[(last + 1 + s) & hist_mask], b1, b2, omb1, omb2, eps);
+    if (SER) {
+        float t1[1] = {th}, m1[1] = {mm}, v1[1] = {vv};
+        el_adam_series_apply<1>(t1, m1, v1, el_adam_series_sums(ns, [&](int s) { return hist[(last + 1 + s) & hist_mask]; }));
+        th = t1[0], mm = m1[0], vv = v1[0];
+    } else {
+        for (int s = 0; s < ns; ++s) el_adam_elem(th, mm, vv, 0.0f, hist[(last + 1 + s) & hist_mask], b1, b2, omb1, omb2, eps);
+    }
     st.Bi[row] = th, st.mBi[row] = mm, st.vBi[row] = vv;
 }
 
 // start of step t, deferred item decay: biases of the batch's distinct items to step t - 1 (one lane per sorted item position;
 // heads work)
+template <bool SER>
 __global__ __launch_bounds__(256) void k_bpr_catchup_ibias(el_bprmf_state st, const u32* __restrict__ keys, u32 key_off, int64_t n, int32_t t,
                                                            const float* __restrict__ hist, int hist_mask) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -703,10 +683,10 @@ __global__ __launch_bounds__(256) void k_bpr_catchup_ibias(el_bprmf_state st, co
     const int64_t row = (int64_t)(key - key_off);
     const int last = st.Gi_last[row];
     const int ns = (t - 1) - last;
-    if (ns > 0) bpr_replay_bias(st, row, last, ns, hist, hist_mask);
+    if (ns > 0) bpr_replay_bias<SER>(st, row, last, ns, hist, hist_mask);
 }
 
-template <int VW>
+template <int VW, bool SER>
 __global__ __launch_bounds__(256) void k_bpr_catchup_items(el_bprmf_state st, const u32* __restrict__ keys, u32 key_off, int64_t n, int32_t t,
                                                            const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
@@ -718,25 +698,26 @@ __global__ __launch_bounds__(256) void k_bpr_catchup_items(el_bprmf_state st, co
     const int last = st.Gi_last[row];
     const int ns = (t - 1) - last;
     if (ns <= 0) return;
-    bpr_replay_row<VW>(st.Gi, st.mGi, st.vGi, st.F, row, lane, last, ns, hist, hist_mask);
+    bpr_replay_row<VW, SER>(st.Gi, st.mGi, st.vGi, st.F, row, lane, last, ns, hist, hist_mask);
     if (lane == 0) st.Gi_last[row] = t - 1;
 }
 
 // every item row (bias: one lane per row; factors: one wave per row, grid-stride) up to step t (lr_t of step t is in the ring: the
 // fused item-segment kernel of that step put it there)
+template <bool SER>
 __global__ __launch_bounds__(256) void k_bpr_flush_ibias(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= st.I) return;
     const int last = st.Gi_last[row];
     const int ns = t - last;
-    if (ns > 0) bpr_replay_bias(st, row, last, ns, hist, hist_mask);
+    if (ns > 0) bpr_replay_bias<SER>(st, row, last, ns, hist, hist_mask);
 }
 
-template <int VW, int NR>
+template <int VW, int NR, bool SER>
 __global__ __launch_bounds__(256) void k_bpr_flush_items(el_bprmf_state st, int32_t t, const float* __restrict__ hist, int hist_mask) {
     const int lane = threadIdx.x & 63;
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < st.I; row0 += (int64_t)gridDim.x * 256)
-        bpr_flush_rows64<VW, NR>(st.Gi, st.mGi, st.vGi, st.Gi_last, st.F, st.I, row0, lane, t, hist, hist_mask);
+        bpr_flush_rows64<VW, NR, SER>(st.Gi, st.mGi, st.vGi, st.Gi_last, st.F, st.I, row0, lane, t, hist, hist_mask);
 }
 
 // ---- item segments -----------------------------------------------------------------------
@@ -989,7 +970,8 @@ __global__ __launch_bounds__(256) void k_bpr_item_split(el_bprmf_state st, ItemF
 // does not contain a whole segment ends with an atomic flush onto the same few cache lines, so long chunks matter for
 // the item side (16 -> 128 positions: 0.84 -> 0.35 ms at B = 1M) as long as enough groups remain to fill the chip.
 static int item_chunk_for(int64_t B, int64_t I) {
-    if (const char* e = getenv("EL_ICHUNK")) return atoi(e) < 16 ? 16 : atoi(e);     // (>= 16: the split list is sized for it)
+    if (g_el_cur_ctx && g_el_cur_ctx->opt.ichunk > 0)           // el_ctx_set_option("ichunk"): tests pin the summation order with it
+        return g_el_cur_ctx->opt.ichunk < 16 ? 16 : (int)g_el_cur_ctx->opt.ichunk;     // (>= 16: the split list is sized for it)
     int64_t c = (2 * B) / 8192;                          // (round 3, with the fused user side: 256 at B = 2^20 -- 1.275 -> 1.25 ms per step;
     c = c < 16 ? 16 : (c > 256 ? 256 : c);               //  128: 0.259, 256: 0.247, 384: 0.256, 512: 0.277 ms for the item segments at 100 K items)
     // Round 5: that optimum belongs to LONG segments (100 K items under 2^21 positions: 20 per item).  With a catalogue the batch
@@ -1003,7 +985,7 @@ static int item_chunk_for(int64_t B, int64_t I) {
     return (int)c;
 }
 static int user_chunk_for(int64_t B) {
-    if (const char* e = getenv("EL_UCHUNK")) return atoi(e);
+    if (g_el_cur_ctx && g_el_cur_ctx->opt.uchunk > 0) return (int)g_el_cur_ctx->opt.uchunk;
     int64_t c = B / 65536;
     return (int)(c < 4 ? 4 : (c > 16 ? 16 : c));
 }
@@ -1091,14 +1073,16 @@ int el_bprmf_apply_items_adam(el_ctx* ctx, hipStream_t s, const el_bprmf_state& 
 // user side of the step as ONE kernel (el_bprmf_state.Gu_next): rowptr, then segments + Adam over every user row
 static int launch_flush_users(const el_bprmf_state& st, hipStream_t s, int32_t t) {
     EL_REQUIRE(st.F % 4 == 0 && st.F <= 512, "el_bprmf_sync_users: F=%d outside the deferred decay's range", st.F);
-    int64_t grid = (st.U + 255) / 256;                       // a wave owns 64 consecutive rows
+    int64_t grid = (st.U + 255) / 256;                       // a wave owns 64 consecutive rows, two pending rows in flight per wave
     if (grid > (1 << 18)) grid = 1 << 18;
     const int mask = st.lr_hist_cap - 1;
-    static const int nr = [] { const char* e = getenv("EL_BPR_FLUSH_ROWS"); const int v = e ? atoi(e) : 0; return v == 4 ? 4 : 2; }();   // rows in flight per wave
-    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<4, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else if (st.F >= 128 && nr == 4) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<2, 4>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+#define EL_FU(VW_, SER_) EL_LAUNCH("k_bpr_flush_users", (k_bpr_flush_users<VW_, 2, SER_>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask)
+    if (st.replay_series) {
+        if (st.F >= 256) EL_FU(4, true); else if (st.F >= 128) EL_FU(2, true); else EL_FU(1, true);
+    } else {
+        if (st.F >= 256) EL_FU(4, false); else if (st.F >= 128) EL_FU(2, false); else EL_FU(1, false);
+    }
+#undef EL_FU
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -1216,14 +1200,18 @@ static int check_item_fuse(const el_bprmf_state& st) {
 
 static int launch_flush_items(const el_bprmf_state& st, hipStream_t s, int32_t t) {
     const int mask = st.lr_hist_cap - 1;
-    EL_LAUNCH("k_bpr_flush_ibias", k_bpr_flush_ibias, dim3((unsigned)((st.I + 255) / 256)), dim3(256), 0, s, st, t, st.lr_hist, mask);
     int64_t grid = (st.I + 255) / 256;                       // a wave owns 64 consecutive rows
     if (grid > (1 << 18)) grid = 1 << 18;
-    static const int nr = [] { const char* e = getenv("EL_BPR_FLUSH_ROWS"); const int v = e ? atoi(e) : 0; return v == 4 ? 4 : 2; }();   // rows in flight per wave
-    if (st.F >= 256) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<4, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else if (st.F >= 128 && nr == 4) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<2, 4>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else if (st.F >= 128) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
-    else EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask);
+    const dim3 gb((unsigned)((st.I + 255) / 256));
+#define EL_FI(VW_, SER_) EL_LAUNCH("k_bpr_flush_items", (k_bpr_flush_items<VW_, 2, SER_>), dim3((unsigned)grid), dim3(256), 0, s, st, t, st.lr_hist, mask)
+    if (st.replay_series) {
+        EL_LAUNCH("k_bpr_flush_ibias", k_bpr_flush_ibias<true>, gb, dim3(256), 0, s, st, t, st.lr_hist, mask);
+        if (st.F >= 256) EL_FI(4, true); else if (st.F >= 128) EL_FI(2, true); else EL_FI(1, true);
+    } else {
+        EL_LAUNCH("k_bpr_flush_ibias", k_bpr_flush_ibias<false>, gb, dim3(256), 0, s, st, t, st.lr_hist, mask);
+        if (st.F >= 256) EL_FI(4, false); else if (st.F >= 128) EL_FI(2, false); else EL_FI(1, false);
+    }
+#undef EL_FI
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -1233,11 +1221,16 @@ static int launch_catchup_items(const el_bprmf_state& st, hipStream_t s, const S
     const int mask = st.lr_hist_cap - 1;
     const int64_t n = 2 * B;
     const u32 off = (u32)st.U;
-    EL_LAUNCH("k_bpr_catchup_ibias", k_bpr_catchup_ibias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
-    const unsigned gc = (unsigned)((n + 3) / 4);
-    if (st.F >= 256) EL_LAUNCH("k_bpr_catchup_items", k_bpr_catchup_items<4>, dim3(gc), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
-    else if (st.F >= 128) EL_LAUNCH("k_bpr_catchup_items", k_bpr_catchup_items<2>, dim3(gc), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
-    else EL_LAUNCH("k_bpr_catchup_items", k_bpr_catchup_items<1>, dim3(gc), dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+    const dim3 gb((unsigned)((n + 255) / 256)), gc((unsigned)((n + 3) / 4));
+#define EL_CI(VW_, SER_) EL_LAUNCH("k_bpr_catchup_items", (k_bpr_catchup_items<VW_, SER_>), gc, dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask)
+    if (st.replay_series) {
+        EL_LAUNCH("k_bpr_catchup_ibias", k_bpr_catchup_ibias<true>, gb, dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+        if (st.F >= 256) EL_CI(4, true); else if (st.F >= 128) EL_CI(2, true); else EL_CI(1, true);
+    } else {
+        EL_LAUNCH("k_bpr_catchup_ibias", k_bpr_catchup_ibias<false>, gb, dim3(256), 0, s, st, w.keyI, off, n, t, st.lr_hist, mask);
+        if (st.F >= 256) EL_CI(4, false); else if (st.F >= 128) EL_CI(2, false); else EL_CI(1, false);
+    }
+#undef EL_CI
     return 0;
 }
 
@@ -1256,37 +1249,21 @@ static int launch_user_adam(const SegParams& pu, hipStream_t s, int64_t B, const
     f.Gu_new = pu.st.Gu_next;
     f.lr_t = lr_t, f.b1 = 0.9f, f.b2 = 0.999f, f.eps = 1e-7f;
     // (rowptr was filled behind the sort: sort_batch)
-    static const int rpg = [] { const char* e = getenv("EL_FUSED_RPG"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 8) ? v : 4; }();
+    const int rpg = 4;                                          // rows per lane group (2 and 8 measured slower: round 3)
     const int64_t groups = (pu.st.U + rpg - 1) / rpg;
     const unsigned grid = (unsigned)((groups * lpt + 255) / 256);
     const size_t lds = (size_t)(256 / lpt) * BPR_USTG * 6 * 4;
-#define EL_UA(CPL_, RPG_) EL_LAUNCH("k_bpr_user_adam", (k_bpr_user_adam<CPL_, RPG_>), dim3(grid), dim3(256), lds, s, pu, f)
-    if (cpl == 1) {
-        if (rpg == 2) EL_UA(1, 2); else if (rpg == 8) EL_UA(1, 8); else EL_UA(1, 4);
-    } else {
-        if (rpg == 2) EL_UA(2, 2); else EL_UA(2, 4);
-    }
-#undef EL_UA
+    if (cpl == 1) EL_LAUNCH("k_bpr_user_adam", (k_bpr_user_adam<1, 4>), dim3(grid), dim3(256), lds, s, pu, f);
+    else EL_LAUNCH("k_bpr_user_adam", (k_bpr_user_adam<2, 4>), dim3(grid), dim3(256), lds, s, pu, f);
     return 0;
 }
 
-// deferred decay: the batch's rows to step t - 1 (one wave per row), then the user segments with the Adam step on each row
-static int launch_user_catchup(const SegParams& pu, hipStream_t s, int64_t B, const SortedWs& w, float lr_t, FusedParams* f) {
+// deferred decay: parameters of the user-segment kernel that catches the batch's rows up and takes the Adam step on each of them
+static void defer_params(const SegParams& pu, const SortedWs& w, float lr_t, FusedParams* f) {
     memset(f, 0, sizeof(*f));
     f->lr_t = lr_t, f->b1 = 0.9f, f->b2 = 0.999f, f->eps = 1e-7f;
     f->last = pu.st.Gu_last, f->old_rows = pu.st.Gu_old, f->hpos = w.hpos;
     f->hist = pu.st.lr_hist, f->hist_mask = pu.st.lr_hist_cap - 1, f->t = pu.step;
-    // the batch's rows to step t - 1: inside the segment kernel (default; F % 4 == 0 is given here), or as a launch of its own
-    // (EL_BPR_USER_CATCHUP=separate: one wave per row, the rows read and written once more -- 0.77 ms of the 3.3 ms step at 10M x 1M)
-    static const bool separate = [] { const char* e = getenv("EL_BPR_USER_CATCHUP"); return e && strcmp(e, "separate") == 0; }();
-    f->replay = separate ? 0 : 1;
-    if (!separate) return 0;
-    const int F = pu.st.F;                                      // elements per lane so that the 64 lanes of a wave span a row
-    const unsigned gc = (unsigned)((B + 3) / 4);
-    if (F >= 256) EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<4>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
-    else if (F >= 128) EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<2>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
-    else EL_LAUNCH("k_bpr_catchup", k_bpr_catchup<1>, dim3(gc), dim3(256), 0, s, pu.st, w.keyU, B, pu.step, pu.st.lr_hist, f->hist_mask, lr_t);
-    return 0;
 }
 
 template <int VW>
@@ -1311,42 +1288,27 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     if (defer) pi.ubase = base.st.Gu_old, pi.uidx = w.hpos;      // the pre-update user rows, one per distinct user of the batch
     const int64_t gu = (B + pu.chunk - 1) / pu.chunk, gi = (2 * B + pi.chunk - 1) / pi.chunk;
     const unsigned gridU = (unsigned)((gu * lpt + 255) / 256), gridI = (unsigned)((gi * lpt + 255) / 256);
-    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * 7 * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
+    // (7 words per staged position where the heads' Gu_last stamps ride along: the PRE instantiations)
+    const size_t ldsU = (size_t)(256 / lpt) * BPR_USTG * ((defer && VW == 4 && cpl <= 2) ? 7 : 6) * 4, ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
     FusedParams fz;
     memset(&fz, 0, sizeof(fz));
-    // EL_BPR_USER_PRE: positions in flight per lane group with the heads' m / v prefetched (0 = the round-4 form: m, v fetched when the
-    // walk reaches the head)
-    static const int upre = [] { const char* e = getenv("EL_BPR_USER_PRE"); const int v = e ? atoi(e) : -1; return (v == 0 || v == 2 || v == 3 || v == 4 || v == 8) ? v : -1; }();
-    // (EL_BPR_USER_WAVE_ROWS=1: measured 1.35 against 1.24 ms for the two-groups-per-wave form at 10M x 1M x 128 -- the replay's lane
-    //  utilisation was not the bound, the loads in flight per wave are; kept as an experiment switch, off)
-    static const bool vw2 = [] { const char* e = getenv("EL_BPR_USER_WAVE_ROWS"); return e && atoi(e) == 1; }();
-    static const bool sep = [] { const char* e = getenv("EL_BPR_USER_CATCHUP"); return e && strcmp(e, "separate") == 0; }();
-    const bool wave_rows = defer && VW == 4 && vw2 && !sep && base.st.F > 64 && base.st.F <= 128;
+    const bool ser = base.st.replay_series != 0;
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
     if (ifuse) {
         fi.last = base.st.Gi_last, fi.split = w.split, fi.hist = base.st.lr_hist, fi.hist_mask = base.st.lr_hist_cap - 1;
         fi.lr_t = lr_t, fi.b1 = 0.9f, fi.b2 = 0.999f, fi.eps = 1e-7f, fi.t = base.step;
     }
+    // deferred user side: two positions in flight per lane group with the heads' m / v / stamp prefetched (rows of <= 512 B per lane
+    // pass: VW == 4, CPL <= 2; measured against 3, 4, 8 in flight and against a row per whole wave in round 5: profiles/r05_*)
 #define EL_SEG(CPL_)                                                                                      \
     do {                                                                                                  \
-        if (defer) {                                                                                      \
-            if (int rc = launch_user_catchup(pu, s, B, w, lr_t, &fz)) return rc;                          \
-            if (wave_rows) {                                                                              \
-                /* a row across the whole wave (64 lanes x 8 B at F = 128): the replay of a segment head then runs on all lanes -- with \
-                   two 32-lane groups per wave each group replays its own gap while the other idles */        \
-                SegParams pw = pu;                                                                        \
-                pw.lpt = 64, pw.pair4 = 1;                                                                \
-                const unsigned gridW = (unsigned)((gu * 64 + 255) / 256);                                 \
-                if (upre == 8) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4, 8>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
-                else if (upre == 4) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4, 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
-                else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<2, 1, VW == 4>), dim3(gridW), dim3(256), (size_t)4 * BPR_USTG * 7 * 4, s, pw, fz);  \
-            } else if (VW == 4 && CPL_ <= 2 && upre != 0) {                                               \
-                if (upre == 3 && CPL_ == 1) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 3>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
-                else if (upre != 4 || CPL_ == 2) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, 2>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
-                else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4, (CPL_ == 1 ? 4 : 2)>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
-            } else {                                                                                      \
-                EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, VW == 4>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
+        if (VW == 4 && defer) {                                                                           \
+            if constexpr (VW == 4) {                                                                      \
+                defer_params(pu, w, lr_t, &fz);                                                           \
+                constexpr int PRE_ = CPL_ <= 2 ? 2 : 0;                                                   \
+                if (ser) EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<4, CPL_, true, PRE_, true>), dim3(gridU), dim3(256), ldsU, s, pu, fz);   \
+                else EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<4, CPL_, true, PRE_, false>), dim3(gridU), dim3(256), ldsU, s, pu, fz);    \
             }                                                                                             \
         } else if (fused) {                                                                               \
             if (int rc = launch_user_adam(pu, s, B, w, lpt, cpl, lr_t)) return rc;                        \

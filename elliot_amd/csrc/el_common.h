@@ -14,7 +14,26 @@ struct el_timing_rec {
     hipEvent_t a, b;
 };
 
+// Switches of the library: ONE table (el_ctx.hip), read from the environment (EL_<NAME>) once, in el_ctx_create, and settable per
+// context with el_ctx_set_option -- nothing in the library calls getenv after that.  Every entry selects between forms that are
+// both product code (a test compares them, or bench.py reports one beside the other); measured-slower experiments do not live here.
+struct el_options {
+    double ichunk = 0;               // positions per lane group of the BPR item segments (0: by batch and catalogue size)
+    double uchunk = 0;               // ... of the user segments
+    double loop_graph = 1;           // el_bprmf_train_loop: small-batch epochs as one captured graph
+    double gemm_split = 1;           // dense products >= 2 GFLOP on the three-plane bf16 kernel (0: the fp32 matrix instruction)
+    double gemm_xcd = 1;             // XCD-aware tile order of that kernel
+    double nmf_side = 1;             // NeuMF: weight-gradient products on the library's second stream
+    double vae_side = 1;             // Mult-VAE: the same
+    double nmf_screen_maxfrac = 0.5; // NeuMF scoring: the screen is kept when it leaves the exact kernel at most this share of the pairs
+    double topk_variant = 0;         // fp32 MFMA top-k: alternative tile geometry for F in (64, 128]
+    double screen_stride = 0;        // screened top-k: catalogue stride of the first pass (0: by catalogue size)
+    double screen_ka = 0;            // ... and the list length it keeps
+    double screen_prof = 0;          // ... per-pass clock counters (profiling builds of the passes)
+};
+
 struct el_ctx {
+    el_options opt;
     int device;
     int cus;
     int64_t hbm_bytes;
@@ -443,6 +462,87 @@ __device__ __forceinline__ void el_adam_replay(float (&th)[VW], float (&mm)[VW],
                 }
             }
         }
+    }
+}
+
+// ---- the gradient-free Adam steps of a waiting row in closed form (el_bprmf_state.replay_series; round 6) ------------------------
+// n gradient-free steps from (theta_0, m_0, v_0) are m_n = b1^n m_0, v_n = b2^n v_0 and
+//     theta_n = theta_0 - m_0 sum_{k=1..n} lr_k b1^k / (r^k a_0 + eps),        a_0 = sqrt(v_0), r = sqrt(b2).
+// With den = a_0 + eps, u = a_0 / den in [0, 1) and z_k = 1 - r^k (small: ~k / 2000), r^k a_0 + eps = den (1 - u z_k), so
+//     1 / (r^k a_0 + eps) = (1 / den) (1 + u z_k + u^2 z_k^2 + u^3 z_k^3 + O(z_k^4))
+// and the sum splits into FOUR ROW-LEVEL scalars that do not depend on the element,
+//     T0 = sum lr_k b1^k,  Z1 = sum lr_k b1^k z_k,  Z2 = sum lr_k b1^k z_k^2,  Z3 = sum lr_k b1^k z_k^3        (all terms positive),
+// and an O(1) update per element: theta_n = theta_0 - (m_0 / den) (T0 + u (Z1 + u (Z2 + u Z3))).  The weights b1^k cut the sums off
+// (b1^k < 2^-149 past k = 980): a gap of any length costs at most 1024 scalar terms per ROW, and one square root + one reciprocal per
+// ELEMENT, against one IEEE square root and one IEEE division per element AND STEP of the step-by-step replay.  Valid for every
+// v_0 >= 0 (u = 0 gives Keras' m / eps exactly); m_0 = v_0 = 0 stays put.  This is NOT the same fp32 rounding sequence as Keras'
+// per-step update: against the exact-arithmetic recurrence it is as close as the fp32 step-by-step form is (relative 1.5e-6 of the
+// move, scripts/exp/series_check.py; tests/test_gpu_bpr.py::test_series_replay_*), which is what north_star's 1e-4 on the loss and
+// the oracle tolerances of the parity tests ask for -- the bit-for-bit mode stays available (replay_series = 0).
+struct el_series {
+    float T0, Z1, Z2, Z3, p1, p2;      // the four sums, b1^n, b2^n
+};
+#define EL_OM_SQRT_B2 5.0011865e-4f    // 1 - sqrt(0.999f), rounded from the double value (NOT 1 - EL_SQRT_B2: the slope of z_k counts)
+#define EL_SERIES_MAX 1024
+
+template <typename LR>
+__device__ __forceinline__ el_series el_adam_series_sums(int n, LR lrs) {
+    const float b1 = 0.9f, b2 = 0.999f;
+    el_series s;
+    s.T0 = s.Z1 = s.Z2 = s.Z3 = 0.f;
+    float p1 = 1.f, p2 = 1.f, z = 0.f;
+    const int c = n < EL_SERIES_MAX ? n : EL_SERIES_MAX;
+    for (int k0 = 0; k0 < c; k0 += 8) {
+        float lrv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lrv[k] = lrs(k0 + k < c ? k0 + k : k0);    // the chunk's step sizes in flight together
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k0 + k < c) {
+                p1 *= b1;
+                p2 *= b2;
+                z = __builtin_fmaf(z, EL_SQRT_B2, EL_OM_SQRT_B2);              // 1 - r^k = (1 - r^(k-1)) r + (1 - r)
+                const float w = lrv[k] * p1;
+                float wz = w * z;
+                s.T0 += w;
+                s.Z1 += wz;
+                wz *= z;
+                s.Z2 += wz;
+                wz *= z;
+                s.Z3 += wz;
+            }
+        }
+    }
+    if (n > EL_SERIES_MAX) {
+        p1 = 0.f;                                                              // 0.9^1024 < 2^-149
+        p2 = powf(b2, (float)n);
+    }
+    s.p1 = p1, s.p2 = p2;
+    return s;
+}
+
+template <int VW>
+__device__ __forceinline__ void el_adam_series_apply(float (&th)[VW], float (&mm)[VW], float (&vv)[VW], const el_series& s) {
+#pragma unroll
+    for (int x = 0; x < VW; ++x) {
+        const float a0 = __builtin_amdgcn_sqrtf(vv[x]);
+        const float inv = __builtin_amdgcn_rcpf(a0 + 1e-7f);
+        const float u = a0 * inv;
+        const float S = __builtin_fmaf(u, __builtin_fmaf(u, __builtin_fmaf(u, s.Z3, s.Z2), s.Z1), s.T0);
+        th[x] = th[x] - (mm[x] * inv) * S;
+        mm[x] = mm[x] * s.p1;
+        vv[x] = vv[x] * s.p2;
+    }
+}
+
+// a waiting row brought forward ns steps: step by step (the same bits as Keras' every-row pass) or in closed form
+template <int VW, bool SER, typename LR>
+__device__ __forceinline__ void el_adam_catchup(float (&th)[VW], float (&mm)[VW], float (&vv)[VW], int ns, LR lrs) {
+    if (SER) {
+        const el_series s = el_adam_series_sums(ns, lrs);
+        el_adam_series_apply<VW>(th, mm, vv, s);
+    } else {
+        el_adam_replay<VW>(th, mm, vv, ns, lrs);
     }
 }
 

@@ -1,5 +1,6 @@
 // Context + error plumbing of the C ABI (include/elliot_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include "el_common.h"
 
 static thread_local char g_el_err[1024] = "";
@@ -15,6 +16,52 @@ void el_set_error(const char* fmt, ...) {
 extern "C" const char* el_last_error(void) { return g_el_err; }
 
 extern "C" int el_abi_version(void) { return EL_ABI_VERSION; }
+
+// ---- options ----------------------------------------------------------------------------------------------------------------
+struct el_opt_entry {
+    const char* name;
+    double el_options::*field;
+};
+static const el_opt_entry g_el_opts[] = {
+    {"ichunk", &el_options::ichunk}, {"uchunk", &el_options::uchunk}, {"loop_graph", &el_options::loop_graph},
+    {"gemm_split", &el_options::gemm_split}, {"gemm_xcd", &el_options::gemm_xcd}, {"nmf_side", &el_options::nmf_side},
+    {"vae_side", &el_options::vae_side}, {"nmf_screen_maxfrac", &el_options::nmf_screen_maxfrac},
+    {"topk_variant", &el_options::topk_variant}, {"screen_stride", &el_options::screen_stride}, {"screen_ka", &el_options::screen_ka},
+    {"screen_prof", &el_options::screen_prof},
+};
+
+// EL_<NAME> in the environment gives an option its initial value (the one place the library reads the environment)
+static void el_options_from_env(el_options* o) {
+    for (const auto& e : g_el_opts) {
+        char env[64] = "EL_";
+        size_t k = 3;
+        for (const char* c = e.name; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+        env[k] = 0;
+        if (const char* v = getenv(env)) o->*(e.field) = atof(v);
+    }
+}
+
+extern "C" int el_ctx_set_option(el_ctx* ctx, const char* name, double value) {
+    EL_REQUIRE(ctx != nullptr && name != nullptr, "el_ctx_set_option: null argument");
+    for (const auto& e : g_el_opts)
+        if (strcmp(e.name, name) == 0) {
+            ctx->opt.*(e.field) = value;
+            return 0;
+        }
+    el_set_error("el_ctx_set_option: unknown option '%s'", name);
+    return 2;
+}
+
+extern "C" int el_ctx_get_option(el_ctx* ctx, const char* name, double* value) {
+    EL_REQUIRE(ctx != nullptr && name != nullptr && value != nullptr, "el_ctx_get_option: null argument");
+    for (const auto& e : g_el_opts)
+        if (strcmp(e.name, name) == 0) {
+            *value = ctx->opt.*(e.field);
+            return 0;
+        }
+    el_set_error("el_ctx_get_option: unknown option '%s'", name);
+    return 2;
+}
 
 extern "C" int el_ctx_create(int device, el_ctx** out) {
     EL_REQUIRE(out != nullptr, "el_ctx_create: out is NULL");
@@ -34,6 +81,7 @@ extern "C" int el_ctx_create(int device, el_ctx** out) {
     strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
     c->arch[sizeof(c->arch) - 1] = 0;
     c->timing = false;
+    el_options_from_env(&c->opt);
     EL_CHECK_HIP(hipSetDevice(device));
     if (hipMalloc((void**)&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) {
         el_set_error("el_ctx_create: cannot allocate the context's scratch on device %d", device);

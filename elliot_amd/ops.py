@@ -55,6 +55,30 @@ class Context:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_option(self, name, value):
+        """A switch of the library on this context (include/elliot_hip.h: el_ctx_set_option); returns the previous value."""
+        old = self.get_option(name)
+        check(self.lib.el_ctx_set_option(self.handle, name.encode(), float(value)), "el_ctx_set_option")
+        return old
+
+    def get_option(self, name):
+        v = C.c_double()
+        check(self.lib.el_ctx_get_option(self.handle, name.encode(), C.byref(v)), "el_ctx_get_option")
+        return v.value
+
+    def option(self, name, value):
+        """with ctx.option("ichunk", 64): ... -- the switch set inside the block, its previous value restored afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = self.set_option(name, value)
+            try:
+                yield
+            finally:
+                self.set_option(name, old)
+        return scope()
+
     def timing(self, on, only=None):
         """Bracket kernel launches with hipEvents; `only` = a kernel name: just those launches (an event between two kernels
         costs their overlap, so timed regions keep them on the kernel of interest)."""
@@ -495,7 +519,7 @@ class BprmfDeviceState:
     _LR_HIST = 1 << 16          # lr_t ring of the deferred decay (a power of two)
 
     def __init__(self, ctx, Gu, Gi, Bi, optimizer="adam", compact_user_grads=None, fused_user_step=None, deferred=None,
-                 fused_item_step=None, item_deferred=None):
+                 fused_item_step=None, item_deferred=None, replay="exact"):
         """compact_user_grads: user-row gradients as compact rows + per-user stamps (el_bprmf_state.uslot) instead of a dense
         [U,F] accumulator -- the dense Adam pass then reads a gradient only for the batch's users and re-zeroes nothing.
         None = automatic (TF-dense Adam on a user table of >= 64 MB with F % 4 == 0), True / False force it.
@@ -510,8 +534,14 @@ class BprmfDeviceState:
         item_deferred: with the fused item side, the item rows a batch leaves alone wait for their gradient-free Adam updates like the
         user rows do (replayed bit for bit when a batch next contains the item, or on sync() / reading `.Gi` / `.Bi`); False = they
         are replayed at the end of every step.  None = decided by the first batch size: on when 2 B <= I (EL_BPR_ITEM_DEFERRED=0 / 1
-        force it)."""
+        force it).
+        replay: how a waiting row is brought forward over its gradient-free steps -- "exact": step by step, the bits of Keras'
+        every-row pass; "series": in closed form from four row-level sums over the lr_t history (el_bprmf_state.replay_series:
+        O(1) per element whatever the gap; as close to the exact-arithmetic recurrence as the fp32 step-by-step form, not its bits)."""
         self.ctx = ctx
+        if replay not in ("exact", "series"):
+            raise ValueError("replay must be 'exact' or 'series'")
+        self.replay = replay
         self.opt = OPTIMIZERS[optimizer] if isinstance(optimizer, str) else int(optimizer)
         dev = ctx.device
         big = int(Gu.shape[0]) * int(Gu.shape[1]) * 4 >= (64 << 20)
@@ -610,7 +640,7 @@ class BprmfDeviceState:
             mBi=self.mBi.data_ptr() if adam else None, vBi=self.vBi.data_ptr() if adam else None,
             tGu=self.tGu.data_ptr() if rows else None, tGi=self.tGi.data_ptr() if rows else None,
             tBi=self.tBi.data_ptr() if rows else None, U=self.U, I=self.I, F=self.F,
-            Gu_next=self.Gu_next.data_ptr() if self.Gu_next is not None else None)
+            Gu_next=self.Gu_next.data_ptr() if self.Gu_next is not None else None, replay_series=int(replay == "series"))
         self.Gu_last = self.Gu_old = self.lr_hist = None
         self.Gi_last = None
         if self.deferred:

@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 6   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
+#define EL_ABI_VERSION 7   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
                             * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*
                             * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
@@ -45,7 +45,9 @@ typedef struct el_ctx el_ctx;
                             * 5: el_bprmf_state ends in Gi_last / Gi_defer (item side of the step fused with its
                             *    Adam pass), el_bprmf_sync_items
                             * 6: el_topk_screen_stats (diagnostics of the screened top-k; no struct changes: a host built
-                            *    against 5 runs unchanged)                                                               */
+                            *    against 5 runs unchanged)
+                            * 7: el_bprmf_state ends in replay_series; el_ctx_set_option / el_ctx_get_option (the library no
+                            *    longer reads the environment after el_ctx_create)                                       */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -71,6 +73,13 @@ int el_timing_filter(el_ctx* ctx, const char* kernel_name);
  * pass on scratch tables) carry their own kernel symbols (k_adam_*<..., true>), so that a rocprofv3 kernel trace of a run
  * lists the product launches and the tuner's probes separately. */
 int el_tuning_mode(el_ctx* ctx, int on);
+/* Switches of the library (ABI 7).  Each has a name ("ichunk", "uchunk", "loop_graph", "gemm_split", "gemm_xcd", "nmf_side",
+ * "vae_side", "nmf_screen_maxfrac", "topk_variant", "screen_stride", "screen_ka", "screen_prof"); el_ctx_create takes its initial
+ * value from the environment variable EL_<NAME IN CAPITALS> when that is set, and that is the only time the library reads the
+ * environment: afterwards a switch moves through el_ctx_set_option alone (per context: two contexts of one process may differ).
+ * Unknown names fail.  The reference has no counterpart (its switches are YAML fields read by the Python layer).              */
+int el_ctx_set_option(el_ctx* ctx, const char* name, double value);
+int el_ctx_get_option(el_ctx* ctx, const char* name, double* value);
 
 /* ---- BPR triplet sampler (K1) ------------------------------------------------ */
 
@@ -195,6 +204,15 @@ typedef struct el_bprmf_state {
      * (segments inside one chunk).  gGi / gBi stay required and are zero on entry and exit; F % 4 == 0, 16-byte aligned tables.
      *   Gi_last  int32[I], zero-initialised: the optimiser step each item row (factors + bias) is current at                 */
     int32_t* Gi_last; int32_t Gi_defer;
+    /* How a waiting row (Gu_last / Gi_last) is brought forward over its n gradient-free steps:
+     *   0  step by step: the same fp32 operations in the same order as Keras' every-row pass, hence the same bits (one IEEE square
+     *      root and one IEEE division per element AND step -- at 10 M users the replay arithmetic, not HBM, bounds the user side);
+     *   1  in closed form: m_n = b1^n m, v_n = b2^n v, theta_n = theta - m / (sqrt(v) + eps) * S(row), with S built from four
+     *      row-level sums over the lr_t history (elliot_amd/csrc/el_common.h: el_adam_series_sums) -- O(1) per element whatever the
+     *      gap.  NOT bit-identical to the step-by-step rounding sequence; as close to the exact-arithmetic recurrence as that sequence
+     *      is (relative 1.5e-6 of a row's move), inside north_star's 1e-4 on the loss and the oracle tolerances of the parity tests
+     *      (tests/test_gpu_fullsize_c4.py runs both modes).  A state keeps one mode from its first step to its last.            */
+    int32_t replay_series;
 } el_bprmf_state;
 
 /* How the duplicate-row gradient sum (OptimizerV2's segment-sum of IndexedSlices) is formed. */

@@ -34,3 +34,15 @@ def ctx():
 @pytest.fixture(scope="session")
 def dev(ctx):
     return ctx.device
+
+
+@pytest.fixture
+def lib_option(ctx):
+    """lib_option(name, value): a switch of the library (el_ctx_set_option) for the duration of one test."""
+    saved = []
+
+    def set_(name, value):
+        saved.append((name, ctx.set_option(name, value)))
+    yield set_
+    for name, old in reversed(saved):
+        ctx.set_option(name, old)

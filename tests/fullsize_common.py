@@ -14,7 +14,10 @@ Checks (the caller asserts on the returned record too):
   (ii)  theta of the sampled rows of A (and R) against the oracle recurrence: <= 2e-4 of the entries beyond 2e-5, none beyond 3 lr;
         R's pre-optimiser gradient rows against the oracle's on the first steps;
   (iii) A == R on theta, m, v of the sampled rows -- bit for bit when the library sums cut item segments in a fixed order
-        (ops.deterministic_item_sums(ctx)), to fp32 re-association accuracy otherwise -- and over the WHOLE tables to that accuracy.
+        (ops.deterministic_item_sums(ctx)) and A replays step by step, to fp32 re-association accuracy otherwise -- and over the
+        WHOLE tables to that accuracy.
+replay="series": A brings its waiting rows forward in closed form (el_bprmf_state.replay_series; what bench.py's headline runs):
+(i), (ii) at the same tolerances, (iii) to re-association accuracy.
 """
 import numpy as np
 import torch
@@ -78,12 +81,12 @@ def _user_grad_rows(st, su, step):
 
 
 def bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, steps, lr, l_w, l_b, n_rows=1024, n_hot=3, seed=42,
-                           grad_check_steps=2):
+                           grad_check_steps=2, replay="exact"):
     from oracle import bprmf_batch as ob
     dev = ctx.device
     U, F = int(Gu.shape[0]), int(Gu.shape[1])
     I = int(Gi.shape[0])
-    A = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense")
+    A = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", replay=replay)
     R = ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", deferred=False, fused_user_step=False, fused_item_step=False)
     assert A.compact and A.fused and A.item_fused, "bench.py's state at this size: compact rows, fused user side, fused item side"
     assert R.compact and not R.fused and not R.item_fused and not R.deferred
@@ -182,7 +185,7 @@ def bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, steps, lr, 
             rec["oracle_err"][tag + "." + name] = (mx, frac)
             assert frac <= 2e-4 and mx < 3 * lr, (tag, name, mx, frac)
     # (iii) bench path == every-row two-pass form
-    exact = ops.deterministic_item_sums(ctx)
+    exact = ops.deterministic_item_sums(ctx) and replay == "exact"
     rec["exact"] = exact
     rec["vs_two_pass"] = {}
     for name, rows in (("Gu", su), ("mGu", su), ("vGu", su), ("Gi", si), ("mGi", si), ("vGi", si), ("Bi", si), ("mBi", si), ("vBi", si)):

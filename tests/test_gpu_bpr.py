@@ -553,16 +553,16 @@ def test_fused_user_side_equals_the_two_kernel_form_bit_for_bit(ctx, F, U):
 
 
 @pytest.mark.parametrize("F,U,hist", [(128, 5003, None), (64, 1024, 8), (256, 2001, 4)])
-def test_deferred_decay_of_the_user_table_equals_the_every_row_pass_bit_for_bit(ctx, F, U, hist, monkeypatch):
+def test_deferred_decay_of_the_user_table_equals_the_every_row_pass_bit_for_bit(ctx, F, U, hist, monkeypatch, lib_option):
     """el_bprmf_state.Gu_last: a step moves only the user rows of its batch, the gradient-free Adam steps of every other row are
     replayed when a batch next contains the user or when the table is read.  Against the every-row fused form on the same batches:
     theta, m, v of the user table BIT-identical at every read -- after stretches of steps that leave most users untouched (batches
     drawn for a tenth of the users), after a read in the middle, through train_step, train_step_presorted and train_loop, with a
     4- / 8-step lr ring whose half-way flushes kick in, and across a grads() + apply() pair (the every-row pass on a deferred
-    state).  The item side is the same code in both; EL_ICHUNK makes its summation order fixed (one lane group walks the whole
+    state).  The item side is the same code in both; the `ichunk` option makes its summation order fixed (one lane group walks the whole
     sorted batch: no chunk-crossing atomics), so both runs see identical inputs at every step."""
     from elliot_amd.synthetic import zipf_csr
-    monkeypatch.setenv("EL_ICHUNK", str(1 << 20))
+    lib_option("ichunk", 1 << 20)
     if hist:
         monkeypatch.setattr(ops.BprmfDeviceState, "_LR_HIST", hist)
     rs = np.random.RandomState(F + U)
@@ -621,16 +621,16 @@ def test_deferred_decay_of_the_user_table_equals_the_every_row_pass_bit_for_bit(
 
 @pytest.mark.parametrize("F,I,defer,hist", [(128, 3001, False, None), (64, 700, True, 8), (256, 5000, True, None), (16, 901, True, 4),
                                             (128, 2000, None, None)])
-def test_fused_item_side_equals_the_two_pass_form_bit_for_bit(ctx, F, I, defer, hist, monkeypatch):
+def test_fused_item_side_equals_the_two_pass_form_bit_for_bit(ctx, F, I, defer, hist, monkeypatch, lib_option):
     """el_bprmf_state.Gi_last: the item segments take Keras' Adam step on their rows in place (no dense gradient table written,
     re-read and cleared); the rows a batch leaves alone are replayed at the end of every step (item_deferred=False) or when a batch
     next contains the item / the table is read (item_deferred=True).  Against the two-pass form (k_bpr_item_seg -> gGi ->
     k_adam_dense_pair) on the same batches: Gi, Bi and their Adam slots BIT-identical at every read, the user table too (it reads
     the item rows) -- through train_step, train_step_presorted, train_loop, a grads() + apply() pair in the middle, stretches of
     batches whose positives AND negatives stay inside an eighth of the catalogue (rows wait up to 9 steps), a 4- / 8-entry lr ring
-    whose half-way flushes kick in.  EL_ICHUNK pins the summation order of both forms (one lane group walks the whole sorted batch);
+    whose half-way flushes kick in.  the `ichunk` option pins the summation order of both forms (one lane group walks the whole sorted batch);
     segments cut by chunk boundaries are exercised by the next test.  defer=None: the state decides by the batch size (2 B <= I)."""
-    monkeypatch.setenv("EL_ICHUNK", str(1 << 20))
+    lib_option("ichunk", 1 << 20)
     if hist:
         monkeypatch.setattr(ops.BprmfDeviceState, "_LR_HIST", hist)
     rs = np.random.RandomState(F + I)
@@ -696,12 +696,12 @@ def test_fused_item_side_equals_the_two_pass_form_bit_for_bit(ctx, F, I, defer, 
 
 @pytest.mark.parametrize("chunk", [16, 64])
 @pytest.mark.parametrize("defer", [False, True])
-def test_fused_item_side_with_segments_cut_by_chunk_boundaries(ctx, chunk, defer, monkeypatch):
+def test_fused_item_side_with_segments_cut_by_chunk_boundaries(ctx, chunk, defer, lib_option):
     """Zipf catalogue, small chunks: the popular items' segments span many lane groups, whose partial rows meet in gGi / gBi through
     atomics; the rows go on the step's split list and a second launch takes the Adam step from the accumulated gradient and clears it.  The order of those atomic
     additions is the hardware's in both forms, so the comparison with the two-pass form is to fp32 re-association accuracy -- and
     exact on every row whose segment lies inside one chunk; the accumulators come back zero, every row is stamped."""
-    monkeypatch.setenv("EL_ICHUNK", str(chunk))
+    lib_option("ichunk", chunk)
     F, U, I, B = 128, 3000, 1200, 8192
     rs = np.random.RandomState(chunk)
     indptr, indices = zipf_csr(U, I, mean_log=2.5, sigma_log=0.9, dmin=1, dmax=200, seed=5)
@@ -725,6 +725,64 @@ def test_fused_item_side_with_segments_cut_by_chunk_boundaries(ctx, chunk, defer
         assert (np.abs(x - y) > 2e-6).mean() < 2e-3 and np.abs(x - y).max() < 12 * lr, (name, np.abs(x - y).max())
     la, lb = a.pop_loss(), b.pop_loss()
     assert abs(la - lb) <= 1e-5 * abs(la)
+
+
+@pytest.mark.parametrize("F,U,I,item_defer", [(128, 5003, 700, False), (64, 1500, 4000, True), (256, 2001, 3000, True)])
+def test_series_replay_matches_the_step_by_step_replay(ctx, F, U, I, item_defer, lib_option):
+    """el_bprmf_state.replay_series: a waiting row brought forward in closed form (four row-level sums over the lr_t history, O(1) per
+    element) against the step-by-step replay (the bits of Keras' every-row pass) on the same batches -- stretches of batches that leave
+    nine users in ten (and seven items in eight) waiting, gaps of 1 .. 13 steps, a sync in the middle, the lr ring's half-way flush.
+    Not the same rounding sequence: theta within 1e-6 of the row's scale on all but isolated elements, m and v to 1e-5 relative, the
+    loss of every step to 1e-6 -- the distance the fp32 step-by-step form itself keeps from the exact-arithmetic recurrence
+    (scripts/exp/series_check.py)."""
+    from elliot_amd.synthetic import zipf_csr
+    lib_option("ichunk", 1 << 20)                               # one summation order on the item side: the two runs see the same gradients
+    rs = np.random.RandomState(F + U)
+    B = 4096
+    indptr, indices = zipf_csr(U, I, mean_log=2.0, sigma_log=0.9, dmin=1, dmax=150, seed=F)
+    pos = ops.DeviceCSR(indptr, indices, I, ctx.device)
+    cutI = max(I // 8, 8)
+    cutU = U // 10
+    keep = (indices < cutI) & (np.repeat(np.arange(U), np.diff(indptr)) < cutU)
+    ip2 = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(U), np.diff(indptr))[keep], minlength=U))]).astype(np.int64)
+    few = ops.DeviceCSR(ip2, indices[keep].astype(np.int32), I, ctx.device)
+    Gu, Gi, Bi = _setup(rs, U, I, F)
+    lr, l_w, l_b = 0.01, 0.1, 0.001
+    mk = lambda mode: ops.BprmfDeviceState(ctx, Gu, Gi, Bi, optimizer="adam_tf_dense", compact_user_grads=True, deferred=True,
+                                           fused_item_step=True, item_deferred=item_defer, replay=mode)
+    a, b = mk("exact"), mk("series")
+    assert a.deferred and b.deferred and b._c.replay_series == 1 and a._c.replay_series == 0
+
+    def close(tag):
+        a.sync(), b.sync()
+        for name in ("Gu", "Gi", "Bi"):
+            x, y = getattr(a, name), getattr(b, name)
+            err = (x - y).abs()
+            assert float((err > 1e-6 * (1 + x.abs())).float().mean()) < 1e-4 and float(err.max()) < 5 * lr, (tag, name, float(err.max()))
+        for name in ("mGu", "vGu", "mGi", "vGi", "mBi", "vBi"):
+            x, y = getattr(a, name), getattr(b, name)
+            rel = (x - y).abs() / (x.abs() + float(x.abs().mean()) + 1e-30)     # (an element near zero is a cancelled sum: table scale)
+            assert float((rel > 1e-5).float().mean()) < 1e-4, (tag, name, float(rel.max()))
+
+    for s in range(30):
+        src = pos if s in (0, 14, 29) else few
+        t = ops.bpr_sample(ctx, src, B, seed=7, first_sample=s * B, item_lo=0, item_hi=I if src is pos else cutI)
+        for st in (a, b):
+            if s % 3 == 1:
+                ws = st.sort_workspace(B)
+                st.presort(t[0], t[1], t[2], ws)
+                st.train_step_presorted(t[0], t[1], t[2], lr, l_w, l_b, ws)
+            else:
+                st.train_step(t[0], t[1], t[2], lr, l_w, l_b)
+        la, lb = a.pop_loss(), b.pop_loss()
+        assert abs(la - lb) <= 1e-6 * abs(la), (s, la, lb)
+        if s in (0, 9, 14):
+            close(s)
+    close("end")
+    # 40 more steps inside the library's epoch loop: nine rows in ten wait for all of them
+    for st in (a, b):
+        st.train_loop(few, 40 * B, B, 11, 0, lr, l_w, l_b)
+    close("loop")
 
 
 def test_packed_replay_arithmetic_is_exact(ctx):

@@ -5,7 +5,8 @@ headline leg) -- through the path the bench runs, with an answer checked at ever
             ~10-step replay gaps in steady state, fused item side, row offsets past 2^31 elements, 2^20-triplet segments cut by chunk
             boundaries, the 64-row flush walk over 10 M rows), sync(); against an fp64 evaluation of every batch loss, against
             oracle/bprmf_batch.py's every-row Keras Adam on 1 024 user rows + 1 024 item rows + the 3 hottest items, and against the
-            every-row two-pass form (grads() + apply()) of the same library on the sampled rows and over the whole tables
+            every-row two-pass form (grads() + apply()) of the same library on the sampled rows and over the whole tables --
+            in both replay modes of the waiting rows: "series" (closed form; what bench.py's `value` runs) and "exact" (step by step)
   top-k     on the TRAINED tables: screened (algo="auto") == fp32 MFMA kernel on index lists and score bits for a 16 384-user block,
             == the C oracle's fma chain on a sample of users
 
@@ -29,8 +30,8 @@ STEPS = 24
 LR, L_W, L_B = 0.001, 0.1, 0.001                                    # BPRMF_batch.py:66-71 defaults (what bench.py trains with)
 
 
-@pytest.fixture(scope="module")
-def c4(ctx):
+@pytest.fixture(scope="module", params=["series", "exact"])
+def c4(ctx, request):
     dev = ctx.device
     free, _ = torch.cuda.mem_get_info()
     if free < (80 << 30):
@@ -44,7 +45,7 @@ def c4(ctx):
     Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * lim_u
     Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * lim_i
     Bi = torch.zeros(I, device=dev)
-    rec = bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, STEPS, LR, L_W, L_B)
+    rec = bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, STEPS, LR, L_W, L_B, replay=request.param)
     del Gu, Gi, Bi
     torch.cuda.empty_cache()
     rec["pos"] = pos

@@ -30,8 +30,8 @@ STEPS = 12
 LR, L_W, L_B = 0.001, 0.1, 0.001
 
 
-@pytest.fixture(scope="module")
-def c5(ctx):
+@pytest.fixture(scope="module", params=["series", "exact"])
+def c5(ctx, request):
     dev = ctx.device
     # ~33 interactions per user (2e8 in all): the CSR is the exclusion mask of the top-k and the sampler's positives
     indptr, indices = zipf_csr_device(U, I, dev, mean_log=3.0, sigma_log=1.0, dmin=5, dmax=2000, seed=2345)
@@ -43,7 +43,7 @@ def c5(ctx):
     Bi = (torch.rand(I, generator=g, device=dev) - 0.5) * 0.02
     # the path bench.py's c5_per_gpu leg runs (cover batches, pipelined presorted steps, deferred user AND item rows), checked against
     # the fp64 loss, the oracle's every-row Adam on sampled rows and the every-row two-pass form: tests/fullsize_common.py
-    rec = bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, STEPS, LR, L_W, L_B)
+    rec = bench_path_vs_two_pass(ctx, pos, indptr, indices, Gu, Gi, Bi, B, STEPS, LR, L_W, L_B, replay=request.param)
     del Gu, Gi, Bi
     torch.cuda.empty_cache()
     rec["pos"], rec["st"] = pos, rec["A"]
