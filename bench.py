@@ -53,7 +53,7 @@ MFMA_B3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 
 def gemm_roofline(rep, flops, steps):
     """Roofline entry of the dense-layer GEMM launches of one step: the three-way-split kernel where it ran (its flop count is the fp32
-    product's, its peak the bf16 instruction's / 6), the fp32 matrix instruction otherwise (EL_GEMM_SPLIT=0, small shapes)."""
+    product's, its peak the bf16 instruction's / 6), the fp32 matrix instruction otherwise (option gemm_split = 0, small shapes)."""
     gms = sum(v[1] for n, v in rep.items() if n.startswith("k_gemm")) / steps
     b3 = sum(v[1] for n, v in rep.items() if n == "k_gemm_b3") / steps
     ach = flops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
@@ -966,15 +966,8 @@ def vae_leg(args, ctx):
         # the per-kernel breakdown: the same kernels back to back on one stream (the step proper runs the weight-gradient products, the
         # column sums and the index of the sparse first-layer gradient on the library's second stream: elapsed times of kernels that
         # overlap mean nothing)
-        prev = os.environ.get("EL_VAE_SIDE")
-        os.environ["EL_VAE_SIDE"] = "0"
-        try:
+        with ctx.option("vae_side", 0):
             step()
-        finally:
-            if prev is None:
-                os.environ.pop("EL_VAE_SIDE", None)
-            else:
-                os.environ["EL_VAE_SIDE"] = prev
 
     dt, rep = timed(ctx, 1, step, W, K, events_in_timed_region=False, fn_breakdown=step_one_stream)
     loss = st.pop_loss()
@@ -1032,15 +1025,8 @@ def neumf_leg(args, ctx):
     def step_one_stream():
         # the per-kernel breakdown: the same kernels on one stream (the step proper runs the tower's weight-gradient products on the library's
         # second stream beside the embedding kernels: elapsed times of overlapping kernels mean nothing)
-        prev = os.environ.get("EL_NMF_SIDE")
-        os.environ["EL_NMF_SIDE"] = "0"
-        try:
+        with ctx.option("nmf_side", 0):
             step()
-        finally:
-            if prev is None:
-                os.environ.pop("EL_NMF_SIDE", None)
-            else:
-                os.environ["EL_NMF_SIDE"] = prev
 
     dt, rep = timed(ctx, 1, step, W, K, finish=st.sync, events_in_timed_region=False, fn_breakdown=step_one_stream)
     loss = st.pop_loss()

@@ -649,11 +649,7 @@ static int launch_rows_apply(const el_bprmf_state& st, const int32_t* u, const i
 
 static unsigned stream_grid(el_ctx* ctx, int64_t n_threads) {
     int64_t blocks = (n_threads + 255) / 256;
-    static const int mult = [] {
-        const char* e = getenv("EL_STREAM_GRID_MULT");      // workgroups per CU of the streaming passes (experiments)
-        const int v = e ? atoi(e) : 0;
-        return (v >= 1 && v <= 64) ? v : 8;
-    }();
+    const int mult = 8;                                     // workgroups per CU of the streaming passes
     int64_t cap = (int64_t)ctx->cus * mult;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -1094,7 +1090,7 @@ extern "C" int el_bprmf_train_loop(el_ctx* ctx, void* stream, const el_bprmf_sta
 
     // graph form: small batch (the atomic gradient kernel is what AUTO picks below 2048), TF-dense Adam on a model small
     // enough for the fused three-tensor pass, no per-kernel timing requested
-    static const bool graphs_on = [] { const char* e = getenv("EL_LOOP_GRAPH"); return !(e && atoi(e) == 0); }();
+    const bool graphs_on = ctx->opt.loop_graph != 0;
     const el_bprmf_state& st = *stp;
     bool use_graph = graphs_on && !ctx->timing && opt == EL_OPT_ADAM_TF_DENSE && steps >= 4 && !stp->uslot &&
                      (algo == EL_BPR_ATOMIC || (algo == EL_BPR_AUTO && B < 2048));

@@ -117,8 +117,11 @@ struct FusedParams {
 // any row arrives) -- at 10 M users nearly every position of a 1 M-triplet batch starts a segment, and fetching m, v only once the
 // walk reaches the head put a second full memory latency behind every position's gathers (5 L + 4 R per four positions instead of
 // L + 4 R, at three waves per SIMD).
+#ifndef EL_USEG_WAVES
+#define EL_USEG_WAVES 4          // (A/B builds: scripts/exp/build_variants.sh)
+#endif
 template <int VW, int CPL, bool DEFER, int SUBD = 0, bool SER = false>
-__global__ __launch_bounds__(256) void k_bpr_user_seg(SegParams p, FusedParams f) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SER && CPL == 1) ? EL_USEG_WAVES : 1, 8))) void k_bpr_user_seg(SegParams p, FusedParams f) {
     const int F = p.st.F, lpt = p.lpt;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = gid / lpt;

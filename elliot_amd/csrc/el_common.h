@@ -26,7 +26,6 @@ struct el_options {
     double nmf_side = 1;             // NeuMF: weight-gradient products on the library's second stream
     double vae_side = 1;             // Mult-VAE: the same
     double nmf_screen_maxfrac = 0.5; // NeuMF scoring: the screen is kept when it leaves the exact kernel at most this share of the pairs
-    double topk_variant = 0;         // fp32 MFMA top-k: alternative tile geometry for F in (64, 128]
     double screen_stride = 0;        // screened top-k: catalogue stride of the first pass (0: by catalogue size)
     double screen_ka = 0;            // ... and the list length it keeps
     double screen_prof = 0;          // ... per-pass clock counters (profiling builds of the passes)

@@ -62,7 +62,6 @@ struct GemmParams {
     int64_t ldy;
     float* colsum;
     int gx, gy, gz;       // tiles along N, M, K-splits
-    int nlin;             // k_gemm_b3p: linear tile ids 0 .. nlin - 1 (the one-tile kernel's grid size)
     int grp_mode;         // 0: 3-D grid as launched; 1: group = the gy row tiles of one column strip; 2: group = the gx column tiles of one
     //                       row strip; 3: group = every tile of one K split
     int ngroups;
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float* __restrict__ w
 // six bf16 products per fp32 product, each exact in the instruction's fp32 accumulator arithmetic, 16 / 6 = 2.7x the fp32
 // instruction's rate at the rounding level of fp32 itself (the terms left out, a1 b2 + a2 b1 + a2 b2, are below 3 * 2^-24 |a b|;
 // a different summation order of the same fp32 products moves a dot product by more).  The parity tests of the Dense layers
-// (tests/test_gpu_dense.py, test_gpu_neumf.py, test_gpu_gemm.py) hold at their fp32 tolerances; EL_GEMM_SPLIT=0 selects the
+// (tests/test_gpu_dense.py, test_gpu_neumf.py, test_gpu_gemm.py) hold at their fp32 tolerances; the option gemm_split = 0 selects the
 // fp32 instruction (k_gemm_f32_v above).
 //   * block tile 128 x 128, BK = 32 (two k-steps), 256 threads, two workgroups per CU
 //   * staging: global -> registers (8 float4 per thread, the next tile in flight under the matrix instructions) -> split -> LDS as
@@ -805,257 +804,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
     }
 }
 
-// ---- k_gemm_b3 over several tiles per workgroup (round 5) -----------------------------------------------------------------------
-// The short-K products of the NeuMF tower (K = 128 ... 512: 4 to 16 k tiles per output tile) pay a prologue -- the first operand
-// tiles cross the memory system with nothing to overlap them -- and an epilogue per 128 x 128 tile: 4.2 us of CU time per k tile
-// against 2.9 at 4096^3.  Here a workgroup walks its tiles lin = blockIdx.x, + gridDim.x, ... (the same linear order as the one-tile
-// kernel: XCD-aware groups when grp_mode says so), and the fetch that the last k step of a tile would spend on zeros loads the FIRST
-// k tile of the next output tile instead: the pipeline stays primed across tiles, the epilogue's stores run under loads already in
-// flight.  Same staging, fragments, products and epilogue per tile as k_gemm_b3: bit-identical results.
-struct B3Tile {
-    int64_t m0, n0, kbeg, kend;
-    unsigned bz;
-};
-__device__ __forceinline__ bool b3_decode(const GemmParams& p, unsigned lin, B3Tile& t) {
-    unsigned bx, by, bz;
-    if (p.grp_mode != 0) {
-        const unsigned xcd = lin & 7u, q = lin >> 3;
-        const unsigned grp = p.grp_mode == 1 ? (unsigned)p.gy : (p.grp_mode == 2 ? (unsigned)p.gx : (unsigned)(p.gx * p.gy));
-        const unsigned gi = (q / grp) * 8u + xcd, ti = q % grp;
-        if (gi >= (unsigned)p.ngroups) return false;
-        if (p.grp_mode == 1) by = ti, bx = gi % (unsigned)p.gx, bz = gi / (unsigned)p.gx;
-        else if (p.grp_mode == 2) bx = ti, by = gi % (unsigned)p.gy, bz = gi / (unsigned)p.gy;
-        else bx = ti % (unsigned)p.gx, by = ti / (unsigned)p.gx, bz = gi;
-    } else {
-        bx = lin % (unsigned)p.gx;
-        const unsigned r = lin / (unsigned)p.gx;
-        by = r % (unsigned)p.gy, bz = r / (unsigned)p.gy;
-        if (bz >= (unsigned)p.gz) return false;
-    }
-    t.m0 = (int64_t)by * B3_BM, t.n0 = (int64_t)bx * B3_BN, t.bz = bz;
-    t.kbeg = (int64_t)bz * p.kchunk;
-    t.kend = (t.kbeg + p.kchunk < p.K) ? t.kbeg + p.kchunk : p.K;
-    return true;
-}
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void k_gemm_b3p(GemmParams p) {
-    constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE;
-    __shared__ __attribute__((aligned(16))) char lds[2 * IMG];   // A image, B image (48 KB)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, g = lane >> 5;
-    const int t = tid & 127;
-    const bool stA = tid < 128;
-    const unsigned nlin = (unsigned)p.nlin, stride = gridDim.x;
-    unsigned lin = blockIdx.x;
-    B3Tile cur, nxt;
-    while (lin < nlin && !b3_decode(p, lin, cur)) lin += stride;
-    if (lin >= nlin) return;
-    float4 rg[8];
-    auto fetch = [&](const B3Tile& T, int64_t k0) {
-        if (stA) b3_load<AKC>(p.A, p.lda, p.M, T.m0, T.kend, k0, t, p.zeros, rg);
-        else b3_load<BKC>(p.B, p.ldb, p.N, T.n0, T.kend, k0, t, p.zeros, rg);
-    };
-    auto stash = [&]() {
-        if (stA) b3_store<AKC>(rg, lds, t);
-        else b3_store<BKC>(rg, lds + IMG, t);
-    };
-    const int fa = (g * 128 + 32 * w + n) * 16, fb = IMG + (g * 128 + n) * 16;
-    fetch(cur, cur.kbeg);
-    for (;;) {
-        unsigned lin2 = lin + stride;
-        bool has_next = false;
-        while (lin2 < nlin && !(has_next = b3_decode(p, lin2, nxt))) lin2 += stride;
-        floatx16 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        for (int64_t k0 = cur.kbeg; k0 < cur.kend; k0 += B3_BK) {
-            b3_lds_barrier();                                 // the previous tile's fragments (and the epilogue's sums) are read
-            stash();
-            b3_lds_barrier();
-            if (k0 + B3_BK < cur.kend) fetch(cur, k0 + B3_BK);
-            else if (has_next) fetch(nxt, nxt.kbeg);          // the next output tile's first operands: in flight under the epilogue
-            b3_h8 a[2][3], b[2][4][3];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[s][pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) b[s][j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
-                }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][2], b[s][j][0], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][1], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][2], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][0], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][1], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][0], acc[j], 0, 0, 0);
-            }
-        }
-        // epilogue of `cur` (as in k_gemm_b3)
-        float* out = p.ws ? p.ws + (int64_t)cur.bz * p.M * p.N : p.C;
-        const int64_t ldo = p.ws ? p.N : p.ldc;
-        const int64_t col = cur.n0 + 4 * n;
-        const int act = p.ws ? EL_ACT_NONE : p.act;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!p.ws && p.bias && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);
-        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col < p.N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = cur.m0 + 4 * (8 * (r >> 2) + 4 * g + (r & 3)) + w;
-                float4 v = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
-                if (act == EL_ACT_RELU) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
-                else if (act != EL_ACT_NONE) v = make_float4(el_act(v.x, act), el_act(v.y, act), el_act(v.z, act), el_act(v.w, act));
-                if (row < p.M) {
-                    if (p.rmask) {
-                        const float4 y = *reinterpret_cast<const float4*>(p.rmask + row * p.ldy + col);
-                        v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
-                        cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
-                    }
-                    *reinterpret_cast<float4*>(out + row * ldo + col) = v;
-                }
-            }
-        }
-        if (p.rmask) {
-            cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64), cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
-            b3_lds_barrier();                                            // every wave is done with the fragment images
-            float* red = reinterpret_cast<float*>(lds);
-            if (g == 0) *reinterpret_cast<float4*>(red + w * 128 + 4 * n) = cs;
-            b3_lds_barrier();
-            if (tid < 128 && cur.n0 + tid < p.N) {
-                const float t4 = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
-                if (t4 != 0.f) atomicAdd(p.colsum + cur.n0 + tid, t4);
-            }
-        }
-        if (!has_next) break;
-        cur = nxt;
-        lin = lin2;
-    }
-}
-
-// one staging role of k_gemm_b3w (below): tile 0 into buffer 0, then per k tile: split + store tile it + 1 into the other buffer, issue
-// the loads of tile it + 2, LDS-only barrier (the loads stay in flight across it)
-template <bool KC>
-__device__ __forceinline__ void b3w_produce(const float* __restrict__ X, int64_t ld, int64_t nX, int64_t x0, int64_t kbeg, int64_t kend, int nit,
-                                            int t, const float* __restrict__ zeros, char* lds, int img_off, int buf_bytes) {
-    float4 rg[8];
-    b3_load<KC>(X, ld, nX, x0, kend, kbeg, t, zeros, rg);
-    b3_store<KC>(rg, lds + img_off, t);
-    b3_load<KC>(X, ld, nX, x0, kend, kbeg + B3_BK, t, zeros, rg);       // (past kend: zeros, never stored)
-    b3_lds_barrier();                                                    // buffer 0 holds tile 0
-    for (int it = 0; it < nit; ++it) {
-        if (it + 1 < nit) {
-            b3_store<KC>(rg, lds + ((it + 1) & 1) * buf_bytes + img_off, t);     // the buffer the consumers left at the previous barrier
-            b3_load<KC>(X, ld, nX, x0, kend, kbeg + (int64_t)(it + 2) * B3_BK, t, zeros, rg);
-        }
-        b3_lds_barrier();
-    }
-}
-
-// ---- the same product with the operand staging on waves of its own (round 5) -----------------------------------------------
-// k_gemm_b3 above makes every wave do both jobs in turn: split + store the next tile (≈ 180 VALU instructions and 12 LDS stores per
-// lane), then read the fragments and issue 48 matrix instructions; while a workgroup stages, its matrix pipes idle, and the overlap
-// rests on the second workgroup of the CU being in the other phase (measured: matrix pipes busy half the time, 150-180 TFLOP/s).
-// Here a workgroup is 8 waves -- two per SIMD: waves 0-3 CONSUME (fragment reads + matrix instructions, nothing else), waves 4-7
-// PRODUCE (global loads of tile t + 2, split + store of tile t + 1 into the other LDS buffer) -- so each SIMD always has a wave with
-// matrix work and a wave with vector work to issue from, and the two pipes run side by side by construction.  Two 48 KB buffers, one
-// workgroup per CU, one LDS-only barrier per k tile.  Same split, same fragment images, same products in the same order, same
-// epilogue as k_gemm_b3: the results are bit-identical to it.
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_b3w(GemmParams p) {
-    constexpr int PLANE = 4 * 128 * 16, IMG = 3 * PLANE, BUF = 2 * IMG;
-    extern __shared__ __attribute__((aligned(16))) char b3w_lds[];            // two buffers of (A image, B image): 96 KB
-    const int tid = threadIdx.x;
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.grp_mode != 0) {                                                     // XCD-aware order: see k_gemm_b3
-        const unsigned b = blockIdx.x, xcd = b & 7u, q = b >> 3;
-        const unsigned grp = p.grp_mode == 1 ? (unsigned)p.gy : (p.grp_mode == 2 ? (unsigned)p.gx : (unsigned)(p.gx * p.gy));
-        const unsigned gi = (q / grp) * 8u + xcd, ti = q % grp;
-        if (gi >= (unsigned)p.ngroups) return;
-        if (p.grp_mode == 1) by = ti, bx = gi % (unsigned)p.gx, bz = gi / (unsigned)p.gx;
-        else if (p.grp_mode == 2) bx = ti, by = gi % (unsigned)p.gy, bz = gi / (unsigned)p.gy;
-        else bx = ti % (unsigned)p.gx, by = ti / (unsigned)p.gx, bz = gi;
-    }
-    const int64_t m0 = (int64_t)by * B3_BM, n0 = (int64_t)bx * B3_BN;
-    const int64_t kbeg = (int64_t)bz * p.kchunk;
-    const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
-    const int nit = kend > kbeg ? (int)((kend - kbeg + B3_BK - 1) / B3_BK) : 0;
-    if (tid >= 256) {
-        // ---- producer waves: waves 4, 5 stage the A tile, waves 6, 7 the B tile (the roles of k_gemm_b3's staging halves).  The
-        // role is decided on a SCALAR (readfirstlane): each role runs its own straight-line loop -- with a per-lane `if (A) ... else
-        // ...` inside one loop the compiler joins the two arms in front of the last load and waits there for every load in flight
-        // (s_waitcnt vmcnt(0) ahead of the barrier: a full memory latency per k tile, measured 0.75 -> 0.94 ms at 4096^3)
-        const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);
-        if (pw < 6) b3w_produce<AKC>(p.A, p.lda, p.M, m0, kbeg, kend, nit, tid - 256, p.zeros, b3w_lds, 0, BUF);
-        else b3w_produce<BKC>(p.B, p.ldb, p.N, n0, kbeg, kend, nit, tid - 384, p.zeros, b3w_lds, IMG, BUF);
-        return;
-    }
-    // ---- consumer waves: wave w = row tile w against the four column tiles, as in k_gemm_b3
-    const int lane = tid & 63, w = tid >> 6, n = lane & 31, g = lane >> 5;
-    floatx16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int fa = (g * 128 + 32 * w + n) * 16, fb = IMG + (g * 128 + n) * 16;
-    b3_lds_barrier();
-    for (int it = 0; it < nit; ++it) {
-        const char* lds = b3w_lds + (it & 1) * BUF;
-        b3_h8 a[2][3], b[2][4][3];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                a[s][pl] = *reinterpret_cast<const b3_h8*>(lds + fa + pl * PLANE + s * 2 * 128 * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[s][j][pl] = *reinterpret_cast<const b3_h8*>(lds + fb + pl * PLANE + (s * 2 * 128 + 32 * j) * 16);
-            }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][2], b[s][j][0], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][1], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][2], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][j][0], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][1], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][j][0], acc[j], 0, 0, 0);
-        }
-        b3_lds_barrier();                                    // fragments of this buffer are in registers; the next one is complete
-    }
-    float* out = p.ws ? p.ws + (int64_t)bz * p.M * p.N : p.C;
-    const int64_t ldo = p.ws ? p.N : p.ldc;
-    const int64_t col = n0 + 4 * n;
-    const int act = p.ws ? EL_ACT_NONE : p.act;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!p.ws && p.bias && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);
-    if (col < p.N) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = m0 + 4 * (8 * (r >> 2) + 4 * g + (r & 3)) + w;
-            float4 v = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
-            if (act == EL_ACT_RELU) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
-            else if (act != EL_ACT_NONE) v = make_float4(el_act(v.x, act), el_act(v.y, act), el_act(v.z, act), el_act(v.w, act));
-            if (row < p.M) *reinterpret_cast<float4*>(out + row * ldo + col) = v;
-        }
-    }
-}
-
-static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K, int wg_per_cu = 2) {
+static int gemm_splits(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
+    const int wg_per_cu = 2;
     const int64_t tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
     const int64_t target = (int64_t)ctx->cus * wg_per_cu;
     if (tiles >= target / 2 || K < 4 * GBK) return 1;
@@ -1085,18 +835,13 @@ static GemmPlan gemm_plan(el_ctx* ctx, int64_t M, int64_t N, int64_t K) {
     // small products (the 512 x 400 x 600 class of the Mult-VAE heads: ~0.25 GFLOP, latency-bound): whole 64 x 64 tiles, one
     // launch, no partial tiles to combine (measured 13-24 us against 21-29 us for stream-K + fix-up)
     if (2.0 * (double)M * (double)N * (double)K < 2.0e9 && ((M + 63) / 64) * ((N + 63) / 64) >= 16) pl.tm = pl.tn = 1, mode = 1;
-    if (const char* e = getenv("EL_GEMM_TILE")) {                 // experiments: "tm,tn[,whole_tiles]"
-        int tm = 2, tn = 2, wt = -1;
-        if (sscanf(e, "%d,%d,%d", &tm, &tn, &wt) >= 2 && (tm == 1 || tm == 2) && (tn == 1 || tn == 2)) pl.tm = tm, pl.tn = tn, mode = wt;
-    }
     const int64_t bm = 64 * pl.tm, bn = 64 * pl.tn;
     pl.nkt = (K + KB - 1) / KB;
     if (pl.nkt < 1) pl.nkt = 1;
     pl.tiles_n = (N + bn - 1) / bn;
     const int64_t tiles = ((M + bm - 1) / bm) * pl.tiles_n;
     pl.units = tiles * pl.nkt;
-    static const int per_cu = [] { const char* e = getenv("EL_GEMM_WG_PER_CU"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 2; }();
-    static const int min_units = [] { const char* e = getenv("EL_GEMM_MIN_UNITS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+    const int per_cu = 2, min_units = 4;        // persistent workgroups per CU; at least this many k tiles per workgroup
     int64_t P = (int64_t)ctx->cus * per_cu;
     // whole tiles per workgroup (no partial tiles to combine) when the rounding costs little: >= 8 tiles per workgroup
     pl.whole_tiles = mode >= 0 ? mode : (tiles >= 8 * P ? 1 : 0);
@@ -1179,24 +924,17 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
     p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
     // aligned fast path: a float4 of either operand never straddles the matrix edge
-    static const bool fast_on = [] { const char* e = getenv("EL_GEMM_FAST"); return !(e && atoi(e) == 0); }();
-    const bool fast0 = fast_on && p.vecA && p.vecB && K >= 1 && (transA ? M : K) % 4 == 0 && (transB ? K : N) % 4 == 0 &&
+    const bool fast0 = p.vecA && p.vecB && K >= 1 && (transA ? M : K) % 4 == 0 && (transB ? K : N) % 4 == 0 &&
                        M < (1LL << 30) && N < (1LL << 30) && K < (1LL << 30) && ctx->zeros != nullptr;
     int splits = 1;
     GemmPlan pl = gemm_plan(ctx, M, N, K);
     const bool fast = fast0 && ws != nullptr && ws_bytes >= (size_t)2 * pl.P * (64 * pl.tm) * (64 * pl.tn) * 4;
     // three-way split on the bf16 matrix instruction (header of k_gemm_b3): the default wherever the fast path's alignment holds
-    const char* esplit = getenv("EL_GEMM_SPLIT");          // (read per call: the tests time and compare both forms in one process)
-    const bool split_on = !(esplit && atoi(esplit) == 0);
+    const bool split_on = ctx->opt.gemm_split != 0;          // (el_ctx_set_option("gemm_split"): the tests time and compare both forms)
     // (products under 2 GFLOP -- the 512 x 400 x 600 class -- are latency-bound: the one-launch small-tile path below stays faster)
     const bool outvec = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
-    // EL_GEMM_B3W=1: the kernel with staging waves of its own, one workgroup per CU (measured: 3-4 % ahead on the long-K weight-gradient
-    // products, 5-20 % behind on the short-K ones; off by default.  Neither form is bound by the memory system: L2 hit rate 62-80 %,
-    // <= 2 TB/s from the fabric, profiles/r05_pmc_gemm_feed.md)
-    const char* ew = getenv("EL_GEMM_B3W");
-    const bool b3w = ew && atoi(ew) == 1;
     if (split_on && fast0 && outvec && 2.0 * (double)M * (double)N * (double)K >= 2.0e9) {
-        splits = gemm_splits(ctx, M, N, K, b3w ? 1 : 2);
+        splits = gemm_splits(ctx, M, N, K);
         if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * 4)) splits = 1;
         p.kchunk = ((K + splits - 1) / splits + B3_BK - 1) / B3_BK * B3_BK;
         if (p.kchunk < B3_BK) p.kchunk = B3_BK;
@@ -1205,15 +943,15 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
         p.ws = splits > 1 ? (float*)ws : nullptr;
         p.zeros = ctx->zeros;
         const bool want_mask = rmask != nullptr && colsum != nullptr;
-        const bool fuse_mask = want_mask && splits == 1 && !b3w && ldy % 4 == 0 && ((uintptr_t)rmask % 16 == 0) && ldy >= N;
+        const bool fuse_mask = want_mask && splits == 1 && ldy % 4 == 0 && ((uintptr_t)rmask % 16 == 0) && ldy >= N;
         if (fuse_mask) {
             p.rmask = rmask, p.ldy = ldy, p.colsum = colsum;
             if (fused) *fused = 1;
         }
         dim3 grid((unsigned)((N + B3_BN - 1) / B3_BN), (unsigned)((M + B3_BM - 1) / B3_BM), (unsigned)splits);
-        // XCD-aware order (EL_GEMM_XCD=0: the 3-D grid of round 4): with K splits every tile of a split shares its two K chunks (up to
+        // XCD-aware order (option gemm_xcd = 0: the plain 3-D grid): with K splits every tile of a split shares its two K chunks (up to
         // 64 tiles per group); without, the tiles along the SHORTER grid edge share the strip of the longer operand
-        static const bool xcd_on = [] { const char* e = getenv("EL_GEMM_XCD"); return !(e && atoi(e) == 0); }();
+        const bool xcd_on = ctx->opt.gemm_xcd != 0;
         p.gx = (int)grid.x, p.gy = (int)grid.y, p.gz = (int)grid.z;
         if (xcd_on && (int64_t)grid.x * grid.y * grid.z >= 16) {
             int64_t grp = 0;
@@ -1231,41 +969,10 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
             }
         }
         // A is k-contiguous unless transposed ([K, M]); B ([K, N]) is k-contiguous when transposed ([N, K])
-        if (b3w) {
-            constexpr int LDSW = 2 * 2 * 3 * 4 * 128 * 16;            // two buffers x (A, B) x three planes x 8 KB
-#define EL_B3W(AK_, BK_)                                                                                                            \
-    do {                                                                                                                            \
-        auto kern = k_gemm_b3w<AK_, BK_>;                                                                                           \
-        EL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW));   \
-        EL_LAUNCH("k_gemm_b3", kern, grid, dim3(512), (size_t)LDSW, s, p);                                                          \
-    } while (0)
-            if (!transA && !transB) EL_B3W(true, false);
-            else if (!transA && transB) EL_B3W(true, true);
-            else if (transA && !transB) EL_B3W(false, false);
-            else EL_B3W(false, true);
-#undef EL_B3W
-        } else {
-            // EL_GEMM_PERSIST=1: several tiles per workgroup (k_gemm_b3p) where a workgroup slot would see four tiles or more of at most
-            // 32 k tiles each.  Measured and left off: the NeuMF tower's short-K products 4-7 % SLOWER (0.537 -> 0.574, 0.475 -> 0.508,
-            // 0.464 -> 0.482 ms) -- with two workgroups per CU the other workgroup already covers a tile's prologue and epilogue, and the
-            // tile loop costs 50-60 more VGPRs; bit-identical, kept as a switch (tests/test_gpu_dense.py runs both)
-            const char* ep = getenv("EL_GEMM_PERSIST");
-            const bool persist_on = ep && atoi(ep) == 1;
-            const int64_t total = (int64_t)grid.x * grid.y * grid.z, slots = (int64_t)ctx->cus * 2;
-            const int64_t ktiles = (p.kchunk + B3_BK - 1) / B3_BK;
-            if (persist_on && total >= 4 * slots && ktiles <= 32 && total < (1LL << 31)) {
-                p.nlin = (int)total;
-                if (p.grp_mode == 0) p.gx = (int)grid.x, p.gy = (int)grid.y, p.gz = (int)grid.z;
-                const dim3 pg((unsigned)slots, 1, 1);                   // (a multiple of 8: a workgroup's tiles stay on its XCD)
-                if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<true, false>), pg, dim3(256), 0, s, p);
-                else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<true, true>), pg, dim3(256), 0, s, p);
-                else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<false, false>), pg, dim3(256), 0, s, p);
-                else EL_LAUNCH("k_gemm_b3", (k_gemm_b3p<false, true>), pg, dim3(256), 0, s, p);
-            } else if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
-            else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
-            else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
-            else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);
-        }
+        if (!transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, false>), grid, dim3(256), 0, s, p);
+        else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
+        else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
+        else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);
     } else if (fast) {
         p.ws = (float*)ws;
         p.units = pl.units;

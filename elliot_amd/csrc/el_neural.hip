@@ -797,24 +797,33 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
         // (round 5) the ReLU derivative and the bias gradient of layer l - 1 ride in the epilogue of the product that writes its input
         // gradient (el_gemm_f32_x: one write of d instead of write + read + write, no read of d for the column sums) -- without Dropout
         // (its mask comes between the product and the ReLU test) and where the product runs on the split kernel unsplit
-        static const bool fuse_env = [] { const char* e = getenv("EL_NMF_FUSE_RELU_BWD"); return !(e && atoi(e) == 0); }();
         // Two streams (round 5): the weight gradients gW[l] = in^T dact[l] (K = the batch: split-K products, 1.0 of the 3.2 ms the
         // tower's products take) are needed by the optimiser only; the chain dact[last] -> ... -> dX0 -> embedding scatter -> embedding
         // rows' Adam step does not wait for them.  They run on the library's second stream, forked as each dact[l] becomes final, and
         // overlap with the chain's bandwidth-bound tail (k_nmf_scatter, k_nmf_apply_rows).  Their split-K partials take the upper half of
-        // the workspace (a host that sizes it 2 x el_gemm_ws_bytes gets the overlap; EL_NMF_SIDE=0 turns it off).
-        const char* side_e = getenv("EL_NMF_SIDE");             // (per call: bench.py's per-kernel breakdown runs one stream)
+        // the workspace (a host that sizes it 2 x el_gemm_ws_bytes gets the overlap; the option nmf_side = 0 turns it off: bench.py's
+        // per-kernel breakdown runs one stream).
         size_t need_w = 0;
         for (int l = 0; l < st->n_layers; ++l) {
             const size_t a = el_gemm_ws_bytes(ctx, l == 0 ? 2 * (int64_t)st->E : st->units[l - 1], st->units[l], n);
             need_w = a > need_w ? a : need_w;
         }
         const size_t half = (st->ws_bytes / 2) & ~(size_t)255;
-        bool side_on = !(side_e && atoi(side_e) == 0) && st->ws != nullptr && half >= need_w && n >= 4096 && !ctx->side_join_pending;
+        bool side_on = ctx->opt.nmf_side != 0 && st->ws != nullptr && half >= need_w && n >= 4096 && !ctx->side_join_pending;
         if (side_on) side_on = el_side_stream_ready(ctx);
         hipStream_t ss = side_on ? ctx->side : s;
         void* ws_w = side_on ? (void*)((char*)st->ws + half) : st->ws;
         const size_t wsb_w = side_on ? half : st->ws_bytes, wsb_d = side_on ? half : st->ws_bytes;
+        // a return out of the layer loop (a failing product or launch) joins whatever was forked to the side stream so far: the
+        // caller's next call -- or its free of the activations / the workspace -- must not race with work still in flight there
+        struct SideGuard {
+            el_ctx* c; hipStream_t s, ss; bool armed;
+            ~SideGuard() {
+                if (!armed) return;
+                (void)hipEventRecord(c->side_ev[7], ss);
+                (void)hipStreamWaitEvent(s, c->side_ev[7], 0);
+            }
+        } guard{ctx, s, ss, side_on};
         bool done_below = false;                  // dact[l] already carries layer l's ReLU derivative and gb[l] its column sums
         for (int l = st->n_layers - 1; l >= 0; --l) {
             const int64_t units = st->units[l];
@@ -842,7 +851,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
             }
             if (int rc = el_gemm_f32(ctx, ss, 1, 0, kin, units, n, in, kin, st->dact[l], units, st->gW[l], units, nullptr, 0, ws_w, wsb_w)) return rc;
             float* din = (l == 0) ? st->dX0 : st->dact[l - 1];
-            if (l >= 1 && fuse_env && !(st->dropout > 0.f)) {
+            if (l >= 1 && !(st->dropout > 0.f)) {
                 int fused = 0;
                 if (int rc = el_gemm_f32_x(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->act[l - 1], kin,
                                            st->gb[l - 1], st->ws, wsb_d, &fused)) return rc;
@@ -855,6 +864,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
         if (side_on) {
             EL_CHECK_HIP(hipEventRecord(ctx->side_ev[7], ss));           // every weight gradient is complete
             ctx->side_join_pending = true;
+            guard.armed = false;                                         // (the regular join: below, or inside the apply half)
         }
     }
     EL_LAUNCH("k_nmf_scatter", k_nmf_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);

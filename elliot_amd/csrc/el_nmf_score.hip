@@ -1398,8 +1398,7 @@ extern "C" int el_nmf_score_topk(el_ctx* ctx, void* stream, el_nmf_state* st, in
         unsigned long long ncands = 0;
         memcpy(&ncands, hflag + 2, 8);
         // worth it when the exact kernel is left with less than half of the pairs (the screen costs a sixth of it; EL_NMF_SCREEN_MAXFRAC overrides)
-        const char* ef = getenv("EL_NMF_SCREEN_MAXFRAC");   // (read per call, beside a stream synchronisation: the tests move it between calls)
-        const double maxfrac = ef ? atof(ef) : 0.5;
+        const double maxfrac = ctx->opt.nmf_screen_maxfrac;   // (el_ctx_set_option: the tests move it between calls)
         const bool use = hflag[0] == 0 && (double)ncands <= maxfrac * (double)n_users * (double)I_local;
         if (use) ctx->nmf_screen_cands = (int64_t)ncands;
         ctx->nmf_screen_fallback = !use;

@@ -592,26 +592,13 @@ static int launch_mfma(const TopkParams& p, int vec, hipStream_t st) {
     return 0;
 }
 
-// experiment hook: EL_TOPK_VARIANT selects an alternative geometry for F in (64,128]
-static int topk_variant() {
-    const char* e = getenv("EL_TOPK_VARIANT");
-    return e ? atoi(e) : 0;
-}
-
 template <int CAP>
 static int dispatch_mfma_fp(const TopkParams& p, int vec, hipStream_t st) {
     if (p.F <= 32) return launch_mfma<32, 4, CAP, 32, 4, 2>(p, vec, st);
     if (p.F <= 64) return launch_mfma<64, 4, CAP, 32, 4, 2>(p, vec, st);
-    if (p.F <= 128) {
-        switch (topk_variant()) {
-            case 1: return launch_mfma<128, 2, CAP, 32, 4, 3>(p, vec, st);   // 64-item tiles, 3 waves/SIMD
-            case 2: return launch_mfma<128, 4, CAP, 64, 8, 2>(p, vec, st);   // 256 users/WG, K chunk 64
-            case 3: return launch_mfma<128, 4, CAP, 64, 4, 1>(p, vec, st);   // K chunk 64, 1 WG/CU
-            case 4: return launch_mfma<128, 2, CAP, 64, 4, 2>(p, vec, st);   // 64-item tiles, K chunk 64
-            case 5: return launch_mfma<128, 4, CAP, 32, 8, 2>(p, vec, st);   // 256 users/WG, K chunk 32
-            default: return launch_mfma<128, 4, CAP, 32, 4, 2>(p, vec, st);
-        }
-    }
+    // (128-item tiles, K chunk 32, 128 users per workgroup, two workgroups per CU: the geometry sweep of round 2 -- 64-item tiles,
+    //  K chunk 64, 256 users per workgroup, one workgroup per CU -- is in profiles/r02_*)
+    if (p.F <= 128) return launch_mfma<128, 4, CAP, 32, 4, 2>(p, vec, st);
     return launch_mfma<256, 2, CAP, 32, 4, 1>(p, vec, st);
 }
 
@@ -814,6 +801,9 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
                              const int32_t* cand_indices, int32_t k, int32_t* out_idx, float* out_val, int algo,
                              void* ws, size_t ws_bytes) {
     if (int rc = el_bind(ctx)) return rc;
+    // el_topk_screen_stats describes the LAST el_score_topk call: cleared here, set again only by a screened run that completed (a call
+    // on another route, a failed call or a freed workspace must not leave pointers of an earlier call behind)
+    ctx->scr_cnt = nullptr, ctx->scr_flagged = nullptr, ctx->scr_users = 0;
     if (int rc = check_topk_args("el_score_topk", u_start, u_stop, I_local, F, k, out_idx, out_val)) return rc;
     const bool items_unchanged = (algo & EL_TOPK_ITEMS_UNCHANGED) != 0;
     algo &= 0xff;
@@ -840,10 +830,7 @@ extern "C" int el_score_topk(el_ctx* ctx, void* stream, const float* Gu, const f
     p.k = k;
     p.out_idx = out_idx;
     p.out_val = out_val;
-    {
-        const char* e = getenv("EL_TOPK_DEBUG");
-        p.dbg = e ? atoi(e) : 0;
-    }
+    p.dbg = 0;
     const bool selig = el_topk_screen_eligible(F, k, cand_indptr);
     if (algo == EL_TOPK_SCREEN) EL_REQUIRE(selig, "el_score_topk: screened kernel needs F<=256, k<=128 and no candidate list");
     if (algo == EL_TOPK_SCREEN ||

@@ -224,14 +224,6 @@ struct ScreenParams {
     int kA;                      // T = kA-th largest clean slot maximum (== k with stride 1: T is then rigorous)
     int surv;                    // unmasked hits a user may have before it is sent to the exact fallback (128 or 512)
     int stride;                  // pass 1 visits tiles t with t % stride == 0
-    // pace keeping of the workgroups of one XCD (round 5): every workgroup sweeps the whole item image, and the 32-64 workgroups
-    // that share an XCD's 4 MB L2 only find each other's tiles there while they stay within ~2 MB of each other -- over the 78 125
-    // tiles of a 5 M x 256 catalogue they drift apart and every one of them fetches the image from HBM itself (PMC: 603 GB per launch
-    // against a 2.56 GB image).  prog[b] = groups workgroup b has retired (published every prog_every groups); before going on, wave 0
-    // looks at the slowest workgroup of its XCD (b % 8: observed placement, used as a hint only) and naps while it is more than
-    // prog_window groups ahead of it -- a bounded number of naps: correctness never depends on it.  NULL = off.
-    u32* prog;
-    int prog_window, prog_every;
     unsigned long long* prof;    // EL_SCREEN_PROF=1: [n_waves][8] cycle / event counters (developer tool)
     unsigned long long* prof2;   // EL_SCREEN_PROF=1: [16] sums over the users of k_screen_final: phase cycles and candidate counts
 };
@@ -463,27 +455,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_screen_pass(ScreenParams sp) {
         }
         if (g + 1 < ng) lstore(g + 1);
         __syncthreads();
-        if (sp.prog != nullptr && (g + 1) % sp.prog_every == 0 && wave_u == 0) {
-            const unsigned me = blockIdx.x, nwg = gridDim.x, peer = (me & 7u) + 8u * (unsigned)lane;
-            if (lane == 0) __hip_atomic_store(sp.prog + me, (u32)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int tries = 0; tries < 24; ++tries) {
-                u32 v = 0xffffffffu;                                  // (a finished workgroup publishes this value too)
-                if (peer < nwg) v = __hip_atomic_load(sp.prog + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const u32 w2 = (u32)__shfl_xor((int)v, o, 64);
-                    v = w2 < v ? w2 : v;
-                }
-                if ((u32)(g + 1) <= v + (u32)sp.prog_window) break;
-                __builtin_amdgcn_s_sleep(100);
-            }
-        }
         if (g + 2 < ng) gload(g + 2);
         mfma_half(g + 1, 0, 0);      // (past the last group this chews on a stale LDS slot; the result is never read)
         epi_half((g * NSUB + NSUB - 1) * step, 1);
     }
 
-    if (sp.prog != nullptr && tid == 0) __hip_atomic_store(sp.prog + blockIdx.x, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (MODE == 1) {
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
@@ -953,22 +929,14 @@ static ScreenPolicy screen_policy(int k, int64_t I_local) {
         if (q.kA > 40) q.kA = 40;                               // (tiny catalogues: the verification decides)
         q.surv = 512;
     }
-    if (const char* se = getenv("EL_SCREEN_STRIDE")) {
-        const int v = atoi(se);
-        if (v >= 1 && v <= 16) q.stride = v;
-    }
-    if (const char* se = getenv("EL_SCREEN_KA")) {
-        const int v = atoi(se);
-        if (v >= 1 && v <= 56) q.kA = v;
+    if (g_el_cur_ctx) {                                         // el_ctx_set_option("screen_stride" / "screen_ka"): the tests force guesses that fail
+        const int sv = (int)g_el_cur_ctx->opt.screen_stride, kv = (int)g_el_cur_ctx->opt.screen_ka;
+        if (sv >= 1 && sv <= 16) q.stride = sv;
+        if (kv >= 1 && kv <= 56) q.kA = kv;
     }
     if (q.stride > 1 || q.kA != k) {
         q.surv = 512;
         q.band = 1.5f, q.band_min = 1.0f;                       // a guessed T: the band follows the spacing of the top scores (k_screen_thr)
-        if (const char* se = getenv("EL_SCREEN_BAND")) {        // experiments: "max[,min]" (one number: a fixed band)
-            float hi = 2.0f, lo = 1.0f;
-            const int n = sscanf(se, "%f,%f", &hi, &lo);
-            if (n >= 1 && hi >= 0.25f && hi <= 2.0f) q.band = hi, q.band_min = (n >= 2 && lo >= 0.25f && lo <= hi) ? lo : hi;
-        }
     }
     return q;
 }
@@ -990,28 +958,10 @@ static int launch_pass(const ScreenParams& sp, hipStream_t st) {
     const int64_t n_users = sp.t.u_stop - sp.t.u_start;
     constexpr int UPB = NW * UB * 32;
     const int64_t n_wg = (n_users + UPB - 1) / UPB;
-    ScreenParams q = sp;
-    // pace keeping: only when every workgroup of the launch is resident at once (a workgroup that has not started would hold its XCD
-    // back for the bounded naps of every check), at most 64 per XCD, and the sweep is long enough for drift to matter
-    // (EL_SCREEN_PACE=1 turns it on.  Measured, round 5: 131 072 users x 1 M x 128 with it 26.1 ms per pass-2 launch against 25.9
-    //  without; at the 5 M x 256 shard the two workgroups a CU would need do not fit beside each other (162 VGPRs), the launch runs in two
-    //  rounds and the condition below keeps it off -- FETCH_SIZE 735 GiB per launch either way.  The pass is not bound by where its item
-    //  tiles come from; left in as a switch, off.)
-    static const bool pace_env = [] { const char* e = getenv("EL_SCREEN_PACE"); return e && atoi(e) == 1; }();
-    q.prog = nullptr;
-    const int64_t group_bytes = (int64_t)NSUB * SCR_TI * FP * 2;
-    const int64_t groups = ((q.t.I_local + SCR_TI - 1) / SCR_TI / (MODE == 1 ? q.stride : 1) + NSUB - 1) / NSUB;
-    if (pace_env && n_wg >= 16 && n_wg <= 512 && n_wg <= n_users && groups * group_bytes >= (int64_t)(64 << 20)) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NW * 64, lds) == hipSuccess && per_cu >= 1 &&
-            n_wg <= (int64_t)per_cu * g_el_cur_ctx->cus) {
-            q.prog = reinterpret_cast<u32*>(q.ulist);                // free until k_screen_flags fills it after the passes
-            q.prog_window = (int)((2 << 20) / group_bytes);          // ~2 MB of lead inside a 4 MB L2
-            if (q.prog_window < 4) q.prog_window = 4;
-            q.prog_every = q.prog_window / 4;
-            EL_CHECK_HIP(hipMemsetAsync(q.prog, 0, (size_t)n_wg * 4, st));
-        }
-    }
+    // (Pace keeping of the workgroups that share an XCD's L2 -- progress counters + bounded naps so that they sweep the item image
+    //  within ~2 MB of each other -- was measured in round 5 and removed in round 6: 26.1 against 25.9 ms per pass-2 launch at
+    //  131 072 users x 1 M x 128, FETCH_SIZE unchanged at the 5 M x 256 shard: the pass is not bound by where its tiles come from.)
+    const ScreenParams& q = sp;
     EL_LAUNCH(MODE == 1 ? "k_screen_pass1" : "k_screen_pass2", kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, st, q);
     EL_CHECK_LAUNCH();
     return 0;
@@ -1118,7 +1068,6 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
     sp.Gib = gib;
     sp.stats = stats;
     sp.prof = nullptr;
-    sp.prog = nullptr, sp.prog_window = 0, sp.prog_every = 1;
     sp.prof2 = nullptr;
     // The item side (bf16 image, max norm, max |bias|) depends on Gi / Bi only.  A caller that scores block after block of
     // users against an unchanged table says so (EL_TOPK_ITEMS_UNCHANGED); the claim is honoured only if this context's
@@ -1154,8 +1103,7 @@ int el_topk_screen_run(const TopkParams& p, void* ws, size_t ws_bytes, hipStream
         EL_CHECK_HIP(hipMemsetAsync(stats, 0, 8, st));
         EL_CHECK_HIP(hipMemsetAsync(stats + SCR_STAT_IB, 0, 8, st));
     }
-    const char* pe = getenv("EL_SCREEN_PROF");
-    const bool prof = pe && pe[0] == '1';
+    const bool prof = ctx->opt.screen_prof != 0;
     int rc;
 #define SCR_RUN(FPV) (prof ? run_passes<FPV, 8, true>(sp, st) : run_passes<FPV, 8, false>(sp, st))
     if (FP == 32)

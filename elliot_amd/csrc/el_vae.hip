@@ -577,13 +577,9 @@ static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const
 // Adam on the variables whose bit is set in `mask` (bit k = variable k of W1 b1 [Wm|Wv] [bm|bv] W3 b3 W4 b4); defined below
 static int vae_apply_vars(el_ctx* ctx, hipStream_t s, const el_vae_state* st, float lr_t, unsigned mask);
 
-// early_lr_t >= 0 (el_vae_train_step): with two streams the output layer's Adam step (W4, b4: half of the optimiser's bytes) is taken
-// on the side stream as soon as its gradients are complete and the chain's dl W4^T has read W4 -- beside the chain's latency-bound
-// tail instead of after it; *early_mask tells vae_apply which variables are done
 static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,
                      const int32_t* rows, int64_t B, int64_t Bd, const float* eps, float anneal, float dropout_rate,
-                     uint64_t dropout_seed, int32_t step, double* loss_out, float early_lr_t = -1.f, unsigned* early_mask = nullptr) {
-    if (early_mask) *early_mask = 0u;
+                     uint64_t dropout_seed, int32_t step, double* loss_out) {
     if (int rc = vae_check(st, B)) return rc;
     EL_REQUIRE(indptr && indices && rows && loss_out && step >= 1 && Bd >= B, "el_vae: bad arguments");
     for (int t = 0; t < 8; ++t) EL_REQUIRE(st->g[t], "el_vae: gradient buffers missing");
@@ -602,10 +598,9 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     // gradients dW4, dW3, dW[m|v] and the five bias gradients (column sums) depend on the chain but nothing depends on them until
     // the optimiser, so they run on the library's second stream beside it (fork after each link, one join at the end).  The side
     // products take the upper half of the workspace: enabled when each half holds what its products need (a host that sizes the
-    // workspace 2 x el_gemm_ws_bytes gets it; EL_VAE_SIDE=0 turns it off), and when dz does not alias z (dW3 reads z while the
-    // chain writes dz).
-    const char* side_e = getenv("EL_VAE_SIDE");             // (read per call: bench.py's per-kernel breakdown pass runs one stream)
-    const bool side_env = !(side_e && atoi(side_e) == 0);
+    // workspace 2 x el_gemm_ws_bytes gets it; the option vae_side = 0 turns it off: bench.py's per-kernel breakdown pass runs one
+    // stream), and when dz does not alias z (dW3 reads z while the chain writes dz).
+    const bool side_env = ctx->opt.vae_side != 0;
     const int64_t LL = st->dae ? L : 2 * L;
     const size_t w1_bytes = ((size_t)(4 * (I + 1) + 4) * 4 + 255) & ~(size_t)255;     // dW1's index arrays (below)
     const size_t half = (st->ws_bytes / 2) & ~(size_t)255;
@@ -623,13 +618,23 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     const size_t wsb1 = side_on ? half : st->ws_bytes;
     void* ws2 = side_on ? (void*)((char*)st->ws + half) : st->ws;
     const size_t wsb2 = side_on ? half - w1_bytes : st->ws_bytes;
+    // From here on every way out of this function joins the side stream (whatever was forked onto it so far): a failing product or
+    // launch in the middle of the backward pass must not leave work in flight on ctx->side that the caller's next call -- or its free
+    // of dl / dh2 / g[] / the workspace -- would race with.
+    struct Join {
+        el_ctx* c; hipStream_t s, ss; bool on;
+        ~Join() {
+            if (!on) return;
+            (void)hipEventRecord(c->side_ev[7], ss);
+            (void)hipStreamWaitEvent(s, c->side_ev[7], 0);
+        }
+    } join{ctx, s, ss, side_on};
     // dW1 = x~^T dhpre by sparse transposition of the batch (k_vae_w1_*) when its scratch fits.  Its index arrays (per-item counts,
     // offsets, cursors, the heavy-item list) depend on the batch alone, the (item-ordered) list of batch rows goes into the logits
     // buffer once dl is consumed: with two streams the side stream builds all of it beside the chain (arrays at the end of its half
     // of the workspace), and the main stream only runs the two kernels that need dh.
-    static const bool sparse_on = [] { const char* e = getenv("EL_VAE_SPARSE_W1"); return !(e && atoi(e) == 0); }();
     const int cpl1 = (H / 4 + 63) / 64;
-    const bool sparse_w1 = sparse_on && B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && st->ws != nullptr &&
+    const bool sparse_w1 = B <= 2048 && I < (1LL << 24) && H % 4 == 0 && cpl1 <= 4 && st->ws != nullptr &&
                            wsb1 >= (size_t)(4 * (I + 1) + 4) * 4 && (((uintptr_t)st->dh | (uintptr_t)st->g[0]) & 15) == 0;
     int32_t* cnt = side_on ? (int32_t*)((char*)st->ws + half + wsb2) : (int32_t*)st->ws;
     int32_t* off = cnt + (I + 1);
@@ -656,25 +661,9 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     if (int rc = colsum(ss, dl, B, I, st->g[7])) return rc;
     if (side_on) EL_CHECK_HIP(hipEventRecord(ctx->side_ev[6], ss));                                                       // dl consumed on the side
     if (int rc = el_gemm_f32(ctx, s, 0, 1, B, H, I, dl, I, st->w[6], I, st->dh2, H, nullptr, 0, ws1, wsb1)) return rc;   // dh2 = dl W4^T
-    // (EL_VAE_EARLY_ADAM=1.  Measured and left off: 0.770-0.781 ms per step against 0.768 -- with two streams the chip is busy end to
-    //  end, moving 0.45 GB of optimiser traffic under the chain's tail only takes bandwidth from the kernels it runs beside)
-    static const bool early_env = [] { const char* e = getenv("EL_VAE_EARLY_ADAM"); return e && atoi(e) == 1; }();
-    if (side_on && early_env && early_lr_t >= 0.f && early_mask != nullptr) {
-        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));                                    // W4's last reader of this step
-        EL_CHECK_HIP(hipStreamWaitEvent(ss, ctx->side_ev[4], 0));
-        if (int rc = vae_apply_vars(ctx, ss, st, early_lr_t, 0xC0u)) return rc;              // W4, b4 (their gradients: this stream, above)
-        *early_mask = 0xC0u;
-    }
-    // (EL_VAE_SIDE_INDEX=1: the index of the sparse dW1 on the side stream as well.  Measured and left off: 0.831-0.837 ms per step, what
-    //  ONE stream takes (0.830), against 0.782 with the index on the chain's own stream -- the side stream then has to wait for the chain's
-    //  dl W4^T before it may overwrite dl with the row list, and everything queued behind that wait starts late)
-    static const bool side_index = [] { const char* e = getenv("EL_VAE_SIDE_INDEX"); return e && atoi(e) == 1; }();
-    const bool index_on_side = side_on && sparse_w1 && side_index;
-    if (index_on_side) {
-        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));                                                                 // ... and on the main one
-        if (int rc = w1_index(ss, true)) return rc;
-        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[5], ss));                                                                // the batch's index is built
-    }
+    // (Measured in round 5 and not kept: the output layer's Adam step on the side stream as soon as its gradients are complete --
+    //  0.770-0.781 against 0.768 ms per step; the dW1 index on the side stream -- 0.831-0.837 against 0.782: the side stream then waits for
+    //  the chain's dl W4^T before it may overwrite dl, and everything queued behind that wait starts late.)
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh2, st->h2, B * H);
     if (int rc = fork(1)) return rc;
     if (int rc = el_gemm_f32(ctx, ss, 1, 0, L, H, B, st->z, L, st->dh2, H, st->g[4], H, nullptr, 0, ws2, wsb2)) return rc;  // dW3 = z^T dh2pre
@@ -697,17 +686,10 @@ static int vae_grads(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const i
     EL_LAUNCH("k_tanh_bwd", k_tanh_bwd, dim3(grid1d(B * H, ctx)), dim3(256), 0, s, st->dh, st->h, B * H);
     if (int rc = fork(3)) return rc;
     if (int rc = colsum(ss, st->dh, B, H, st->g[1])) return rc;
-    if (side_on) {
-        EL_CHECK_HIP(hipEventRecord(ctx->side_ev[7], ss));             // join: everything the side stream was given
-        EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[6], 0));       // the logits buffer is free again (dW1's scratch lives there)
-    }
-    struct Join {                                                      // (every return path below joins)
-        el_ctx* c; hipStream_t s; bool on;
-        ~Join() { if (on) (void)hipStreamWaitEvent(s, c->side_ev[7], 0); }
-    } join{ctx, s, side_on};
+    if (side_on) EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[6], 0));       // the logits buffer is free again (dW1's scratch lives there)
+    // (nothing is forked after this point: the Join guard above records the side stream's end and waits for it on every return below)
     if (sparse_w1) {
-        if (index_on_side) EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[5], 0));      // built on the side stream (above)
-        else if (int rc = w1_index(s, false)) return rc;                                  // on this stream, here (dl is consumed: ev 6 above)
+        if (int rc = w1_index(s, false)) return rc;                                       // on this stream, here (dl is consumed: ev 6 above)
         int cap = 1024;                                             // presence flags: >= 64 batch rows per wave
         while (cap < B) cap <<= 1;
         const size_t lds = (size_t)W1_NW * (H / 4) * 16 + (size_t)cap;
@@ -812,10 +794,8 @@ extern "C" int el_vae_train_step(el_ctx* ctx, void* stream, const el_vae_state* 
                                  const int32_t* indices, const int32_t* rows, int64_t B, const float* eps, float anneal,
                                  float dropout_rate, uint64_t dropout_seed, int32_t step, float lr_t, double* loss_out) {
     if (int rc = el_bind(ctx)) return rc;
-    unsigned early = 0u;
-    if (int rc = vae_grads(ctx, (hipStream_t)stream, st, indptr, indices, rows, B, B, eps, anneal, dropout_rate, dropout_seed, step, loss_out,
-                           lr_t, &early)) return rc;
-    return vae_apply(ctx, (hipStream_t)stream, st, lr_t, early);
+    if (int rc = vae_grads(ctx, (hipStream_t)stream, st, indptr, indices, rows, B, B, eps, anneal, dropout_rate, dropout_seed, step, loss_out)) return rc;
+    return vae_apply(ctx, (hipStream_t)stream, st, lr_t);
 }
 
 extern "C" int el_vae_grads(el_ctx* ctx, void* stream, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,

@@ -446,9 +446,6 @@ def tune_table_layout(ctx, rows, F, compact=False):
     cache = ctx.__dict__.setdefault("_layout_cache", {})
     if key in cache:
         return cache[key]
-    if os.environ.get("EL_LAYOUT_GAP_MIB"):                       # experiments: a fixed distance instead of the timed pick
-        cache[key] = int(float(os.environ["EL_LAYOUT_GAP_MIB"]) * (1 << 20))
-        return cache[key]
     if os.environ.get("EL_TUNE_LAYOUT", "1") == "0" or rows * F * 4 < (64 << 20):
         cache[key] = 0
         return 0
@@ -506,9 +503,6 @@ def tune_table_layout(ctx, rows, F, compact=False):
             best, best_ms = gap, ms
         del tabs, big
     check(ctx.lib.el_tuning_mode(ctx.handle, 0), "el_tuning_mode")
-    if os.environ.get("EL_TUNE_DEBUG"):
-        import sys
-        print(f"[tune_table_layout] {key}: gap {best / (1 << 20):.1f} MiB at {best_ms:.4f} ms per pass", file=sys.stderr)
     cache[key] = best
     return best
 
@@ -527,14 +521,13 @@ class BprmfDeviceState:
         contains the user or when the table is read (el_bprmf_state.Gu_last): a step moves only the batch's user rows.  It pays
         when a batch touches a small part of the users (10 M users, 1 M triplets: the user side of the step 7.2 -> ~2 ms) and costs
         when it touches most of them (B = U: +10 %), so None = decided at the first training call: on when 4 B <= U and the fused
-        user-side step applies (EL_BPR_DEFERRED=0 / 1 force it); reading `.Gu` syncs, `.mGu` / `.vGu` want sync() first.
+        user-side step applies; reading `.Gu` syncs, `.mGu` / `.vGu` want sync() first.
         fused_item_step: the item side of the step as ONE kernel (el_bprmf_state.Gi_last): the item segments take Keras' Adam step on
         their rows in place, no dense gradient table is written, re-read and cleared.  None = whenever the fused user side applies
-        (EL_FUSED_ITEM=0 turns it off); grads() / apply() always run the two-pass form.
+        (fused_item_step=False turns it off); grads() / apply() always run the two-pass form.
         item_deferred: with the fused item side, the item rows a batch leaves alone wait for their gradient-free Adam updates like the
         user rows do (replayed bit for bit when a batch next contains the item, or on sync() / reading `.Gi` / `.Bi`); False = they
-        are replayed at the end of every step.  None = decided by the first batch size: on when 2 B <= I (EL_BPR_ITEM_DEFERRED=0 / 1
-        force it).
+        are replayed at the end of every step.  None = decided by the first batch size: on when 2 B <= I.
         replay: how a waiting row is brought forward over its gradient-free steps -- "exact": step by step, the bits of Keras'
         every-row pass; "series": in closed form from four row-level sums over the lr_t history (el_bprmf_state.replay_series:
         O(1) per element whatever the gap; as close to the exact-arithmetic recurrence as the fp32 step-by-step form, not its bits)."""
@@ -545,28 +538,19 @@ class BprmfDeviceState:
         self.opt = OPTIMIZERS[optimizer] if isinstance(optimizer, str) else int(optimizer)
         dev = ctx.device
         big = int(Gu.shape[0]) * int(Gu.shape[1]) * 4 >= (64 << 20)
-        env = os.environ.get("EL_COMPACT_UGRAD")
-        if compact_user_grads is None and env in ("0", "1"):
-            compact_user_grads = env == "1"
         self.compact = bool(self.opt == EL_OPT_ADAM_TF_DENSE and int(Gu.shape[1]) % 4 == 0 and optimizer != "sgd_dense" and
                             (big if compact_user_grads is None else compact_user_grads))
 
         # fused user side (el_bprmf_state.Gu_next): segments + Keras Adam over every user row in ONE kernel, the new rows written to a
-        # second table that swaps roles with Gu after every step -- whenever the compact form applies (EL_FUSED_USER=0: the
+        # second table that swaps roles with Gu after every step -- whenever the compact form applies (fused_user_step=False: the
         # two-kernel form, which grads() / apply() always use)
-        self.fused = bool(self.compact and fused_user_step is not False and os.environ.get("EL_FUSED_USER", "1") != "0"
+        self.fused = bool(self.compact and fused_user_step is not False
                           and int(Gu.shape[1]) <= 512)
         self.Gu_next = None
-        env_d = os.environ.get("EL_BPR_DEFERRED")
-        if deferred is None and env_d in ("0", "1"):
-            deferred = env_d == "1"
         self._deferred_auto = bool(self.fused and deferred is None)    # decided by the first batch size (_resolve_deferred)
         self.deferred = bool(self.fused and deferred is True)
         self._pending = False
-        self.item_fused = bool(self.fused and fused_item_step is not False and os.environ.get("EL_FUSED_ITEM", "1") != "0")
-        env_i = os.environ.get("EL_BPR_ITEM_DEFERRED")
-        if item_deferred is None and env_i in ("0", "1"):
-            item_deferred = env_i == "1"
+        self.item_fused = bool(self.fused and fused_item_step is not False)
         self._item_deferred_auto = bool(self.item_fused and item_deferred is None)
         self.item_deferred = bool(self.item_fused and item_deferred is True)
         self._pending_items = False
@@ -612,16 +596,10 @@ class BprmfDeviceState:
         self.gGi = self.item_grad_flat[:self.I * self.F].view(self.I, self.F)
         self.gBi = self.item_grad_flat[rows_end:]
         self._item_block = None
-        item_gap = os.environ.get("EL_ITEM_LAYOUT_GAP_MIB")
-        if adam and item_gap is not None and self.I * self.F * 4 >= (64 << 20):
-            # experiment (round 5): theta, m, v of the item table carved from ONE allocation a fixed distance apart, instead of three
-            # allocations wherever the allocator puts them -- k_bpr_item_seg is bimodal from process to process
-            (gi2, self.mGi, self.vGi), self._item_block = _strided_tables(self.I, self.F, 3, int(float(item_gap) * (1 << 20)), dev)
-            gi2.copy_(self._Gi)
-            self._Gi = gi2
-        else:
-            self.mGi = z(self._Gi) if adam else None
-            self.vGi = z(self._Gi) if adam else None
+        # (theta, m, v of the item table from ONE allocation a fixed distance apart was tried in round 5: consistent, not faster -- and the
+        #  process-to-process spread of the item kernels is not about these tables at all: profiles/r06_placement_probe.md)
+        self.mGi = z(self._Gi) if adam else None
+        self.vGi = z(self._Gi) if adam else None
         self.mBi = z(self._Bi) if adam else None
         self.vBi = z(self._Bi) if adam else None
         rows = self.opt in (EL_OPT_ADAM_LAZY, EL_OPT_SGD) and optimizer != "sgd_dense"
@@ -1173,12 +1151,12 @@ class NmfDeviceState:
 
     def __init__(self, ctx, weights, max_batch, dropout=0.0, dropout_seed=42, deferred=None):
         """deferred: Keras' every-row Adam decay of the embedding tables is postponed per row and replayed bit for bit when the
-        row is next needed (include/elliot_hip.h, el_nmf_state.row_last).  None = on unless EL_NMF_DEFERRED=0; a data-parallel
+        row is next needed (include/elliot_hip.h, el_nmf_state.row_last).  None = on; a data-parallel
         owner that all-reduces gtab of replicated tables turns it off (set_deferred(False); parallel.ShardedNmf does)."""
         self.ctx = ctx
         dev = ctx.device
         self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
-        self.deferred = (os.environ.get("EL_NMF_DEFERRED", "1") != "0") if deferred is None else bool(deferred)
+        self.deferred = True if deferred is None else bool(deferred)
         f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) if isinstance(x, np.ndarray) \
             else x.to(device=dev, dtype=torch.float32).contiguous().clone()
         self.use_mf = "Umf" in weights
@@ -1400,17 +1378,13 @@ class NmfDeviceState:
         layer 1 in its separable form, layers 2-3 and the head per (user, item) pair on fp32 MFMA tiles, selection fused.
         screen (full-catalogue calls only): layers 2-3 first on the half-precision matrix instruction with a per-pair error bound, the
         fp32 kernel on the surviving pairs -- the same lists and logit bits (EL_NMF_SCREEN in the header).  True / False force it;
-        None (default; EL_NMF_SCREEN=1 / 0 in the environment force it too) screens, and when a call had to take the unscreened
+        None (default) screens, and when a call had to take the unscreened
         route (the bound depends on the weights: el_nmf_screen_stats) leaves the next 15 calls unscreened before it tries again."""
         n = int(u_stop) - int(u_start)
         I_local = self.I - int(item_offset) if I_local is None else int(I_local)
         auto = screen is None
         if auto:
-            env = os.environ.get("EL_NMF_SCREEN", "auto")
-            if env in ("0", "1"):
-                screen, auto = env == "1", False
-            else:
-                screen = True
+            screen = True
         screen = bool(screen) and cand is None
         use = screen
         if auto and screen and getattr(self, "_screen_skip", 0) > 0:

@@ -477,6 +477,29 @@ class HipUserShardBackend:
     def item_grads(self):
         return [self.state.item_grad_flat]                    # gGi rows + gBi in one buffer: one collective per step
 
+    # -- row-sparse exchange of the item gradients (ShardedBprmfByUser, item_exchange="rows") --------------------------------
+    def touched_item_rows(self, i, j):
+        """The distinct items of this rank's batch (ascending) and their rows of the gradient accumulators the segment kernels just
+        filled: (ids int32 [n], dGi rows [n, F], dBi [n]).  Every non-zero row of gGi / gBi is in the list."""
+        st = self.state
+        ids = torch.unique(torch.cat([i, j]).to(torch.int64))
+        return ids.to(torch.int32), st.gGi.index_select(0, ids), st.gBi.index_select(0, ids)
+
+    def set_item_grads(self, ids_all, rows_all, bias_all):
+        """gGi / gBi <- the sum, per item, of the gathered (id, row) records of every rank -- the rows in the gathered order, which is
+        the same on every rank (el_rows_segment_sum: stable sort by id, one lane group walks a segment): identical replicas.  Every row
+        a rank's own batch touched is among the records, so every stale local row is overwritten with the global sum."""
+        import ctypes as C
+        st, ctx = self.state, self.ctx
+        n = int(ids_all.numel())
+        need = int(ctx.lib.el_rows_segment_sum_ws_bytes(n, int(st.I)))
+        if getattr(self, "_ws_rows", None) is None or self._ws_rows.numel() < need:
+            self._ws_rows = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+        for rows, F, out in ((rows_all, st.F, st.gGi), (bias_all, 1, st.gBi)):
+            ops.check(ctx.lib.el_rows_segment_sum(ctx.handle, ctx.stream(), ops._ptr(ids_all, torch.int32), ops._ptr(rows, torch.float32), n,
+                                                  int(F), int(st.I), ops._ptr(out, torch.float32), C.c_void_p(self._ws_rows.data_ptr()),
+                                                  self._ws_rows.numel()), "el_rows_segment_sum")
+
     def _apply(self, c_state, lr):
         import ctypes as C
         st, ctx = self.state, self.ctx
@@ -518,9 +541,37 @@ class ShardedBprmfByUser:
     reference-semantics step on the concatenated batch.  Full-catalogue top-k then needs no collective at all: each rank
     scores the users it owns."""
 
-    def __init__(self, backend, coll=None):
+    def __init__(self, backend, coll=None, item_exchange="dense"):
+        """item_exchange: how the item-side gradients meet.  "dense" -- one all-reduce of gGi [I, F] + gBi [I] (I (F + 1) 4 bytes whatever
+        the batch).  "rows" -- every rank contributes only the rows its batch touched: all-gather of (item id, dGi row, dBi) records,
+        padded to the longest list, then a segment sum per item in the gathered order on every rank (the same order everywhere:
+        identical replicas, and a deterministic sum -- the all-reduce's order is RCCL's).  G n (F + 2) 4 bytes for lists of n rows:
+        it wins while G^2 n < 2 (G - 1) I, i.e. for batches that touch a small part of the catalogue (pick_item_exchange)."""
+        if item_exchange not in ("dense", "rows"):
+            raise ValueError("item_exchange must be 'dense' or 'rows'")
         self.backend = backend
         self.coll = coll or _Collectives()
+        self.item_exchange = item_exchange
+        self.last_rows = None                                   # rows mode: (local list length, padded length) of the last step
+
+    def _exchange_rows(self, i, j):
+        """All-gather of the ranks' touched item rows.  One host synchronisation per step: the list lengths."""
+        be, coll = self.backend, self.coll
+        ids, rows, bias = be.touched_item_rows(i, j)
+        n = int(ids.shape[0])
+        if coll.world == 1 and not coll.always:
+            self.last_rows = (n, n)
+            return ids, rows, bias
+        cnt = coll.all_gather(torch.tensor([n], dtype=torch.int64, device=ids.device))
+        n_max = int(cnt.max().item())
+        self.last_rows = (n, n_max)
+        if n < n_max:                                            # padding records: a touched id of this rank with a zero row (adds nothing)
+            pad = n_max - n
+            fill = ids[:1] if n else torch.zeros(1, dtype=ids.dtype, device=ids.device)
+            ids = torch.cat([ids, fill.expand(pad)])
+            rows = torch.cat([rows, torch.zeros((pad, rows.shape[1]), dtype=rows.dtype, device=rows.device)])
+            bias = torch.cat([bias, torch.zeros(pad, dtype=bias.dtype, device=bias.device)])
+        return coll.all_gather(ids.contiguous()), coll.all_gather(rows.contiguous()), coll.all_gather(bias.contiguous())
 
     def train_step(self, u_local, i, j, lr, l_w, l_b, overlap=None, presorted=False):
         """overlap: optional callable enqueuing model-independent work (drawing AND ordering the NEXT batch: backend.presort)
@@ -531,6 +582,15 @@ class ShardedBprmfByUser:
             be.grads(u_local, i, j, l_w, l_b, presorted=True)
         else:
             be.grads(u_local, i, j, l_w, l_b)
+        if self.item_exchange == "rows":
+            gathered = self._exchange_rows(i, j)
+            be.begin_step()
+            be.apply_users(lr)
+            if overlap is not None:
+                overlap()
+            be.set_item_grads(*gathered)
+            be.apply_items(lr)
+            return
         if not hasattr(be, "apply_users"):                      # test backends: plain order
             for g in be.item_grads():
                 coll.all_reduce_sum(g)
@@ -553,6 +613,29 @@ class ShardedBprmfByUser:
         tot = self.coll.all_reduce_sum(t.clone())
         t.zero_()
         return float(tot.item())
+
+
+def expected_touched_items(n_items, batch_per_rank):
+    """Expected distinct items of one rank's batch when both of a triplet's items are drawn uniformly (an upper bound: the
+    positives of a real catalogue are popularity-skewed and collide more)."""
+    import math
+    return n_items * (1.0 - math.exp(-2.0 * batch_per_rank / max(1, n_items)))
+
+
+def item_exchange_bytes(n_items, F, batch_per_rank, world, rows=None):
+    """Bytes a rank puts on the wire per step for the item-gradient exchange of the user-sharded step: the dense all-reduce
+    (2 (G - 1) / G of the table) and the all-gather of touched rows ((G - 1) lists of `rows` records of F + 2 words arrive)."""
+    n = expected_touched_items(n_items, batch_per_rank) if rows is None else rows
+    return {"dense": 2.0 * (world - 1) / world * n_items * (F + 1) * 4, "rows": (world - 1) * n * (F + 2) * 4.0, "touched": n}
+
+
+def pick_item_exchange(n_items, F, batch_per_rank, world):
+    """ "rows" while the gathered lists are smaller than what the all-reduce moves; "dense" otherwise (every configuration of
+    BASELINE.json at B = 2^20 per rank: a batch touches 24 % (C5) to 88 % (C4) of the catalogue, eight of them all of it)."""
+    if world <= 1:
+        return "dense"
+    b = item_exchange_bytes(n_items, F, batch_per_rank, world)
+    return "rows" if b["rows"] < 0.8 * b["dense"] else "dense"
 
 
 def pick_exchange(n_users, batch_per_rank, world):

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; T=${1:-pmcs}; mkdir -p gpurun_out/$T
-export EL_NMF_SCREEN=1
+# (the screened route is the default of NmfDeviceState.score_topk_logits)
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/$T/pmc -o pmc --output-format csv -- python scripts/mb.py nmfscore --users 1250000 --items 1000000 --factors 128 --score-users 128 --iters 1 > gpurun_out/$T/pmc.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d $R/gpurun_out/$T/pmc2 -o pmc --output-format csv -- python scripts/mb.py nmfscore --users 1250000 --items 1000000 --factors 128 --score-users 128 --iters 1 >> gpurun_out/$T/pmc.log 2>&1
 python - <<'PY' > gpurun_out/$T/pmc_screen.txt 2>&1

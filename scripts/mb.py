@@ -25,15 +25,13 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20)
     ap.add_argument("--algo", default="mfma")
     ap.add_argument("--opt", default="adam_tf_dense")
-    ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-excl", action="store_true")
     ap.add_argument("--train-steps", type=int, default=0, help="topk: BPR steps (B = --batch, TF-dense Adam) on the tables before scoring -- "
                     "the candidate windows of the screened kernels depend on the norms a trained model has")
-    ap.add_argument("--sweep", default="", help="topk: comma list of stride:kA settings (EL_SCREEN_STRIDE / EL_SCREEN_KA) to time after the default")
+    ap.add_argument("--sweep", default="", help="topk: comma list of stride:kA settings (options screen_stride / screen_ka) to time after the default")
     ap.add_argument("--model", default="FunkSVD", choices=["MF", "PMF", "FunkSVD", "LogisticMF", "NeuMF", "GMF"])
     ap.add_argument("--shape", action="append", default=None, help="gemm: M,N,K,tA,tB (repeatable; default: the model shapes)")
     a = ap.parse_args()
-    os.environ["EL_TOPK_VARIANT"] = str(a.variant)
     ctx = ops.get_context(0)
     dev = ctx.device
     g = torch.Generator(device=dev)
@@ -189,11 +187,8 @@ def main():
             Gu, Gi, Bi = stt.Gu, stt.Gi, stt.Bi
         settings = [("default", None, None)] + [(x, x.split(":")[0], x.split(":")[1]) for x in a.sweep.split(",") if x]
         for name, sd, ka in settings:
-            for var, val in (("EL_SCREEN_STRIDE", sd), ("EL_SCREEN_KA", ka)):
-                if val is None:
-                    os.environ.pop(var, None)
-                else:
-                    os.environ[var] = val
+            for opt, val in (("screen_stride", sd), ("screen_ka", ka)):
+                ctx.set_option(opt, 0 if val is None else int(val))
             ctx.timing(False)
             ops.score_topk(ctx, Gu, Gi, Bi, 0, U, a.k, excl=None if a.no_excl else pos, algo=a.algo)   # warm-up: code load, workspace
             torch.cuda.synchronize()

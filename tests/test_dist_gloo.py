@@ -382,6 +382,18 @@ class NumpyUserShardBackend:
     def item_grads(self):
         return [self.gGi, self.gBi]
 
+    def touched_item_rows(self, i, j):
+        ids = torch.unique(torch.cat([i, j]).to(torch.int64))
+        return ids.to(torch.int32), self.gGi.index_select(0, ids), self.gBi.index_select(0, ids)
+
+    def set_item_grads(self, ids_all, rows_all, bias_all):
+        ids = ids_all.numpy().astype(np.int64)
+        touched = np.unique(ids)
+        g = np.zeros((self.gGi.shape[0], self.gGi.shape[1] + 1), np.float32)
+        np.add.at(g, ids, np.concatenate([rows_all.numpy(), bias_all.numpy()[:, None]], axis=1))     # (gathered order)
+        self.gGi[touched] = torch.from_numpy(g[touched, :-1])
+        self.gBi[touched] = torch.from_numpy(g[touched, -1])
+
     def _apply(self, which, lr):
         for n, (th, g, m, v) in enumerate(zip((self.Bi, self.Gu, self.Gi), (self.gBi.numpy(), self.gGu, self.gGi.numpy()), self.m, self.v)):
             if n in which:
@@ -409,7 +421,7 @@ class NumpyUserShardBackend:
         return self.loss
 
 
-def _user_shard_worker(rank, world, port, out):
+def _user_shard_worker(rank, world, port, out, item_exchange="dense"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -421,19 +433,24 @@ def _user_shard_worker(rank, world, port, out):
         Bi = rs.normal(scale=0.01, size=I).astype(np.float32)
         ulo, uhi = parallel.user_range(U, rank, world)
         be = NumpyUserShardBackend(Gu[ulo:uhi], Gi, Bi)
-        tr = parallel.ShardedBprmfByUser(be, parallel._Collectives())
+        tr = parallel.ShardedBprmfByUser(be, parallel._Collectives(), item_exchange=item_exchange)
         ref = ob.BPRMFBatchOracle(Gu, Gi, Bi, 0.01, 0.1, 0.001)
         for step in range(3):
             batches = []
             for r in range(world):
                 brs = np.random.RandomState(400 + 10 * step + r)
                 l, h = parallel.user_range(U, r, world)
-                batches.append((brs.randint(l, h, B), brs.randint(0, I, B), brs.randint(0, I, B)))   # items: whole catalogue
+                # items: whole catalogue; rows mode: rank 1 draws from a narrower range, so the ranks' lists differ in length (padding)
+                hi_i = I if (item_exchange == "dense" or r == 0) else I // 3
+                batches.append((brs.randint(l, h, B), brs.randint(0, hi_i, B), brs.randint(0, hi_i, B)))
             u, i, j = batches[rank]
             tr.train_step(torch.from_numpy((u - ulo).astype(np.int32)), torch.from_numpy(i.astype(np.int32)),
                           torch.from_numpy(j.astype(np.int32)), 0.01, 0.1, 0.001)
             loss = tr.pop_loss()
             assert be.order == ["users", "items"]            # own rows under the collective, the replica after it
+            if item_exchange == "rows":
+                n, n_max = tr.last_rows
+                assert n <= n_max and (rank == 0 or n < n_max)                # rank 1's list is the shorter one: padded records in play
             cu, ci, cj = (np.concatenate([b[x] for b in batches]) for x in range(3))
             ref_loss = ref.train_step((cu, ci, cj))
             assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss), (loss, ref_loss)
@@ -449,12 +466,17 @@ def _user_shard_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(120)
-def test_user_sharded_training_world2_gloo():
+@pytest.mark.parametrize("item_exchange", ["dense", "rows"])
+def test_user_sharded_training_world2_gloo(item_exchange):
+    """User shards over two gloo ranks == one reference-semantics step on the concatenated batch -- with the item gradients meeting in
+    one dense all-reduce, and with the row-sparse exchange (all-gather of each rank's touched (item id, gradient row) records, lists of
+    unequal length, segment sum in the gathered order on every rank)."""
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_user_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_user_shard_worker, args=(2, port, out, item_exchange), nprocs=2, join=True)
     assert dict(out) == {0: 1, 1: 1}
+    assert parallel.pick_item_exchange(5_000_000, 256, 1 << 20, 8) == "dense" and parallel.pick_item_exchange(5_000_000, 256, 1 << 14, 8) == "rows"
     assert [parallel.user_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
 
 

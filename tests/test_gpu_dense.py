@@ -33,7 +33,7 @@ def test_gemm_matches_fp64(ctx, tA, tB, M, N, K):
 
 
 @pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_three_way_split_is_fp32_grade(ctx, tA, tB, monkeypatch):
+def test_gemm_three_way_split_is_fp32_grade(ctx, tA, tB, lib_option):
     """k_gemm_b3 (fp32 operands as three bf16 planes, six products on the bf16 matrix instruction) against the fp32 matrix
     instruction on the same operands -- entries spread over 12 orders of magnitude, sums that cancel: its error against fp64 stays
     within 2x the fp32 instruction's own (both are a few ulp of sum |a b|), edge tiles and a split K included."""
@@ -44,9 +44,9 @@ def test_gemm_three_way_split_is_fp32_grade(ctx, tA, tB, monkeypatch):
         d = ctx.device
         a64, b64 = (A.T if tA else A).astype(np.float64), (Bm.T if tB else Bm).astype(np.float64)
         ref, mag = a64 @ b64, np.abs(a64) @ np.abs(b64)
-        monkeypatch.setenv("EL_GEMM_SPLIT", "1")
+        lib_option("gemm_split", 1)
         got3 = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
-        monkeypatch.setenv("EL_GEMM_SPLIT", "0")
+        lib_option("gemm_split", 0)
         got1 = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
         e3, e1 = np.abs(got3 - ref) / mag, np.abs(got1 - ref) / mag
         assert e3.max() <= max(2.0 * e1.max(), 4 * 2.0 ** -24), (M, N, K, float(e3.max()), float(e1.max()))
@@ -54,61 +54,32 @@ def test_gemm_three_way_split_is_fp32_grade(ctx, tA, tB, monkeypatch):
 
 
 @pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_with_staging_waves_equals_the_one_role_kernel_bit_for_bit(ctx, tA, tB, monkeypatch):
-    """k_gemm_b3w (four waves stage, four multiply, two LDS buffers) performs the products of k_gemm_b3 in the same order on the same
-    fragment images: identical bits -- whole tiles, edge tiles, a K that is no multiple of the k tile, a split K (same split count
-    forced through the workspace-less call is not possible, so the split case compares against fp64 instead), bias + activation in
-    the epilogue, the XCD-aware workgroup order on and off."""
+def test_gemm_xcd_aware_order_equals_the_plain_grid_bit_for_bit(ctx, tA, tB, lib_option):
+    """k_gemm_b3 with its tiles dealt to the XCDs in groups that share an operand strip (option gemm_xcd, the default) against the plain
+    3-D grid: the same tiles, the same products in the same order -- identical bits: whole tiles, edge tiles, a K that is no multiple of
+    the k tile, bias + activation in the epilogue; the split-K form (partials in the workspace + k_gemm_reduce) against fp64."""
     rs = np.random.RandomState(11)
     d = ctx.device
-    for M, N, K in ((512, 26744, 600), (600, 1304, 1500), (260, 520, 8004), (128, 1028, 8000)):
+    for M, N, K in ((512, 26744, 600), (600, 1304, 1500), (260, 520, 8004), (128, 1028, 8000), (8200, 4100, 260), (33000, 1028, 128)):
         A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
         Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
         bias = rs.normal(size=N).astype(np.float32)
         At, Bt, bt = torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), torch.from_numpy(bias).to(d)
         outs = {}
-        for w, x in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
-            monkeypatch.setenv("EL_GEMM_B3W", w)
-            monkeypatch.setenv("EL_GEMM_XCD", x)
-            outs[(w, x)] = (ops.gemm(ctx, At, Bt, tA, tB, ws=False).clone(), ops.gemm(ctx, At, Bt, tA, tB, bias=bt, act="relu", ws=False).clone())
-        ref = outs[("0", "0")]
-        for key, val in outs.items():
-            assert torch.equal(val[0].view(torch.int32), ref[0].view(torch.int32)), (M, N, K, key)
-            assert torch.equal(val[1].view(torch.int32), ref[1].view(torch.int32)), (M, N, K, key)
-    # long K, few tiles: the split-K form (partials in the workspace + k_gemm_reduce) of either kernel against fp64
-    M, N, K = 512, 600, 26744
+        for x in (1, 0):
+            lib_option("gemm_xcd", x)
+            outs[x] = (ops.gemm(ctx, At, Bt, tA, tB, ws=False).clone(), ops.gemm(ctx, At, Bt, tA, tB, bias=bt, act="relu", ws=False).clone())
+        assert torch.equal(outs[1][0].view(torch.int32), outs[0][0].view(torch.int32)), (M, N, K)
+        assert torch.equal(outs[1][1].view(torch.int32), outs[0][1].view(torch.int32)), (M, N, K)
+        r64 = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
+        assert np.abs(cpu(outs[1][0]) - r64).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02
+    lib_option("gemm_xcd", 1)
+    M, N, K = 512, 600, 26744                                  # long K, few tiles: split K
     A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
     Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
     ref = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
-    for w in ("1", "0"):
-        monkeypatch.setenv("EL_GEMM_B3W", w)
-        got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
-        assert np.abs(got - ref).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02, w
-
-
-@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_with_several_tiles_per_workgroup_equals_the_one_tile_kernel_bit_for_bit(ctx, tA, tB, monkeypatch):
-    """k_gemm_b3p (a workgroup walks several output tiles, the next tile's first operands in flight under the epilogue of the current
-    one) against k_gemm_b3 on products it is chosen for (>= 4 tiles per workgroup slot, short K): identical bits, with edge tiles in
-    both dimensions, a K that is no multiple of the k tile, bias + ReLU in the epilogue, XCD-aware order on and off."""
-    rs = np.random.RandomState(13)
-    d = ctx.device
-    for M, N, K in ((8200, 4100, 260), (33000, 1028, 128)):
-        A = rs.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
-        Bm = rs.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
-        bias = rs.normal(size=N).astype(np.float32)
-        At, Bt, bt = torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), torch.from_numpy(bias).to(d)
-        outs = {}
-        for pz, x in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
-            monkeypatch.setenv("EL_GEMM_PERSIST", pz)
-            monkeypatch.setenv("EL_GEMM_XCD", x)
-            outs[(pz, x)] = (ops.gemm(ctx, At, Bt, tA, tB, ws=False).clone(), ops.gemm(ctx, At, Bt, tA, tB, bias=bt, act="relu", ws=False).clone())
-        ref = outs[("0", "0")]
-        for key, val in outs.items():
-            assert torch.equal(val[0].view(torch.int32), ref[0].view(torch.int32)), (M, N, K, key)
-            assert torch.equal(val[1].view(torch.int32), ref[1].view(torch.int32)), (M, N, K, key)
-        r64 = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
-        assert np.abs(cpu(ref[0]) - r64).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02
+    got = cpu(ops.gemm(ctx, torch.from_numpy(A).to(d), torch.from_numpy(Bm).to(d), tA, tB))
+    assert np.abs(got - ref).max() < 3e-6 * np.sqrt(K) * 4 + 1e-6 * K * 0.02
 
 
 def test_gemm_unaligned_leading_dims(ctx):

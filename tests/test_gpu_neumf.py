@@ -187,9 +187,9 @@ def _relu_branch_audit(st, w, n):
 
 
 @pytest.mark.parametrize("split", ["0", "1"])
-def test_neumf_step_at_d128_matches_oracle(ctx, monkeypatch, split):
+def test_neumf_step_at_d128_matches_oracle(ctx, lib_option, split):
     """BASELINE configs[3] model shape: d = 128, tower (512, 256, 128) (neural_matrix_factorization.py:71-72), batch 65 536 -- the
-    GEMM shapes of the full-size run, on the fp32 matrix instruction (EL_GEMM_SPLIT=0) and on the three-way bf16 split (=1, the
+    GEMM shapes of the full-size run, on the fp32 matrix instruction (option gemm_split = 0) and on the three-way bf16 split (=1, the
     default for these shapes); users x items kept small so that the NumPy oracle finishes in seconds.  Ten batches.
 
     The ReLU derivative is a step function: of the 58 M unit evaluations of a batch a few have a pre-activation within fp32
@@ -202,7 +202,7 @@ def test_neumf_step_at_d128_matches_oracle(ctx, monkeypatch, split):
         64x the fp32 oracle's own rms distance from fp64), none further than 5 % of the largest entry;
       weights after Keras Adam (first batch): <= 2e-3 of the entries off by more than 2e-5, none by more than 5 lr.
     Match: neural_matrix_factorization_model.py:96-106."""
-    monkeypatch.setenv("EL_GEMM_SPLIT", split)
+    lib_option("gemm_split", int(split))
     U, I, F, B, lr = 20000, 8000, 128, 65536, 0.001
     w0 = on.init_neumf(U, I, F, 3)
     st = ops.NmfDeviceState(ctx, w0, max_batch=B)
@@ -264,7 +264,7 @@ def test_neumf_step_at_d128_matches_oracle(ctx, monkeypatch, split):
                 for a, b in pairs:
                     err = np.abs(a - b)
                     assert int((err > 2e-5).sum()) <= max(2, int(2e-3 * err.size)) and err.max() < 5 * lr, (k, float(err.max()), int((err > 2e-5).sum()))
-    print(f"EL_GEMM_SPLIT={split}: {total_flips} ReLU units took the other branch than fp64 over 10 batches x 58.7 M unit evaluations")
+    print(f"gemm_split={split}: {total_flips} ReLU units took the other branch than fp64 over 10 batches x 58.7 M unit evaluations")
 
 
 def test_pointwise_replay_sampler_emits_the_reference_stream(ctx, golden):

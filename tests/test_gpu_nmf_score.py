@@ -223,13 +223,13 @@ def test_unsupported_tower_takes_the_pair_route(ctx):
 # ---------------------------------------------------------------------------------------------------- screened route (EL_NMF_SCREEN)
 @pytest.mark.parametrize("F,units,k,I", [(128, None, 10, 30000), (64, None, 20, 9000), (32, [128, 64, 32], 10, 6000), (16, [72, 40, 16], 50, 5000),
                                          (128, None, 100, 12000), (24, [300, 128, 40], 10, 7000)])
-def test_screened_route_returns_the_unscreened_lists_and_logit_bits(ctx, F, units, k, I, monkeypatch):
+def test_screened_route_returns_the_unscreened_lists_and_logit_bits(ctx, F, units, k, I, monkeypatch, lib_option):
     """EL_NMF_SCREEN: layers 2-3 on the half-precision matrix instruction with a per-pair error bound, a per-user threshold from the
     lower bounds, the fp32 kernel on the pairs whose upper bound reaches it.  The answer is the fp32 kernel's: index lists and logit
     bits equal the unscreened call's -- with an exclusion CSR, without, on an item shard with its offset, with the item image kept
-    from the previous call.  (EL_NMF_SCREEN_MAXFRAC = 1: the candidate route runs whatever share of the pairs survives -- with
+    from the previous call.  (the option nmf_screen_maxfrac = 1: the candidate route runs whatever share of the pairs survives -- with
     these scaled-up weights and biases the bound keeps most of them, which exercises the candidate regions at every fill.)"""
-    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    lib_option("nmf_screen_maxfrac", 1.0)
     U = 48
     w = _weights(U, I, F, seed=F + k, units=units)
     st = ops.NmfDeviceState(ctx, w, max_batch=1024)
@@ -273,27 +273,26 @@ def test_screened_route_on_glorot_weights_filters_and_matches_the_oracle(ctx):
     assert_topk_equal("nmf_screen_d128", cpu(idx[:2]), cpu(val[:2]), ei, ev)
 
 
-def test_screened_route_falls_back_when_too_many_pairs_survive_or_a_row_is_short(ctx, monkeypatch):
-    """More surviving pairs than EL_NMF_SCREEN_MAXFRAC of the block, or a user with fewer than k unmasked items, sends the call
+def test_screened_route_falls_back_when_too_many_pairs_survive_or_a_row_is_short(ctx, monkeypatch, lib_option):
+    """More surviving pairs than the option nmf_screen_maxfrac of the block, or a user with fewer than k unmasked items, sends the call
     through the unscreened route: same answer, `fell_back` set; the default policy of score_topk_logits then leaves the next calls
     unscreened."""
     U, I, F, k = 12, 8000, 32, 10
     w = _weights(U, I, F, seed=9)
     st = ops.NmfDeviceState(ctx, w, max_batch=512)
     ref_i, ref_v = st.score_topk_logits(0, U, k, screen=False)
-    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "0.0001")           # 9.6 pairs: fewer than the k * U the lists themselves need
+    lib_option("nmf_screen_maxfrac", 0.0001)           # 9.6 pairs: fewer than the k * U the lists themselves need
     got_i, got_v = st.score_topk_logits(0, U, k, screen=True)
     pairs, fell_back = st.screen_stats()
     assert fell_back and pairs == U * I                           # the exact kernel scored every pair
     assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
-    monkeypatch.delenv("EL_NMF_SCREEN", raising=False)
     got_i, got_v = st.score_topk_logits(0, U, k)                   # default policy: screens, falls back, ...
     assert st.screen_stats()[1] and st._screen_skip == 15
     assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
     got_i, got_v = st.score_topk_logits(0, U, k)                   # ... and does not try again at once
     assert st.screen_stats() == (U * I, False) and st._screen_skip == 14
     assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
-    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    lib_option("nmf_screen_maxfrac", 1.0)
     # user 3 keeps only 4 unmasked items
     keep = np.array([5, 77, 4000, 7999])
     rows = [np.zeros(0, np.int32)] * U
@@ -307,10 +306,10 @@ def test_screened_route_falls_back_when_too_many_pairs_survive_or_a_row_is_short
     assert torch.equal(got_i, ref_i) and torch.equal(got_v.view(torch.int32), ref_v.view(torch.int32))
 
 
-def test_screened_route_survives_activations_past_the_half_range(ctx, monkeypatch):
+def test_screened_route_survives_activations_past_the_half_range(ctx, monkeypatch, lib_option):
     """Weights large enough for layer-1 activations beyond 65504: the half-precision pass overflows (inf, NaN), those pairs carry no
     bound and go to the exact kernel; the lists are still the unscreened call's."""
-    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    lib_option("nmf_screen_maxfrac", 1.0)
     U, I, F, k = 8, 6000, 32, 10
     w = _weights(U, I, F, seed=4)
     w["Umlp"] = (w["Umlp"] * 3e4).astype(np.float32)               # PU_u ~ 1e5 on some units
@@ -341,13 +340,13 @@ def test_screened_route_rebuilds_its_item_image_after_an_unscreened_call_rebuilt
 
 
 @pytest.mark.parametrize("between", ["nothing", "unscreened_call"])
-def test_screened_route_keeps_its_item_image_across_user_blocks_of_other_sizes(ctx, between, monkeypatch):
-    """(EL_NMF_SCREEN_MAXFRAC = 1: whatever share survives, the screened route is taken.)
+def test_screened_route_keeps_its_item_image_across_user_blocks_of_other_sizes(ctx, between, monkeypatch, lib_option):
+    """(the option nmf_screen_maxfrac = 1: whatever share survives, the screened route is taken.)
     The last, shorter user block of an evaluation reuses the workspace with EL_TOPK_ITEMS_UNCHANGED: the half-precision item image
     and its residual norms must be found where the full block built them (they sit in front of every region sized by the user range,
     k or the split), and an unscreened call in between -- whose user-side regions lie over the image -- forces their rebuild.  Lists
     and logit bits equal the unscreened call's either way, for a shorter block, another k, and a longer block again."""
-    monkeypatch.setenv("EL_NMF_SCREEN_MAXFRAC", "1.0")
+    lib_option("nmf_screen_maxfrac", 1.0)
     U, I, F = 300, 40_000, 64
     w = on.init_neumf(U, I, F, 31)
     st = ops.NmfDeviceState(ctx, w, max_batch=1024)
