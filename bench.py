@@ -91,6 +91,9 @@ def parse():
                          "ITEM table (north_star's formulation: user table replicated, user-gradient exchange per --exchange)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "dense"],
                     help="N > 1, item shards: how user-row gradients travel (parallel.pick_exchange)")
+    ap.add_argument("--item-exchange", default="auto", choices=["auto", "dense", "rows"],
+                    help="N > 1, user shards: the item gradients meet in one dense all-reduce of [I, F + 1], or as an all-gather of each rank's "
+                         "touched (item id, gradient row) records (parallel.pick_item_exchange: rows only while the lists are smaller)")
     ap.add_argument("--topk-shard", default=None, choices=["user", "item"],
                     help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial "
                          "top-k (default: user for --shard user, item for the item-shard leg)")
@@ -545,7 +548,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         uix = indices[int(indptr[ulo]):int(indptr[uhi])].contiguous()
         pos_train = ops.DeviceCSR.from_tensors(uip, uix, I)
         be = parallel.HipUserShardBackend(ctx, Gu[ulo:uhi], Gi, Bi, optimizer=args.opt)
-        trainer = parallel.ShardedBprmfByUser(be, coll)
+        item_ex = args.item_exchange if args.item_exchange != "auto" else parallel.pick_item_exchange(I, F, B, world)
+        trainer = parallel.ShardedBprmfByUser(be, coll, item_exchange=item_ex)
         st = be.state
         exchange = "user"
         # the triplets of step t+1 are drawn AND sorted while step t's all-reduce is in flight (neither reads the model):
@@ -566,8 +570,14 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
 
         pop_loss = trainer.pop_loss
         scratch = torch.zeros_like(st.item_grad_flat)
-        collectives.append(("item gradients gGi [I,F] + gBi [I]", "all_reduce", scratch.numel() * 4,
-                            lambda: coll.all_reduce_sum(scratch)))
+        ixb = parallel.item_exchange_bytes(I, F, B, world)
+        n_touch = int(ixb["touched"])
+        rows_scratch = torch.zeros((max(1, n_touch), F + 2), dtype=torch.float32, device=dev)
+        # both forms are timed and priced (expected_ms: the wire model); the step itself runs `item_ex`
+        collectives.append(("item gradients gGi [I,F] + gBi [I], dense" + (" (in use)" if item_ex == "dense" else ""), "all_reduce",
+                            scratch.numel() * 4, lambda: coll.all_reduce_sum(scratch)))
+        collectives.append((f"item gradients as touched rows: ~{n_touch} (id, dGi row, dBi) records per rank" + (" (in use)" if item_ex == "rows" else ""),
+                            "all_gather", world * rows_scratch.numel() * 4, lambda: coll.all_gather(rows_scratch)))
     else:
         # item-sharded training: B triplets PER RANK with positive and negative inside the rank's shard, exchange of the
         # user-row gradients, identical user-table replicas (elliot_amd/parallel.py)
@@ -843,7 +853,8 @@ def bpr_leg(args, ctx, world, rank, data, shard, topk_shard, with_metrics=False,
         par = "single"
     elif exchange == "user":
         par = (f"user-shard x{world}: train = {B} triplets/rank for the rank's own users (item table replicated) + "
-               f"all-reduce of the item gradients ({I * (F + 1) * 4 / 1e6:.0f} MB)")
+               + (f"all-reduce of the item gradients ({I * (F + 1) * 4 / 1e6:.0f} MB)" if item_ex == "dense" else
+                  f"all-gather of the ranks' touched item-gradient rows (~{n_touch} records of {F + 2} words per rank)"))
     else:
         par = (f"item-shard x{world}: train = {B} triplets/rank + "
                + ("reduce-scatter of the dense user-gradient table, optimiser on U/G user rows, all-gather of the rows"

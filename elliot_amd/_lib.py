@@ -62,6 +62,21 @@ class VaeState(C.Structure):
 _P4 = C.c_void_p * 4
 
 
+class GraphCsr(C.Structure):
+    _fields_ = [
+        ("indptr", _i64p), ("indices", _i32p), ("vals", _f32p), ("N", C.c_int64), ("n0", C.c_int64),
+        ("chunk_row", _i32p), ("chunk_lo", _i64p), ("chunk_slot", _i32p), ("n_chunks", C.c_int64),
+        ("multi_row", _i32p), ("multi_slot", _i32p), ("multi_cnt", _i32p), ("n_multi", C.c_int64), ("part", _f32p),
+    ]
+
+
+class Mf2020State(C.Structure):
+    _fields_ = [
+        ("P", _f64p), ("Q", _f64p), ("bu", _f64p), ("bi", _f64p), ("gb", _f64p),
+        ("U", C.c_int64), ("I", C.c_int64), ("F", C.c_int32), ("lr", C.c_double), ("reg", C.c_double),
+    ]
+
+
 class NmfState(C.Structure):
     _fields_ = [
         ("U", C.c_int64), ("I", C.c_int64), ("Bmax", C.c_int64),
@@ -149,6 +164,10 @@ PROTOTYPES = {
     "el_rows_segment_sum": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int32, C.c_int64, _f32p,
                                       C.c_void_p, C.c_size_t]),
     "el_bprmf_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), C.c_float, C.c_int, C.c_int32, C.c_float]),
+    "el_spmm_csr_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GraphCsr), _f32p, _f32p, C.c_int32, _f32p, _f32p]),
+    "el_lightgcn_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "el_lightgcn_propagate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GraphCsr), _f32p, _f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "el_mf2020_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Mf2020State), _i32p, C.c_int64, _f64p]),
     "el_bprsgd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,
                                   C.c_int64, C.c_int64]),
     "el_bprsgd_apply_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,

@@ -936,6 +936,140 @@ class BprmfDeviceState:
         return v
 
 
+
+# ------------------------------------------------------------------------------------------
+# graph propagation: LightGCN (graph_based/lightgcn) -- SURVEY 8f N3
+# ------------------------------------------------------------------------------------------
+SPMM_CHUNK = 512          # el_graph.hip: SPMM_CH
+
+
+def normalized_bipartite_laplacian(train_csr_indptr, train_csr_indices, n_users, n_items):
+    """LightGCN._create_adj_mat (LightGCN.py:96-118) without the dok / lil detour: the symmetric adjacency over U + I nodes (users first),
+    D^-1/2 A D^-1/2 with the reference's arithmetic -- fp32 row sums + 1e-7 (added in fp32), power -1/2 in fp32, the two diagonal
+    products one fp32 multiplication each: value(r, c) = fl(fl(1 * dinv[c]) * dinv[r]).  Returns CSR (indptr int64, indices int32
+    ascending, vals fp32) as NumPy arrays.  (The reference's own construction is pinned against this one in tests/test_oracle_graph.py.)"""
+    import scipy.sparse as sp
+    indptr = np.asarray(train_csr_indptr, dtype=np.int64)
+    cols = np.asarray(train_csr_indices, dtype=np.int64)
+    T = cols.shape[0]
+    rows = np.repeat(np.arange(n_users, dtype=np.int64), np.diff(indptr))
+    N = n_users + n_items
+    A = sp.csr_matrix((np.ones(2 * T, np.float32), (np.concatenate([rows, cols + n_users]), np.concatenate([cols + n_users, rows]))), shape=(N, N))
+    A.sum_duplicates()
+    A.data[:] = 1.0                                              # (a dok assignment of the ratings matrix: entries are the stored values;
+    #                                                               sp_i_train holds ones, dataset.py:236-241)
+    rowsum = np.asarray(A.sum(1), dtype=np.float32).reshape(-1)
+    rowsum = rowsum + np.float32(1e-7)
+    dinv = np.power(rowsum, np.float32(-0.5)).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0.0
+    A.sort_indices()
+    r = np.repeat(np.arange(N, dtype=np.int64), np.diff(A.indptr))
+    vals = (A.data.astype(np.float32) * dinv[A.indices]).astype(np.float32) * dinv[r]
+    return A.indptr.astype(np.int64), A.indices.astype(np.int32), vals.astype(np.float32)
+
+
+class GraphCSR:
+    """el_graph_csr: a sparse N x N operator over the stacked [users; items] table, device-resident, with the chunk decomposition
+    of its product (every row cut into chunks of <= 512 non-zeros; multi-chunk rows reduce their partial rows in order)."""
+
+    def __init__(self, ctx, indptr, indices, vals, n_users, width):
+        dev = ctx.device
+        self.ctx = ctx
+        t = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt).contiguous()
+        self.indptr, self.indices, self.vals = t(indptr, torch.int64), t(indices, torch.int32), t(vals, torch.float32)
+        self.N, self.n0, self.width = int(self.indptr.numel() - 1), int(n_users), int(width)
+        ln = self.indptr[1:] - self.indptr[:-1]
+        nch = torch.clamp((ln + SPMM_CHUNK - 1) // SPMM_CHUNK, min=1)                 # an empty row keeps one (empty) chunk
+        first = torch.cumsum(nch, 0) - nch                                            # first chunk of every row
+        n_chunks = int(nch.sum().item())
+        row_of = torch.repeat_interleave(torch.arange(self.N, device=dev, dtype=torch.int64), nch)
+        k_in_row = torch.arange(n_chunks, device=dev, dtype=torch.int64) - first[row_of]
+        self.chunk_row = row_of.to(torch.int32)
+        self.chunk_lo = (self.indptr[:-1][row_of] + k_in_row * SPMM_CHUNK).contiguous()
+        multi = nch > 1
+        mrows = torch.nonzero(multi).flatten()
+        mcnt = nch[mrows]
+        mfirst = torch.cumsum(mcnt, 0) - mcnt                                         # first partial slot of every multi-chunk row
+        slot_of_row = torch.full((self.N,), -1, dtype=torch.int64, device=dev)
+        slot_of_row[mrows] = mfirst
+        cs = slot_of_row[row_of]
+        self.chunk_slot = torch.where(cs >= 0, cs + k_in_row, cs).to(torch.int32)
+        self.multi_row, self.multi_slot, self.multi_cnt = mrows.to(torch.int32), mfirst.to(torch.int32), mcnt.to(torch.int32)
+        n_part = int(mcnt.sum().item()) if mrows.numel() else 0
+        self.part = torch.empty((max(n_part, 1), self.width), dtype=torch.float32, device=dev)
+        p = lambda x: x.data_ptr()
+        self._c = _lib.GraphCsr(indptr=p(self.indptr), indices=p(self.indices), vals=p(self.vals), N=self.N, n0=self.n0,
+                                chunk_row=p(self.chunk_row), chunk_lo=p(self.chunk_lo), chunk_slot=p(self.chunk_slot), n_chunks=n_chunks,
+                                multi_row=p(self.multi_row) if mrows.numel() else None, multi_slot=p(self.multi_slot) if mrows.numel() else None,
+                                multi_cnt=p(self.multi_cnt) if mrows.numel() else None, n_multi=int(mrows.numel()), part=p(self.part))
+
+    @property
+    def nnz(self):
+        return int(self.indices.numel())
+
+    def spmm(self, X0, X1, out0=None, out1=None):
+        """[Y0; Y1] = L [X0; X1] (el_spmm_csr_f32)."""
+        F = int(X0.shape[1])
+        if F > self.width:
+            raise ValueError("GraphCSR was sized for narrower tables")
+        out0 = torch.empty_like(X0) if out0 is None else out0
+        out1 = torch.empty_like(X1) if out1 is None else out1
+        check(self.ctx.lib.el_spmm_csr_f32(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(X0, torch.float32), _ptr(X1, torch.float32),
+                                           F, _ptr(out0, torch.float32), _ptr(out1, torch.float32)), "el_spmm_csr_f32")
+        return out0, out1
+
+
+class LightGcnDeviceState:
+    """LightGCN_model (graph_based/lightgcn/LightGCN_model.py:19-172) in HBM: Gu / Gi with Keras Adam slots + the normalised adjacency.
+    One train step = `_propagate_embeddings` (ASSIGNED to the variables, :93-94) + the BPR head of BPRMF_batch without an item bias and
+    with the L2 term doubled (:150-158) + Adam's every-row apply -- the head runs on the segment kernels of the BPR-MF path
+    (BprmfDeviceState with the every-row fused forms: the propagation reads and rewrites every row each step, nothing may wait)."""
+
+    def __init__(self, ctx, Gu, Gi, graph, n_layers=1):
+        self.ctx, self.graph, self.n_layers = ctx, graph, int(n_layers)
+        self.bpr = BprmfDeviceState(ctx, Gu, Gi, np.zeros(int(Gi.shape[0]), np.float32), optimizer="adam_tf_dense", deferred=False,
+                                    item_deferred=False)
+        self.U, self.I, self.F = self.bpr.U, self.bpr.I, self.bpr.F
+        if graph.N != self.U + self.I or graph.n0 != self.U:
+            raise ValueError("the graph does not describe these tables")
+        need = int(ctx.lib.el_lightgcn_ws_bytes(self.U, self.I, self.F, self.n_layers))
+        self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=ctx.device)
+
+    @property
+    def Gu(self):
+        return self.bpr.Gu
+
+    @property
+    def Gi(self):
+        return self.bpr.Gi
+
+    @property
+    def step(self):
+        return self.bpr.step
+
+    def propagate(self):
+        """_propagate_embeddings (:68-94), in place."""
+        st = self.bpr
+        st.sync()
+        check(self.ctx.lib.el_lightgcn_propagate(self.ctx.handle, self.ctx.stream(), C.byref(self.graph._c), _ptr(st._Gu, torch.float32),
+                                                 _ptr(st._Gi, torch.float32), self.F, self.n_layers, C.c_void_p(self._ws.data_ptr()),
+                                                 self._ws.numel()), "el_lightgcn_propagate")
+
+    def train_step(self, u, i, j, lr, l_w):
+        """train_step (:136-167): propagate, then the BPR step on the propagated tables.  reg_loss = l_w * sum(l2_loss) * 2 is the
+        BPRMF_batch head's l_w * sum(l2_loss) with twice the coefficient; there is no item bias: the bias slot of the BPR state is
+        kept at zero (its gradient -- the triplet's dloss/dd -- is discarded after every step), l_b = 0."""
+        self.propagate()
+        st = self.bpr
+        st.train_step(u, i, j, lr, 2.0 * float(l_w), 0.0)
+        st.sync()
+        st._Bi.zero_()
+        st.mBi.zero_()
+        st.vBi.zero_()
+
+    def pop_loss(self):
+        return self.bpr.pop_loss()
+
 # ------------------------------------------------------------------------------------------
 # BPRMF (NumPy semantics, fp64)
 # ------------------------------------------------------------------------------------------
@@ -978,6 +1112,42 @@ class BprSgdDeviceState:
                                                   _ptr(u), _ptr(i), _ptr(j), starts.ctypes.data_as(C.c_void_p),
                                                   int(starts.shape[0] - 1)), "el_bprsgd_apply_levels")
         return int(starts.shape[0] - 1)
+
+
+class Mf2020DeviceState:
+    """MFModel of MF2020 (latent_factor_models/MF2020/MF_model.py:14-56) in HBM, fp64: user / item factors, the two bias vectors, the
+    global bias.  train(samples) = MFModel.train_step (:80-113) on one batch of (user, item, rating) rows, in order."""
+
+    def __init__(self, ctx, P, Q, bu=None, bi=None, gb=0.0, lr=0.05, reg=0.0):
+        self.ctx = ctx
+        dev = ctx.device
+        own = lambda x: (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).to(device=dev, dtype=torch.float64).contiguous().clone()
+        self.P, self.Q = own(P), own(Q)
+        self.U, self.F = int(self.P.shape[0]), int(self.P.shape[1])
+        self.I = int(self.Q.shape[0])
+        self.bu = own(bu) if bu is not None else torch.zeros(self.U, dtype=torch.float64, device=dev)
+        self.bi = own(bi) if bi is not None else torch.zeros(self.I, dtype=torch.float64, device=dev)
+        self.gb = torch.full((1,), float(gb), dtype=torch.float64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.lr, self.reg = float(lr), float(reg)
+        self._c = _lib.Mf2020State(P=self.P.data_ptr(), Q=self.Q.data_ptr(), bu=self.bu.data_ptr(), bi=self.bi.data_ptr(), gb=self.gb.data_ptr(),
+                                   U=self.U, I=self.I, F=self.F, lr=self.lr, reg=self.reg)
+
+    def train(self, samples):
+        """samples: int32 [n, 3] device tensor of (user, item, rating) rows; the sum of their losses accumulates in self.loss."""
+        s = samples.to(device=self.ctx.device, dtype=torch.int32).contiguous()
+        check(self.ctx.lib.el_mf2020_train(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(s, torch.int32), int(s.shape[0]),
+                                           _ptr(self.loss, torch.float64)), "el_mf2020_train")
+
+    def pop_loss(self):
+        v = float(self.loss.item())
+        self.loss.zero_()
+        return v
+
+    def predictions(self):
+        """prepare_predictions (:115-116): user_bias[:, None] + (global_bias + item_bias + P Q^T), fp64 [U, I] (small catalogues only:
+        the reference materialises it too)."""
+        return self.bu[:, None] + (self.gb + self.bi[None, :] + self.P @ self.Q.T)
 
 
 def sgd_levels(u_host, i_host, j_host, U, I):

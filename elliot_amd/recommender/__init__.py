@@ -8,6 +8,8 @@ from .latent_factor_models.PMF.probabilistic_matrix_factorization import PMF
 from .latent_factor_models.FunkSVD.funk_svd import FunkSVD
 from .latent_factor_models.LogisticMF.logistic_matrix_factorization import LMF, LogisticMatrixFactorization
 from .latent_factor_models.CML.CML import CML
+from .latent_factor_models.MF2020.MF import MF2020
+from .graph_based.lightgcn.LightGCN import LightGCN
 from .generic.Proxy.Proxy import ProxyRecommender
 from .autoencoders.vae.multi_vae import MultiVAE
 from .autoencoders.dae.multi_dae import MultiDAE
@@ -15,4 +17,4 @@ from .neural.NeuMF.neural_matrix_factorization import NeuMF
 from .neural.GeneralizedMF.generalized_matrix_factorization import GMF
 
 __all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF", "MultiVAE", "MultiDAE", "NeuMF", "GMF",
-           "MF", "PMF", "FunkSVD", "LogisticMatrixFactorization", "LMF", "CML", "ProxyRecommender"]
+           "MF", "PMF", "FunkSVD", "LogisticMatrixFactorization", "LMF", "CML", "MF2020", "LightGCN", "ProxyRecommender"]

@@ -47,7 +47,8 @@ typedef struct el_ctx el_ctx;
                             * 6: el_topk_screen_stats (diagnostics of the screened top-k; no struct changes: a host built
                             *    against 5 runs unchanged)
                             * 7: el_bprmf_state ends in replay_series; el_ctx_set_option / el_ctx_get_option (the library no
-                            *    longer reads the environment after el_ctx_create)                                       */
+                            *    longer reads the environment after el_ctx_create); el_graph_csr, el_spmm_csr_f32,
+                            *    el_lightgcn_propagate; el_mf2020_train                                                  */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -838,6 +839,62 @@ int el_host_split_flags(const int64_t* seg_len, int64_t n_seg, int mode, double 
 int el_host_split_flags_state(const int64_t* seg_len, int64_t n_seg, int mode, double param, uint32_t* np_state625, int32_t n_folds,
                               int8_t* flags);
 int el_host_pyset_order(const int64_t* keys, int64_t n, int64_t* out, int64_t* n_out);
+
+/* ---- graph propagation (LightGCN / NGCF BPR heads; ABI 7) ------------------------------------------------ */
+
+/* The normalised adjacency D^-1/2 A D^-1/2 of the user-item graph over N = U + I nodes (users first), as the reference builds it
+ * (graph_based/lightgcn/LightGCN.py:96-118: rowsum + 1e-7, power -1/2, two sparse products, all in fp32), in CSR with ascending column
+ * indices -- plus the work decomposition of the product, built once per graph by the host (elliot_amd/ops.py: GraphCSR): every row is
+ * cut into chunks of at most 512 consecutive non-zeros (an empty row keeps one empty chunk), one lane group per chunk; a row of several
+ * chunks sums their partial rows in chunk order in a second launch (no floating-point atomics: a fixed summation order).            */
+typedef struct el_graph_csr {
+    const int64_t* indptr;       /* [N + 1] */
+    const int32_t* indices;      /* [nnz]   */
+    const float* vals;           /* [nnz]   */
+    int64_t N, n0;               /* nodes; rows / columns [0, n0) are users (the first table), the rest items (the second) */
+    const int32_t* chunk_row;    /* [n_chunks] row of the chunk                                                        */
+    const int64_t* chunk_lo;     /* [n_chunks] its first non-zero (it ends 512 further on, or at the end of the row)    */
+    const int32_t* chunk_slot;   /* [n_chunks] -1: the only chunk of its row; else its partial row in `part`            */
+    int64_t n_chunks;
+    const int32_t* multi_row;    /* [n_multi] rows cut into several chunks ...                                          */
+    const int32_t* multi_slot;   /* [n_multi] ... their first partial slot (consecutive slots, chunk order) ...         */
+    const int32_t* multi_cnt;    /* [n_multi] ... and how many                                                          */
+    int64_t n_multi;
+    float* part;                 /* [n_partials, F] scratch of the product, F = the widest table it is used with        */
+} el_graph_csr;
+
+/* Y = L X for the stacked table X = [X0 (n0 rows); X1 (N - n0 rows)] of width F (a multiple of 4, 16-byte aligned tables).
+ * Replaces: tf.sparse.sparse_dense_matmul(A_fold_hat[f], ego_embeddings) over all folds (LightGCN_model.py:78-82, NGCF_model.py:118-121). */
+int el_spmm_csr_f32(el_ctx* ctx, void* stream, const el_graph_csr* g, const float* X0, const float* X1, int32_t F, float* Y0, float* Y1);
+
+/* Replaces: LightGCN_model._propagate_embeddings (LightGCN_model.py:68-94), in place:
+ *   [Gu; Gi] <- mean over k = 0 .. n_layers of alpha_k L^k [Gu; Gi],  alpha_0 = 1, alpha_k = 1 / (1 + k)
+ * (the reference ASSIGNS the result to the variables inside train_step: the BPR step that follows moves the propagated tables, and
+ * the next step propagates them again).  ws: el_lightgcn_ws_bytes(U, I, F, n_layers) bytes, 16-byte aligned.                       */
+size_t el_lightgcn_ws_bytes(int64_t U, int64_t I, int32_t F, int32_t n_layers);
+int el_lightgcn_propagate(el_ctx* ctx, void* stream, const el_graph_csr* g, float* Gu, float* Gi, int32_t F, int32_t n_layers,
+                          void* ws, size_t ws_bytes);
+
+/* ---- MF2020: point-wise logistic SGD, fp64, strictly sequential (ABI 7) ------------------------------------ */
+
+/* Parameters of latent_factor_models/MF2020/MF_model.py:37-56 in HBM (fp64, as NumPy holds them). */
+typedef struct el_mf2020_state {
+    double* P;      /* [U,F] _user_factors */
+    double* Q;      /* [I,F] _item_factors */
+    double* bu;     /* [U]   _user_bias    */
+    double* bi;     /* [I]   _item_bias    */
+    double* gb;     /* [1]   _global_bias  */
+    int64_t U, I;
+    int32_t F;
+    double lr, reg;
+} el_mf2020_state;
+
+/* Replaces: MFModel.train_step (MF2020/MF_model.py:80-113): the (user, item, rating) rows of `samples` (int32 [n,3], the rows
+ * custom_sampler_rendle.Sampler.step yields) taken ONE AFTER THE OTHER -- prediction with the global bias, the two stable branches
+ * of the logistic loss, the five in-place updates (the item row sees the UPDATED user row: `uf_` is a view, :103-104) -- exactly
+ * the reference's order: every sample reads and writes _global_bias, so the chain is strict and one workgroup walks it on LDS
+ * (elliot_amd/csrc/el_mf2020.hip).  *loss_out (device double, may be NULL) += the sum of the samples' losses (:108).           */
+int el_mf2020_train(el_ctx* ctx, void* stream, const el_mf2020_state* st, const int32_t* samples, int64_t n, double* loss_out);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,8 @@ is written there).  The reference modules are loaded BY FILE PATH because import
   bprmf_sgd_trace.npz   MFModel init + N sequential update_factors calls (BPRMF_model.py:40-56,91-117)
   bprmf_sgd_topk.npz    MFModel.get_user_predictions (BPRMF_model.py:70-85)
   ndcg_ref.npz          elliot.evaluation nDCG/Precision/Recall/HR on fixed recs (evaluator oracle)
+  mf2020_ref.npz        MF2020: MFModel init + train_step trace (MF_model.py:37-113) and one epoch of custom_sampler_rendle.Sampler
+  lightgcn_laplacian.npz  LightGCN._create_adj_mat (LightGCN.py:96-118) on a small train matrix
   bprmf_e2e_ref.npz     one epoch of the reference BPRMF loop + its recommendations; bprmf_ref_weights.pkl = its checkpoint
 
 Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
@@ -122,6 +124,8 @@ def main():
     gen_pointwise_and_neumf_samplers()
     gen_negative_sampling()
     gen_loader()
+    gen_mf2020()
+    gen_lightgcn_laplacian()
 
 
 def gen_bprmf_end_to_end(cs, mfm):
@@ -404,6 +408,86 @@ def gen_metrics(U, I, indptr, indices):
     np.savez_compressed(os.path.join(OUT, "metrics_ref.npz"), test_indptr=np.arange(0, 3 * U + 1, 3, dtype=np.int64),
                         test_items=ti, test_ratings=tr, recs=ridx, k=k,
                         names=np.array(list(out.keys())), values=np.array(list(out.values())))
+
+
+def gen_mf2020():
+    """The reference's MF2020 MFModel and its Rendle sampler, executed unmodified (NumPy only): initial parameters, the parameters after
+    two train_step calls on the first batches of one sampled epoch, the batch losses, the prediction matrix."""
+    import scipy.sparse as sp
+    from oracle import mf2020 as om
+    mfm = load_by_path("ref_mf2020_model", "elliot/recommender/latent_factor_models/MF2020/MF_model.py")
+    smp = load_by_path("ref_mf2020_sampler", "elliot/recommender/latent_factor_models/MF2020/custom_sampler_rendle.py")
+    U, I, F, seed, lr, reg, m = 60, 45, 10, 42, 0.05, 0.01, 2
+    indptr, indices, itd = small_dataset(U, I, seed=3)
+    I = int(indices.max()) + 1
+    R = sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(U, I))
+    data = SimpleNamespace(users=list(range(U)), items=list(range(I)), private_users={}, public_users={}, private_items={}, public_items={})
+    model = mfm.MFModel(F, data, lr, reg, seed)
+    res = {"U": U, "I": I, "F": F, "seed": seed, "lr": lr, "reg": reg, "m": m, "indptr": indptr, "indices": indices,
+           "P0": model._user_factors.copy(), "Q0": model._item_factors.copy()}
+    sampler = smp.Sampler(itd, m, R, seed)
+    batches = list(sampler.step(256))
+    epoch = np.concatenate(batches)
+    res["epoch"] = epoch.astype(np.int32)
+    assert np.array_equal(epoch, om.rendle_epoch(R, m, seed)), "oracle/mf2020.rendle_epoch differs from the reference sampler"
+    losses = []
+    for b in batches[:3]:
+        losses.append(model.train_step(b))
+    res.update(losses=np.array(losses), n_batches=3, batch=256, P=model._user_factors, Q=model._item_factors, bu=model._user_bias,
+               bi=model._item_bias, gb=np.float64(model._global_bias))
+    model.prepare_predictions()
+    res["preds"] = model._preds
+    # the restatement agrees with the reference to the last bits (the dot product's summation order is BLAS')
+    P, Q, bu, bi, gb = om.initialize(U, I, F, seed)
+    assert np.array_equal(P, res["P0"]) and np.array_equal(Q, res["Q0"])
+    for k, b in enumerate(batches[:3]):
+        l, gb = om.train_step(P, Q, bu, bi, gb, b, lr, reg)
+        assert abs(l - losses[k]) <= 1e-12 * abs(losses[k])
+    assert np.abs(P - res["P"]).max() < 1e-13 and np.abs(Q - res["Q"]).max() < 1e-13 and abs(gb - res["gb"]) < 1e-13
+    np.savez_compressed(os.path.join(OUT, "mf2020_ref.npz"), **res)
+    print("wrote mf2020_ref.npz")
+
+
+def gen_lightgcn_laplacian():
+    """LightGCN._create_adj_mat (graph_based/lightgcn/LightGCN.py:96-118) executed from the reference's file: the plugin module's imports
+    (the TF model file, the base classes -- not needed by this method) are satisfied by empty stand-in modules, the method runs on a
+    stand-in `self` that carries what it reads (_num_users, _num_items, _data.sp_i_train)."""
+    import types
+    import scipy.sparse as sp
+    from oracle import lightgcn as ol
+    stubs = {}
+    for name, attrs in (("elliot", {}), ("elliot.utils", {}), ("elliot.utils.write", {"store_recommendation": None}),
+                        ("elliot.dataset", {}), ("elliot.dataset.samplers", {"custom_sampler": None}),
+                        ("elliot.recommender", {"BaseRecommenderModel": type("BaseRecommenderModel", (), {})}),
+                        ("elliot.recommender.recommender_utils_mixin", {"RecMixin": type("RecMixin", (), {})}),
+                        ("elliot.recommender.base_recommender_model", {"init_charger": lambda f: f}),
+                        ("elliot.recommender.graph_based", {}), ("elliot.recommender.graph_based.lightgcn", {}),
+                        ("elliot.recommender.graph_based.lightgcn.LightGCN_model", {"LightGCNModel": None}),
+                        ("tqdm", {"tqdm": None})):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__dict__.update(attrs)
+            sys.modules[name] = stubs[name] = mod
+    try:
+        ref = load_by_path("ref_lightgcn_plugin", "elliot/recommender/graph_based/lightgcn/LightGCN.py")
+    finally:
+        for name in stubs:
+            sys.modules.pop(name, None)
+    U, I = 70, 50
+    indptr, indices, _ = small_dataset(U, I, seed=5)
+    I = int(indices.max()) + 1
+    R = sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(U, I))
+    fake = SimpleNamespace(_num_users=U, _num_items=I, _data=SimpleNamespace(sp_i_train=R))
+    adj, lap = ref.LightGCN._create_adj_mat(fake)
+    lap = lap.tocsr()
+    lap.sort_indices()
+    _, ol_lap = ol.create_adj_mat(R, U, I)
+    ol_lap.sort_indices()
+    assert np.array_equal(lap.indptr, ol_lap.indptr) and np.array_equal(lap.indices, ol_lap.indices)
+    assert np.array_equal(lap.data.astype(np.float32).view(np.uint32), ol_lap.data.view(np.uint32)), "oracle Laplacian differs from the reference's"
+    np.savez_compressed(os.path.join(OUT, "lightgcn_laplacian.npz"), U=U, I=I, indptr=indptr, indices=indices, lap_indptr=lap.indptr.astype(np.int64),
+                        lap_indices=lap.indices.astype(np.int32), lap_data=lap.data.astype(np.float32), adj_nnz=adj.nnz)
+    print("wrote lightgcn_laplacian.npz")
 
 
 if __name__ == "__main__":

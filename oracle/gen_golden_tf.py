@@ -212,11 +212,48 @@ def gen_gmf(ref, out, tf, prefix="tf_"):
     print(f"wrote {prefix}gmf.npz")
 
 
+def gen_lightgcn(ref, out, tf, prefix="tf_"):
+    """graph_based/lightgcn/LightGCN_model.py executed unmodified: Laplacian from the oracle's restatement of LightGCN.py:96-118 (itself
+    pinned to the reference's method: tests/golden/lightgcn_laplacian.npz), injected non-zero tables (the reference initialises them to
+    zero, :63-65, where every gradient vanishes), three train steps with repeated users / items, n_layers = 1 and 2, a prediction block."""
+    import scipy.sparse as sp
+    from oracle import lightgcn as ol
+    if not hasattr(np, "mat"):
+        np.mat = np.asmatrix                                     # (:59 uses np.mat, removed in NumPy 2)
+    mod = load_by_path(ref, "elliot/recommender/graph_based/lightgcn/LightGCN_model.py", "ref_lightgcn_model")
+    U, I, F, lr, l_w = 26, 19, 8, 0.005, 0.1
+    rs = np.random.RandomState(11)
+    R = sp.random(U, I, density=0.2, format="csr", random_state=rs, dtype=np.float32)
+    R.data[:] = 1.0
+    adj, lap = ol.create_adj_mat(R, U, I)
+    res = {"U": U, "I": I, "F": F, "lr": lr, "l_w": l_w, "R_indptr": R.indptr.astype(np.int64), "R_indices": R.indices.astype(np.int32)}
+    for n_layers in (1, 2):
+        m = mod.LightGCNModel(U, I, lr, F, l_w, n_layers, 2, adj, lap, 42)
+        Gu0 = rs.normal(scale=0.3, size=(U, F)).astype(np.float32)
+        Gi0 = rs.normal(scale=0.3, size=(I, F)).astype(np.float32)
+        m.Gu.assign(Gu0)
+        m.Gi.assign(Gi0)
+        res[f"L{n_layers}_Gu0"], res[f"L{n_layers}_Gi0"] = Gu0, Gi0
+        for step in range(3):
+            u = rs.randint(0, U, size=24).astype(np.int64)
+            i = rs.randint(0, I, size=24).astype(np.int64)
+            j = rs.randint(0, I, size=24).astype(np.int64)
+            u[:4] = u[4]
+            i[:3] = i[5]
+            loss = m.train_step((tf.constant(u.reshape(-1, 1)), tf.constant(i.reshape(-1, 1)), tf.constant(j.reshape(-1, 1))))
+            res[f"L{n_layers}_u{step}"], res[f"L{n_layers}_i{step}"], res[f"L{n_layers}_j{step}"] = u, i, j
+            res[f"L{n_layers}_loss{step}"] = np.float32(loss.numpy())
+            res[f"L{n_layers}_Gu{step + 1}"], res[f"L{n_layers}_Gi{step + 1}"] = m.Gu.numpy().copy(), m.Gi.numpy().copy()
+        res[f"L{n_layers}_preds"] = m.predict(3, 11).numpy()
+    np.savez_compressed(os.path.join(out, f"{prefix}lightgcn.npz"), **res)
+    print(f"wrote {prefix}lightgcn.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", required=True, help="path of the sisinflab/elliot checkout (v0.3.1)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
-    ap.add_argument("--only", default="bprmf_batch,multivae,neumf,gmf")
+    ap.add_argument("--only", default="bprmf_batch,multivae,neumf,gmf,lightgcn")
     args = ap.parse_args()
     os.environ.setdefault("CUDA_VISIBLE_DEVICES", "-1")          # the reference's default device (namespace_model.py:74)
     try:
@@ -234,6 +271,8 @@ def main():
         gen_neumf(args.reference, args.out, tf)
     if "gmf" in todo:
         gen_gmf(args.reference, args.out, tf)
+    if "lightgcn" in todo:
+        gen_lightgcn(args.reference, args.out, tf)
     with open(os.path.join(args.out, "tf_VERSION.txt"), "w") as f:
         f.write(f"tensorflow {tf.__version__}\nnumpy {np.__version__}\n")
 

@@ -212,9 +212,41 @@ def reduce_sum(x, axis=None):
     return Tensor(t.sum() if axis is None else t.sum(dim=axis))
 
 
-def reduce_mean(x, axis=None):
+def reduce_mean(x, axis=None, keepdims=False):
     t = _raw(x)
-    return Tensor(t.mean() if axis is None else t.mean(dim=axis))
+    return Tensor(t.mean() if axis is None else t.mean(dim=axis, keepdim=keepdims))
+
+
+def stack(values, axis=0):
+    return Tensor(torch.stack([_raw(v) for v in values], dim=axis))
+
+
+def split(value, num_or_size_splits, axis=0):
+    return [Tensor(t) for t in torch.split(_raw(value), list(num_or_size_splits) if isinstance(num_or_size_splits, (list, tuple))
+                                           else _raw(value).shape[axis] // int(num_or_size_splits), dim=axis)]
+
+
+class SparseTensor:
+    """tf.SparseTensor(indices [nnz, 2], values, dense_shape): held as a SciPy CSR (row-major, column order inside a row -- the order
+    tf.sparse.sparse_dense_matmul walks a row's entries in)."""
+
+    def __init__(self, indices, values, dense_shape):
+        import scipy.sparse as sp
+        idx = np.asarray(indices)
+        self.m = sp.csr_matrix((np.asarray(_raw(values).detach().numpy() if not isinstance(values, np.ndarray) else values, dtype=np.float32),
+                                (idx[:, 0].astype(np.int64).ravel(), idx[:, 1].astype(np.int64).ravel())), shape=tuple(int(d) for d in dense_shape))
+        self.m.sort_indices()
+
+
+class _Sparse:
+    @staticmethod
+    def sparse_dense_matmul(sp_a, b):
+        # (no gradient path: the model files that use it assign the result to a variable -- Variable.assign cuts the tape)
+        dense = _raw(b).detach().numpy().astype(np.float32)
+        return Tensor(torch.from_numpy(np.ascontiguousarray((sp_a.m @ dense).astype(np.float32))))
+
+
+sparse = _Sparse()
 
 
 def exp(x):

@@ -102,7 +102,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     pairs = {"el_bprmf_state": _lib.BprmfState, "el_bprsgd_state": _lib.BprsgdState, "el_vae_state": _lib.VaeState,
-             "el_nmf_state": _lib.NmfState, "el_pwmf_state": _lib.PwmfState}
+             "el_nmf_state": _lib.NmfState, "el_pwmf_state": _lib.PwmfState, "el_graph_csr": _lib.GraphCsr,
+             "el_mf2020_state": _lib.Mf2020State}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "elliot_hip.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append(f'    printf("{cname} %zu\\n", sizeof({cname}));')

@@ -305,8 +305,9 @@ def test_item_sharded_dense_exchange_hip_path_equals_concatenated_batch(ctx):
 
 def test_user_sharded_hip_path_equals_concatenated_batch(ctx):
     """User shards (parallel.ShardedBprmfByUser) with two virtual ranks on one GPU: local user rows, full item replicas,
-    the all-reduce of the item gradients emulated with a torch add: one reference-semantics step on the concatenated batch,
-    item replicas bit-identical."""
+    the all-reduce of the item gradients emulated with a torch add (steps 0, 1) and the row-sparse exchange emulated with a
+    concatenation of the ranks' touched-row lists (step 2): one reference-semantics step on the concatenated batch, item replicas
+    bit-identical."""
     from elliot_amd import parallel
     rs = np.random.RandomState(33)
     U, I, F, B, G = 701, 400, 64, 3000, 2
@@ -321,10 +322,25 @@ def test_user_sharded_hip_path_equals_concatenated_batch(ctx):
         for be, (lo, hi), (u, i, j) in zip(bes, rng, batches):
             be.grads(torch.from_numpy((u - lo).astype(np.int32)).to(d), torch.from_numpy(i.astype(np.int32)).to(d),
                      torch.from_numpy(j.astype(np.int32)).to(d), l_w, l_b)
-        for gs in zip(*[be.item_grads() for be in bes]):             # the all-reduce
-            tot = gs[0] + gs[1]
-            for g in gs:
-                g.copy_(tot)
+        if step == 2:
+            # the row-sparse exchange (ShardedBprmfByUser, item_exchange="rows"): every rank's touched (item id, row, bias) records,
+            # the shorter list padded, concatenated in rank order = the all-gather; el_rows_segment_sum on every rank
+            lists = [be.touched_item_rows(torch.from_numpy(b[1].astype(np.int32)).to(d), torch.from_numpy(b[2].astype(np.int32)).to(d))
+                     for be, b in zip(bes, batches)]
+            n_max = max(int(l[0].shape[0]) for l in lists)
+            padded = []
+            for ids, rows, bias in lists:
+                pad = n_max - int(ids.shape[0])
+                padded.append((torch.cat([ids, ids[:1].expand(pad)]), torch.cat([rows, torch.zeros((pad, F), device=d)]),
+                               torch.cat([bias, torch.zeros(pad, device=d)])))
+            gathered = tuple(torch.cat([p[x] for p in padded]).contiguous() for x in range(3))
+            for be in bes:
+                be.set_item_grads(*gathered)
+        else:
+            for gs in zip(*[be.item_grads() for be in bes]):         # the all-reduce
+                tot = gs[0] + gs[1]
+                for g in gs:
+                    g.copy_(tot)
         loss = 0.0
         for be in bes:
             if step == 1:

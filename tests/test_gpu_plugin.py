@@ -572,3 +572,85 @@ def test_mini_runner_runs_every_model_and_the_proxy_reads_its_recs(ctx, tmp_path
     trained = next(r for n, r in res.items() if n.startswith("BPRNN_"))          # one epoch -> one file = the reported result
     for metric, value in trained[10]["test_results"].items():
         assert abs(proxy_res[10]["test_results"][metric] - value) < 1e-12, metric
+
+
+def test_lightgcn_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
+    """external.LightGCN driven like ModelCoordinator.single: injected (non-zero) tables, two epochs of Philox triplets, against the
+    oracle's replay of LightGCN_model.train_step on the same triplets with the reference's Laplacian (oracle/lightgcn.create_adj_mat);
+    and the reference's own initialisation -- all-zero tables (LightGCN_model.py:63-65) -- which never learns: constant loss, lists by item id."""
+    from elliot_amd.recommender import LightGCN
+    from oracle import lightgcn as ol
+    data, cfg = make_data(tmp_path)
+    U, I, T = data.num_users, data.num_items, data.transactions
+    F, lr, l_w, B, epochs, L = 16, 0.005, 0.05, 512, 2, 2
+    rs = np.random.RandomState(3)
+    Gu0 = rs.normal(scale=0.2, size=(U, F)).astype(np.float32)
+    Gi0 = rs.normal(scale=0.2, size=(I, F)).astype(np.float32)
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=epochs, batch_size=B, factors=F, lr=lr, l_w=l_w,
+                             n_layers=L, n_fold=3, seed=42)
+    model = LightGCN(data=data, config=cfg, params=params, init_weights=(Gu0, Gi0))
+    assert model.name.startswith("LightGCN_seed=42_e=2_bs=512")
+    _, lap = ol.create_adj_mat(data.sp_i_train, U, I)
+    mine = model._laplacian.tocsr()
+    mine.sort_indices()
+    lap.sort_indices()
+    assert np.array_equal(mine.indices, lap.indices) and np.array_equal(mine.data.view(np.uint32), lap.data.astype(np.float32).view(np.uint32))
+    model.train()
+    orc = ol.LightGCNOracle(Gu0, Gi0, lap, lr, l_w, L)
+    m = data.sp_i_train
+    drawn = 0
+    for it in range(epochs):
+        tot = 0.0
+        for start in range(0, T, B):
+            n = min(start + B, T) - start
+            u, i, j = osampler.philox_sample(m.indptr, m.indices, U, I, 42, drawn, n)
+            drawn += n
+            tot += orc.train_step((u, i, j))
+        assert abs(model._losses[it] - tot / (it + 1)) <= 1e-4 * abs(tot / (it + 1)), (it, model._losses[it], tot / (it + 1))
+    st = model._model.state
+    assert np.abs(st.Gu.cpu().numpy() - orc.Gu).max() < 2e-5 and np.abs(st.Gi.cpu().numpy() - orc.Gi).max() < 2e-5
+    res = model.get_results()
+    assert 0.0 <= res[10]["test_results"]["nDCG"] <= 1.0
+    # the reference's own initialisation
+    zero = LightGCN(data=data, config=cfg, params=SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=1, batch_size=B,
+                                                                 factors=F, lr=lr, l_w=l_w, n_layers=1, n_fold=1, seed=42))
+    zero.train()
+    zs = zero._model.state
+    assert not bool(zs.Gu.any()) and not bool(zs.Gi.any())
+    steps = -(-T // B)
+    assert abs(zero._losses[0] - T * np.log(2.0)) < 1e-3 * T, (zero._losses[0], T * np.log(2.0), steps)
+
+
+def test_mf2020_plugin_epoch_equals_the_oracle_on_the_reference_samplers_stream(ctx, tmp_path):
+    """external.MF2020: one epoch (every positive + m = 2 uniform negatives each, the reference's shuffle) through the plugin == the
+    oracle's MFModel.train_step on the oracle's restatement of the Rendle sampler (both pinned to the reference in
+    tests/test_oracle_graph.py): parameters to 1e-11, the epoch loss, fp64 scores of the recommendation lists."""
+    from elliot_amd.recommender import MF2020
+    from oracle import mf2020 as om
+    data, cfg = make_data(tmp_path)
+    U, I = data.num_users, data.num_items
+    F, lr, reg, m_neg = 12, 0.05, 0.003, 2
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=1, factors=F, lr=lr, reg=reg, m=m_neg, seed=42)
+    model = MF2020(data=data, config=cfg, params=params)
+    assert model.name.startswith("MF2020_seed=42_e=1")
+    model.train()
+    P, Q, bu, bi, gb = om.initialize(U, I, F, 42)
+    ep = om.rendle_epoch(data.sp_i_train, m_neg, 42)
+    tot, nb = 0.0, 0
+    for s in range(0, ep.shape[0], 100000):
+        b = ep[s:s + 100000]
+        l, gb = om.train_step(P, Q, bu, bi, gb, b, lr, reg)
+        tot += l / len(b)
+        nb += 1
+    st = model._model.state
+    assert np.abs(st.P.cpu().numpy() - P).max() < 1e-11 and np.abs(st.Q.cpu().numpy() - Q).max() < 1e-11
+    assert np.abs(st.bu.cpu().numpy() - bu).max() < 1e-11 and abs(float(st.gb.item()) - gb) < 1e-11
+    assert abs(model._losses[0] - tot) <= 1e-10 * abs(tot)
+    recs_val, recs_test = model.get_recommendations(10)
+    scores = om.prepare_predictions(P, Q, bu, bi, gb)
+    train = data.sp_i_train.toarray() > 0
+    for pub_u, lst in list(recs_test.items())[:40]:
+        u = data.public_users[pub_u]
+        s = np.where(train[u], -np.inf, scores[u])
+        best = np.sort(s)[::-1][:10]
+        assert np.allclose([v for _, v in lst], best, rtol=1e-10, atol=1e-12)
