@@ -167,6 +167,10 @@ PROTOTYPES = {
     "el_spmm_csr_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GraphCsr), _f32p, _f32p, C.c_int32, _f32p, _f32p]),
     "el_lightgcn_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "el_lightgcn_propagate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GraphCsr), _f32p, _f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "el_ngcf_pre": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int32, _f32p]),
+    "el_ngcf_post": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, _f32p, _f32p,
+                               _f32p, C.c_int32, C.c_int32]),
+    "el_adam_l2_dense": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float]),
     "el_mf2020_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Mf2020State), _i32p, C.c_int64, _f64p]),
     "el_bprsgd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprsgdState), _i32p, _i32p, _i32p,
                                   C.c_int64, C.c_int64]),

@@ -283,3 +283,97 @@ extern "C" int el_lightgcn_propagate(el_ctx* ctx, void* stream, const el_graph_c
     EL_CHECK_HIP(hipMemcpyAsync(Gi, T + (size_t)U * F, (size_t)I * F * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
+
+// ---- NGCF (graph_based/ngcf/NGCF_model.py:106-142): the dense half of one embedding-propagation layer ------------------------------
+// With ego = E_{k-1} [N, kin] and lap = L ego (el_spmm_csr_f32), the reference forms
+//     first  = (lap + ego) W1 + b1,   second = (ego * lap) W2 + b2,   ego' = leaky_relu(first + second),   ego' = dropout(ego', rate),
+//     all_embeddings += l2_normalize(ego', axis = 1)
+// Here: k_ngcf_pre writes X2 = [lap + ego | ego * lap] ([N, 2 kin]), ONE product X2 [W1; W2] + (b1 + b2) on the library's GEMM gives
+// first + second, and k_ngcf_post applies leaky_relu (slope 0.2, tf.nn.leaky_relu's default) and the dropout mask, stores ego' for the
+// next layer and its row-normalised copy into the column block [col_off, col_off + kout) of Gu / Gi (row stride W): the `tf.concat(...,
+// 1)` + `assign` of :139-142 without a concatenated temporary.
+__global__ __launch_bounds__(256) void k_ngcf_pre(const float* __restrict__ ego, const float* __restrict__ lap, int64_t n4, int k4, float* __restrict__ X2) {
+    // one thread per float4 of ego: row r = t / k4, chunk c = t % k4
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const int64_t r = t / k4;
+    const int c = (int)(t - r * k4);
+    const float4 e = reinterpret_cast<const float4*>(ego)[t], l = reinterpret_cast<const float4*>(lap)[t];
+    float4* o = reinterpret_cast<float4*>(X2) + r * 2 * k4;
+    o[c] = make_float4(l.x + e.x, l.y + e.y, l.z + e.z, l.w + e.w);
+    o[k4 + c] = make_float4(e.x * l.x, e.y * l.y, e.z * l.z, e.w * l.w);
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void k_ngcf_post(const float* __restrict__ S, int64_t N, int64_t n0, int kout, float slope, float rate,
+                                                   u64 seed, u32 step, float* __restrict__ ego_next, float* __restrict__ Gu,
+                                                   float* __restrict__ Gi, int W, int col_off) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const float keep_scale = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    float ss = 0.f;
+    for (int c = lane; c < kout; c += 64) {
+        float v = S[r * kout + c];
+        v = v > 0.f ? v : slope * v;
+        if (rate > 0.f) {
+            // counter-based mask (the reference's is TensorFlow's stateful uniform stream: not reproducible outside TensorFlow)
+            const el_philox4 q = el_philox4x32_10((u32)(r & 0xffffffffu), (u32)((u64)r >> 32), (u32)c, step, (u32)seed, (u32)(seed >> 32));
+            const float uni = (float)(q.x >> 8) * (1.0f / 16777216.0f);
+            v = uni >= rate ? v * keep_scale : 0.f;
+        }
+        ego_next[r * kout + c] = v;
+        ss += v * v;
+    }
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                  // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, epsilon = 1e-12))
+    float* dst = r < n0 ? Gu + r * W + col_off : Gi + (r - n0) * W + col_off;
+    for (int c = lane; c < kout; c += 64) dst[c] = ego_next[r * kout + c] * inv;
+}
+
+extern "C" int el_ngcf_pre(el_ctx* ctx, void* stream, const float* ego, const float* lap, int64_t N, int32_t k, float* X2) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(ego && lap && X2 && N >= 0 && k >= 4 && k % 4 == 0, "el_ngcf_pre: bad arguments (k=%d must be a multiple of 4)", k);
+    EL_REQUIRE((((uintptr_t)ego | (uintptr_t)lap | (uintptr_t)X2) & 15) == 0, "el_ngcf_pre: tables must be 16-byte aligned");
+    const int64_t n4 = N * (k / 4);
+    if (n4 == 0) return 0;
+    EL_LAUNCH("k_ngcf_pre", k_ngcf_pre, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ego, lap, n4, k / 4, X2);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int el_ngcf_post(el_ctx* ctx, void* stream, const float* S, int64_t N, int64_t n0, int32_t kout, float rate, uint64_t seed,
+                            uint32_t step, float* ego_next, float* Gu, float* Gi, int32_t W, int32_t col_off) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(S && ego_next && Gu && Gi && N >= 0 && n0 >= 0 && n0 <= N && kout >= 1 && col_off >= 0 && col_off + kout <= W,
+               "el_ngcf_post: bad arguments");
+    EL_REQUIRE(rate >= 0.f && rate < 1.f, "el_ngcf_post: dropout rate %g outside [0, 1)", (double)rate);
+    if (N == 0) return 0;
+    EL_LAUNCH("k_ngcf_post", k_ngcf_post, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, N, n0, (int)kout, 0.2f, rate,
+              (u64)seed, (u32)step, ego_next, Gu, Gi, (int)W, (int)col_off);
+    EL_CHECK_LAUNCH();
+    return 0;
+}
+
+// Keras Adam (dense apply) on a variable whose only gradient is its L2 term: g = two_lw * theta.  (NGCF's GraphLayers: the tape of
+// NGCF_model.train_step reaches them through reg_loss alone -- the propagation's result is ASSIGNED to Gu / Gi, :141-142.)
+__global__ __launch_bounds__(256) void k_adam_l2_dense(float* __restrict__ th, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
+                                                       float two_lw) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    const float g = two_lw * th[t];
+    const float mm = m[t] + (g - m[t]) * (1.0f - b1);           // Keras dense apply: m += (g - m) (1 - b1)
+    const float vv = v[t] + (g * g - v[t]) * (1.0f - b2);
+    th[t] = th[t] - (mm * lr_t) / (sqrtf(vv) + eps);
+    m[t] = mm, v[t] = vv;
+}
+
+extern "C" int el_adam_l2_dense(el_ctx* ctx, void* stream, float* theta, float* m, float* v, int64_t n, float lr_t, float two_lw) {
+    if (int rc = el_bind(ctx)) return rc;
+    EL_REQUIRE(theta && m && v && n >= 0, "el_adam_l2_dense: bad arguments");
+    if (n == 0) return 0;
+    EL_LAUNCH("k_adam_l2_dense", k_adam_l2_dense, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, theta, m, v, n, lr_t, two_lw);
+    EL_CHECK_LAUNCH();
+    return 0;
+}

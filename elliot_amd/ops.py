@@ -1070,6 +1070,92 @@ class LightGcnDeviceState:
     def pop_loss(self):
         return self.bpr.pop_loss()
 
+
+class NgcfDeviceState:
+    """NGCFModel (graph_based/ngcf/NGCF_model.py:18-226) in HBM.  Gu / Gi are [rows, sum(weight_size_list)] wide (:88-91): the first
+    embed_k columns are the trainable layer-0 embeddings, the others are REWRITTEN by every `_propagate_embeddings` (:106-142) with the
+    row-normalised outputs of the propagation layers; the BPR head (bias-free, L2 doubled, :199-209) and Adam act on the full-width rows.
+    The GraphLayers (W_1, b_1, W_2, b_2 per layer) see the loss through reg_loss only -- the propagated tables are ASSIGNED (:141-142) --
+    so their Adam step runs on g = 2 l_w theta (el_adam_l2_dense).  layers: [{"W1": [kin, kout], "b1": [1, kout], "W2", "b2"}, ...]."""
+
+    def __init__(self, ctx, Gu, Gi, graph, layers, embed_k, message_dropout=None, dropout_seed=42):
+        self.ctx, self.graph, self.embed_k = ctx, graph, int(embed_k)
+        dev = ctx.device
+        self.bpr = BprmfDeviceState(ctx, Gu, Gi, np.zeros(int(Gi.shape[0]), np.float32), optimizer="adam_tf_dense", deferred=False,
+                                    item_deferred=False)
+        self.U, self.I, self.W = self.bpr.U, self.bpr.I, self.bpr.F
+        own = lambda x: (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).to(device=dev, dtype=torch.float32).contiguous().clone()
+        self.layers = [{k: own(v) for k, v in l.items()} for l in layers]
+        self.slots = [{k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in l.items()} for l in self.layers]
+        sizes = [self.embed_k] + [int(l["W1"].shape[1]) for l in self.layers]
+        if sum(sizes) != self.W or any(int(l["W1"].shape[0]) != sizes[n] for n, l in enumerate(self.layers)):
+            raise ValueError("layer shapes do not chain to the table width")
+        self.sizes = sizes
+        self.message_dropout = [float(x) for x in (message_dropout or [0.0] * len(self.layers))]
+        self.dropout_seed = int(dropout_seed)
+        N, kmax = self.U + self.I, max(sizes)
+        self._lap = torch.empty((N, kmax), dtype=torch.float32, device=dev)
+        self._x2 = torch.empty((N, 2 * kmax), dtype=torch.float32, device=dev)
+        self._s = torch.empty((N, kmax), dtype=torch.float32, device=dev)
+        self._ego = [torch.empty((N, kmax), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    @property
+    def Gu(self):
+        return self.bpr.Gu
+
+    @property
+    def Gi(self):
+        return self.bpr.Gi
+
+    @property
+    def step(self):
+        return self.bpr.step
+
+    def propagate(self):
+        """_propagate_embeddings (:106-142), in place on the column blocks of Gu / Gi."""
+        st, ctx, U, N = self.bpr, self.ctx, self.U, self.U + self.I
+        st.sync()
+        k0 = self.embed_k
+        ego = self._ego[0].view(-1)[:N * k0].view(N, k0)
+        ego[:U].copy_(st._Gu[:, :k0])
+        ego[U:].copy_(st._Gi[:, :k0])
+        off = k0
+        for n, l in enumerate(self.layers):
+            kin, kout = self.sizes[n], self.sizes[n + 1]
+            lap = self._lap.view(-1)[:N * kin].view(N, kin)
+            self.graph.spmm(ego[:U], ego[U:], lap[:U], lap[U:])
+            x2 = self._x2.view(-1)[:N * 2 * kin].view(N, 2 * kin)
+            check(ctx.lib.el_ngcf_pre(ctx.handle, ctx.stream(), _ptr(ego, torch.float32), _ptr(lap, torch.float32), N, kin, _ptr(x2, torch.float32)), "el_ngcf_pre")
+            wcat = torch.cat([l["W1"], l["W2"]], 0)
+            bcat = (l["b1"] + l["b2"]).reshape(-1)
+            s = self._s.view(-1)[:N * kout].view(N, kout)
+            gemm(ctx, x2, wcat, bias=bcat, out=s)
+            nxt = self._ego[(n + 1) & 1].view(-1)[:N * kout].view(N, kout)
+            check(ctx.lib.el_ngcf_post(ctx.handle, ctx.stream(), _ptr(s, torch.float32), N, U, kout, float(self.message_dropout[n]),
+                                       self.dropout_seed & 0xFFFFFFFFFFFFFFFF, int(st.step * 16 + n) & 0xFFFFFFFF, _ptr(nxt, torch.float32),
+                                       _ptr(st._Gu, torch.float32), _ptr(st._Gi, torch.float32), self.W, off), "el_ngcf_post")
+            ego, off = nxt, off + kout
+
+    def train_step(self, u, i, j, lr, l_w):
+        """train_step (:187-217): propagate, the bias-free BPR step with the doubled L2 term on the full-width rows, the GraphLayers' L2-only
+        Adam step; the batch loss includes l_w * sum ||layer parameter||^2 (:203-206)."""
+        self.propagate()
+        st, ctx = self.bpr, self.ctx
+        st.train_step(u, i, j, lr, 2.0 * float(l_w), 0.0)
+        st.sync()
+        st._Bi.zero_(), st.mBi.zero_(), st.vBi.zero_()
+        reg = sum((p.double() ** 2).sum() for l in self.layers for p in l.values())
+        st.loss += float(l_w) * reg                                   # (device arithmetic: no synchronisation)
+        lr_t = adam_lr_t(lr, st.step)
+        for l, sl in zip(self.layers, self.slots):
+            for k, p in l.items():
+                m, v = sl[k]
+                check(ctx.lib.el_adam_l2_dense(ctx.handle, ctx.stream(), _ptr(p, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
+                                               p.numel(), float(lr_t), 2.0 * float(l_w)), "el_adam_l2_dense")
+
+    def pop_loss(self):
+        return self.bpr.pop_loss()
+
 # ------------------------------------------------------------------------------------------
 # BPRMF (NumPy semantics, fp64)
 # ------------------------------------------------------------------------------------------

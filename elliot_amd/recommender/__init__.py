@@ -10,6 +10,7 @@ from .latent_factor_models.LogisticMF.logistic_matrix_factorization import LMF, 
 from .latent_factor_models.CML.CML import CML
 from .latent_factor_models.MF2020.MF import MF2020
 from .graph_based.lightgcn.LightGCN import LightGCN
+from .graph_based.ngcf.NGCF import NGCF
 from .generic.Proxy.Proxy import ProxyRecommender
 from .autoencoders.vae.multi_vae import MultiVAE
 from .autoencoders.dae.multi_dae import MultiDAE
@@ -17,4 +18,4 @@ from .neural.NeuMF.neural_matrix_factorization import NeuMF
 from .neural.GeneralizedMF.generalized_matrix_factorization import GMF
 
 __all__ = ["BaseRecommenderModel", "init_charger", "RecMixin", "BPRMF_batch", "BPRMF", "MultiVAE", "MultiDAE", "NeuMF", "GMF",
-           "MF", "PMF", "FunkSVD", "LogisticMatrixFactorization", "LMF", "CML", "MF2020", "LightGCN", "ProxyRecommender"]
+           "MF", "PMF", "FunkSVD", "LogisticMatrixFactorization", "LMF", "CML", "MF2020", "LightGCN", "NGCF", "ProxyRecommender"]

@@ -875,6 +875,18 @@ size_t el_lightgcn_ws_bytes(int64_t U, int64_t I, int32_t F, int32_t n_layers);
 int el_lightgcn_propagate(el_ctx* ctx, void* stream, const el_graph_csr* g, float* Gu, float* Gi, int32_t F, int32_t n_layers,
                           void* ws, size_t ws_bytes);
 
+/* NGCF (graph_based/ngcf/NGCF_model.py:106-142), the dense half of one embedding-propagation layer around el_spmm_csr_f32 and
+ * el_gemm_f32:  el_ngcf_pre   X2 [N, 2k] = [lap + ego | ego * lap]   (the two operands of W_1 and W_2, :123-133, as ONE product's input)
+ *               el_ngcf_post  ego' = dropout(leaky_relu(S), rate) -> ego_next [N, kout] and l2_normalize(ego') into columns
+ *                             [col_off, col_off + kout) of Gu / Gi (row stride W): the concat + assign of :139-142.  The dropout mask is a
+ *                             counter-based draw (seed, step, row, column): TensorFlow's stream cannot be reproduced outside TensorFlow.
+ *               el_adam_l2_dense  Keras Adam on a variable whose only gradient is its L2 term (g = two_lw * theta): the GraphLayers,
+ *                             which the tape of train_step (:199-215) reaches through reg_loss alone.                              */
+int el_ngcf_pre(el_ctx* ctx, void* stream, const float* ego, const float* lap, int64_t N, int32_t k, float* X2);
+int el_ngcf_post(el_ctx* ctx, void* stream, const float* S, int64_t N, int64_t n0, int32_t kout, float rate, uint64_t seed, uint32_t step,
+                 float* ego_next, float* Gu, float* Gi, int32_t W, int32_t col_off);
+int el_adam_l2_dense(el_ctx* ctx, void* stream, float* theta, float* m, float* v, int64_t n, float lr_t, float two_lw);
+
 /* ---- MF2020: point-wise logistic SGD, fp64, strictly sequential (ABI 7) ------------------------------------ */
 
 /* Parameters of latent_factor_models/MF2020/MF_model.py:37-56 in HBM (fp64, as NumPy holds them). */

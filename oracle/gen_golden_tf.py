@@ -249,11 +249,56 @@ def gen_lightgcn(ref, out, tf, prefix="tf_"):
     print(f"wrote {prefix}lightgcn.npz")
 
 
+def gen_ngcf(ref, out, tf, prefix="tf_"):
+    """graph_based/ngcf/NGCF_model.py executed unmodified: two propagation layers (8 -> 12 -> 4: widths in multiples of 4, what the device kernels take), no node dropout, message dropout 0
+    (TensorFlow's stream is not reproducible), injected layer-0 embeddings, three train steps, a prediction block."""
+    import scipy.sparse as sp
+    from oracle import lightgcn as ol
+    if not hasattr(np, "mat"):
+        np.mat = np.asmatrix
+    mod = load_by_path(ref, "elliot/recommender/graph_based/ngcf/NGCF_model.py", "ref_ngcf_model")
+    U, I, F, lr, l_w, ws = 24, 17, 8, 0.005, 0.05, [12, 4]
+    rs = np.random.RandomState(21)
+    R = sp.random(U, I, density=0.25, format="csr", random_state=rs, dtype=np.float32)
+    R.data[:] = 1.0
+    adj, lap = ol.create_adj_mat(R, U, I)
+    m = mod.NGCFModel(U, I, lr, F, l_w, ws, len(ws), [], [0.0, 0.0], 2, adj, lap, 42)
+    W = F + sum(ws)
+    Gu0, Gi0 = np.zeros((U, W), np.float32), np.zeros((I, W), np.float32)
+    Gu0[:, :F] = rs.normal(scale=0.3, size=(U, F))
+    Gi0[:, :F] = rs.normal(scale=0.3, size=(I, F))
+    m.Gu.assign(Gu0)
+    m.Gi.assign(Gi0)
+    res = {"U": U, "I": I, "F": F, "lr": lr, "l_w": l_w, "weight_size": np.array(ws), "R_indptr": R.indptr.astype(np.int64),
+           "R_indices": R.indices.astype(np.int32), "Gu0": Gu0, "Gi0": Gi0}
+    for k in range(len(ws)):
+        for nm in ("W_1", "b_1", "W_2", "b_2"):
+            v = m.GraphLayers[f"{nm}_{k}"]
+            w = rs.normal(scale=0.4, size=v.shape).astype(np.float32)
+            v.assign(w)
+            res[f"{nm}_{k}_0"] = w
+    for step in range(3):
+        u = rs.randint(0, U, size=20).astype(np.int64)
+        i = rs.randint(0, I, size=20).astype(np.int64)
+        j = rs.randint(0, I, size=20).astype(np.int64)
+        u[:3] = u[3]
+        loss = m.train_step((tf.constant(u.reshape(-1, 1)), tf.constant(i.reshape(-1, 1)), tf.constant(j.reshape(-1, 1))))
+        res[f"u{step}"], res[f"i{step}"], res[f"j{step}"] = u, i, j
+        res[f"loss{step}"] = np.float32(loss.numpy())
+        res[f"Gu{step + 1}"], res[f"Gi{step + 1}"] = m.Gu.numpy().copy(), m.Gi.numpy().copy()
+        for k in range(len(ws)):
+            for nm in ("W_1", "b_1", "W_2", "b_2"):
+                res[f"{nm}_{k}_{step + 1}"] = m.GraphLayers[f"{nm}_{k}"].numpy().copy()
+    res["preds"] = m.predict(2, 9).numpy()
+    np.savez_compressed(os.path.join(out, f"{prefix}ngcf.npz"), **res)
+    print(f"wrote {prefix}ngcf.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", required=True, help="path of the sisinflab/elliot checkout (v0.3.1)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
-    ap.add_argument("--only", default="bprmf_batch,multivae,neumf,gmf,lightgcn")
+    ap.add_argument("--only", default="bprmf_batch,multivae,neumf,gmf,lightgcn,ngcf")
     args = ap.parse_args()
     os.environ.setdefault("CUDA_VISIBLE_DEVICES", "-1")          # the reference's default device (namespace_model.py:74)
     try:
@@ -273,6 +318,8 @@ def main():
         gen_gmf(args.reference, args.out, tf)
     if "lightgcn" in todo:
         gen_lightgcn(args.reference, args.out, tf)
+    if "ngcf" in todo:
+        gen_ngcf(args.reference, args.out, tf)
     with open(os.path.join(args.out, "tf_VERSION.txt"), "w") as f:
         f.write(f"tensorflow {tf.__version__}\nnumpy {np.__version__}\n")
 

@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="bprmf_batch,multivae,neumf,gmf,lightgcn")
+    ap.add_argument("--only", default="bprmf_batch,multivae,neumf,gmf,lightgcn,ngcf")
     args = ap.parse_args()
     sys.dont_write_bytecode = True                              # nothing may be written under the reference checkout
     sys.path.insert(0, os.path.join(HERE, "tf_shim"))           # `import tensorflow` -> the stand-in
@@ -35,7 +35,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     todo = set(args.only.split(","))
     for name, fn in (("bprmf_batch", g.gen_bprmf_batch), ("multivae", g.gen_multivae), ("neumf", g.gen_neumf), ("gmf", g.gen_gmf),
-                     ("lightgcn", g.gen_lightgcn)):
+                     ("lightgcn", g.gen_lightgcn), ("ngcf", g.gen_ngcf)):
         if name in todo:
             fn(args.reference, args.out, tf, prefix="tfshim_")
     with open(os.path.join(args.out, "tfshim_VERSION.txt"), "w") as f:

@@ -217,6 +217,11 @@ def reduce_mean(x, axis=None, keepdims=False):
     return Tensor(t.mean() if axis is None else t.mean(dim=axis, keepdim=keepdims))
 
 
+def multiply(a, b):
+    x = _raw(a)
+    return Tensor(x * _raw(b, x))
+
+
 def stack(values, axis=0):
     return Tensor(torch.stack([_raw(v) for v in values], dim=axis))
 
@@ -362,6 +367,24 @@ class _NN:
         return _TopK((Tensor(torch.from_numpy(np.ascontiguousarray(vals))), Tensor(torch.from_numpy(order.astype(np.int32)))))
 
 
+def _leaky_relu(x, alpha=0.2):
+    return Tensor(torch.nn.functional.leaky_relu(_raw(x), negative_slope=alpha))
+
+
+def _nn_dropout(x, rate, **kw):
+    if float(rate) != 0.0:
+        raise NotImplementedError("tf.nn.dropout with rate > 0 draws TensorFlow's random stream: the shim refuses what it cannot reproduce")
+    return Tensor(_raw(x))
+
+
+def _l2_normalize(x, axis=None, epsilon=1e-12):
+    t = _raw(x)
+    return Tensor(t * torch.rsqrt(torch.clamp((t * t).sum(dim=axis, keepdim=True), min=epsilon)))
+
+
+_NN.leaky_relu = staticmethod(_leaky_relu)
+_NN.dropout = staticmethod(_nn_dropout)
+_NN.l2_normalize = staticmethod(_l2_normalize)
 nn = _NN()
 
 

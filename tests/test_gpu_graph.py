@@ -131,3 +131,32 @@ def test_mf2020_equals_the_reference_trace_and_the_oracle(ctx, golden):
         assert abs(st.pop_loss() - exp_loss) <= 1e-10 * abs(exp_loss)
         assert np.abs(cpu(st.P) - P).max() < 1e-11 and np.abs(cpu(st.Q) - Q).max() < 1e-11
         assert np.abs(cpu(st.bu) - bu).max() < 1e-11 and np.abs(cpu(st.bi) - bi).max() < 1e-11 and abs(float(st.gb.item()) - gb) < 1e-11
+
+
+def test_ngcf_train_steps_equal_the_reference_model_file(ctx, golden):
+    """NgcfDeviceState against the fixture NGCF_model.py produced on the tensorflow stand-in (tests/golden/tfshim_ngcf.npz): three steps,
+    two propagation layers -- loss, the full-width tables and every GraphLayers parameter."""
+    g = golden("tfshim_ngcf.npz")
+    U, I, F = int(g["U"]), int(g["I"]), int(g["F"])
+    lr, l_w = float(g["lr"]), float(g["l_w"])
+    R = sp.csr_matrix((np.ones(len(g["R_indices"]), np.float32), g["R_indices"], g["R_indptr"]), shape=(U, I))
+    ws = [int(x) for x in g["weight_size"]]
+    graph, _ = _graph(ctx, R, U, I, max([F] + ws))
+    layers = [{"W1": g[f"W_1_{k}_0"], "b1": g[f"b_1_{k}_0"], "W2": g[f"W_2_{k}_0"], "b2": g[f"b_2_{k}_0"]} for k in range(len(ws))]
+    st = ops.NgcfDeviceState(ctx, g["Gu0"], g["Gi0"], graph, layers, F, message_dropout=[0.0] * len(ws))
+    for step in range(3):
+        u, i, j = (torch.from_numpy(g[f"{x}{step}"].astype(np.int32)).to(ctx.device) for x in "uij")
+        st.train_step(u, i, j, lr, l_w)
+        loss = st.pop_loss()
+        assert abs(loss - float(g[f"loss{step}"])) <= 1e-4 * abs(loss), (step, loss, float(g[f"loss{step}"]))
+        assert np.abs(cpu(st.Gu) - g[f"Gu{step + 1}"]).max() < 1e-5 and np.abs(cpu(st.Gi) - g[f"Gi{step + 1}"]).max() < 1e-5, step
+        for k in range(len(ws)):
+            for mine, name in (("W1", "W_1"), ("b1", "b_1"), ("W2", "W_2"), ("b2", "b_2")):
+                assert np.abs(cpu(st.layers[k][mine]) - g[f"{name}_{k}_{step + 1}"]).max() < 2e-6, (step, k, name)
+    # message dropout: a counter-based mask -- kept entries scaled by 1 / (1 - rate), the expected share dropped, rows stay unit length
+    st2 = ops.NgcfDeviceState(ctx, g["Gu0"], g["Gi0"], graph, layers, F, message_dropout=[0.5, 0.0])
+    st2.propagate()
+    blk = cpu(st2.Gu)[:, F:F + ws[0]]
+    assert 0.25 < (blk == 0).mean() < 0.75
+    nz = np.linalg.norm(blk, axis=1)
+    assert np.all((np.abs(nz - 1) < 1e-5) | (nz == 0))

@@ -586,8 +586,8 @@ def test_lightgcn_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
     rs = np.random.RandomState(3)
     Gu0 = rs.normal(scale=0.2, size=(U, F)).astype(np.float32)
     Gi0 = rs.normal(scale=0.2, size=(I, F)).astype(np.float32)
-    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=epochs, batch_size=B, factors=F, lr=lr, l_w=l_w,
-                             n_layers=L, n_fold=3, seed=42)
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=epochs, batch_size=B, latent_dim=F, lr=lr, l_w=l_w,
+                             n_layers=L, n_fold=3, seed=42)      # (`latent_dim` is the key LightGCN.py:72 reads; `factors` is its file-name shortcut)
     model = LightGCN(data=data, config=cfg, params=params, init_weights=(Gu0, Gi0))
     assert model.name.startswith("LightGCN_seed=42_e=2_bs=512")
     _, lap = ol.create_adj_mat(data.sp_i_train, U, I)
@@ -613,7 +613,7 @@ def test_lightgcn_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
     assert 0.0 <= res[10]["test_results"]["nDCG"] <= 1.0
     # the reference's own initialisation
     zero = LightGCN(data=data, config=cfg, params=SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=1, batch_size=B,
-                                                                 factors=F, lr=lr, l_w=l_w, n_layers=1, n_fold=1, seed=42))
+                                                                 latent_dim=F, lr=lr, l_w=l_w, n_layers=1, n_fold=1, seed=42))
     zero.train()
     zs = zero._model.state
     assert not bool(zs.Gu.any()) and not bool(zs.Gi.any())
@@ -654,3 +654,48 @@ def test_mf2020_plugin_epoch_equals_the_oracle_on_the_reference_samplers_stream(
         s = np.where(train[u], -np.inf, scores[u])
         best = np.sort(s)[::-1][:10]
         assert np.allclose([v for _, v in lst], best, rtol=1e-10, atol=1e-12)
+
+
+def test_ngcf_plugin_end_to_end_matches_cpu_replay(ctx, tmp_path):
+    """external.NGCF: injected layer-0 embeddings and GraphLayers, two propagation layers, message dropout 0, one epoch of Philox triplets
+    against the oracle's replay of NGCF_model.train_step; then the defaults (zero tables, message dropout 0.1, a node dropout) run."""
+    from elliot_amd.recommender import NGCF
+    from oracle import lightgcn as ol
+    from oracle import ngcf as on
+    data, cfg = make_data(tmp_path)
+    U, I, T = data.num_users, data.num_items, data.transactions
+    F, ws, lr, l_w, B = 16, [12, 8], 0.005, 0.02, 512
+    rs = np.random.RandomState(8)
+    W = F + sum(ws)
+    Gu0, Gi0 = np.zeros((U, W), np.float32), np.zeros((I, W), np.float32)
+    Gu0[:, :F] = rs.normal(scale=0.2, size=(U, F))
+    Gi0[:, :F] = rs.normal(scale=0.2, size=(I, F))
+    sizes = [F] + ws
+    layers = [{"W1": rs.normal(scale=0.3, size=(sizes[k], sizes[k + 1])).astype(np.float32), "b1": rs.normal(scale=0.1, size=(1, sizes[k + 1])).astype(np.float32),
+               "W2": rs.normal(scale=0.3, size=(sizes[k], sizes[k + 1])).astype(np.float32), "b2": rs.normal(scale=0.1, size=(1, sizes[k + 1])).astype(np.float32)}
+              for k in range(len(ws))]
+    params = SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=1, batch_size=B, latent_dim=F, lr=lr, l_w=l_w,
+                             weight_size=str(tuple(ws)), node_dropout="()", message_dropout="(0.0, 0.0)", n_fold=2, seed=42)
+    model = NGCF(data=data, config=cfg, params=params, init_weights=(Gu0, Gi0, layers))
+    assert model.name.startswith("NGCF_seed=42_e=1_bs=512") and "weight_size=12-8_node_dropout=_message_dropout=0$0-0$0" in model.name
+    model.train()
+    _, lap = ol.create_adj_mat(data.sp_i_train, U, I)
+    orc = on.NGCFOracle(Gu0, Gi0, lap, layers, F, lr, l_w)
+    m = data.sp_i_train
+    drawn, tot = 0, 0.0
+    for start in range(0, T, B):
+        n = min(start + B, T) - start
+        u, i, j = osampler.philox_sample(m.indptr, m.indices, U, I, 42, drawn, n)
+        drawn += n
+        tot += orc.train_step((u, i, j))
+    assert abs(model._losses[0] - tot) <= 1e-4 * abs(tot), (model._losses[0], tot)
+    st = model._model.state
+    assert np.abs(st.Gu.cpu().numpy() - orc.Gu).max() < 5e-5 and np.abs(st.Gi.cpu().numpy() - orc.Gi).max() < 5e-5
+    for l, ref in zip(st.layers, orc.layers):
+        for k in ref:
+            assert np.abs(l[k].cpu().numpy() - ref[k]).max() < 1e-5, k
+    assert 0.0 <= model.get_results()[10]["test_results"]["nDCG"] <= 1.0
+    dflt = NGCF(data=data, config=cfg, params=SimpleNamespace(meta=SimpleNamespace(save_recs=False, verbose=False), epochs=1, batch_size=B,
+                                                              latent_dim=F, node_dropout="(0.9,)", seed=42))
+    dflt.train()
+    assert np.isfinite(dflt._losses[0]) and not bool(dflt._model.state.Gu[:, :F].any())           # layer-0 columns: zero, forever
