@@ -98,7 +98,7 @@ def parse():
                     help="N > 1: users are independent units (no collective) / north_star's item shards + all-gather of partial "
                          "top-k (default: user for --shard user, item for the item-shard leg)")
     ap.add_argument("--legs", default="auto",
-                    help="comma list of bpr,item_shard,c2,sweep,plugin,c5,vae,neumf,metrics (auto: N=1 -> all but item_shard; N>1 -> bpr,item_shard)")
+                    help="comma list of bpr,item_shard,c2,sweep,plugin,c5,vae,neumf,graph,metrics (auto: N=1 -> all but item_shard; N>1 -> bpr,item_shard)")
     ap.add_argument("--c2-shape", default="1000000,100000", help="users,items of the c2 leg (BASELINE configs[1]; sweep and plugin legs run on its data)")
     ap.add_argument("--c5-shape", default="6250000,5000000,256",
                     help="users,items,factors of the c5 leg (BASELINE configs[4] = 50M x 5M x 256 on 8 GPUs: the per-GPU shape under user sharding)")
@@ -122,6 +122,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget of each cpu_baseline measurement")
     ap.add_argument("--vae-shape", default="138493,26744,600,200,512", help="users,items,hidden,latent,batch of the vae leg")
     ap.add_argument("--neumf-shape", default="1250000,1000000,128,262144", help="users,items,factors,batch of the neumf leg")
+    ap.add_argument("--graph-shape", default="1000000,100000,64,2", help="users,items,factors,n_layers of the graph leg (LightGCN; MF2020 beside it)")
     ap.add_argument("--neumf-topk-users", type=int, default=128, help="users per full-catalogue scoring step of the neumf leg (0: skip)")
     return ap.parse_args()
 
@@ -1002,6 +1003,70 @@ def vae_leg(args, ctx):
                          "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}
 
 
+def graph_leg(args, ctx):
+    """SURVEY 8f N3 siblings with kernels of their own: LightGCN (one propagation of the normalised adjacency -- the CSR x dense gather
+    kernel, HBM-bound -- + the bias-free BPR head) at BASELINE configs[1]'s users x items, F = 64 (the reference's default width,
+    LightGCN.py:72), n_layers = 2; and MF2020's strictly sequential fp64 SGD (samples/s of one chain)."""
+    from elliot_amd import ops
+    from elliot_amd.synthetic import zipf_csr_device
+    dev = ctx.device
+    U, I, F, L = (int(x) for x in args.graph_shape.split(","))
+    K, W = args.steps, args.warmup
+    B = args.batch
+    ip, ix = zipf_csr_device(U, I, dev, mean_log=3.9, sigma_log=1.0, dmin=5, dmax=2000, seed=1234)
+    pos = ops.DeviceCSR.from_tensors(ip, ix, I)
+    lip, lix, lv = ops.normalized_bipartite_laplacian_device(ip, ix, U, I)
+    graph = ops.GraphCSR(ctx, lip, lix, lv, U, F)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    Gu = (torch.rand((U, F), generator=g, device=dev) * 2 - 1) * 0.05      # (the reference starts at zero and stays there: injected tables)
+    Gi = (torch.rand((I, F), generator=g, device=dev) * 2 - 1) * 0.05
+    st = ops.LightGcnDeviceState(ctx, Gu, Gi, graph, n_layers=L)
+    drawn = [0]
+
+    def step():
+        t = ops.bpr_sample(ctx, pos, B, seed=42, first_sample=drawn[0])
+        drawn[0] += B
+        st.train_step(t[0], t[1], t[2], 0.0005, 0.1)
+
+    dt, rep = timed(ctx, 1, step, W, K)
+    loss = st.pop_loss()
+    nnz, N = graph.nnz, U + I
+    spmm_bytes = nnz * (8.0 + 4.0 * F) + N * 4.0 * F * 2                   # per layer: index + value + one gathered row per non-zero; a row
+    #                                                                         written (and the layer-combination operand read) per node
+    cnt, ms = getattr(rep, "live", {}).get("k_spmm_csr", rep.get("k_spmm_csr", (0, 0.0)))
+    if not cnt:
+        cnt, ms = rep.get("k_spmm_csr", (1, 0.0))
+    sec = ms / max(cnt, 1) * 1e-3
+    out = {"lightgcn": {"value": B * K / dt, "unit": "pairs/s", "ms_per_step": dt / K * 1e3, "repeats_ms_per_step": rep.repeats_ms,
+                        "loss_per_pair_last": loss / (B * max(rep.calls, 1)),
+                        "workload": f"LightGCN {U} users x {I} items, F={F}, n_layers={L}, {nnz} non-zeros of the normalised adjacency, B={B}",
+                        "roofline": {"kernel": "k_spmm_csr", "bound": "hbm", "achieved": spmm_bytes / sec / 1e9 if sec > 0 else None,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None,
+                                     "traffic": None, "bytes_per_launch": spmm_bytes,
+                                     "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}}
+    del st, graph, Gu, Gi
+    torch.cuda.empty_cache()
+    # MF2020: one chain of point-wise SGD updates (MF_model.py:80-113), F = 64, uniform samples over the same users x items
+    Um, Im = min(U, 1_000_000), min(I, 100_000)
+    n = 400_000
+    P = torch.randn((Um, 64), generator=g, device=dev, dtype=torch.float64) * 0.1
+    Q = torch.randn((Im, 64), generator=g, device=dev, dtype=torch.float64) * 0.1
+    mf = ops.Mf2020DeviceState(ctx, P, Q, lr=0.05, reg=0.0025)
+    smp = torch.stack([torch.randint(0, Um, (n,), generator=g, device=dev), torch.randint(0, Im, (n,), generator=g, device=dev),
+                       torch.randint(0, 2, (n,), generator=g, device=dev)], 1).to(torch.int32)
+    mf.train(smp[:20000])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mf.train(smp)
+    torch.cuda.synchronize()
+    dtm = time.perf_counter() - t0
+    out["mf2020"] = {"value": n / dtm, "unit": "samples/s", "us_per_sample": dtm / n * 1e6, "loss_per_sample": mf.pop_loss() / (n + 20000),
+                     "workload": f"MF2020 sequential fp64 SGD, {n} samples over {Um} users x {Im} items, F=64 (one chain: every sample updates the global bias)",
+                     "note": "bound by the chain's latency (fp64 exp / log / division + one 64-lane reduction per sample on one wave), not by a roofline"}
+    return out
+
+
 def neumf_leg(args, ctx):
     """neural_matrix_factorization_model.py:96-106 train_step, d=128, tower (4F, 2F, F): samples/s + MFMA roofline."""
     from elliot_amd import ops
@@ -1319,6 +1384,11 @@ def compact_line(full):
                                                   "survivor_frac": nt["trained"]["screen"].get("exact_pairs_frac"),
                                                   "fell_back": nt["trained"]["screen"].get("fell_back")}} if "trained" in nt else {})} if nt else None,
                          "workload": "NeuMF d=128, 1.25M users x 1M items (configs[3] per GPU), B=262144"}
+    if "graph" in full:
+        gl, gm = full["graph"]["lightgcn"], full["graph"]["mf2020"]
+        legs["lightgcn"] = {"pairs_per_s": gl.get("value"), "ms_per_step": gl.get("ms_per_step"), "roofline": _roof(gl.get("roofline")),
+                            "workload": "LightGCN 1M users x 100K items, F=64, 2 layers"}
+        legs["mf2020"] = {"samples_per_s": gm.get("value"), "us_per_sample": gm.get("us_per_sample")}
     if legs:
         line["legs"] = legs
     cb = full.get("cpu_baseline")
@@ -1397,7 +1467,7 @@ def main():
     U, I, F, B, k = args.users, args.items, args.factors, args.batch, args.k
     sharded = world > 1 or args.force_sharded
     legs = args.legs.split(",") if args.legs != "auto" else (["bpr", "item_shard"] if world > 1 else
-                                                            ["bpr", "c2", "metrics", "sweep", "plugin", "c5", "vae", "neumf"])
+                                                            ["bpr", "c2", "metrics", "sweep", "plugin", "c5", "vae", "neumf", "graph"])
 
     # ---------------- synthetic inputs, resident in HBM -------------------------------------------
     # headline: north_star's target shape (every rank builds the same CSR and keeps its part)
@@ -1421,7 +1491,7 @@ def main():
         second = bpr_leg(args, ctx, world, rank, data, "item", args.topk_shard or "item")
     del data, indptr, indices
     torch.cuda.empty_cache()
-    sweep = plugin = vae = neumf = c2 = c5 = None
+    sweep = plugin = vae = neumf = c2 = c5 = graph = None
     if world == 1 and not args.force_sharded:
         if "c2" in legs or "sweep" in legs or "plugin" in legs:
             # BASELINE configs[1] (1 M users x 100 K items, d = 128: the headline of rounds 1-3): the same two steps, the every-row fused
@@ -1459,6 +1529,9 @@ def main():
             torch.cuda.empty_cache()
         if "neumf" in legs:
             neumf = neumf_leg(args, ctx)
+            torch.cuda.empty_cache()
+        if "graph" in legs:
+            graph = graph_leg(args, ctx)
             torch.cuda.empty_cache()
     # every rank empties its C-level stdout (RCCL's banner) before rank 0 prints the line, so that the line is the last one
     try:
@@ -1518,6 +1591,8 @@ def main():
         line["vae"] = vae
     if neumf is not None:
         line["neumf"] = neumf
+    if graph is not None:
+        line["graph"] = graph
     if want_cpu and host is not None:
         line["cpu_baseline"] = cpu_baseline(args, host)
     emit(line, args)

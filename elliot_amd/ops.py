@@ -968,6 +968,27 @@ def normalized_bipartite_laplacian(train_csr_indptr, train_csr_indices, n_users,
     return A.indptr.astype(np.int64), A.indices.astype(np.int32), vals.astype(np.float32)
 
 
+def normalized_bipartite_laplacian_device(indptr, indices, n_users, n_items):
+    """The same operator built on the device from a device CSR (large synthetic graphs: 1.6e8 non-zeros take a minute through SciPy).
+    Same pattern and order; the values come from torch's fp32 pow, which may differ from NumPy's in the last bit -- the plugin (whose
+    values are pinned to the reference's, tests/test_oracle_graph.py) uses the host builder above."""
+    dev = indptr.device
+    U, I = int(n_users), int(n_items)
+    deg_u = (indptr[1:] - indptr[:-1])
+    cols = indices.to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(U, device=dev, dtype=torch.int64), deg_u)
+    deg_i = torch.bincount(cols, minlength=I)
+    deg = torch.cat([deg_u, deg_i]).to(torch.float32) + torch.tensor(1e-7, dtype=torch.float32, device=dev)
+    dinv = deg.pow(-0.5)
+    order = torch.sort(cols * U + rows, stable=True).indices                       # item rows: (item, user) ascending
+    t_rows, t_cols = cols[order], rows[order]
+    lap_indptr = torch.cat([indptr, indptr[-1] + torch.cumsum(deg_i, 0)]).to(torch.int64)
+    lap_indices = torch.cat([cols + U, t_cols]).to(torch.int32)
+    r_all = torch.cat([rows, t_rows + U])
+    vals = (dinv[lap_indices.long()] * dinv[r_all]).to(torch.float32)
+    return lap_indptr, lap_indices, vals
+
+
 class GraphCSR:
     """el_graph_csr: a sparse N x N operator over the stacked [users; items] table, device-resident, with the chunk decomposition
     of its product (every row cut into chunks of <= 512 non-zeros; multi-chunk rows reduce their partial rows in order)."""
