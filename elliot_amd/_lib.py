@@ -150,7 +150,8 @@ PROTOTYPES = {
     "el_bprmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
                                       C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_float, _f64p,
                                       C.c_int, C.c_void_p, C.c_size_t]),
-    "el_bprmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "el_bprmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
+    "el_bprmf_deterministic": (C.c_int, []),
     "el_bprmf_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
                                  C.c_float, C.c_float, C.c_int32, _f64p, C.c_void_p, C.c_size_t]),
     "el_bprmf_grads_presorted": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64,
@@ -224,7 +225,7 @@ PROTOTYPES = {
                                       C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int32, C.c_void_p,
                                       _f64p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "el_topk_rerank": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int64, C.c_int64, C.c_int32]),
-    "el_cml_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "el_cml_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "el_cml_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float,
                                  _f32p, _f32p, _f64p]),
     "el_cml_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BprmfState), _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float,

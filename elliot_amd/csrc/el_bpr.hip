@@ -763,7 +763,7 @@ extern "C" __attribute__((visibility("hidden"))) int el_bprmf_train_step_sorted(
                                           const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w,
                                           float l_b, int opt, int32_t step, float lr_t, double* loss_out, void* ws,
                                           size_t ws_bytes);
-extern "C" size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I);
+extern "C" size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I, int32_t F);
 
 extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, const int32_t* u,
                                    const int32_t* i, const int32_t* j, int64_t B, float lr, float l_w, float l_b,
@@ -776,17 +776,17 @@ extern "C" int el_bprmf_train_step(el_ctx* ctx, void* stream, const el_bprmf_sta
     if (B <= 0) return 0;
     const el_bprmf_state st = *stp;
     bool sorted = (algo == EL_BPR_SORTED);
-    if (algo == EL_BPR_AUTO) sorted = (B >= 2048 || st.uslot) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I);
-    if (st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE && algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I)) sorted = true;
+    if (algo == EL_BPR_AUTO) sorted = (B >= 2048 || st.uslot) && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I, st.F);
+    if (st.Gu_next && opt == EL_OPT_ADAM_TF_DENSE && algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I, st.F)) sorted = true;
     if (st.Gu_last) {
-        EL_REQUIRE(algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I),
+        EL_REQUIRE(algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I, st.F),
                    "el_bprmf_train_step: the deferred decay (Gu_last) needs the SORTED path and its workspace");
         sorted = true;
     }
     if (st.Gi_last) {
         // (the fused item side stamps Gi_last per row: a step on another path would leave the stamps behind and a later sorted step
         //  would replay gradient-free updates on rows that are already current)
-        EL_REQUIRE(algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I),
+        EL_REQUIRE(algo != EL_BPR_ATOMIC && ws != nullptr && ws_bytes >= el_bprmf_ws_bytes(B, st.U, st.I, st.F),
                    "el_bprmf_train_step: the fused item side (Gi_last) needs the SORTED path and its workspace");
         sorted = true;
     }

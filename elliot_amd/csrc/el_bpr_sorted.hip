@@ -11,8 +11,10 @@
 //   4. k_bpr_item_seg      per item segment: dGi row = sum +-s_b gamma_u(b) + cnt l_w gamma_item, dBi
 //   5. optimiser           k_adam_dense (TF semantics) / k_rows_apply (el_bpr.hip)
 // Segments longer than a chunk (popular items under Zipf: tens of thousands of occurrences) are
-// split over several lane groups whose partial rows are combined with a few atomics; segments that
-// live inside one chunk are written with plain stores.
+// split over several lane groups; segments that live inside one chunk are written with plain stores, a
+// segment cut by chunk boundaries leaves one partial row per chunk and k_bpr_item_combine adds them IN
+// CHUNK ORDER (round 6: no floating-point atomics anywhere in the sorted step -- two runs on the same
+// batches give the same bits, and the fused / deferred forms equal the two-pass form bit for bit at any size).
 #include "el_common.h"
 #include <cstdlib>
 #include <cstring>
@@ -728,15 +730,19 @@ __global__ __launch_bounds__(256) void k_bpr_flush_items(el_bprmf_state st, int3
 // of a segment into gGi, this form takes Keras' Adam step on the item row right away -- theta (it is the L2 term's operand
 // anyway), m, v and the bias with its slots, IN PLACE -- and stamps Gi_last[item] = t.  The three rows of a segment head are
 // fetched together with the gamma_u gathers of its SUB-batch, so a walk over cold items (a new segment at nearly every position)
-// keeps as many loads in flight as the two-pass walk did.  A segment cut by a chunk boundary (the popular items of a Zipf
-// catalogue) still adds its partial rows into gGi / gBi with atomics; the partial that holds the segment's first position puts
-// the item on the step's split list, and k_bpr_item_split -- the next launch -- takes the step on the listed rows from the
-// accumulated gradient and clears it.  (No in-kernel "last partial" hand-over: an agent-scope fence on this part writes back the
+// keeps as many loads in flight as the two-pass walk did.
+// Both forms: a segment cut by a chunk boundary (the popular items of a Zipf catalogue) leaves its partial rows in the step's partial
+// buffer -- slot 2 g for the segment that reaches INTO lane group g's chunk from the left, slot 2 g + 1 for the one that starts
+// inside it and runs on -- and the group that holds the segment's first position puts (item, g) on the step's split list;
+// k_bpr_item_combine -- the next launch -- adds a listed item's partials in chunk order and takes the step (fused form) or stores the
+// gradient row (two-pass form).  (No in-kernel "last partial" hand-over: an agent-scope fence on this part writes back the
 // XCD's L2 -- measured: 0.25 -> 0.92 ms for the item segments at configs[1] with one fence pair per chunk.)
 // (The user-side kernel of the step ran before: nothing else reads an item row here.)
 struct ItemFuse {
     int32_t* last;       // [I]
-    int32_t* split;      // [0] = number of listed rows (zeroed before the launch), [1 ..] = the rows
+    int32_t* split;      // [0] = number of listed rows (zeroed before the launch), [1 + 2 e], [2 + 2 e] = row and head group of entry e
+    float* part;         // [2 groups, F] partial rows of cut segments; part_b [2 groups] their bias parts
+    float* part_b;
     float* hist;         // lr ring: this kernel records lr_t of step t for the replays that follow
     int hist_mask;
     float lr_t, b1, b2, eps;
@@ -761,7 +767,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     int cpos = 0, cneg = 0;
     auto flush = [&](bool ends_inside) {
         const float* pr = p.st.Gi + cur * F;
-        float* g = p.st.gGi + cur * F;
         // CML: d/di of +-|u - i|^2 adds -(sum of the coefficients) times the row itself
         const float w = (float)(cpos + cneg) * p.l_w - (p.cml ? bacc : 0.f);
         const bool plain = started_inside && ends_inside;
@@ -792,6 +797,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             }
             return;
         }
+        // the gradient row of this walk: the whole segment's (plain, two-pass form: stored) or a partial of a cut segment
+        float* g = plain ? p.st.gGi + cur * F : f.part + (2 * grp + (started_inside ? 1 : 0)) * (int64_t)F;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int e = (sub + q * lpt) * VW;
@@ -805,12 +812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 }
 #pragma unroll
                 for (int x = 0; x < VW; ++x) v[x] = acc[q][x] + w * r[x];
-                if (plain) {
-                    stv<VW>(g + e, v);
-                } else {
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) atomicAdd(g + e + x, v[x]);
-                }
+                stv<VW>(g + e, v);
             }
         }
         if (sub == 0) {
@@ -819,13 +821,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             if (plain)
                 p.st.gBi[cur] = gb;
             else
-                atomicAdd(p.st.gBi + cur, gb);
+                f.part_b[2 * grp + (started_inside ? 1 : 0)] = gb;
             if (p.st.tGi) {
                 p.st.tGi[cur] = p.step;
                 p.st.tBi[cur] = p.step;
             }
+            if (!plain && started_inside) {                       // the head of a cut segment: one entry on the split list
+                const int e2 = atomicAdd(f.split, 1);
+                f.split[1 + 2 * e2] = (int32_t)cur;
+                f.split[2 + 2 * e2] = (int32_t)grp;
+            }
         }
-        if (IFUSE && started_inside && sub == 0) f.split[1 + atomicAdd(f.split, 1)] = (int32_t)cur;
     };
     // staged index chains, as in k_bpr_user_seg: BPR_ISTG positions per stage (key, payload -> s_b, u_b)
     extern __shared__ unsigned char seg_lds[];
@@ -928,43 +934,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     flush(p1 == p.n || (int64_t)(p.keys[p1] - p.key_off) != cur);
 }
 
-// the rows the fused item segments put on the split list (segments cut by a chunk boundary): Keras' Adam step from the gradient the
-// partials accumulated in gGi / gBi, accumulators cleared, Gi_last stamped.  One lane group per listed row.
-template <int CPL>
-__global__ __launch_bounds__(256) void k_bpr_item_split(el_bprmf_state st, ItemFuse f, int lpt) {
-    constexpr int VW = 4;
+// The rows on the split list (segments cut by chunk boundaries): one WORKGROUP per listed row.  The segment's partial rows are the
+// head's (slot 2 g0 + 1) and one per following lane group whose chunk still begins inside the segment (slot 2 g, g = g0 + 1 ...: the
+// sorted key at that chunk's first position is still this item).  The lane groups of the workgroup each add a contiguous share of the
+// partials in ascending order, their sums meet in LDS in lane-group order: a fixed order for a given batch -- no atomics, the same bits on
+// every run and in both forms.  Then: fused form -- Keras' Adam step on the row in place, Gi_last stamped; two-pass form -- the gradient
+// row stored into gGi / gBi for the dense pass.  (The hottest item of a Zipf catalogue holds ~1 100 partials at B = 2^20: eight lane
+// groups x eight loads in flight walk them in ~18 round trips.)
+template <int VW, int CPL, bool IFUSE>
+__global__ __launch_bounds__(256) void k_bpr_item_combine(el_bprmf_state st, ItemFuse f, const u32* __restrict__ keys, u32 key_off, int64_t n,
+                                                          int chunk, int lpt) {
     const int F = st.F;
-    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpt;
-    const int sub = (int)(threadIdx.x & (lpt - 1));
-    if (g >= (int64_t)f.split[0]) return;
-    const int64_t row = (int64_t)f.split[1 + g];
-    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-        const int e = (sub + q * lpt) * VW;
-        if (e < F) {
-            float th[VW], mm[VW], vv[VW], gg[VW], zz[VW];
-            ldv<VW>(st.Gi + row * F + e, th);
-            ldv<VW>(st.mGi + row * F + e, mm);
-            ldv<VW>(st.vGi + row * F + e, vv);
-            ldv<VW>(st.gGi + row * F + e, gg);
-#pragma unroll
-            for (int x = 0; x < VW; ++x) {
-                el_adam_elem(th[x], mm[x], vv[x], gg[x], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
-                zz[x] = 0.f;
-            }
-            stv<VW>(st.Gi + row * F + e, th);
-            stv<VW>(st.mGi + row * F + e, mm);
-            stv<VW>(st.vGi + row * F + e, vv);
-            stv<VW>(st.gGi + row * F + e, zz);
+    const int nlist = f.split[0];
+    __shared__ int s_np;
+    __shared__ float s_red[4096];                             // (256 / lpt) lane groups x F floats: lpt * VW * CPL >= F, CPL <= 4 -> <= 4096
+    __shared__ float s_rb[32];
+    const int ngl = 256 / lpt, gl = threadIdx.x / lpt, sub = threadIdx.x & (lpt - 1);
+    for (int ent = blockIdx.x; ent < nlist; ent += gridDim.x) {
+        const int64_t row = (int64_t)f.split[1 + 2 * ent];
+        const int64_t g0 = (int64_t)f.split[2 + 2 * ent];
+        // how many lane groups after g0 continue the segment (consecutive): the first chunk whose first key is another item ends it
+        if (threadIdx.x == 0) s_np = 0x7fffffff;
+        __syncthreads();
+        for (int base = 0; s_np == 0x7fffffff; base += 256) {
+            const int64_t gq = g0 + 1 + base + threadIdx.x, pos = gq * (int64_t)chunk;
+            const bool cont = pos < n && (int64_t)(keys[pos] - key_off) == row;
+            if (!cont) atomicMin(&s_np, base + (int)threadIdx.x);
+            __syncthreads();
         }
-    }
-    if (sub == 0) {
-        float beta = st.Bi[row], mb = st.mBi[row], vb = st.vBi[row];
-        el_adam_elem(beta, mb, vb, st.gBi[row], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
-        st.Bi[row] = beta, st.mBi[row] = mb, st.vBi[row] = vb;
-        st.gBi[row] = 0.f;
-        f.last[row] = f.t;
+        const int ncont = s_np;                                // continuation partials: slots 2 (g0 + 1 + k), k < ncont
+        const int np = 1 + ncont;                              // + the head's
+        const int per = (np + ngl - 1) / ngl;
+        const int k0 = gl * per, k1 = (k0 + per < np) ? k0 + per : np;
+        float acc[CPL][VW];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+        float accb = 0.f;
+        auto slot_of = [&](int k) { return k == 0 ? 2 * g0 + 1 : 2 * (g0 + k); };
+        for (int k = k0; k < k1; k += 8) {
+            float v[8][CPL][VW];
+            float vb[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int kk = k + t < k1 ? k + t : k;
+                const int64_t sl = slot_of(kk);
+                vb[t] = f.part_b[sl];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) v[t][q][x] = 0.f;
+                    if (e < F) ldv<VW>(f.part + sl * F + e, v[t][q]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (k + t >= k1) continue;
+                accb += vb[t];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) acc[q][x] += v[t][q][x];
+            }
+        }
+        // lane-group sums -> LDS -> added in lane-group order by group 0
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) stv<VW>(s_red + gl * F + e, acc[q]);
+        }
+        if (sub == 0) s_rb[gl] = accb;
+        __syncthreads();
+        if (gl == 0) {
+            const int used = (np + per - 1) / per;              // lane groups that held partials
+            float gb = 0.f;
+            for (int h = 0; h < used; ++h) gb += s_rb[h];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+                if (e >= F) continue;
+                float gg[VW];
+#pragma unroll
+                for (int x = 0; x < VW; ++x) gg[x] = 0.f;
+                for (int h = 0; h < used; ++h) {
+                    float t4[VW];
+                    ldv<VW>(s_red + h * F + e, t4);
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) gg[x] += t4[x];
+                }
+                if (IFUSE) {
+                    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+                    float th[VW], mm[VW], vv[VW];
+                    ldv<VW>(st.Gi + row * F + e, th);
+                    ldv<VW>(st.mGi + row * F + e, mm);
+                    ldv<VW>(st.vGi + row * F + e, vv);
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], gg[x], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                    stv<VW>(st.Gi + row * F + e, th);
+                    stv<VW>(st.mGi + row * F + e, mm);
+                    stv<VW>(st.vGi + row * F + e, vv);
+                } else {
+                    stv<VW>(st.gGi + row * F + e, gg);
+                }
+            }
+            if (sub == 0) {
+                if (IFUSE) {
+                    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+                    float beta = st.Bi[row], mb = st.mBi[row], vb2 = st.vBi[row];
+                    el_adam_elem(beta, mb, vb2, gb, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+                    st.Bi[row] = beta, st.mBi[row] = mb, st.vBi[row] = vb2;
+                    f.last[row] = f.t;
+                } else {
+                    st.gBi[row] = gb;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1008,11 +1095,15 @@ struct SortedWs {
     size_t tmp_bytes;
     int32_t* rowptr;       // [U + 1] first sorted position of every user row (fused user-side kernel)
     int32_t* hpos;         // [B] per triplet: sorted head position of its user's segment (deferred decay)
-    int32_t* split;        // [1 + B / 8 + 2] fused item side: rows whose segment a chunk boundary cut (count, then the rows)
+    int32_t* split;        // [1 + 2 (B / 8 + 4)] item segments cut by a chunk boundary: count, then (row, head lane group) pairs
+    float* part;           // [2 (B / 8 + 1), F] + [2 (B / 8 + 1)]: their partial rows and bias parts (NULL when carved without F)
+    float* part_b;
     size_t total;
 };
 
-static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
+// F = 0: the part of the layout the sort needs (el_bprmf_presort does not know the factor count); F > 0: + the partial rows of the cut
+// item segments at the END (the arrays in front of them sit at the same offsets either way)
+static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w, int F = 0) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char* p = base ? base + off : nullptr;
@@ -1036,7 +1127,12 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w) {
     w->tmp = take(w->tmp_bytes);
     w->rowptr = (int32_t*)take((size_t)(U + 1) * 4);
     w->hpos = (int32_t*)take((size_t)B * 4);
-    w->split = (int32_t*)take((size_t)(B / 8 + 4) * 4);
+    w->split = (int32_t*)take((size_t)(2 * (B / 8 + 4) + 4) * 4);
+    w->part = w->part_b = nullptr;
+    if (F > 0) {                                         // (lane groups: at most 2 B / 16 -- item_chunk_for never goes below 16 positions)
+        w->part = (float*)take((size_t)2 * (B / 8 + 1) * (size_t)F * 4);
+        w->part_b = (float*)take((size_t)2 * (B / 8 + 1) * 4);
+    }
     w->total = off;
     return 0;
 }
@@ -1057,12 +1153,15 @@ static int sort_batch(hipStream_t s, const SortedWs& w, const int32_t* u, const 
     return 0;
 }
 
-extern "C" size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I) {
-    if (B <= 0) return 0;
+extern "C" size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I, int32_t F) {
+    if (B <= 0 || F <= 0) return 0;
     SortedWs w;
-    if (carve_ws(B, U, I, nullptr, &w)) return 0;
+    if (carve_ws(B, U, I, nullptr, &w, F)) return 0;
     return w.total;
 }
+
+// 1: the sorted step sums every gradient row in a fixed order (no floating-point atomics on rows): same batches, same bits
+extern "C" int el_bprmf_deterministic(void) { return 1; }
 
 // defined in el_bpr.hip
 int el_bprmf_apply_optimizer(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st, const int32_t* u, const int32_t* i,
@@ -1298,10 +1397,12 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     const bool ser = base.st.replay_series != 0;
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
+    fi.split = w.split, fi.part = w.part, fi.part_b = w.part_b;
     if (ifuse) {
-        fi.last = base.st.Gi_last, fi.split = w.split, fi.hist = base.st.lr_hist, fi.hist_mask = base.st.lr_hist_cap - 1;
+        fi.last = base.st.Gi_last, fi.hist = base.st.lr_hist, fi.hist_mask = base.st.lr_hist_cap - 1;
         fi.lr_t = lr_t, fi.b1 = 0.9f, fi.b2 = 0.999f, fi.eps = 1e-7f, fi.t = base.step;
     }
+    const unsigned gridC = (unsigned)(gi < 4096 ? (gi < 1 ? 1 : gi) : 4096);      // one workgroup per listed row, grid-stride
     // deferred user side: two positions in flight per lane group with the heads' m / v / stamp prefetched (rows of <= 512 B per lane
     // pass: VW == 4, CPL <= 2; measured against 3, 4, 8 in flight and against a row per whole wave in round 5: profiles/r05_*)
 #define EL_SEG(CPL_)                                                                                      \
@@ -1318,12 +1419,13 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
         } else {                                                                                          \
             EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, false>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
         }                                                                                                 \
-        if (ifuse) {                                                                                      \
-            EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));                                               \
+        EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));                                                   \
+        if (ifuse && VW == 4 && CPL_ <= 2) {                                                              \
             EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridI), dim3(256), ldsI, s, pi, fi);   \
-            EL_LAUNCH("k_bpr_item_split", (k_bpr_item_split<CPL_>), dim3(gridI), dim3(256), 0, s, pi.st, fi, lpt);       \
+            EL_LAUNCH("k_bpr_item_combine", (k_bpr_item_combine<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridC), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, pi.n, pi.chunk, lpt);  \
         } else {                                                                                          \
             EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi);    \
+            EL_LAUNCH("k_bpr_item_combine", (k_bpr_item_combine<VW, CPL_, false>), dim3(gridC), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, pi.n, pi.chunk, lpt);  \
         }                                                                                                 \
     } while (0)
     if (cpl == 1) EL_SEG(1);
@@ -1346,7 +1448,7 @@ static int sorted_step(el_ctx* ctx, void* stream, const el_bprmf_state* stp, con
     EL_REQUIRE(B < (1LL << 30), "el_bprmf_train_step_sorted: batch too large");
     const el_bprmf_state st = *stp;
     SortedWs w;
-    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_bprmf_train_step_sorted: rocprim size query failed");
+    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w, st.F) == 0, "el_bprmf_train_step_sorted: rocprim size query failed");
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_train_step_sorted: workspace too small (%zu < %zu)",
                ws_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
@@ -1428,7 +1530,7 @@ int el_bpr_sorted_cml_grads(el_ctx* ctx, hipStream_t s, const el_bprmf_state& st
                             const int32_t* j, int64_t B, float l_w, float l_b, float* cD, const float* cE, void* ws,
                             size_t ws_bytes) {
     SortedWs w;
-    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
+    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w, st.F) == 0, "el_cml_train_step: rocprim size query failed");
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_cml_train_step: segment workspace too small (%zu < %zu)", ws_bytes, w.total);
     if (int rc = sort_batch(s, w, u, i, j, B, st.U, st.I, false)) return rc;
     SegParams base;
@@ -1632,7 +1734,7 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     const el_bprmf_state st = *stp;
     vec = vec && (((uintptr_t)dU) % 16 == 0);
     SortedWs w;
-    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w) == 0, "el_bprmf_shard_grads: rocprim size query failed");
+    EL_REQUIRE(carve_ws(B, st.U, st.I, (char*)ws, &w, st.F) == 0, "el_bprmf_shard_grads: rocprim size query failed");
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "el_bprmf_shard_grads: workspace too small (%zu < %zu)", ws_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
     int cpl = 1;
@@ -1678,7 +1780,15 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     const size_t ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
-#define EL_IS(VW_, CPL_) EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi)
+    fi.split = w.split, fi.part = w.part, fi.part_b = w.part_b;
+    EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));
+    const unsigned gridC = (unsigned)(gi < 4096 ? (gi < 1 ? 1 : gi) : 4096);
+#define EL_IS(VW_, CPL_)                                                                                                                     \
+    do {                                                                                                                                     \
+        EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi);                            \
+        EL_LAUNCH("k_bpr_item_combine", (k_bpr_item_combine<VW_, CPL_, false>), dim3(gridC), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, \
+                  pi.n, pi.chunk, lpt);                                                                                                      \
+    } while (0)
     if (vec) {
         if (cpl == 1) EL_IS(4, 1); else if (cpl == 2) EL_IS(4, 2); else EL_IS(4, 4);
     } else {

@@ -282,11 +282,11 @@ static CmlArgs cml_args(const el_bprmf_state* stp, const int32_t* u, const int32
     return p;
 }
 
-extern "C" size_t el_cml_ws_bytes(int64_t B, int64_t B_all, int64_t U, int64_t I) {
+extern "C" size_t el_cml_ws_bytes(int64_t B, int64_t B_all, int64_t U, int64_t I, int32_t F) {
     if (B <= 0) return 0;
     CmlWs w;
     if (carve(B, B_all < B ? B : B_all, nullptr, &w)) return 0;
-    return w.total + el_bprmf_ws_bytes(B, U, I);             // + the sort / segment scratch of the gradient pass
+    return w.total + el_bprmf_ws_bytes(B, U, I, F);             // + the sort / segment scratch of the gradient pass
 }
 
 // phase 1: D_a, E_a of the rank's triplets (+ the regulariser into loss_out)
@@ -334,7 +334,7 @@ extern "C" int el_cml_grads(el_ctx* ctx, void* stream, const el_bprmf_state* stp
     EL_REQUIRE(D && E && D_all && E_all && B_all >= B && B_all < (1LL << 31) && loss_out, "el_cml_grads: bad arguments");
     CmlWs w;
     EL_REQUIRE(carve(B, B_all, (char*)ws, &w) == 0, "el_cml_grads: rocprim size query failed");
-    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I) : 0);
+    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I, stp->F) : 0);
     EL_REQUIRE(ws != nullptr && ws_bytes >= need, "el_cml_grads: workspace too small (%zu < %zu)", ws_bytes, need);
     return cml_grads(ctx, (hipStream_t)stream, stp, u, i, j, B, l_w, l_b, margin, D, E, D_all, E_all, B_all, loss_out, (char*)ws, ws_bytes, w);
 }
@@ -349,7 +349,7 @@ extern "C" int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state
     EL_REQUIRE(loss_out && step >= 1, "el_cml_train_step: bad loss pointer / step");
     CmlWs w;
     EL_REQUIRE(carve(B, B, (char*)ws, &w) == 0, "el_cml_train_step: rocprim size query failed");
-    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I) : 0);
+    const size_t need = w.total + (B >= 2048 ? el_bprmf_ws_bytes(B, stp->U, stp->I, stp->F) : 0);
     EL_REQUIRE(ws != nullptr && ws_bytes >= need, "el_cml_train_step: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     CmlArgs p = cml_args(stp, u, i, j, B, l_w, l_b, margin, loss_out);

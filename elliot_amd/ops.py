@@ -832,7 +832,7 @@ class BprmfDeviceState:
                 self.ensure_rows(B)
             self._ensure_old(B)
         if algo == _lib.EL_BPR_SORTED or (algo == _lib.EL_BPR_AUTO and B >= 2048) or self.compact:
-            need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
+            need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I), int(self.F)))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
             ws, ws_bytes = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
@@ -848,7 +848,7 @@ class BprmfDeviceState:
         """First half of train_step: loss + the summed row gradients of the batch (what OptimizerV2 receives after its segment
         sum, BPRMF_batch_model.py:77) into gGu (or the compact rows) / gGi / gBi, no optimiser.  apply() consumes them."""
         B = u.numel()
-        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I)))
+        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I), int(self.F)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         self.ensure_rows(B)
@@ -874,7 +874,7 @@ class BprmfDeviceState:
     #    batch of step t+1 can be drawn and ordered on a side stream while step t's segment kernels and optimiser pass run
     def sort_workspace(self, B):
         """A workspace tensor for presort() / train_step_presorted() (el_bprmf_ws_bytes): one per batch in flight."""
-        return torch.empty(int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))), dtype=torch.uint8, device=self.ctx.device)
+        return torch.empty(int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I), int(self.F))), dtype=torch.uint8, device=self.ctx.device)
 
     def presort(self, u, i, j, ws):
         """First half of the sorted gradient path: (row, triplet) pairs of the batch, ordered, into `ws` (current stream)."""
@@ -913,7 +913,7 @@ class BprmfDeviceState:
         if not self.fused:
             self.ensure_rows(B)
         self._ensure_old(B)
-        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I))) if (B >= 2048 or self.compact) else 0
+        need = int(self.ctx.lib.el_bprmf_ws_bytes(int(B), int(self.U), int(self.I), int(self.F))) if (B >= 2048 or self.compact) else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         lneed = int(self.ctx.lib.el_bprmf_train_loop_ws_bytes(int(events), int(B)))
@@ -1984,7 +1984,7 @@ class CmlDeviceState(BprmfDeviceState):
         self._items2 = None
 
     def _cml_workspace(self, B, B_all):
-        need = int(self.ctx.lib.el_cml_ws_bytes(int(B), int(B_all), int(self.U), int(self.I)))
+        need = int(self.ctx.lib.el_cml_ws_bytes(int(B), int(B_all), int(self.U), int(self.I), int(self.F)))
         if self._cml_ws is None or self._cml_ws.numel() < need:
             self._cml_ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         return need

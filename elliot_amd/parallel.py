@@ -287,7 +287,7 @@ class HipBackend:
         import ctypes as C
         st, ctx = self.state, self.ctx
         B = u.numel()
-        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I)))
+        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I), int(st.F)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
         if self._dU is None or self._dU.shape[0] != B:
@@ -371,7 +371,7 @@ class HipDenseBackend:
         C = self._C
         st, ctx = self.state, self.ctx
         B = u.numel()
-        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I)))
+        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I), int(st.F)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
         ops.check(ctx.lib.el_bprmf_grads(ctx.handle, ctx.stream(), C.byref(st._c), ops._ptr(u, torch.int32),
@@ -449,7 +449,7 @@ class HipUserShardBackend:
 
     def _workspace(self, B):
         st, ctx = self.state, self.ctx
-        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I)))
+        need = int(ctx.lib.el_bprmf_ws_bytes(int(B), int(st.U), int(st.I), int(st.F)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
 

@@ -66,7 +66,7 @@ int main(void) {
     int32_t* d_indices = dev_copy(indices, sizeof(indices));
     int32_t* trip = dev_copy(NULL, 3 * B * sizeof(int32_t));
     double* d_loss = dev_copy(NULL, sizeof(double));
-    size_t ws_bytes = el_bprmf_ws_bytes(B, U, I);
+    size_t ws_bytes = el_bprmf_ws_bytes(B, U, I, F);
     void* ws = dev_copy(NULL, ws_bytes);
 
     const float lr = 0.01f;

@@ -48,7 +48,7 @@ typedef struct el_ctx el_ctx;
                             *    against 5 runs unchanged)
                             * 7: el_bprmf_state ends in replay_series; el_ctx_set_option / el_ctx_get_option (the library no
                             *    longer reads the environment after el_ctx_create); el_graph_csr, el_spmm_csr_f32,
-                            *    el_lightgcn_propagate; el_mf2020_train                                                  */
+                            *    el_lightgcn_propagate; el_ngcf_*; el_mf2020_train; el_bprmf_ws_bytes / el_cml_ws_bytes take F, el_bprmf_deterministic                                                  */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -225,7 +225,12 @@ enum {
 };
 
 /* Bytes of scratch el_bprmf_train_step needs for the SORTED path with batch size B. */
-size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I);
+size_t el_bprmf_ws_bytes(int64_t B, int64_t U, int64_t I, int32_t F);   /* (ABI 7: + F -- the workspace also holds the partial rows of cut item segments) */
+/* 1 when the sorted step sums every gradient row in a fixed order (ABI 7: always): no floating-point atomics on table rows -- cut item
+ * segments leave per-chunk partial rows that a second launch adds in chunk order -- so two runs on the same batches give the same bits, and
+ * the fused / deferred forms equal the every-row two-pass form bit for bit.  (The batch LOSS is still a sum of per-workgroup partials in
+ * arrival order: it may differ in its last bits from run to run; no state depends on it.) */
+int el_bprmf_deterministic(void);
 
 /* Replaces: BPRMF_batch_model.train_step (BPRMF_batch_model.py:58-80): two gathers
  * (:49-51), x_ui/x_uj (:53), clip + softplus batch SUM (:65-66), L2 terms (:68-72),
@@ -262,7 +267,7 @@ int el_selftest_replay_math(el_ctx* ctx, void* stream, int64_t n_pairs, uint64_t
  * Bi [I_r], their accumulators); i/j are LOCAL item ids (both inside the shard).  Computes the batch loss,
  * the item-row gradients (gGi/gBi, sorted segments) and one user-gradient row per triplet:
  *   dU[b,:] = s_b (gamma_i - gamma_j) + l_w gamma_u      (float [B,F], reduced by user after the all-gather)
- * ws: el_bprmf_ws_bytes(B, U, I_r).                                                               */
+ * ws: el_bprmf_ws_bytes(B, U, I_r, F).                                                               */
 int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                          const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                          float l_w, float l_b, int32_t step, float* dU, double* loss_out,
@@ -296,13 +301,13 @@ int el_rows_segment_sum(el_ctx* ctx, void* stream, const int32_t* ids, const flo
  * (sorted segments, exactly the first half of el_bprmf_train_step) + loss; no optimiser.  The caller then
  * reduce-scatters gGu over the ranks (RCCL), zeroes it, runs el_bprmf_apply on a state that describes its OWN user rows
  * (Gu/mGu/vGu offset to the shard, gGu = the reduce-scatter output, U = shard rows) and all-gathers the updated rows.
- * ws: el_bprmf_ws_bytes(B, U, I).                                                                      */
+ * ws: el_bprmf_ws_bytes(B, U, I, F).                                                                    */
 int el_bprmf_grads(el_ctx* ctx, void* stream, const el_bprmf_state* st,
                    const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                    float l_w, float l_b, int32_t step, double* loss_out, void* ws, size_t ws_bytes);
 
 /* el_bprmf_grads in two halves: ordering a batch reads only its triplets, so a multi-GPU step can do it for the NEXT batch
- * while the item-gradient all-reduce is in flight.  el_bprmf_presort fills ws (el_bprmf_ws_bytes(B, U, I)) with the sorted
+ * while the item-gradient all-reduce is in flight.  el_bprmf_presort fills ws (el_bprmf_ws_bytes(B, U, I, F)) with the sorted
  * (row, triplet) pairs of (u, i, j); el_bprmf_grads_presorted is el_bprmf_grads on the same triplets and the same ws.     */
 int el_bprmf_presort(el_ctx* ctx, void* stream, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                      int64_t U, int64_t I, void* ws, size_t ws_bytes);
@@ -730,7 +735,7 @@ int el_topk_rerank(el_ctx* ctx, void* stream, int32_t* idx, float* vals, int64_t
  * D_a = |u_a - j_a|^2 - |u_a - i_a|^2, E_b = b(i_b) - b(j_b).  Evaluated in O(B log B) (two float sorts + binary searches;
  * el_cml.hip).  Variables, gradient accumulators and Adam slots are an el_bprmf_state (Gu, Gi, Bi); optimiser = Keras
  * Adam with TF 2.3 sparse-apply semantics (EL_OPT_ADAM_TF_DENSE).  loss_out: device double[1], ADDED to.            */
-size_t el_cml_ws_bytes(int64_t B, int64_t B_all, int64_t U, int64_t I);   /* B_all = B on one GPU */
+size_t el_cml_ws_bytes(int64_t B, int64_t B_all, int64_t U, int64_t I, int32_t F);   /* B_all = B on one GPU */
 int el_cml_train_step(el_ctx* ctx, void* stream, const el_bprmf_state* st, const int32_t* u, const int32_t* i,
                       const int32_t* j, int64_t B, float l_w, float l_b, float margin, int32_t step, float lr_t,
                       double* loss_out, void* ws, size_t ws_bytes);
