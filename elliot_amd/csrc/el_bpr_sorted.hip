@@ -741,6 +741,7 @@ __global__ __launch_bounds__(256) void k_bpr_flush_items(el_bprmf_state st, int3
 struct ItemFuse {
     int32_t* last;       // [I]
     int32_t* split;      // [0] = number of listed rows (zeroed before the launch), [1 + 2 e], [2 + 2 e] = row and head group of entry e
+    int32_t* split_long; // the same layout: listed rows with a whole lane group's width of continuations or more (k_bpr_item_combine fills it)
     float* part;         // [2 groups, F] partial rows of cut segments; part_b [2 groups] their bias parts
     float* part_b;
     float* hist;         // lr ring: this kernel records lr_t of step t for the replays that follow
@@ -934,25 +935,123 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     flush(p1 == p.n || (int64_t)(p.keys[p1] - p.key_off) != cur);
 }
 
-// The rows on the split list (segments cut by chunk boundaries): one WORKGROUP per listed row.  The segment's partial rows are the
-// head's (slot 2 g0 + 1) and one per following lane group whose chunk still begins inside the segment (slot 2 g, g = g0 + 1 ...: the
-// sorted key at that chunk's first position is still this item).  The lane groups of the workgroup each add a contiguous share of the
-// partials in ascending order, their sums meet in LDS in lane-group order: a fixed order for a given batch -- no atomics, the same bits on
-// every run and in both forms.  Then: fused form -- Keras' Adam step on the row in place, Gi_last stamped; two-pass form -- the gradient
-// row stored into gGi / gBi for the dense pass.  (The hottest item of a Zipf catalogue holds ~1 100 partials at B = 2^20: eight lane
-// groups x eight loads in flight walk them in ~18 round trips.)
+// ---- the rows on the split list (segments cut by chunk boundaries) ---------------------------------------------------------------------
+// A listed item's partial rows are the head's (slot 2 g0 + 1) and one per following lane group whose chunk still begins inside the segment
+// (slot 2 g, g = g0 + 1 ...: the sorted key at that chunk's first position is still this item).  They are added in a FIXED order -- no
+// atomics, the same bits on every run and in both forms -- and then: fused form -- Keras' Adam step on the row in place, Gi_last stamped;
+// two-pass form -- the gradient row stored into gGi / gBi for the dense pass.
+//   k_bpr_item_combine       one LANE GROUP per listed row (most rows are cut once: two partials); lane k looks at lane group g0 + 1 + k:
+//                            up to lpt - 1 continuations are summed here in ascending order, longer segments go on the long list
+//   k_bpr_item_combine_long  one WORKGROUP per row of the long list (the popular items of a Zipf catalogue: ~1 100 partials for the
+//                            hottest at B = 2^20): each lane group adds a contiguous share in ascending order, eight loads in flight, the
+//                            shares meet in LDS in lane-group order
+template <int VW, int CPL, bool IFUSE>
+__device__ __forceinline__ void item_row_finish(const el_bprmf_state& st, const ItemFuse& f, int64_t row, int sub, int lpt, const float (&gg)[CPL][VW],
+                                                float gb) {
+    const int F = st.F;
+    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+        if (e >= F) continue;
+        if (IFUSE) {
+            float th[VW], mm[VW], vv[VW];
+            ldv<VW>(st.Gi + row * F + e, th);
+            ldv<VW>(st.mGi + row * F + e, mm);
+            ldv<VW>(st.vGi + row * F + e, vv);
+#pragma unroll
+            for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], gg[q][x], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+            stv<VW>(st.Gi + row * F + e, th);
+            stv<VW>(st.mGi + row * F + e, mm);
+            stv<VW>(st.vGi + row * F + e, vv);
+        } else {
+            stv<VW>(st.gGi + row * F + e, gg[q]);
+        }
+    }
+    if (sub == 0) {
+        if (IFUSE) {
+            float beta = st.Bi[row], mb = st.mBi[row], vb2 = st.vBi[row];
+            el_adam_elem(beta, mb, vb2, gb, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
+            st.Bi[row] = beta, st.mBi[row] = mb, st.vBi[row] = vb2;
+            f.last[row] = f.t;
+        } else {
+            st.gBi[row] = gb;
+        }
+    }
+}
+
 template <int VW, int CPL, bool IFUSE>
 __global__ __launch_bounds__(256) void k_bpr_item_combine(el_bprmf_state st, ItemFuse f, const u32* __restrict__ keys, u32 key_off, int64_t n,
                                                           int chunk, int lpt) {
     const int F = st.F;
-    const int nlist = f.split[0];
+    const int64_t ent = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpt;
+    const int sub = (int)(threadIdx.x & (lpt - 1));
+    if (ent >= (int64_t)f.split[0]) return;
+    const int64_t row = (int64_t)f.split[1 + 2 * ent];
+    const int64_t g0 = (int64_t)f.split[2 + 2 * ent];
+    const int64_t pos = (g0 + 1 + sub) * (int64_t)chunk;
+    const bool cont = pos < n && (int64_t)(keys[pos] - key_off) == row;
+    const unsigned long long bal = __ballot(cont);
+    const int lane0 = (int)(threadIdx.x & 63) & ~(lpt - 1);
+    const unsigned long long mine = lpt >= 64 ? bal : ((bal >> lane0) & ((1ull << lpt) - 1ull));
+    const unsigned long long full = lpt >= 64 ? ~0ull : ((1ull << lpt) - 1ull);
+    if (mine == full) {                                         // lpt or more continuations: the workgroup kernel's
+        if (sub == 0) {
+            const int e2 = atomicAdd(f.split_long, 1);
+            f.split_long[1 + 2 * e2] = (int32_t)row;
+            f.split_long[2 + 2 * e2] = (int32_t)g0;
+        }
+        return;
+    }
+    const int ncont = __builtin_ctzll(~mine);                   // consecutive continuations
+    float acc[CPL][VW];
+    float accb = f.part_b[2 * g0 + 1];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int e = (sub + q * lpt) * VW;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) acc[q][x] = 0.f;
+        if (e < F) ldv<VW>(f.part + (2 * g0 + 1) * F + e, acc[q]);
+    }
+    for (int k = 1; k <= ncont; k += 4) {
+        float v[4][CPL][VW], vb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t sl = 2 * (g0 + (k + t <= ncont ? k + t : k));
+            vb[t] = f.part_b[sl];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int e = (sub + q * lpt) * VW;
+#pragma unroll
+                for (int x = 0; x < VW; ++x) v[t][q][x] = 0.f;
+                if (e < F) ldv<VW>(f.part + sl * F + e, v[t][q]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (k + t > ncont) continue;
+            accb += vb[t];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int x = 0; x < VW; ++x) acc[q][x] += v[t][q][x];
+        }
+    }
+    item_row_finish<VW, CPL, IFUSE>(st, f, row, sub, lpt, acc, accb);
+}
+
+template <int VW, int CPL, bool IFUSE>
+__global__ __launch_bounds__(256) void k_bpr_item_combine_long(el_bprmf_state st, ItemFuse f, const u32* __restrict__ keys, u32 key_off, int64_t n,
+                                                               int chunk, int lpt) {
+    const int F = st.F;
+    const int nlist = f.split_long[0];
     __shared__ int s_np;
     __shared__ float s_red[4096];                             // (256 / lpt) lane groups x F floats: lpt * VW * CPL >= F, CPL <= 4 -> <= 4096
     __shared__ float s_rb[32];
     const int ngl = 256 / lpt, gl = threadIdx.x / lpt, sub = threadIdx.x & (lpt - 1);
     for (int ent = blockIdx.x; ent < nlist; ent += gridDim.x) {
-        const int64_t row = (int64_t)f.split[1 + 2 * ent];
-        const int64_t g0 = (int64_t)f.split[2 + 2 * ent];
+        const int64_t row = (int64_t)f.split_long[1 + 2 * ent];
+        const int64_t g0 = (int64_t)f.split_long[2 + 2 * ent];
         // how many lane groups after g0 continue the segment (consecutive): the first chunk whose first key is another item ends it
         if (threadIdx.x == 0) s_np = 0x7fffffff;
         __syncthreads();
@@ -962,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_bpr_item_combine(el_bprmf_state st, Ite
             if (!cont) atomicMin(&s_np, base + (int)threadIdx.x);
             __syncthreads();
         }
-        const int ncont = s_np;                                // continuation partials: slots 2 (g0 + 1 + k), k < ncont
+        const int ncont = s_np;                                // continuation partials: slots 2 (g0 + k), k = 1 .. ncont
         const int np = 1 + ncont;                              // + the head's
         const int per = (np + ngl - 1) / ngl;
         const int k0 = gl * per, k1 = (k0 + per < np) ? k0 + per : np;
@@ -1011,45 +1110,21 @@ __global__ __launch_bounds__(256) void k_bpr_item_combine(el_bprmf_state st, Ite
             const int used = (np + per - 1) / per;              // lane groups that held partials
             float gb = 0.f;
             for (int h = 0; h < used; ++h) gb += s_rb[h];
+            float gg[CPL][VW];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 const int e = (sub + q * lpt) * VW;
-                if (e >= F) continue;
-                float gg[VW];
 #pragma unroll
-                for (int x = 0; x < VW; ++x) gg[x] = 0.f;
+                for (int x = 0; x < VW; ++x) gg[q][x] = 0.f;
+                if (e >= F) continue;
                 for (int h = 0; h < used; ++h) {
                     float t4[VW];
                     ldv<VW>(s_red + h * F + e, t4);
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) gg[x] += t4[x];
-                }
-                if (IFUSE) {
-                    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
-                    float th[VW], mm[VW], vv[VW];
-                    ldv<VW>(st.Gi + row * F + e, th);
-                    ldv<VW>(st.mGi + row * F + e, mm);
-                    ldv<VW>(st.vGi + row * F + e, vv);
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) el_adam_elem(th[x], mm[x], vv[x], gg[x], f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
-                    stv<VW>(st.Gi + row * F + e, th);
-                    stv<VW>(st.mGi + row * F + e, mm);
-                    stv<VW>(st.vGi + row * F + e, vv);
-                } else {
-                    stv<VW>(st.gGi + row * F + e, gg);
+                    for (int x = 0; x < VW; ++x) gg[q][x] += t4[x];
                 }
             }
-            if (sub == 0) {
-                if (IFUSE) {
-                    const float omb1 = 1.0f - f.b1, omb2 = 1.0f - f.b2;
-                    float beta = st.Bi[row], mb = st.mBi[row], vb2 = st.vBi[row];
-                    el_adam_elem(beta, mb, vb2, gb, f.lr_t, f.b1, f.b2, omb1, omb2, f.eps);
-                    st.Bi[row] = beta, st.mBi[row] = mb, st.vBi[row] = vb2;
-                    f.last[row] = f.t;
-                } else {
-                    st.gBi[row] = gb;
-                }
-            }
+            item_row_finish<VW, CPL, IFUSE>(st, f, row, sub, lpt, gg, gb);
         }
         __syncthreads();
     }
@@ -1096,6 +1171,7 @@ struct SortedWs {
     int32_t* rowptr;       // [U + 1] first sorted position of every user row (fused user-side kernel)
     int32_t* hpos;         // [B] per triplet: sorted head position of its user's segment (deferred decay)
     int32_t* split;        // [1 + 2 (B / 8 + 4)] item segments cut by a chunk boundary: count, then (row, head lane group) pairs
+    int32_t* split_long;   // the same, for the rows k_bpr_item_combine hands on to k_bpr_item_combine_long
     float* part;           // [2 (B / 8 + 1), F] + [2 (B / 8 + 1)]: their partial rows and bias parts (NULL when carved without F)
     float* part_b;
     size_t total;
@@ -1128,6 +1204,7 @@ static int carve_ws(int64_t B, int64_t U, int64_t I, char* base, SortedWs* w, in
     w->rowptr = (int32_t*)take((size_t)(U + 1) * 4);
     w->hpos = (int32_t*)take((size_t)B * 4);
     w->split = (int32_t*)take((size_t)(2 * (B / 8 + 4) + 4) * 4);
+    w->split_long = (int32_t*)take((size_t)(2 * (B / 8 + 4) + 4) * 4);
     w->part = w->part_b = nullptr;
     if (F > 0) {                                         // (lane groups: at most 2 B / 16 -- item_chunk_for never goes below 16 positions)
         w->part = (float*)take((size_t)2 * (B / 8 + 1) * (size_t)F * 4);
@@ -1397,12 +1474,13 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
     const bool ser = base.st.replay_series != 0;
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
-    fi.split = w.split, fi.part = w.part, fi.part_b = w.part_b;
+    fi.split = w.split, fi.split_long = w.split_long, fi.part = w.part, fi.part_b = w.part_b;
     if (ifuse) {
         fi.last = base.st.Gi_last, fi.hist = base.st.lr_hist, fi.hist_mask = base.st.lr_hist_cap - 1;
         fi.lr_t = lr_t, fi.b1 = 0.9f, fi.b2 = 0.999f, fi.eps = 1e-7f, fi.t = base.step;
     }
-    const unsigned gridC = (unsigned)(gi < 4096 ? (gi < 1 ? 1 : gi) : 4096);      // one workgroup per listed row, grid-stride
+    const unsigned gridC = gridI;                                 // a lane group per listed row: at most one row per item lane group
+    const unsigned gridL = (unsigned)(gi < 1024 ? (gi < 1 ? 1 : gi) : 1024);      // long rows: one workgroup each, grid-stride
     // deferred user side: two positions in flight per lane group with the heads' m / v / stamp prefetched (rows of <= 512 B per lane
     // pass: VW == 4, CPL <= 2; measured against 3, 4, 8 in flight and against a row per whole wave in round 5: profiles/r05_*)
 #define EL_SEG(CPL_)                                                                                      \
@@ -1420,12 +1498,15 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
             EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, false>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
         }                                                                                                 \
         EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));                                                   \
+        EL_CHECK_HIP(hipMemsetAsync(w.split_long, 0, 4, s));                                              \
         if (ifuse && VW == 4 && CPL_ <= 2) {                                                              \
             EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridI), dim3(256), ldsI, s, pi, fi);   \
             EL_LAUNCH("k_bpr_item_combine", (k_bpr_item_combine<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridC), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, pi.n, pi.chunk, lpt);  \
+            EL_LAUNCH("k_bpr_item_combine_long", (k_bpr_item_combine_long<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridL), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, pi.n, pi.chunk, lpt);  \
         } else {                                                                                          \
             EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi);    \
             EL_LAUNCH("k_bpr_item_combine", (k_bpr_item_combine<VW, CPL_, false>), dim3(gridC), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, pi.n, pi.chunk, lpt);  \
+            EL_LAUNCH("k_bpr_item_combine_long", (k_bpr_item_combine_long<VW, CPL_, false>), dim3(gridL), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, pi.n, pi.chunk, lpt);  \
         }                                                                                                 \
     } while (0)
     if (cpl == 1) EL_SEG(1);
@@ -1780,14 +1861,17 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     const size_t ldsI = (size_t)(256 / lpt) * BPR_ISTG * 4 * 4;
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
-    fi.split = w.split, fi.part = w.part, fi.part_b = w.part_b;
+    fi.split = w.split, fi.split_long = w.split_long, fi.part = w.part, fi.part_b = w.part_b;
     EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));
-    const unsigned gridC = (unsigned)(gi < 4096 ? (gi < 1 ? 1 : gi) : 4096);
+    EL_CHECK_HIP(hipMemsetAsync(w.split_long, 0, 4, s));
+    const unsigned gridC = gridI, gridL = (unsigned)(gi < 1024 ? (gi < 1 ? 1 : gi) : 1024);
 #define EL_IS(VW_, CPL_)                                                                                                                     \
     do {                                                                                                                                     \
         EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW_, CPL_, false>), dim3(gridI), dim3(256), ldsI, s, pi, fi);                            \
         EL_LAUNCH("k_bpr_item_combine", (k_bpr_item_combine<VW_, CPL_, false>), dim3(gridC), dim3(256), 0, s, pi.st, fi, pi.keys, pi.key_off, \
                   pi.n, pi.chunk, lpt);                                                                                                      \
+        EL_LAUNCH("k_bpr_item_combine_long", (k_bpr_item_combine_long<VW_, CPL_, false>), dim3(gridL), dim3(256), 0, s, pi.st, fi, pi.keys,       \
+                  pi.key_off, pi.n, pi.chunk, lpt);                                                                                          \
     } while (0)
     if (vec) {
         if (cpl == 1) EL_IS(4, 1); else if (cpl == 2) EL_IS(4, 2); else EL_IS(4, 4);
