@@ -1180,7 +1180,11 @@ def neumf_leg(args, ctx):
     gms, groof = gemm_roofline(rep, mlp_flops, K)
     emb_bytes = 24.0 * 2 * (U + I) * F                                 # Keras Adam moves every row of the 4 embedding tables
     ams = sum(v[1] for n, v in rep.items() if n.startswith("k_adam_dense")) / K
-    rows_ms = sum(v[1] for n, v in rep.items() if n in ("k_nmf_catchup", "k_nmf_apply_rows", "k_nmf_flush_rows")) / K
+    # the embedding side: sort of the batch's (row, sample) keys + the two segment passes (+ the long-segment / tail kernels) + the flush
+    seg_names = ("k_nmf_keys", "rocprim_radix_sort_pairs", "k_nmf_seg_fwd", "k_nmf_seg_fwd_tail", "k_nmf_seg_bwd", "k_nmf_seg_bwd_long", "k_nmf_flush_rows")
+    rows_ms = sum(v[1] for n, v in rep.items() if n in seg_names) / K
+    gemm_names = ("k_gemm_b3", "k_gemm_f32", "k_gemm_reduce")
+    non_gemm_ms = sum(v[1] for n, v in rep.items() if n not in gemm_names and n != "k_pw_sample") / K
     return {"value": B * K / dt, "unit": "samples/s", "ms_per_step": ms,
             "workload": f"NeuMF d={F} (GMF + MLP {units}), {U} users x {I} items = the per-GPU shape of BASELINE configs[3] (10M x 1M over "
                         f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: every row of "
@@ -1195,6 +1199,7 @@ def neumf_leg(args, ctx):
                          "step_TFLOPs_mlp": mlp_flops / (ms * 1e-3) / 1e12,
                          "adam_tables_GBs": emb_bytes / (ams * 1e-3) / 1e9 if ams > 0 else None,
                          "embedding_rows_ms_per_step": rows_ms if st.deferred else None,
+                         "non_gemm_ms_per_step": non_gemm_ms,
                          "embedding_step_equivalent_GBs": emb_bytes / (rows_ms * 1e-3) / 1e9 if (st.deferred and rows_ms > 0) else None,
                          "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}
 

@@ -118,8 +118,10 @@ __attribute__((visibility("hidden"))) bool el_side_stream_ready(el_ctx* ctx);   
 // (el_gemm.hip; library-internal, not exported: the C ABI's el_gemm_f32 is its plain form)
 __attribute__((visibility("hidden"))) int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                                                         const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
-                                                        const float* bias, int act, const float* rmask, int64_t ldy, float* colsum, void* ws,
-                                                        size_t ws_bytes, int* fused);
+                                                        const float* bias, int act, const float* rmask, int64_t ldy, float* colsum,
+                                                        float* colsum_part, void* ws, size_t ws_bytes, int* fused);
+// out[c] = sum of part[0 .. P, c] in a fixed order (el_gemm.hip)
+__attribute__((visibility("hidden"))) int el_colsum_finish(void* stream, const float* part, int P, int64_t C, float* out);
 
 #define EL_CHECK_HIP(expr)                                                                \
     do {                                                                                  \

@@ -57,10 +57,11 @@ struct GemmParams {
     // k_gemm_b3, XCD-aware workgroup order (1-D grid): tiles that read the same operand strip form a GROUP of `grp` consecutive
     // workgroups of one XCD (workgroup b runs on XCD b % 8: observed, used for speed only -- any placement is correct)
     // k_gemm_b3 epilogue of a Dense layer's backward pass (el_gemm_f32_x): C <- C where rmask > 0 else 0 (the ReLU derivative of the layer
-    // below, taken from its OUTPUT), colsum[n] += sum_m C[m, n] (that layer's bias gradient; colsum zeroed by the caller)
+    // below, taken from its OUTPUT); the tile's column sums go to colsum_part[row tile, n] (plain stores: el_colsum_finish adds the row
+    // tiles in order -- that layer's bias gradient, the same bits on every run)
     const float* rmask;
     int64_t ldy;
-    float* colsum;
+    float* colsum_part;
     int gx, gy, gz;       // tiles along N, M, K-splits
     int grp_mode;         // 0: 3-D grid as launched; 1: group = the gy row tiles of one column strip; 2: group = the gx column tiles of one
     //                       row strip; 3: group = every tile of one K split
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
     }
     if (p.rmask) {
         // column sums of the tile: the two lane halves hold different rows of the same four columns, the four waves different rows
-        // again -- one atomic per column and tile (the bias gradient's summation order is the hardware's, as in k_relu_bwd_colsum)
+        // again -- one store per column and tile into the tile's row of the partial sums
         cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64), cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
         __syncthreads();                                                // every wave is done with the fragment images
         float* red = reinterpret_cast<float*>(lds);
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(GemmParams p) {
         __syncthreads();
         if (tid < 128 && n0 + tid < p.N) {
             const float t4 = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
-            if (t4 != 0.f) atomicAdd(p.colsum + n0 + tid, t4);
+            p.colsum_part[(m0 / B3_BM) * p.N + n0 + tid] = t4;
         }
     }
 }
@@ -891,15 +892,53 @@ static int gemm_launch_tile(el_ctx* ctx, const GemmParams& p, const GemmPlan& pl
 extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                            const float* bias, int act, void* ws, size_t ws_bytes) {
-    return el_gemm_f32_x(ctx, stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, nullptr, 0, nullptr, ws, ws_bytes, nullptr);
+    return el_gemm_f32_x(ctx, stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, nullptr, 0, nullptr, nullptr, ws, ws_bytes, nullptr);
+}
+
+// out[c] = part[0, c] + part[1, c] + ... + part[P - 1, c], in a FIXED order: a workgroup owns 16 columns, its 64 thread rows a contiguous
+// share of the P partial rows each (ascending), the 64 shares are added in ascending order by the first thread row.  Used wherever a
+// reduction over the batch used to end in float atomics (bias gradients, head-weight gradients).
+__global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ part, int P, int64_t C, float* __restrict__ out) {
+    __shared__ float red[64][17];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 16 + tc;
+    const int per = (P + 63) / 64;
+    const int r0 = tr * per, r1 = r0 + per < P ? r0 + per : P;
+    float acc = 0.f;
+    if (c < C) {
+        for (int r = r0; r < r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (r + k < r1) ? part[(int64_t)(r + k) * C + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (r + k < r1) acc += v[k];
+        }
+    }
+    red[tr][tc] = acc;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        const int used = (P + per - 1) / per;
+        float t = 0.f;
+        for (int h = 0; h < used; ++h) t += red[h][tc];
+        out[c] = t;
+    }
+}
+
+int el_colsum_finish(void* stream, const float* part, int P, int64_t C, float* out) {
+    if (C <= 0) return 0;
+    EL_REQUIRE(part && out && P >= 1, "el_colsum_finish: bad arguments");
+    EL_LAUNCH("k_colsum_finish", k_colsum_finish, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, (hipStream_t)stream, part, P, C, out);
+    return 0;
 }
 
 // el_gemm_f32 + the optional backward epilogue of a Dense layer (library-internal: el_neural.hip).  rmask / colsum: C is masked with
-// the ReLU derivative of rmask [M, ldy] and its column sums are ADDED to colsum[N] inside the GEMM's epilogue -- when the product runs on
-// k_gemm_b3 without a K split; *fused tells (0: C holds the plain product, the caller applies mask and sums itself).
+// the ReLU derivative of rmask [M, ldy] and colsum[N] receives its column sums (SET, summed in a fixed order through colsum_part
+// [ceil(M / 128), N]) -- when the product runs on k_gemm_b3 without a K split; *fused tells (0: C holds the plain product, the caller
+// applies mask and sums itself).
 int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, const float* rmask, int64_t ldy,
-                  float* colsum, void* ws, size_t ws_bytes, int* fused) {
+                  float* colsum, float* colsum_part, void* ws, size_t ws_bytes, int* fused) {
     if (fused) *fused = 0;
     if (int rc = el_bind(ctx)) return rc;
     EL_REQUIRE(A && B && C, "el_gemm_f32: null matrix");
@@ -942,10 +981,10 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
         if (splits < 1) splits = 1;
         p.ws = splits > 1 ? (float*)ws : nullptr;
         p.zeros = ctx->zeros;
-        const bool want_mask = rmask != nullptr && colsum != nullptr;
+        const bool want_mask = rmask != nullptr && colsum != nullptr && colsum_part != nullptr;
         const bool fuse_mask = want_mask && splits == 1 && ldy % 4 == 0 && ((uintptr_t)rmask % 16 == 0) && ldy >= N;
         if (fuse_mask) {
-            p.rmask = rmask, p.ldy = ldy, p.colsum = colsum;
+            p.rmask = rmask, p.ldy = ldy, p.colsum_part = colsum_part;
             if (fused) *fused = 1;
         }
         dim3 grid((unsigned)((N + B3_BN - 1) / B3_BN), (unsigned)((M + B3_BM - 1) / B3_BM), (unsigned)splits);
@@ -973,6 +1012,8 @@ int el_gemm_f32_x(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, 
         else if (!transA && transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<true, true>), grid, dim3(256), 0, s, p);
         else if (transA && !transB) EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, false>), grid, dim3(256), 0, s, p);
         else EL_LAUNCH("k_gemm_b3", (k_gemm_b3<false, true>), grid, dim3(256), 0, s, p);
+        if (fuse_mask)
+            if (int rc = el_colsum_finish(s, colsum_part, p.gy, N, colsum)) return rc;
     } else if (fast) {
         p.ws = (float*)ws;
         p.units = pl.units;

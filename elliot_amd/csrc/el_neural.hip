@@ -14,6 +14,7 @@
 // A.4, k_adam_dense of el_bpr.hip); Dense kernels/biases and the head use the dense ApplyAdam arithmetic.
 // Gathers/scatters are HBM-bound row operations (one lane group per sample, 16 B per lane); the MLP is GEMM-bound.
 #include "el_common.h"
+#include <rocprim/device/device_radix_sort.hpp>
 
 extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
@@ -163,14 +164,17 @@ __global__ __launch_bounds__(256) void k_nmf_gather(el_nmf_state st, const int32
 // One wave per sample, persistent waves.  mode 0: forward only (out_prob[b] = p).  mode 1: training.
 // The head-weight gradient ghw[f] = sum_b dlogit_b cat[b, f] is a reduction over the WHOLE batch onto F + Hl addresses:
 // every wave keeps its share in registers (feature f = lane + 64 q), the four waves of a workgroup are combined in LDS and
-// each workgroup issues one atomic per feature -- per-sample atomics on those few addresses cost 6.4 ms at B = 262 144.
+// each workgroup stores ONE row of partial sums (features, then the bias gradient; its loss share beside it): k_nmf_head_finish adds
+// the workgroups' rows in a fixed order -- no float atomics, the same bits on every run.
+// mfu / mfi (training): the two factors of the MF product as k_nmf_seg_fwd left them; NULL: the product itself in st.MF (k_nmf_gather).
 #define NMF_HEAD_Q 16                                    // features per lane held in registers: F + Hl <= 1024
 // Q = ceil((F + Hl) / 64) rounded up to a power of two (host): the feature loops carry no dead iterations; the head weights
 // sit in registers; the NEXT sample's row is fetched while this one's reduction / exp / log chain runs.
 template <int Q>
 __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* __restrict__ label, int64_t n, int mode,
-                                                  float* out_prob, double* loss_out, int64_t n_div) {
-    __shared__ float wsum[4];
+                                                  float* out_prob, int64_t n_div, const float* __restrict__ mfu,
+                                                  const float* __restrict__ mfi, float* __restrict__ part, double* __restrict__ ploss) {
+    __shared__ float wsum[4], bsum[4];
     __shared__ float facc[4][64 * Q];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int F = st.use_mf ? st.F : 0;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
         for (int q = 0; q < Q; ++q) {
             const int f = lane + 64 * q;
             v[q] = 0.f;
-            if (f < NF) v[q] = f < F ? st.MF[b * F + f] : act_last[b * (int64_t)Hl + (f - F)];
+            if (f < NF) v[q] = f < F ? (mfu ? mfu[b * F + f] * mfi[b * F + f] : st.MF[b * F + f]) : act_last[b * (int64_t)Hl + (f - F)];
         }
     };
     float bacc = 0.f, myloss = 0.f;
@@ -238,24 +242,67 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
 #pragma unroll
     for (int q = 0; q < Q; ++q) facc[wv][lane + 64 * q] = acc[q];
     float wl = el_group_sum(myloss, 64);
-    if (lane == 0) wsum[wv] = wl;
+    if (lane == 0) wsum[wv] = wl, bsum[wv] = bacc;
     __syncthreads();
-    for (int f = threadIdx.x; f < NF; f += 256) {
-        const float g = (facc[0][f] + facc[1][f]) + (facc[2][f] + facc[3][f]);
-        if (g != 0.f) atomicAdd(st.ghw + f, g);
+    float* prow = part + (int64_t)blockIdx.x * (NF + 1);
+    for (int f = threadIdx.x; f < NF; f += 256) prow[f] = (facc[0][f] + facc[1][f]) + (facc[2][f] + facc[3][f]);
+    if (threadIdx.x == 0) {
+        prow[NF] = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
+        ploss[blockIdx.x] = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
     }
-    if (st.head_bias && lane == 0 && bacc != 0.f) atomicAdd(st.ghb, bacc);
-    if (threadIdx.x == 0 && loss_out) {
-        const double tot = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
-        if (tot != 0.0) atomicAdd(loss_out, tot);
+}
+
+// ghw[f] = sum over the workgroups' partial rows (column f), ghb = column NF: el_gemm.hip's ordered column sums with the last column
+// going to its own address
+__global__ __launch_bounds__(1024) void k_nmf_head_finish(const float* __restrict__ part, int P, int NF, float* __restrict__ ghw,
+                                                          float* __restrict__ ghb) {
+    __shared__ float red[64][17];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc, C = NF + 1;
+    const int per = (P + 63) / 64;
+    const int r0 = tr * per, r1 = r0 + per < P ? r0 + per : P;
+    float acc = 0.f;
+    if (c < C) {
+        for (int r = r0; r < r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (r + k < r1) ? part[(int64_t)(r + k) * C + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (r + k < r1) acc += v[k];
+        }
+    }
+    red[tr][tc] = acc;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        const int used = (P + per - 1) / per;
+        float t = 0.f;
+        for (int h = 0; h < used; ++h) t += red[h][tc];
+        if (c < NF) ghw[c] = t;
+        else if (ghb) ghb[0] = t;
+    }
+}
+
+// *loss_out += the workgroups' loss shares, in workgroup order (one wave: lane l adds a contiguous share, lane 0 the 64 shares)
+__global__ __launch_bounds__(64) void k_nmf_loss_finish(const double* __restrict__ ploss, int P, double* loss_out) {
+    __shared__ double sh[64];
+    const int per = (P + 63) / 64, r0 = threadIdx.x * per, r1 = r0 + per < P ? r0 + per : P;
+    double a = 0.0;
+    for (int r = r0; r < r1; ++r) a += ploss[r];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int h = 0; h < 64; ++h) t += sh[h];
+        *loss_out += t;
     }
 }
 
 static void launch_nmf_head(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const float* label, int64_t n, int mode, float* out_prob,
-                            double* loss_out, int64_t n_div, unsigned grid) {
+                            int64_t n_div, unsigned grid, const float* mfu, const float* mfi, float* part, double* ploss) {
     const int NF = (st->use_mf ? st->F : 0) + (st->use_mlp ? st->units[st->n_layers - 1] : 0);
     const int nq = (NF + 63) / 64;
-#define EL_HEAD(Q_) EL_LAUNCH("k_nmf_head", k_nmf_head<Q_>, dim3(grid), dim3(256), 0, s, *st, label, n, mode, out_prob, loss_out, n_div)
+#define EL_HEAD(Q_) EL_LAUNCH("k_nmf_head", k_nmf_head<Q_>, dim3(grid), dim3(256), 0, s, *st, label, n, mode, out_prob, n_div, mfu, mfi, part, ploss)
     if (nq <= 1) EL_HEAD(1);
     else if (nq <= 2) EL_HEAD(2);
     else if (nq <= 4) EL_HEAD(4);
@@ -272,9 +319,10 @@ __global__ __launch_bounds__(256) void k_relu_bwd(float* __restrict__ d, const f
         if (!(y[t] > 0.f)) d[t] = 0.f;
 }
 
-// relu backward + bias gradient in one pass over d [n, units]:  d <- d * (y > 0);  gb[c] += sum_b d[b, c]
-// (gb zeroed by the caller).  A workgroup owns the column block blockIdx.x (W = min(units, 256) columns, 256 / W rows at a
-// time) and walks the rows blockIdx.y, blockIdx.y + gridDim.y, ...; the column sums stay in registers until the end.
+// relu backward + bias gradient in one pass over d [n, units]:  d <- d * (y > 0);  part[blockIdx.y, c] = this workgroup's share of
+// sum_b d[b, c] (el_colsum_finish adds the gridDim.y shares in order).  A workgroup owns the column block blockIdx.x (W = min(units,
+// 256) columns, 256 / W rows at a time) and walks the rows blockIdx.y, blockIdx.y + gridDim.y, ...; the column sums stay in
+// registers until the end.
 __global__ __launch_bounds__(256) void k_relu_bwd_colsum(float* __restrict__ d, const float* __restrict__ y, int64_t n,
                                                          int64_t units, float* __restrict__ gb) {
     __shared__ float part[256];
@@ -318,12 +366,12 @@ __global__ __launch_bounds__(256) void k_relu_bwd_colsum(float* __restrict__ d, 
     if (tr == 0 && c < units) {
         float t = 0.f;
         for (int r = 0; r < R; ++r) t += part[r * W + tc];
-        if (t != 0.f) atomicAdd(gb + c, t);
+        gb[(int64_t)blockIdx.y * units + c] = t;
     }
 }
 
-// bias gradient alone: gb[c] += sum_b d[b, c] (gb zeroed by the caller); d already carries the ReLU derivative (k_nmf_head
-// applies it for the last layer).  Same walk as k_relu_bwd_colsum, one read of d and nothing else.
+// bias gradient alone (partial rows as above); d already carries the ReLU derivative (k_nmf_head applies it for the last layer).
+// Same walk as k_relu_bwd_colsum, one read of d and nothing else.
 __global__ __launch_bounds__(256) void k_nmf_colsum(const float* __restrict__ d, int64_t n, int64_t units, float* __restrict__ gb) {
     __shared__ float part[256];
     const int W = units < 256 ? (int)units : 256, R = 256 / W;
@@ -344,7 +392,7 @@ __global__ __launch_bounds__(256) void k_nmf_colsum(const float* __restrict__ d,
     if (tr == 0 && c < units) {
         float t = 0.f;
         for (int r = 0; r < R; ++r) t += part[r * W + tc];
-        if (t != 0.f) atomicAdd(gb + c, t);
+        gb[(int64_t)blockIdx.y * units + c] = t;
     }
 }
 
@@ -371,50 +419,16 @@ __global__ __launch_bounds__(256) void k_nmf_dropout(float* __restrict__ x, int6
     }
 }
 
-// embedding gradients (IndexedSlices, duplicates summed): scatter-add one row per sample and table
-__global__ __launch_bounds__(256) void k_nmf_scatter(el_nmf_state st, const int32_t* __restrict__ bu,
-                                                     const int32_t* __restrict__ bi, int64_t n) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n) return;
-    const int64_t u = bu[b], i = bi[b];
-    if (st.use_mf) {
-        const float dl = st.dlogit[b];
-        const float* pu = st.tab[0] + u * st.F;
-        const float* pi = st.tab[1] + i * st.F;
-        float* gu = st.gtab[0] + u * st.F;
-        float* gi = st.gtab[1] + i * st.F;
-        for (int f = lane; f < st.F; f += 64) {
-            const float s = dl * st.hw[f];
-            atomicAdd(gu + f, s * pi[f]);
-            atomicAdd(gi + f, s * pu[f]);
-        }
-    }
-    if (st.use_mlp) {
-        const float* dx = st.dX0 + b * 2 * st.E;
-        float* gu = st.gtab[2] + u * st.E;
-        float* gi = st.gtab[3] + i * st.E;
-        for (int f = lane; f < st.E; f += 64) {
-            atomicAdd(gu + f, dx[f]);
-            atomicAdd(gi + f, dx[st.E + f]);
-        }
-    }
-}
-
 // ---- deferred decay of the embedding tables ---------------------------------------------------------------------------
 // Keras' Adam moves EVERY row of an embedding table at every step: m <- b1 m, v <- b2 v,
 // theta <- theta - lr_t m / (sqrt(v) + eps), gradient or not.  The eager form streams theta, g, m, v of all (U + I)(F + E)
 // parameters per step: 3.3 of the 10 ms of a step at 1.25 M x 1 M x 128, for a batch that touches a fifth of the rows.
 // For a row WITHOUT a gradient that update reads nothing but the row itself, so it can be postponed and replayed in
 // registers -- the same fp32 operations on the same operands in the same order, hence the same bits -- at the moment the row is
-// needed again: by a batch that contains it (k_nmf_catchup, before the forward pass reads it) or by anything that reads the
+// needed again: by a batch that contains it (k_nmf_seg_fwd, before the forward pass reads it) or by anything that reads the
 // tables as a whole (k_nmf_flush_rows: scoring, weights(), a checkpoint).  row_last[side][r] = the optimiser step row r of
 // that side's tables is current at; lr_hist[s - hist_base] = lr_t of step s.  Every (element, step) update is still performed
 // exactly once; what disappears is the HBM round trip of the rows a step does not touch.
-//
-// One wave per (sample, side: 0 user / 1 item).  The first wave to stamp a row with this batch's claim number owns it: it
-// replays the row's missed steps (last, t-1] now and applies step t with the accumulated gradient row after the backward pass
-// (k_nmf_apply_rows); the other occurrences of the row do nothing.
 struct NmfRowTabs {
     float* th[2];
     float* g[2];
@@ -473,6 +487,35 @@ __device__ __forceinline__ void nmf_rows_load(NmfRowRegs<VW, Q>& r, const NmfRow
         }
 }
 
+// one array of the side's tables (theta, or the gradient rows) alone
+template <int VW>
+__device__ __forceinline__ void nmf_rows_load_arr(float (&dst)[2][1][VW], const float* const (&src)[2], const NmfRowTabs& rt, int64_t row, int f0,
+                                                  int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int f = f0 + lane * VW;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) dst[k][0][x] = 0.f;
+        if (k < rt.n && f < rt.D[k]) {
+            const float* sp = src[k] + row * rt.D[k] + f;
+            if (VW == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(sp);
+                dst[k][0][0] = t.x, dst[k][0][VW - 1] = t.y;
+            } else dst[k][0][0] = sp[0];
+        }
+    }
+}
+template <int VW>
+__device__ __forceinline__ void nmf_rows_load_theta(NmfRowRegs<VW, 1>& r, const NmfRowTabs& rt, int64_t row, int f0, int lane) {
+    const float* const src[2] = {rt.th[0], rt.th[1]};
+    nmf_rows_load_arr<VW>(r.a, src, rt, row, f0, lane);
+}
+template <int VW>
+__device__ __forceinline__ void nmf_rows_load_g(float (&g)[2][1][VW], const NmfRowTabs& rt, int64_t row, int f0, int lane) {
+    const float* const src[2] = {rt.g[0], rt.g[1]};
+    nmf_rows_load_arr<VW>(g, src, rt, row, f0, lane);
+}
+
 template <int VW, int Q>
 __device__ __forceinline__ void nmf_rows_store(const float (&val)[2][Q][VW], float* const (&dst)[2], const NmfRowTabs& rt, int64_t row,
                                                int f0, int lane) {
@@ -515,126 +558,467 @@ __device__ __forceinline__ void nmf_rows_replay(NmfRowRegs<VW, Q>& r, const floa
     }
 }
 
-// MODE 0 (catch-up): theta of the row to step t - 1 (m, v are read, replayed in registers and NOT written: k_nmf_apply_rows
-//                    replays them again -- two multiplications per step -- when it rewrites them anyway)
-// MODE 1 (apply):    m, v to step t - 1, then step t with the gradient row; theta, m, v written, gradient row zeroed
-// MODE 2 (flush):    theta, m, v to step t
-template <int VW, int Q, int MODE>
-__device__ __forceinline__ void nmf_row_pass(const el_nmf_state& st, const NmfRowTabs& rt, int64_t row, int lane, int last, int32_t t, float lr_t) {
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    const int nsteps = (MODE == 2 ? t : t - 1) - last;
+// flush: theta, m, v of one row (both tables of the side) from step `last` to step t
+template <int VW>
+__device__ __forceinline__ void nmf_row_flush(const el_nmf_state& st, const NmfRowTabs& rt, int64_t row, int lane, int last, int32_t t) {
+    const int nsteps = t - last;
     const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
     const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
-    for (int f0 = 0; f0 < Dmax; f0 += 64 * Q * VW) {
-        NmfRowRegs<VW, Q> r;
-        nmf_rows_load<VW, Q, true>(r, rt, row, f0, lane);
-        float g[2][Q][VW];
-        if (MODE == 1) {
+    for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
+        NmfRowRegs<VW, 1> r;
+        nmf_rows_load<VW, 1, true>(r, rt, row, f0, lane);
+        // m = v = 0 (rows that never had a gradient) is a fixed point of the gradient-free step -- m <- 0, v <- 0,
+        // theta <- theta - lr 0 / (0 + eps) = theta: nothing to replay and nothing to write, whatever the gap
+        bool nz = false;
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const int f = f0 + (lane + 64 * q) * VW;
+            for (int x = 0; x < VW; ++x) nz = nz || r.m[k][0][x] != 0.f || r.v[k][0][x] != 0.f;
+        if (__ballot(nz) == 0ull) continue;
+        nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps);
+        float* const dth[2] = {rt.th[0], rt.th[1]};
+        float* const dm[2] = {rt.m[0], rt.m[1]};
+        float* const dv[2] = {rt.v[0], rt.v[1]};
+        nmf_rows_store<VW, 1>(r.a, dth, rt, row, f0, lane);
+        nmf_rows_store<VW, 1>(r.m, dm, rt, row, f0, lane);
+        nmf_rows_store<VW, 1>(r.v, dv, rt, row, f0, lane);
+    }
+}
+
+// ---- the embedding side on sorted segments --------------------------------------------------------------------------------------------
+// A batch names its rows through (u[b], i[b]); several samples may name the same row.  The step sorts the 2 n keys (u[b], then U + i[b];
+// value = b; stable radix sort: ascending b inside a row's segment) once and walks the SEGMENTS both ways:
+//   forward   k_nmf_seg_fwd: one wave per segment (the wave of the segment's first sorted position; the others leave).  Deferred decay:
+//             the row's postponed gradient-free steps (last, t - 1] are replayed on theta now (m, v are read for it, not written: the
+//             backward pass replays them -- two multiplications per step -- when it rewrites them anyway).  The row then goes to the
+//             activation rows of the segment's samples: X0[b] = [Umlp[u] ; Imlp[i]], and the two factors of MF[b] = Umf[u] * Imf[i]
+//             to mfp[0][b] / mfp[1][b] (the head multiplies them; the backward pass needs each factor again AFTER the partner's row
+//             has moved on).  Samples 64, 65, ... of a long segment: k_nmf_seg_fwd_long (the rows go on a list here).
+//   backward  k_nmf_seg_bwd: the gradient row of a segment = the sum of its samples' rows in ascending b -- no atomics, the same bits
+//             on every run -- and then   MODE 0: stored to gtab (el_nmf_grads; the eager every-row Adam or el_nmf_apply consume it)
+//                                        MODE 1: Keras' Adam step t on the row at once (el_nmf_train_step with the deferred decay)
+//                                        MODE 2: no sums: step t with the row el_nmf_grads left in gtab (el_nmf_apply, deferred)
+//             Segments of more than 64 samples (popular items; listed with their length by the forward pass): k_nmf_seg_bwd_part, a 16-wave
+//             workgroup per block of 1 024 samples (wave w: samples [64 w, 64 w + 64) in ascending order, the waves' rows added in
+//             wave order), then k_nmf_seg_bwd_long, a wave per row adding the blocks' rows in block order.  The order is a function
+//             of the segment alone: MODE 0 + 2 and MODE 1 give the same bits.
+// Replaces the rounds 3-5 pair k_nmf_catchup / k_nmf_gather and k_nmf_scatter (float atomics) / k_nmf_apply_rows.
+struct NmfSeg {
+    const u32* keys;       // [2 n] sorted
+    const int32_t* perm;   // [2 n] sample of the sorted position
+    int64_t n2;
+    float* mfp[2];         // [n, F] copies of Umf[u[b]] / Imf[i[b]] as the forward pass saw them
+    int32_t* llist;        // long segments: [0] count, [1] partial rows handed out, then (head position, samples, first partial row) triples
+    float* lpart;          // partial gradient rows of the long segments' blocks of NMF_LBLK samples: [rows, Dsum]
+    int32_t t;
+    float lr_t;
+};
+
+__global__ __launch_bounds__(256) void k_nmf_keys(const int32_t* __restrict__ bu, const int32_t* __restrict__ bi, int64_t n, int64_t U,
+                                                  u32* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    keys[b] = (u32)bu[b], keys[n + b] = (u32)(U + bi[b]);
+    vals[b] = vals[n + b] = (int32_t)b;
+}
+
+// What the wave of sorted position p needs to know about its segment, with every load issued before the first use (one round trip to
+// memory instead of three: the kernels below are bound by the length of their dependent-load chain, not by bytes): is p the first
+// position of its segment (head), the segment's samples len = 1 .. 64, or 65 for "more than 64", and the sample of position p + lane.
+#define NMF_LBLK 1024        // samples of a long segment per workgroup (16 waves x 64)
+#define NMF_LY 8             // blocks of one segment in flight (gridDim.y of the long kernels)
+struct NmfHead {
+    bool head;
+    u32 key;
+    int len;
+    int32_t myb;
+};
+__device__ __forceinline__ NmfHead nmf_seg_head(const NmfSeg& sg, int64_t p, int lane) {
+    const int64_t last = sg.n2 - 1;
+    const int64_t q = p - 1 + lane;                                          // lane 0: the position in front, lane l: p + l - 1
+    const u32 kk = sg.keys[q < 0 ? 0 : (q < last ? q : last)];
+    const int64_t q2 = p + 63 + (lane & 1);                                  // (lane 0: p + 63, lane 1: p + 64)
+    const u32 kt = sg.keys[q2 < last ? q2 : last];
+    const int64_t q3 = p + lane;
+    NmfHead h;
+    h.myb = sg.perm[q3 < last ? q3 : last];
+    h.key = (u32)__shfl((int)kk, 1, 64);
+    const u32 prev = (u32)__shfl((int)kk, 0, 64);
+    h.head = p == 0 || prev != h.key;
+    const bool same = lane >= 1 && q <= last && kk == h.key;                 // positions p .. p + 62
+    const unsigned long long bal = __ballot(same) >> 1;
+    const u32 k63 = (u32)__shfl((int)kt, 0, 64), k64 = (u32)__shfl((int)kt, 1, 64);
+    if (bal != 0x7fffffffffffffffull) h.len = __builtin_ctzll(~bal);
+    else if (!(p + 63 <= last && k63 == h.key)) h.len = 63;
+    else h.len = (p + 64 <= last && k64 == h.key) ? 65 : 64;
+    return h;
+}
+
+// theta of one row chunk (both tables of the side) -> the activation rows of sample b
+template <int VW>
+__device__ __forceinline__ void nmf_act_store(const el_nmf_state& st, const NmfSeg& sg, const NmfRowTabs& rt, int side, int64_t b, int f0, int lane,
+                                              const float (&a)[2][1][VW]) {
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) g[k][q][x] = 0.f;
-                    if (k < rt.n && f < rt.D[k]) {
-                        const float* gp = rt.g[k] + row * rt.D[k] + f;
-                        if (VW == 2) {
-                            const float2 t2 = *reinterpret_cast<const float2*>(gp);
-                            g[k][q][0] = t2.x, g[k][q][VW - 1] = t2.y;
-                        } else {
-                            g[k][q][0] = gp[0];
-                        }
-                    }
-                }
-            nmf_rows_replay<VW, Q, false>(r, lr_from, nsteps);
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int q = 0; q < Q; ++q)
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) el_adam_elem(r.a[k][q][x], r.m[k][q][x], r.v[k][q][x], g[k][q][x], lr_t, b1, b2, omb1, omb2, eps);
-        } else {
-            // m = v = 0 (rows that never had a gradient) is a fixed point of the gradient-free step -- m <- 0, v <- 0,
-            // theta <- theta - lr 0 / (0 + eps) = theta: nothing to replay and nothing to write, whatever the gap
+    for (int k = 0; k < 2; ++k) {
+        const int f = f0 + lane * VW;
+        if (k < rt.n && f < rt.D[k]) {
+            const bool mf = st.use_mf && k == 0;
+            float* d = mf ? sg.mfp[side] + b * st.F + f : st.X0 + b * 2 * st.E + (int64_t)side * st.E + f;
+            if (VW == 2) *reinterpret_cast<float2*>(d) = make_float2(a[k][0][0], a[k][0][VW - 1]);
+            else d[0] = a[k][0][0];
+        }
+    }
+}
+
+template <int VW, bool DEFER>
+__global__ __launch_bounds__(256) void k_nmf_seg_fwd(el_nmf_state st, NmfSeg sg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= sg.n2) return;
+    const NmfHead hd = nmf_seg_head(sg, p, lane);
+    if (!hd.head) return;
+    const u32 key = hd.key;
+    const int side = (int64_t)key >= st.U ? 1 : 0;
+    const int64_t row = (int64_t)key - (side ? st.U : 0);
+    int len = hd.len;
+    if (len > 64) {                                                          // the rest: k_nmf_seg_fwd_long; the list serves the backward pass too
+        int64_t lo = p + 64, hi = sg.n2;                                     // first position past the segment (keys ascend)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (sg.keys[mid] <= key) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lane == 0) {
+            const int total = (int)(lo - p), nblk = (total + NMF_LBLK - 1) / NMF_LBLK;
+            const int ent = atomicAdd(sg.llist, 1), slot0 = atomicAdd(sg.llist + 1, nblk);
+            sg.llist[2 + 3 * ent] = (int32_t)p, sg.llist[3 + 3 * ent] = total, sg.llist[4 + 3 * ent] = slot0;
+        }
+        len = 64;
+    }
+    const int32_t myb = hd.myb;
+    const NmfRowTabs rt = nmf_row_tabs(st, side);
+    int nsteps = 0;
+    const float* lr_from = nullptr;
+    if (DEFER) {
+        const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
+        nsteps = (sg.t - 1) - last;
+        lr_from = st.lr_hist + (last + 1 - st.hist_base);
+    }
+    const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
+    for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
+        NmfRowRegs<VW, 1> r;
+        bool fresh = false;
+        if (DEFER && nsteps > 0) {
+            nmf_rows_load<VW, 1, true>(r, rt, row, f0, lane);
+            // m = v = 0 (rows that never had a gradient) is a fixed point of the gradient-free step: nothing to replay, nothing to write
             bool nz = false;
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int q = 0; q < Q; ++q)
+                for (int x = 0; x < VW; ++x) nz = nz || r.m[k][0][x] != 0.f || r.v[k][0][x] != 0.f;
+            if (__ballot(nz) != 0ull) {
+                nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps);
+                fresh = true;
+            }
+        } else {
+            nmf_rows_load_theta<VW>(r, rt, row, f0, lane);
+        }
+        if (fresh) {
+            float* const dth[2] = {rt.th[0], rt.th[1]};
+            nmf_rows_store<VW, 1>(r.a, dth, rt, row, f0, lane);
+        }
+        for (int j = 0; j < len; ++j) nmf_act_store<VW>(st, sg, rt, side, (int64_t)__shfl(myb, j, 64), f0, lane, r.a);
+    }
+}
+
+// samples 64, 65, ... of the long segments: a workgroup per (listed row, block of NMF_LBLK samples), 64 samples per wave
+template <int VW>
+__global__ __launch_bounds__(1024) void k_nmf_seg_fwd_long(el_nmf_state st, NmfSeg sg) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nlist = sg.llist[0];
+    for (int ent = blockIdx.x; ent < nlist; ent += gridDim.x) {
+        const int64_t p = sg.llist[2 + 3 * ent];
+        const int total = sg.llist[3 + 3 * ent];
+        const u32 key = sg.keys[p];
+        const int side = (int64_t)key >= st.U ? 1 : 0;
+        const int64_t row = (int64_t)key - (side ? st.U : 0);
+        const NmfRowTabs rt = nmf_row_tabs(st, side);
+        const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
+        for (int j0 = blockIdx.y * NMF_LBLK + wv * 64; j0 < total; j0 += NMF_LY * NMF_LBLK) {
+            if (j0 < 64) continue;                                           // (k_nmf_seg_fwd wrote the first 64)
+            const int cnt = total - j0 < 64 ? total - j0 : 64;
+            const int32_t b = lane < cnt ? sg.perm[p + j0 + lane] : 0;
+            for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
+                NmfRowRegs<VW, 1> r;
+                nmf_rows_load_theta<VW>(r, rt, row, f0, lane);               // (k_nmf_seg_fwd has brought the row to t - 1)
+                for (int j = 0; j < cnt; ++j) nmf_act_store<VW>(st, sg, rt, side, (int64_t)__shfl(b, j, 64), f0, lane, r.a);
+            }
+        }
+    }
+}
+
+// g += the gradient rows of the cnt <= 64 samples the lanes hold in myb (lane j: the j-th), ascending, NB samples' loads in flight
+//   MF tables: d loss / d Umf[u] = (dlogit_b h_f) Imf[i]_f (the partner's factor as the forward pass saw it); MLP tables: the halves of dX0[b]
+template <int VW, int NB>
+__device__ __forceinline__ void nmf_seg_sum(const el_nmf_state& st, const NmfSeg& sg, int side, int32_t myb, int cnt, int f0, int lane,
+                                            float (&g)[2][VW]) {
+    const int f = f0 + lane * VW;
+    float hwv[VW];
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) nz = nz || r.m[k][q][x] != 0.f || r.v[k][q][x] != 0.f;
-            if (__ballot(nz) == 0ull) continue;
-            nmf_rows_replay<VW, Q, true>(r, lr_from, nsteps);
+    for (int x = 0; x < VW; ++x) hwv[x] = 0.f;
+    const bool has_mf = st.use_mf && f < st.F;
+    if (has_mf) {
+#pragma unroll
+        for (int x = 0; x < VW; ++x) hwv[x] = st.hw[f + x];
+    }
+    const int kml = st.use_mf ? 1 : 0;                                       // table slot of the MLP embedding
+    const bool has_ml = st.use_mlp && f < st.E;
+    const float* part = sg.mfp[side ^ 1];
+    for (int j = 0; j < cnt; j += NB) {
+        float pv[NB][VW], dv[NB][VW], dl[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int64_t b = __shfl(myb, j + q < cnt ? j + q : j, 64);
+            dl[q] = st.dlogit[b];
+#pragma unroll
+            for (int x = 0; x < VW; ++x) pv[q][x] = dv[q][x] = 0.f;
+            if (has_mf) {
+                if (VW == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(part + b * st.F + f);
+                    pv[q][0] = t2.x, pv[q][VW - 1] = t2.y;
+                } else pv[q][0] = part[b * st.F + f];
+            }
+            if (has_ml) {
+                const float* dx = st.dX0 + b * 2 * st.E + (int64_t)side * st.E + f;
+                if (VW == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(dx);
+                    dv[q][0] = t2.x, dv[q][VW - 1] = t2.y;
+                } else dv[q][0] = dx[0];
+            }
         }
-        float* const dth[2] = {rt.th[0], rt.th[1]};
-        nmf_rows_store<VW, Q>(r.a, dth, rt, row, f0, lane);
-        if (MODE != 0) {
-            float* const dm[2] = {rt.m[0], rt.m[1]};
-            float* const dv[2] = {rt.v[0], rt.v[1]};
-            nmf_rows_store<VW, Q>(r.m, dm, rt, row, f0, lane);
-            nmf_rows_store<VW, Q>(r.v, dv, rt, row, f0, lane);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            if (j + q >= cnt) continue;
+#pragma unroll
+            for (int x = 0; x < VW; ++x) {
+                if (has_mf) {
+                    const float s = dl[q] * hwv[x];
+                    g[0][x] += s * pv[q][x];
+                }
+                if (has_ml) g[kml][x] += dv[q][x];
+            }
         }
-        if (MODE == 1) {
+    }
+}
+
+// the same for a segment of ONE sample b (nine rows in ten): 0 + term, as the loop above adds it
+template <int VW>
+__device__ __forceinline__ void nmf_seg_one(const el_nmf_state& st, const NmfSeg& sg, int side, int64_t b, int f0, int lane, float (&g)[2][VW]) {
+    const int f = f0 + lane * VW;
+    const int kml = st.use_mf ? 1 : 0;
+    if (st.use_mf && f < st.F) {
+        const float dl = st.dlogit[b];
+        const float* part = sg.mfp[side ^ 1] + b * st.F + f;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+            const float s = dl * st.hw[f + x];
+            g[0][x] += s * part[x];
+        }
+    }
+    if (st.use_mlp && f < st.E) {
+        const float* dx = st.dX0 + b * 2 * st.E + (int64_t)side * st.E + f;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) g[kml][x] += dx[x];
+    }
+}
+
+// the row chunk's gradient g -> gtab (MODE 0) or Keras' Adam step t on theta, m, v (MODE 1, 2; m, v first replayed to t - 1)
+template <int VW, int MODE>
+__device__ __forceinline__ void nmf_seg_finish(const el_nmf_state& st, const NmfSeg& sg, const NmfRowTabs& rt, int64_t row, int f0, int lane,
+                                               NmfRowRegs<VW, 1>& r, float (&g)[2][1][VW], int nsteps, const float* lr_from) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    if (MODE == 0) {
+        float* const dg[2] = {rt.g[0], rt.g[1]};
+        nmf_rows_store<VW, 1>(g, dg, rt, row, f0, lane);
+        return;
+    }
+    nmf_rows_replay<VW, 1, false>(r, lr_from, nsteps);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int x = 0; x < VW; ++x) el_adam_elem(r.a[k][0][x], r.m[k][0][x], r.v[k][0][x], g[k][0][x], sg.lr_t, b1, b2, omb1, omb2, eps);
+    float* const dth[2] = {rt.th[0], rt.th[1]};
+    float* const dm[2] = {rt.m[0], rt.m[1]};
+    float* const dv[2] = {rt.v[0], rt.v[1]};
+    nmf_rows_store<VW, 1>(r.a, dth, rt, row, f0, lane);
+    nmf_rows_store<VW, 1>(r.m, dm, rt, row, f0, lane);
+    nmf_rows_store<VW, 1>(r.v, dv, rt, row, f0, lane);
+    if (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int x = 0; x < VW; ++x) g[k][0][x] = 0.f;
+        float* const dg[2] = {rt.g[0], rt.g[1]};
+        nmf_rows_store<VW, 1>(g, dg, rt, row, f0, lane);
+    }
+}
+
+template <int VW, int MODE>
+__global__ __launch_bounds__(256) void k_nmf_seg_bwd(el_nmf_state st, NmfSeg sg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (MODE != 0 && p == 0 && lane == 0) st.lr_hist[sg.t - st.hist_base] = sg.lr_t;     // this step's lr_t for later replays (this
+    //                                                                                        kernel's own replays read steps < t only)
+    if (p >= sg.n2) return;
+    const NmfHead hd = nmf_seg_head(sg, p, lane);
+    if (!hd.head) return;
+    const u32 key = hd.key;
+    const int side = (int64_t)key >= st.U ? 1 : 0;
+    const int64_t row = (int64_t)key - (side ? st.U : 0);
+    const int len = hd.len;
+    if (MODE != 2 && len > 64) return;                                        // k_nmf_seg_bwd_long's (on the list since the forward pass)
+    const NmfRowTabs rt = nmf_row_tabs(st, side);
+    int nsteps = 0;
+    const float* lr_from = nullptr;
+    if (MODE != 0) {
+        const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
+        nsteps = (sg.t - 1) - last;
+        lr_from = st.lr_hist + (last + 1 - st.hist_base);
+    }
+    const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
+    for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
+        NmfRowRegs<VW, 1> r;
+        if (MODE != 0) nmf_rows_load<VW, 1, true>(r, rt, row, f0, lane);
+        float g[2][1][VW];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int x = 0; x < VW; ++x) g[k][0][x] = 0.f;
+        if (MODE == 2) {
+            nmf_rows_load_g<VW>(g, rt, row, f0, lane);
+        } else {
+            float gs[2][VW];
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int q = 0; q < Q; ++q)
+                for (int x = 0; x < VW; ++x) gs[k][x] = 0.f;
+            if (len == 1) nmf_seg_one<VW>(st, sg, side, (int64_t)__shfl(hd.myb, 0, 64), f0, lane, gs);
+            else nmf_seg_sum<VW, 4>(st, sg, side, hd.myb, len, f0, lane, gs);
 #pragma unroll
-                    for (int x = 0; x < VW; ++x) g[k][q][x] = 0.f;
-            float* const dg[2] = {rt.g[0], rt.g[1]};
-            nmf_rows_store<VW, Q>(g, dg, rt, row, f0, lane);
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int x = 0; x < VW; ++x) g[k][0][x] = gs[k][x];
+        }
+        nmf_seg_finish<VW, MODE>(st, sg, rt, row, f0, lane, r, g, nsteps, lr_from);
+    }
+    if (MODE != 0 && lane == 0) st.row_last[side][row] = sg.t;
+}
+
+// long segments, step 1: the partial gradient row of every block of NMF_LBLK samples -- wave w of the block's workgroup adds samples
+// [64 w, 64 w + 64) of the block in ascending order, the 16 waves' rows are added in wave order -> lpart[first row of the segment + block]
+template <int VW>
+__global__ __launch_bounds__(1024) void k_nmf_seg_bwd_part(el_nmf_state st, NmfSeg sg) {
+    __shared__ float s_red[16][2][64 * VW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nlist = sg.llist[0];
+    const int Fa = st.use_mf ? st.F : 0, Dsum = Fa + (st.use_mlp ? st.E : 0);
+    for (int ent = blockIdx.x; ent < nlist; ent += gridDim.x) {
+        const int64_t p = sg.llist[2 + 3 * ent];
+        const int total = sg.llist[3 + 3 * ent], slot0 = sg.llist[4 + 3 * ent];
+        const u32 key = sg.keys[p];
+        const int side = (int64_t)key >= st.U ? 1 : 0;
+        const NmfRowTabs rt = nmf_row_tabs(st, side);
+        const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
+        const int nblk = (total + NMF_LBLK - 1) / NMF_LBLK;
+        for (int blk = blockIdx.y; blk < nblk; blk += NMF_LY) {
+            const int j0 = blk * NMF_LBLK + wv * 64;
+            const int cnt = j0 >= total ? 0 : (total - j0 < 64 ? total - j0 : 64);
+            const int used = ((total - blk * NMF_LBLK < NMF_LBLK ? total - blk * NMF_LBLK : NMF_LBLK) + 63) / 64;
+            const int32_t myb = lane < cnt ? sg.perm[p + j0 + lane] : 0;
+            for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
+                float gs[2][VW];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) gs[k][x] = 0.f;
+                if (cnt > 0) nmf_seg_sum<VW, 8>(st, sg, side, myb, cnt, f0, lane, gs);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) s_red[wv][k][lane * VW + x] = gs[k][x];
+                __syncthreads();
+                if (wv < 2 && wv < rt.n) {                                   // wave k adds table k's 16 rows in wave order
+                    const int f = f0 + lane * VW;
+                    if (f < rt.D[wv]) {
+                        float* d = sg.lpart + (int64_t)(slot0 + blk) * Dsum + (wv == 1 ? Fa : 0) + f;
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            float t = 0.f;
+                            for (int h = 0; h < used; ++h) t += s_red[h][wv][lane * VW + x];
+                            d[x] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 }
 
-// VW = 2 when every table row starts 8-byte aligned (even dimensions); one chunk of 128 (VW 2) / 64 (VW 1) elements per lane pass
-template <int MODE>
-__device__ __forceinline__ void nmf_row_dispatch(const el_nmf_state& st, const NmfRowTabs& rt, int64_t row, int lane, int last, int32_t t,
-                                                 float lr_t) {
-    const bool even = (rt.D[0] % 2 == 0) && (rt.n < 2 || rt.D[1] % 2 == 0);
-    if (even) nmf_row_pass<2, 1, MODE>(st, rt, row, lane, last, t, lr_t);
-    else nmf_row_pass<1, 1, MODE>(st, rt, row, lane, last, t, lr_t);
-}
-
-__global__ __launch_bounds__(256) void k_nmf_catchup(el_nmf_state st, const int32_t* __restrict__ bu, const int32_t* __restrict__ bi,
-                                                     int64_t n, int32_t t, int32_t claim) {
+// long segments, step 2: one wave per listed row adds its blocks' partial rows in block order, then as k_nmf_seg_bwd (MODE 0 / 1)
+template <int VW, int MODE>
+__global__ __launch_bounds__(256) void k_nmf_seg_bwd_long(el_nmf_state st, NmfSeg sg) {
     const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= 2 * n) return;
-    const int side = p >= n ? 1 : 0;
-    const int64_t b = p - (side ? n : 0);
-    const int64_t row = side ? bi[b] : bu[b];
-    int own = 0, last = 0;
-    if (lane == 0) {
-        own = atomicExch(st.row_stamp[side] + row, claim) != claim;
-        st.row_own[(int64_t)side * st.Bmax + b] = (uint8_t)own;
-        if (own) last = st.row_last[side][row];
+    const int nlist = sg.llist[0];
+    const int Fa = st.use_mf ? st.F : 0, Dsum = Fa + (st.use_mlp ? st.E : 0);
+    for (int ent = blockIdx.x * 4 + (threadIdx.x >> 6); ent < nlist; ent += gridDim.x * 4) {
+        const int64_t p = sg.llist[2 + 3 * ent];
+        const int total = sg.llist[3 + 3 * ent], slot0 = sg.llist[4 + 3 * ent];
+        const u32 key = sg.keys[p];
+        const int side = (int64_t)key >= st.U ? 1 : 0;
+        const int64_t row = (int64_t)key - (side ? st.U : 0);
+        const NmfRowTabs rt = nmf_row_tabs(st, side);
+        const int nblk = (total + NMF_LBLK - 1) / NMF_LBLK;
+        int nsteps = 0;
+        const float* lr_from = nullptr;
+        if (MODE != 0) {
+            const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
+            nsteps = (sg.t - 1) - last;
+            lr_from = st.lr_hist + (last + 1 - st.hist_base);
+        }
+        const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
+        for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
+            NmfRowRegs<VW, 1> r;
+            if (MODE != 0) nmf_rows_load<VW, 1, true>(r, rt, row, f0, lane);
+            float g[2][1][VW];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int x = 0; x < VW; ++x) g[k][0][x] = 0.f;
+            const int f = f0 + lane * VW;
+            for (int blk = 0; blk < nblk; blk += 8) {
+                float v[8][2][VW];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float* src = sg.lpart + (int64_t)(slot0 + (blk + q < nblk ? blk + q : blk)) * Dsum + (k == 1 ? Fa : 0) + f;
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) v[q][k][x] = (k < rt.n && f < rt.D[k]) ? src[x] : 0.f;
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (blk + q >= nblk) continue;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) g[k][0][x] += v[q][k][x];
+                }
+            }
+            nmf_seg_finish<VW, MODE>(st, sg, rt, row, f0, lane, r, g, nsteps, lr_from);
+        }
+        if (MODE != 0 && lane == 0) st.row_last[side][row] = sg.t;
     }
-    own = __builtin_amdgcn_readfirstlane(own);
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!own || (t - 1) - last <= 0) return;
-    const NmfRowTabs rt = nmf_row_tabs(st, side);
-    nmf_row_dispatch<0>(st, rt, row, lane, last, t, 0.f);
-}
-
-// step t on the rows this batch owns: Keras sparse apply with the accumulated gradient row (duplicates already summed); the
-// gradient row is zero again afterwards
-__global__ __launch_bounds__(256) void k_nmf_apply_rows(el_nmf_state st, const int32_t* __restrict__ bu, const int32_t* __restrict__ bi,
-                                                        int64_t n, int32_t t, float lr_t) {
-    const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p == 0 && lane == 0) st.lr_hist[t - st.hist_base] = lr_t;        // this step's lr_t for later replays (the replays of this
-    //                                                                      kernel read steps < t only)
-    if (p >= 2 * n) return;
-    const int side = p >= n ? 1 : 0;
-    const int64_t b = p - (side ? n : 0);
-    if (!st.row_own[(int64_t)side * st.Bmax + b]) return;
-    const int64_t row = side ? bi[b] : bu[b];
-    const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
-    const NmfRowTabs rt = nmf_row_tabs(st, side);
-    nmf_row_dispatch<1>(st, rt, row, lane, last, t, lr_t);
-    if (lane == 0) st.row_last[side][row] = t;
 }
 
 // every row of one side up to step t (one wave per row)
@@ -644,7 +1028,9 @@ __global__ __launch_bounds__(256) void k_nmf_flush_rows(el_nmf_state st, int sid
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
         if (t - last <= 0) continue;
-        nmf_row_dispatch<2>(st, rt, row, lane, last, t, 0.f);
+        const bool even = (rt.D[0] % 2 == 0) && (rt.n < 2 || rt.D[1] % 2 == 0);      // VW = 2 when every table row starts 8-byte aligned
+        if (even) nmf_row_flush<2>(st, rt, row, lane, last, t);
+        else nmf_row_flush<1>(st, rt, row, lane, last, t);
         if (lane == 0) st.row_last[side][row] = t;
     }
 }
@@ -660,6 +1046,72 @@ static unsigned g1(int64_t n, el_ctx* ctx) {
 static unsigned head_grid(int64_t n, el_ctx* ctx) {
     const int64_t want = (n + 3) / 4, cap = (int64_t)ctx->cus * 8;
     return (unsigned)(want < cap ? want : cap);
+}
+
+// ---- the step workspace (el_nmf_state.step_ws): sort buffers, the long-segment list, the MF factor copies, partial sums ------------------
+static int nmf_bits_for(int64_t n) {
+    int b = 1;
+    while (b < 32 && (1LL << b) < n) ++b;
+    return b;
+}
+struct NmfStepWs {
+    u32 *kin, *kout;
+    int32_t *vin, *vout;
+    void* tmp;
+    size_t tmp_bytes;
+    int32_t* llist;
+    float* lpart;
+    float* mfp[2];
+    float* hpart;          // head: [P, NF + 1]
+    double* hloss;         // head: [P]
+    float* cpart[4];       // per layer: column-sum partial rows (k_nmf_colsum / k_relu_bwd_colsum: <= P rows; the GEMM epilogue: ceil(B / 128))
+};
+static int nmf_carve(el_ctx* ctx, const el_nmf_state* st, void* base, NmfStepWs* w, size_t* total) {
+    const int64_t B = st->Bmax;
+    const int64_t P = (int64_t)ctx->cus * 8;                      // workgroups of the head / rows of the column-sum grids at most
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* r = base ? (void*)((char*)base + off) : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    w->kin = (u32*)take((size_t)2 * B * 4), w->kout = (u32*)take((size_t)2 * B * 4);
+    w->vin = (int32_t*)take((size_t)2 * B * 4), w->vout = (int32_t*)take((size_t)2 * B * 4);
+    size_t tb = 0;
+    u32* np = nullptr;
+    int32_t* nv = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, tb, np, np, nv, nv, (unsigned)(2 * B), 0, nmf_bits_for(st->U + st->I), (hipStream_t)0) != hipSuccess) {
+        el_set_error("el_nmf: rocprim::radix_sort_pairs size query failed");
+        return 1;
+    }
+    w->tmp_bytes = tb;
+    w->tmp = take(tb + 256);
+    w->llist = (int32_t*)take((size_t)(3 * (2 * B / 65 + 2) + 8) * 4);
+    {   // partial rows of the long segments' blocks: at most one per NMF_LBLK positions + one per long segment
+        const int64_t Dsum = (st->use_mf ? st->F : 0) + (st->use_mlp ? st->E : 0);
+        w->lpart = (float*)take((size_t)(2 * B / NMF_LBLK + 2 * B / 65 + 4) * Dsum * 4);
+    }
+    for (int side = 0; side < 2; ++side) w->mfp[side] = st->use_mf ? (float*)take((size_t)B * st->F * 4) : nullptr;
+    const int NF = (st->use_mf ? st->F : 0) + (st->use_mlp ? st->units[st->n_layers > 0 ? st->n_layers - 1 : 0] : 0);
+    w->hpart = (float*)take((size_t)P * (NF + 1) * 4);
+    w->hloss = (double*)take((size_t)P * 8);
+    for (int l = 0; l < 4; ++l) {
+        w->cpart[l] = nullptr;
+        if (!st->use_mlp || l >= st->n_layers) continue;
+        const int64_t rows = P > (B + 127) / 128 ? P : (B + 127) / 128;
+        w->cpart[l] = (float*)take((size_t)rows * st->units[l] * 4);
+    }
+    *total = off;
+    return 0;
+}
+
+// Bytes of el_nmf_state.step_ws for this state's shape (U, I, Bmax, F, E, units; 256-byte aligned base)
+extern "C" size_t el_nmf_step_ws_bytes(el_ctx* ctx, const el_nmf_state* st) {
+    if (el_bind(ctx) || !st || st->Bmax < 1 || st->n_layers < 0 || st->n_layers > 4) return 0;
+    NmfStepWs w;
+    size_t total = 0;
+    if (nmf_carve(ctx, st, nullptr, &w, &total)) return 0;
+    return total;
 }
 
 static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
@@ -680,11 +1132,14 @@ static int nmf_check(const el_nmf_state* st, int64_t n, bool train) {
         EL_REQUIRE(st->ghw && st->mhw && st->vhw, "el_nmf: head optimiser buffers missing");
         if (st->use_mlp) EL_REQUIRE(st->dX0 != nullptr, "el_nmf: dX0 missing");
     }
+    if (train) {
+        EL_REQUIRE(st->step_ws != nullptr && (uintptr_t)st->step_ws % 256 == 0, "el_nmf: training needs el_nmf_state.step_ws (el_nmf_step_ws_bytes, 256-byte aligned)");
+        EL_REQUIRE(st->U + st->I < (1LL << 31), "el_nmf: U + I must stay below 2^31 (sort keys)");
+    }
     if (st->row_last[0] || st->row_last[1]) {
-        EL_REQUIRE(st->row_last[0] && st->row_last[1] && st->row_stamp[0] && st->row_stamp[1] && st->row_own && st->lr_hist &&
-                   st->lr_hist_cap >= 2, "el_nmf: deferred decay needs row_last[2], row_stamp[2], row_own and lr_hist");
+        EL_REQUIRE(st->row_last[0] && st->row_last[1] && st->lr_hist && st->lr_hist_cap >= 2, "el_nmf: deferred decay needs row_last[2] and lr_hist");
         EL_REQUIRE(st->opt_step >= 0 && st->flushed_step >= 0 && st->flushed_step <= st->opt_step && st->hist_base >= 1,
-                   "el_nmf: deferred-decay counters corrupt (zero-initialise opt_step / flushed_step / claim_seq, hist_base = 1)");
+                   "el_nmf: deferred-decay counters corrupt (zero-initialise opt_step / flushed_step, hist_base = 1)");
     }
     return 0;
 }
@@ -715,20 +1170,28 @@ extern "C" int el_nmf_sync_tables(el_ctx* ctx, void* stream, el_nmf_state* st) {
     return nmf_sync(ctx, (hipStream_t)stream, st);
 }
 
-// deferred decay, start of step t = opt_step + 1: record lr_t, elect the owners of the batch's rows and bring those rows to t - 1
-static int nmf_begin_rows(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n) {
-    const int32_t t = st->opt_step + 1;
-    if (t - st->hist_base >= st->lr_hist_cap)            // history full: bring every row to t - 1, restart the history at t
+// The step's segments: sort keys (u[b], U + i[b]) -> (keys, perm); with the deferred decay, room in the lr history first.
+static inline bool nmf_even(const el_nmf_state* st) {      // every table row starts 8-byte aligned: float2 accesses
+    return (!st->use_mf || st->F % 2 == 0) && (!st->use_mlp || st->E % 2 == 0);
+}
+
+static int nmf_sort_batch(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n, NmfStepWs* w,
+                          NmfSeg* sg) {
+    size_t total = 0;
+    if (int rc = nmf_carve(ctx, st, st->step_ws, w, &total)) return rc;
+    EL_REQUIRE(st->step_ws_bytes >= total, "el_nmf: step_ws holds %zu bytes, el_nmf_step_ws_bytes asks for %zu", st->step_ws_bytes, total);
+    if (nmf_deferred(st) && (st->opt_step + 1) - st->hist_base >= st->lr_hist_cap)     // history full: every row to t - 1, the history restarts at t
         if (int rc = nmf_sync(ctx, s, st)) return rc;
-    if (st->claim_seq >= 0x7ffffffe || st->claim_seq < 0) {     // 2^31 gradient evaluations: start the claim numbers again
-        EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[0], 0, (size_t)st->U * 4, s));
-        EL_CHECK_HIP(hipMemsetAsync(st->row_stamp[1], 0, (size_t)st->I * 4, s));
-        st->claim_seq = 0;
+    EL_LAUNCH("k_nmf_keys", k_nmf_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, i, n, st->U, w->kin, w->vin);
+    {
+        ElKernelTimer tm("rocprim_radix_sort_pairs", s);
+        size_t tb = w->tmp_bytes;
+        EL_CHECK_HIP(rocprim::radix_sort_pairs(w->tmp, tb, w->kin, w->kout, w->vin, w->vout, (unsigned)(2 * n), 0, nmf_bits_for(st->U + st->I), s));
     }
-    st->claim_seq += 1;
-    EL_LAUNCH("k_nmf_catchup", k_nmf_catchup, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, s, *st, u, i, n, t, st->claim_seq);
-    EL_CHECK_LAUNCH();
-    st->batch_u = u, st->batch_i = i, st->batch_n = n;
+    sg->keys = w->kout, sg->perm = w->vout, sg->n2 = 2 * n;
+    sg->mfp[0] = w->mfp[0], sg->mfp[1] = w->mfp[1];
+    sg->llist = w->llist, sg->lpart = w->lpart;
+    sg->t = st->opt_step + 1, sg->lr_t = 0.f;
     return 0;
 }
 
@@ -739,8 +1202,21 @@ static void nmf_dropout(hipStream_t s, const el_nmf_state* st, float* x, int64_t
 }
 
 static int nmf_forward(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n,
-                       bool train = false) {
-    EL_LAUNCH("k_nmf_gather", k_nmf_gather, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
+                       bool train = false, const NmfSeg* sg = nullptr) {
+    if (sg) {                                        // training: catch-up (deferred decay) + gather, one wave per segment
+        EL_CHECK_HIP(hipMemsetAsync(sg->llist, 0, 8, s));
+        const bool even = nmf_even(st);
+        const dim3 grid((unsigned)((sg->n2 + 3) / 4));
+        const bool defer = nmf_deferred(st);
+        if (even && defer) EL_LAUNCH("k_nmf_seg_fwd", (k_nmf_seg_fwd<2, true>), grid, dim3(256), 0, s, *st, *sg);
+        else if (even) EL_LAUNCH("k_nmf_seg_fwd", (k_nmf_seg_fwd<2, false>), grid, dim3(256), 0, s, *st, *sg);
+        else if (defer) EL_LAUNCH("k_nmf_seg_fwd", (k_nmf_seg_fwd<1, true>), grid, dim3(256), 0, s, *st, *sg);
+        else EL_LAUNCH("k_nmf_seg_fwd", (k_nmf_seg_fwd<1, false>), grid, dim3(256), 0, s, *st, *sg);
+        const dim3 gl((unsigned)ctx->cus, NMF_LY);
+        if (even) EL_LAUNCH("k_nmf_seg_fwd_long", k_nmf_seg_fwd_long<2>, gl, dim3(1024), 0, s, *st, *sg);
+        else EL_LAUNCH("k_nmf_seg_fwd_long", k_nmf_seg_fwd_long<1>, gl, dim3(1024), 0, s, *st, *sg);
+    } else
+        EL_LAUNCH("k_nmf_gather", k_nmf_gather, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
     const bool drop = train && st->dropout > 0.f;
     if (st->use_mlp) {
         float* in = st->X0;
@@ -767,7 +1243,7 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, el_nmf_state* st, const
     hipStream_t s = (hipStream_t)stream;
     if (int rc = nmf_sync(ctx, s, st)) return rc;
     if (int rc = nmf_forward(ctx, s, st, u, i, n)) return rc;
-    launch_nmf_head(ctx, s, st, nullptr, n, 0, out_prob, nullptr, n, head_grid(n, ctx));
+    launch_nmf_head(ctx, s, st, nullptr, n, 0, out_prob, n, head_grid(n, ctx), nullptr, nullptr, nullptr, nullptr);
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -776,23 +1252,51 @@ extern "C" int el_nmf_forward(el_ctx* ctx, void* stream, el_nmf_state* st, const
 // backward: every gradient buffer of the state is complete on exit
 // defer_join (el_nmf_train_step): the weight-gradient products may still be running on the library's second stream when this returns;
 // nmf_apply waits for them after it has launched the embedding rows' step (ctx->side_join_pending)
+// the embedding rows of the step's segments: MODE 0 gradient rows -> gtab, 1 sums + Adam, 2 Adam on the gtab rows (header of the kernels)
+static void nmf_launch_bwd(hipStream_t s, const el_nmf_state* st, const NmfSeg* sg, int mode, el_ctx* ctx) {
+    const bool even = nmf_even(st);
+    const dim3 grid((unsigned)((sg->n2 + 3) / 4)), gl((unsigned)ctx->cus, NMF_LY), gc((unsigned)ctx->cus);
+#define NMF_BWD(VW_, M_)                                                                                              \
+    do {                                                                                                              \
+        EL_LAUNCH("k_nmf_seg_bwd", (k_nmf_seg_bwd<VW_, M_>), grid, dim3(256), 0, s, *st, *sg);                        \
+        if (M_ != 2) {                                                                                                \
+            EL_LAUNCH("k_nmf_seg_bwd_part", k_nmf_seg_bwd_part<VW_>, gl, dim3(1024), 0, s, *st, *sg);                 \
+            EL_LAUNCH("k_nmf_seg_bwd_long", (k_nmf_seg_bwd_long<VW_, (M_ == 2 ? 0 : M_)>), gc, dim3(256), 0, s, *st, *sg);   \
+        }                                                                                                             \
+    } while (0)
+    if (even) {
+        if (mode == 0) NMF_BWD(2, 0);
+        else if (mode == 1) NMF_BWD(2, 1);
+        else NMF_BWD(2, 2);
+    } else {
+        if (mode == 0) NMF_BWD(1, 0);
+        else if (mode == 1) NMF_BWD(1, 1);
+        else NMF_BWD(1, 2);
+    }
+#undef NMF_BWD
+}
+
+// fused_rows (el_nmf_train_step with the deferred decay): the embedding rows' sums and their Adam step in one pass, lr_t known here
 static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, const float* label,
-                     int64_t n, int64_t n_div, double* loss_out, bool defer_join = false) {
+                     int64_t n, int64_t n_div, double* loss_out, bool defer_join = false, bool fused_rows = false, float lr_t = 0.f) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
-    if (nmf_deferred(st)) {
+    if (nmf_deferred(st))
         EL_REQUIRE(st->batch_n == 0, "el_nmf_grads: the previous el_nmf_grads has not been applied (deferred decay: the batch's rows are "
                    "half-way between two steps until el_nmf_apply)");
-        if (int rc = nmf_begin_rows(ctx, s, st, u, i, n)) return rc;
-    }
-    if (int rc = nmf_forward(ctx, s, st, u, i, n, true)) return rc;
-    EL_CHECK_HIP(hipMemsetAsync(st->ghw, 0, (size_t)(F + Hl) * 4, s));
-    if (st->head_bias) EL_CHECK_HIP(hipMemsetAsync(st->ghb, 0, 4, s));
-    if (st->use_mlp)
-        for (int l = 0; l < st->n_layers; ++l) EL_CHECK_HIP(hipMemsetAsync(st->gb[l], 0, (size_t)st->units[l] * 4, s));
+    NmfStepWs w;
+    NmfSeg sg;
+    if (int rc = nmf_sort_batch(ctx, s, st, u, i, n, &w, &sg)) return rc;
+    if (int rc = nmf_forward(ctx, s, st, u, i, n, true, &sg)) return rc;
     // the head leaves dact[last] = d loss / d pre-activation of the last layer (its ReLU derivative applied where the output row is
     // in registers anyway); the layers below take theirs in k_relu_bwd_colsum together with the bias gradient
-    launch_nmf_head(ctx, s, st, label, n, 1, nullptr, loss_out, n_div, head_grid(n, ctx));
+    const unsigned hg = head_grid(n, ctx);
+    launch_nmf_head(ctx, s, st, label, n, 1, nullptr, n_div, hg, w.mfp[0], w.mfp[1], w.hpart, w.hloss);
+    {   // the workgroups' partial rows, added in order: head weights; the bias gradient is column F + Hl of the same rows
+        EL_LAUNCH("k_nmf_head_finish", k_nmf_head_finish, dim3((unsigned)((F + Hl + 1 + 15) / 16)), dim3(1024), 0, s, w.hpart, (int)hg, F + Hl, st->ghw,
+                  st->head_bias ? st->ghb : nullptr);
+        EL_LAUNCH("k_nmf_loss_finish", k_nmf_loss_finish, dim3(1), dim3(64), 0, s, w.hloss, (int)hg, loss_out);
+    }
     if (st->use_mlp) {
         // (round 5) the ReLU derivative and the bias gradient of layer l - 1 ride in the epilogue of the product that writes its input
         // gradient (el_gemm_f32_x: one write of d instead of write + read + write, no read of d for the column sums) -- without Dropout
@@ -800,7 +1304,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
         // Two streams (round 5): the weight gradients gW[l] = in^T dact[l] (K = the batch: split-K products, 1.0 of the 3.2 ms the
         // tower's products take) are needed by the optimiser only; the chain dact[last] -> ... -> dX0 -> embedding scatter -> embedding
         // rows' Adam step does not wait for them.  They run on the library's second stream, forked as each dact[l] becomes final, and
-        // overlap with the chain's bandwidth-bound tail (k_nmf_scatter, k_nmf_apply_rows).  Their split-K partials take the upper half of
+        // overlap with the chain's bandwidth-bound tail (the embedding rows' segment pass).  Their split-K partials take the upper half of
         // the workspace (a host that sizes it 2 x el_gemm_ws_bytes gets the overlap; the option nmf_side = 0 turns it off: bench.py's
         // per-kernel breakdown runs one stream).
         size_t need_w = 0;
@@ -839,10 +1343,13 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
                         EL_CHECK_HIP(hipEventRecord(ctx->side_ev[4], s));
                         EL_CHECK_HIP(hipStreamWaitEvent(ss, ctx->side_ev[4], 0));
                     }
-                    EL_LAUNCH("k_nmf_colsum", k_nmf_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, ss, st->dact[l], n, units, st->gb[l]);
-                } else
+                    EL_LAUNCH("k_nmf_colsum", k_nmf_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, ss, st->dact[l], n, units, w.cpart[l]);
+                    if (int rc = el_colsum_finish(ss, w.cpart[l], (int)gy, units, st->gb[l])) return rc;
+                } else {
                     EL_LAUNCH("k_relu_bwd_colsum", k_relu_bwd_colsum, dim3(gx, (unsigned)gy), dim3(256), 0, s, st->dact[l], st->act[l], n,
-                              units, st->gb[l]);
+                              units, w.cpart[l]);
+                    if (int rc = el_colsum_finish(s, w.cpart[l], (int)gy, units, st->gb[l])) return rc;
+                }
             }
             done_below = false;
             if (side_on) {                        // dact[l] is final: its weight gradient goes to the side stream
@@ -854,7 +1361,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
             if (l >= 1 && !(st->dropout > 0.f)) {
                 int fused = 0;
                 if (int rc = el_gemm_f32_x(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->act[l - 1], kin,
-                                           st->gb[l - 1], st->ws, wsb_d, &fused)) return rc;
+                                           st->gb[l - 1], w.cpart[l - 1], st->ws, wsb_d, &fused)) return rc;
                 done_below = fused != 0;
             } else if (int rc = el_gemm_f32(ctx, s, 0, 1, n, kin, units, st->dact[l], units, st->W[l], units, din, kin, nullptr, 0, st->ws, wsb_d)) return rc;
             // gradient w.r.t. the DROPPED input -> w.r.t. the layer below: the same mask again.  (The relu test of the layer
@@ -867,8 +1374,12 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
             guard.armed = false;                                         // (the regular join: below, or inside the apply half)
         }
     }
-    EL_LAUNCH("k_nmf_scatter", k_nmf_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, *st, u, i, n);
+    // the embedding rows: gradient rows of the segments -> gtab (the eager Adam passes or el_nmf_apply take them from there), or sums
+    // + step t at once
+    sg.lr_t = lr_t;
+    nmf_launch_bwd(s, st, &sg, fused_rows ? 1 : 0, ctx);
     EL_CHECK_LAUNCH();
+    if (nmf_deferred(st) && !fused_rows) st->batch_u = u, st->batch_i = i, st->batch_n = n;
     if (ctx->side_join_pending && !defer_join) {                         // el_nmf_grads: the caller reads the gradients next
         EL_CHECK_HIP(hipStreamWaitEvent(s, ctx->side_ev[7], 0));
         ctx->side_join_pending = false;
@@ -877,18 +1388,23 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
 }
 
 // Keras Adam on every variable (dense apply; the embedding gradients are dense accumulators, zero again on exit)
-static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t) {
+static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t, bool rows_done = false) {
     const int F = st->use_mf ? st->F : 0;
     const int Hl = st->use_mlp ? st->units[st->n_layers - 1] : 0;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     const int64_t rows[4] = {st->U, st->I, st->U, st->I};
     const int64_t dims[4] = {st->F, st->F, st->E, st->E};
-    if (nmf_deferred(st)) {
+    if (nmf_deferred(st) && !rows_done) {
         EL_REQUIRE(st->batch_u && st->batch_i && st->batch_n >= 1, "el_nmf_apply: deferred decay applies the rows of the preceding el_nmf_grads");
         const int32_t t = st->opt_step + 1;
-        EL_REQUIRE(t - st->hist_base < st->lr_hist_cap, "el_nmf_apply: lr history overrun");        // (nmf_begin_rows made room)
-        EL_LAUNCH("k_nmf_apply_rows", k_nmf_apply_rows, dim3((unsigned)((2 * st->batch_n + 3) / 4)), dim3(256), 0, s, *st, st->batch_u,
-                  st->batch_i, st->batch_n, t, lr_t);
+        EL_REQUIRE(t - st->hist_base < st->lr_hist_cap, "el_nmf_apply: lr history overrun");        // (nmf_sort_batch made room)
+        NmfStepWs w;                                  // the sorted keys of the el_nmf_grads call are still in the step workspace
+        size_t total = 0;
+        if (int rc = nmf_carve(ctx, st, st->step_ws, &w, &total)) return rc;
+        NmfSeg sg;
+        sg.keys = w.kout, sg.perm = w.vout, sg.n2 = 2 * st->batch_n, sg.mfp[0] = w.mfp[0], sg.mfp[1] = w.mfp[1], sg.llist = w.llist, sg.lpart = w.lpart;
+        sg.t = t, sg.lr_t = lr_t;
+        nmf_launch_bwd(s, st, &sg, 2, ctx);
         st->batch_u = st->batch_i = nullptr, st->batch_n = 0;
     }
     if (ctx->side_join_pending) {                  // the Dense layers' weight gradients (second stream) before their Adam step
@@ -929,8 +1445,9 @@ extern "C" int el_nmf_train_step(el_ctx* ctx, void* stream, el_nmf_state* st, co
     if (int rc = nmf_check(st, n, true)) return rc;
     EL_REQUIRE(u && i && label && loss_out && step >= 1, "el_nmf_train_step: bad arguments");
     if (nmf_deferred(st)) EL_REQUIRE(step == st->opt_step + 1, "el_nmf_train_step: step %d does not follow the state's %d applied steps", (int)step, (int)st->opt_step);
-    if (int rc = nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n, loss_out, true)) return rc;
-    return nmf_apply(ctx, (hipStream_t)stream, st, lr_t);
+    const bool fused_rows = nmf_deferred(st);
+    if (int rc = nmf_grads(ctx, (hipStream_t)stream, st, u, i, label, n, n, loss_out, true, fused_rows, lr_t)) return rc;
+    return nmf_apply(ctx, (hipStream_t)stream, st, lr_t, fused_rows);
 }
 
 extern "C" int el_nmf_grads(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i,

@@ -1492,21 +1492,29 @@ class NmfDeviceState:
             dropout=self.dropout, drop_step=0, drop_seed=self.dropout_seed & 0xFFFFFFFFFFFFFFFF)
         self._drop_calls = 0
         self._c.hist_base = 1
+        self._alloc_step_ws()
         if self.deferred:
             self._alloc_deferred()
+
+    def _alloc_step_ws(self):
+        """el_nmf_state.step_ws: sort buffers of the batch's (row, sample) keys, the MF factor copies, partial rows of the reductions."""
+        need = int(self.ctx.lib.el_nmf_step_ws_bytes(self.ctx.handle, C.byref(self._c)))
+        if need <= 0:
+            raise RuntimeError("el_nmf_step_ws_bytes failed: " + (_lib.load().el_last_error() or b"").decode())
+        self._step_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.ctx.device)
+        base = (self._step_ws.data_ptr() + 255) // 256 * 256
+        self._c.step_ws, self._c.step_ws_bytes = base, need
 
     def _alloc_deferred(self):
         dev, c = self.ctx.device, self._c
         zi = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
-        self._row_last, self._row_stamp = [zi(self.U), zi(self.I)], [zi(self.U), zi(self.I)]
+        self._row_last = [zi(self.U), zi(self.I)]
         if self.step:
             for t in self._row_last:
                 t.fill_(self.step)                                    # switched on mid-run: every row is current
-        self._row_own = torch.zeros(2 * self.Bmax, dtype=torch.uint8, device=dev)
         self._lr_hist = torch.zeros(self._LR_HIST, dtype=torch.float32, device=dev)
         c.row_last = (C.c_void_p * 2)(*[t.data_ptr() for t in self._row_last])
-        c.row_stamp = (C.c_void_p * 2)(*[t.data_ptr() for t in self._row_stamp])
-        c.row_own, c.lr_hist, c.lr_hist_cap = self._row_own.data_ptr(), self._lr_hist.data_ptr(), self._LR_HIST
+        c.lr_hist, c.lr_hist_cap = self._lr_hist.data_ptr(), self._LR_HIST
         c.hist_base, c.claim_seq = self.step + 1, 0
         c.opt_step = c.flushed_step = self.step
 
@@ -1524,9 +1532,9 @@ class NmfDeviceState:
             self.sync()
             self.deferred = False
             c = self._c
-            c.row_last, c.row_stamp = (C.c_void_p * 2)(None, None), (C.c_void_p * 2)(None, None)
-            c.row_own = c.lr_hist = None
-            self._row_last = self._row_stamp = self._row_own = self._lr_hist = None
+            c.row_last = (C.c_void_p * 2)(None, None)
+            c.lr_hist = None
+            self._row_last = self._lr_hist = None
         else:
             self.deferred = True
             self._alloc_deferred()
@@ -1557,7 +1565,7 @@ class NmfDeviceState:
         hold the activations -- never splits the batch into several steps behind the caller's back."""
         if n <= self.Bmax:
             return
-        self.X0 = self.dX0 = self.MF = self.dlogit = self._ws = None
+        self.X0 = self.dX0 = self.MF = self.dlogit = self._ws = self._step_ws = None
         self.act, self.dact = [], []
         torch.cuda.empty_cache()
         self._alloc_activations(n)
@@ -1566,9 +1574,7 @@ class NmfDeviceState:
         c = self._c
         c.Bmax, c.X0, c.dX0, c.MF, c.dlogit = self.Bmax, p(self.X0), p(self.dX0), p(self.MF), p(self.dlogit)
         c.act, c.dact, c.ws, c.ws_bytes = a4(self.act), a4(self.dact), self._ws.data_ptr(), self._ws.numel()
-        if self.deferred:
-            self._row_own = torch.zeros(2 * self.Bmax, dtype=torch.uint8, device=self.ctx.device)
-            c.row_own = self._row_own.data_ptr()
+        self._alloc_step_ws()
 
     def _next_mask(self):
         self._drop_calls += 1                                        # a fresh dropout mask per gradient evaluation

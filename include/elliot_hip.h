@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct el_ctx el_ctx;
 
-#define EL_ABI_VERSION 7   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
+#define EL_ABI_VERSION 8   /* 2: el_score_topk_ws_bytes takes excl_nnz; screened top-k, list / metrics / grads entry points
                             * 3: el_pwmf_* (point-wise factor models), el_bprmf_train_loop, el_cml_*
                             * 4: el_bprmf_state ends in uslot / gGu_rows / gGu_cap (a host built against version 3 passes a
                             *    shorter struct: compare el_abi_version() with EL_ABI_VERSION before the first call);
@@ -48,7 +48,10 @@ typedef struct el_ctx el_ctx;
                             *    against 5 runs unchanged)
                             * 7: el_bprmf_state ends in replay_series; el_ctx_set_option / el_ctx_get_option (the library no
                             *    longer reads the environment after el_ctx_create); el_graph_csr, el_spmm_csr_f32,
-                            *    el_lightgcn_propagate; el_ngcf_*; el_mf2020_train; el_bprmf_ws_bytes / el_cml_ws_bytes take F, el_bprmf_deterministic                                                  */
+                            *    el_lightgcn_propagate; el_ngcf_*; el_mf2020_train; el_bprmf_ws_bytes / el_cml_ws_bytes take F, el_bprmf_deterministic
+                            * 8: el_nmf_state ends in step_ws / step_ws_bytes (el_nmf_step_ws_bytes): the NeuMF / GMF step walks its embedding rows
+                            *    as sorted segments and sums every batch reduction in a fixed order (no float atomics); training
+                            *    calls REQUIRE the workspace; row_stamp / row_own / claim_seq are no longer read              */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -567,15 +570,24 @@ typedef struct el_nmf_state {
      * replicated table over several ranks (el_nmf_grads / el_nmf_apply) leaves the feature off: the rows of other ranks'
      * samples are not known here.  With it on, every el_nmf_grads is followed by its el_nmf_apply.
      *   row_last[0] int32[U], row_last[1] int32[I]   zero-initialised: the optimiser step the row is current at
-     *   row_stamp[0] int32[U], row_stamp[1] int32[I] zero-initialised scratch
-     *   row_own      uint8[2 * Bmax]                 scratch
+     *   row_stamp, row_own                           unused since ABI 8 (may be NULL)
      *   lr_hist      float[lr_hist_cap]              the library records lr_t per step here (cap >= 2; when it is full every
      *                                                row is brought up to date and the history restarts)
      *   hist_base = 1, opt_step = flushed_step = claim_seq = 0, batch_* = NULL/0 at creation; maintained by the library.      */
     int32_t* row_last[2]; int32_t* row_stamp[2]; uint8_t* row_own; float* lr_hist;
     int32_t lr_hist_cap, hist_base, opt_step, flushed_step, claim_seq;
     const int32_t* batch_u; const int32_t* batch_i; int64_t batch_n;
+    /* Step workspace (ABI 8; REQUIRED by el_nmf_train_step / el_nmf_grads / el_nmf_apply): el_nmf_step_ws_bytes(ctx, st) bytes of
+     * device memory, 256-byte aligned, owned by this state (one per state: el_nmf_apply reads what el_nmf_grads left in it).
+     * Holds the sorted (row, sample) keys of the batch, the two factors of the MF product per sample and the partial rows of the
+     * batch reductions: the step sorts the batch by embedding row and walks the segments (catch-up + gather one way, gradient sums
+     * + Adam the other), and every reduction over the batch (embedding rows, Dense biases, head weights, loss) is added in a fixed
+     * order -- two runs from the same state give the same bits.                                                              */
+    void* step_ws; size_t step_ws_bytes;
 } el_nmf_state;
+
+/* Bytes of el_nmf_state.step_ws for the state's shape (U, I, Bmax, F, E, n_layers, units, use_mf, use_mlp must be filled in). */
+size_t el_nmf_step_ws_bytes(el_ctx* ctx, const el_nmf_state* st);
 
 /* Replaces: pointwise_pos_neg_sampler.Sampler.step (dataset/samplers/pointwise_pos_neg_sampler.py:26-50):
  * u uniform, fair coin, positive item of u (label 1) or rejected-uniform negative (label 0); Philox stream. */

@@ -42,7 +42,7 @@ def test_binding_matches_header():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.el_abi_version() == 7
+    assert lib.el_abi_version() == 8
     assert isinstance(lib.el_last_error(), bytes)
 
 

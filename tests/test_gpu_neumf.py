@@ -348,3 +348,61 @@ def test_deferred_decay_replays_the_every_row_adam_bit_for_bit(ctx, model, F, hi
         _adam_np(*sh[nm], g[nm], np.float32(ops.adam_lr_t(lr, 25)))
     for nm in names:
         assert np.array_equal(cpu(st.tab[tix[nm]]), sh[nm][0]), nm
+
+
+def _flat_weights(w):
+    out = {}
+    for k, v in w.items():
+        if isinstance(v, list):
+            for j, a in enumerate(v):
+                out[f"{k}{j}"] = np.asarray(a)
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+@pytest.mark.parametrize("model,F,split", [("neumf", 64, 1), ("neumf", 64, 0), ("gmf", 32, 1), ("neumf", 33, 1), ("neumf", 128, 1)])
+def test_the_step_is_deterministic_and_its_forms_agree_bit_for_bit(ctx, lib_option, model, F, split):
+    """The NeuMF / GMF step without float atomics: the embedding rows of a batch are walked as sorted segments
+    (k_nmf_seg_fwd / k_nmf_seg_bwd; hot items of the Zipf batch take the long-segment kernel), the Dense biases', the head's and the
+    loss' reductions over the batch add workgroup partials in a fixed order.  50 steps twice from the same state: every variable and the
+    loss history bit-identical; the fused step (sums + Adam in one pass, deferred decay), el_nmf_grads + el_nmf_apply (gradient rows through
+    gtab) and the eager every-row form give the same bits again."""
+    lib_option("gemm_split", split)
+    U, I, B, lr, steps = 6000, 2500, 4096, 0.003, 50
+    units = [4 * F, 2 * F, F] if F != 33 else [64, 32, 16]
+    w0 = on.init_neumf(U, I, F, 21, units=units) if model == "neumf" else on.init_gmf(U, I, F, 21)
+    d = ctx.device
+    rs = np.random.RandomState(8)
+    batches = []
+    for s in range(steps):
+        n = B if s % 7 else 1000
+        u = rs.randint(0, U, n).astype(np.int32)
+        i = (rs.zipf(1.25, n) % I).astype(np.int32)                     # a few items hold hundreds of samples each
+        y = rs.randint(0, 2, n).astype(np.float32)
+        batches.append(tuple(torch.from_numpy(a).to(d) for a in (u, i, y)))
+    assert max(np.bincount(cpu(b[1])).max() for b in batches) > 200      # the long-segment kernel runs
+
+    def run(form):
+        st = ops.NmfDeviceState(ctx, w0, max_batch=B, deferred=(form != "eager"))
+        losses = []
+        for u, i, y in batches:
+            if form == "two_pass":
+                st.grads(u, i, y)
+                st.apply(lr)
+            else:
+                st.train_step(u, i, y, lr)
+            losses.append(st.pop_loss())
+        w = _flat_weights(st.weights())
+        for t, nm in enumerate(("Umf", "Imf", "Umlp", "Imlp")):
+            if st.mtab[t] is not None:
+                w["m_" + nm], w["v_" + nm] = cpu(st.mtab[t]), cpu(st.vtab[t])
+        return w, losses
+
+    a, la = run("fused")
+    assert np.isfinite(la).all()
+    for form in ("fused", "two_pass", "eager"):
+        b, lb = run(form)
+        assert la == lb, (form, [k for k in range(steps) if la[k] != lb[k]][:5])
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (form, k, int((a[k] != b[k]).sum()), float(np.abs(a[k] - b[k]).max()))
