@@ -1044,6 +1044,12 @@ def graph_leg(args, ctx):
                         "roofline": {"kernel": "k_spmm_csr", "bound": "hbm", "achieved": spmm_bytes / sec / 1e9 if sec > 0 else None,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None,
                                      "traffic": None, "bytes_per_launch": spmm_bytes,
+                                     "hbm_compulsory_bytes_per_launch": nnz * 8.0 + N * 4.0 * F * 3,
+                                     "note": "bytes_per_launch counts one gathered operand row per non-zero (the algorithmic unit of a CSR x dense "
+                                             "product, as the BPR kernels count a gathered row per triplet); the operand itself "
+                                             f"({N * 4.0 * F / 1e6:.0f} MB) is about the size of the 256 MiB Infinity Cache, so most of those rows are served "
+                                             "on-die: `achieved` is a gather rate, the HBM-side traffic is near hbm_compulsory_bytes_per_launch "
+                                             "(index + value per non-zero, operand read once, result written, combination operand read)",
                                      "kernels_ms_per_step": {n: v[1] / K for n, v in rep.items()}}}}
     del st, graph, Gu, Gi
     torch.cuda.empty_cache()
@@ -1063,7 +1069,7 @@ def graph_leg(args, ctx):
     dtm = time.perf_counter() - t0
     out["mf2020"] = {"value": n / dtm, "unit": "samples/s", "us_per_sample": dtm / n * 1e6, "loss_per_sample": mf.pop_loss() / (n + 20000),
                      "workload": f"MF2020 sequential fp64 SGD, {n} samples over {Um} users x {Im} items, F=64 (one chain: every sample updates the global bias)",
-                     "note": "bound by the chain's latency (fp64 exp / log / division + one 64-lane reduction per sample on one wave), not by a roofline"}
+                     "note": "bound by the chain's latency (two LDS row reads, one 64-lane fp64 reduction, one fp64 exp and one division per sample on one wave; the loss terms are computed off the chain), not by a roofline"}
     return out
 
 

@@ -13,9 +13,12 @@
 //   phase B (one wave)     the C updates in order, entirely on LDS and registers: lane f holds element f of the two rows, the dot product
 //                          is one wave reduction, exp / log / the division in fp64; the global bias stays in a register
 //   phase C (256 threads)  the slots back to HBM
-// ~0.35 us per sample against ~20 us for the reference's NumPy calls (fp64 exp, log, division and a 64-lane reduction on the critical
-// path); a chain cannot go faster than its links.  The dot product's summation order is the butterfly's, NumPy's is its BLAS': results
-// agree to the last bits of fp64 (tests: 1e-12), not bit for bit -- as for BPRMF's el_bprsgd_apply.
+// What sits on the chain per sample: two LDS row reads, the 64-lane fp64 sum (data-parallel-primitive row operations, no LDS crossbar),
+// one fp64 exp and one division, the row updates.  The loss is NOT on it: phase B leaves the sample's prediction in LDS and phase C
+// computes the chunk's loss terms on all threads and adds them in sample order (`loss += this_loss`, :108).  Against ~20 us per sample
+// for the reference's NumPy calls; a chain cannot go faster than its links.  The dot product's summation order is the reduction
+// tree's, NumPy's is its BLAS': results agree to the last bits of fp64 (tests: 1e-12), not bit for bit -- as for BPRMF's
+// el_bprsgd_apply.
 #include "el_common.h"
 
 #define MF20_THREADS 256
@@ -34,6 +37,8 @@ struct Mf20Lds {
     int32_t* key_u;    // [C] row id held by a slot
     int32_t* key_i;
     int32_t* cnt;      // [2] slots in use
+    double* pred;      // [C] the samples' predictions (loss terms: phase C)
+    double* lterm;     // [C]
     double* bu;        // [C] slot biases
     double* bi;
     double* P;         // [C, F] slot rows
@@ -62,6 +67,26 @@ __device__ __forceinline__ int32_t mf20_lookup(const int32_t* hk, const int32_t*
     return hs[h];
 }
 
+// sum of v over the 64 lanes, returned to every lane: row operations of the data-parallel primitives on the two halves of the double
+// (quad swaps, half-row and row mirrors, then the row broadcasts 15 / 31), the total read from lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double mf20_dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double mf20_wave_sum(double v) {
+    v = mf20_dpp_add<0xB1, 0xf>(v);       // quad_perm [1, 0, 3, 2]
+    v = mf20_dpp_add<0x4E, 0xf>(v);       // quad_perm [2, 3, 0, 1]
+    v = mf20_dpp_add<0x141, 0xf>(v);      // row_half_mirror
+    v = mf20_dpp_add<0x140, 0xf>(v);      // row_mirror: every lane holds its row's 16-lane sum
+    v = mf20_dpp_add<0x142, 0xa>(v);      // row_bcast15 into rows 1, 3
+    v = mf20_dpp_add<0x143, 0xc>(v);      // row_bcast31 into rows 2, 3: lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(MF20_THREADS) void k_mf2020_seq(el_mf2020_state st, const int32_t* __restrict__ samples, int64_t n, int C,
                                                              double* loss_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mf20_lds[];
@@ -73,6 +98,8 @@ __global__ __launch_bounds__(MF20_THREADS) void k_mf2020_seq(el_mf2020_state st,
         L.Q = (double*)p, p += (size_t)C * F * 8;
         L.bu = (double*)p, p += (size_t)C * 8;
         L.bi = (double*)p, p += (size_t)C * 8;
+        L.pred = (double*)p, p += (size_t)C * 8;
+        L.lterm = (double*)p, p += (size_t)C * 8;
         L.s_u = (int32_t*)p, p += (size_t)C * 4;
         L.s_i = (int32_t*)p, p += (size_t)C * 4;
         L.s_y = (float*)p, p += (size_t)C * 4;
@@ -115,23 +142,23 @@ __global__ __launch_bounds__(MF20_THREADS) void k_mf2020_seq(el_mf2020_state st,
         __syncthreads();
         // ---- phase B: the chunk's updates, in order, one wave
         if (tid < 64) {
+            int su_n = L.su[0], si_n = L.si[0];
+            float y_n = L.s_y[0];
             for (int s = 0; s < cs; ++s) {
-                const int su = L.su[s], si = L.si[s];
-                const double y = (double)L.s_y[s];
+                const int su = su_n, si = si_n;
+                const double y = (double)y_n;
+                if (s + 1 < cs) su_n = L.su[s + 1], si_n = L.si[s + 1], y_n = L.s_y[s + 1];      // (not on the chain: fetched a sample ahead)
                 double dot = 0.0;
                 for (int f = lane; f < F; f += 64) dot += L.P[su * F + f] * L.Q[si * F + f];
-                for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+                dot = mf20_wave_sum(dot);
                 const double ub = L.bu[su], ib = L.bi[si];
                 const double pred = gb + ub + ib + dot;                       // :89
-                double sig, this_loss;
-                if (pred > 0) {                                               // :92-96
-                    const double opm = 1.0 + exp(-pred);
-                    sig = 1.0 / opm;
-                    this_loss = log(opm) + (1.0 - y) * pred;
-                } else {                                                      // :97-99
+                if (lane == 0) L.pred[s] = pred;
+                double sig;
+                if (pred > 0) sig = 1.0 / (1.0 + exp(-pred));                 // :92-94
+                else {                                                        // :97-98
                     const double ep = exp(pred);
                     sig = ep / (1.0 + ep);
-                    this_loss = -y * pred + log(1.0 + ep);
                 }
                 const double grad = y - sig;                                  // :101
                 for (int f = lane; f < F; f += 64) {
@@ -145,16 +172,26 @@ __global__ __launch_bounds__(MF20_THREADS) void k_mf2020_seq(el_mf2020_state st,
                     L.bi[si] = ib + lr * (grad - reg * ib);                   // :106
                 }
                 gb = gb + lr * (grad - reg * gb);                             // :107
-                loss += this_loss;                                            // :108
                 el_wave_lds_sync();                                           // the next sample reads what this one wrote
             }
         }
         __syncthreads();
-        // ---- phase C: slots back to the tables
+        // ---- phase C: the chunk's loss terms (:94-99), every thread one sample; added in sample order below (:108)
+        if (tid < cs) {
+            const double pred = L.pred[tid], y = (double)L.s_y[tid];
+            double this_loss;
+            if (pred > 0) this_loss = log(1.0 + exp(-pred)) + (1.0 - y) * pred;
+            else this_loss = -y * pred + log(1.0 + exp(pred));
+            L.lterm[tid] = this_loss;
+        }
+        // ---- slots back to the tables
         for (int x = tid; x < nu * F; x += MF20_THREADS) st.P[(int64_t)L.key_u[x / F] * F + x % F] = L.P[x];
         for (int x = tid; x < ni * F; x += MF20_THREADS) st.Q[(int64_t)L.key_i[x / F] * F + x % F] = L.Q[x];
         for (int x = tid; x < nu; x += MF20_THREADS) st.bu[L.key_u[x]] = L.bu[x];
         for (int x = tid; x < ni; x += MF20_THREADS) st.bi[L.key_i[x]] = L.bi[x];
+        __syncthreads();
+        if (tid == 0)
+            for (int s2 = 0; s2 < cs; ++s2) loss += L.lterm[s2];
         __syncthreads();
     }
     if (tid == 0) {
@@ -164,7 +201,7 @@ __global__ __launch_bounds__(MF20_THREADS) void k_mf2020_seq(el_mf2020_state st,
 }
 
 static size_t mf20_lds_bytes(int C, int F) {
-    return (size_t)2 * C * F * 8 + (size_t)2 * C * 8 + (size_t)7 * C * 4 + (size_t)4 * MF20_HASH * 4 + 16;
+    return (size_t)2 * C * F * 8 + (size_t)4 * C * 8 + (size_t)7 * C * 4 + (size_t)4 * MF20_HASH * 4 + 16;
 }
 
 // Replaces: MFModel.train_step (MF2020/MF_model.py:80-113) on one batch of (user, item, rating) rows, in order.
