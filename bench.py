@@ -182,7 +182,7 @@ def dist_setup(args):
     return world, rank, local, backend
 
 
-from elliot_amd.pipeline import PrefetchSampler, cover_batches, cover_triplets  # noqa: E402,F401  (the step pipeline the tests drive too)
+from elliot_amd.pipeline import PrefetchPointwise, PrefetchSampler, cover_batches, cover_triplets  # noqa: E402,F401  (the step pipeline the tests drive too)
 
 
 def barrier(world):
@@ -1097,10 +1097,15 @@ def neumf_leg(args, ctx):
     del w
     it = [0]
 
+    # the sampler never reads the model (pointwise_pos_neg_sampler.py:26-50): batch t+1 is drawn, and its (embedding row, sample) keys
+    # ordered (el_nmf_presort), on a side stream under step t -- elliot_amd/pipeline.py, as for the BPR leg
+    pipe = PrefetchPointwise(ctx, pos, B, seed=3, enabled=not getattr(args, "no_prefetch", False), presort_state=st)
+
     def step():
-        u, i, y = ops.pointwise_sample(ctx, pos, B, seed=3, first_sample=it[0] * B)
+        (u, i, y), b = pipe.next()
         it[0] += 1
         st.train_step(u, i, y, 0.001)
+        pipe.release(b)
 
     # the timed region ends with st.sync(): under the deferred decay (el_nmf_state.row_last) the postponed every-row updates of
     # the K steps are replayed there -- every (element, step) update of Keras' Adam is inside the timed region

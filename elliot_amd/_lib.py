@@ -95,6 +95,7 @@ class NmfState(C.Structure):
         ("claim_seq", C.c_int32),
         ("batch_u", C.c_void_p), ("batch_i", C.c_void_p), ("batch_n", C.c_int64),
         ("step_ws", C.c_void_p), ("step_ws_bytes", C.c_size_t),
+        ("pre_u", C.c_void_p), ("pre_i", C.c_void_p), ("pre_n", C.c_int64), ("sort_set", C.c_int32),
     ]
 
 
@@ -213,6 +214,7 @@ PROTOTYPES = {
                                     C.c_int32, C.c_float, _f64p]),
     "el_nmf_sync_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState)]),
     "el_nmf_step_ws_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(NmfState)]),
+    "el_nmf_presort": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(NmfState), C.c_void_p, C.c_void_p, C.c_int64]),
     "el_nmf_score_supported": (C.c_int, [C.POINTER(NmfState), C.c_int32]),
     "el_nmf_screen_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "el_nmf_score_ws_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(NmfState), C.c_int64, C.c_int64, C.c_int32, C.c_int]),

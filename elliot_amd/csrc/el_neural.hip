@@ -697,19 +697,18 @@ __global__ __launch_bounds__(256) void k_nmf_seg_fwd(el_nmf_state st, NmfSeg sg)
     }
     const int32_t myb = hd.myb;
     const NmfRowTabs rt = nmf_row_tabs(st, side);
-    int nsteps = 0;
-    const float* lr_from = nullptr;
-    if (DEFER) {
-        const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
-        nsteps = (sg.t - 1) - last;
-        lr_from = st.lr_hist + (last + 1 - st.hist_base);
-    }
+    // the row stamp and the row itself are fetched TOGETHER (the stamp is not needed to address the row; m, v of the rare row that
+    // needs no replay are wasted): one round trip instead of two in front of the replay
+    const int last_v = DEFER ? st.row_last[side][row] : 0;
     const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
     for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
         NmfRowRegs<VW, 1> r;
         bool fresh = false;
+        if (DEFER) nmf_rows_load<VW, 1, true>(r, rt, row, f0, lane);
+        const int last = __builtin_amdgcn_readfirstlane(last_v);
+        const int nsteps = DEFER ? (sg.t - 1) - last : 0;
+        const float* lr_from = st.lr_hist + (last + 1 - st.hist_base);
         if (DEFER && nsteps > 0) {
-            nmf_rows_load<VW, 1, true>(r, rt, row, f0, lane);
             // m = v = 0 (rows that never had a gradient) is a fixed point of the gradient-free step: nothing to replay, nothing to write
             bool nz = false;
 #pragma unroll
@@ -720,7 +719,7 @@ __global__ __launch_bounds__(256) void k_nmf_seg_fwd(el_nmf_state st, NmfSeg sg)
                 nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps);
                 fresh = true;
             }
-        } else {
+        } else if (!DEFER) {
             nmf_rows_load_theta<VW>(r, rt, row, f0, lane);
         }
         if (fresh) {
@@ -878,13 +877,7 @@ __global__ __launch_bounds__(256) void k_nmf_seg_bwd(el_nmf_state st, NmfSeg sg)
     const int len = hd.len;
     if (MODE != 2 && len > 64) return;                                        // k_nmf_seg_bwd_long's (on the list since the forward pass)
     const NmfRowTabs rt = nmf_row_tabs(st, side);
-    int nsteps = 0;
-    const float* lr_from = nullptr;
-    if (MODE != 0) {
-        const int last = __builtin_amdgcn_readfirstlane(st.row_last[side][row]);
-        nsteps = (sg.t - 1) - last;
-        lr_from = st.lr_hist + (last + 1 - st.hist_base);
-    }
+    const int last_v = MODE != 0 ? st.row_last[side][row] : 0;              // (consumed after the row loads below are in flight)
     const int Dmax = rt.n == 2 ? (rt.D[0] > rt.D[1] ? rt.D[0] : rt.D[1]) : rt.D[0];
     for (int f0 = 0; f0 < Dmax; f0 += 64 * VW) {
         NmfRowRegs<VW, 1> r;
@@ -909,7 +902,8 @@ __global__ __launch_bounds__(256) void k_nmf_seg_bwd(el_nmf_state st, NmfSeg sg)
 #pragma unroll
                 for (int x = 0; x < VW; ++x) g[k][0][x] = gs[k][x];
         }
-        nmf_seg_finish<VW, MODE>(st, sg, rt, row, f0, lane, r, g, nsteps, lr_from);
+        const int last = __builtin_amdgcn_readfirstlane(last_v);
+        nmf_seg_finish<VW, MODE>(st, sg, rt, row, f0, lane, r, g, (sg.t - 1) - last, st.lr_hist + (last + 1 - st.hist_base));
     }
     if (MODE != 0 && lane == 0) st.row_last[side][row] = sg.t;
 }
@@ -1055,9 +1049,10 @@ static int nmf_bits_for(int64_t n) {
     return b;
 }
 struct NmfStepWs {
-    u32 *kin, *kout;
-    int32_t *vin, *vout;
-    void* tmp;
+    // two complete sort sets: el_nmf_presort orders the NEXT batch into the set the current step does not use
+    u32 *kin[2], *kout[2];
+    int32_t *vin[2], *vout[2];
+    void* tmp[2];
     size_t tmp_bytes;
     int32_t* llist;
     float* lpart;
@@ -1075,8 +1070,10 @@ static int nmf_carve(el_ctx* ctx, const el_nmf_state* st, void* base, NmfStepWs*
         off += (bytes + 255) & ~(size_t)255;
         return r;
     };
-    w->kin = (u32*)take((size_t)2 * B * 4), w->kout = (u32*)take((size_t)2 * B * 4);
-    w->vin = (int32_t*)take((size_t)2 * B * 4), w->vout = (int32_t*)take((size_t)2 * B * 4);
+    for (int k = 0; k < 2; ++k) {
+        w->kin[k] = (u32*)take((size_t)2 * B * 4), w->kout[k] = (u32*)take((size_t)2 * B * 4);
+        w->vin[k] = (int32_t*)take((size_t)2 * B * 4), w->vout[k] = (int32_t*)take((size_t)2 * B * 4);
+    }
     size_t tb = 0;
     u32* np = nullptr;
     int32_t* nv = nullptr;
@@ -1085,7 +1082,7 @@ static int nmf_carve(el_ctx* ctx, const el_nmf_state* st, void* base, NmfStepWs*
         return 1;
     }
     w->tmp_bytes = tb;
-    w->tmp = take(tb + 256);
+    for (int k = 0; k < 2; ++k) w->tmp[k] = take(tb + 256);
     w->llist = (int32_t*)take((size_t)(3 * (2 * B / 65 + 2) + 8) * 4);
     {   // partial rows of the long segments' blocks: at most one per NMF_LBLK positions + one per long segment
         const int64_t Dsum = (st->use_mf ? st->F : 0) + (st->use_mlp ? st->E : 0);
@@ -1175,20 +1172,30 @@ static inline bool nmf_even(const el_nmf_state* st) {      // every table row st
     return (!st->use_mf || st->F % 2 == 0) && (!st->use_mlp || st->E % 2 == 0);
 }
 
+static int nmf_sort_into(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n, const NmfStepWs* w,
+                         int set) {
+    EL_LAUNCH("k_nmf_keys", k_nmf_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, i, n, st->U, w->kin[set], w->vin[set]);
+    ElKernelTimer tm("rocprim_radix_sort_pairs", s);
+    size_t tb = w->tmp_bytes;
+    EL_CHECK_HIP(rocprim::radix_sort_pairs(w->tmp[set], tb, w->kin[set], w->kout[set], w->vin[set], w->vout[set], (unsigned)(2 * n), 0,
+                                           nmf_bits_for(st->U + st->I), s));
+    (void)ctx;
+    return 0;
+}
+
 static int nmf_sort_batch(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n, NmfStepWs* w,
                           NmfSeg* sg) {
     size_t total = 0;
     if (int rc = nmf_carve(ctx, st, st->step_ws, w, &total)) return rc;
     EL_REQUIRE(st->step_ws_bytes >= total, "el_nmf: step_ws holds %zu bytes, el_nmf_step_ws_bytes asks for %zu", st->step_ws_bytes, total);
+    EL_REQUIRE(st->sort_set == 0 || st->sort_set == 1, "el_nmf: sort_set corrupt (zero-initialise the state)");
     if (nmf_deferred(st) && (st->opt_step + 1) - st->hist_base >= st->lr_hist_cap)     // history full: every row to t - 1, the history restarts at t
         if (int rc = nmf_sync(ctx, s, st)) return rc;
-    EL_LAUNCH("k_nmf_keys", k_nmf_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, i, n, st->U, w->kin, w->vin);
-    {
-        ElKernelTimer tm("rocprim_radix_sort_pairs", s);
-        size_t tb = w->tmp_bytes;
-        EL_CHECK_HIP(rocprim::radix_sort_pairs(w->tmp, tb, w->kin, w->kout, w->vin, w->vout, (unsigned)(2 * n), 0, nmf_bits_for(st->U + st->I), s));
-    }
-    sg->keys = w->kout, sg->perm = w->vout, sg->n2 = 2 * n;
+    if (st->pre_u == u && st->pre_i == i && st->pre_n == n && u != nullptr) {           // el_nmf_presort ordered this batch already
+        st->sort_set ^= 1;
+        st->pre_u = st->pre_i = nullptr, st->pre_n = 0;
+    } else if (int rc = nmf_sort_into(ctx, s, st, u, i, n, w, st->sort_set)) return rc;
+    sg->keys = w->kout[st->sort_set], sg->perm = w->vout[st->sort_set], sg->n2 = 2 * n;
     sg->mfp[0] = w->mfp[0], sg->mfp[1] = w->mfp[1];
     sg->llist = w->llist, sg->lpart = w->lpart;
     sg->t = st->opt_step + 1, sg->lr_t = 0.f;
@@ -1402,7 +1409,7 @@ static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t, b
         size_t total = 0;
         if (int rc = nmf_carve(ctx, st, st->step_ws, &w, &total)) return rc;
         NmfSeg sg;
-        sg.keys = w.kout, sg.perm = w.vout, sg.n2 = 2 * st->batch_n, sg.mfp[0] = w.mfp[0], sg.mfp[1] = w.mfp[1], sg.llist = w.llist, sg.lpart = w.lpart;
+        sg.keys = w.kout[st->sort_set], sg.perm = w.vout[st->sort_set], sg.n2 = 2 * st->batch_n, sg.mfp[0] = w.mfp[0], sg.mfp[1] = w.mfp[1], sg.llist = w.llist, sg.lpart = w.lpart;
         sg.t = t, sg.lr_t = lr_t;
         nmf_launch_bwd(s, st, &sg, 2, ctx);
         st->batch_u = st->batch_i = nullptr, st->batch_n = 0;
@@ -1435,6 +1442,25 @@ static int nmf_apply(el_ctx* ctx, hipStream_t s, el_nmf_state* st, float lr_t, b
     EL_CHECK_LAUNCH();
     st->opt_step += 1;
     if (!nmf_deferred(st)) st->flushed_step = st->opt_step;
+    return 0;
+}
+
+// The (row, sample) keys of a batch ordered AHEAD of its step: the sort reads u and i only, so a training loop whose sampler runs a batch
+// ahead (it never reads the model) calls this on another stream while the previous step trains; the el_nmf_train_step / el_nmf_grads
+// call that follows with the SAME u, i, n (the arrays unchanged in between, this call complete in the step's stream order: the caller's
+// event) then skips its own sort.  One batch can be pending; a step on other arrays sorts for itself and leaves the pending one alone.
+extern "C" int el_nmf_presort(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n) {
+    if (int rc = el_bind(ctx)) return rc;
+    if (int rc = nmf_check(st, n, true)) return rc;
+    EL_REQUIRE(u && i && n >= 1, "el_nmf_presort: bad arguments");
+    NmfStepWs w;
+    size_t total = 0;
+    if (int rc = nmf_carve(ctx, st, st->step_ws, &w, &total)) return rc;
+    EL_REQUIRE(st->step_ws_bytes >= total, "el_nmf: step_ws holds %zu bytes, el_nmf_step_ws_bytes asks for %zu", st->step_ws_bytes, total);
+    EL_REQUIRE(st->sort_set == 0 || st->sort_set == 1, "el_nmf: sort_set corrupt (zero-initialise the state)");
+    if (int rc = nmf_sort_into(ctx, (hipStream_t)stream, st, u, i, n, &w, st->sort_set ^ 1)) return rc;
+    EL_CHECK_LAUNCH();
+    st->pre_u = u, st->pre_i = i, st->pre_n = n;
     return 0;
 }
 

@@ -1404,12 +1404,15 @@ class VaeDeviceState:
 # ------------------------------------------------------------------------------------------
 # NeuMF / GMF
 # ------------------------------------------------------------------------------------------
-def pointwise_sample(ctx, pos, n, seed, first_sample=0, use_meta=True):
+def pointwise_sample(ctx, pos, n, seed, first_sample=0, use_meta=True, out=None):
     """pointwise_pos_neg_sampler.Sampler.step (pointwise_pos_neg_sampler.py:26-50) on the device (use_meta: through the per-user
-    sampler records -- same draws, fewer cache lines)."""
-    u = torch.empty(n, dtype=torch.int32, device=ctx.device)
-    i = torch.empty(n, dtype=torch.int32, device=ctx.device)
-    y = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    sampler records -- same draws, fewer cache lines).  out: (u int32[n], i int32[n], label float32[n]) to fill."""
+    if out is not None:
+        u, i, y = out
+    else:
+        u = torch.empty(n, dtype=torch.int32, device=ctx.device)
+        i = torch.empty(n, dtype=torch.int32, device=ctx.device)
+        y = torch.empty(n, dtype=torch.float32, device=ctx.device)
     meta = sampler_meta(ctx, pos) if use_meta else None
     check(ctx.lib.el_pointwise_sample_meta(ctx.handle, ctx.stream(), *_csr_ptrs(pos),
                                            C.c_void_p(meta.data_ptr()) if meta is not None else None, int(pos.n_rows),
@@ -1504,6 +1507,8 @@ class NmfDeviceState:
         self._step_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.ctx.device)
         base = (self._step_ws.data_ptr() + 255) // 256 * 256
         self._c.step_ws, self._c.step_ws_bytes = base, need
+        self._c.pre_u = self._c.pre_i = None                        # (a batch ordered ahead into the old workspace is forgotten)
+        self._c.pre_n, self._c.sort_set = 0, 0
 
     def _alloc_deferred(self):
         dev, c = self.ctx.device, self._c
@@ -1606,6 +1611,13 @@ class NmfDeviceState:
                                              float(adam_lr_t(lr, t)), _ptr(self.loss, torch.float64)),
               "el_nmf_train_step")
         self.step = t
+
+    def presort(self, u, i):
+        """Order the batch's (embedding row, sample) keys ahead of its step, on the CURRENT stream (a side stream, while the previous
+        step trains: el_nmf_presort); the train_step / grads call that follows with the same tensors skips its sort."""
+        self.ensure_batch(u.numel())
+        check(self.ctx.lib.el_nmf_presort(self.ctx.handle, self.ctx.stream(), C.byref(self._c), _ptr(u, torch.int32), _ptr(i, torch.int32),
+                                          int(u.numel())), "el_nmf_presort")
 
     def grads(self, u, i, label, n_global=None):
         """Forward + loss + backward only (multi-GPU: the BCE mean runs over n_global samples); gradients stay in the

@@ -58,6 +58,56 @@ class PrefetchSampler:
             self.free[b] = ev
 
 
+class PrefetchPointwise:
+    """The same pipeline for the point-wise models (NeuMF / GMF: neural_matrix_factorization.py:87-95 `for batch in sampler.step(...):
+    train_step(batch)`): (u, i, label) of step t+1 drawn on a side stream under step t, and -- presort_state: an NmfDeviceState --
+    the batch's (embedding row, sample) keys ordered there too (el_nmf_presort: the sort reads u and i only)."""
+
+    def __init__(self, ctx, pos, B, seed, enabled=True, presort_state=None):
+        dev = ctx.device
+        self.ctx, self.pos, self.B, self.seed, self.enabled = ctx, pos, B, seed, enabled
+        self.state = presort_state if enabled else None
+        self.bufs = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                      torch.empty(B, dtype=torch.float32, device=dev)) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [None, None]
+        self.cur, self.ctr = 0, 0
+        if enabled:
+            self._issue(0)
+
+    def _draw(self, b):
+        ops.pointwise_sample(self.ctx, self.pos, self.B, seed=self.seed, first_sample=self.ctr, out=self.bufs[b])
+        self.ctr += self.B
+        if self.state is not None:
+            self.state.presort(self.bufs[b][0], self.bufs[b][1])
+
+    def _issue(self, b):
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            if self.free[b] is not None:
+                self.side.wait_event(self.free[b])                    # the training step that read this buffer is done
+            self._draw(b)
+            self.ready[b].record(self.side)
+
+    def next(self):
+        """(u, i, label) of this step (valid on the current stream) and the buffer index to release() after the step."""
+        b = self.cur
+        if not self.enabled:
+            self._draw(b)
+            return self.bufs[b], b
+        torch.cuda.current_stream().wait_event(self.ready[b])
+        self.cur ^= 1
+        self._issue(self.cur)                                         # next batch: overlaps this step's kernels
+        return self.bufs[b], b
+
+    def release(self, b):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.free[b] = ev
+
+
 def cover_triplets(indptr, indices, cover_users, cover_items, U, I, B):
     """The batches of cover_batches(), one (u, i, j) int32 triple per step: users in order with one of their positives each,
     negatives in item order."""

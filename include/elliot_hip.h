@@ -49,7 +49,7 @@ typedef struct el_ctx el_ctx;
                             * 7: el_bprmf_state ends in replay_series; el_ctx_set_option / el_ctx_get_option (the library no
                             *    longer reads the environment after el_ctx_create); el_graph_csr, el_spmm_csr_f32,
                             *    el_lightgcn_propagate; el_ngcf_*; el_mf2020_train; el_bprmf_ws_bytes / el_cml_ws_bytes take F, el_bprmf_deterministic
-                            * 8: el_nmf_state ends in step_ws / step_ws_bytes (el_nmf_step_ws_bytes): the NeuMF / GMF step walks its embedding rows
+                            * 8: el_nmf_state ends in step_ws / step_ws_bytes (el_nmf_step_ws_bytes) + the el_nmf_presort bookkeeping: the NeuMF / GMF step walks its embedding rows
                             *    as sorted segments and sums every batch reduction in a fixed order (no float atomics); training
                             *    calls REQUIRE the workspace; row_stamp / row_own / claim_seq are no longer read              */
 
@@ -584,10 +584,18 @@ typedef struct el_nmf_state {
      * + Adam the other), and every reduction over the batch (embedding rows, Dense biases, head weights, loss) is added in a fixed
      * order -- two runs from the same state give the same bits.                                                              */
     void* step_ws; size_t step_ws_bytes;
+    /* el_nmf_presort bookkeeping (zero at creation; maintained by the library): the batch whose keys are ordered ahead, and which of
+     * the workspace's two sort sets the current step uses */
+    const int32_t* pre_u; const int32_t* pre_i; int64_t pre_n; int32_t sort_set;
 } el_nmf_state;
 
 /* Bytes of el_nmf_state.step_ws for the state's shape (U, I, Bmax, F, E, n_layers, units, use_mf, use_mlp must be filled in). */
 size_t el_nmf_step_ws_bytes(el_ctx* ctx, const el_nmf_state* st);
+
+/* Orders the (embedding row, sample) keys of the batch (u, i) AHEAD of its step (the sort reads u and i only): call it on another
+ * stream while the previous step trains; the el_nmf_train_step / el_nmf_grads that follows with the same u, i, n -- arrays unchanged
+ * in between, this call complete before the step in stream order (the caller's event) -- skips its own sort.  One batch pending. */
+int el_nmf_presort(el_ctx* ctx, void* stream, el_nmf_state* st, const int32_t* u, const int32_t* i, int64_t n);
 
 /* Replaces: pointwise_pos_neg_sampler.Sampler.step (dataset/samplers/pointwise_pos_neg_sampler.py:26-50):
  * u uniform, fair coin, positive item of u (label 1) or rejected-uniform negative (label 0); Philox stream. */

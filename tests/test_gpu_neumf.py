@@ -383,6 +383,8 @@ def test_the_step_is_deterministic_and_its_forms_agree_bit_for_bit(ctx, lib_opti
         batches.append(tuple(torch.from_numpy(a).to(d) for a in (u, i, y)))
     assert max(np.bincount(cpu(b[1])).max() for b in batches) > 200      # the long-segment kernel runs
 
+    side = torch.cuda.Stream(device=d)
+
     def run(form):
         st = ops.NmfDeviceState(ctx, w0, max_batch=B, deferred=(form != "eager"))
         losses = []
@@ -390,6 +392,12 @@ def test_the_step_is_deterministic_and_its_forms_agree_bit_for_bit(ctx, lib_opti
             if form == "two_pass":
                 st.grads(u, i, y)
                 st.apply(lr)
+            elif form == "presort":                                   # keys ordered ahead of the step on another stream (el_nmf_presort)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    st.presort(u, i)
+                torch.cuda.current_stream().wait_stream(side)
+                st.train_step(u, i, y, lr)
             else:
                 st.train_step(u, i, y, lr)
             losses.append(st.pop_loss())
@@ -401,7 +409,7 @@ def test_the_step_is_deterministic_and_its_forms_agree_bit_for_bit(ctx, lib_opti
 
     a, la = run("fused")
     assert np.isfinite(la).all()
-    for form in ("fused", "two_pass", "eager"):
+    for form in ("fused", "two_pass", "eager", "presort"):
         b, lb = run(form)
         assert la == lb, (form, [k for k in range(steps) if la[k] != lb[k]][:5])
         for k in a:
