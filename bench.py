@@ -112,6 +112,7 @@ def parse():
                          "kernels and optimiser pass run (default: pipelined, 1.47 -> 1.41 ms per step; same kernels, same results)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N > 1 code path even with one rank (API check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--neumf-prefetch", action="store_true", help="NeuMF leg: sampler + el_nmf_presort of the next batch on a side stream (measured slower: off)")
     ap.add_argument("--trained-epochs", type=float, default=1.0, help="N = 1: epochs of further training before the top-k block is timed a second "
                                                                      "time on trained tables (0: skip)")
     ap.add_argument("--neumf-trained-steps", type=int, default=3000, help="neumf leg: further training steps before its scoring step is timed a "
@@ -1097,9 +1098,11 @@ def neumf_leg(args, ctx):
     del w
     it = [0]
 
-    # the sampler never reads the model (pointwise_pos_neg_sampler.py:26-50): batch t+1 is drawn, and its (embedding row, sample) keys
-    # ordered (el_nmf_presort), on a side stream under step t -- elliot_amd/pipeline.py, as for the BPR leg
-    pipe = PrefetchPointwise(ctx, pos, B, seed=3, enabled=not getattr(args, "no_prefetch", False), presort_state=st)
+    # the sampler never reads the model (pointwise_pos_neg_sampler.py:26-50): batch t+1 COULD be drawn, and its (embedding row, sample)
+    # keys ordered (el_nmf_presort), on a side stream under step t as in the BPR leg (elliot_amd/pipeline.py: --neumf-prefetch).
+    # Measured and OFF: the sort's dozen small kernels land between the tower's products, whose grids are sized to the machine, and
+    # cost them a second round of workgroups -- 5.13 -> 6.5 ms per step (scripts/exp/nmf_ab.sh); the step draws and sorts in line
+    pipe = PrefetchPointwise(ctx, pos, B, seed=3, enabled=bool(getattr(args, "neumf_prefetch", False)), presort_state=st)
 
     def step():
         (u, i, y), b = pipe.next()

@@ -1,9 +1,9 @@
 #!/bin/bash
-# The NeuMF leg of the bench with its per-kernel breakdown.  usage (on the GPU box): scripts/exp/nmf_ab.sh "name|ENV=.." ...
+# The NeuMF leg of the bench with its per-kernel breakdown.  usage (on the GPU box): scripts/exp/nmf_ab.sh "name|ENV=..[|extra bench args]" ...
 mkdir -p gpurun_out
 for spec in "$@"; do
-  name=${spec%%|*}; envs=${spec#*|}
-  env $envs python bench.py --legs neumf --no-cpu-baseline --neumf-trained-steps 0 --legs-file gpurun_out/nmf_$name.json > gpurun_out/nmf_$name.line 2> gpurun_out/nmf_$name.err
+  name=${spec%%|*}; rest=${spec#*|}; envs=${rest%%|*}; extra=""; [[ "$rest" == *"|"* ]] && extra=${rest#*|}
+  env $envs python bench.py $extra --legs neumf --no-cpu-baseline --neumf-trained-steps 0 --legs-file gpurun_out/nmf_$name.json > gpurun_out/nmf_$name.line 2> gpurun_out/nmf_$name.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/nmf_$name.json"))
