@@ -24,6 +24,7 @@ struct el_options {
     double gemm_split = 1;           // dense products >= 2 GFLOP on the three-plane bf16 kernel (0: the fp32 matrix instruction)
     double gemm_xcd = 1;             // XCD-aware tile order of that kernel
     double nmf_side = 1;             // NeuMF: weight-gradient products on the library's second stream
+    double nmf_head4 = 1;            // NeuMF head: four samples per wave where the rows are 16-byte aligned (0: one sample per wave)
     double vae_side = 1;             // Mult-VAE: the same
     double nmf_screen_maxfrac = 0.5; // NeuMF scoring: the screen is kept when it leaves the exact kernel at most this share of the pairs
     double screen_stride = 0;        // screened top-k: catalogue stride of the first pass (0: by catalogue size)

@@ -24,7 +24,7 @@ struct el_opt_entry {
 };
 static const el_opt_entry g_el_opts[] = {
     {"ichunk", &el_options::ichunk}, {"uchunk", &el_options::uchunk}, {"loop_graph", &el_options::loop_graph},
-    {"gemm_split", &el_options::gemm_split}, {"gemm_xcd", &el_options::gemm_xcd}, {"nmf_side", &el_options::nmf_side},
+    {"gemm_split", &el_options::gemm_split}, {"gemm_xcd", &el_options::gemm_xcd}, {"nmf_side", &el_options::nmf_side}, {"nmf_head4", &el_options::nmf_head4},
     {"vae_side", &el_options::vae_side}, {"nmf_screen_maxfrac", &el_options::nmf_screen_maxfrac},
     {"screen_stride", &el_options::screen_stride}, {"screen_ka", &el_options::screen_ka},
     {"screen_prof", &el_options::screen_prof},

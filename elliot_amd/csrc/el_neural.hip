@@ -252,6 +252,108 @@ __global__ __launch_bounds__(256) void k_nmf_head(el_nmf_state st, const float* 
     }
 }
 
+// The same head with FOUR samples per wave (16 lanes each; lane `sub` holds the float4 chunks sub + 16 q of the sample's F + Hl
+// features): the reduction over a sample's features is four row operations instead of six, and the exp / log / division chain of the
+// loss runs once per wave-instruction for four samples -- the one-sample form issues ~85 instructions per sample and is bound by
+// instruction issue (0.21 ms at B = 262 144, eight waves per SIMD), this one ~35.  Needs F % 4 == 0 and Hl % 4 == 0 (16-byte chunks that
+// do not straddle the MF / MLP boundary); summation orders differ from the one-sample form (results at fp32 rounding level).
+template <int Q4>
+__global__ __launch_bounds__(256) void k_nmf_head4(el_nmf_state st, const float* __restrict__ label, int64_t n, int mode,
+                                                   float* out_prob, int64_t n_div, const float* __restrict__ mfu,
+                                                   const float* __restrict__ mfi, float* __restrict__ part, double* __restrict__ ploss) {
+    __shared__ float wsum[4], bsum[4];
+    __shared__ float facc[4][64 * Q4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, grp = lane >> 4;
+    const int F = st.use_mf ? st.F : 0;
+    const int Hl = st.use_mlp ? st.units[st.n_layers - 1] : 0;
+    const int NF = F + Hl;
+    const float hbias = st.head_bias ? st.hb[0] : 0.f;
+    const float* act_last = st.use_mlp ? st.act[st.n_layers - 1] : nullptr;
+    float* dact_last = st.use_mlp ? st.dact[st.n_layers - 1] : nullptr;
+    float4 acc[Q4], hwr[Q4];
+#pragma unroll
+    for (int q = 0; q < Q4; ++q) {
+        acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int f = (sub + 16 * q) * 4;
+        hwr[q] = f < NF ? *reinterpret_cast<const float4*>(st.hw + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto fetch = [&](int64_t b, float4 (&v)[Q4]) {
+#pragma unroll
+        for (int q = 0; q < Q4; ++q) {
+            const int f = (sub + 16 * q) * 4;
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < F) {
+                if (mfu) {
+                    const float4 a = *reinterpret_cast<const float4*>(mfu + b * F + f), c = *reinterpret_cast<const float4*>(mfi + b * F + f);
+                    v[q] = make_float4(a.x * c.x, a.y * c.y, a.z * c.z, a.w * c.w);
+                } else v[q] = *reinterpret_cast<const float4*>(st.MF + b * F + f);
+            } else if (f < NF) v[q] = *reinterpret_cast<const float4*>(act_last + b * (int64_t)Hl + (f - F));
+        }
+    };
+    float bacc = 0.f, myloss = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    int64_t b = ((int64_t)blockIdx.x * 4 + wv) * 4 + grp;
+    float4 nxt[Q4];
+    if (b < n) fetch(b, nxt);
+    for (; b < n; b += stride) {
+        float4 val[Q4];
+#pragma unroll
+        for (int q = 0; q < Q4; ++q) val[q] = nxt[q];
+        if (b + stride < n) fetch(b + stride, nxt);
+        float pr = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q4; ++q) pr += (val[q].x * hwr[q].x + val[q].y * hwr[q].y) + (val[q].z * hwr[q].z + val[q].w * hwr[q].w);
+        const float logit = el_group_sum(pr, 16) + hbias;
+        const float p = 1.0f / (1.0f + expf(-logit));
+        if (mode == 0) {
+            if (sub == 0) out_prob[b] = p;
+            continue;
+        }
+        const float t = label[b];
+        // K.binary_crossentropy (oracle/tf_clauses.py): the probability clipped to [1e-7, 1 - 1e-7], epsilon added again inside both logarithms
+        const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);
+        if (sub == 0) myloss += -(t * logf(pc + 1e-7f) + (1.0f - t) * logf((1.0f - pc) + 1e-7f)) / (float)n_div;
+        float dlogit = 0.f;                                             // d/dlogit: zero where the clip is active
+        if (p > 1e-7f && p < 1.0f - 1e-7f) {
+            const float dp = -(t / (p + 1e-7f) - (1.0f - t) / ((1.0f - p) + 1e-7f));
+            dlogit = dp * (p * (1.0f - p)) / (float)n_div;
+        }
+        if (sub == 0) st.dlogit[b] = dlogit, bacc += dlogit;
+#pragma unroll
+        for (int q = 0; q < Q4; ++q) {
+            acc[q].x += dlogit * val[q].x, acc[q].y += dlogit * val[q].y, acc[q].z += dlogit * val[q].z, acc[q].w += dlogit * val[q].w;
+            const int f = (sub + 16 * q) * 4;
+            if (f >= F && f < NF)                                       // the last Dense(relu) layer's pre-activation gradient (its ReLU derivative here)
+                *reinterpret_cast<float4*>(dact_last + b * (int64_t)Hl + (f - F)) =
+                    make_float4(val[q].x > 0.f ? dlogit * hwr[q].x : 0.f, val[q].y > 0.f ? dlogit * hwr[q].y : 0.f,
+                                val[q].z > 0.f ? dlogit * hwr[q].z : 0.f, val[q].w > 0.f ? dlogit * hwr[q].w : 0.f);
+        }
+    }
+    if (mode == 0) return;
+    // the four lane groups of a wave (different samples, same features) in a fixed order, then the four waves through LDS
+#pragma unroll
+    for (int q = 0; q < Q4; ++q) {
+        float* a4 = reinterpret_cast<float*>(&acc[q]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float v = a4[x];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            a4[x] = v;
+        }
+        if (grp == 0) *reinterpret_cast<float4*>(&facc[wv][(sub + 16 * q) * 4]) = acc[q];
+    }
+    float wl = el_group_sum(myloss, 64), wb = el_group_sum(bacc, 64);
+    if (lane == 0) wsum[wv] = wl, bsum[wv] = wb;
+    __syncthreads();
+    float* prow = part + (int64_t)blockIdx.x * (NF + 1);
+    for (int f = threadIdx.x; f < NF; f += 256) prow[f] = (facc[0][f] + facc[1][f]) + (facc[2][f] + facc[3][f]);
+    if (threadIdx.x == 0) {
+        prow[NF] = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
+        ploss[blockIdx.x] = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+    }
+}
+
 // ghw[f] = sum over the workgroups' partial rows (column f), ghb = column NF: el_gemm.hip's ordered column sums with the last column
 // going to its own address
 __global__ __launch_bounds__(1024) void k_nmf_head_finish(const float* __restrict__ part, int P, int NF, float* __restrict__ ghw,
@@ -298,10 +400,32 @@ __global__ __launch_bounds__(64) void k_nmf_loss_finish(const double* __restrict
     }
 }
 
-static void launch_nmf_head(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const float* label, int64_t n, int mode, float* out_prob,
+// returns the number of workgroups launched (= partial rows written in training mode)
+static unsigned launch_nmf_head(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, const float* label, int64_t n, int mode, float* out_prob,
                             int64_t n_div, unsigned grid, const float* mfu, const float* mfi, float* part, double* ploss) {
     const int NF = (st->use_mf ? st->F : 0) + (st->use_mlp ? st->units[st->n_layers - 1] : 0);
     const int nq = (NF + 63) / 64;
+    const int F = st->use_mf ? st->F : 0, Hl = NF - F;
+    const bool al = [&] {                                             // 16-byte chunks: every row of every source starts aligned
+        auto ok = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        if (F % 4 || Hl % 4 || !ok(st->hw)) return false;
+        if (F && !(mfu ? ok(mfu) && ok(mfi) : ok(st->MF))) return false;
+        if (Hl && !(ok(st->act[st->n_layers - 1]) && (mode == 0 || ok(st->dact[st->n_layers - 1])))) return false;
+        return true;
+    }();
+    if (al && ctx->opt.nmf_head4 != 0) {
+        unsigned g4 = (unsigned)((n + 15) / 16);
+        if (g4 > grid) g4 = grid;
+        if (g4 < 1) g4 = 1;
+#define EL_HEAD4(Q_) EL_LAUNCH("k_nmf_head", k_nmf_head4<Q_>, dim3(g4), dim3(256), 0, s, *st, label, n, mode, out_prob, n_div, mfu, mfi, part, ploss)
+        if (nq <= 1) EL_HEAD4(1);
+        else if (nq <= 2) EL_HEAD4(2);
+        else if (nq <= 4) EL_HEAD4(4);
+        else if (nq <= 8) EL_HEAD4(8);
+        else EL_HEAD4(16);
+#undef EL_HEAD4
+        return g4;
+    }
 #define EL_HEAD(Q_) EL_LAUNCH("k_nmf_head", k_nmf_head<Q_>, dim3(grid), dim3(256), 0, s, *st, label, n, mode, out_prob, n_div, mfu, mfi, part, ploss)
     if (nq <= 1) EL_HEAD(1);
     else if (nq <= 2) EL_HEAD(2);
@@ -309,7 +433,7 @@ static void launch_nmf_head(el_ctx* ctx, hipStream_t s, const el_nmf_state* st, 
     else if (nq <= 8) EL_HEAD(8);
     else EL_HEAD(16);
 #undef EL_HEAD
-    (void)ctx;
+    return grid;
 }
 
 // in place: d <- d * (y > 0)   (relu backward)
@@ -1297,8 +1421,7 @@ static int nmf_grads(el_ctx* ctx, hipStream_t s, el_nmf_state* st, const int32_t
     if (int rc = nmf_forward(ctx, s, st, u, i, n, true, &sg)) return rc;
     // the head leaves dact[last] = d loss / d pre-activation of the last layer (its ReLU derivative applied where the output row is
     // in registers anyway); the layers below take theirs in k_relu_bwd_colsum together with the bias gradient
-    const unsigned hg = head_grid(n, ctx);
-    launch_nmf_head(ctx, s, st, label, n, 1, nullptr, n_div, hg, w.mfp[0], w.mfp[1], w.hpart, w.hloss);
+    const unsigned hg = launch_nmf_head(ctx, s, st, label, n, 1, nullptr, n_div, head_grid(n, ctx), w.mfp[0], w.mfp[1], w.hpart, w.hloss);
     {   // the workgroups' partial rows, added in order: head weights; the bias gradient is column F + Hl of the same rows
         EL_LAUNCH("k_nmf_head_finish", k_nmf_head_finish, dim3((unsigned)((F + Hl + 1 + 15) / 16)), dim3(1024), 0, s, w.hpart, (int)hg, F + Hl, st->ghw,
                   st->head_bias ? st->ghb : nullptr);

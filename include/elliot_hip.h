@@ -78,7 +78,7 @@ int el_timing_filter(el_ctx* ctx, const char* kernel_name);
  * lists the product launches and the tuner's probes separately. */
 int el_tuning_mode(el_ctx* ctx, int on);
 /* Switches of the library (ABI 7).  Each has a name ("ichunk", "uchunk", "loop_graph", "gemm_split", "gemm_xcd", "nmf_side",
- * "vae_side", "nmf_screen_maxfrac", "screen_stride", "screen_ka", "screen_prof"); el_ctx_create takes its initial
+ * "nmf_head4", "vae_side", "nmf_screen_maxfrac", "screen_stride", "screen_ka", "screen_prof"); el_ctx_create takes its initial
  * value from the environment variable EL_<NAME IN CAPITALS> when that is set, and that is the only time the library reads the
  * environment: afterwards a switch moves through el_ctx_set_option alone (per context: two contexts of one process may differ).
  * Unknown names fail.  The reference has no counterpart (its switches are YAML fields read by the Python layer).              */

@@ -414,3 +414,41 @@ def test_the_step_is_deterministic_and_its_forms_agree_bit_for_bit(ctx, lib_opti
         assert la == lb, (form, [k for k in range(steps) if la[k] != lb[k]][:5])
         for k in a:
             assert np.array_equal(a[k], b[k]), (form, k, int((a[k] != b[k]).sum()), float(np.abs(a[k] - b[k]).max()))
+
+
+@pytest.mark.parametrize("model,F", [("neumf", 32), ("gmf", 64), ("neumf", 128)])
+def test_the_four_samples_per_wave_head_agrees_with_the_one_sample_form(ctx, lib_option, model, F):
+    """k_nmf_head4 (16 lanes per sample, option nmf_head4 = 1, the default where the rows are 16-byte aligned) against k_nmf_head: the
+    two order the feature sums differently, so probabilities, the loss and every gradient agree at fp32 rounding level, not bit for bit;
+    a batch that is no multiple of 16 and one smaller than a workgroup's share are in."""
+    U, I = 3000, 2000
+    units = [4 * F, 2 * F, F]
+    w0 = on.init_neumf(U, I, F, 5, units=units) if model == "neumf" else on.init_gmf(U, I, F, 5)
+    d = ctx.device
+    rs = np.random.RandomState(2)
+    out = {}
+    for h4 in (1, 0):
+        lib_option("nmf_head4", h4)
+        st = ops.NmfDeviceState(ctx, w0, max_batch=5000, deferred=False)
+        res = []
+        for n in (5000, 4099, 7):
+            u = torch.from_numpy(rs.randint(0, U, n).astype(np.int32)).to(d)
+            i = torch.from_numpy(rs.randint(0, I, n).astype(np.int32)).to(d)
+            y = torch.from_numpy(rs.randint(0, 2, n).astype(np.float32)).to(d)
+            p = cpu(st.forward(u, i))
+            st.grads(u, i, y)
+            res.append((p, st.pop_loss(), cpu(st.ghw), cpu(st.ghb) if st.head_bias else None, cpu(st.dlogit[:n]),
+                        [cpu(g) for g in st.gW], cpu(st.gtab[0]) if st.gtab[0] is not None else None))
+            st.apply(0.001)
+        out[h4] = res
+        rs = np.random.RandomState(2)
+    for a, b in zip(out[1], out[0]):
+        assert np.abs(a[0] - b[0]).max() < 2e-6
+        assert abs(a[1] - b[1]) <= 2e-6 * max(abs(b[1]), 1e-3)
+        for x, y in ((a[2], b[2]), (a[3], b[3]), (a[4], b[4]), (a[6], b[6])):
+            if x is not None:
+                sc = max(float(np.abs(y).max()), 1e-12)
+                assert np.abs(x - y).max() <= 2e-5 * sc, float(np.abs(x - y).max() / sc)
+        for x, y in zip(a[5], b[5]):
+            sc = max(float(np.abs(y).max()), 1e-12)
+            assert np.abs(x - y).max() <= 5e-5 * sc
