@@ -1094,7 +1094,7 @@ def neumf_leg(args, ctx):
         w["b"].append(torch.zeros(n_out, device=dev))
         kin = n_out
     w["hw"], w["hb"] = gu(F + units[-1], 1)[:, 0].contiguous(), torch.zeros(1, device=dev)
-    st = ops.NmfDeviceState(ctx, w, max_batch=B)
+    st = ops.NmfDeviceState(ctx, w, max_batch=B, replay=getattr(args, "replay", "series"))
     del w
     it = [0]
 
@@ -1203,8 +1203,9 @@ def neumf_leg(args, ctx):
             "workload": f"NeuMF d={F} (GMF + MLP {units}), {U} users x {I} items = the per-GPU shape of BASELINE configs[3] (10M x 1M over "
                         f"8 GPUs) under user sharding, batch {B}, point-wise sampler on the device, Adam (Keras semantics: every row of "
                         f"the four embedding tables moves at every step"
-                        + (f"; rows without a gradient are replayed bit for bit when next needed, the {K}-step region ends with the replay of "
-                           f"all of them)" if st.deferred else ", one dense pass per table and step)"),
+                        + (f"; rows without a gradient are brought forward when next needed ({'in closed form: el_nmf_state.replay_series' if st.replay == 'series' else 'replayed bit for bit'}), "
+                           f"the {K}-step region ends with the replay of all of them)" if st.deferred else ", one dense pass per table and step)"),
+            "replay": st.replay,
             "loss_mean": loss / max(rep.calls, 1), "repeats_ms_per_step": rep.repeats_ms,
             **({"topk": tk} if tk is not None else {}),
             "roofline": {**groof, "traffic": ntraffic.get("k_gemm_per_step", ntraffic.get("k_gemm_f32_per_step")),
@@ -1393,7 +1394,7 @@ def compact_line(full):
     if "neumf" in full:
         n = full["neumf"]
         nt = n.get("topk") or {}
-        legs["neumf"] = {"samples_per_s": n.get("value"), "ms_per_step": n.get("ms_per_step"),
+        legs["neumf"] = {"samples_per_s": n.get("value"), "ms_per_step": n.get("ms_per_step"), "replay": n.get("replay"),
                          "roofline": _roof(n.get("roofline"), ("gemm_ms_per_step",)),
                          "topk": {"users_per_s": nt.get("value"), "ms_per_step": nt.get("ms_per_step"),
                                   "roofline": _roof(nt.get("roofline")), "survivor_frac": (nt.get("screen") or {}).get("exact_pairs_frac"),

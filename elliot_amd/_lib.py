@@ -96,6 +96,7 @@ class NmfState(C.Structure):
         ("batch_u", C.c_void_p), ("batch_i", C.c_void_p), ("batch_n", C.c_int64),
         ("step_ws", C.c_void_p), ("step_ws_bytes", C.c_size_t),
         ("pre_u", C.c_void_p), ("pre_i", C.c_void_p), ("pre_n", C.c_int64), ("sort_set", C.c_int32),
+        ("replay_series", C.c_int32),
     ]
 
 

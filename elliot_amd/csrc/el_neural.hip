@@ -656,10 +656,27 @@ __device__ __forceinline__ void nmf_rows_store(const float (&val)[2][Q][VW], flo
         }
 }
 
-// nsteps gradient-free steps on the registers (theta too when WITH_TH): exactly el_adam_elem with g = 0
+// nsteps gradient-free steps on the registers (theta too when WITH_TH): exactly el_adam_elem with g = 0 -- or, ser (el_nmf_state.
+// replay_series), in closed form from four row-level sums over the lr_t history (el_common.h: el_adam_series_*; O(1) per element
+// whatever the gap, as close to the exact recurrence as the step-by-step fp32 form, not its bits)
 template <int VW, int Q, bool WITH_TH>
-__device__ __forceinline__ void nmf_rows_replay(NmfRowRegs<VW, Q>& r, const float* __restrict__ lr_from, int nsteps) {
+__device__ __forceinline__ void nmf_rows_replay(NmfRowRegs<VW, Q>& r, const float* __restrict__ lr_from, int nsteps, bool ser = false) {
     const float b1 = 0.9f, b2 = 0.999f, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    if (ser) {
+        if (nsteps <= 0) return;
+        const el_series sr = el_adam_series_sums(nsteps, [&](int s) { return lr_from[s]; });
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (WITH_TH) el_adam_series_apply<VW>(r.a[k][q], r.m[k][q], r.v[k][q], sr);
+                else {
+#pragma unroll
+                    for (int x = 0; x < VW; ++x) r.m[k][q][x] = r.m[k][q][x] * sr.p1, r.v[k][q][x] = r.v[k][q][x] * sr.p2;
+                }
+            }
+        return;
+    }
     if (WITH_TH) {
         // (el_common.h: the step on packed fp32 instructions where the values allow it, el_adam_elem otherwise -- the same bits;
         // the element groups are independent, so each runs its own loop over the steps)
@@ -699,7 +716,7 @@ __device__ __forceinline__ void nmf_row_flush(const el_nmf_state& st, const NmfR
 #pragma unroll
             for (int x = 0; x < VW; ++x) nz = nz || r.m[k][0][x] != 0.f || r.v[k][0][x] != 0.f;
         if (__ballot(nz) == 0ull) continue;
-        nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps);
+        nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps, st.replay_series != 0);
         float* const dth[2] = {rt.th[0], rt.th[1]};
         float* const dm[2] = {rt.m[0], rt.m[1]};
         float* const dv[2] = {rt.v[0], rt.v[1]};
@@ -840,7 +857,7 @@ __global__ __launch_bounds__(256) void k_nmf_seg_fwd(el_nmf_state st, NmfSeg sg)
 #pragma unroll
                 for (int x = 0; x < VW; ++x) nz = nz || r.m[k][0][x] != 0.f || r.v[k][0][x] != 0.f;
             if (__ballot(nz) != 0ull) {
-                nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps);
+                nmf_rows_replay<VW, 1, true>(r, lr_from, nsteps, st.replay_series != 0);
                 fresh = true;
             }
         } else if (!DEFER) {
@@ -965,7 +982,7 @@ __device__ __forceinline__ void nmf_seg_finish(const el_nmf_state& st, const Nmf
         nmf_rows_store<VW, 1>(g, dg, rt, row, f0, lane);
         return;
     }
-    nmf_rows_replay<VW, 1, false>(r, lr_from, nsteps);
+    nmf_rows_replay<VW, 1, false>(r, lr_from, nsteps, st.replay_series != 0);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll

@@ -1429,12 +1429,15 @@ class NmfDeviceState:
 
     _LR_HIST = 1 << 16          # optimiser steps of lr_t history kept on the device by the deferred decay
 
-    def __init__(self, ctx, weights, max_batch, dropout=0.0, dropout_seed=42, deferred=None):
+    def __init__(self, ctx, weights, max_batch, dropout=0.0, dropout_seed=42, deferred=None, replay="exact"):
         """deferred: Keras' every-row Adam decay of the embedding tables is postponed per row and replayed bit for bit when the
         row is next needed (include/elliot_hip.h, el_nmf_state.row_last).  None = on; a data-parallel
         owner that all-reduces gtab of replicated tables turns it off (set_deferred(False); parallel.ShardedNmf does)."""
         self.ctx = ctx
         dev = ctx.device
+        if replay not in ("exact", "series"):
+            raise ValueError("replay must be 'exact' or 'series'")
+        self.replay = replay                                         # how waiting rows are brought forward (BprmfDeviceState: the same two modes)
         self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
         self.deferred = True if deferred is None else bool(deferred)
         f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) if isinstance(x, np.ndarray) \
@@ -1495,6 +1498,7 @@ class NmfDeviceState:
             dropout=self.dropout, drop_step=0, drop_seed=self.dropout_seed & 0xFFFFFFFFFFFFFFFF)
         self._drop_calls = 0
         self._c.hist_base = 1
+        self._c.replay_series = int(replay == "series")
         self._alloc_step_ws()
         if self.deferred:
             self._alloc_deferred()

@@ -587,6 +587,9 @@ typedef struct el_nmf_state {
     /* el_nmf_presort bookkeeping (zero at creation; maintained by the library): the batch whose keys are ordered ahead, and which of
      * the workspace's two sort sets the current step uses */
     const int32_t* pre_u; const int32_t* pre_i; int64_t pre_n; int32_t sort_set;
+    /* Deferred decay only: 0 = waiting rows are replayed step by step (the bits of Keras' every-row update); 1 = in closed form from
+     * four row-level sums over the lr_t history, O(1) per element (as el_bprmf_state.replay_series: inside the parity tolerances). */
+    int32_t replay_series;
 } el_nmf_state;
 
 /* Bytes of el_nmf_state.step_ws for the state's shape (U, I, Bmax, F, E, n_layers, units, use_mf, use_mlp must be filled in). */

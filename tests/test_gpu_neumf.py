@@ -452,3 +452,49 @@ def test_the_four_samples_per_wave_head_agrees_with_the_one_sample_form(ctx, lib
         for x, y in zip(a[5], b[5]):
             sc = max(float(np.abs(y).max()), 1e-12)
             assert np.abs(x - y).max() <= 5e-5 * sc
+
+
+@pytest.mark.parametrize("model,F", [("neumf", 64), ("gmf", 32), ("neumf", 33)])
+def test_series_replay_of_the_embedding_rows_stays_at_rounding_level(ctx, model, F):
+    """el_nmf_state.replay_series: waiting embedding rows brought forward in closed form (four row-level sums over the lr_t history, O(1) per
+    element) against the step-by-step replay -- which is bit-identical to the eager every-row Adam (test above).  40 steps in which most
+    users wait several steps between two of their batches and 10 % of the items never appear: losses agree to 1e-5, the embedding tables
+    and their Adam slots to 1e-4 of the table's scale on all but 1e-4 of the elements (median below 1e-6): fp32 rounding, amplified by
+    Adam like any other reordering -- not a different trajectory."""
+    U, I, B, lr, steps = 5000, 3000, 1024, 0.003, 40
+    units = [4 * F, 2 * F, F] if F != 33 else [64, 32, 16]
+    w0 = on.init_neumf(U, I, F, 4, units=units) if model == "neumf" else on.init_gmf(U, I, F, 4)
+    d = ctx.device
+    rs = np.random.RandomState(12)
+    batches = []
+    for s in range(steps):
+        u = rs.randint(0, U // 2 if s % 3 else U, B).astype(np.int32)
+        i = (rs.zipf(1.3, B) % (I - I // 10)).astype(np.int32)
+        y = rs.randint(0, 2, B).astype(np.float32)
+        batches.append(tuple(torch.from_numpy(a).to(d) for a in (u, i, y)))
+    res = {}
+    for mode in ("exact", "series"):
+        st = ops.NmfDeviceState(ctx, w0, max_batch=B, deferred=True, replay=mode)
+        losses = []
+        for k, (u, i, y) in enumerate(batches):
+            st.train_step(u, i, y, lr)
+            losses.append(st.pop_loss())
+            if k == 17:
+                st.sync()                                            # a flush in the middle (k_nmf_flush_rows takes the same mode)
+        w = _flat_weights(st.weights())
+        for t, nm in enumerate(("Umf", "Imf", "Umlp", "Imlp")):
+            if st.mtab[t] is not None:
+                w["m_" + nm], w["v_" + nm] = cpu(st.mtab[t]), cpu(st.vtab[t])
+        res[mode] = (w, losses)
+    (wa, la), (wb, lb) = res["exact"], res["series"]
+    assert np.allclose(la, lb, rtol=1e-5, atol=1e-7), float(np.abs(np.array(la) - np.array(lb)).max())
+    moved = False
+    for k in wa:
+        sc = max(float(np.abs(wa[k]).max()), 1e-12)
+        rel = np.abs(wa[k] - wb[k]) / sc
+        if rel.size >= 1000:
+            assert (rel > 1e-4).mean() < 1e-4 and np.median(rel) < 1e-6, (k, float(rel.max()), float((rel > 1e-4).mean()), float(np.median(rel)))
+        else:
+            assert rel.max() < 1e-4, (k, float(rel.max()))            # (biases, the head: a handful of elements)
+        moved = moved or bool((wa[k] != wb[k]).any())
+    assert moved                                                     # (the two modes are different arithmetic: identical bits would mean the switch is dead)
