@@ -23,7 +23,6 @@ extern "C" int el_gemm_f32(el_ctx* ctx, void* stream, int transA, int transB, in
 __global__ void k_adam_dense(float* th, float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps);
 __global__ void k_adam_apply_dense(float* th, float* g, float* m, float* v, int64_t n, float alpha, float b1, float b2,
                                    float eps, int zero_g);
-__global__ void k_colsum(const float* X, int64_t B, int64_t N, int64_t ld, float* out);
 
 // ---- point-wise sampler (GMF) --------------------------------------------------------------------------
 struct PwPhilox {

@@ -386,17 +386,6 @@ __global__ __launch_bounds__(256) void k_tanh_bwd(float* __restrict__ d, const f
     }
 }
 
-// out[n] += sum over a 32-row slab of X[b, n]   (out zeroed by the caller; grid.y = ceil(B/32))
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t B, int64_t N, int64_t ld,
-                                                float* __restrict__ out) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int64_t b0 = (int64_t)blockIdx.y * 32;
-    const int64_t b1 = (b0 + 32 < B) ? b0 + 32 : B;
-    float s = 0.f;
-    for (int64_t b = b0; b < b1; ++b) s += X[b * ld + n];
-    atomicAdd(out + n, s);
-}
 
 // ---- row-wise log-softmax / multinomial NLL / gradient ---------------------------------------------------
 // One workgroup per batch row over logits[b, 0..I).
@@ -547,10 +536,11 @@ static int vae_check(const el_vae_state* st, int64_t B) {
         else EL_LAUNCH(#KERN, (KERN<4>), dim3(g), dim3(ENC_NW * 64), lds, s, __VA_ARGS__);              \
     } while (0)
 
+// out[n] = sum_b X[b, n] in a FIXED order (el_gemm.hip: el_colsum_finish -- 16 columns x 64 contiguous row shares per workgroup, the
+// shares added in ascending order): the bias gradients carried the last float atomics of the step's variables (k_colsum added 32-row
+// slabs in whatever order they finished)
 static int colsum(hipStream_t s, const float* X, int64_t B, int64_t N, float* out) {
-    EL_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)N * 4, s));
-    EL_LAUNCH("k_colsum", k_colsum, dim3((unsigned)((N + 255) / 256), (unsigned)((B + 31) / 32)), dim3(256), 0, s, X, B, N, N, out);
-    return 0;
+    return el_colsum_finish(s, X, (int)B, N, out);
 }
 
 static int vae_forward(el_ctx* ctx, hipStream_t s, const el_vae_state* st, const int64_t* indptr, const int32_t* indices,

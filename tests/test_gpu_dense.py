@@ -265,3 +265,41 @@ def test_vae_step_at_the_ml20m_shape_matches_oracle(ctx):
         for k in ov.NAMES:
             err = np.abs(gw[k] - orc.w[k])
             assert (err > 2e-5).mean() < 2e-3 and err.max() < 5 * lr, (s, k, float(err.max()), float((err > 2e-5).mean()))
+
+
+@pytest.mark.parametrize("split", [1, 0])
+def test_the_vae_step_leaves_the_same_bits_on_every_run(ctx, lib_option, split):
+    """Every variable of the Mult-VAE step without float atomics: the first layer's gradient is built from sorted (item, row) lists, the
+    split-K products add their partials in a fixed order, and the bias gradients -- the last atomics of the step's variables -- are
+    column sums in a fixed order (el_colsum_finish).  30 steps twice from the same state, with the backward pass on two streams: all ten
+    variables and their Adam slots bit-identical.  (The scalar loss still collects its per-workgroup shares with a double-precision
+    atomic: it may differ in its last bits.)"""
+    lib_option("gemm_split", split)
+    rs = np.random.RandomState(5)
+    U, I, H, L, B = 2000, 5000, 128, 32, 512
+    X = (rs.rand(U, I) < 0.01).astype(np.float32)
+    X[np.arange(U), rs.randint(0, I, U)] = 1.0
+    m = sp.csr_matrix(X)
+    m.sort_indices()
+    w0 = ov.init_weights(I, H, L, 7)
+    d = ctx.device
+    csr = ops.DeviceCSR(m.indptr, m.indices, I, d)
+    steps = [(torch.from_numpy(rs.permutation(U)[:B].astype(np.int32)).to(d), torch.from_numpy(rs.normal(size=(B, L)).astype(np.float32)).to(d))
+             for _ in range(30)]
+
+    def run():
+        st = ops.VaeDeviceState(ctx, w0, max_batch=B)
+        losses = []
+        for s, (rows, eps) in enumerate(steps):
+            st.train_step(csr, rows, 0.001, min(0.2, s / 20.0), eps=eps, dropout_rate=0.3, dropout_seed=9)
+            losses.append(st.pop_loss())
+        torch.cuda.synchronize()
+        return st.weights(), [cpu(t) for t in list(st.m) + list(st.v)], losses
+
+    wa, sa, la = run()
+    wb, sb, lb = run()
+    for k in ov.NAMES:
+        assert np.array_equal(wa[k], wb[k]), (k, int((wa[k] != wb[k]).sum()))
+    for a, b in zip(sa, sb):
+        assert np.array_equal(a, b)
+    assert np.allclose(la, lb, rtol=1e-12, atol=0)
