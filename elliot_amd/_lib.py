@@ -240,7 +240,7 @@ PROTOTYPES = {
     "el_cml_prepare_items": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p]),
     "el_cml_rescore": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_int32, _i32p, C.c_int64, C.c_int64, C.c_int32,
                                  C.c_int64, _f32p]),
-    "el_pwmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "el_pwmf_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "el_pwmf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, C.c_int64, _f32p]),
     "el_pwmf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PwmfState), _i32p, _i32p, _f32p, C.c_int64, C.c_int,
                                      C.c_int, C.c_int32, C.c_float, _f64p, C.c_void_p, C.c_size_t]),

@@ -7,12 +7,15 @@
 //   3. k_pw_seg (users) dGu[u] = sum_{b in segment} c_b gamma_i(b) (+ cnt l_w gamma_u),  dBu[u] = sum c_b
 //      k_pw_seg (items) dGi[i] = sum_{b in segment} c_b gamma_u(b) (+ cnt l_w gamma_i),  dBi[i] = sum c_b
 //      Segments are cut into chunks of `chunk` sorted positions per lane group; a segment that lives inside one chunk is
-//      written with plain stores, one that crosses chunk borders (popular items) is combined with a few atomics.
+//      written with plain stores, the pieces of one that crosses chunk borders (popular items) go to partial slots and are added
+//      in a fixed order by k_seg_combine / k_seg_combine_long (el_segcombine.h; round 6: no floating-point atomics -- the same
+//      gradient bits on every run).
 //   4. k_adam_dense / k_adagrad_dense over every variable of the updated side (TF 2.3 sparse-apply semantics).
 // The layout of the work (lane group per row, 16-byte lanes, chunks sized so that >= 16K groups are in flight) is the one
 // measured for the BPR step (el_bpr_sorted.hip); the BPR kernels fuse the forward into the user segments, which a
 // point-wise sample cannot do (its c_b is needed by two different segment owners).
 #include "el_common.h"
+#include "el_segcombine.h"
 #include "el_topk_common.h"
 
 #include <cstdlib>
@@ -158,6 +161,26 @@ struct PwSeg {
     int64_t n;
     int F, chunk, lpt;
     float l_w;
+    // pieces of segments cut by chunk boundaries (el_segcombine.h)
+    float* part;
+    float* part_b;
+    int32_t* split;
+};
+
+// finish of a combined row: the gradient row and its bias part, stored
+struct PwFinish {
+    float* g;
+    float* gb;
+    int F;
+    template <int CPL, int VW>
+    __device__ __forceinline__ void operator()(int64_t row, int sub, int lpt, const float (&gg)[CPL][VW], float b) const {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int e = (sub + q * lpt) * VW;
+            if (e < F) sc_st<VW>(g + row * F + e, gg[q]);
+        }
+        if (sub == 0 && gb) gb[row] = b;
+    }
 };
 
 template <int VW, int CPL>
@@ -175,8 +198,10 @@ __global__ __launch_bounds__(256) void k_pw_seg(PwSeg p) {
     float bacc = 0.f;
     int cnt = 0;
     auto flush = [&](bool ends_inside) {
-        float* g = p.g + cur * F;
         const bool plain = started_inside && ends_inside;
+        // a cut piece: slot 2 grp + 1 when the segment starts in this chunk (the head piece: it lists the row), 2 grp otherwise
+        const int64_t slot = 2 * grp + (started_inside ? 1 : 0);
+        float* g = plain ? p.g + cur * F : p.part + slot * F;
         const float w = (float)cnt * p.l_w;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
@@ -191,19 +216,15 @@ __global__ __launch_bounds__(256) void k_pw_seg(PwSeg p) {
 #pragma unroll
                     for (int x = 0; x < VW; ++x) v[x] += w * r[x];
                 }
-                if (plain) {
-                    pw_st<VW>(g + e, v);
-                } else {
-#pragma unroll
-                    for (int x = 0; x < VW; ++x) atomicAdd(g + e + x, v[x]);
-                }
+                pw_st<VW>(g + e, v);
             }
         }
-        if (sub == 0 && p.gb) {
-            if (plain)
-                p.gb[cur] = bacc;
-            else
-                atomicAdd(p.gb + cur, bacc);
+        if (sub == 0) {
+            if (plain) {
+                if (p.gb) p.gb[cur] = bacc;
+            } else {
+                p.part_b[slot] = bacc;                         // (k_seg_combine finds the head pieces from the keys: no list)
+            }
         }
     };
     // The index chain of a position (sorted key, sample -> coefficient and the other table's row id) is two dependent
@@ -350,9 +371,14 @@ struct PwWs {
     float* coef;
     void* tmp;
     size_t tmp_bytes, total;
+    float *part, *part_b;          // partial rows of cut segments: 2 per lane group of the finer side
+    int32_t *split, *split_long;
 };
 
-int carve(int64_t n, int64_t U, int64_t I, char* base, PwWs* w) {
+int item_chunk(int64_t n);
+int user_chunk(int64_t n);
+
+int carve(int64_t n, int64_t U, int64_t I, int F, char* base, PwWs* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char* p = base ? base + off : nullptr;
@@ -375,6 +401,12 @@ int carve(int64_t n, int64_t U, int64_t I, char* base, PwWs* w) {
     if (t3 > t1) t1 = t3;
     w->tmp_bytes = t1;
     w->tmp = take(w->tmp_bytes);
+    const int cu = user_chunk(n), ci = item_chunk(n);
+    const int64_t groups = (n + (cu < ci ? cu : ci) - 1) / (cu < ci ? cu : ci) + 1;
+    w->part = (float*)take((size_t)2 * groups * (size_t)(F > 0 ? F : 1) * 4);
+    w->part_b = (float*)take((size_t)2 * groups * 4);
+    w->split = (int32_t*)take((size_t)(2 * groups + 4) * 4);
+    w->split_long = (int32_t*)take((size_t)(2 * groups + 4) * 4);
     w->total = off;
     return 0;
 }
@@ -433,14 +465,26 @@ int launch_fwd(PwFwd p, hipStream_t s) {
 }
 
 template <int VW>
-int launch_seg(PwSeg p, const char* nm, hipStream_t s) {
+int launch_seg(PwSeg p, const PwWs& w, const char* nm, hipStream_t s) {
     int cpl = 1;
     p.lpt = el_pick_lpt(p.F, VW, &cpl);
+    p.part = w.part, p.part_b = w.part_b, p.split = w.split;
     const int64_t groups = (p.n + p.chunk - 1) / p.chunk;
     const unsigned grid = (unsigned)((groups * p.lpt + 255) / 256);
-    if (cpl == 1) EL_LAUNCH(nm, (k_pw_seg<VW, 1>), dim3(grid), dim3(256), 0, s, p);
-    else if (cpl == 2) EL_LAUNCH(nm, (k_pw_seg<VW, 2>), dim3(grid), dim3(256), 0, s, p);
-    else EL_LAUNCH(nm, (k_pw_seg<VW, 4>), dim3(grid), dim3(256), 0, s, p);
+    EL_CHECK_HIP(hipMemsetAsync(w.split_long, 0, 4, s));
+    SegParts sp = {p.keys, p.key_off, p.n, p.chunk, p.lpt, p.F, nullptr, w.split_long, w.part, w.part_b};
+    PwFinish fin = {p.g, p.gb, p.F};
+    const unsigned gl = (unsigned)(groups < 1024 ? (groups < 1 ? 1 : groups) : 1024);
+#define EL_PW_SEG(CPL_)                                                                                                \
+    do {                                                                                                               \
+        EL_LAUNCH(nm, (k_pw_seg<VW, CPL_>), dim3(grid), dim3(256), 0, s, p);                                           \
+        EL_LAUNCH("k_seg_combine", (k_seg_combine<VW, CPL_, PwFinish>), dim3(grid), dim3(256), 0, s, sp, fin);         \
+        EL_LAUNCH("k_seg_combine_long", (k_seg_combine_long<VW, CPL_, PwFinish>), dim3(gl), dim3(256), 0, s, sp, fin); \
+    } while (0)
+    if (cpl == 1) EL_PW_SEG(1);
+    else if (cpl == 2) EL_PW_SEG(2);
+    else EL_PW_SEG(4);
+#undef EL_PW_SEG
     EL_CHECK_LAUNCH();
     return 0;
 }
@@ -456,10 +500,10 @@ int apply(el_ctx* ctx, hipStream_t s, int opt, const char* nm, float* th, float*
 
 }  // namespace
 
-extern "C" size_t el_pwmf_ws_bytes(int64_t n, int64_t U, int64_t I) {
+extern "C" size_t el_pwmf_ws_bytes(int64_t n, int64_t U, int64_t I, int32_t F) {
     if (n <= 0) return 0;
     PwWs w;
-    if (carve(n, U, I, nullptr, &w)) return 0;
+    if (carve(n, U, I, F, nullptr, &w)) return 0;
     return w.total;
 }
 
@@ -484,7 +528,7 @@ static int pw_grads(el_ctx* ctx, hipStream_t s, const el_pwmf_state* stp, const 
     EL_REQUIRE(stp->U + stp->I < (1LL << 32), "%s: U + I must fit a 32-bit sort key", who);
     const el_pwmf_state st = *stp;
     PwWs w;
-    EL_REQUIRE(carve(n, st.U, st.I, (char*)ws, &w) == 0, "%s: rocprim size query failed", who);
+    EL_REQUIRE(carve(n, st.U, st.I, st.F, (char*)ws, &w) == 0, "%s: rocprim size query failed", who);
     EL_REQUIRE(ws != nullptr && ws_bytes >= w.total, "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total);
     const bool vec = rows_vec4(st);
 
@@ -511,11 +555,11 @@ static int pw_grads(el_ctx* ctx, hipStream_t s, const el_pwmf_state* stp, const 
     const float l_w = st.kind == EL_PW_LOGISTIC ? st.l_w : 0.f;
     if (do_users) {
         PwSeg p = {w.keyU, 0u, w.valU, w.coef, i, st.Gi, st.Gu, st.gGu, st.gBu, n, st.F, user_chunk(n), 0, l_w};
-        if (int rc = vec ? launch_seg<4>(p, "k_pw_seg_users", s) : launch_seg<1>(p, "k_pw_seg_users", s)) return rc;
+        if (int rc = vec ? launch_seg<4>(p, w, "k_pw_seg_users", s) : launch_seg<1>(p, w, "k_pw_seg_users", s)) return rc;
     }
     if (do_items) {
         PwSeg p = {w.keyI, (u32)st.U, w.valI, w.coef, u, st.Gu, st.Gi, st.gGi, st.gBi, n, st.F, item_chunk(n), 0, l_w};
-        if (int rc = vec ? launch_seg<4>(p, "k_pw_seg_items", s) : launch_seg<1>(p, "k_pw_seg_items", s)) return rc;
+        if (int rc = vec ? launch_seg<4>(p, w, "k_pw_seg_items", s) : launch_seg<1>(p, w, "k_pw_seg_items", s)) return rc;
     }
     (void)ctx;
     return 0;

@@ -1846,7 +1846,7 @@ class PwmfDeviceState:
                                  **{pre + n: p(getattr(self, pre + n)) for pre in ("", "g", "m", "v") for n in names})
 
     def _workspace(self, n):
-        need = int(self.ctx.lib.el_pwmf_ws_bytes(int(n), int(self.U), int(self.I)))
+        need = int(self.ctx.lib.el_pwmf_ws_bytes(int(n), int(self.U), int(self.I), int(self.F)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
         return C.c_void_p(self._ws.data_ptr()), need

@@ -51,7 +51,8 @@ typedef struct el_ctx el_ctx;
                             *    el_lightgcn_propagate; el_ngcf_*; el_mf2020_train; el_bprmf_ws_bytes / el_cml_ws_bytes take F, el_bprmf_deterministic
                             * 8: el_nmf_state ends in step_ws / step_ws_bytes (el_nmf_step_ws_bytes) + the el_nmf_presort bookkeeping: the NeuMF / GMF step walks its embedding rows
                             *    as sorted segments and sums every batch reduction in a fixed order (no float atomics); training
-                            *    calls REQUIRE the workspace; row_stamp / row_own / claim_seq are no longer read              */
+                            *    calls REQUIRE the workspace; row_stamp / row_own / claim_seq are no longer read; el_pwmf_ws_bytes takes F (the
+                            *    point-wise models' segment sums without float atomics); el_nmf_presort, el_nmf_state.replay_series              */
 
 /* ---- context ---------------------------------------------------------------- */
 
@@ -706,7 +707,7 @@ typedef struct el_pwmf_state {
     float* vGu; float* vGi; float* vBu; float* vBi;   /* Adam v (NULL for Adagrad)                           */
 } el_pwmf_state;
 
-size_t el_pwmf_ws_bytes(int64_t n, int64_t U, int64_t I);
+size_t el_pwmf_ws_bytes(int64_t n, int64_t U, int64_t I, int32_t F);   /* (ABI 8: takes F -- partial rows of cut segments, summed in a fixed order) */
 
 /* out[b] = link(score of (u[b], i[b])): model.predict / get_recs on an explicit pair list
  * (matrix_factorization_model.py:74-99).  EL_PW_LOGISTIC returns x (predict_batch has no link, :88-89).         */
@@ -714,7 +715,7 @@ int el_pwmf_forward(el_ctx* ctx, void* stream, const el_pwmf_state* st, const in
                     int64_t n, float* out);
 
 /* One train_step on n samples; label float[n]; step = 1-based optimiser iteration; loss_out: device double[1],
- * the batch loss is ADDED.  ws: el_pwmf_ws_bytes(n, U, I).                                                      */
+ * the batch loss is ADDED.  ws: el_pwmf_ws_bytes(n, U, I, F).                                                     */
 int el_pwmf_train_step(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int32_t* u, const int32_t* i,
                        const float* label, int64_t n, int opt, int side, int32_t step, float lr_t,
                        double* loss_out, void* ws, size_t ws_bytes);
@@ -732,7 +733,7 @@ int el_pwmf_apply(el_ctx* ctx, void* stream, const el_pwmf_state* st, int opt, i
  * B): loss += model.train_step(batch)`) from ONE call, as el_bprmf_train_loop does for BPRMF_batch: el_pointwise_sample_meta
  * (first_sample + start; up to 4 M draws per launch, sampler_meta may be NULL) + el_pwmf_train_step per batch.
  *   lr_t_host[k]: step size of batch k (Adam: bias-corrected; Adagrad: lr); first_step: optimiser iteration of batch 0
- *   ws: el_pwmf_ws_bytes(B, U, I); loop_ws: el_pwmf_train_loop_ws_bytes(events, B).                                        */
+ *   ws: el_pwmf_ws_bytes(B, U, I, F); loop_ws: el_pwmf_train_loop_ws_bytes(events, B).                                        */
 size_t el_pwmf_train_loop_ws_bytes(int64_t events, int64_t B);
 int el_pwmf_train_loop(el_ctx* ctx, void* stream, const el_pwmf_state* st, const int64_t* pos_indptr, const int32_t* pos_indices,
                        const void* sampler_meta, uint64_t seed, uint64_t first_sample, int64_t events, int64_t B, int opt, int side,
