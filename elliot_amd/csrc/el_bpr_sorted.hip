@@ -827,11 +827,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 p.st.tGi[cur] = p.step;
                 p.st.tBi[cur] = p.step;
             }
-            if (!plain && started_inside) {                       // the head of a cut segment: one entry on the split list
-                const int e2 = atomicAdd(f.split, 1);
-                f.split[1 + 2 * e2] = (int32_t)cur;
-                f.split[2 + 2 * e2] = (int32_t)grp;
-            }
+            // (the head of a cut segment is not listed: k_bpr_item_combine finds it from the keys -- tens of thousands of appends to
+            //  one counter cost more than three key reads per lane group)
         }
     };
     // staged index chains, as in k_bpr_user_seg: BPR_ISTG positions per stage (key, payload -> s_b, u_b)
@@ -986,9 +983,15 @@ __global__ __launch_bounds__(256) void k_bpr_item_combine(el_bprmf_state st, Ite
     const int F = st.F;
     const int64_t ent = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpt;
     const int sub = (int)(threadIdx.x & (lpt - 1));
-    if (ent >= (int64_t)f.split[0]) return;
-    const int64_t row = (int64_t)f.split[1 + 2 * ent];
-    const int64_t g0 = (int64_t)f.split[2 + 2 * ent];
+    // lane group g0 looks at ITS chunk: the chunk's last segment is the head of a cut row when it goes on into chunk g0 + 1 and started
+    // inside chunk g0
+    const int64_t g0 = ent;
+    const int64_t p0 = g0 * (int64_t)chunk, p1 = p0 + chunk;
+    if (p1 >= n) return;                                        // (the last chunk's last segment ends with the data)
+    const u32 kl = keys[p1 - 1];
+    if (keys[p1] != kl) return;                                 // ends inside
+    if (keys[p0] == kl && p0 > 0 && keys[p0 - 1] == kl) return; // a middle piece: spans the whole chunk, started before it
+    const int64_t row = (int64_t)(kl - key_off);
     const int64_t pos = (g0 + 1 + sub) * (int64_t)chunk;
     const bool cont = pos < n && (int64_t)(keys[pos] - key_off) == row;
     const unsigned long long bal = __ballot(cont);
@@ -1170,7 +1173,7 @@ struct SortedWs {
     size_t tmp_bytes;
     int32_t* rowptr;       // [U + 1] first sorted position of every user row (fused user-side kernel)
     int32_t* hpos;         // [B] per triplet: sorted head position of its user's segment (deferred decay)
-    int32_t* split;        // [1 + 2 (B / 8 + 4)] item segments cut by a chunk boundary: count, then (row, head lane group) pairs
+    int32_t* split;        // (unused since the combine pass finds the cut rows from the keys; kept so that the workspace layout stays put)
     int32_t* split_long;   // the same, for the rows k_bpr_item_combine hands on to k_bpr_item_combine_long
     float* part;           // [2 (B / 8 + 1), F] + [2 (B / 8 + 1)]: their partial rows and bias parts (NULL when carved without F)
     float* part_b;
@@ -1497,7 +1500,6 @@ static int launch_segs(const SegParams& base, hipStream_t s, int64_t B, const So
         } else {                                                                                          \
             EL_LAUNCH("k_bpr_user_seg", (k_bpr_user_seg<VW, CPL_, false>), dim3(gridU), dim3(256), ldsU, s, pu, fz);  \
         }                                                                                                 \
-        EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));                                                   \
         EL_CHECK_HIP(hipMemsetAsync(w.split_long, 0, 4, s));                                              \
         if (ifuse && VW == 4 && CPL_ <= 2) {                                                              \
             EL_LAUNCH("k_bpr_item_seg", (k_bpr_item_seg<VW, CPL_, (VW == 4 && CPL_ <= 2)>), dim3(gridI), dim3(256), ldsI, s, pi, fi);   \
@@ -1862,7 +1864,6 @@ extern "C" int el_bprmf_shard_grads(el_ctx* ctx, void* stream, const el_bprmf_st
     ItemFuse fi;
     memset(&fi, 0, sizeof(fi));
     fi.split = w.split, fi.split_long = w.split_long, fi.part = w.part, fi.part_b = w.part_b;
-    EL_CHECK_HIP(hipMemsetAsync(w.split, 0, 4, s));
     EL_CHECK_HIP(hipMemsetAsync(w.split_long, 0, 4, s));
     const unsigned gridC = gridI, gridL = (unsigned)(gi < 1024 ? (gi < 1 ? 1 : gi) : 1024);
 #define EL_IS(VW_, CPL_)                                                                                                                     \
