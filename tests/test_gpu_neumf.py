@@ -498,3 +498,37 @@ def test_series_replay_of_the_embedding_rows_stays_at_rounding_level(ctx, model,
             assert rel.max() < 1e-4, (k, float(rel.max()))            # (biases, the head: a handful of elements)
         moved = moved or bool((wa[k] != wb[k]).any())
     assert moved                                                     # (the two modes are different arithmetic: identical bits would mean the switch is dead)
+
+
+def test_a_pending_presort_is_left_alone_by_a_step_on_other_arrays(ctx):
+    """el_nmf_presort bookkeeping: a batch ordered ahead stays pending while a step runs on OTHER arrays (that step sorts for itself
+    into the other sort set), is consumed by the step that names the same arrays, and is forgotten when the activation buffers -- and
+    with them the workspace -- are re-allocated for a larger batch.  Every variant ends on the same bits as plain steps."""
+    U, I, F, B, lr = 4000, 2500, 32, 2048, 0.003
+    w0 = on.init_neumf(U, I, F, 3, units=[64, 32, 16])
+    d = ctx.device
+    rs = np.random.RandomState(6)
+    mk = lambda n: tuple(torch.from_numpy(a).to(d) for a in (rs.randint(0, U, n).astype(np.int32), (rs.zipf(1.3, n) % I).astype(np.int32),
+                                                             rs.randint(0, 2, n).astype(np.float32)))
+    b1, b2, b3, big = mk(B), mk(B), mk(B), mk(3 * B)
+
+    ref = ops.NmfDeviceState(ctx, w0, max_batch=B)
+    for b in (b1, b2, b3):
+        ref.train_step(*b, lr)
+    ref.ensure_batch(3 * B)
+    ref.train_step(*big, lr)
+    want = _flat_weights(ref.weights())
+
+    st = ops.NmfDeviceState(ctx, w0, max_batch=B)
+    st.presort(b2[0], b2[1])                 # b2 ordered ahead ...
+    st.train_step(*b1, lr)                   # ... a step on other arrays sorts for itself
+    st.train_step(*b2, lr)                   # consumes the pending order
+    st.presort(b3[0], b3[1])
+    st.presort(b3[0], b3[1])                 # ordering the same batch twice is harmless
+    st.train_step(*b3, lr)
+    st.presort(b1[0], b1[1])                 # pending when the buffers grow: forgotten with the old workspace
+    st.ensure_batch(3 * B)
+    st.train_step(*big, lr)
+    got = _flat_weights(st.weights())
+    for k in want:
+        assert np.array_equal(want[k], got[k]), (k, int((want[k] != got[k]).sum()))
